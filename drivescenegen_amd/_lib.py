@@ -1,0 +1,130 @@
+"""ctypes binding of libdsg.so (C ABI: include/dsg.h).
+
+The product path has no CPU fallback: if the HIP library is missing or fails to load this module
+raises, and every op raises when handed a non-GPU tensor.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import threading
+
+import torch  # noqa: F401  (imported first so libdsg.so binds to the HIP runtime torch already loaded)
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libdsg.so")
+
+OK = 0
+ERR_NAMES = {-1: "DSG_ERR_INVALID_ARG", -2: "DSG_ERR_UNSUPPORTED_SHAPE", -3: "DSG_ERR_WORKSPACE_TOO_SMALL",
+             -4: "DSG_ERR_HIP", -5: "DSG_ERR_NOT_READY"}
+
+
+class DsgError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"{ERR_NAMES.get(code, code)}: {msg}")
+        self.code = code
+
+
+class ConvArgs(C.Structure):
+    """Mirror of ``dsg_conv_args`` (include/dsg.h)."""
+    _fields_ = [
+        ("src0", C.c_void_p), ("src1", C.c_void_p),
+        ("c0", C.c_int32), ("c1", C.c_int32),
+        ("n", C.c_int32), ("hin", C.c_int32), ("win", C.c_int32),
+        ("upsample", C.c_int32), ("ksize", C.c_int32), ("stride", C.c_int32), ("cout", C.c_int32),
+        ("weight", C.c_void_p), ("bias", C.c_void_p), ("gn_scale_shift", C.c_void_p),
+        ("silu", C.c_int32),
+        ("temb", C.c_void_p), ("temb_stride", C.c_int32),
+        ("residual", C.c_void_p), ("dst", C.c_void_p),
+    ]
+
+
+class UNetConfig(C.Structure):
+    """Mirror of ``dsg_unet_config`` (include/dsg.h)."""
+    _fields_ = [
+        ("in_channels", C.c_int32), ("out_channels", C.c_int32),
+        ("sample_h", C.c_int32), ("sample_w", C.c_int32),
+        ("layers_per_block", C.c_int32), ("num_blocks", C.c_int32),
+        ("block_out_channels", C.c_int32 * 8), ("down_attn", C.c_int32 * 8), ("up_attn", C.c_int32 * 8),
+        ("norm_num_groups", C.c_int32), ("norm_eps", C.c_float),
+        ("attention_head_dim", C.c_int32), ("add_attention", C.c_int32),
+    ]
+
+
+_vp, _i32, _i64, _f32, _sz = C.c_void_p, C.c_int32, C.c_int64, C.c_float, C.c_size_t
+
+# name -> argtypes; every function returns int32 status unless noted.  This table is the single
+# Python-side statement of the ABI; tests/test_abi.py checks it against include/dsg.h.
+SIGNATURES = {
+    "dsg_conv2d_fwd": [C.POINTER(ConvArgs), _vp],
+    "dsg_conv2d_fwd_direct": [C.POINTER(ConvArgs), _vp],
+    "dsg_conv_weight_relayout": [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp],
+    "dsg_gn_channel_stats": [_vp, _i32, _vp, _i32, _i32, _i32, _vp, _vp],
+    "dsg_gn_finalize": [_vp, _vp, _vp, _i32, _i32, _i32, _i32, _f32, _vp, _vp],
+    "dsg_gn_apply": [_vp, _vp, _i32, _vp, _i32, _i32, _i32, _vp],
+    "dsg_attention_fwd": [_vp, _vp, _i32, _i32, _i32, _i32, _vp],
+    "dsg_time_embed_fwd": [_vp, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp],
+    "dsg_linear_fwd": [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _vp],
+    "dsg_add_noise": [_vp, _vp, _vp, _vp, _vp, _i32, _i64, _vp],
+    "dsg_ddpm_step": [_vp, _vp, _vp, _vp, _i64, _f32, _f32, _f32, _f32, _f32, _f32, _vp],
+    "dsg_ddim_step": [_vp, _vp, _vp, _i64, _f32, _f32, _f32, _f32, _f32, _vp],
+    "dsg_postprocess": [_vp, _vp, _i32, _i32, _i32, _i32, _vp],
+    "dsg_unet_create": [C.POINTER(UNetConfig), C.POINTER(_vp)],
+    "dsg_unet_set_param": [_vp, C.c_char_p, _vp, _i64, _vp],
+    "dsg_unet_num_params": [_vp, C.POINTER(_i64), C.POINTER(_i64), C.POINTER(_i64)],
+    "dsg_unet_param_name": [_vp, _i64, C.POINTER(C.c_char_p), C.POINTER(_i64)],
+    "dsg_unet_workspace_bytes": [_vp, _i32, C.POINTER(_sz)],
+    "dsg_unet_forward": [_vp, _vp, _vp, _vp, _i32, _vp, _sz, _vp],
+}
+OTHER_SYMBOLS = ["dsg_version", "dsg_last_error", "dsg_unet_destroy"]
+
+_lib = None
+_lock = threading.Lock()
+
+
+def load():
+    """Load libdsg.so once; raise loudly when it is absent (no fallback path exists)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    with _lock:
+        if _lib is not None:
+            return _lib
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                f"libdsg.so not found at {LIB_PATH}: build it with `python drivescenegen_amd/csrc/build.py` "
+                "(or __graft_entry__.build()). The engine has no CPU fallback.")
+        lib = C.CDLL(LIB_PATH)
+        for name, argtypes in SIGNATURES.items():
+            fn = getattr(lib, name)
+            fn.argtypes = argtypes
+            fn.restype = C.c_int32
+        lib.dsg_version.restype = C.c_int32
+        lib.dsg_version.argtypes = []
+        lib.dsg_last_error.restype = C.c_char_p
+        lib.dsg_last_error.argtypes = []
+        lib.dsg_unet_destroy.restype = None
+        lib.dsg_unet_destroy.argtypes = [_vp]
+        _lib = lib
+    return _lib
+
+
+def check(rc: int):
+    if rc != OK:
+        raise DsgError(rc, load().dsg_last_error().decode("utf-8", "replace"))
+
+
+def stream_ptr(device=None) -> int:
+    return torch.cuda.current_stream(device).cuda_stream
+
+
+def ptr(t):
+    """Device pointer of a contiguous fp32/int64 GPU tensor (or None)."""
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise RuntimeError("drivescenegen_amd: the HIP engine needs GPU tensors (got a CPU tensor); "
+                           "there is no CPU fallback")
+    if not t.is_contiguous():
+        raise RuntimeError("drivescenegen_amd: tensor must be contiguous")
+    return t.data_ptr()

@@ -1,0 +1,172 @@
+// Self-attention core softmax(Q^T K / sqrt(d)) V for gfx950, fp32, head_dim 8..64.
+//
+// Replaces F.scaled_dot_product_attention inside diffusers' Attention block as instantiated by
+// UNetMidBlock2D (and Attn{Down,Up}Block2D) of the UNet2DModel that DriveSceneGen builds at
+// DriveSceneGen/scripts/train.py:39-57 (attention_head_dim = 8 -> 64 heads x 8 dims over 1024 tokens;
+// SURVEY.md App. A.2).  0.6 % of the network's FLOPs; K = d = 8 starves an MFMA tile, so this first
+// version runs the two tiny contractions on the VALU with K/V tiles broadcast from LDS and a
+// chunked online softmax; each thread owns QPT query rows so a K/V LDS read is amortised QPT times.
+//
+// Layout: qkv [N][3C][L] is the output of the fused q/k/v projection (a 1x1 conv over [N,C,L]);
+// channel = head*D + i, so a head's q/k/v are D rows of L contiguous floats.  out is [N][C][L].
+#include "dsg_common.h"
+
+namespace dsg {
+
+constexpr int ATT_LDS_FLOATS = 4096;  // per K and per V tile: 16 KiB each, keys per tile = 4096 / D
+constexpr int ATT_KB = 8;    // keys per online-softmax chunk
+
+template <int D, int QPT>
+__global__ __launch_bounds__(256) void attention_kernel(const float* __restrict__ qkv, float* __restrict__ out, int c,
+                                                        int heads, int l, float qscale) {
+  constexpr int ATT_KT = ATT_LDS_FLOATS / D;
+  __shared__ __attribute__((aligned(16))) float KVl[2 * ATT_KT * D];
+  float* Kl = KVl;
+  float* Vl = KVl + ATT_KT * D;
+  const int tid = threadIdx.x;
+  const int h = blockIdx.y, n = blockIdx.z;
+  const float* qp = qkv + ((size_t)n * 3 * c + h * D) * l;
+  const float* kp = qp + (size_t)c * l;
+  const float* vp = kp + (size_t)c * l;
+
+  float q[QPT][D], o[QPT][D], m[QPT], lsum[QPT];
+  int qi[QPT];
+#pragma unroll
+  for (int u = 0; u < QPT; ++u) {
+    qi[u] = (blockIdx.x * QPT + u) * 256 + tid;
+    const int qc = min(qi[u], l - 1);
+#pragma unroll
+    for (int i = 0; i < D; ++i) {
+      q[u][i] = qp[(size_t)i * l + qc] * qscale;
+      o[u][i] = 0.f;
+    }
+    m[u] = -1e30f;
+    lsum[u] = 0.f;
+  }
+
+  for (int j0 = 0; j0 < l; j0 += ATT_KT) {
+    const int kt = min(ATT_KT, l - j0);
+    __syncthreads();
+    for (int e = tid; e < ATT_KT * D; e += 256) {
+      const int i = e / ATT_KT, j = e - i * ATT_KT;  // coalesced global read along j
+      float kv = 0.f, vv = 0.f;
+      if (j < kt) {
+        kv = kp[(size_t)i * l + j0 + j];
+        vv = vp[(size_t)i * l + j0 + j];
+      }
+      Kl[j * D + i] = kv;
+      Vl[j * D + i] = vv;
+    }
+    __syncthreads();
+    const int nchunk = (kt + ATT_KB - 1) / ATT_KB;
+    for (int ch = 0; ch < nchunk; ++ch) {
+      const int jb = ch * ATT_KB;
+      float s[QPT][ATT_KB];
+#pragma unroll
+      for (int jj = 0; jj < ATT_KB; ++jj) {
+        float kr[D];
+#pragma unroll
+        for (int i4 = 0; i4 < D; i4 += 4) {
+          const float4 t = *reinterpret_cast<const float4*>(&Kl[(jb + jj) * D + i4]);
+          kr[i4] = t.x; kr[i4 + 1] = t.y; kr[i4 + 2] = t.z; kr[i4 + 3] = t.w;
+        }
+        const bool valid = (jb + jj) < kt;
+#pragma unroll
+        for (int u = 0; u < QPT; ++u) {
+          float a = 0.f;
+#pragma unroll
+          for (int i = 0; i < D; ++i) a = fmaf(q[u][i], kr[i], a);
+          s[u][jj] = valid ? a : -1e30f;
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < QPT; ++u) {
+        float mx = s[u][0];
+#pragma unroll
+        for (int jj = 1; jj < ATT_KB; ++jj) mx = fmaxf(mx, s[u][jj]);
+        const float mn = fmaxf(m[u], mx);
+        const float sc = exp2f(m[u] - mn);
+        m[u] = mn;
+        float ps = 0.f;
+#pragma unroll
+        for (int jj = 0; jj < ATT_KB; ++jj) {
+          s[u][jj] = exp2f(s[u][jj] - mn);
+          ps += s[u][jj];
+        }
+        lsum[u] = lsum[u] * sc + ps;
+#pragma unroll
+        for (int i = 0; i < D; ++i) o[u][i] *= sc;
+      }
+#pragma unroll
+      for (int jj = 0; jj < ATT_KB; ++jj) {
+        float vr[D];
+#pragma unroll
+        for (int i4 = 0; i4 < D; i4 += 4) {
+          const float4 t = *reinterpret_cast<const float4*>(&Vl[(jb + jj) * D + i4]);
+          vr[i4] = t.x; vr[i4 + 1] = t.y; vr[i4 + 2] = t.z; vr[i4 + 3] = t.w;
+        }
+#pragma unroll
+        for (int u = 0; u < QPT; ++u)
+#pragma unroll
+          for (int i = 0; i < D; ++i) o[u][i] = fmaf(s[u][jj], vr[i], o[u][i]);
+      }
+    }
+  }
+
+  float* op = out + ((size_t)n * c + h * D) * l;
+#pragma unroll
+  for (int u = 0; u < QPT; ++u) {
+    if (qi[u] < l) {
+      const float inv = 1.0f / lsum[u];
+#pragma unroll
+      for (int i = 0; i < D; ++i) op[(size_t)i * l + qi[u]] = o[u][i] * inv;
+    }
+  }
+}
+
+template <int D>
+static int launch_attention(const float* qkv, float* out, int n, int c, int heads, int l, hipStream_t st) {
+  // scores are kept in the log2 domain: q is pre-scaled by log2(e)/sqrt(D)
+  const float qscale = 1.4426950408889634f / sqrtf((float)D);
+  const long work = (long)n * heads * l;
+  int qpt = 4;
+  if (work / (256 * 4) < 512) qpt = 2;
+  if (work / (256 * 2) < 512) qpt = 1;
+  if (D > 16) qpt = 1;
+  dim3 grid(cdiv(l, 256 * qpt), heads, n);
+  if constexpr (D <= 16) {  // wider heads keep one query per thread (register budget)
+    if (qpt == 4) {
+      hipLaunchKernelGGL((attention_kernel<D, 4>), grid, dim3(256), 0, st, qkv, out, c, heads, l, qscale);
+      DSG_LAUNCH_CHECK();
+      return DSG_OK;
+    }
+    if (qpt == 2) {
+      hipLaunchKernelGGL((attention_kernel<D, 2>), grid, dim3(256), 0, st, qkv, out, c, heads, l, qscale);
+      DSG_LAUNCH_CHECK();
+      return DSG_OK;
+    }
+  }
+  hipLaunchKernelGGL((attention_kernel<D, 1>), grid, dim3(256), 0, st, qkv, out, c, heads, l, qscale);
+  DSG_LAUNCH_CHECK();
+  return DSG_OK;
+}
+
+}  // namespace dsg
+
+DSG_API int dsg_attention_fwd(const float* qkv, float* out, int32_t n, int32_t c, int32_t heads, int32_t l,
+                              void* stream) {
+  DSG_CHECK_ARG(qkv && out, "dsg_attention_fwd: NULL pointer");
+  DSG_CHECK_ARG(n > 0 && c > 0 && heads > 0 && l > 0, "dsg_attention_fwd: bad dims");
+  DSG_CHECK_ARG(c % heads == 0, "dsg_attention_fwd: channels (%d) not divisible by heads (%d)", c, heads);
+  DSG_CHECK_ARG(heads <= 65535 && n <= 65535, "dsg_attention_fwd: grid too large");
+  const int d = c / heads;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  switch (d) {
+    case 8: return dsg::launch_attention<8>(qkv, out, n, c, heads, l, st);
+    case 16: return dsg::launch_attention<16>(qkv, out, n, c, heads, l, st);
+    case 32: return dsg::launch_attention<32>(qkv, out, n, c, heads, l, st);
+    case 64: return dsg::launch_attention<64>(qkv, out, n, c, heads, l, st);
+    default:
+      return dsg::fail(DSG_ERR_UNSUPPORTED_SHAPE, "dsg_attention_fwd: head_dim %d not in {8,16,32,64}", d);
+  }
+}

@@ -1,0 +1,65 @@
+#!/usr/bin/env python3
+"""Build libdsg.so for gfx950 with hipcc (cross-compiles without a GPU).
+
+    python drivescenegen_amd/csrc/build.py [--force]
+
+Objects go to drivescenegen_amd/csrc/build/, the library to drivescenegen_amd/lib/libdsg.so
+(git-ignored, but shipped to the GPU box by gpurun).
+"""
+import concurrent.futures as cf
+import os
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+SOURCES = ["common.hip", "conv.hip", "groupnorm.hip", "attention.hip", "temb.hip", "scheduler.hip", "unet.hip"]
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fvisibility=hidden", "-Wall", "-Wno-unused-function"]
+LIB = os.path.join(ROOT, "lib", "libdsg.so")
+
+
+def _newer(a, b):
+    return not os.path.exists(b) or os.path.getmtime(a) > os.path.getmtime(b)
+
+
+def build(force=False, verbose=True):
+    bdir = os.path.join(HERE, "build")
+    os.makedirs(bdir, exist_ok=True)
+    os.makedirs(os.path.dirname(LIB), exist_ok=True)
+    hdrs = [os.path.join(HERE, "dsg_common.h"), os.path.join(ROOT, "..", "include", "dsg.h")]
+    jobs = []
+    for s in SOURCES:
+        src = os.path.join(HERE, s)
+        obj = os.path.join(bdir, s.replace(".hip", ".o"))
+        if force or _newer(src, obj) or any(_newer(h, obj) for h in hdrs):
+            jobs.append((src, obj))
+
+    def cc(job):
+        src, obj = job
+        cmd = ["hipcc"] + FLAGS + ["-c", src, "-o", obj]
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        return job, r
+
+    with cf.ThreadPoolExecutor(max_workers=min(8, max(1, len(jobs)))) as ex:
+        for (src, obj), r in ex.map(cc, jobs):
+            if r.returncode != 0:
+                sys.stderr.write(r.stdout + r.stderr)
+                raise RuntimeError(f"hipcc failed on {src}")
+            if verbose:
+                if r.stderr.strip():
+                    sys.stderr.write(r.stderr)
+                print(f"[dsg build] compiled {os.path.basename(src)}")
+    objs = [os.path.join(bdir, s.replace(".hip", ".o")) for s in SOURCES]
+    if force or jobs or not os.path.exists(LIB):
+        cmd = ["hipcc", "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs + ["-Wl,-rpath,/opt/rocm/lib"]
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            sys.stderr.write(r.stdout + r.stderr)
+            raise RuntimeError("link failed")
+        if verbose:
+            print(f"[dsg build] linked {LIB}")
+    return LIB
+
+
+if __name__ == "__main__":
+    build(force="--force" in sys.argv)

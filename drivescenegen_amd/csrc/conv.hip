@@ -1,0 +1,377 @@
+// Fused implicit-GEMM convolution for gfx950 (MI355X), fp32 on the f32-input matrix cores.
+//
+// Replaces every nn.Conv2d / attention nn.Linear call of diffusers' UNet2DModel.forward as used by
+// DriveSceneGen (reference: DriveSceneGen/scripts/train.py:39-57 builds the net,
+// DriveSceneGen/pipeline/training_pipeline.py:84 runs it; semantics SURVEY.md App. A.2).
+//
+// GEMM view:  D[cout][pixel] = sum_{cin,tap} W[cin][tap][cout] * X[cin][pixel + tap]
+//   A operand = weights  (M = cout)    -> v_mfma_f32_32x32x2_f32, exact f32 (fmaf chain in k order)
+//   B operand = pixels   (N = 32 consecutive pixels of one output row -> 128-B coalesced stores)
+// A workgroup (4 waves) owns BM = 32*MT couts x (8 rows x 32 cols) output pixels of one image.
+// Per K-chunk of KC input channels it stages, through registers, the weight slab [KC][taps][BM] and
+// the input halo patch [KC][PH][PW] into LDS -- GroupNorm-apply + SiLU of the previous norm is folded
+// into that staging pass, the [x || skip] concat and the nearest-x2 upsample into its gather -- then
+// all 9 taps are served from the single patch (no im2col blow-up).  The next chunk's global loads are
+// issued before the MFMA phase and written to LDS after it (issue-early / write-late).
+// Epilogue: + bias (+ time-embedding column) (+ residual), 128-B row stores.
+#include "dsg_common.h"
+#include <algorithm>
+
+namespace dsg {
+
+struct ConvP {
+  const float* src0;
+  const float* src1;
+  int c0, c1, cin;
+  int n, hin, win;  // source dims
+  int hc, wc;       // conv-input dims (after optional upsample)
+  int hout, wout;
+  int cout;
+  const float* w;
+  const float* bias;
+  const float* ss;
+  int silu;
+  const float* temb;
+  int temb_stride;
+  const float* res;
+  float* dst;
+  int tiles_x, tiles_y;
+};
+
+constexpr int TH = 8;   // output rows per workgroup
+constexpr int TW = 32;  // output cols per workgroup (= MFMA N)
+
+template <int KS, int STRIDE, int KC>
+struct ConvGeom {
+  static constexpr int TAPS = KS * KS;
+  static constexpr int PH = (TH - 1) * STRIDE + KS;
+  static constexpr int PW = (TW - 1) * STRIDE + KS;
+  static constexpr int PSZ = PH * PW;
+  static constexpr int XN = KC * PSZ;
+  static constexpr int XN_PAD = (XN + 3) & ~3;
+};
+
+template <int KS, int STRIDE, bool UPS, int MT, int KC>
+__global__ __launch_bounds__(256) void conv_mfma_kernel(ConvP p) {
+  using G = ConvGeom<KS, STRIDE, KC>;
+  constexpr int TAPS = G::TAPS, PH = G::PH, PW = G::PW, PSZ = G::PSZ, XN = G::XN;
+  constexpr int BM = MT * 32;
+  constexpr int NE = (XN + 255) / 256;
+  constexpr int WN4 = KC * TAPS * BM / 4;
+  constexpr int NW = (WN4 + 255) / 256;
+  (void)PH;
+
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* Wl = smem;                    // [KC][TAPS][BM]
+  float* Xl = smem + KC * TAPS * BM;   // [KC][PH][PW]
+  float* SSl = Xl + G::XN_PAD;         // [cin][2] (only when p.ss)
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int half = lane >> 5;
+  const int l31 = lane & 31;
+
+  int bid = blockIdx.x;
+  const int tx = bid % p.tiles_x;
+  bid /= p.tiles_x;
+  const int ty = bid % p.tiles_y;
+  const int n = bid / p.tiles_y;
+  const int m0 = blockIdx.y * BM;
+  const int oy0 = ty * TH, ox0 = tx * TW;
+  const int iy0 = oy0 * STRIDE - KS / 2, ix0 = ox0 * STRIDE - KS / 2;
+  const int plane = p.hin * p.win;
+
+  // Per-thread gather offsets (relative to the chunk's first channel plane); -1 = zero padding.
+  int goff[NE];
+#pragma unroll
+  for (int i = 0; i < NE; ++i) {
+    const int e = tid + 256 * i;
+    int off = -1;
+    if (e < XN) {
+      const int c = e / PSZ;
+      const int r = e - c * PSZ;
+      const int py = r / PW;
+      const int px = r - py * PW;
+      const int gy = iy0 + py, gx = ix0 + px;
+      if (gy >= 0 && gy < p.hc && gx >= 0 && gx < p.wc) {
+        const int sy = UPS ? (gy >> 1) : gy;
+        const int sx = UPS ? (gx >> 1) : gx;
+        off = c * plane + sy * p.win + sx;
+      }
+    }
+    goff[i] = off;
+  }
+
+  if (p.ss) {
+    const float* ssg = p.ss + (size_t)n * p.cin * 2;
+    for (int i = tid; i < 2 * p.cin; i += 256) SSl[i] = ssg[i];
+  }
+
+  float xr[NE];
+  float wr[NW][4];  // scalar array: a float4[] here is not promoted to registers by hipcc
+
+  auto prefetch = [&](int q) {
+    const int cb = q * KC;
+    const float* sp = (cb < p.c0) ? p.src0 + ((size_t)n * p.c0 + cb) * plane
+                                  : p.src1 + ((size_t)n * p.c1 + (cb - p.c0)) * plane;
+#pragma unroll
+    for (int i = 0; i < NE; ++i) xr[i] = goff[i] >= 0 ? sp[goff[i]] : 0.f;
+    const float* wp = p.w + (size_t)q * (KC * TAPS) * p.cout + m0;
+#pragma unroll
+    for (int i = 0; i < NW; ++i) {
+      // clamped, unconditional load keeps wr[] in registers (a predicated partial fill goes to scratch)
+      const int idx = min(tid + 256 * i, WN4 - 1);
+      const int row = idx / (BM / 4);
+      const int c4 = idx - row * (BM / 4);
+      const float4 t4 = *reinterpret_cast<const float4*>(wp + (size_t)row * p.cout + c4 * 4);
+      wr[i][0] = t4.x; wr[i][1] = t4.y; wr[i][2] = t4.z; wr[i][3] = t4.w;
+    }
+  };
+
+  auto commit = [&](int q) {
+#pragma unroll
+    for (int i = 0; i < NE; ++i) {
+      const int e = tid + 256 * i;
+      if (e < XN) {
+        float v = xr[i];
+        if (p.ss && goff[i] >= 0) {
+          const int c = q * KC + e / PSZ;
+          v = v * SSl[2 * c] + SSl[2 * c + 1];
+          if (p.silu) v = silu_f(v);
+        }
+        Xl[e] = v;
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < NW; ++i) {
+      const int idx = tid + 256 * i;
+      if (idx < WN4) reinterpret_cast<float4*>(Wl)[idx] = make_float4(wr[i][0], wr[i][1], wr[i][2], wr[i][3]);
+    }
+  };
+
+  f32x16 acc[MT][2];
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[mt][nt][r] = 0.f;
+
+  const float* wl = Wl + half * (TAPS * BM) + l31;
+  const float* xl = Xl + half * PSZ + (wave * 2 * STRIDE) * PW + l31 * STRIDE;
+
+  const int nq = p.cin / KC;
+  prefetch(0);
+  for (int q = 0; q < nq; ++q) {
+    __syncthreads();  // previous MFMA phase has finished reading LDS (and SSl is visible)
+    commit(q);
+    __syncthreads();
+    if (q + 1 < nq) prefetch(q + 1);
+#pragma unroll
+    for (int cp = 0; cp < KC / 2; ++cp) {
+#pragma unroll
+      for (int tap = 0; tap < TAPS; ++tap) {
+        const int dy = tap / KS, dx = tap % KS;
+        float a[MT], b[2];
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) a[mt] = wl[(2 * cp) * (TAPS * BM) + tap * BM + mt * 32];
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) b[nt] = xl[(2 * cp) * PSZ + (nt * STRIDE + dy) * PW + dx];
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+          for (int nt = 0; nt < 2; ++nt)
+            acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mt], b[nt], acc[mt][nt], 0, 0, 0);
+      }
+    }
+  }
+
+  // Epilogue. C/D layout of the 32x32 tile: col (pixel) = lane&31, row (cout) = (r&3) + 8*(r>>2) + 4*half.
+  const int x = ox0 + l31;
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int co = m0 + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+      float add = p.bias ? p.bias[co] : 0.f;
+      const bool has_t = p.temb != nullptr;
+      const float tv = has_t ? p.temb[(size_t)n * p.temb_stride + co] : 0.f;
+#pragma unroll
+      for (int nt = 0; nt < 2; ++nt) {
+        const int y = oy0 + wave * 2 + nt;
+        const size_t idx = (((size_t)n * p.cout + co) * p.hout + y) * p.wout + x;
+        float v = acc[mt][nt][r] + add;
+        if (has_t) v = v + tv;
+        if (p.res) v = v + p.res[idx];
+        p.dst[idx] = v;
+      }
+    }
+  }
+}
+
+// General VALU fallback: any channel counts / sizes (conv_in with Cin = 3/4/8, conv_out with
+// Cout = 3/4/8, odd spatial sizes).  One thread per output pixel, COB couts per thread.
+template <int COB>
+__global__ __launch_bounds__(256) void conv_direct_kernel(ConvP p, int ks, int stride, int ups) {
+  const int pix = blockIdx.x * 256 + threadIdx.x;
+  const int n = blockIdx.z;
+  const int co0 = blockIdx.y * COB;
+  if (pix >= p.hout * p.wout) return;
+  const int oy = pix / p.wout, ox = pix - oy * p.wout;
+  const int pad = ks / 2;
+  const int plane = p.hin * p.win;
+  float acc[COB];
+#pragma unroll
+  for (int j = 0; j < COB; ++j) acc[j] = 0.f;
+  const int taps = ks * ks;
+  for (int c = 0; c < p.cin; ++c) {
+    const float* sp = (c < p.c0) ? p.src0 + ((size_t)n * p.c0 + c) * plane
+                                 : p.src1 + ((size_t)n * p.c1 + (c - p.c0)) * plane;
+    float sc = 1.f, sh = 0.f;
+    if (p.ss) {
+      sc = p.ss[((size_t)n * p.cin + c) * 2];
+      sh = p.ss[((size_t)n * p.cin + c) * 2 + 1];
+    }
+    for (int dy = 0; dy < ks; ++dy) {
+      const int gy = oy * stride - pad + dy;
+      if (gy < 0 || gy >= p.hc) continue;
+      for (int dx = 0; dx < ks; ++dx) {
+        const int gx = ox * stride - pad + dx;
+        if (gx < 0 || gx >= p.wc) continue;
+        const int sy = ups ? (gy >> 1) : gy, sx = ups ? (gx >> 1) : gx;
+        float v = sp[sy * p.win + sx];
+        if (p.ss) {
+          v = v * sc + sh;
+          if (p.silu) v = silu_f(v);
+        }
+        const float* wrow = p.w + ((size_t)c * taps + dy * ks + dx) * p.cout + co0;
+#pragma unroll
+        for (int j = 0; j < COB; ++j)
+          if (co0 + j < p.cout) acc[j] = fmaf(wrow[j], v, acc[j]);
+      }
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < COB; ++j) {
+    const int co = co0 + j;
+    if (co >= p.cout) break;
+    const size_t idx = ((size_t)n * p.cout + co) * p.hout * p.wout + pix;
+    float v = acc[j] + (p.bias ? p.bias[co] : 0.f);
+    if (p.temb) v = v + p.temb[(size_t)n * p.temb_stride + co];
+    if (p.res) v = v + p.res[idx];
+    p.dst[idx] = v;
+  }
+}
+
+__global__ void weight_relayout_kernel(const float* __restrict__ w, float* __restrict__ dst, int cout, int cin,
+                                       int taps, int cout_total, int cout_off) {
+  const int64_t total = (int64_t)cout * cin * taps;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    // destination-major so that writes coalesce: i -> (ci, tap, co)
+    const int co = (int)(i % cout);
+    const int64_t r = i / cout;
+    const int tap = (int)(r % taps);
+    const int ci = (int)(r / taps);
+    dst[((int64_t)ci * taps + tap) * cout_total + cout_off + co] = w[((int64_t)co * cin + ci) * taps + tap];
+  }
+}
+
+template <int KS, int STRIDE, bool UPS, int MT, int KC>
+static int launch_mfma(const ConvP& p, hipStream_t st) {
+  using G = ConvGeom<KS, STRIDE, KC>;
+  const size_t lds = (size_t)(KC * G::TAPS * MT * 32 + G::XN_PAD + (p.ss ? 2 * p.cin : 0)) * sizeof(float);
+  dim3 grid(p.tiles_x * p.tiles_y * p.n, p.cout / (MT * 32));
+  auto kern = conv_mfma_kernel<KS, STRIDE, UPS, MT, KC>;
+  if (lds > 64 * 1024) {
+    static bool raised = false;  // idempotent attribute; benign if set twice
+    if (!raised) {
+      DSG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  160 * 1024));
+      raised = true;
+    }
+  }
+  hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, p);
+  DSG_LAUNCH_CHECK();
+  return DSG_OK;
+}
+
+static int launch_direct(const ConvP& p, int ks, int stride, int ups, hipStream_t st) {
+  const int npix = p.hout * p.wout;
+  if (p.cout <= 4) {
+    dim3 grid(cdiv(npix, 256), cdiv(p.cout, 4), p.n);
+    hipLaunchKernelGGL(conv_direct_kernel<4>, grid, dim3(256), 0, st, p, ks, stride, ups);
+  } else {
+    dim3 grid(cdiv(npix, 256), cdiv(p.cout, 8), p.n);
+    hipLaunchKernelGGL(conv_direct_kernel<8>, grid, dim3(256), 0, st, p, ks, stride, ups);
+  }
+  DSG_LAUNCH_CHECK();
+  return DSG_OK;
+}
+
+int conv2d_fwd_impl(const dsg_conv_args* a, hipStream_t st, int force_direct) {
+  DSG_CHECK_ARG(a != nullptr, "dsg_conv2d_fwd: args is NULL");
+  DSG_CHECK_ARG(a->src0 && a->weight && a->dst, "dsg_conv2d_fwd: src0/weight/dst must be non-NULL");
+  DSG_CHECK_ARG(a->c0 > 0 && a->c1 >= 0 && a->n > 0 && a->hin > 0 && a->win > 0 && a->cout > 0,
+                "dsg_conv2d_fwd: non-positive dimension");
+  DSG_CHECK_ARG((a->c1 == 0) == (a->src1 == nullptr), "dsg_conv2d_fwd: src1/c1 mismatch");
+  DSG_CHECK_ARG(a->ksize == 3 || a->ksize == 1, "dsg_conv2d_fwd: ksize must be 1 or 3 (got %d)", a->ksize);
+  DSG_CHECK_ARG(a->stride == 1 || a->stride == 2, "dsg_conv2d_fwd: stride must be 1 or 2 (got %d)", a->stride);
+  DSG_CHECK_ARG(!(a->upsample && a->stride != 1), "dsg_conv2d_fwd: upsample requires stride 1");
+  DSG_CHECK_ARG(!(a->temb && a->temb_stride <= 0), "dsg_conv2d_fwd: temb_stride must be positive");
+  if (a->n == 0) return DSG_OK;
+
+  ConvP p;
+  p.src0 = a->src0; p.src1 = a->src1; p.c0 = a->c0; p.c1 = a->c1; p.cin = a->c0 + a->c1;
+  p.n = a->n; p.hin = a->hin; p.win = a->win;
+  p.hc = a->upsample ? 2 * a->hin : a->hin;
+  p.wc = a->upsample ? 2 * a->win : a->win;
+  const int pad = a->ksize / 2;
+  p.hout = (p.hc + 2 * pad - a->ksize) / a->stride + 1;
+  p.wout = (p.wc + 2 * pad - a->ksize) / a->stride + 1;
+  p.cout = a->cout; p.w = a->weight; p.bias = a->bias; p.ss = a->gn_scale_shift; p.silu = a->silu;
+  p.temb = a->temb; p.temb_stride = a->temb_stride; p.res = a->residual; p.dst = a->dst;
+  p.tiles_x = p.wout / TW; p.tiles_y = p.hout / TH;
+
+  const bool tile_ok = (p.wout % TW == 0) && (p.hout % TH == 0) && (p.cout % 32 == 0) && p.cin <= 4096;
+  const int s = a->stride, k = a->ksize, u = a->upsample;
+  if (!force_direct && tile_ok) {
+    const bool mt2 = (p.cout % 64 == 0);
+    if (k == 3 && p.cin % 8 == 0 && p.c0 % 8 == 0) {
+      if (s == 1 && !u) return mt2 ? launch_mfma<3, 1, false, 2, 8>(p, st) : launch_mfma<3, 1, false, 1, 8>(p, st);
+      if (s == 1 && u) return mt2 ? launch_mfma<3, 1, true, 2, 8>(p, st) : launch_mfma<3, 1, true, 1, 8>(p, st);
+      if (s == 2) return mt2 ? launch_mfma<3, 2, false, 2, 8>(p, st) : launch_mfma<3, 2, false, 1, 8>(p, st);
+    }
+    if (k == 1 && s == 1 && !u) {
+      if (p.cin % 32 == 0 && p.c0 % 32 == 0)
+        return mt2 ? launch_mfma<1, 1, false, 2, 32>(p, st) : launch_mfma<1, 1, false, 1, 32>(p, st);
+      if (p.cin % 8 == 0 && p.c0 % 8 == 0)
+        return mt2 ? launch_mfma<1, 1, false, 2, 8>(p, st) : launch_mfma<1, 1, false, 1, 8>(p, st);
+    }
+  }
+  return launch_direct(p, k, s, u, st);
+}
+
+}  // namespace dsg
+
+DSG_API int dsg_conv2d_fwd(const dsg_conv_args* a, void* stream) {
+  return dsg::conv2d_fwd_impl(a, static_cast<hipStream_t>(stream), 0);
+}
+
+// Test hook: same contract, forced through the VALU reference kernel (cross-check of the MFMA path).
+DSG_API int dsg_conv2d_fwd_direct(const dsg_conv_args* a, void* stream) {
+  return dsg::conv2d_fwd_impl(a, static_cast<hipStream_t>(stream), 1);
+}
+
+DSG_API int dsg_conv_weight_relayout(const float* w_oihw, float* dst, int32_t cout, int32_t cin, int32_t ksize,
+                                     int32_t cout_total, int32_t cout_off, void* stream) {
+  DSG_CHECK_ARG(w_oihw && dst, "dsg_conv_weight_relayout: NULL pointer");
+  DSG_CHECK_ARG(cout > 0 && cin > 0 && (ksize == 1 || ksize == 3), "dsg_conv_weight_relayout: bad dims");
+  DSG_CHECK_ARG(cout_off >= 0 && cout_off + cout <= cout_total, "dsg_conv_weight_relayout: column range");
+  const int64_t total = (int64_t)cout * cin * ksize * ksize;
+  const int blocks = (int)std::min<int64_t>(dsg::cdiv64(total, 256), 4096);
+  hipLaunchKernelGGL(dsg::weight_relayout_kernel, dim3(blocks), dim3(256), 0, static_cast<hipStream_t>(stream),
+                     w_oihw, dst, cout, cin, ksize * ksize, cout_total, cout_off);
+  DSG_LAUNCH_CHECK();
+  return DSG_OK;
+}

@@ -1,0 +1,142 @@
+// GroupNorm for gfx950: per-channel fp64 statistics -> per-(n, c) scale/shift -> apply(+SiLU).
+//
+// Replaces nn.GroupNorm(32, C, eps=1e-5) (+ F.silu) at ResnetBlock2D.norm1/norm2,
+// Attention.group_norm and conv_norm_out of diffusers' UNet2DModel (reference: the model built at
+// DriveSceneGen/scripts/train.py:39-57).  HBM-bound streaming kernels:
+// one float4 read per element for the statistics; the apply pass is normally folded into the
+// consuming convolution's staging (conv.hip) and only runs standalone for tests.
+//
+// Statistics are kept per CHANNEL (sum, sum of squares, fp64) so that a group straddling the
+// [x || skip] concat of the up path (6 of the 12 up-resnet norm1's) needs no concat tensor.
+#include "dsg_common.h"
+
+namespace dsg {
+
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+  return v;
+}
+
+// grid = (c0 + c1, n); block = 256
+__global__ __launch_bounds__(256) void gn_channel_stats_kernel(const float* __restrict__ src0, int c0,
+                                                               const float* __restrict__ src1, int c1, int hw,
+                                                               double* __restrict__ stats) {
+  const int c = blockIdx.x, n = blockIdx.y;
+  const int ct = c0 + c1;
+  const float* sp = (c < c0) ? src0 + ((size_t)n * c0 + c) * hw : src1 + ((size_t)n * c1 + (c - c0)) * hw;
+  double s = 0.0, ss = 0.0;
+  if ((hw & 3) == 0) {
+    const float4* sp4 = reinterpret_cast<const float4*>(sp);
+    const int n4 = hw >> 2;
+    for (int i = threadIdx.x; i < n4; i += 256) {
+      const float4 v = sp4[i];
+      // fp32 partial over 4 elements, fp64 across (exact enough: 4-term fp32 sums feed an fp64 tree)
+      s += (double)v.x + (double)v.y + (double)v.z + (double)v.w;
+      ss += (double)v.x * v.x + (double)v.y * v.y + (double)v.z * v.z + (double)v.w * v.w;
+    }
+  } else {
+    for (int i = threadIdx.x; i < hw; i += 256) {
+      const double v = sp[i];
+      s += v;
+      ss += v * v;
+    }
+  }
+  __shared__ double red[2][4];
+  s = wave_sum(s);
+  ss = wave_sum(ss);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (lane == 0) {
+    red[0][wave] = s;
+    red[1][wave] = ss;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double* o = stats + ((size_t)n * ct + c) * 2;
+    o[0] = red[0][0] + red[0][1] + red[0][2] + red[0][3];
+    o[1] = red[1][0] + red[1][1] + red[1][2] + red[1][3];
+  }
+}
+
+// one thread per (n, c)
+__global__ void gn_finalize_kernel(const double* __restrict__ stats, const float* __restrict__ gamma,
+                                   const float* __restrict__ beta, int n, int c, int groups, int hw, float eps,
+                                   float* __restrict__ out) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n * c) return;
+  const int ni = i / c, ci = i - ni * c;
+  const int cpg = c / groups;
+  const int g0 = (ci / cpg) * cpg;
+  double s = 0.0, ss = 0.0;
+  for (int k = 0; k < cpg; ++k) {
+    const double* p = stats + ((size_t)ni * c + g0 + k) * 2;
+    s += p[0];
+    ss += p[1];
+  }
+  const double cnt = (double)cpg * (double)hw;
+  const double mean = s / cnt;
+  double var = ss / cnt - mean * mean;
+  if (var < 0.0) var = 0.0;
+  const float rstd = (float)(1.0 / sqrt(var + (double)eps));
+  const float meanf = (float)mean;
+  const float sc = rstd * gamma[ci];
+  out[2 * (size_t)i] = sc;
+  out[2 * (size_t)i + 1] = beta[ci] - meanf * sc;
+}
+
+// grid = (ceil(hw/1024), c, n)
+__global__ __launch_bounds__(256) void gn_apply_kernel(const float* __restrict__ src, const float* __restrict__ ssb,
+                                                       int silu, float* __restrict__ dst, int c, int hw) {
+  const int ci = blockIdx.y, n = blockIdx.z;
+  const size_t base = ((size_t)n * c + ci) * hw;
+  const float sc = ssb[((size_t)n * c + ci) * 2], sh = ssb[((size_t)n * c + ci) * 2 + 1];
+  const int i0 = (blockIdx.x * 256 + threadIdx.x) * 4;
+  if ((hw & 3) == 0) {
+    if (i0 < hw) {
+      float4 v = *reinterpret_cast<const float4*>(src + base + i0);
+      v.x = v.x * sc + sh; v.y = v.y * sc + sh; v.z = v.z * sc + sh; v.w = v.w * sc + sh;
+      if (silu) { v.x = silu_f(v.x); v.y = silu_f(v.y); v.z = silu_f(v.z); v.w = silu_f(v.w); }
+      *reinterpret_cast<float4*>(dst + base + i0) = v;
+    }
+  } else {
+    for (int k = 0; k < 4 && i0 + k < hw; ++k) {
+      float v = src[base + i0 + k] * sc + sh;
+      dst[base + i0 + k] = silu ? silu_f(v) : v;
+    }
+  }
+}
+
+}  // namespace dsg
+
+DSG_API int dsg_gn_channel_stats(const float* src0, int32_t c0, const float* src1, int32_t c1, int32_t n, int32_t hw,
+                                 double* chan_stats, void* stream) {
+  DSG_CHECK_ARG(src0 && chan_stats, "dsg_gn_channel_stats: NULL pointer");
+  DSG_CHECK_ARG(c0 > 0 && c1 >= 0 && n > 0 && hw > 0, "dsg_gn_channel_stats: bad dims");
+  DSG_CHECK_ARG((c1 == 0) == (src1 == nullptr), "dsg_gn_channel_stats: src1/c1 mismatch");
+  DSG_CHECK_ARG(n <= 65535, "dsg_gn_channel_stats: batch too large for one launch");
+  hipLaunchKernelGGL(dsg::gn_channel_stats_kernel, dim3(c0 + c1, n), dim3(256), 0, static_cast<hipStream_t>(stream),
+                     src0, c0, src1, c1, hw, chan_stats);
+  DSG_LAUNCH_CHECK();
+  return DSG_OK;
+}
+
+DSG_API int dsg_gn_finalize(const double* chan_stats, const float* gamma, const float* beta, int32_t n, int32_t c,
+                            int32_t groups, int32_t hw, float eps, float* scale_shift, void* stream) {
+  DSG_CHECK_ARG(chan_stats && gamma && beta && scale_shift, "dsg_gn_finalize: NULL pointer");
+  DSG_CHECK_ARG(n > 0 && c > 0 && groups > 0 && hw > 0, "dsg_gn_finalize: bad dims");
+  DSG_CHECK_ARG(c % groups == 0, "dsg_gn_finalize: channels (%d) not divisible by groups (%d)", c, groups);
+  hipLaunchKernelGGL(dsg::gn_finalize_kernel, dim3(dsg::cdiv(n * c, 256)), dim3(256), 0,
+                     static_cast<hipStream_t>(stream), chan_stats, gamma, beta, n, c, groups, hw, eps, scale_shift);
+  DSG_LAUNCH_CHECK();
+  return DSG_OK;
+}
+
+DSG_API int dsg_gn_apply(const float* src, const float* scale_shift, int32_t silu, float* dst, int32_t n, int32_t c,
+                         int32_t hw, void* stream) {
+  DSG_CHECK_ARG(src && scale_shift && dst, "dsg_gn_apply: NULL pointer");
+  DSG_CHECK_ARG(n > 0 && c > 0 && hw > 0 && c <= 65535 && n <= 65535, "dsg_gn_apply: bad dims");
+  hipLaunchKernelGGL(dsg::gn_apply_kernel, dim3(dsg::cdiv(hw, 1024), c, n), dim3(256), 0,
+                     static_cast<hipStream_t>(stream), src, scale_shift, silu, dst, c, hw);
+  DSG_LAUNCH_CHECK();
+  return DSG_OK;
+}

@@ -1,0 +1,87 @@
+// Timestep path for gfx950: sinusoid -> linear_1 -> SiLU -> linear_2 -> SiLU, and the batched
+// time_emb_proj of all resnets as one small GEMV-class product.
+//
+// Replaces UNet2DModel.time_proj / time_embedding and every ResnetBlock2D.time_emb_proj(silu(temb))
+// (diffusers 0.20.0 as used at DriveSceneGen/scripts/train.py:39-57; SURVEY.md App. A.2 lines 1-3).
+// All resnets consume silu(temb), so the activation is applied once here.  Work is a few MFLOP per
+// sample: latency-bound, one workgroup per sample / per 4 output rows.
+#include "dsg_common.h"
+
+namespace dsg {
+
+// grid = n, block = 256; dynamic LDS = (ch + dim) floats
+__global__ __launch_bounds__(256) void time_embed_kernel(const int64_t* __restrict__ timesteps, int ch, int dim,
+                                                         const float* __restrict__ w1, const float* __restrict__ b1,
+                                                         const float* __restrict__ w2, const float* __restrict__ b2,
+                                                         float* __restrict__ act) {
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  float* e = sm;        // [ch] sinusoid, cos first (flip_sin_to_cos=True, freq_shift=0)
+  float* h1 = sm + ch;  // [dim]
+  const int n = blockIdx.x;
+  const float t = (float)timesteps[n];
+  const int half = ch / 2;
+  for (int i = threadIdx.x; i < half; i += 256) {
+    // exp(-ln(10000) * i / half), evaluated as the reference does: fp32 exponent, fp32 exp
+    const float ex = (-9.210340371976184f * (float)i) / (float)half;
+    const float a = t * expf(ex);
+    e[i] = cosf(a);
+    e[half + i] = sinf(a);
+  }
+  __syncthreads();
+  for (int j = threadIdx.x; j < dim; j += 256) {
+    const float* wr = w1 + (size_t)j * ch;
+    float s = 0.f;
+    for (int k = 0; k < ch; ++k) s = fmaf(wr[k], e[k], s);
+    h1[j] = silu_f(s + b1[j]);
+  }
+  __syncthreads();
+  for (int j = threadIdx.x; j < dim; j += 256) {
+    const float* wr = w2 + (size_t)j * dim;
+    float s = 0.f;
+    for (int k = 0; k < dim; ++k) s = fmaf(wr[k], h1[k], s);
+    act[(size_t)n * dim + j] = silu_f(s + b2[j]);
+  }
+}
+
+// y[n][j] = x[n][:] . w[j][:] + b[j].  One wave per output row j, lanes stride the K axis
+// (coalesced weight reads); grid = ceil(out_f / 4), block = 256.
+__global__ __launch_bounds__(256) void linear_rows_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                          const float* __restrict__ b, float* __restrict__ y, int n,
+                                                          int in_f, int out_f) {
+  const int lane = threadIdx.x & 63;
+  const int j = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (j >= out_f) return;
+  const float* wr = w + (size_t)j * in_f;
+  for (int ni = 0; ni < n; ++ni) {
+    const float* xr = x + (size_t)ni * in_f;
+    float s = 0.f;
+    for (int k = lane; k < in_f; k += 64) s = fmaf(wr[k], xr[k], s);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_down(s, o, 64);
+    if (lane == 0) y[(size_t)ni * out_f + j] = s + (b ? b[j] : 0.f);
+  }
+}
+
+}  // namespace dsg
+
+DSG_API int dsg_time_embed_fwd(const int64_t* timesteps, int32_t n, int32_t ch, int32_t dim, const float* w1,
+                               const float* b1, const float* w2, const float* b2, float* act, void* stream) {
+  DSG_CHECK_ARG(timesteps && w1 && b1 && w2 && b2 && act, "dsg_time_embed_fwd: NULL pointer");
+  DSG_CHECK_ARG(n > 0 && ch > 0 && (ch % 2) == 0 && dim > 0, "dsg_time_embed_fwd: bad dims");
+  const size_t lds = (size_t)(ch + dim) * sizeof(float);
+  DSG_CHECK_SHAPE(lds <= 64 * 1024, "dsg_time_embed_fwd: ch + dim too large (%d + %d)", ch, dim);
+  hipLaunchKernelGGL(dsg::time_embed_kernel, dim3(n), dim3(256), lds, static_cast<hipStream_t>(stream), timesteps,
+                     ch, dim, w1, b1, w2, b2, act);
+  DSG_LAUNCH_CHECK();
+  return DSG_OK;
+}
+
+DSG_API int dsg_linear_fwd(const float* x, const float* w, const float* b, float* y, int32_t n, int32_t in_f,
+                           int32_t out_f, void* stream) {
+  DSG_CHECK_ARG(x && w && y, "dsg_linear_fwd: NULL pointer");
+  DSG_CHECK_ARG(n > 0 && in_f > 0 && out_f > 0, "dsg_linear_fwd: bad dims");
+  hipLaunchKernelGGL(dsg::linear_rows_kernel, dim3(dsg::cdiv(out_f, 4)), dim3(256), 0,
+                     static_cast<hipStream_t>(stream), x, w, b, y, n, in_f, out_f);
+  DSG_LAUNCH_CHECK();
+  return DSG_OK;
+}

@@ -1,0 +1,507 @@
+// Whole-network plan: diffusers' UNet2DModel.forward as one host call that enqueues the fused
+// gfx950 kernels of conv.hip / groupnorm.hip / attention.hip / temb.hip on the caller's stream.
+//
+// Reference: the model is constructed at DriveSceneGen/scripts/train.py:39-57 and evaluated once per
+// denoising step inside DDPMPipeline.__call__ (DriveSceneGen/pipeline/training_pipeline.py:26-32,
+// DriveSceneGen/scripts/generation.py:14-20).  Block wiring follows SURVEY.md App. A.1 (constructor
+// resolution) and A.2 (forward order, skip bookkeeping); parameters are addressed by their diffusers
+// state-dict keys (App. A.5) so checkpoints load unchanged.
+//
+// Data layout in HBM: activations NCHW fp32, carved from ONE caller-owned workspace by a first-fit
+// arena whose decisions depend only on (config, batch) -- the same dry run sizes the workspace.
+// Concat, nearest-upsample, GroupNorm-apply+SiLU, bias, time-embedding add and residual add never
+// materialise: they are folded into the gather / epilogue of dsg_conv2d_fwd.
+#include "dsg_common.h"
+
+#include <algorithm>
+#include <cstring>
+#include <map>
+#include <memory>
+#include <string>
+#include <vector>
+
+namespace dsg {
+int conv2d_fwd_impl(const dsg_conv_args* a, hipStream_t st, int force_direct);
+}
+
+namespace {
+
+using dsg::fail;
+
+struct Arena {
+  // free list sorted by offset; capacity is unbounded, the high-water mark is what matters
+  std::vector<std::pair<size_t, size_t>> free_;  // (offset, size)
+  size_t high = 0;
+  Arena() { free_.push_back({0, (size_t)1 << 62}); }
+  size_t alloc(size_t bytes) {
+    bytes = (bytes + 255) & ~(size_t)255;
+    for (size_t i = 0; i < free_.size(); ++i) {
+      if (free_[i].second >= bytes) {
+        const size_t off = free_[i].first;
+        free_[i].first += bytes;
+        free_[i].second -= bytes;
+        if (free_[i].second == 0) free_.erase(free_.begin() + i);
+        if (off + bytes > high) high = off + bytes;
+        return off;
+      }
+    }
+    return (size_t)-1;
+  }
+  void release(size_t off, size_t bytes) {
+    bytes = (bytes + 255) & ~(size_t)255;
+    size_t i = 0;
+    while (i < free_.size() && free_[i].first < off) ++i;
+    free_.insert(free_.begin() + i, {off, bytes});
+    if (i + 1 < free_.size() && free_[i].first + free_[i].second == free_[i + 1].first) {
+      free_[i].second += free_[i + 1].second;
+      free_.erase(free_.begin() + i + 1);
+    }
+    if (i > 0 && free_[i - 1].first + free_[i - 1].second == free_[i].first) {
+      free_[i - 1].second += free_[i].second;
+      free_.erase(free_.begin() + i);
+    }
+  }
+};
+
+struct Buf {
+  Arena* a;
+  size_t off, bytes;
+  Buf(Arena* a_, size_t o, size_t b) : a(a_), off(o), bytes(b) {}
+  ~Buf() { a->release(off, bytes); }
+};
+
+struct T {  // activation [N, c, h, w] (or any scratch when c/h/w are unused)
+  std::shared_ptr<Buf> b;
+  float* p = nullptr;
+  int c = 0, h = 0, w = 0;
+};
+
+struct Conv { float* w = nullptr; float* b = nullptr; int cin = 0, cout = 0, k = 0; };
+struct GN { float* g = nullptr; float* b = nullptr; int c = 0; };
+struct Res { GN n1; Conv c1; int toff = 0; GN n2; Conv c2; bool sc = false; Conv csc; int cin = 0, cout = 0; };
+struct Att { GN gn; Conv qkv; Conv out; int c = 0, heads = 0; };
+struct Stage { std::vector<Res> res; std::vector<Att> att; bool resample = false; Conv rconv; };
+
+enum ParamKind { P_COPY, P_CONV };
+struct Param {
+  std::string name;
+  ParamKind kind;
+  float* dst;
+  int64_t numel;
+  int cout, cin, k, cout_total, cout_off;
+  bool set;
+};
+
+}  // namespace
+
+struct dsg_unet {
+  dsg_unet_config cfg;
+  std::vector<void*> allocs;
+  std::vector<Param> params;
+  std::map<std::string, int> index;
+  int temb_dim = 0, proj_total = 0;
+  float *w1 = nullptr, *b1 = nullptr, *w2 = nullptr, *b2 = nullptr, *wp = nullptr, *bp = nullptr;
+  Conv conv_in, conv_out;
+  GN norm_out;
+  std::vector<Stage> down, up;
+  Res mid0, mid1;
+  bool mid_attn = false;
+  Att mid_att;
+  std::map<int, size_t> ws_cache;
+  std::string err;
+
+  float* dalloc(int64_t numel) {
+    void* p = nullptr;
+    if (hipMalloc(&p, (size_t)numel * sizeof(float)) != hipSuccess) return nullptr;
+    allocs.push_back(p);
+    return static_cast<float*>(p);
+  }
+  void add_param(const std::string& name, ParamKind kind, float* dst, int64_t numel, int cout = 0, int cin = 0,
+                 int k = 0, int cout_total = 0, int cout_off = 0) {
+    index[name] = (int)params.size();
+    params.push_back({name, kind, dst, numel, cout, cin, k, cout_total, cout_off, false});
+  }
+  void reg_conv(const std::string& pre, Conv& c, int cin, int cout, int k) {
+    c.cin = cin; c.cout = cout; c.k = k;
+    c.w = dalloc((int64_t)cin * k * k * cout);
+    c.b = dalloc(cout);
+    add_param(pre + ".weight", P_CONV, c.w, (int64_t)cin * k * k * cout, cout, cin, k, cout, 0);
+    add_param(pre + ".bias", P_COPY, c.b, cout);
+  }
+  void reg_gn(const std::string& pre, GN& g, int c) {
+    g.c = c;
+    g.g = dalloc(c);
+    g.b = dalloc(c);
+    add_param(pre + ".weight", P_COPY, g.g, c);
+    add_param(pre + ".bias", P_COPY, g.b, c);
+  }
+  void reg_res(const std::string& pre, Res& r, int cin, int cout) {
+    r.cin = cin; r.cout = cout;
+    reg_gn(pre + ".norm1", r.n1, cin);
+    reg_conv(pre + ".conv1", r.c1, cin, cout, 3);
+    r.toff = proj_total;
+    proj_total += cout;
+    reg_gn(pre + ".norm2", r.n2, cout);
+    reg_conv(pre + ".conv2", r.c2, cout, cout, 3);
+    r.sc = cin != cout;
+    if (r.sc) reg_conv(pre + ".conv_shortcut", r.csc, cin, cout, 1);
+  }
+  void reg_att(const std::string& pre, Att& a, int c) {
+    a.c = c;
+    a.heads = c / cfg.attention_head_dim;
+    reg_gn(pre + ".group_norm", a.gn, c);
+    a.qkv.cin = c; a.qkv.cout = 3 * c; a.qkv.k = 1;
+    a.qkv.w = dalloc((int64_t)c * 3 * c);
+    a.qkv.b = dalloc(3 * c);
+    const char* names[3] = {"to_q", "to_k", "to_v"};
+    for (int i = 0; i < 3; ++i) {
+      add_param(pre + "." + names[i] + ".weight", P_CONV, a.qkv.w, (int64_t)c * c, c, c, 1, 3 * c, i * c);
+      add_param(pre + "." + names[i] + ".bias", P_COPY, a.qkv.b + i * c, c);
+    }
+    reg_conv(pre + ".to_out.0", a.out, c, c, 1);
+  }
+};
+
+namespace {
+
+// second pass over the resnets: time_emb_proj rows live in one [proj_total][dim] matrix
+void reg_tproj(dsg_unet* h, const std::string& pre, const Res& r) {
+  h->add_param(pre + ".time_emb_proj.weight", P_COPY, h->wp + (int64_t)r.toff * h->temb_dim,
+               (int64_t)r.cout * h->temb_dim);
+  h->add_param(pre + ".time_emb_proj.bias", P_COPY, h->bp + r.toff, r.cout);
+}
+
+struct Runner {
+  dsg_unet* h;
+  int B;
+  char* ws;
+  bool dry;
+  hipStream_t st;
+  Arena arena;
+  int rc = DSG_OK;
+
+  T alloc(int c, int hh, int w, size_t elems = 0, size_t esz = sizeof(float)) {
+    T t;
+    const size_t n = elems ? elems : (size_t)B * c * hh * w;
+    const size_t bytes = n * esz;
+    const size_t off = arena.alloc(bytes);
+    t.b = std::make_shared<Buf>(&arena, off, bytes);
+    t.p = reinterpret_cast<float*>(ws + off);
+    t.c = c; t.h = hh; t.w = w;
+    return t;
+  }
+  bool ok() const { return rc == DSG_OK; }
+
+  // scale/shift of GroupNorm(gn) over cat(x, skip)
+  T gn_ss(const T& x, const T* skip, const GN& gn) {
+    const int c = x.c + (skip ? skip->c : 0);
+    T stats = alloc(0, 0, 0, (size_t)B * c * 2, sizeof(double));
+    T ss = alloc(0, 0, 0, (size_t)B * c * 2);
+    if (!dry && ok()) {
+      rc = dsg_gn_channel_stats(x.p, x.c, skip ? skip->p : nullptr, skip ? skip->c : 0, B, x.h * x.w,
+                                reinterpret_cast<double*>(stats.p), st);
+      if (ok())
+        rc = dsg_gn_finalize(reinterpret_cast<double*>(stats.p), gn.g, gn.b, B, c, h->cfg.norm_num_groups,
+                             x.h * x.w, h->cfg.norm_eps, ss.p, st);
+    }
+    return ss;
+  }
+
+  T conv(const T& x, const T* skip, const Conv& cv, int stride, int ups, const T* ss, int silu, const float* temb,
+         const T* res, float* dst_override = nullptr) {
+    const int hc = ups ? 2 * x.h : x.h, wc = ups ? 2 * x.w : x.w;
+    const int pad = cv.k / 2;
+    const int ho = (hc + 2 * pad - cv.k) / stride + 1, wo = (wc + 2 * pad - cv.k) / stride + 1;
+    T y;
+    if (dst_override) {
+      y.p = dst_override; y.c = cv.cout; y.h = ho; y.w = wo;
+    } else {
+      y = alloc(cv.cout, ho, wo);
+    }
+    if (!dry && ok()) {
+      dsg_conv_args a;
+      std::memset(&a, 0, sizeof(a));
+      a.src0 = x.p; a.c0 = x.c;
+      a.src1 = skip ? skip->p : nullptr; a.c1 = skip ? skip->c : 0;
+      a.n = B; a.hin = x.h; a.win = x.w; a.upsample = ups; a.ksize = cv.k; a.stride = stride; a.cout = cv.cout;
+      a.weight = cv.w; a.bias = cv.b;
+      a.gn_scale_shift = ss ? ss->p : nullptr; a.silu = silu;
+      a.temb = temb; a.temb_stride = h->proj_total;
+      a.residual = res ? res->p : nullptr;
+      a.dst = y.p;
+      rc = dsg::conv2d_fwd_impl(&a, st, 0);
+    }
+    return y;
+  }
+
+  T resnet(const T& x, const T* skip, const Res& r, const float* tproj) {
+    T ss1 = gn_ss(x, skip, r.n1);
+    T hmid = conv(x, skip, r.c1, 1, 0, &ss1, 1, tproj + r.toff, nullptr);
+    ss1 = T();
+    T ss2 = gn_ss(hmid, nullptr, r.n2);
+    T y;
+    if (r.sc) {
+      T sc = conv(x, skip, r.csc, 1, 0, nullptr, 0, nullptr, nullptr);
+      y = conv(hmid, nullptr, r.c2, 1, 0, &ss2, 1, nullptr, &sc);
+    } else {
+      y = conv(hmid, nullptr, r.c2, 1, 0, &ss2, 1, nullptr, &x);
+    }
+    return y;
+  }
+
+  T attention(const T& x, const Att& at) {
+    T ss = gn_ss(x, nullptr, at.gn);
+    T qkv = conv(x, nullptr, at.qkv, 1, 0, &ss, 0, nullptr, nullptr);
+    ss = T();
+    T o = alloc(x.c, x.h, x.w);
+    if (!dry && ok()) rc = dsg_attention_fwd(qkv.p, o.p, B, x.c, at.heads, x.h * x.w, st);
+    qkv = T();
+    return conv(o, nullptr, at.out, 1, 0, nullptr, 0, nullptr, &x);
+  }
+
+  int run(const float* xin, const int64_t* t, float* out) {
+    const dsg_unet_config& cfg = h->cfg;
+    T act = alloc(0, 0, 0, (size_t)B * h->temb_dim);
+    T tproj = alloc(0, 0, 0, (size_t)B * h->proj_total);
+    if (!dry) {
+      rc = dsg_time_embed_fwd(t, B, cfg.block_out_channels[0], h->temb_dim, h->w1, h->b1, h->w2, h->b2, act.p, st);
+      if (ok()) rc = dsg_linear_fwd(act.p, h->wp, h->bp, tproj.p, B, h->temb_dim, h->proj_total, st);
+    }
+    act = T();
+    T x0;
+    x0.p = const_cast<float*>(xin); x0.c = cfg.in_channels; x0.h = cfg.sample_h; x0.w = cfg.sample_w;
+    T x = conv(x0, nullptr, h->conv_in, 1, 0, nullptr, 0, nullptr, nullptr);
+    std::vector<T> skips;
+    skips.push_back(x);
+    for (auto& d : h->down) {
+      for (size_t j = 0; j < d.res.size(); ++j) {
+        x = resnet(x, nullptr, d.res[j], tproj.p);
+        if (!d.att.empty()) x = attention(x, d.att[j]);
+        skips.push_back(x);
+      }
+      if (d.resample) {
+        x = conv(x, nullptr, d.rconv, 2, 0, nullptr, 0, nullptr, nullptr);
+        skips.push_back(x);
+      }
+    }
+    x = resnet(x, nullptr, h->mid0, tproj.p);
+    if (h->mid_attn) x = attention(x, h->mid_att);
+    x = resnet(x, nullptr, h->mid1, tproj.p);
+    for (auto& u : h->up) {
+      for (size_t j = 0; j < u.res.size(); ++j) {
+        T s = skips.back();
+        skips.pop_back();
+        x = resnet(x, &s, u.res[j], tproj.p);
+        if (!u.att.empty()) x = attention(x, u.att[j]);
+      }
+      if (u.resample) x = conv(x, nullptr, u.rconv, 1, 1, nullptr, 0, nullptr, nullptr);
+    }
+    T ssf = gn_ss(x, nullptr, h->norm_out);
+    conv(x, nullptr, h->conv_out, 1, 0, &ssf, 1, nullptr, nullptr, out);
+    return rc;
+  }
+};
+
+int check_cfg(const dsg_unet_config* c) {
+  DSG_CHECK_ARG(c != nullptr, "dsg_unet_create: cfg is NULL");
+  DSG_CHECK_ARG(c->num_blocks >= 1 && c->num_blocks <= 8, "dsg_unet_create: num_blocks %d not in [1,8]",
+                c->num_blocks);
+  DSG_CHECK_ARG(c->in_channels > 0 && c->out_channels > 0 && c->sample_h > 0 && c->sample_w > 0,
+                "dsg_unet_create: non-positive channel / size");
+  DSG_CHECK_ARG(c->layers_per_block >= 1 && c->norm_num_groups >= 1 && c->attention_head_dim >= 1,
+                "dsg_unet_create: bad layers_per_block / norm_num_groups / attention_head_dim");
+  for (int i = 0; i < c->num_blocks; ++i) {
+    const int ch = c->block_out_channels[i];
+    DSG_CHECK_ARG(ch > 0 && ch % c->norm_num_groups == 0,
+                  "dsg_unet_create: block_out_channels[%d]=%d not a positive multiple of norm_num_groups=%d", i, ch,
+                  c->norm_num_groups);
+  }
+  const int f = 1 << (c->num_blocks - 1);
+  DSG_CHECK_ARG(c->sample_h % f == 0 && c->sample_w % f == 0,
+                "dsg_unet_create: sample size %dx%d not divisible by 2^(num_blocks-1)=%d", c->sample_h, c->sample_w,
+                f);
+  return DSG_OK;
+}
+
+}  // namespace
+
+DSG_API int dsg_unet_create(const dsg_unet_config* cfg, dsg_unet_t** out) {
+  DSG_CHECK_ARG(out != nullptr, "dsg_unet_create: out is NULL");
+  *out = nullptr;
+  int rc = check_cfg(cfg);
+  if (rc != DSG_OK) return rc;
+  std::unique_ptr<dsg_unet> h(new dsg_unet());
+  h->cfg = *cfg;
+  const int nb = cfg->num_blocks;
+  const int* boc = cfg->block_out_channels;
+  const int hd = cfg->attention_head_dim;
+  h->temb_dim = 4 * boc[0];
+
+  h->reg_conv("conv_in", h->conv_in, cfg->in_channels, boc[0], 3);
+  h->w1 = h->dalloc((int64_t)h->temb_dim * boc[0]);
+  h->b1 = h->dalloc(h->temb_dim);
+  h->w2 = h->dalloc((int64_t)h->temb_dim * h->temb_dim);
+  h->b2 = h->dalloc(h->temb_dim);
+  h->add_param("time_embedding.linear_1.weight", P_COPY, h->w1, (int64_t)h->temb_dim * boc[0]);
+  h->add_param("time_embedding.linear_1.bias", P_COPY, h->b1, h->temb_dim);
+  h->add_param("time_embedding.linear_2.weight", P_COPY, h->w2, (int64_t)h->temb_dim * h->temb_dim);
+  h->add_param("time_embedding.linear_2.bias", P_COPY, h->b2, h->temb_dim);
+
+  int out_ch = boc[0];
+  h->down.resize(nb);
+  for (int i = 0; i < nb; ++i) {
+    const int in_ch = out_ch;
+    out_ch = boc[i];
+    Stage& d = h->down[i];
+    const std::string pre = "down_blocks." + std::to_string(i);
+    d.res.resize(cfg->layers_per_block);
+    if (cfg->down_attn[i]) {
+      DSG_CHECK_ARG(out_ch % hd == 0, "dsg_unet_create: channels %d not divisible by attention_head_dim %d", out_ch, hd);
+      d.att.resize(cfg->layers_per_block);
+    }
+    for (int j = 0; j < cfg->layers_per_block; ++j) {
+      h->reg_res(pre + ".resnets." + std::to_string(j), d.res[j], j == 0 ? in_ch : out_ch, out_ch);
+      if (cfg->down_attn[i]) h->reg_att(pre + ".attentions." + std::to_string(j), d.att[j], out_ch);
+    }
+    d.resample = i != nb - 1;
+    if (d.resample) h->reg_conv(pre + ".downsamplers.0.conv", d.rconv, out_ch, out_ch, 3);
+  }
+  h->reg_res("mid_block.resnets.0", h->mid0, boc[nb - 1], boc[nb - 1]);
+  h->mid_attn = cfg->add_attention != 0;
+  if (h->mid_attn) {
+    DSG_CHECK_ARG(boc[nb - 1] % hd == 0, "dsg_unet_create: channels %d not divisible by attention_head_dim %d",
+                  boc[nb - 1], hd);
+    h->reg_att("mid_block.attentions.0", h->mid_att, boc[nb - 1]);
+  }
+  h->reg_res("mid_block.resnets.1", h->mid1, boc[nb - 1], boc[nb - 1]);
+
+  h->up.resize(nb);
+  out_ch = boc[nb - 1];
+  for (int i = 0; i < nb; ++i) {
+    const int prev = out_ch;
+    out_ch = boc[nb - 1 - i];
+    const int in_ch = boc[nb - 1 - std::min(i + 1, nb - 1)];
+    Stage& u = h->up[i];
+    const std::string pre = "up_blocks." + std::to_string(i);
+    const int nl = cfg->layers_per_block + 1;
+    u.res.resize(nl);
+    if (cfg->up_attn[i]) {
+      DSG_CHECK_ARG(out_ch % hd == 0, "dsg_unet_create: channels %d not divisible by attention_head_dim %d", out_ch, hd);
+      u.att.resize(nl);
+    }
+    for (int j = 0; j < nl; ++j) {
+      const int skip = (j == nl - 1) ? in_ch : out_ch;
+      const int rin = (j == 0) ? prev : out_ch;
+      h->reg_res(pre + ".resnets." + std::to_string(j), u.res[j], rin + skip, out_ch);
+      if (cfg->up_attn[i]) h->reg_att(pre + ".attentions." + std::to_string(j), u.att[j], out_ch);
+    }
+    u.resample = i != nb - 1;
+    if (u.resample) h->reg_conv(pre + ".upsamplers.0.conv", u.rconv, out_ch, out_ch, 3);
+  }
+  h->reg_gn("conv_norm_out", h->norm_out, boc[0]);
+  h->reg_conv("conv_out", h->conv_out, boc[0], cfg->out_channels, 3);
+
+  // time_emb_proj: one [proj_total][temb_dim] matrix
+  h->wp = h->dalloc((int64_t)h->proj_total * h->temb_dim);
+  h->bp = h->dalloc(h->proj_total);
+  for (int i = 0; i < nb; ++i)
+    for (size_t j = 0; j < h->down[i].res.size(); ++j)
+      reg_tproj(h.get(), "down_blocks." + std::to_string(i) + ".resnets." + std::to_string(j), h->down[i].res[j]);
+  reg_tproj(h.get(), "mid_block.resnets.0", h->mid0);
+  reg_tproj(h.get(), "mid_block.resnets.1", h->mid1);
+  for (int i = 0; i < nb; ++i)
+    for (size_t j = 0; j < h->up[i].res.size(); ++j)
+      reg_tproj(h.get(), "up_blocks." + std::to_string(i) + ".resnets." + std::to_string(j), h->up[i].res[j]);
+
+  for (void* p : h->allocs)
+    if (p == nullptr) return fail(DSG_ERR_HIP, "dsg_unet_create: hipMalloc failed");
+  for (auto& p : h->params)
+    if (p.dst == nullptr) return fail(DSG_ERR_HIP, "dsg_unet_create: hipMalloc failed for %s", p.name.c_str());
+  *out = h.release();
+  return DSG_OK;
+}
+
+DSG_API void dsg_unet_destroy(dsg_unet_t* h) {
+  if (!h) return;
+  for (void* p : h->allocs)
+    if (p) (void)hipFree(p);
+  delete h;
+}
+
+DSG_API int dsg_unet_set_param(dsg_unet_t* h, const char* name, const float* data, int64_t numel, void* stream) {
+  DSG_CHECK_ARG(h && name && data, "dsg_unet_set_param: NULL argument");
+  std::string key(name);
+  // pre-0.18 diffusers attention names
+  static const char* legacy[][2] = {{".query.", ".to_q."}, {".key.", ".to_k."}, {".value.", ".to_v."},
+                                    {".proj_attn.", ".to_out.0."}};
+  for (auto& l : legacy) {
+    const size_t pos = key.find(l[0]);
+    if (pos != std::string::npos) key.replace(pos, std::strlen(l[0]), l[1]);
+  }
+  auto it = h->index.find(key);
+  if (it == h->index.end()) return fail(DSG_ERR_INVALID_ARG, "dsg_unet_set_param: unknown parameter '%s'", name);
+  Param& p = h->params[it->second];
+  DSG_CHECK_ARG(p.numel == numel, "dsg_unet_set_param: '%s' expects %lld elements, got %lld", name,
+                (long long)p.numel, (long long)numel);
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  if (p.kind == P_COPY) {
+    DSG_HIP(hipMemcpyAsync(p.dst, data, (size_t)numel * sizeof(float), hipMemcpyDeviceToDevice, st));
+  } else {
+    const int rc = dsg_conv_weight_relayout(data, p.dst, p.cout, p.cin, p.k, p.cout_total, p.cout_off, stream);
+    if (rc != DSG_OK) return rc;
+  }
+  DSG_HIP(hipStreamSynchronize(st));
+  p.set = true;
+  return DSG_OK;
+}
+
+DSG_API int dsg_unet_num_params(const dsg_unet_t* h, int64_t* expected_tensors, int64_t* set_tensors,
+                                int64_t* total_elements) {
+  DSG_CHECK_ARG(h != nullptr, "dsg_unet_num_params: handle is NULL");
+  int64_t ns = 0, ne = 0;
+  for (auto& p : h->params) {
+    ns += p.set ? 1 : 0;
+    ne += p.numel;
+  }
+  if (expected_tensors) *expected_tensors = (int64_t)h->params.size();
+  if (set_tensors) *set_tensors = ns;
+  if (total_elements) *total_elements = ne;
+  return DSG_OK;
+}
+
+DSG_API int dsg_unet_param_name(const dsg_unet_t* h, int64_t index, const char** name, int64_t* numel) {
+  DSG_CHECK_ARG(h != nullptr, "dsg_unet_param_name: handle is NULL");
+  DSG_CHECK_ARG(index >= 0 && index < (int64_t)h->params.size(), "dsg_unet_param_name: index out of range");
+  if (name) *name = h->params[index].name.c_str();
+  if (numel) *numel = h->params[index].numel;
+  return DSG_OK;
+}
+
+DSG_API int dsg_unet_workspace_bytes(dsg_unet_t* h, int32_t batch, size_t* bytes) {
+  DSG_CHECK_ARG(h && bytes, "dsg_unet_workspace_bytes: NULL argument");
+  DSG_CHECK_ARG(batch > 0, "dsg_unet_workspace_bytes: batch must be positive");
+  auto it = h->ws_cache.find(batch);
+  if (it == h->ws_cache.end()) {
+    Runner r{h, batch, nullptr, true, nullptr};
+    r.run(nullptr, nullptr, nullptr);
+    it = h->ws_cache.emplace(batch, r.arena.high).first;
+  }
+  *bytes = it->second;
+  return DSG_OK;
+}
+
+DSG_API int dsg_unet_forward(dsg_unet_t* h, const float* x, const int64_t* timesteps, float* out, int32_t batch,
+                             void* workspace, size_t workspace_bytes, void* stream) {
+  DSG_CHECK_ARG(h && x && timesteps && out && workspace, "dsg_unet_forward: NULL argument");
+  DSG_CHECK_ARG(batch > 0, "dsg_unet_forward: batch must be positive");
+  for (auto& p : h->params)
+    if (!p.set) return fail(DSG_ERR_NOT_READY, "dsg_unet_forward: parameter '%s' was never set", p.name.c_str());
+  size_t need = 0;
+  int rc = dsg_unet_workspace_bytes(h, batch, &need);
+  if (rc != DSG_OK) return rc;
+  if (workspace_bytes < need)
+    return fail(DSG_ERR_WORKSPACE_TOO_SMALL, "dsg_unet_forward: workspace %zu bytes < required %zu", workspace_bytes,
+                need);
+  Runner r{h, batch, static_cast<char*>(workspace), false, static_cast<hipStream_t>(stream)};
+  return r.run(x, timesteps, out);
+}

@@ -1,0 +1,129 @@
+"""Thin Python wrappers over the per-op C-ABI entry points of libdsg.so (include/dsg.h).
+
+Used by the training path (autograd.py) and by the parity tests; the sampler hot loop goes through
+the whole-network plan (dsg_unet_forward) instead.  GPU tensors only -- no fallback.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import torch
+
+from . import _lib
+
+
+def _st(t):
+    return _lib.stream_ptr(t.device)
+
+
+def relayout_conv_weight(w_oihw: torch.Tensor, out: torch.Tensor = None, cout_total: int = None,
+                         cout_off: int = 0) -> torch.Tensor:
+    """OIHW (or Linear [out,in]) -> engine layout [Cin][k*k][cout_total]."""
+    w = w_oihw.contiguous()
+    cout, cin = w.shape[0], w.shape[1]
+    k = w.shape[2] if w.dim() == 4 else 1
+    cout_total = cout_total or cout
+    if out is None:
+        out = torch.empty((cin, k * k, cout_total), dtype=torch.float32, device=w.device)
+    with torch.cuda.device(w.device):
+        _lib.check(_lib.load().dsg_conv_weight_relayout(_lib.ptr(w), _lib.ptr(out), cout, cin, k, cout_total,
+                                                        cout_off, _st(w)))
+    return out
+
+
+def conv2d_fused(src0, weight_r, bias=None, src1=None, ksize=3, stride=1, upsample=False, gn_scale_shift=None,
+                 silu=False, temb=None, temb_stride=0, residual=None, out=None, direct=False):
+    """dsg_conv2d_fwd: see include/dsg.h.  `weight_r` is in engine layout; `temb` is a [N, temb_stride] view
+    whose first `cout` columns (from its data pointer) are added per (n, cout)."""
+    lib = _lib.load()
+    n, c0, hin, win = src0.shape
+    c1 = src1.shape[1] if src1 is not None else 0
+    cout = weight_r.shape[-1]
+    hc, wc = (2 * hin, 2 * win) if upsample else (hin, win)
+    pad = ksize // 2
+    ho = (hc + 2 * pad - ksize) // stride + 1
+    wo = (wc + 2 * pad - ksize) // stride + 1
+    if out is None:
+        out = torch.empty((n, cout, ho, wo), dtype=torch.float32, device=src0.device)
+    a = _lib.ConvArgs()
+    a.src0, a.src1 = _lib.ptr(src0), _lib.ptr(src1)
+    a.c0, a.c1, a.n, a.hin, a.win = c0, c1, n, hin, win
+    a.upsample, a.ksize, a.stride, a.cout = int(upsample), ksize, stride, cout
+    a.weight, a.bias = _lib.ptr(weight_r), _lib.ptr(bias)
+    a.gn_scale_shift, a.silu = _lib.ptr(gn_scale_shift), int(silu)
+    if temb is not None:
+        if not temb.is_cuda:
+            raise RuntimeError("temb must be a GPU tensor")
+        a.temb, a.temb_stride = temb.data_ptr(), int(temb_stride or temb.stride(0))
+    a.residual, a.dst = _lib.ptr(residual), _lib.ptr(out)
+    fn = lib.dsg_conv2d_fwd_direct if direct else lib.dsg_conv2d_fwd
+    with torch.cuda.device(src0.device):
+        _lib.check(fn(C.byref(a), _st(src0)))
+    return out
+
+
+def gn_scale_shift(src0, gamma, beta, groups, eps, src1=None):
+    """Per-(n, c) scale/shift of GroupNorm over cat(src0, src1): [N][C][2]."""
+    lib = _lib.load()
+    n, c0 = src0.shape[0], src0.shape[1]
+    hw = src0.shape[2] * src0.shape[3] if src0.dim() == 4 else src0.shape[2]
+    c1 = src1.shape[1] if src1 is not None else 0
+    c = c0 + c1
+    stats = torch.empty((n, c, 2), dtype=torch.float64, device=src0.device)
+    ss = torch.empty((n, c, 2), dtype=torch.float32, device=src0.device)
+    with torch.cuda.device(src0.device):
+        _lib.check(lib.dsg_gn_channel_stats(_lib.ptr(src0), c0, _lib.ptr(src1), c1, n, hw, _lib.ptr(stats),
+                                            _st(src0)))
+        _lib.check(lib.dsg_gn_finalize(_lib.ptr(stats), _lib.ptr(gamma), _lib.ptr(beta), n, c, groups, hw,
+                                       float(eps), _lib.ptr(ss), _st(src0)))
+    return ss
+
+
+def gn_apply(src, scale_shift, silu=False):
+    out = torch.empty_like(src)
+    n, c = src.shape[0], src.shape[1]
+    hw = src.numel() // (n * c)
+    with torch.cuda.device(src.device):
+        _lib.check(_lib.load().dsg_gn_apply(_lib.ptr(src), _lib.ptr(scale_shift), int(silu), _lib.ptr(out), n, c,
+                                            hw, _st(src)))
+    return out
+
+
+def attention(qkv, heads):
+    """qkv [N, 3C, L] -> [N, C, L]."""
+    n, c3, l = qkv.shape
+    c = c3 // 3
+    out = torch.empty((n, c, l), dtype=torch.float32, device=qkv.device)
+    with torch.cuda.device(qkv.device):
+        _lib.check(_lib.load().dsg_attention_fwd(_lib.ptr(qkv), _lib.ptr(out), n, c, heads, l, _st(qkv)))
+    return out
+
+
+def time_embed(timesteps, w1, b1, w2, b2):
+    """silu(linear_2(silu(linear_1(sinusoid(t))))) -> [N, dim]."""
+    n = timesteps.numel()
+    dim, ch = w1.shape
+    act = torch.empty((n, dim), dtype=torch.float32, device=w1.device)
+    with torch.cuda.device(w1.device):
+        _lib.check(_lib.load().dsg_time_embed_fwd(_lib.ptr(timesteps), n, ch, dim, _lib.ptr(w1), _lib.ptr(b1),
+                                                 _lib.ptr(w2), _lib.ptr(b2), _lib.ptr(act), _st(w1)))
+    return act
+
+
+def linear(x, w, b=None):
+    n, in_f = x.shape
+    out_f = w.shape[0]
+    y = torch.empty((n, out_f), dtype=torch.float32, device=x.device)
+    with torch.cuda.device(x.device):
+        _lib.check(_lib.load().dsg_linear_fwd(_lib.ptr(x), _lib.ptr(w), _lib.ptr(b), _lib.ptr(y), n, in_f, out_f,
+                                             _st(x)))
+    return y
+
+
+def postprocess(x, mode=0):
+    """(x/2+0.5).clamp(0,1), NCHW->NHWC; mode 0 float, 1 uint8 round, 2 uint8 truncation."""
+    b, c, h, w = x.shape
+    out = torch.empty((b, h, w, c), dtype=torch.float32 if mode == 0 else torch.uint8, device=x.device)
+    with torch.cuda.device(x.device):
+        _lib.check(_lib.load().dsg_postprocess(_lib.ptr(x.contiguous()), out.data_ptr(), b, c, h * w, mode, _st(x)))
+    return out

@@ -1,0 +1,163 @@
+"""``DDPMPipeline`` / ``DDIMPipeline`` -- the sampler objects DriveSceneGen's scripts call.
+
+Reference call sites:
+ - /root/reference/DriveSceneGen/pipeline/training_pipeline.py:101 ``DDPMPipeline(unet=..., scheduler=...)``,
+   :26-32 ``pipeline(num_inference_steps=750, batch_size, generator=torch.manual_seed(seed),
+   output_type="np.array", return_dict=False)``, :107 ``pipeline.save_pretrained(output_dir)``;
+ - /root/reference/DriveSceneGen/scripts/generation.py:7 ``DDPMPipeline.from_pretrained(path, variant="fp16")
+   .to('cuda')`` and :14-20 ``ddpm(batch_size=5, num_inference_steps=750).images``.
+Semantics: SURVEY.md App. A.4 (noise stream order, post-processing) and A.5 (folder layout).
+
+The denoising loop stays host-driven like the reference's, but each iteration is two asynchronous C-ABI
+calls on the current HIP stream (dsg_unet_forward + dsg_ddpm_step / dsg_ddim_step); batched inference
+shards samples over ranks with no collective (``shard=(rank, world)``).
+"""
+from __future__ import annotations
+
+import json
+import os
+from types import SimpleNamespace
+
+import numpy as np
+import torch
+
+from . import _lib
+from .schedulers import DDIMScheduler, DDPMScheduler, _randn_like_reference
+from .unet import UNet2DModel
+
+
+class ImagePipelineOutput(SimpleNamespace):
+    pass
+
+
+def numpy_to_pil(images: np.ndarray):
+    """diffusers ``numpy_to_pil``: (x*255).round().astype(uint8); C=1 -> mode L."""
+    from PIL import Image
+    if images.ndim == 3:
+        images = images[None, ...]
+    images = (images * 255).round().astype("uint8")
+    if images.shape[-1] == 1:
+        return [Image.fromarray(im.squeeze(), mode="L") for im in images]
+    if images.shape[-1] not in (3, 4):
+        raise ValueError(f"PIL output supports 1, 3 or 4 channels (got {images.shape[-1]}); "
+                         "use output_type='np.array'")
+    return [Image.fromarray(im) for im in images]
+
+
+class _PipelineBase:
+    _class_name = "DDPMPipeline"
+    _scheduler_cls = DDPMScheduler
+
+    def __init__(self, unet, scheduler):
+        self.unet = unet
+        self.scheduler = scheduler
+
+    @property
+    def device(self):
+        return self.unet.device
+
+    def to(self, device):
+        self.unet.to(device)
+        return self
+
+    # ---- App. A.5 folder layout -------------------------------------------------------------------
+    def save_pretrained(self, save_directory, safe_serialization: bool = False, variant=None):
+        os.makedirs(save_directory, exist_ok=True)
+        index = {"_class_name": self._class_name, "_diffusers_version": "0.20.0",
+                 "scheduler": ["diffusers", type(self.scheduler)._class_name],
+                 "unet": ["diffusers", "UNet2DModel"]}
+        with open(os.path.join(save_directory, "model_index.json"), "w") as f:
+            json.dump(index, f, indent=2, sort_keys=True)
+            f.write("\n")
+        self.unet.save_pretrained(os.path.join(save_directory, "unet"), safe_serialization=safe_serialization,
+                                  variant=variant)
+        self.scheduler.save_pretrained(os.path.join(save_directory, "scheduler"))
+
+    @classmethod
+    def from_pretrained(cls, path, variant=None, torch_dtype=None, **_unused):
+        with open(os.path.join(path, "model_index.json")) as f:
+            index = json.load(f)
+        sched_name = index.get("scheduler", ["diffusers", "DDPMScheduler"])[1]
+        sched_cls = {"DDPMScheduler": DDPMScheduler, "DDIMScheduler": DDIMScheduler}.get(sched_name)
+        if sched_cls is None:
+            raise NotImplementedError(f"scheduler class {sched_name!r} not supported")
+        if cls._scheduler_cls is not sched_cls:
+            # diffusers lets a pipeline adopt a compatible scheduler config
+            scheduler = cls._scheduler_cls.from_config(
+                {k: v for k, v in json.load(open(os.path.join(path, "scheduler", "scheduler_config.json"))).items()})
+        else:
+            scheduler = sched_cls.from_pretrained(path, subfolder="scheduler")
+        unet = UNet2DModel.from_pretrained(path, subfolder="unet", variant=variant, torch_dtype=torch_dtype)
+        return cls(unet=unet, scheduler=scheduler)
+
+    # ---- shared loop --------------------------------------------------------------------------------
+    def _initial_noise(self, batch_size, generator, shard):
+        c = self.unet.config
+        ss = c.sample_size
+        shape = (batch_size, c.in_channels, ss, ss) if isinstance(ss, int) else (batch_size, c.in_channels, *ss)
+        image = _randn_like_reference(shape, generator, self.device, torch.float32)
+        return self._shard(image, shard)
+
+    @staticmethod
+    def _shard(x, shard):
+        if shard is None:
+            return x
+        rank, world = shard
+        b = x.shape[0]
+        if b % world != 0:
+            raise ValueError(f"batch {b} not divisible by world size {world}")
+        per = b // world
+        return x[rank * per:(rank + 1) * per].contiguous()
+
+    def _finish(self, image, output_type, return_dict):
+        b, c, h, w = image.shape
+        out = torch.empty((b, h, w, c), dtype=torch.float32, device=image.device)
+        with torch.cuda.device(image.device):
+            _lib.check(_lib.load().dsg_postprocess(_lib.ptr(image.contiguous()), _lib.ptr(out), b, c, h * w, 0,
+                                                  _lib.stream_ptr(image.device)))
+        arr = out.cpu().numpy()
+        if output_type == "pil":
+            arr = numpy_to_pil(arr)
+        if not return_dict:
+            return (arr,)
+        return ImagePipelineOutput(images=arr)
+
+
+class DDPMPipeline(_PipelineBase):
+    _class_name = "DDPMPipeline"
+    _scheduler_cls = DDPMScheduler
+
+    @torch.no_grad()
+    def __call__(self, batch_size: int = 1, generator=None, num_inference_steps: int = 1000, output_type="pil",
+                 return_dict: bool = True, shard=None):
+        if self.device.type != "cuda":
+            raise RuntimeError("DDPMPipeline runs on the MI355X HIP engine only: call .to('cuda') first")
+        image = self._initial_noise(batch_size, generator, shard)
+        self.scheduler.set_timesteps(num_inference_steps)
+        for t in self.scheduler.timesteps:
+            eps = self.unet(image, t).sample
+            noise = None
+            if int(t) > 0:
+                # reference semantics: one generator stream for the whole batch (App. A.4); a shard
+                # draws the full-batch noise and keeps its rows so that N-GPU output == 1-GPU output
+                full = (batch_size,) + tuple(image.shape[1:])
+                noise = self._shard(_randn_like_reference(full, generator, self.device, torch.float32), shard)
+            image = self.scheduler.step(eps, t, image, variance_noise=noise).prev_sample
+        return self._finish(image, output_type, return_dict)
+
+
+class DDIMPipeline(_PipelineBase):
+    _class_name = "DDIMPipeline"
+    _scheduler_cls = DDIMScheduler
+
+    @torch.no_grad()
+    def __call__(self, batch_size: int = 1, generator=None, eta: float = 0.0, num_inference_steps: int = 50,
+                 use_clipped_model_output=None, output_type="pil", return_dict: bool = True, shard=None):
+        if self.device.type != "cuda":
+            raise RuntimeError("DDIMPipeline runs on the MI355X HIP engine only: call .to('cuda') first")
+        image = self._initial_noise(batch_size, generator, shard)
+        self.scheduler.set_timesteps(num_inference_steps)
+        for t in self.scheduler.timesteps:
+            eps = self.unet(image, t).sample
+            image = self.scheduler.step(eps, t, image, eta=eta, generator=generator).prev_sample
+        return self._finish(image, output_type, return_dict)

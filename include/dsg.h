@@ -1,0 +1,173 @@
+/*
+ * dsg.h -- C ABI of libdsg.so, the MI355X (gfx950) denoising engine for DriveSceneGen's
+ * scene-raster U-Net.
+ *
+ * The reference (SS47816/DriveSceneGen) has no FFI of its own: its hot path calls Python objects
+ * from diffusers 0.20.0.  Each entry point below names the reference call site whose arithmetic it
+ * replaces (paths relative to the reference checkout) -- the Python shim in drivescenegen_amd/
+ * binds these with ctypes.
+ *
+ * Conventions
+ *  - every tensor is a raw DEVICE pointer, fp32, contiguous; activations NCHW, as the reference's
+ *    checkpoints and call sites use (train.py:39-57, training_pipeline.py:84);
+ *  - the caller owns every buffer, including workspaces; nothing is allocated per call; only
+ *    dsg_unet_* handles own device memory (their re-laid-out weights) until dsg_unet_destroy;
+ *  - `stream` is a hipStream_t passed as void*; calls enqueue and return without synchronising;
+ *  - every function returns DSG_OK (0) or a negative dsg_status; dsg_last_error() gives the
+ *    thread-local message.  No exception or abort crosses this boundary.
+ */
+#ifndef DSG_H_
+#define DSG_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum {
+  DSG_OK = 0,
+  DSG_ERR_INVALID_ARG = -1,
+  DSG_ERR_UNSUPPORTED_SHAPE = -2,
+  DSG_ERR_WORKSPACE_TOO_SMALL = -3,
+  DSG_ERR_HIP = -4,
+  DSG_ERR_NOT_READY = -5
+} dsg_status;
+
+int dsg_version(void);
+const char* dsg_last_error(void);
+
+/* ------------------------------------------------------------------------------------------
+ * Fused convolution: the Conv2d call sites of UNet2DModel.forward (train.py:39-57 builds it,
+ * training_pipeline.py:84 calls it): conv_in / resnet conv1, conv2 / conv_shortcut /
+ * downsamplers.0.conv (stride 2) / upsamplers.0.conv (after nearest x2) / attention q,k,v,out
+ * projections (1x1 over [N,C,H*W]) / conv_out.
+ *
+ *   dst = conv(act(affine(cat(src0, src1)[optionally nearest-upsampled x2])), W) + bias
+ *         (+ temb[n, cout]) (+ residual)
+ *
+ * affine/act is the GroupNorm-apply(+SiLU) of the preceding norm folded into the gather
+ * (gn_scale_shift[n][cin] = {rstd*gamma, beta - mean*rstd*gamma}); zero padding is applied after it.
+ * Weight is in the engine layout produced by dsg_conv_weight_relayout: [Cin][k*k][Cout].
+ * ---------------------------------------------------------------------------------------- */
+typedef struct {
+  const float* src0;            /* [N, c0, hin, win] */
+  const float* src1;            /* optional [N, c1, hin, win] concatenated after src0 on channels */
+  int32_t c0, c1;
+  int32_t n, hin, win;          /* source dims (before the optional upsample) */
+  int32_t upsample;             /* 1: nearest x2 of the source before the conv (Upsample2D) */
+  int32_t ksize;                /* 3 or 1; padding = ksize/2 */
+  int32_t stride;               /* 1 or 2 (Downsample2D) */
+  int32_t cout;
+  const float* weight;          /* [c0+c1][ksize*ksize][cout] */
+  const float* bias;            /* [cout] or NULL */
+  const float* gn_scale_shift;  /* optional [N][c0+c1][2] */
+  int32_t silu;                 /* 1: SiLU after the affine */
+  const float* temb;            /* optional: temb[n*temb_stride + cout_index] added per (n, cout) */
+  int32_t temb_stride;
+  const float* residual;        /* optional [N, cout, hout, wout] */
+  float* dst;                   /* [N, cout, hout, wout] */
+} dsg_conv_args;
+
+int dsg_conv2d_fwd(const dsg_conv_args* a, void* stream);
+
+/* OIHW (checkpoint layout) -> engine layout [Cin][k*k][cout_total], written at
+ * column offset cout_off (used to fuse to_q/to_k/to_v into one projection). nn.Linear weights
+ * [out][in] are the k=1 case. */
+int dsg_conv_weight_relayout(const float* w_oihw, float* dst, int32_t cout, int32_t cin, int32_t ksize,
+                             int32_t cout_total, int32_t cout_off, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * GroupNorm (ResnetBlock2D.norm1/norm2, Attention.group_norm, conv_norm_out).
+ * Statistics are per-channel (sum, sum of squares) in fp64 so that groups spanning the
+ * [x || skip] concat of the up path combine exactly; finalize turns them into the per-(n, c)
+ * scale/shift consumed by dsg_conv2d_fwd / dsg_gn_apply.
+ * ---------------------------------------------------------------------------------------- */
+int dsg_gn_channel_stats(const float* src0, int32_t c0, const float* src1, int32_t c1, int32_t n,
+                         int32_t hw, double* chan_stats /* [N][c0+c1][2] */, void* stream);
+int dsg_gn_finalize(const double* chan_stats, const float* gamma, const float* beta, int32_t n,
+                    int32_t c, int32_t groups, int32_t hw, float eps,
+                    float* scale_shift /* [N][C][2] */, void* stream);
+int dsg_gn_apply(const float* src, const float* scale_shift, int32_t silu, float* dst, int32_t n,
+                 int32_t c, int32_t hw, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Self-attention core (UNetMidBlock2D.attentions.0, Attn{Down,Up}Block2D): softmax(Q^T K / sqrt(d)) V
+ * per (n, head) over L = H*W tokens.  qkv is the fused projection output [N][3*C][L] (q rows
+ * first, then k, then v; channel = head*d + i); out is [N][C][L].
+ * ---------------------------------------------------------------------------------------- */
+int dsg_attention_fwd(const float* qkv, float* out, int32_t n, int32_t c, int32_t heads, int32_t l,
+                      void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Timestep path (UNet2DModel.time_proj + time_embedding + every ResnetBlock2D.time_emb_proj):
+ *   act = silu(linear_2(silu(linear_1(sinusoid(t)))))   [N][dim]   (dim = 4*block_out_channels[0])
+ *   proj = act @ Wp^T + bp                               [N][proj_total]
+ * timesteps: device int64 [N] (training_pipeline.py:76).  W1 [dim][ch], W2 [dim][dim], Wp [proj_total][dim].
+ * ---------------------------------------------------------------------------------------- */
+int dsg_time_embed_fwd(const int64_t* timesteps, int32_t n, int32_t ch, int32_t dim, const float* w1,
+                       const float* b1, const float* w2, const float* b2, float* act, void* stream);
+int dsg_linear_fwd(const float* x, const float* w, const float* b, float* y, int32_t n, int32_t in_f,
+                   int32_t out_f, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Noise scheduler elementwise math (diffusers DDPMScheduler / DDIMScheduler):
+ *   add_noise   training_pipeline.py:80       x_t = sqrt_a[n]*x0 + sqrt_1ma[n]*eps
+ *   ddpm_step   DDPMPipeline loop (training_pipeline.py:26-32, generation.py:14-20)
+ *   ddim_step   BASELINE.json configs[1], [3]
+ * Host-computed fp32 scalars are passed by value; evaluation order matches the reference so that
+ * results are bit-identical to the torch-CPU expression on the same inputs.
+ * ---------------------------------------------------------------------------------------- */
+int dsg_add_noise(const float* x0, const float* noise, const float* sqrt_a /* device [N] */,
+                  const float* sqrt_1ma /* device [N] */, float* out, int32_t n, int64_t per_sample,
+                  void* stream);
+int dsg_ddpm_step(const float* sample, const float* eps, const float* noise /* NULL when t == 0 */,
+                  float* prev, int64_t numel, float sqrt_beta_prod_t, float sqrt_alpha_prod_t,
+                  float clip /* <=0: no clip */, float coef_x0, float coef_xt, float sigma, void* stream);
+int dsg_ddim_step(const float* sample, const float* eps, float* prev, int64_t numel,
+                  float sqrt_beta_prod_t, float sqrt_alpha_prod_t, float clip, float sqrt_alpha_prev,
+                  float dir_coef, void* stream);
+/* Pipeline post-process (DDPMPipeline.__call__ tail, App. A.4): (x/2+0.5).clamp(0,1), NCHW -> NHWC;
+ * mode 0: float out; mode 1: uint8 round (generation.py `.images`); mode 2: uint8 truncation
+ * (training_pipeline.py:21-22). */
+int dsg_postprocess(const float* x, void* out, int32_t n, int32_t c, int32_t hw, int32_t mode, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Whole-network plan: UNet2DModel.forward as one call, for the sampler loops
+ * (DDPMPipeline.__call__: training_pipeline.py:26-32, generation.py:14-20).
+ * ---------------------------------------------------------------------------------------- */
+typedef struct dsg_unet dsg_unet_t;
+
+typedef struct {
+  int32_t in_channels, out_channels;
+  int32_t sample_h, sample_w;
+  int32_t layers_per_block;
+  int32_t num_blocks;               /* <= 8 */
+  int32_t block_out_channels[8];
+  int32_t down_attn[8];             /* 1: AttnDownBlock2D, 0: DownBlock2D */
+  int32_t up_attn[8];               /* 1: AttnUpBlock2D,   0: UpBlock2D  */
+  int32_t norm_num_groups;
+  float norm_eps;
+  int32_t attention_head_dim;
+  int32_t add_attention;            /* mid-block attention */
+} dsg_unet_config;
+
+int dsg_unet_create(const dsg_unet_config* cfg, dsg_unet_t** out);
+void dsg_unet_destroy(dsg_unet_t* h);
+/* Copies (and re-lays-out) one checkpoint tensor, named by its diffusers state-dict key
+ * (SURVEY App. A.5), from device memory into the plan.  Synchronises `stream` before returning. */
+int dsg_unet_set_param(dsg_unet_t* h, const char* name, const float* data, int64_t numel, void* stream);
+/* Number of parameters the plan expects / that have been set. */
+int dsg_unet_num_params(const dsg_unet_t* h, int64_t* expected_tensors, int64_t* set_tensors,
+                        int64_t* total_elements);
+int dsg_unet_param_name(const dsg_unet_t* h, int64_t index, const char** name, int64_t* numel);
+int dsg_unet_workspace_bytes(dsg_unet_t* h, int32_t batch, size_t* bytes);
+/* eps = UNet(x, t).  timesteps: device int64 [batch]. */
+int dsg_unet_forward(dsg_unet_t* h, const float* x, const int64_t* timesteps, float* out, int32_t batch,
+                     void* workspace, size_t workspace_bytes, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DSG_H_ */

@@ -1,0 +1,63 @@
+#!/usr/bin/env python3
+"""Regenerate tests/golden/cfg1_golden.npz from the CPU oracle (run from the repo root):
+
+    python tests/golden/make_golden.py
+
+Golden vectors for BASELINE.json configs[0] (64x64x3 tiny UNet2DModel, 2 down/up, 32 base channels):
+forward outputs at t in {0, 1, 499, 999}, add_noise outputs, a 10-step DDPM trajectory with
+host-supplied noise and a 10-step DDIM trajectory.  Inputs and weights are the deterministic numpy
+streams of drivescenegen_amd/synth.py, so only expected OUTPUTS are stored.  The reference itself
+cannot be imported here (diffusers is absent), so these pin the oracle against drift, not against
+diffusers (parity unpinned, see oracle/__init__.py).
+"""
+import os
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+
+from drivescenegen_amd import synth  # noqa: E402
+from oracle.scheduler_oracle import OracleDDIMScheduler, OracleDDPMScheduler  # noqa: E402
+from oracle.unet_oracle import OracleUNet2DModel  # noqa: E402
+from tests.common import CFG1, noisy_inputs, synth_weights  # noqa: E402
+
+
+def main():
+    torch.set_num_threads(max(1, os.cpu_count() or 1))
+    torch.manual_seed(0)
+    net = synth_weights(OracleUNet2DModel(**CFG1)).eval()
+    out = {}
+    x = noisy_inputs(CFG1, 2)
+    with torch.no_grad():
+        for t in (0, 1, 499, 999):
+            out[f"fwd_t{t}"] = net(x, t).sample.numpy()
+        out["fwd_tvec"] = net(x, torch.tensor([17, 801])).sample.numpy()
+        sch = OracleDDPMScheduler()
+        x0 = torch.from_numpy(synth.synth_scene_rasters(2, 3, 64, 64, 7))
+        nz = torch.from_numpy(synth.normal(8, (2, 3, 64, 64)))
+        out["add_noise"] = sch.add_noise(x0, nz, torch.tensor([3, 977])).numpy()
+        # 10-step DDPM with host-supplied noise (stream s = 100 + step index)
+        sch.set_timesteps(10)
+        img = torch.from_numpy(synth.normal(9, (2, 3, 64, 64)))
+        for i, t in enumerate(sch.timesteps):
+            eps = net(img, t).sample
+            z = torch.from_numpy(synth.normal(9, (2, 3, 64, 64), stream=100 + i)) if int(t) > 0 else None
+            img = sch.step(eps, t, img, noise=z).prev_sample
+        out["ddpm10_final"] = img.numpy()
+        dd = OracleDDIMScheduler()
+        dd.set_timesteps(10)
+        img = torch.from_numpy(synth.normal(9, (2, 3, 64, 64)))
+        for t in dd.timesteps:
+            img = dd.step(net(img, t).sample, t, img).prev_sample
+        out["ddim10_final"] = img.numpy()
+    out["input_checksum"] = np.array([float(np.abs(x.numpy()).sum())])
+    path = os.path.join(ROOT, "tests", "golden", "cfg1_golden.npz")
+    np.savez_compressed(path, **out)
+    print("wrote", path, {k: v.shape for k, v in out.items()})
+
+
+if __name__ == "__main__":
+    main()

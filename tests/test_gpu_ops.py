@@ -1,0 +1,210 @@
+"""Per-op parity of the HIP kernels (through the C ABI) against plain torch-CPU fp32 references.
+
+fp32 tolerances: contractions max|d| <= 2e-4*max(1,|y|inf) and rel-L2 <= 1e-4 (they are far
+tighter in practice -- the f32 MFMA is an exact fmaf chain); scheduler math is bit-exact."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+from drivescenegen_amd import ops, synth  # noqa: E402
+from oracle.scheduler_oracle import OracleDDIMScheduler, OracleDDPMScheduler  # noqa: E402
+from oracle.unet_oracle import timestep_embedding  # noqa: E402
+from tests.common import max_abs, rel_l2  # noqa: E402
+
+DEV = "cuda"
+
+
+def _t(seed, shape, scale=1.0):
+    return torch.from_numpy(synth.normal(seed, shape) * scale)
+
+
+def _check(got, want, tol_rel=1e-4, tol_abs=2e-4):
+    got = got.cpu()
+    assert got.shape == want.shape
+    assert torch.isfinite(got).all()
+    assert rel_l2(got, want) <= tol_rel, rel_l2(got, want)
+    assert max_abs(got, want) <= tol_abs * max(1.0, float(want.abs().max())), max_abs(got, want)
+
+
+CONV_CASES = [
+    # name, c0, c1, cout, h, w, k, stride, ups, gn, silu, temb, res
+    ("res_conv_64", 64, 0, 64, 32, 64, 3, 1, False, True, True, True, False),
+    ("res_conv2_resid", 64, 0, 128, 16, 32, 3, 1, False, True, True, False, True),
+    ("cout32_mt1", 32, 0, 32, 64, 64, 3, 1, False, True, True, True, True),
+    ("concat_straddle", 128, 64, 128, 16, 32, 3, 1, False, True, True, True, False),
+    ("upsample", 64, 0, 64, 16, 16, 3, 1, True, False, False, False, False),
+    ("stride2", 64, 0, 64, 32, 64, 3, 2, False, False, False, False, False),
+    ("shortcut_1x1_kc32", 128, 64, 64, 16, 32, 1, 1, False, False, False, False, False),
+    ("proj_1x1_kc8", 40, 0, 64, 8, 32, 1, 1, False, True, False, False, True),
+    ("conv_in_direct", 3, 0, 64, 32, 32, 3, 1, False, False, False, False, False),
+    ("conv_out_direct", 64, 0, 4, 32, 32, 3, 1, False, True, True, False, False),
+    ("odd_size_direct", 16, 0, 8, 13, 19, 3, 2, False, True, True, False, False),
+]
+
+
+@pytest.mark.parametrize("case", CONV_CASES, ids=[c[0] for c in CONV_CASES])
+@pytest.mark.parametrize("batch", [1, 3])
+def test_conv_fused(case, batch):
+    name, c0, c1, cout, h, w, k, stride, ups, gn, silu, temb, res = case
+    cin = c0 + c1
+    x0 = _t(1, (batch, c0, h, w))
+    x1 = _t(2, (batch, c1, h, w)) if c1 else None
+    wt = _t(3, (cout, cin, k, k), 1.0 / np.sqrt(cin * k * k))
+    bias = _t(4, (cout,), 0.1)
+    groups = 8 if cin % 8 == 0 else 1
+    gamma, beta = 1 + _t(5, (cin,), 0.1), _t(6, (cin,), 0.1)
+    xin = torch.cat([x0, x1], 1) if c1 else x0
+    ref = xin
+    if gn:
+        ref = F.group_norm(ref, groups, gamma, beta, 1e-5)
+        if silu:
+            ref = F.silu(ref)
+    if ups:
+        ref = F.interpolate(ref, scale_factor=2.0, mode="nearest")
+    ref = F.conv2d(ref, wt, bias, stride=stride, padding=k // 2)
+    tproj = _t(7, (batch, cout + 5), 0.5)
+    if temb:
+        ref = ref + tproj[:, 3:3 + cout, None, None]
+    r = _t(8, tuple(ref.shape))
+    if res:
+        ref = ref + r
+
+    d = lambda t: None if t is None else t.to(DEV)
+    wr = ops.relayout_conv_weight(d(wt))
+    ss = ops.gn_scale_shift(d(x0), d(gamma), d(beta), groups, 1e-5, src1=d(x1)) if gn else None
+    tp = d(tproj)
+    for direct in (False, True):
+        got = ops.conv2d_fused(d(x0), wr, d(bias), src1=d(x1), ksize=k, stride=stride, upsample=ups,
+                               gn_scale_shift=ss, silu=silu, temb=tp[:, 3:] if temb else None,
+                               temb_stride=tp.stride(0), residual=d(r) if res else None, direct=direct)
+        _check(got, ref)
+
+
+def test_conv_mfma_is_fmaf_chain_vs_fp64():
+    """The fp32 error of the MFMA path against an fp64 reference is no worse than torch-CPU's own."""
+    x = _t(11, (2, 256, 32, 32))
+    wt = _t(12, (64, 256, 3, 3), 1 / 48.0)
+    ref64 = F.conv2d(x.double(), wt.double(), None, padding=1)
+    cpu32 = F.conv2d(x, wt, None, padding=1)
+    got = ops.conv2d_fused(x.to(DEV), ops.relayout_conv_weight(wt.to(DEV))).cpu()
+    e_gpu, e_cpu = max_abs(got, ref64), max_abs(cpu32, ref64)
+    assert e_gpu <= 2 * e_cpu + 1e-6, (e_gpu, e_cpu)
+
+
+@pytest.mark.parametrize("c0,c1,groups,hw", [(64, 0, 32, (32, 32)), (128, 64, 32, (16, 16)), (32, 0, 32, (8, 24)),
+                                             (64, 0, 32, (256, 256))])
+def test_groupnorm(c0, c1, groups, hw):
+    h, w = hw
+    x0 = _t(21, (2, c0, h, w)) * 2 + 0.7
+    x1 = (_t(22, (2, c1, h, w)) - 0.3) if c1 else None
+    c = c0 + c1
+    gamma, beta = 1 + _t(23, (c,), 0.2), _t(24, (c,), 0.2)
+    xin = torch.cat([x0, x1], 1) if c1 else x0
+    for silu in (False, True):
+        ref = F.group_norm(xin, groups, gamma, beta, 1e-5)
+        ref = F.silu(ref) if silu else ref
+        ss = ops.gn_scale_shift(x0.to(DEV), gamma.to(DEV), beta.to(DEV), groups, 1e-5,
+                                src1=None if x1 is None else x1.to(DEV))
+        got = ops.gn_apply(xin.to(DEV), ss, silu)
+        _check(got, ref, tol_rel=2e-6, tol_abs=5e-6)
+
+
+@pytest.mark.parametrize("n,c,heads,l", [(2, 64, 8, 1024), (1, 512, 64, 1024), (3, 32, 4, 256), (1, 32, 2, 200),
+                                         (1, 64, 2, 64)])
+def test_attention(n, c, heads, l):
+    qkv = _t(31, (n, 3 * c, l), 1.5)
+    d = c // heads
+    q, k, v = [qkv[:, i * c:(i + 1) * c].view(n, heads, d, l).transpose(2, 3) for i in range(3)]
+    ref = F.scaled_dot_product_attention(q, k, v)  # [n, heads, l, d]
+    ref = ref.transpose(2, 3).reshape(n, c, l)
+    got = ops.attention(qkv.to(DEV), heads)
+    _check(got, ref, tol_rel=1e-5, tol_abs=1e-5)
+
+
+def test_attention_spiked_scores():
+    """Large score range: exercises the online-softmax rescale (one key dominates late in the sweep)."""
+    n, c, heads, l = 1, 16, 2, 1024
+    qkv = _t(32, (n, 3 * c, l))
+    qkv[:, :c, 5] *= 6.0
+    qkv[:, c:2 * c, 900] *= 8.0
+    d = c // heads
+    q, k, v = [qkv[:, i * c:(i + 1) * c].view(n, heads, d, l).transpose(2, 3).double() for i in range(3)]
+    ref = F.scaled_dot_product_attention(q, k, v).transpose(2, 3).reshape(n, c, l)
+    got = ops.attention(qkv.to(DEV), heads)
+    _check(got, ref.float(), tol_rel=1e-5, tol_abs=1e-5)
+
+
+def test_time_embedding_and_proj():
+    ch, dim = 64, 256
+    t = torch.tensor([0, 1, 499, 999, 37], dtype=torch.long)
+    w1, b1 = _t(41, (dim, ch), 1 / 8.0), _t(42, (dim,), 0.1)
+    w2, b2 = _t(43, (dim, dim), 1 / 16.0), _t(44, (dim,), 0.1)
+    emb = timestep_embedding(t, ch)
+    ref = F.silu(F.linear(F.silu(F.linear(emb, w1, b1)), w2, b2))
+    got = ops.time_embed(t.to(DEV), w1.to(DEV), b1.to(DEV), w2.to(DEV), b2.to(DEV))
+    _check(got, ref, tol_rel=2e-6, tol_abs=5e-6)
+    wp, bp = _t(45, (777, dim), 1 / 16.0), _t(46, (777,), 0.1)
+    _check(ops.linear(got, wp.to(DEV), bp.to(DEV)), F.linear(got.cpu(), wp, bp), tol_rel=2e-6, tol_abs=5e-6)
+
+
+def test_add_noise_bit_exact():
+    import drivescenegen_amd as d
+    o, s = OracleDDPMScheduler(), d.DDPMScheduler()
+    assert torch.equal(o.alphas_cumprod, s.alphas_cumprod)
+    x0, nz = _t(51, (4, 3, 64, 64)).clamp(-1, 1), _t(52, (4, 3, 64, 64))
+    t = torch.tensor([0, 3, 500, 999])
+    got = s.add_noise(x0.to(DEV), nz.to(DEV), t.to(DEV)).cpu()
+    assert torch.equal(got, o.add_noise(x0, nz, t))
+    # train.py:91 form: a single HWC image with timesteps=[100]
+    img = x0[0].permute(1, 2, 0).contiguous()
+    got = s.add_noise(img.to(DEV), nz[0].permute(1, 2, 0).contiguous().to(DEV), torch.LongTensor([100])).cpu()
+    assert torch.equal(got, o.add_noise(img, nz[0].permute(1, 2, 0).contiguous(), torch.LongTensor([100])))
+
+
+@pytest.mark.parametrize("steps", [10, 50, 750, 1000])
+def test_ddpm_step_bit_exact(steps):
+    import drivescenegen_amd as d
+    o, s = OracleDDPMScheduler(), d.DDPMScheduler()
+    o.set_timesteps(steps)
+    s.set_timesteps(steps)
+    assert torch.equal(o.timesteps, s.timesteps) and s.timesteps.dtype == torch.int64
+    x, e, z = _t(61, (2, 4, 32, 32)) * 1.3, _t(62, (2, 4, 32, 32)), _t(63, (2, 4, 32, 32))
+    for t in [int(s.timesteps[0]), int(s.timesteps[len(s.timesteps) // 2]), int(s.timesteps[-2]), 0]:
+        want = o.step(e, t, x, noise=z).prev_sample
+        got = s.step(e.to(DEV), t, x.to(DEV), variance_noise=z.to(DEV)).prev_sample.cpu()
+        assert torch.equal(got, want), (steps, t, max_abs(got, want))
+
+
+@pytest.mark.parametrize("steps", [10, 50, 100])
+def test_ddim_step_bit_exact(steps):
+    import drivescenegen_amd as d
+    o, s = OracleDDIMScheduler(), d.DDIMScheduler()
+    o.set_timesteps(steps)
+    s.set_timesteps(steps)
+    assert torch.equal(o.timesteps, s.timesteps)
+    x, e = _t(71, (2, 4, 32, 32)) * 1.3, _t(72, (2, 4, 32, 32))
+    for t in [int(v) for v in s.timesteps[[0, len(s.timesteps) // 2, -1]]]:
+        want = o.step(e, t, x).prev_sample
+        got = s.step(e.to(DEV), t, x.to(DEV)).prev_sample.cpu()
+        assert torch.equal(got, want), (steps, t, max_abs(got, want))
+
+
+def test_postprocess_modes():
+    x = _t(81, (2, 3, 16, 16)) * 1.2
+    ref = (x / 2 + 0.5).clamp(0, 1).permute(0, 2, 3, 1)
+    assert torch.equal(ops.postprocess(x.to(DEV), 0).cpu(), ref)
+    assert np.array_equal(ops.postprocess(x.to(DEV), 1).cpu().numpy(), (ref.numpy() * 255).round().astype("uint8"))
+    assert np.array_equal(ops.postprocess(x.to(DEV), 2).cpu().numpy(), (ref * 255.).numpy().astype(np.uint8))
+
+
+def test_errors_are_reported_not_fatal():
+    from drivescenegen_amd import _lib
+    x = torch.zeros(1, 8, 16, 16, device=DEV)
+    w = torch.zeros(8, 9, 8, device=DEV)
+    with pytest.raises(_lib.DsgError, match="stride"):
+        ops.conv2d_fused(x, w, stride=3)
+    with pytest.raises(_lib.DsgError, match="head_dim"):
+        ops.attention(torch.zeros(1, 3 * 24, 16, device=DEV), 2)

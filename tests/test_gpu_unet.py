@@ -1,0 +1,170 @@
+"""Whole-network and sampler parity of the HIP engine against the CPU oracle and the golden vectors."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+import drivescenegen_amd as d  # noqa: E402
+from drivescenegen_amd import synth  # noqa: E402
+from oracle.scheduler_oracle import OracleDDIMScheduler, OracleDDPMScheduler, oracle_pipeline  # noqa: E402
+from oracle.unet_oracle import OracleUNet2DModel  # noqa: E402
+from tests.common import CFG1, CFG2, CFG4_SMALL, DEFAULT3, max_abs, noisy_inputs, rel_l2, synth_weights  # noqa: E402
+
+DEV = "cuda"
+GOLD = np.load(os.path.join(os.path.dirname(__file__), "golden", "cfg1_golden.npz"))
+# fp32 single-forward tolerance
+TOL_REL, TOL_ABS = 1e-4, 2e-4
+
+
+def _pair(cfg):
+    net = synth_weights(d.UNet2DModel(**cfg)).to(DEV).eval().requires_grad_(False)
+    ora = synth_weights(OracleUNet2DModel(**cfg)).eval()
+    return net, ora
+
+
+def _assert_close(got, want, rel=TOL_REL, ab=TOL_ABS):
+    got = got.cpu()
+    assert torch.isfinite(got).all()
+    assert rel_l2(got, want) <= rel, rel_l2(got, want)
+    assert max_abs(got, want) <= ab * max(1.0, float(want.abs().max())), max_abs(got, want)
+
+
+@pytest.fixture(scope="module")
+def tiny():
+    return _pair(CFG1)
+
+
+def test_cfg1_forward_vs_golden_and_oracle(tiny):
+    net, ora = tiny
+    x = noisy_inputs(CFG1, 2)
+    assert abs(float(np.abs(x.numpy()).sum()) - float(GOLD["input_checksum"][0])) < 1e-3
+    for t in (0, 1, 499, 999):
+        got = net(x.to(DEV), t).sample
+        _assert_close(got, torch.from_numpy(GOLD[f"fwd_t{t}"]))
+        with torch.no_grad():
+            _assert_close(got, ora(x, t).sample)
+    tv = torch.tensor([17, 801])
+    got = net(x.to(DEV), tv.to(DEV), return_dict=False)[0]
+    _assert_close(got, torch.from_numpy(GOLD["fwd_tvec"]))
+    # 0-d tensor timestep, as the pipeline loop passes it
+    got = net(x.to(DEV), torch.tensor(499)).sample
+    _assert_close(got, torch.from_numpy(GOLD["fwd_t499"]))
+
+
+def test_cfg1_trajectories_vs_golden(tiny):
+    net, _ = tiny
+    sch = d.DDPMScheduler()
+    sch.set_timesteps(10)
+    img = torch.from_numpy(synth.normal(9, (2, 3, 64, 64))).to(DEV)
+    for i, t in enumerate(sch.timesteps):
+        eps = net(img, t).sample
+        z = torch.from_numpy(synth.normal(9, (2, 3, 64, 64), stream=100 + i)).to(DEV) if int(t) > 0 else None
+        img = sch.step(eps, t, img, variance_noise=z).prev_sample
+    _assert_close(img, torch.from_numpy(GOLD["ddpm10_final"]), rel=1e-3, ab=1e-3)  # free-running trajectory
+    dd = d.DDIMScheduler()
+    dd.set_timesteps(10)
+    img = torch.from_numpy(synth.normal(9, (2, 3, 64, 64))).to(DEV)
+    for t in dd.timesteps:
+        img = dd.step(net(img, t).sample, t, img).prev_sample
+    _assert_close(img, torch.from_numpy(GOLD["ddim10_final"]), rel=1e-3, ab=1e-3)
+
+
+def test_cfg1_pipeline_seeded_generator_matches_oracle(tiny):
+    """training_pipeline.py:26-32: CPU generator seed -> device-independent noise stream (App. A.4)."""
+    net, ora = tiny
+    pipe = d.DDPMPipeline(unet=net, scheduler=d.DDPMScheduler())
+    got = pipe(num_inference_steps=10, batch_size=2, generator=torch.manual_seed(14555), output_type="np.array",
+               return_dict=False)[0]
+    want = oracle_pipeline(ora, OracleDDPMScheduler(), batch_size=2, generator=torch.manual_seed(14555),
+                           num_inference_steps=10, output_type="np.array")
+    assert got.shape == (2, 64, 64, 3) and got.dtype == np.float32
+    assert float(np.abs(got - want).max()) <= 2e-3
+    # sharded sampling (no collective) reproduces the rows of the unsharded run
+    parts = [pipe(num_inference_steps=10, batch_size=2, generator=torch.manual_seed(14555), output_type="np.array",
+                  return_dict=False, shard=(r, 2))[0] for r in range(2)]
+    assert float(np.abs(np.concatenate(parts) - got).max()) <= 2e-3
+    # uint8 outputs: <= 1 LSB on <= 0.1 % of pixels
+    pil = pipe(num_inference_steps=10, batch_size=2, generator=torch.manual_seed(14555)).images
+    w8 = (want * 255).round().astype("uint8")
+    g8 = np.stack([np.asarray(im) for im in pil])
+    diff = np.abs(g8.astype(int) - w8.astype(int))
+    assert diff.max() <= 1 and (diff > 0).mean() <= 1e-3
+
+
+def test_cfg1_ddim_pipeline_matches_oracle(tiny):
+    net, ora = tiny
+    pipe = d.DDIMPipeline(unet=net, scheduler=d.DDIMScheduler())
+    got = pipe(num_inference_steps=10, batch_size=2, generator=torch.manual_seed(7), output_type="np.array").images
+    want = oracle_pipeline(ora, OracleDDIMScheduler(), batch_size=2, generator=torch.manual_seed(7),
+                           num_inference_steps=10, output_type="np.array", ddim=True)
+    assert float(np.abs(got - want).max()) <= 2e-3
+
+
+def test_attn_blocks_forward_vs_oracle():
+    """AttnDownBlock2D / AttnUpBlock2D (BASELINE configs[3]'s block types), spatially shrunk."""
+    net, ora = _pair(CFG4_SMALL)
+    x = noisy_inputs(CFG4_SMALL, 2)
+    t = torch.tensor([990, 10])
+    with torch.no_grad():
+        want = ora(x, t).sample
+    _assert_close(net(x.to(DEV), t.to(DEV)).sample, want)
+
+
+def test_default_unet_256_forward_vs_oracle():
+    """The train.py:39-57 network itself (56,574,595 params), B=1, 256x256x3."""
+    net, ora = _pair(DEFAULT3)
+    assert sum(p.numel() for p in net.parameters()) == 56_574_595
+    x = noisy_inputs(DEFAULT3, 1)
+    with torch.no_grad():
+        want = ora(x, 749).sample
+    got = net(x.to(DEV), 749).sample
+    _assert_close(got, want)
+
+
+def test_cfg2_full_size_batch_properties():
+    """BASELINE configs[1] shape (256x256x4, B=16): size-independent properties instead of a CPU oracle run --
+    batch rows are independent (row i of a B=16 call == the B=1 call on row i, bitwise: the kernels'
+    reduction order does not depend on batch) and one oracle spot-check on row 0."""
+    net, ora = _pair(CFG2)
+    x = noisy_inputs(CFG2, 16)
+    t = torch.full((16,), 500, dtype=torch.long)
+    t[1] = 20
+    out = net(x.to(DEV), t.to(DEV)).sample
+    assert torch.isfinite(out).all()
+    for i in (0, 1, 15):
+        one = net(x[i:i + 1].to(DEV), t[i:i + 1].to(DEV)).sample
+        assert torch.equal(one[0], out[i]), i
+    with torch.no_grad():
+        want = ora(x[:1], t[:1]).sample
+    _assert_close(out[:1], want)
+
+
+def test_checkpoint_roundtrip(tmp_path, tiny):
+    """save_pretrained / from_pretrained keep the App. A.5 folder layout (training_pipeline.py:107, generation.py:7)."""
+    net, _ = tiny
+    pipe = d.DDPMPipeline(unet=net, scheduler=d.DDPMScheduler())
+    pipe.save_pretrained(str(tmp_path))
+    for rel in ("model_index.json", "unet/config.json", "unet/diffusion_pytorch_model.bin",
+                "scheduler/scheduler_config.json"):
+        assert (tmp_path / rel).exists(), rel
+    re = d.DDPMPipeline.from_pretrained(str(tmp_path), variant="fp16").to(DEV)
+    re.unet.requires_grad_(False)
+    x = noisy_inputs(CFG1, 1).to(DEV)
+    assert torch.equal(re.unet(x, 3).sample, net(x, 3).sample)
+    u2 = d.UNet2DModel.from_pretrained(str(tmp_path), subfolder="unet")
+    assert list(u2.state_dict().keys()) == list(net.state_dict().keys())
+
+
+def test_param_update_is_picked_up(tiny):
+    net, _ = tiny
+    x = noisy_inputs(CFG1, 1).to(DEV)
+    a = net(x, 5).sample
+    with torch.no_grad():
+        net.conv_out.bias.add_(1.0)
+    b = net(x, 5).sample
+    assert torch.allclose(b - a, torch.ones_like(a), atol=1e-5)
+    with torch.no_grad():
+        net.conv_out.bias.sub_(1.0)

@@ -1,0 +1,105 @@
+"""Pins for the CPU oracle: structural, integer and constant known-answer values.
+
+The reference ships no tests and diffusers cannot be imported here, so these KATs
+(plus tests/golden/) are what pins the oracle."""
+import math
+
+import numpy as np
+import torch
+
+from oracle.scheduler_oracle import OracleDDIMScheduler, OracleDDPMScheduler, cosine_lr_lambda
+from oracle.unet_oracle import OracleUNet2DModel
+
+DEFAULT = dict(sample_size=(256, 256), in_channels=3, out_channels=3, layers_per_block=2,
+               block_out_channels=(64, 128, 256, 512), down_block_types=("DownBlock2D",) * 4,
+               up_block_types=("UpBlock2D",) * 4)
+
+
+def _count(m):
+    return sum(p.numel() for p in m.parameters())
+
+
+def test_param_counts():
+    assert _count(OracleUNet2DModel(**DEFAULT)) == 56_574_595
+    assert len(OracleUNet2DModel(**DEFAULT).state_dict()) == 282
+    tiny = dict(DEFAULT, sample_size=64, block_out_channels=(32, 64), down_block_types=("DownBlock2D",) * 2,
+                up_block_types=("UpBlock2D",) * 2)
+    assert _count(OracleUNet2DModel(**tiny)) == 919_043
+    assert _count(OracleUNet2DModel(**dict(DEFAULT, in_channels=4, out_channels=4))) == 56_575_748
+    assert _count(OracleUNet2DModel(**dict(DEFAULT, in_channels=8, out_channels=8))) == 56_580_360
+    cfg4 = dict(sample_size=512, in_channels=4, out_channels=4, layers_per_block=2,
+                block_out_channels=(64, 64, 128, 128, 256, 512),
+                down_block_types=("DownBlock2D",) * 4 + ("AttnDownBlock2D",) * 2,
+                up_block_types=("AttnUpBlock2D",) * 2 + ("UpBlock2D",) * 4)
+    assert _count(OracleUNet2DModel(**cfg4)) == 66_294_660
+
+
+def test_state_dict_keys():
+    keys = set(OracleUNet2DModel(**DEFAULT).state_dict().keys())
+    for k in ["conv_in.weight", "time_embedding.linear_1.bias", "down_blocks.0.resnets.1.time_emb_proj.weight",
+              "down_blocks.1.resnets.0.conv_shortcut.weight", "down_blocks.2.downsamplers.0.conv.bias",
+              "mid_block.attentions.0.group_norm.weight", "mid_block.attentions.0.to_q.weight",
+              "mid_block.attentions.0.to_out.0.bias", "up_blocks.0.resnets.2.conv_shortcut.bias",
+              "up_blocks.2.upsamplers.0.conv.weight", "conv_norm_out.bias", "conv_out.weight"]:
+        assert k in keys, k
+    assert "down_blocks.0.resnets.0.conv_shortcut.weight" not in keys
+    assert "down_blocks.3.downsamplers.0.conv.weight" not in keys
+    assert "up_blocks.3.upsamplers.0.conv.weight" not in keys
+    m = OracleUNet2DModel(**DEFAULT)
+    ups = [m.up_blocks[i].resnets[j].norm1.num_channels for i in range(4) for j in range(3)]
+    assert ups == [1024, 1024, 768, 768, 512, 384, 384, 256, 192, 192, 128, 128]
+
+
+def test_timestep_tables_bit_exact():
+    s = OracleDDPMScheduler()
+    for n, first, ratio in [(10, 900, 100), (50, 980, 20), (100, 990, 10), (750, 749, 1), (1000, 999, 1)]:
+        s.set_timesteps(n)
+        ts = s.timesteps.numpy()
+        assert ts.dtype == np.int64 and len(ts) == n
+        assert ts[0] == first and ts[-1] == 0
+        assert np.array_equal(ts, np.arange(n)[::-1] * ratio)
+        assert s._prev(int(ts[0])) == first - ratio
+
+
+def test_alphas_cumprod_hex():
+    ac = OracleDDPMScheduler().alphas_cumprod
+    assert ac.dtype == torch.float32
+    want = {0: "0x1.fff2e4p-1", 1: "0x1.ffe32cp-1", 100: "0x1.ca4ff8p-1", 499: "0x1.41e4bp-4",
+            749: "0x1.b729d2p-9", 980: "0x1.ef3e1cp-15", 990: "0x1.95c2d4p-15", 999: "0x1.528cccp-15"}
+    for i, hx in want.items():
+        assert float(ac[i]) == float.fromhex(hx), (i, float(ac[i]).hex(), hx)
+
+
+def test_ddpm_variances():
+    s = OracleDDPMScheduler()
+    ac = s.alphas_cumprod
+
+    def var(t, prev):
+        a_t, a_p = ac[t], ac[prev]
+        return float(torch.clamp((1 - a_p) / (1 - a_t) * (1 - a_t / a_p), min=1e-20))
+
+    assert math.isclose(var(749, 748), 0.015019242651760578, rel_tol=1e-6)
+    assert math.isclose(var(1, 0), 5.4534793889615685e-05, rel_tol=1e-6)
+    assert math.isclose(var(990, 980), 0.18068037927150726, rel_tol=1e-6)
+
+
+def test_lr_lambda():
+    vals = [cosine_lr_lambda(s, 500, 50_000) for s in (0, 1, 250, 500, 25_250, 50_000)]
+    assert vals[0] == 0.0 and vals[1] == 0.002 and vals[2] == 0.5 and vals[3] == 1.0
+    assert abs(vals[4] - 0.5) < 1e-12 and abs(vals[5]) < 1e-12
+
+
+def test_step_t0_has_no_noise_and_clamps():
+    s = OracleDDPMScheduler()
+    s.set_timesteps(750)
+    x = torch.full((1, 3, 4, 4), 5.0)
+    eps = torch.zeros_like(x)
+    g = torch.Generator().manual_seed(1)
+    st = g.get_state()
+    out = s.step(eps, 0, x, generator=g)
+    assert torch.equal(g.get_state(), st)  # no draw at t == 0
+    assert float(out.pred_original_sample.max()) == 1.0
+    d = OracleDDIMScheduler()
+    d.set_timesteps(50)
+    out = d.step(eps, 0, x)
+    assert torch.allclose(out.prev_sample, torch.ones_like(x))  # alpha_prev = 1 at the last step
