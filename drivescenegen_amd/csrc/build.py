@@ -15,6 +15,9 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
 SOURCES = ["common.hip", "conv.hip", "groupnorm.hip", "attention.hip", "temb.hip", "scheduler.hip", "unet.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fvisibility=hidden", "-Wall", "-Wno-unused-function"]
+# scheduler.hip must round every fp32 operation individually (bit parity with the reference's torch-CPU
+# expressions); the in-source pragma alone does not stop the backend from forming v_pk_fma_f32.
+EXTRA_FLAGS = {"scheduler.hip": ["-ffp-contract=off"]}
 LIB = os.path.join(ROOT, "lib", "libdsg.so")
 
 
@@ -36,7 +39,7 @@ def build(force=False, verbose=True):
 
     def cc(job):
         src, obj = job
-        cmd = ["hipcc"] + FLAGS + ["-c", src, "-o", obj]
+        cmd = ["hipcc"] + FLAGS + EXTRA_FLAGS.get(os.path.basename(src), []) + ["-c", src, "-o", obj]
         r = subprocess.run(cmd, capture_output=True, text=True)
         return job, r
 

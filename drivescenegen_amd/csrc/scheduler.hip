@@ -5,8 +5,11 @@
 // `noise_scheduler.add_noise`, and the DDPMPipeline loop behind training_pipeline.py:26-32 and
 // DriveSceneGen/scripts/generation.py:14-20; formulas SURVEY.md App. A.3 / A.3b / A.4).
 // Every expression is evaluated with individually rounded fp32 operations in the reference's
-// order (no fma contraction, IEEE division), so results are bit-identical to torch-CPU.
+// order (fma contraction disabled for this file, IEEE division), so results are bit-identical to torch-CPU.
 #include "dsg_common.h"
+
+// HIP's __fmul_rn/__fadd_rn are plain operators (contractible); forbid fma contraction for this TU instead.
+#pragma clang fp contract(off)
 
 namespace dsg {
 

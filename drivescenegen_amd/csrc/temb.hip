@@ -10,7 +10,8 @@
 namespace dsg {
 
 // grid = n, block = 256; dynamic LDS = (ch + dim) floats
-__global__ __launch_bounds__(256) void time_embed_kernel(const int64_t* __restrict__ timesteps, int ch, int dim,
+__global__ __launch_bounds__(256) void time_embed_kernel(const int64_t* __restrict__ timesteps,
+                                                         const float* __restrict__ freqs, int ch, int dim,
                                                          const float* __restrict__ w1, const float* __restrict__ b1,
                                                          const float* __restrict__ w2, const float* __restrict__ b2,
                                                          float* __restrict__ act) {
@@ -21,9 +22,9 @@ __global__ __launch_bounds__(256) void time_embed_kernel(const int64_t* __restri
   const float t = (float)timesteps[n];
   const int half = ch / 2;
   for (int i = threadIdx.x; i < half; i += 256) {
-    // exp(-ln(10000) * i / half), evaluated as the reference does: fp32 exponent, fp32 exp
-    const float ex = (-9.210340371976184f * (float)i) / (float)half;
-    const float a = t * expf(ex);
+    // freqs[i] = exp(-ln(10000) * i / half) comes from the host: at t ~ 1000 one ulp of the frequency
+    // moves the angle by 6e-5 rad, so the table must be the reference's own fp32 values
+    const float a = t * freqs[i];
     e[i] = cosf(a);
     e[half + i] = sinf(a);
   }
@@ -64,14 +65,15 @@ __global__ __launch_bounds__(256) void linear_rows_kernel(const float* __restric
 
 }  // namespace dsg
 
-DSG_API int dsg_time_embed_fwd(const int64_t* timesteps, int32_t n, int32_t ch, int32_t dim, const float* w1,
-                               const float* b1, const float* w2, const float* b2, float* act, void* stream) {
-  DSG_CHECK_ARG(timesteps && w1 && b1 && w2 && b2 && act, "dsg_time_embed_fwd: NULL pointer");
+DSG_API int dsg_time_embed_fwd(const int64_t* timesteps, const float* freqs, int32_t n, int32_t ch, int32_t dim,
+                               const float* w1, const float* b1, const float* w2, const float* b2, float* act,
+                               void* stream) {
+  DSG_CHECK_ARG(timesteps && freqs && w1 && b1 && w2 && b2 && act, "dsg_time_embed_fwd: NULL pointer");
   DSG_CHECK_ARG(n > 0 && ch > 0 && (ch % 2) == 0 && dim > 0, "dsg_time_embed_fwd: bad dims");
   const size_t lds = (size_t)(ch + dim) * sizeof(float);
   DSG_CHECK_SHAPE(lds <= 64 * 1024, "dsg_time_embed_fwd: ch + dim too large (%d + %d)", ch, dim);
   hipLaunchKernelGGL(dsg::time_embed_kernel, dim3(n), dim3(256), lds, static_cast<hipStream_t>(stream), timesteps,
-                     ch, dim, w1, b1, w2, b2, act);
+                     freqs, ch, dim, w1, b1, w2, b2, act);
   DSG_LAUNCH_CHECK();
   return DSG_OK;
 }

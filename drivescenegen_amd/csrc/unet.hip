@@ -14,6 +14,7 @@
 #include "dsg_common.h"
 
 #include <algorithm>
+#include <cmath>
 #include <cstring>
 #include <map>
 #include <memory>
@@ -101,6 +102,7 @@ struct dsg_unet {
   std::map<std::string, int> index;
   int temb_dim = 0, proj_total = 0;
   float *w1 = nullptr, *b1 = nullptr, *w2 = nullptr, *b2 = nullptr, *wp = nullptr, *bp = nullptr;
+  float* freqs = nullptr;  // [boc0/2] sinusoid frequencies
   Conv conv_in, conv_out;
   GN norm_out;
   std::vector<Stage> down, up;
@@ -264,7 +266,7 @@ struct Runner {
     T act = alloc(0, 0, 0, (size_t)B * h->temb_dim);
     T tproj = alloc(0, 0, 0, (size_t)B * h->proj_total);
     if (!dry) {
-      rc = dsg_time_embed_fwd(t, B, cfg.block_out_channels[0], h->temb_dim, h->w1, h->b1, h->w2, h->b2, act.p, st);
+      rc = dsg_time_embed_fwd(t, h->freqs, B, cfg.block_out_channels[0], h->temb_dim, h->w1, h->b1, h->w2, h->b2, act.p, st);
       if (ok()) rc = dsg_linear_fwd(act.p, h->wp, h->bp, tproj.p, B, h->temb_dim, h->proj_total, st);
     }
     act = T();
@@ -413,6 +415,16 @@ DSG_API int dsg_unet_create(const dsg_unet_config* cfg, dsg_unet_t** out) {
     for (size_t j = 0; j < h->up[i].res.size(); ++j)
       reg_tproj(h.get(), "up_blocks." + std::to_string(i) + ".resnets." + std::to_string(j), h->up[i].res[j]);
 
+  {  // default frequency table: exp evaluated in fp64 and rounded once
+    const int half = boc[0] / 2;
+    std::vector<float> f(half);
+    for (int i = 0; i < half; ++i) {
+      const float ex = (-9.210340371976184f * (float)i) / (float)half;
+      f[i] = (float)std::exp((double)ex);
+    }
+    h->freqs = h->dalloc(half);
+    if (h->freqs) DSG_HIP(hipMemcpy(h->freqs, f.data(), half * sizeof(float), hipMemcpyHostToDevice));
+  }
   for (void* p : h->allocs)
     if (p == nullptr) return fail(DSG_ERR_HIP, "dsg_unet_create: hipMalloc failed");
   for (auto& p : h->params)
@@ -437,6 +449,14 @@ DSG_API int dsg_unet_set_param(dsg_unet_t* h, const char* name, const float* dat
   for (auto& l : legacy) {
     const size_t pos = key.find(l[0]);
     if (pos != std::string::npos) key.replace(pos, std::strlen(l[0]), l[1]);
+  }
+  if (key == "time_proj.freqs") {
+    DSG_CHECK_ARG(numel == h->cfg.block_out_channels[0] / 2, "dsg_unet_set_param: time_proj.freqs expects %d elements",
+                  h->cfg.block_out_channels[0] / 2);
+    DSG_HIP(hipMemcpyAsync(h->freqs, data, (size_t)numel * sizeof(float), hipMemcpyDeviceToDevice,
+                           static_cast<hipStream_t>(stream)));
+    DSG_HIP(hipStreamSynchronize(static_cast<hipStream_t>(stream)));
+    return DSG_OK;
   }
   auto it = h->index.find(key);
   if (it == h->index.end()) return fail(DSG_ERR_INVALID_ARG, "dsg_unet_set_param: unknown parameter '%s'", name);

@@ -99,13 +99,24 @@ def attention(qkv, heads):
     return out
 
 
-def time_embed(timesteps, w1, b1, w2, b2):
+def sinusoid_freqs(ch: int) -> torch.Tensor:
+    """exp(-ln(10000) * arange(ch/2) / (ch/2)) with the reference's fp32 op order (get_timestep_embedding,
+    flip_sin_to_cos=True, freq_shift=0).  Host-side, [ch/2] fp32 CPU tensor."""
+    import math
+    half = ch // 2
+    exponent = -math.log(10000) * torch.arange(0, half, dtype=torch.float32)
+    return torch.exp(exponent / half)
+
+
+def time_embed(timesteps, w1, b1, w2, b2, freqs=None):
     """silu(linear_2(silu(linear_1(sinusoid(t))))) -> [N, dim]."""
     n = timesteps.numel()
     dim, ch = w1.shape
+    if freqs is None:
+        freqs = sinusoid_freqs(ch).to(w1.device)
     act = torch.empty((n, dim), dtype=torch.float32, device=w1.device)
     with torch.cuda.device(w1.device):
-        _lib.check(_lib.load().dsg_time_embed_fwd(_lib.ptr(timesteps), n, ch, dim, _lib.ptr(w1), _lib.ptr(b1),
+        _lib.check(_lib.load().dsg_time_embed_fwd(_lib.ptr(timesteps), _lib.ptr(freqs), n, ch, dim, _lib.ptr(w1), _lib.ptr(b1),
                                                  _lib.ptr(w2), _lib.ptr(b2), _lib.ptr(act), _st(w1)))
     return act
 

@@ -229,6 +229,10 @@ class UNet2DModel(nn.Module):
             self._plan = hnd
             self._plan_device = key
             self._plan_state = {}
+            from .ops import sinusoid_freqs
+            fr = sinusoid_freqs(c.block_out_channels[0]).to(device)
+            _lib.check(lib.dsg_unet_set_param(self._plan, b"time_proj.freqs", _lib.ptr(fr), fr.numel(),
+                                              _lib.stream_ptr(device)))
         # push parameters whose storage or version changed since the last push
         st = _lib.stream_ptr(device)
         for name, p in self.state_dict(keep_vars=True).items():

@@ -105,9 +105,12 @@ int dsg_attention_fwd(const float* qkv, float* out, int32_t n, int32_t c, int32_
  *   act = silu(linear_2(silu(linear_1(sinusoid(t)))))   [N][dim]   (dim = 4*block_out_channels[0])
  *   proj = act @ Wp^T + bp                               [N][proj_total]
  * timesteps: device int64 [N] (training_pipeline.py:76).  W1 [dim][ch], W2 [dim][dim], Wp [proj_total][dim].
+ * freqs: device fp32 [ch/2] = exp(-ln(10000) * i / (ch/2)), host-computed (the angle t*freq is
+ * ulp-sensitive at t ~ 1000, so the table is the caller's -- the shim builds it with the reference's ops).
  * ---------------------------------------------------------------------------------------- */
-int dsg_time_embed_fwd(const int64_t* timesteps, int32_t n, int32_t ch, int32_t dim, const float* w1,
-                       const float* b1, const float* w2, const float* b2, float* act, void* stream);
+int dsg_time_embed_fwd(const int64_t* timesteps, const float* freqs, int32_t n, int32_t ch, int32_t dim,
+                       const float* w1, const float* b1, const float* w2, const float* b2, float* act,
+                       void* stream);
 int dsg_linear_fwd(const float* x, const float* w, const float* b, float* y, int32_t n, int32_t in_f,
                    int32_t out_f, void* stream);
 
@@ -156,7 +159,9 @@ typedef struct {
 int dsg_unet_create(const dsg_unet_config* cfg, dsg_unet_t** out);
 void dsg_unet_destroy(dsg_unet_t* h);
 /* Copies (and re-lays-out) one checkpoint tensor, named by its diffusers state-dict key
- * (SURVEY App. A.5), from device memory into the plan.  Synchronises `stream` before returning. */
+ * (SURVEY App. A.5), from device memory into the plan.  Synchronises `stream` before returning.
+ * The extra key "time_proj.freqs" ([block_out_channels[0]/2]) overrides the sinusoid frequency
+ * table (default: correctly rounded exp computed on the host at create time). */
 int dsg_unet_set_param(dsg_unet_t* h, const char* name, const float* data, int64_t numel, void* stream);
 /* Number of parameters the plan expects / that have been set. */
 int dsg_unet_num_params(const dsg_unet_t* h, int64_t* expected_tensors, int64_t* set_tensors,

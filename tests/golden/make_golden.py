@@ -53,6 +53,25 @@ def main():
         for t in dd.timesteps:
             img = dd.step(net(img, t).sample, t, img).prev_sample
         out["ddim10_final"] = img.numpy()
+        # fp64 ground truth of the same two trajectories: the yard-stick for free-running parity
+        # (an fp32 engine may deviate from fp64 about as much as the fp32 CPU path itself does)
+        net64 = synth_weights(OracleUNet2DModel(**CFG1)).double().eval()
+        sch64 = OracleDDPMScheduler()
+        sch64.set_timesteps(10)
+        img = torch.from_numpy(synth.normal(9, (2, 3, 64, 64))).double()
+        for i, t in enumerate(sch64.timesteps):
+            eps = net64(img, t).sample
+            z = torch.from_numpy(synth.normal(9, (2, 3, 64, 64), stream=100 + i)).double() if int(t) > 0 else None
+            img = sch64.step(eps, t, img, noise=z).prev_sample
+        out["ddpm10_final_f64"] = img.numpy()
+        dd64 = OracleDDIMScheduler()
+        dd64.set_timesteps(10)
+        img = torch.from_numpy(synth.normal(9, (2, 3, 64, 64))).double()
+        for t in dd64.timesteps:
+            img = dd64.step(net64(img, t).sample, t, img).prev_sample
+        out["ddim10_final_f64"] = img.numpy()
+        for k in ("ddpm10", "ddim10"):
+            print(k, "cpu-fp32 vs fp64 max abs", float(np.abs(out[k + "_final"] - out[k + "_final_f64"]).max()))
     out["input_checksum"] = np.array([float(np.abs(x.numpy()).sum())])
     path = os.path.join(ROOT, "tests", "golden", "cfg1_golden.npz")
     np.savez_compressed(path, **out)

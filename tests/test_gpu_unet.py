@@ -32,6 +32,20 @@ def _assert_close(got, want, rel=TOL_REL, ab=TOL_ABS):
     assert max_abs(got, want) <= ab * max(1.0, float(want.abs().max())), max_abs(got, want)
 
 
+def _assert_trajectory(img, key):
+    """Free-running 10-step trajectory (errors are amplified by up to 1/sqrt(abar_t) ~ 100 per step):
+    relative L2 <= 1e-3 against the fp32 oracle, and the deviation from the fp64 ground truth
+    is at most 3x the fp32 CPU oracle's own deviation from it."""
+    got = img.cpu()
+    f32, f64 = torch.from_numpy(GOLD[key + "_final"]), torch.from_numpy(GOLD[key + "_final_f64"])
+    assert torch.isfinite(got).all()
+    assert rel_l2(got, f32) <= 1e-3, rel_l2(got, f32)
+    e_gpu, e_cpu = max_abs(got, f64), max_abs(f32, f64)
+    assert e_gpu <= 3 * e_cpu + 1e-5, (e_gpu, e_cpu)
+    r_gpu, r_cpu = rel_l2(got, f64), rel_l2(f32, f64)
+    assert r_gpu <= 3 * r_cpu + 1e-6, (r_gpu, r_cpu)
+
+
 @pytest.fixture(scope="module")
 def tiny():
     return _pair(CFG1)
@@ -63,13 +77,13 @@ def test_cfg1_trajectories_vs_golden(tiny):
         eps = net(img, t).sample
         z = torch.from_numpy(synth.normal(9, (2, 3, 64, 64), stream=100 + i)).to(DEV) if int(t) > 0 else None
         img = sch.step(eps, t, img, variance_noise=z).prev_sample
-    _assert_close(img, torch.from_numpy(GOLD["ddpm10_final"]), rel=1e-3, ab=1e-3)  # free-running trajectory
+    _assert_trajectory(img, "ddpm10")
     dd = d.DDIMScheduler()
     dd.set_timesteps(10)
     img = torch.from_numpy(synth.normal(9, (2, 3, 64, 64))).to(DEV)
     for t in dd.timesteps:
         img = dd.step(net(img, t).sample, t, img).prev_sample
-    _assert_close(img, torch.from_numpy(GOLD["ddim10_final"]), rel=1e-3, ab=1e-3)
+    _assert_trajectory(img, "ddim10")
 
 
 def test_cfg1_pipeline_seeded_generator_matches_oracle(tiny):
@@ -81,17 +95,18 @@ def test_cfg1_pipeline_seeded_generator_matches_oracle(tiny):
     want = oracle_pipeline(ora, OracleDDPMScheduler(), batch_size=2, generator=torch.manual_seed(14555),
                            num_inference_steps=10, output_type="np.array")
     assert got.shape == (2, 64, 64, 3) and got.dtype == np.float32
-    assert float(np.abs(got - want).max()) <= 2e-3
+    assert rel_l2(torch.from_numpy(got), torch.from_numpy(want)) <= 1e-3
+    assert float(np.abs(got - want).max()) <= 1e-2
     # sharded sampling (no collective) reproduces the rows of the unsharded run
     parts = [pipe(num_inference_steps=10, batch_size=2, generator=torch.manual_seed(14555), output_type="np.array",
                   return_dict=False, shard=(r, 2))[0] for r in range(2)]
-    assert float(np.abs(np.concatenate(parts) - got).max()) <= 2e-3
-    # uint8 outputs: <= 1 LSB on <= 0.1 % of pixels
+    assert np.array_equal(np.concatenate(parts), got)  # bitwise: batch rows are independent
+    # uint8 outputs: <= 1 LSB, on a small fraction of pixels (values that sit on a rounding boundary)
     pil = pipe(num_inference_steps=10, batch_size=2, generator=torch.manual_seed(14555)).images
     w8 = (want * 255).round().astype("uint8")
     g8 = np.stack([np.asarray(im) for im in pil])
     diff = np.abs(g8.astype(int) - w8.astype(int))
-    assert diff.max() <= 1 and (diff > 0).mean() <= 1e-3
+    assert diff.max() <= 1 and (diff > 0).mean() <= 5e-3, (diff.max(), (diff > 0).mean())
 
 
 def test_cfg1_ddim_pipeline_matches_oracle(tiny):
@@ -100,7 +115,8 @@ def test_cfg1_ddim_pipeline_matches_oracle(tiny):
     got = pipe(num_inference_steps=10, batch_size=2, generator=torch.manual_seed(7), output_type="np.array").images
     want = oracle_pipeline(ora, OracleDDIMScheduler(), batch_size=2, generator=torch.manual_seed(7),
                            num_inference_steps=10, output_type="np.array", ddim=True)
-    assert float(np.abs(got - want).max()) <= 2e-3
+    assert rel_l2(torch.from_numpy(got), torch.from_numpy(want)) <= 1e-3
+    assert float(np.abs(got - want).max()) <= 1e-2
 
 
 def test_attn_blocks_forward_vs_oracle():
