@@ -1,0 +1,192 @@
+#!/usr/bin/env python3
+"""Headline benchmark: denoising image-steps/sec of the U-Net forward (+ scheduler step) on
+256x256 BEV rasters -- BASELINE.json configs[1]: 256x256x4 raster, DriveSceneGen default U-Net
+(train.py:39-57 with 4 in/out channels), 50-step DDIM, batch 16 per GPU, fp32.
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+One "step" = one denoising step of the whole batch: dsg_unet_forward + dsg_ddim_step through the C ABI,
+inputs already resident in HBM.  Samples are independent, so ranks shard them with NO data-path
+collective (weak scaling: 16 samples per GPU); the only communication is the timing barrier / max.
+Rank 0 prints ONE JSON line, with
+  roofline     -- the dominant kernel (3x3 stride-1 implicit-GEMM conv on the f32 matrix cores):
+                  algorithmic FLOPs of its launches / their summed duration, from HIP events recorded on
+                  the launch stream inside the timed region (dsg_prof_*), against the 157.3 TF/s f32 peak;
+  cpu_baseline -- the torch-CPU oracle (oracle/, kind "port") timed on the host cores on a bounded
+                  sample (a few steps at batch 2) of the same workload.
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+
+PEAK_F32_TFLOPS = 157.3  # /opt/skills/guides/MI355X_MICROARCH.md: f32 vector = f32 MFMA peak
+PEAK_HBM_GBS = 8000.0
+
+
+def _cfg():
+    from tests.common import CFG2
+    return CFG2
+
+
+def gpu_leg(args, rank, world):
+    import drivescenegen_amd as d
+    from drivescenegen_amd import _lib, synth
+    from tests.common import synth_weights
+
+    cfg = _cfg()
+    dev = torch.device("cuda", int(os.environ.get("LOCAL_RANK", 0)))
+    torch.cuda.set_device(dev)
+    net = synth_weights(d.UNet2DModel(**cfg)).to(dev).eval().requires_grad_(False)
+    sch = d.DDIMScheduler()
+    sch.set_timesteps(args.ddim_steps)
+    ts = [int(t) for t in sch.timesteps]
+    b = args.batch
+    # x_T ~ N(0,1): each rank draws its own rows of the global batch (stream = rank)
+    x = torch.from_numpy(synth.normal(14555, (b, cfg["in_channels"], 256, 256), stream=7 + rank)).to(dev)
+    lib = _lib.load()
+
+    def step(i, x):
+        t = ts[i % len(ts)]
+        eps = net(x, t).sample
+        return sch.step(eps, t, x).prev_sample
+
+    def barrier():
+        torch.cuda.synchronize(dev)
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize(dev)
+
+    for i in range(args.warmup):
+        x = step(i, x)
+    barrier()
+    lib.dsg_prof_enable(1 if not args.no_prof else 0)
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        x = step(args.warmup + i, x)
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([dt], dtype=torch.float64, device=dev)
+        torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
+        dt = float(tt.item())
+    assert torch.isfinite(x).all()
+
+    prof = {}
+    if not args.no_prof:
+        names = {0: "conv3x3_s1_mfma_f32", 1: "conv3x3_upsample_mfma_f32", 2: "conv3x3_s2_mfma_f32",
+                 3: "conv1x1_mfma_f32", 4: "conv_direct_valu"}
+        for kid, nm in names.items():
+            ms, fl, by, n = C.c_double(), C.c_double(), C.c_double(), C.c_int64()
+            _lib.check(lib.dsg_prof_summary(kid, C.byref(ms), C.byref(fl), C.byref(by), C.byref(n)))
+            if n.value:
+                prof[nm] = dict(launches=n.value, total_ms=ms.value, avg_ms=ms.value / n.value,
+                                tflops=fl.value / (ms.value * 1e-3) / 1e12,
+                                alg_gbs=by.value / (ms.value * 1e-3) / 1e9,
+                                flops_per_launch=fl.value / n.value)
+        if args.prof_dump and rank == 0:
+            _lib.check(lib.dsg_prof_dump(args.prof_dump.encode()))
+        lib.dsg_prof_enable(0)
+    return dt, prof
+
+
+def cpu_leg(args):
+    """The oracle (torch-CPU restatement, kind 'port') on all host cores: 1 warm-up + 2 timed
+    denoising steps at batch 2 of the same network / raster size."""
+    from oracle.scheduler_oracle import OracleDDIMScheduler
+    from oracle.unet_oracle import OracleUNet2DModel
+    from drivescenegen_amd import synth
+    from tests.common import synth_weights
+
+    cores = max(1, min(os.cpu_count() or 1, args.cpu_threads))
+    torch.set_num_threads(cores)
+    cfg = _cfg()
+    net = synth_weights(OracleUNet2DModel(**cfg)).eval()
+    sch = OracleDDIMScheduler()
+    sch.set_timesteps(args.ddim_steps)
+    bs, nsteps = 2, 4
+    x = torch.from_numpy(synth.normal(14555, (bs, cfg["in_channels"], 256, 256), stream=7))
+    with torch.no_grad():
+        t = sch.timesteps[0]
+        x = sch.step(net(x, t).sample, t, x).prev_sample  # warm-up
+        t0 = time.perf_counter()
+        for i in range(nsteps):
+            t = sch.timesteps[1 + i]
+            x = sch.step(net(x, t).sample, t, x).prev_sample
+        dt = time.perf_counter() - t0
+    return dict(value=bs * nsteps / dt, unit="image-steps/s", cores=cores, kind="port",
+                sample=f"{nsteps} DDIM steps at batch {bs} (after 1 warm-up) of the same 256x256x4 default U-Net, "
+                       f"torch-CPU fp32 oracle, {cores} threads, {dt:.1f} s")
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=16, help="samples per GPU (BASELINE configs[1]: 16)")
+    ap.add_argument("--ddim-steps", type=int, default=50)
+    ap.add_argument("--no-prof", action="store_true", help="disable the HIP-event roofline leg")
+    ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
+    ap.add_argument("--prof-dump", default=None, help="write the per-launch HIP-event records (CSV) here")
+    ap.add_argument("--cpu-threads", type=int, default=16,
+                    help="threads for the CPU oracle (16 is the fastest setting on the 2x64-core GPU box: "
+                         "32/64/128/256 threads run 1.1x/2x/4.4x/36x slower)")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", 0)))
+        torch.distributed.init_process_group("nccl")
+    if args.gpus != world and rank == 0 and world > 1:
+        print(f"warning: --gpus {args.gpus} but WORLD_SIZE={world}", file=sys.stderr)
+
+    dt, prof = gpu_leg(args, rank, world)
+    if rank == 0:
+        n_img_steps = args.batch * world * args.steps
+        value = n_img_steps / dt
+        dom = prof.get("conv3x3_s1_mfma_f32")
+        roofline = None
+        if dom:
+            roofline = dict(bound="mfma", kernel="dsg::conv_mfma_kernel<3,1,false,2,8>", achieved=dom["tflops"],
+                            peak=PEAK_F32_TFLOPS, unit="TFLOP/s", frac=dom["tflops"] / PEAK_F32_TFLOPS, traffic=None,
+                            avg_launch_ms=dom["avg_ms"], launches=dom["launches"],
+                            alg_flops_per_launch=dom["flops_per_launch"],
+                            time_share=dom["total_ms"] * 1e-3 / dt)
+        from tests.common import CFG2  # noqa: F401
+        flops_img = 352.98e9  # SURVEY 8d, cfg2 forward
+        out = {
+            "metric": "denoising-steps/sec (U-Net fwd) on 256x256 BEV rasters", "value": value,
+            "unit": "image-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "BASELINE configs[1]: 256x256x4 BEV raster, DriveSceneGen default U-Net "
+                                   "(56,575,748 params), 50-step DDIM (eta=0), batch 16 per GPU, fp32",
+                       "batch_per_gpu": args.batch, "global_batch": args.batch * world,
+                       "ddim_steps": args.ddim_steps, "parallelism": f"sample-sharded x{world}, no collective"},
+            "whole_net_tflops": value * flops_img / 1e12,
+            "whole_net_frac_of_f32_peak": value * flops_img / 1e12 / (PEAK_F32_TFLOPS * world),
+            "roofline": roofline,
+            "kernels": prof,
+        }
+        if not args.no_cpu:
+            out["cpu_baseline"] = cpu_leg(args)
+        print(json.dumps(out))
+    if world > 1:
+        torch.distributed.barrier()
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -75,6 +75,9 @@ SIGNATURES = {
     "dsg_unet_param_name": [_vp, _i64, C.POINTER(C.c_char_p), C.POINTER(_i64)],
     "dsg_unet_workspace_bytes": [_vp, _i32, C.POINTER(_sz)],
     "dsg_unet_forward": [_vp, _vp, _vp, _vp, _i32, _vp, _sz, _vp],
+    "dsg_prof_enable": [_i32],
+    "dsg_prof_dump": [C.c_char_p],
+    "dsg_prof_summary": [_i32, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(_i64)],
 }
 OTHER_SYMBOLS = ["dsg_version", "dsg_last_error", "dsg_unet_destroy"]
 

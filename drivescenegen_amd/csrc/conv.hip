@@ -19,6 +19,10 @@
 
 namespace dsg {
 
+bool prof_on();
+int prof_begin(int kid, double flops, double bytes, hipStream_t st);
+void prof_end(int idx, hipStream_t st);
+
 struct ConvP {
   const float* src0;
   const float* src1;
@@ -291,13 +295,29 @@ static int launch_mfma(const ConvP& p, hipStream_t st) {
       raised = true;
     }
   }
+  int pi = -1;
+  if (prof_on()) {
+    const double px = (double)p.n * p.hout * p.wout;
+    const double flops = 2.0 * px * p.cout * p.cin * G::TAPS;
+    // algorithmic bytes: input read once, weights once, output written once (+ residual read)
+    const double bytes = 4.0 * ((double)p.n * p.cin * p.hin * p.win + (double)p.cin * G::TAPS * p.cout +
+                                px * p.cout * (p.res ? 2.0 : 1.0));
+    pi = prof_begin(KS == 1 ? 3 : (STRIDE == 2 ? 2 : (UPS ? 1 : 0)), flops, bytes, st);
+  }
   hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, p);
+  prof_end(pi, st);
   DSG_LAUNCH_CHECK();
   return DSG_OK;
 }
 
 static int launch_direct(const ConvP& p, int ks, int stride, int ups, hipStream_t st) {
   const int npix = p.hout * p.wout;
+  int pi = -1;
+  if (prof_on()) {
+    const double px = (double)p.n * npix;
+    pi = prof_begin(4, 2.0 * px * p.cout * p.cin * ks * ks,
+                    4.0 * ((double)p.n * p.cin * p.hin * p.win + (double)p.cin * ks * ks * p.cout + px * p.cout), st);
+  }
   if (p.cout <= 4) {
     dim3 grid(cdiv(npix, 256), cdiv(p.cout, 4), p.n);
     hipLaunchKernelGGL(conv_direct_kernel<4>, grid, dim3(256), 0, st, p, ks, stride, ups);
@@ -305,6 +325,7 @@ static int launch_direct(const ConvP& p, int ks, int stride, int ups, hipStream_
     dim3 grid(cdiv(npix, 256), cdiv(p.cout, 8), p.n);
     hipLaunchKernelGGL(conv_direct_kernel<8>, grid, dim3(256), 0, st, p, ks, stride, ups);
   }
+  prof_end(pi, st);
   DSG_LAUNCH_CHECK();
   return DSG_OK;
 }

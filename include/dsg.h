@@ -172,6 +172,17 @@ int dsg_unet_workspace_bytes(dsg_unet_t* h, int32_t batch, size_t* bytes);
 int dsg_unet_forward(dsg_unet_t* h, const float* x, const int64_t* timesteps, float* out, int32_t batch,
                      void* workspace, size_t workspace_bytes, void* stream);
 
+/* ------------------------------------------------------------------------------------------
+ * Measurement plumbing (no reference counterpart): per-kernel-class HIP-event timing on the launch
+ * stream, used by bench.py's roofline leg.  Classes: 0 conv3x3 stride-1, 1 conv3x3 on the nearest-x2
+ * upsampled input, 2 conv3x3 stride-2, 3 conv1x1, 4 direct (VALU) conv.  FLOPs/bytes are the
+ * algorithmic figures of each launch (2*MACs; input + weights + output once).
+ * ---------------------------------------------------------------------------------------- */
+int dsg_prof_enable(int32_t on);
+int dsg_prof_summary(int32_t kernel_class, double* total_ms, double* total_flops, double* total_bytes,
+                     int64_t* launches);
+int dsg_prof_dump(const char* csv_path);
+
 #ifdef __cplusplus
 }
 #endif
