@@ -76,6 +76,7 @@ SIGNATURES = {
     "dsg_unet_workspace_bytes": [_vp, _i32, C.POINTER(_sz)],
     "dsg_unet_forward": [_vp, _vp, _vp, _vp, _i32, _vp, _sz, _vp],
     "dsg_prof_enable": [_i32],
+    "dsg_set_tuning": [_i32, _i32],
     "dsg_prof_dump": [C.c_char_p],
     "dsg_prof_summary": [_i32, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(_i64)],
 }

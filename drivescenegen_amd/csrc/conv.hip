@@ -214,6 +214,207 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvP p) {
   }
 }
 
+
+__device__ __forceinline__ float silu_fast(float x) {
+  // x * 1/(1+exp(-x)) with v_exp_f32 / v_rcp_f32 (a few ulp; far inside the 1e-4 forward tolerance)
+  return x * __builtin_amdgcn_rcpf(1.0f + __expf(-x));
+}
+
+// v2: double-buffered LDS, ONE barrier per K-chunk.  While the wave issues the MFMAs of chunk q from
+// buffer q&1, the staging of chunk q+1 (GN-apply+SiLU, ds_write into the other buffer) and the global
+// loads of chunk q+2 are sliced into NP pieces and interleaved between the MFMA groups in program order,
+// so a single wave per SIMD keeps its matrix pipe busy (the f32 MFMA leaves 15 of 16 issue slots free).
+// The chunk body is branch-free (clamped loads, selects, stores into padded LDS slabs) so that it stays
+// ONE basic block and the scheduler can run the ds_reads ahead of the MFMAs that consume them.
+template <int KS, int STRIDE, bool UPS, int MT, int KC>
+__global__ __launch_bounds__(256, (KC == 4 && KS == 3 && STRIDE == 1) ? 3 : 2) void conv_mfma2_kernel(ConvP p) {
+  using G = ConvGeom<KS, STRIDE, KC>;
+  constexpr int TAPS = G::TAPS, PW = G::PW, PSZ = G::PSZ, XN = G::XN;
+  constexpr int BM = MT * 32;
+  constexpr int NE = (XN + 255) / 256;
+  constexpr int WN4 = KC * TAPS * BM / 4;
+  constexpr int NW = (WN4 + 255) / 256;
+  constexpr int WSZ = NW * 256 * 4;  // padded weight slab (floats)
+  constexpr int XSZ = NE * 256;      // padded patch (floats)
+  constexpr int BUF = WSZ + XSZ;
+  constexpr int NIT = (KC / 2) * TAPS;  // MFMA groups per chunk
+  constexpr int NP = NE + NW;           // staging pieces per chunk
+
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* SSl = smem + 2 * BUF;  // [cin][2]; identity when the conv has no prologue
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int half = lane >> 5;
+  const int l31 = lane & 31;
+
+  int bid = blockIdx.x;
+  const int tx = bid % p.tiles_x;
+  bid /= p.tiles_x;
+  const int ty = bid % p.tiles_y;
+  const int n = bid / p.tiles_y;
+  const int m0 = blockIdx.y * BM;
+  const int oy0 = ty * TH, ox0 = tx * TW;
+  const int iy0 = oy0 * STRIDE - KS / 2, ix0 = ox0 * STRIDE - KS / 2;
+  const int plane = p.hin * p.win;
+
+  int goff[NE];        // clamped gather offsets
+  unsigned valid = 0;  // bit i: element i is inside the image (else zero padding)
+#pragma unroll
+  for (int i = 0; i < NE; ++i) {
+    const int e = tid + 256 * i;
+    int off = 0;
+    if (e < XN) {
+      const int c = e / PSZ;
+      const int r = e - c * PSZ;
+      const int py = r / PW;
+      const int px = r - py * PW;
+      const int gy = iy0 + py, gx = ix0 + px;
+      if (gy >= 0 && gy < p.hc && gx >= 0 && gx < p.wc) {
+        const int sy = UPS ? (gy >> 1) : gy;
+        const int sx = UPS ? (gx >> 1) : gx;
+        off = c * plane + sy * p.win + sx;
+        valid |= 1u << i;
+      }
+    }
+    goff[i] = off;
+  }
+  const bool has_ss = p.ss != nullptr;
+  const bool do_silu = has_ss && p.silu;
+  {
+    const float* ssg = has_ss ? p.ss + (size_t)n * p.cin * 2 : nullptr;
+    for (int i = tid; i < 2 * p.cin; i += 256) SSl[i] = has_ss ? ssg[i] : ((i & 1) ? 0.f : 1.f);
+  }
+
+  float xr[NE];
+  float wr[NW][4];
+  const int nq = p.cin / KC;
+
+  auto src_of = [&](int q) -> const float* {
+    const int cb = q * KC;
+    return (cb < p.c0) ? p.src0 + ((size_t)n * p.c0 + cb) * plane
+                       : p.src1 + ((size_t)n * p.c1 + (cb - p.c0)) * plane;
+  };
+  auto w_of = [&](int q) -> const float* { return p.w + (size_t)q * (KC * TAPS) * p.cout + m0; };
+  // piece pc < NE: one patch element per thread; pc >= NE: one float4 of the weight slab
+  auto load_piece = [&](int pc, const float* sp, const float* wp) {
+    if (pc < NE) {
+      xr[pc] = sp[goff[pc]];
+    } else {
+      const int i = pc - NE;
+      const int idx = min(tid + 256 * i, WN4 - 1);
+      const int row = idx / (BM / 4);
+      const int c4 = idx - row * (BM / 4);
+      const float4 t4 = *reinterpret_cast<const float4*>(wp + (size_t)row * p.cout + c4 * 4);
+      wr[i][0] = t4.x; wr[i][1] = t4.y; wr[i][2] = t4.z; wr[i][3] = t4.w;
+    }
+  };
+  auto commit_piece = [&](int pc, int q, float* Wd, float* Xd) {
+    if (pc < NE) {
+      const int e = tid + 256 * pc;
+      const int c = q * KC + min(e / PSZ, KC - 1);
+      const float2 s2 = *reinterpret_cast<const float2*>(&SSl[2 * c]);
+      float v = xr[pc] * s2.x + s2.y;
+      const float sv = silu_fast(v);
+      v = do_silu ? sv : v;
+      v = ((valid >> pc) & 1u) ? v : 0.f;
+      Xd[e] = v;  // e >= XN lands in the slab's padding
+    } else {
+      const int i = pc - NE;
+      reinterpret_cast<float4*>(Wd)[tid + 256 * i] = make_float4(wr[i][0], wr[i][1], wr[i][2], wr[i][3]);
+    }
+  };
+
+  f32x16 acc[MT][2];
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[mt][nt][r] = 0.f;
+
+  // prologue: chunk 0 into buffer 0, chunk 1 into registers
+  {
+    const float* sp = src_of(0);
+    const float* wp = w_of(0);
+#pragma unroll
+    for (int pc = 0; pc < NP; ++pc) load_piece(pc, sp, wp);
+  }
+  __syncthreads();  // SSl visible
+#pragma unroll
+  for (int pc = 0; pc < NP; ++pc) commit_piece(pc, 0, smem, smem + WSZ);
+  {
+    const int q1 = min(1, nq - 1);
+    const float* sp = src_of(q1);
+    const float* wp = w_of(q1);
+#pragma unroll
+    for (int pc = 0; pc < NP; ++pc) load_piece(pc, sp, wp);
+  }
+  __syncthreads();
+
+  const int wl_off = half * (TAPS * BM) + l31;
+  const int xl_off = WSZ + half * PSZ + (wave * 2 * STRIDE) * PW + l31 * STRIDE;
+
+  for (int q = 0; q < nq; ++q) {
+    const float* cur = smem + (q & 1) * BUF;
+    float* nxt = smem + ((q & 1) ^ 1) * BUF;
+    const float* wl = cur + wl_off;
+    const float* xl = cur + xl_off;
+    const int qc = min(q + 1, nq - 1);  // chunk being committed (redundant, harmless work on the last one)
+    const int ql = min(q + 2, nq - 1);  // chunk being loaded
+    const float* spn = src_of(ql);
+    const float* wpn = w_of(ql);
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+#pragma unroll
+      for (int pc = 0; pc < NP; ++pc) {
+        if (pc * NIT / NP == it) {
+          commit_piece(pc, qc, nxt, nxt + WSZ);
+          load_piece(pc, spn, wpn);
+        }
+      }
+      const int cp = it / TAPS, tap = it % TAPS;
+      const int dy = tap / KS, dx = tap % KS;
+      float a[MT], b[2];
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) a[mt] = wl[(2 * cp) * (TAPS * BM) + tap * BM + mt * 32];
+#pragma unroll
+      for (int nt = 0; nt < 2; ++nt) b[nt] = xl[(2 * cp) * PSZ + (nt * STRIDE + dy) * PW + dx];
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt)
+          acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mt], b[nt], acc[mt][nt], 0, 0, 0);
+    }
+    __syncthreads();
+  }
+
+  const int x = ox0 + l31;
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int co = m0 + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+      float add = p.bias ? p.bias[co] : 0.f;
+      const bool has_t = p.temb != nullptr;
+      const float tv = has_t ? p.temb[(size_t)n * p.temb_stride + co] : 0.f;
+#pragma unroll
+      for (int nt = 0; nt < 2; ++nt) {
+        const int y = oy0 + wave * 2 + nt;
+        const size_t idx = (((size_t)n * p.cout + co) * p.hout + y) * p.wout + x;
+        float v = acc[mt][nt][r] + add;
+        if (has_t) v = v + tv;
+        if (p.res) v = v + p.res[idx];
+        p.dst[idx] = v;
+      }
+    }
+  }
+}
+
+static int g_conv_variant = 2;  // 1: single-buffer two-barrier kernel, 2: double-buffer interleaved kernel
+static int g_conv_kc = 0;       // K-chunk of the 3x3 stride-1 v2 kernel: 4 | 8 | 0 = by grid size (measured, r01)
+
 // General VALU fallback: any channel counts / sizes (conv_in with Cin = 3/4/8, conv_out with
 // Cout = 3/4/8, odd spatial sizes).  One thread per output pixel, COB couts per thread.
 template <int COB>
@@ -310,6 +511,34 @@ static int launch_mfma(const ConvP& p, hipStream_t st) {
   return DSG_OK;
 }
 
+template <int KS, int STRIDE, bool UPS, int MT, int KC>
+static int launch_mfma2(const ConvP& p, hipStream_t st) {
+  using G = ConvGeom<KS, STRIDE, KC>;
+  constexpr int NE = (G::XN + 255) / 256;
+  constexpr int NW = (KC * G::TAPS * MT * 32 / 4 + 255) / 256;
+  const size_t lds = (size_t)(2 * (NW * 1024 + NE * 256) + 2 * p.cin) * sizeof(float);
+  dim3 grid(p.tiles_x * p.tiles_y * p.n, p.cout / (MT * 32));
+  auto kern = conv_mfma2_kernel<KS, STRIDE, UPS, MT, KC>;
+  static bool raised = false;
+  if (!raised) {
+    DSG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                160 * 1024));
+    raised = true;
+  }
+  int pi = -1;
+  if (prof_on()) {
+    const double px = (double)p.n * p.hout * p.wout;
+    const double flops = 2.0 * px * p.cout * p.cin * G::TAPS;
+    const double bytes = 4.0 * ((double)p.n * p.cin * p.hin * p.win + (double)p.cin * G::TAPS * p.cout +
+                                px * p.cout * (p.res ? 2.0 : 1.0));
+    pi = prof_begin(KS == 1 ? 3 : (STRIDE == 2 ? 2 : (UPS ? 1 : 0)), flops, bytes, st);
+  }
+  hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, p);
+  prof_end(pi, st);
+  DSG_LAUNCH_CHECK();
+  return DSG_OK;
+}
+
 static int launch_direct(const ConvP& p, int ks, int stride, int ups, hipStream_t st) {
   const int npix = p.hout * p.wout;
   int pi = -1;
@@ -358,6 +587,22 @@ int conv2d_fwd_impl(const dsg_conv_args* a, hipStream_t st, int force_direct) {
   const int s = a->stride, k = a->ksize, u = a->upsample;
   if (!force_direct && tile_ok) {
     const bool mt2 = (p.cout % 64 == 0);
+    if (g_conv_variant == 2 && p.cin <= 2048) {
+      if (k == 3 && p.cin % 8 == 0 && p.c0 % 8 == 0) {
+        // KC=4 keeps 3 workgroups per CU (30 KB LDS, 127 VGPRs): better when the grid has >= 3 per CU to give;
+        // KC=8 (2 per CU, half the barriers) wins on the low-resolution levels.
+        const int nblk = p.tiles_x * p.tiles_y * p.n * (p.cout / 64);
+        const bool kc4 = mt2 && (g_conv_kc == 4 || (g_conv_kc == 0 && nblk >= 768));
+        if (s == 1 && !u && kc4) return launch_mfma2<3, 1, false, 2, 4>(p, st);
+        if (s == 1 && u && kc4) return launch_mfma2<3, 1, true, 2, 4>(p, st);
+        if (s == 1 && !u) return mt2 ? launch_mfma2<3, 1, false, 2, 8>(p, st) : launch_mfma2<3, 1, false, 1, 8>(p, st);
+        if (s == 1 && u) return mt2 ? launch_mfma2<3, 1, true, 2, 8>(p, st) : launch_mfma2<3, 1, true, 1, 8>(p, st);
+        if (s == 2 && p.cin % 4 == 0 && p.c0 % 4 == 0)
+          return mt2 ? launch_mfma2<3, 2, false, 2, 4>(p, st) : launch_mfma2<3, 2, false, 1, 4>(p, st);
+      }
+      if (k == 1 && s == 1 && !u && p.cin % 16 == 0 && p.c0 % 16 == 0)
+        return mt2 ? launch_mfma2<1, 1, false, 2, 16>(p, st) : launch_mfma2<1, 1, false, 1, 16>(p, st);
+    }
     if (k == 3 && p.cin % 8 == 0 && p.c0 % 8 == 0) {
       if (s == 1 && !u) return mt2 ? launch_mfma<3, 1, false, 2, 8>(p, st) : launch_mfma<3, 1, false, 1, 8>(p, st);
       if (s == 1 && u) return mt2 ? launch_mfma<3, 1, true, 2, 8>(p, st) : launch_mfma<3, 1, true, 1, 8>(p, st);
@@ -374,6 +619,19 @@ int conv2d_fwd_impl(const dsg_conv_args* a, hipStream_t st, int force_direct) {
 }
 
 }  // namespace dsg
+
+// Tuning / A-B switch (key 0: conv kernel variant 1|2).  Not part of the reference surface.
+DSG_API int dsg_set_tuning(int32_t key, int32_t value) {
+  if (key == 0 && (value == 1 || value == 2)) {
+    dsg::g_conv_variant = value;
+    return DSG_OK;
+  }
+  if (key == 1 && (value == 0 || value == 4 || value == 8)) {
+    dsg::g_conv_kc = value;
+    return DSG_OK;
+  }
+  return dsg::fail(DSG_ERR_INVALID_ARG, "dsg_set_tuning: unknown key/value %d/%d", key, value);
+}
 
 DSG_API int dsg_conv2d_fwd(const dsg_conv_args* a, void* stream) {
   return dsg::conv2d_fwd_impl(a, static_cast<hipStream_t>(stream), 0);

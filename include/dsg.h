@@ -182,6 +182,8 @@ int dsg_prof_enable(int32_t on);
 int dsg_prof_summary(int32_t kernel_class, double* total_ms, double* total_flops, double* total_bytes,
                      int64_t* launches);
 int dsg_prof_dump(const char* csv_path);
+/* A/B switch for kernel variants (key 0: conv kernel 1 = single LDS buffer, 2 = double-buffered, default). */
+int dsg_set_tuning(int32_t key, int32_t value);
 
 #ifdef __cplusplus
 }
