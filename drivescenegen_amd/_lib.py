@@ -32,10 +32,11 @@ class ConvArgs(C.Structure):
         ("c0", C.c_int32), ("c1", C.c_int32),
         ("n", C.c_int32), ("hin", C.c_int32), ("win", C.c_int32),
         ("upsample", C.c_int32), ("ksize", C.c_int32), ("stride", C.c_int32), ("cout", C.c_int32),
-        ("weight", C.c_void_p), ("bias", C.c_void_p), ("gn_scale_shift", C.c_void_p),
+        ("weight", C.c_void_p), ("weight_cout_stride", C.c_int32),
+        ("bias", C.c_void_p), ("gn_scale_shift", C.c_void_p),
         ("silu", C.c_int32),
         ("temb", C.c_void_p), ("temb_stride", C.c_int32),
-        ("residual", C.c_void_p), ("dst", C.c_void_p),
+        ("residual", C.c_void_p), ("dst", C.c_void_p), ("pool2", C.c_int32),
     ]
 
 
@@ -59,6 +60,7 @@ SIGNATURES = {
     "dsg_conv2d_fwd": [C.POINTER(ConvArgs), _vp],
     "dsg_conv2d_fwd_direct": [C.POINTER(ConvArgs), _vp],
     "dsg_conv_weight_relayout": [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp],
+    "dsg_conv_weight_relayout_dgrad": [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp],
     "dsg_gn_channel_stats": [_vp, _i32, _vp, _i32, _i32, _i32, _vp, _vp],
     "dsg_gn_finalize": [_vp, _vp, _vp, _i32, _i32, _i32, _i32, _f32, _vp, _vp],
     "dsg_gn_apply": [_vp, _vp, _i32, _vp, _i32, _i32, _i32, _vp],

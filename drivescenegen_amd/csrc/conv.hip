@@ -2,7 +2,9 @@
 //
 // Replaces every nn.Conv2d / attention nn.Linear call of diffusers' UNet2DModel.forward as used by
 // DriveSceneGen (reference: DriveSceneGen/scripts/train.py:39-57 builds the net,
-// DriveSceneGen/pipeline/training_pipeline.py:84 runs it; semantics SURVEY.md App. A.2).
+// DriveSceneGen/pipeline/training_pipeline.py:84 runs it; semantics SURVEY.md App. A.2), and -- with
+// transposed/flipped weights -- the data-gradient convolutions of the backward pass
+// (training_pipeline.py:86 `accelerator.backward(loss)`).
 //
 // GEMM view:  D[cout][pixel] = sum_{cin,tap} W[cin][tap][cout] * X[cin][pixel + tap]
 //   A operand = weights  (M = cout)    -> v_mfma_f32_32x32x2_f32, exact f32 (fmaf chain in k order)
@@ -10,10 +12,17 @@
 // A workgroup (4 waves) owns BM = 32*MT couts x (8 rows x 32 cols) output pixels of one image.
 // Per K-chunk of KC input channels it stages, through registers, the weight slab [KC][taps][BM] and
 // the input halo patch [KC][PH][PW] into LDS -- GroupNorm-apply + SiLU of the previous norm is folded
-// into that staging pass, the [x || skip] concat and the nearest-x2 upsample into its gather -- then
-// all 9 taps are served from the single patch (no im2col blow-up).  The next chunk's global loads are
-// issued before the MFMA phase and written to LDS after it (issue-early / write-late).
-// Epilogue: + bias (+ time-embedding column) (+ residual), 128-B row stores.
+// into that staging pass; the [x || skip] concat, the nearest-x2 upsample (gather mode 1) and the
+// zero-stuffed x2 upsample of a stride-2 conv's data gradient (gather mode 2) into its gather -- then all
+// 9 taps are served from the single patch (no im2col blow-up).
+//
+// Pipeline: double-buffered LDS, ONE barrier per K-chunk.  While the wave issues the MFMAs of chunk q
+// from buffer q&1, the staging of chunk q+1 (ds_write into the other buffer) and the global loads of
+// chunk q+2 are sliced into NP pieces and interleaved between the MFMA groups in program order (the f32
+// MFMA leaves 15 of 16 issue slots free).  The chunk body is branch-free (clamped loads, selects, stores
+// into padded LDS slabs) so it stays ONE basic block and the scheduler runs ds_reads ahead of the MFMAs.
+// Epilogue: + bias (+ time-embedding column) (+ residual), 128-B row stores; optional 2x2 sum-pool
+// (the adjoint of the nearest-x2 upsample).
 #include "dsg_common.h"
 #include <algorithm>
 
@@ -28,9 +37,10 @@ struct ConvP {
   const float* src1;
   int c0, c1, cin;
   int n, hin, win;  // source dims
-  int hc, wc;       // conv-input dims (after optional upsample)
-  int hout, wout;
-  int cout;
+  int hc, wc;       // conv-input dims (after the optional x2 gather mode)
+  int hout, wout;   // conv output dims (before the optional pool)
+  int cout;         // real output channels
+  int wstride;      // row stride of the weight matrix (>= cout, multiple of 32 for the MFMA path)
   const float* w;
   const float* bias;
   const float* ss;
@@ -39,6 +49,7 @@ struct ConvP {
   int temb_stride;
   const float* res;
   float* dst;
+  int pool;  // 1: 2x2 sum-pool in the epilogue; dst is [N, cout, hout/2, wout/2]
   int tiles_x, tiles_y;
 };
 
@@ -52,196 +63,31 @@ struct ConvGeom {
   static constexpr int PW = (TW - 1) * STRIDE + KS;
   static constexpr int PSZ = PH * PW;
   static constexpr int XN = KC * PSZ;
-  static constexpr int XN_PAD = (XN + 3) & ~3;
 };
-
-template <int KS, int STRIDE, bool UPS, int MT, int KC>
-__global__ __launch_bounds__(256) void conv_mfma_kernel(ConvP p) {
-  using G = ConvGeom<KS, STRIDE, KC>;
-  constexpr int TAPS = G::TAPS, PH = G::PH, PW = G::PW, PSZ = G::PSZ, XN = G::XN;
-  constexpr int BM = MT * 32;
-  constexpr int NE = (XN + 255) / 256;
-  constexpr int WN4 = KC * TAPS * BM / 4;
-  constexpr int NW = (WN4 + 255) / 256;
-  (void)PH;
-
-  extern __shared__ __attribute__((aligned(16))) float smem[];
-  float* Wl = smem;                    // [KC][TAPS][BM]
-  float* Xl = smem + KC * TAPS * BM;   // [KC][PH][PW]
-  float* SSl = Xl + G::XN_PAD;         // [cin][2] (only when p.ss)
-
-  const int tid = threadIdx.x;
-  const int lane = tid & 63;
-  const int wave = tid >> 6;
-  const int half = lane >> 5;
-  const int l31 = lane & 31;
-
-  int bid = blockIdx.x;
-  const int tx = bid % p.tiles_x;
-  bid /= p.tiles_x;
-  const int ty = bid % p.tiles_y;
-  const int n = bid / p.tiles_y;
-  const int m0 = blockIdx.y * BM;
-  const int oy0 = ty * TH, ox0 = tx * TW;
-  const int iy0 = oy0 * STRIDE - KS / 2, ix0 = ox0 * STRIDE - KS / 2;
-  const int plane = p.hin * p.win;
-
-  // Per-thread gather offsets (relative to the chunk's first channel plane); -1 = zero padding.
-  int goff[NE];
-#pragma unroll
-  for (int i = 0; i < NE; ++i) {
-    const int e = tid + 256 * i;
-    int off = -1;
-    if (e < XN) {
-      const int c = e / PSZ;
-      const int r = e - c * PSZ;
-      const int py = r / PW;
-      const int px = r - py * PW;
-      const int gy = iy0 + py, gx = ix0 + px;
-      if (gy >= 0 && gy < p.hc && gx >= 0 && gx < p.wc) {
-        const int sy = UPS ? (gy >> 1) : gy;
-        const int sx = UPS ? (gx >> 1) : gx;
-        off = c * plane + sy * p.win + sx;
-      }
-    }
-    goff[i] = off;
-  }
-
-  if (p.ss) {
-    const float* ssg = p.ss + (size_t)n * p.cin * 2;
-    for (int i = tid; i < 2 * p.cin; i += 256) SSl[i] = ssg[i];
-  }
-
-  float xr[NE];
-  float wr[NW][4];  // scalar array: a float4[] here is not promoted to registers by hipcc
-
-  auto prefetch = [&](int q) {
-    const int cb = q * KC;
-    const float* sp = (cb < p.c0) ? p.src0 + ((size_t)n * p.c0 + cb) * plane
-                                  : p.src1 + ((size_t)n * p.c1 + (cb - p.c0)) * plane;
-#pragma unroll
-    for (int i = 0; i < NE; ++i) xr[i] = goff[i] >= 0 ? sp[goff[i]] : 0.f;
-    const float* wp = p.w + (size_t)q * (KC * TAPS) * p.cout + m0;
-#pragma unroll
-    for (int i = 0; i < NW; ++i) {
-      // clamped, unconditional load keeps wr[] in registers (a predicated partial fill goes to scratch)
-      const int idx = min(tid + 256 * i, WN4 - 1);
-      const int row = idx / (BM / 4);
-      const int c4 = idx - row * (BM / 4);
-      const float4 t4 = *reinterpret_cast<const float4*>(wp + (size_t)row * p.cout + c4 * 4);
-      wr[i][0] = t4.x; wr[i][1] = t4.y; wr[i][2] = t4.z; wr[i][3] = t4.w;
-    }
-  };
-
-  auto commit = [&](int q) {
-#pragma unroll
-    for (int i = 0; i < NE; ++i) {
-      const int e = tid + 256 * i;
-      if (e < XN) {
-        float v = xr[i];
-        if (p.ss && goff[i] >= 0) {
-          const int c = q * KC + e / PSZ;
-          v = v * SSl[2 * c] + SSl[2 * c + 1];
-          if (p.silu) v = silu_f(v);
-        }
-        Xl[e] = v;
-      }
-    }
-#pragma unroll
-    for (int i = 0; i < NW; ++i) {
-      const int idx = tid + 256 * i;
-      if (idx < WN4) reinterpret_cast<float4*>(Wl)[idx] = make_float4(wr[i][0], wr[i][1], wr[i][2], wr[i][3]);
-    }
-  };
-
-  f32x16 acc[MT][2];
-#pragma unroll
-  for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-    for (int nt = 0; nt < 2; ++nt)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[mt][nt][r] = 0.f;
-
-  const float* wl = Wl + half * (TAPS * BM) + l31;
-  const float* xl = Xl + half * PSZ + (wave * 2 * STRIDE) * PW + l31 * STRIDE;
-
-  const int nq = p.cin / KC;
-  prefetch(0);
-  for (int q = 0; q < nq; ++q) {
-    __syncthreads();  // previous MFMA phase has finished reading LDS (and SSl is visible)
-    commit(q);
-    __syncthreads();
-    if (q + 1 < nq) prefetch(q + 1);
-#pragma unroll
-    for (int cp = 0; cp < KC / 2; ++cp) {
-#pragma unroll
-      for (int tap = 0; tap < TAPS; ++tap) {
-        const int dy = tap / KS, dx = tap % KS;
-        float a[MT], b[2];
-#pragma unroll
-        for (int mt = 0; mt < MT; ++mt) a[mt] = wl[(2 * cp) * (TAPS * BM) + tap * BM + mt * 32];
-#pragma unroll
-        for (int nt = 0; nt < 2; ++nt) b[nt] = xl[(2 * cp) * PSZ + (nt * STRIDE + dy) * PW + dx];
-#pragma unroll
-        for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-          for (int nt = 0; nt < 2; ++nt)
-            acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mt], b[nt], acc[mt][nt], 0, 0, 0);
-      }
-    }
-  }
-
-  // Epilogue. C/D layout of the 32x32 tile: col (pixel) = lane&31, row (cout) = (r&3) + 8*(r>>2) + 4*half.
-  const int x = ox0 + l31;
-#pragma unroll
-  for (int mt = 0; mt < MT; ++mt) {
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int co = m0 + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-      float add = p.bias ? p.bias[co] : 0.f;
-      const bool has_t = p.temb != nullptr;
-      const float tv = has_t ? p.temb[(size_t)n * p.temb_stride + co] : 0.f;
-#pragma unroll
-      for (int nt = 0; nt < 2; ++nt) {
-        const int y = oy0 + wave * 2 + nt;
-        const size_t idx = (((size_t)n * p.cout + co) * p.hout + y) * p.wout + x;
-        float v = acc[mt][nt][r] + add;
-        if (has_t) v = v + tv;
-        if (p.res) v = v + p.res[idx];
-        p.dst[idx] = v;
-      }
-    }
-  }
-}
-
 
 __device__ __forceinline__ float silu_fast(float x) {
   // x * 1/(1+exp(-x)) with v_exp_f32 / v_rcp_f32 (a few ulp; far inside the 1e-4 forward tolerance)
   return x * __builtin_amdgcn_rcpf(1.0f + __expf(-x));
 }
 
-// v2: double-buffered LDS, ONE barrier per K-chunk.  While the wave issues the MFMAs of chunk q from
-// buffer q&1, the staging of chunk q+1 (GN-apply+SiLU, ds_write into the other buffer) and the global
-// loads of chunk q+2 are sliced into NP pieces and interleaved between the MFMA groups in program order,
-// so a single wave per SIMD keeps its matrix pipe busy (the f32 MFMA leaves 15 of 16 issue slots free).
-// The chunk body is branch-free (clamped loads, selects, stores into padded LDS slabs) so that it stays
-// ONE basic block and the scheduler can run the ds_reads ahead of the MFMAs that consume them.
-template <int KS, int STRIDE, bool UPS, int MT, int KC>
-__global__ __launch_bounds__(256, (KC == 4 && KS == 3 && STRIDE == 1) ? 3 : 2) void conv_mfma2_kernel(ConvP p) {
+// GM: gather mode 0 plain, 1 nearest x2 (source pixel [y>>1][x>>1]), 2 zero-stuffed x2 (source pixel
+// [y/2][x/2] at even (y, x), zero elsewhere)
+template <int KS, int STRIDE, int GM, int MT, int KC>
+__global__ __launch_bounds__(256, (KC == 4 && KS == 3 && STRIDE == 1) ? 3 : 2) void conv_mfma_kernel(ConvP p) {
   using G = ConvGeom<KS, STRIDE, KC>;
   constexpr int TAPS = G::TAPS, PW = G::PW, PSZ = G::PSZ, XN = G::XN;
   constexpr int BM = MT * 32;
-  constexpr int NE = (XN + 255) / 256;
+  constexpr int TPC = 256 / KC;               // threads staging one channel of the patch
+  constexpr int NE = (PSZ + TPC - 1) / TPC;   // patch elements per thread per chunk (all of ONE channel)
   constexpr int WN4 = KC * TAPS * BM / 4;
   constexpr int NW = (WN4 + 255) / 256;
-  constexpr int WSZ = NW * 256 * 4;  // padded weight slab (floats)
-  constexpr int XSZ = NE * 256;      // padded patch (floats)
+  constexpr int WSZ = NW * 256 * 4;           // padded weight slab (floats)
+  constexpr int XSZ = (XN + 4 + 3) & ~3;      // patch + one dump slot for masked-off lanes
   constexpr int BUF = WSZ + XSZ;
-  constexpr int NIT = (KC / 2) * TAPS;  // MFMA groups per chunk
-  constexpr int NP = NE + NW;           // staging pieces per chunk
+  constexpr int NIT = (KC / 2) * TAPS;        // MFMA groups per chunk
+  constexpr int NP = NE + NW;                 // staging pieces per chunk
 
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  float* SSl = smem + 2 * BUF;  // [cin][2]; identity when the conv has no prologue
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -258,47 +104,54 @@ __global__ __launch_bounds__(256, (KC == 4 && KS == 3 && STRIDE == 1) ? 3 : 2) v
   const int oy0 = ty * TH, ox0 = tx * TW;
   const int iy0 = oy0 * STRIDE - KS / 2, ix0 = ox0 * STRIDE - KS / 2;
   const int plane = p.hin * p.win;
+  const int nq = (p.cin + KC - 1) / KC;
 
-  int goff[NE];        // clamped gather offsets
-  unsigned valid = 0;  // bit i: element i is inside the image (else zero padding)
+  // This thread stages channel `tc` of every chunk: NE positions of its halo patch.
+  const int tc = tid / TPC;
+  const int tr = tid - tc * TPC;
+  int goff[NE];        // clamped gather offsets within the channel plane
+  int loff[NE];        // LDS offset in the patch slab (dump slot when the position is past the patch)
+  unsigned valid = 0;  // bit i: position i is inside the image (else zero padding)
 #pragma unroll
   for (int i = 0; i < NE; ++i) {
-    const int e = tid + 256 * i;
+    const int r = tr + TPC * i;
     int off = 0;
-    if (e < XN) {
-      const int c = e / PSZ;
-      const int r = e - c * PSZ;
+    if (r < PSZ) {
       const int py = r / PW;
       const int px = r - py * PW;
       const int gy = iy0 + py, gx = ix0 + px;
-      if (gy >= 0 && gy < p.hc && gx >= 0 && gx < p.wc) {
-        const int sy = UPS ? (gy >> 1) : gy;
-        const int sx = UPS ? (gx >> 1) : gx;
-        off = c * plane + sy * p.win + sx;
+      bool ok = gy >= 0 && gy < p.hc && gx >= 0 && gx < p.wc;
+      if (GM == 2) ok = ok && ((gy | gx) & 1) == 0;
+      if (ok) {
+        const int sy = GM ? (gy >> 1) : gy;
+        const int sx = GM ? (gx >> 1) : gx;
+        off = sy * p.win + sx;
         valid |= 1u << i;
       }
     }
     goff[i] = off;
+    loff[i] = r < PSZ ? tc * PSZ + r : XN;
   }
   const bool has_ss = p.ss != nullptr;
   const bool do_silu = has_ss && p.silu;
-  {
-    const float* ssg = has_ss ? p.ss + (size_t)n * p.cin * 2 : nullptr;
-    for (int i = tid; i < 2 * p.cin; i += 256) SSl[i] = has_ss ? ssg[i] : ((i & 1) ? 0.f : 1.f);
-  }
+  const float* ssg = has_ss ? p.ss + (size_t)n * p.cin * 2 : nullptr;
 
   float xr[NE];
   float wr[NW][4];
-  const int nq = p.cin / KC;
+  float sc_r = 1.f, sh_r = 0.f;  // GroupNorm scale/shift of this thread's channel in the chunk held in xr
+  bool cok_r = true;             // ... and whether that channel exists (cin not a multiple of KC)
 
-  auto src_of = [&](int q) -> const float* {
-    const int cb = q * KC;
-    return (cb < p.c0) ? p.src0 + ((size_t)n * p.c0 + cb) * plane
-                       : p.src1 + ((size_t)n * p.c1 + (cb - p.c0)) * plane;
+  // chunk q covers channels [q*KC, q*KC+KC) of ONE source (c0 % KC == 0 when there are two)
+  auto chan_of = [&](int q, bool& ok) -> const float* {
+    int c = q * KC + tc;
+    ok = c < p.cin;
+    c = min(c, p.cin - 1);
+    return (c < p.c0) ? p.src0 + ((size_t)n * p.c0 + c) * plane : p.src1 + ((size_t)n * p.c1 + (c - p.c0)) * plane;
   };
-  auto w_of = [&](int q) -> const float* { return p.w + (size_t)q * (KC * TAPS) * p.cout + m0; };
+  auto w_of = [&](int q) -> const float* { return p.w + (size_t)q * (KC * TAPS) * p.wstride + m0; };
+  const int wrow_max = p.cin * TAPS - 1;
   // piece pc < NE: one patch element per thread; pc >= NE: one float4 of the weight slab
-  auto load_piece = [&](int pc, const float* sp, const float* wp) {
+  auto load_piece = [&](int pc, int q, const float* sp, const float* wp) {
     if (pc < NE) {
       xr[pc] = sp[goff[pc]];
     } else {
@@ -306,20 +159,26 @@ __global__ __launch_bounds__(256, (KC == 4 && KS == 3 && STRIDE == 1) ? 3 : 2) v
       const int idx = min(tid + 256 * i, WN4 - 1);
       const int row = idx / (BM / 4);
       const int c4 = idx - row * (BM / 4);
-      const float4 t4 = *reinterpret_cast<const float4*>(wp + (size_t)row * p.cout + c4 * 4);
+      const int grow = min(q * (KC * TAPS) + row, wrow_max) - q * (KC * TAPS);  // rows past cin: finite junk x 0
+      const float4 t4 = *reinterpret_cast<const float4*>(wp + (ptrdiff_t)grow * p.wstride + c4 * 4);
       wr[i][0] = t4.x; wr[i][1] = t4.y; wr[i][2] = t4.z; wr[i][3] = t4.w;
     }
   };
-  auto commit_piece = [&](int pc, int q, float* Wd, float* Xd) {
+  auto load_ss = [&](int q) {
+    if (has_ss) {
+      const int c = min(q * KC + tc, p.cin - 1);
+      const float2 s2 = *reinterpret_cast<const float2*>(ssg + 2 * c);
+      sc_r = s2.x;
+      sh_r = s2.y;
+    }
+  };
+  auto commit_piece = [&](int pc, float* Wd, float* Xd) {
     if (pc < NE) {
-      const int e = tid + 256 * pc;
-      const int c = q * KC + min(e / PSZ, KC - 1);
-      const float2 s2 = *reinterpret_cast<const float2*>(&SSl[2 * c]);
-      float v = xr[pc] * s2.x + s2.y;
+      float v = xr[pc] * sc_r + sh_r;
       const float sv = silu_fast(v);
       v = do_silu ? sv : v;
-      v = ((valid >> pc) & 1u) ? v : 0.f;
-      Xd[e] = v;  // e >= XN lands in the slab's padding
+      v = (((valid >> pc) & 1u) && cok_r) ? v : 0.f;
+      Xd[loff[pc]] = v;
     } else {
       const int i = pc - NE;
       reinterpret_cast<float4*>(Wd)[tid + 256 * i] = make_float4(wr[i][0], wr[i][1], wr[i][2], wr[i][3]);
@@ -336,20 +195,21 @@ __global__ __launch_bounds__(256, (KC == 4 && KS == 3 && STRIDE == 1) ? 3 : 2) v
 
   // prologue: chunk 0 into buffer 0, chunk 1 into registers
   {
-    const float* sp = src_of(0);
+    const float* sp = chan_of(0, cok_r);
     const float* wp = w_of(0);
+    load_ss(0);
 #pragma unroll
-    for (int pc = 0; pc < NP; ++pc) load_piece(pc, sp, wp);
+    for (int pc = 0; pc < NP; ++pc) load_piece(pc, 0, sp, wp);
   }
-  __syncthreads();  // SSl visible
 #pragma unroll
-  for (int pc = 0; pc < NP; ++pc) commit_piece(pc, 0, smem, smem + WSZ);
+  for (int pc = 0; pc < NP; ++pc) commit_piece(pc, smem, smem + WSZ);
   {
     const int q1 = min(1, nq - 1);
-    const float* sp = src_of(q1);
+    const float* sp = chan_of(q1, cok_r);
     const float* wp = w_of(q1);
+    load_ss(q1);
 #pragma unroll
-    for (int pc = 0; pc < NP; ++pc) load_piece(pc, sp, wp);
+    for (int pc = 0; pc < NP; ++pc) load_piece(pc, q1, sp, wp);
   }
   __syncthreads();
 
@@ -361,17 +221,23 @@ __global__ __launch_bounds__(256, (KC == 4 && KS == 3 && STRIDE == 1) ? 3 : 2) v
     float* nxt = smem + ((q & 1) ^ 1) * BUF;
     const float* wl = cur + wl_off;
     const float* xl = cur + xl_off;
-    const int qc = min(q + 1, nq - 1);  // chunk being committed (redundant, harmless work on the last one)
-    const int ql = min(q + 2, nq - 1);  // chunk being loaded
-    const float* spn = src_of(ql);
+    // registers hold chunk min(q+1, nq-1); it is committed to the other buffer while chunk min(q+2, nq-1)
+    // is loaded behind it (redundant, harmless work on the last two iterations)
+    const int ql = min(q + 2, nq - 1);
+    bool cok_n;
+    const float* spn = chan_of(ql, cok_n);
     const float* wpn = w_of(ql);
 #pragma unroll
     for (int it = 0; it < NIT; ++it) {
 #pragma unroll
       for (int pc = 0; pc < NP; ++pc) {
         if (pc * NIT / NP == it) {
-          commit_piece(pc, qc, nxt, nxt + WSZ);
-          load_piece(pc, spn, wpn);
+          commit_piece(pc, nxt, nxt + WSZ);
+          load_piece(pc, ql, spn, wpn);
+          if (pc == NE - 1) {  // last patch piece of the committed chunk: switch to the next chunk's scalars
+            load_ss(ql);
+            cok_r = cok_n;
+          }
         }
       }
       const int cp = it / TAPS, tap = it % TAPS;
@@ -390,35 +256,55 @@ __global__ __launch_bounds__(256, (KC == 4 && KS == 3 && STRIDE == 1) ? 3 : 2) v
     __syncthreads();
   }
 
+  // Epilogue. C/D layout of the 32x32 tile: col (pixel) = lane&31, row (cout) = (r&3) + 8*(r>>2) + 4*half.
   const int x = ox0 + l31;
+  const bool has_t = p.temb != nullptr;
+  if (!p.pool) {
 #pragma unroll
-  for (int mt = 0; mt < MT; ++mt) {
+    for (int mt = 0; mt < MT; ++mt) {
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int co = m0 + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-      float add = p.bias ? p.bias[co] : 0.f;
-      const bool has_t = p.temb != nullptr;
-      const float tv = has_t ? p.temb[(size_t)n * p.temb_stride + co] : 0.f;
+      for (int r = 0; r < 16; ++r) {
+        const int co = m0 + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+        if (co < p.cout) {
+          const float add = p.bias ? p.bias[co] : 0.f;
+          const float tv = has_t ? p.temb[(size_t)n * p.temb_stride + co] : 0.f;
 #pragma unroll
-      for (int nt = 0; nt < 2; ++nt) {
-        const int y = oy0 + wave * 2 + nt;
-        const size_t idx = (((size_t)n * p.cout + co) * p.hout + y) * p.wout + x;
-        float v = acc[mt][nt][r] + add;
-        if (has_t) v = v + tv;
-        if (p.res) v = v + p.res[idx];
-        p.dst[idx] = v;
+          for (int nt = 0; nt < 2; ++nt) {
+            const int y = oy0 + wave * 2 + nt;
+            const size_t idx = (((size_t)n * p.cout + co) * p.hout + y) * p.wout + x;
+            float v = acc[mt][nt][r] + add;
+            if (has_t) v = v + tv;
+            if (p.res) v = v + p.res[idx];
+            p.dst[idx] = v;
+          }
+        }
+      }
+    }
+  } else {
+    // 2x2 sum-pool: the wave's two rows are one pooled row; column pairs are adjacent lanes
+    const int ho2 = p.hout >> 1, wo2 = p.wout >> 1;
+    const int y2 = (oy0 >> 1) + wave;
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int co = m0 + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+        float v = acc[mt][0][r] + acc[mt][1][r];
+        v += __shfl_xor(v, 1, 64);
+        if (co < p.cout && (l31 & 1) == 0) {
+          const size_t idx = (((size_t)n * p.cout + co) * ho2 + y2) * wo2 + (x >> 1);
+          float o = v + (p.bias ? 4.f * p.bias[co] : 0.f);
+          if (p.res) o = o + p.res[idx];
+          p.dst[idx] = o;
+        }
       }
     }
   }
 }
 
-static int g_conv_variant = 2;  // 1: single-buffer two-barrier kernel, 2: double-buffer interleaved kernel
-static int g_conv_kc = 0;       // K-chunk of the 3x3 stride-1 v2 kernel: 4 | 8 | 0 = by grid size (measured, r01)
-
-// General VALU fallback: any channel counts / sizes (conv_in with Cin = 3/4/8, conv_out with
-// Cout = 3/4/8, odd spatial sizes).  One thread per output pixel, COB couts per thread.
+// General VALU fallback: any channel counts / sizes.  One thread per output pixel, COB couts per thread.
 template <int COB>
-__global__ __launch_bounds__(256) void conv_direct_kernel(ConvP p, int ks, int stride, int ups) {
+__global__ __launch_bounds__(256) void conv_direct_kernel(ConvP p, int ks, int stride, int gm) {
   const int pix = blockIdx.x * 256 + threadIdx.x;
   const int n = blockIdx.z;
   const int co0 = blockIdx.y * COB;
@@ -444,13 +330,14 @@ __global__ __launch_bounds__(256) void conv_direct_kernel(ConvP p, int ks, int s
       for (int dx = 0; dx < ks; ++dx) {
         const int gx = ox * stride - pad + dx;
         if (gx < 0 || gx >= p.wc) continue;
-        const int sy = ups ? (gy >> 1) : gy, sx = ups ? (gx >> 1) : gx;
+        if (gm == 2 && ((gy | gx) & 1)) continue;
+        const int sy = gm ? (gy >> 1) : gy, sx = gm ? (gx >> 1) : gx;
         float v = sp[sy * p.win + sx];
         if (p.ss) {
           v = v * sc + sh;
           if (p.silu) v = silu_f(v);
         }
-        const float* wrow = p.w + ((size_t)c * taps + dy * ks + dx) * p.cout + co0;
+        const float* wrow = p.w + ((size_t)c * taps + dy * ks + dx) * p.wstride + co0;
 #pragma unroll
         for (int j = 0; j < COB; ++j)
           if (co0 + j < p.cout) acc[j] = fmaf(wrow[j], v, acc[j]);
@@ -469,56 +356,39 @@ __global__ __launch_bounds__(256) void conv_direct_kernel(ConvP p, int ks, int s
   }
 }
 
+// mode 0: forward layout  dst[(ci*taps + tap)*cout_total + cout_off + co] = w[co][ci][tap]
+// mode 1: data-gradient layout (transposed, taps flipped)  dst[(co*taps + (taps-1-tap))*cout_total + cout_off + ci]
 __global__ void weight_relayout_kernel(const float* __restrict__ w, float* __restrict__ dst, int cout, int cin,
-                                       int taps, int cout_total, int cout_off) {
+                                       int taps, int cout_total, int cout_off, int mode) {
   const int64_t total = (int64_t)cout * cin * taps;
   for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-    // destination-major so that writes coalesce: i -> (ci, tap, co)
-    const int co = (int)(i % cout);
-    const int64_t r = i / cout;
-    const int tap = (int)(r % taps);
-    const int ci = (int)(r / taps);
-    dst[((int64_t)ci * taps + tap) * cout_total + cout_off + co] = w[((int64_t)co * cin + ci) * taps + tap];
-  }
-}
-
-template <int KS, int STRIDE, bool UPS, int MT, int KC>
-static int launch_mfma(const ConvP& p, hipStream_t st) {
-  using G = ConvGeom<KS, STRIDE, KC>;
-  const size_t lds = (size_t)(KC * G::TAPS * MT * 32 + G::XN_PAD + (p.ss ? 2 * p.cin : 0)) * sizeof(float);
-  dim3 grid(p.tiles_x * p.tiles_y * p.n, p.cout / (MT * 32));
-  auto kern = conv_mfma_kernel<KS, STRIDE, UPS, MT, KC>;
-  if (lds > 64 * 1024) {
-    static bool raised = false;  // idempotent attribute; benign if set twice
-    if (!raised) {
-      DSG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                  160 * 1024));
-      raised = true;
+    if (mode == 0) {
+      const int co = (int)(i % cout);
+      const int64_t r = i / cout;
+      const int tap = (int)(r % taps);
+      const int ci = (int)(r / taps);
+      dst[((int64_t)ci * taps + tap) * cout_total + cout_off + co] = w[((int64_t)co * cin + ci) * taps + tap];
+    } else {
+      const int ci = (int)(i % cin);
+      const int64_t r = i / cin;
+      const int tap = (int)(r % taps);
+      const int co = (int)(r / taps);
+      dst[((int64_t)co * taps + (taps - 1 - tap)) * cout_total + cout_off + ci] =
+          w[((int64_t)co * cin + ci) * taps + tap];
     }
   }
-  int pi = -1;
-  if (prof_on()) {
-    const double px = (double)p.n * p.hout * p.wout;
-    const double flops = 2.0 * px * p.cout * p.cin * G::TAPS;
-    // algorithmic bytes: input read once, weights once, output written once (+ residual read)
-    const double bytes = 4.0 * ((double)p.n * p.cin * p.hin * p.win + (double)p.cin * G::TAPS * p.cout +
-                                px * p.cout * (p.res ? 2.0 : 1.0));
-    pi = prof_begin(KS == 1 ? 3 : (STRIDE == 2 ? 2 : (UPS ? 1 : 0)), flops, bytes, st);
-  }
-  hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, p);
-  prof_end(pi, st);
-  DSG_LAUNCH_CHECK();
-  return DSG_OK;
 }
 
-template <int KS, int STRIDE, bool UPS, int MT, int KC>
-static int launch_mfma2(const ConvP& p, hipStream_t st) {
+static int g_conv_kc = 0;  // K-chunk of the 3x3 stride-1 kernel: 4 | 8 | 0 = by grid size (measured, r01)
+
+template <int KS, int STRIDE, int GM, int MT, int KC>
+static int launch_mfma(const ConvP& p, hipStream_t st) {
   using G = ConvGeom<KS, STRIDE, KC>;
-  constexpr int NE = (G::XN + 255) / 256;
   constexpr int NW = (KC * G::TAPS * MT * 32 / 4 + 255) / 256;
-  const size_t lds = (size_t)(2 * (NW * 1024 + NE * 256) + 2 * p.cin) * sizeof(float);
-  dim3 grid(p.tiles_x * p.tiles_y * p.n, p.cout / (MT * 32));
-  auto kern = conv_mfma2_kernel<KS, STRIDE, UPS, MT, KC>;
+  constexpr int XSZ = (G::XN + 4 + 3) & ~3;
+  const size_t lds = (size_t)(2 * (NW * 1024 + XSZ)) * sizeof(float);
+  dim3 grid(p.tiles_x * p.tiles_y * p.n, (p.cout + MT * 32 - 1) / (MT * 32));
+  auto kern = conv_mfma_kernel<KS, STRIDE, GM, MT, KC>;
   static bool raised = false;
   if (!raised) {
     DSG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -529,9 +399,10 @@ static int launch_mfma2(const ConvP& p, hipStream_t st) {
   if (prof_on()) {
     const double px = (double)p.n * p.hout * p.wout;
     const double flops = 2.0 * px * p.cout * p.cin * G::TAPS;
+    // algorithmic bytes: input read once, weights once, output written once (+ residual read)
     const double bytes = 4.0 * ((double)p.n * p.cin * p.hin * p.win + (double)p.cin * G::TAPS * p.cout +
                                 px * p.cout * (p.res ? 2.0 : 1.0));
-    pi = prof_begin(KS == 1 ? 3 : (STRIDE == 2 ? 2 : (UPS ? 1 : 0)), flops, bytes, st);
+    pi = prof_begin(KS == 1 ? 3 : (STRIDE == 2 ? 2 : (GM ? 1 : 0)), flops, bytes, st);
   }
   hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, p);
   prof_end(pi, st);
@@ -539,7 +410,7 @@ static int launch_mfma2(const ConvP& p, hipStream_t st) {
   return DSG_OK;
 }
 
-static int launch_direct(const ConvP& p, int ks, int stride, int ups, hipStream_t st) {
+static int launch_direct(const ConvP& p, int ks, int stride, int gm, hipStream_t st) {
   const int npix = p.hout * p.wout;
   int pi = -1;
   if (prof_on()) {
@@ -549,10 +420,10 @@ static int launch_direct(const ConvP& p, int ks, int stride, int ups, hipStream_
   }
   if (p.cout <= 4) {
     dim3 grid(cdiv(npix, 256), cdiv(p.cout, 4), p.n);
-    hipLaunchKernelGGL(conv_direct_kernel<4>, grid, dim3(256), 0, st, p, ks, stride, ups);
+    hipLaunchKernelGGL(conv_direct_kernel<4>, grid, dim3(256), 0, st, p, ks, stride, gm);
   } else {
     dim3 grid(cdiv(npix, 256), cdiv(p.cout, 8), p.n);
-    hipLaunchKernelGGL(conv_direct_kernel<8>, grid, dim3(256), 0, st, p, ks, stride, ups);
+    hipLaunchKernelGGL(conv_direct_kernel<8>, grid, dim3(256), 0, st, p, ks, stride, gm);
   }
   prof_end(pi, st);
   DSG_LAUNCH_CHECK();
@@ -567,9 +438,12 @@ int conv2d_fwd_impl(const dsg_conv_args* a, hipStream_t st, int force_direct) {
   DSG_CHECK_ARG((a->c1 == 0) == (a->src1 == nullptr), "dsg_conv2d_fwd: src1/c1 mismatch");
   DSG_CHECK_ARG(a->ksize == 3 || a->ksize == 1, "dsg_conv2d_fwd: ksize must be 1 or 3 (got %d)", a->ksize);
   DSG_CHECK_ARG(a->stride == 1 || a->stride == 2, "dsg_conv2d_fwd: stride must be 1 or 2 (got %d)", a->stride);
+  DSG_CHECK_ARG(a->upsample >= 0 && a->upsample <= 2, "dsg_conv2d_fwd: upsample must be 0, 1 or 2");
   DSG_CHECK_ARG(!(a->upsample && a->stride != 1), "dsg_conv2d_fwd: upsample requires stride 1");
   DSG_CHECK_ARG(!(a->temb && a->temb_stride <= 0), "dsg_conv2d_fwd: temb_stride must be positive");
-  if (a->n == 0) return DSG_OK;
+  DSG_CHECK_ARG(a->weight_cout_stride == 0 || a->weight_cout_stride >= a->cout,
+                "dsg_conv2d_fwd: weight_cout_stride smaller than cout");
+  DSG_CHECK_ARG(!(a->pool2 && (a->temb || a->stride != 1)), "dsg_conv2d_fwd: pool2 excludes temb / stride 2");
 
   ConvP p;
   p.src0 = a->src0; p.src1 = a->src1; p.c0 = a->c0; p.c1 = a->c1; p.cin = a->c0 + a->c1;
@@ -579,53 +453,50 @@ int conv2d_fwd_impl(const dsg_conv_args* a, hipStream_t st, int force_direct) {
   const int pad = a->ksize / 2;
   p.hout = (p.hc + 2 * pad - a->ksize) / a->stride + 1;
   p.wout = (p.wc + 2 * pad - a->ksize) / a->stride + 1;
-  p.cout = a->cout; p.w = a->weight; p.bias = a->bias; p.ss = a->gn_scale_shift; p.silu = a->silu;
+  p.cout = a->cout; p.wstride = a->weight_cout_stride ? a->weight_cout_stride : a->cout;
+  p.w = a->weight; p.bias = a->bias; p.ss = a->gn_scale_shift; p.silu = a->silu;
   p.temb = a->temb; p.temb_stride = a->temb_stride; p.res = a->residual; p.dst = a->dst;
+  p.pool = a->pool2;
   p.tiles_x = p.wout / TW; p.tiles_y = p.hout / TH;
+  DSG_CHECK_ARG(!(p.pool && ((p.hout | p.wout) & 1)), "dsg_conv2d_fwd: pool2 needs even output dims");
 
-  const bool tile_ok = (p.wout % TW == 0) && (p.hout % TH == 0) && (p.cout % 32 == 0) && p.cin <= 4096;
+  const bool tile_ok = (p.wout % TW == 0) && (p.hout % TH == 0) && (p.wstride % 32 == 0) && p.cin <= 2048 &&
+                       (p.wstride >= ((p.cout + 31) / 32) * 32);
   const int s = a->stride, k = a->ksize, u = a->upsample;
   if (!force_direct && tile_ok) {
-    const bool mt2 = (p.cout % 64 == 0);
-    if (g_conv_variant == 2 && p.cin <= 2048) {
-      if (k == 3 && p.cin % 8 == 0 && p.c0 % 8 == 0) {
-        // KC=4 keeps 3 workgroups per CU (30 KB LDS, 127 VGPRs): better when the grid has >= 3 per CU to give;
-        // KC=8 (2 per CU, half the barriers) wins on the low-resolution levels.
-        const int nblk = p.tiles_x * p.tiles_y * p.n * (p.cout / 64);
-        const bool kc4 = mt2 && (g_conv_kc == 4 || (g_conv_kc == 0 && nblk >= 768));
-        if (s == 1 && !u && kc4) return launch_mfma2<3, 1, false, 2, 4>(p, st);
-        if (s == 1 && u && kc4) return launch_mfma2<3, 1, true, 2, 4>(p, st);
-        if (s == 1 && !u) return mt2 ? launch_mfma2<3, 1, false, 2, 8>(p, st) : launch_mfma2<3, 1, false, 1, 8>(p, st);
-        if (s == 1 && u) return mt2 ? launch_mfma2<3, 1, true, 2, 8>(p, st) : launch_mfma2<3, 1, true, 1, 8>(p, st);
-        if (s == 2 && p.cin % 4 == 0 && p.c0 % 4 == 0)
-          return mt2 ? launch_mfma2<3, 2, false, 2, 4>(p, st) : launch_mfma2<3, 2, false, 1, 4>(p, st);
+    const bool mt2 = (p.wstride % 64 == 0) && p.cout > 32;
+    const bool dual_ok4 = p.c1 == 0 || p.c0 % 4 == 0;
+    const bool dual_ok8 = p.c1 == 0 || p.c0 % 8 == 0;
+    if (k == 3 && s == 1) {
+      // KC=4 keeps 3 workgroups per CU (30 KB LDS, 127 VGPRs): better when the grid has >= 3 per CU to give;
+      // KC=8 (2 per CU, half the barriers) wins on the low-resolution levels.  Few channels: KC=4.
+      const int nblk = p.tiles_x * p.tiles_y * p.n * ((p.cout + 63) / 64);
+      const bool kc4 = p.cin <= 4 || !dual_ok8 || g_conv_kc == 4 || (g_conv_kc == 0 && nblk >= 768);
+      if (kc4 && dual_ok4) {
+        if (u == 0) return mt2 ? launch_mfma<3, 1, 0, 2, 4>(p, st) : launch_mfma<3, 1, 0, 1, 4>(p, st);
+        if (u == 1) return mt2 ? launch_mfma<3, 1, 1, 2, 4>(p, st) : launch_mfma<3, 1, 1, 1, 4>(p, st);
+        return mt2 ? launch_mfma<3, 1, 2, 2, 4>(p, st) : launch_mfma<3, 1, 2, 1, 4>(p, st);
       }
-      if (k == 1 && s == 1 && !u && p.cin % 16 == 0 && p.c0 % 16 == 0)
-        return mt2 ? launch_mfma2<1, 1, false, 2, 16>(p, st) : launch_mfma2<1, 1, false, 1, 16>(p, st);
+      if (dual_ok8) {
+        if (u == 0) return mt2 ? launch_mfma<3, 1, 0, 2, 8>(p, st) : launch_mfma<3, 1, 0, 1, 8>(p, st);
+        if (u == 1) return mt2 ? launch_mfma<3, 1, 1, 2, 8>(p, st) : launch_mfma<3, 1, 1, 1, 8>(p, st);
+        return mt2 ? launch_mfma<3, 1, 2, 2, 8>(p, st) : launch_mfma<3, 1, 2, 1, 8>(p, st);
+      }
     }
-    if (k == 3 && p.cin % 8 == 0 && p.c0 % 8 == 0) {
-      if (s == 1 && !u) return mt2 ? launch_mfma<3, 1, false, 2, 8>(p, st) : launch_mfma<3, 1, false, 1, 8>(p, st);
-      if (s == 1 && u) return mt2 ? launch_mfma<3, 1, true, 2, 8>(p, st) : launch_mfma<3, 1, true, 1, 8>(p, st);
-      if (s == 2) return mt2 ? launch_mfma<3, 2, false, 2, 8>(p, st) : launch_mfma<3, 2, false, 1, 8>(p, st);
-    }
-    if (k == 1 && s == 1 && !u) {
-      if (p.cin % 32 == 0 && p.c0 % 32 == 0)
-        return mt2 ? launch_mfma<1, 1, false, 2, 32>(p, st) : launch_mfma<1, 1, false, 1, 32>(p, st);
-      if (p.cin % 8 == 0 && p.c0 % 8 == 0)
-        return mt2 ? launch_mfma<1, 1, false, 2, 8>(p, st) : launch_mfma<1, 1, false, 1, 8>(p, st);
-    }
+    if (k == 3 && s == 2 && u == 0 && dual_ok4)
+      return mt2 ? launch_mfma<3, 2, 0, 2, 4>(p, st) : launch_mfma<3, 2, 0, 1, 4>(p, st);
+    if (k == 1 && s == 1 && u == 0 && (p.c1 == 0 || p.c0 % 16 == 0))
+      return mt2 ? launch_mfma<1, 1, 0, 2, 16>(p, st) : launch_mfma<1, 1, 0, 1, 16>(p, st);
   }
+  DSG_CHECK_SHAPE(!p.pool, "dsg_conv2d_fwd: pool2 is only implemented on the MFMA path (shape %dx%d, cin %d)",
+                  p.hout, p.wout, p.cin);
   return launch_direct(p, k, s, u, st);
 }
 
 }  // namespace dsg
 
-// Tuning / A-B switch (key 0: conv kernel variant 1|2).  Not part of the reference surface.
+// Tuning / A-B switch (key 1: K-chunk of the 3x3 kernel, 0 = auto | 4 | 8).  Not part of the reference surface.
 DSG_API int dsg_set_tuning(int32_t key, int32_t value) {
-  if (key == 0 && (value == 1 || value == 2)) {
-    dsg::g_conv_variant = value;
-    return DSG_OK;
-  }
   if (key == 1 && (value == 0 || value == 4 || value == 8)) {
     dsg::g_conv_kc = value;
     return DSG_OK;
@@ -642,15 +513,26 @@ DSG_API int dsg_conv2d_fwd_direct(const dsg_conv_args* a, void* stream) {
   return dsg::conv2d_fwd_impl(a, static_cast<hipStream_t>(stream), 1);
 }
 
-DSG_API int dsg_conv_weight_relayout(const float* w_oihw, float* dst, int32_t cout, int32_t cin, int32_t ksize,
-                                     int32_t cout_total, int32_t cout_off, void* stream) {
+static int relayout(const float* w_oihw, float* dst, int32_t cout, int32_t cin, int32_t ksize, int32_t cout_total,
+                    int32_t cout_off, int mode, void* stream) {
   DSG_CHECK_ARG(w_oihw && dst, "dsg_conv_weight_relayout: NULL pointer");
   DSG_CHECK_ARG(cout > 0 && cin > 0 && (ksize == 1 || ksize == 3), "dsg_conv_weight_relayout: bad dims");
-  DSG_CHECK_ARG(cout_off >= 0 && cout_off + cout <= cout_total, "dsg_conv_weight_relayout: column range");
+  const int width = mode == 0 ? cout : cin;
+  DSG_CHECK_ARG(cout_off >= 0 && cout_off + width <= cout_total, "dsg_conv_weight_relayout: column range");
   const int64_t total = (int64_t)cout * cin * ksize * ksize;
   const int blocks = (int)std::min<int64_t>(dsg::cdiv64(total, 256), 4096);
   hipLaunchKernelGGL(dsg::weight_relayout_kernel, dim3(blocks), dim3(256), 0, static_cast<hipStream_t>(stream),
-                     w_oihw, dst, cout, cin, ksize * ksize, cout_total, cout_off);
+                     w_oihw, dst, cout, cin, ksize * ksize, cout_total, cout_off, mode);
   DSG_LAUNCH_CHECK();
   return DSG_OK;
+}
+
+DSG_API int dsg_conv_weight_relayout(const float* w_oihw, float* dst, int32_t cout, int32_t cin, int32_t ksize,
+                                     int32_t cout_total, int32_t cout_off, void* stream) {
+  return relayout(w_oihw, dst, cout, cin, ksize, cout_total, cout_off, 0, stream);
+}
+
+DSG_API int dsg_conv_weight_relayout_dgrad(const float* w_oihw, float* dst, int32_t cout, int32_t cin, int32_t ksize,
+                                           int32_t cin_total, int32_t cin_off, void* stream) {
+  return relayout(w_oihw, dst, cout, cin, ksize, cin_total, cin_off, 1, stream);
 }

@@ -77,7 +77,7 @@ struct T {  // activation [N, c, h, w] (or any scratch when c/h/w are unused)
   int c = 0, h = 0, w = 0;
 };
 
-struct Conv { float* w = nullptr; float* b = nullptr; int cin = 0, cout = 0, k = 0; };
+struct Conv { float* w = nullptr; float* b = nullptr; int cin = 0, cout = 0, k = 0, wstride = 0; };
 struct GN { float* g = nullptr; float* b = nullptr; int c = 0; };
 struct Res { GN n1; Conv c1; int toff = 0; GN n2; Conv c2; bool sc = false; Conv csc; int cin = 0, cout = 0; };
 struct Att { GN gn; Conv qkv; Conv out; int c = 0, heads = 0; };
@@ -125,9 +125,11 @@ struct dsg_unet {
   }
   void reg_conv(const std::string& pre, Conv& c, int cin, int cout, int k) {
     c.cin = cin; c.cout = cout; c.k = k;
-    c.w = dalloc((int64_t)cin * k * k * cout);
+    c.wstride = (cout + 31) / 32 * 32;  // zero-padded columns: every conv takes the matrix-core path
+    c.w = dalloc((int64_t)cin * k * k * c.wstride);
+    if (c.w && c.wstride != cout) (void)hipMemset(c.w, 0, (size_t)cin * k * k * c.wstride * sizeof(float));
     c.b = dalloc(cout);
-    add_param(pre + ".weight", P_CONV, c.w, (int64_t)cin * k * k * cout, cout, cin, k, cout, 0);
+    add_param(pre + ".weight", P_CONV, c.w, (int64_t)cin * k * k * cout, cout, cin, k, c.wstride, 0);
     add_param(pre + ".bias", P_COPY, c.b, cout);
   }
   void reg_gn(const std::string& pre, GN& g, int c) {
@@ -152,7 +154,7 @@ struct dsg_unet {
     a.c = c;
     a.heads = c / cfg.attention_head_dim;
     reg_gn(pre + ".group_norm", a.gn, c);
-    a.qkv.cin = c; a.qkv.cout = 3 * c; a.qkv.k = 1;
+    a.qkv.cin = c; a.qkv.cout = 3 * c; a.qkv.k = 1; a.qkv.wstride = 3 * c;
     a.qkv.w = dalloc((int64_t)c * 3 * c);
     a.qkv.b = dalloc(3 * c);
     const char* names[3] = {"to_q", "to_k", "to_v"};
@@ -226,7 +228,7 @@ struct Runner {
       a.src0 = x.p; a.c0 = x.c;
       a.src1 = skip ? skip->p : nullptr; a.c1 = skip ? skip->c : 0;
       a.n = B; a.hin = x.h; a.win = x.w; a.upsample = ups; a.ksize = cv.k; a.stride = stride; a.cout = cv.cout;
-      a.weight = cv.w; a.bias = cv.b;
+      a.weight = cv.w; a.weight_cout_stride = cv.wstride; a.bias = cv.b;
       a.gn_scale_shift = ss ? ss->p : nullptr; a.silu = silu;
       a.temb = temb; a.temb_stride = h->proj_total;
       a.residual = res ? res->p : nullptr;

@@ -16,40 +16,62 @@ def _st(t):
     return _lib.stream_ptr(t.device)
 
 
+def _pad32(c: int) -> int:
+    return (c + 31) // 32 * 32
+
+
 def relayout_conv_weight(w_oihw: torch.Tensor, out: torch.Tensor = None, cout_total: int = None,
                          cout_off: int = 0) -> torch.Tensor:
-    """OIHW (or Linear [out,in]) -> engine layout [Cin][k*k][cout_total]."""
+    """OIHW (or Linear [out,in]) -> engine layout [Cin][k*k][cout_total]; cout_total defaults to cout rounded up
+    to 32 (zero columns) so that every conv can take the matrix-core path."""
     w = w_oihw.contiguous()
     cout, cin = w.shape[0], w.shape[1]
     k = w.shape[2] if w.dim() == 4 else 1
-    cout_total = cout_total or cout
+    cout_total = cout_total or _pad32(cout)
     if out is None:
-        out = torch.empty((cin, k * k, cout_total), dtype=torch.float32, device=w.device)
+        out = torch.zeros((cin, k * k, cout_total), dtype=torch.float32, device=w.device)
     with torch.cuda.device(w.device):
         _lib.check(_lib.load().dsg_conv_weight_relayout(_lib.ptr(w), _lib.ptr(out), cout, cin, k, cout_total,
                                                         cout_off, _st(w)))
     return out
 
 
+def relayout_conv_weight_dgrad(w_oihw: torch.Tensor, out: torch.Tensor = None) -> torch.Tensor:
+    """OIHW -> [Cout][k*k flipped][Cin padded to 32]: weight of the data-gradient conv dX = conv(dY, .)."""
+    w = w_oihw.contiguous()
+    cout, cin = w.shape[0], w.shape[1]
+    k = w.shape[2] if w.dim() == 4 else 1
+    if out is None:
+        out = torch.zeros((cout, k * k, _pad32(cin)), dtype=torch.float32, device=w.device)
+    with torch.cuda.device(w.device):
+        _lib.check(_lib.load().dsg_conv_weight_relayout_dgrad(_lib.ptr(w), _lib.ptr(out), cout, cin, k,
+                                                              out.shape[-1], 0, _st(w)))
+    return out
+
+
 def conv2d_fused(src0, weight_r, bias=None, src1=None, ksize=3, stride=1, upsample=False, gn_scale_shift=None,
-                 silu=False, temb=None, temb_stride=0, residual=None, out=None, direct=False):
+                 silu=False, temb=None, temb_stride=0, residual=None, out=None, direct=False, cout=None,
+                 pool2=False):
     """dsg_conv2d_fwd: see include/dsg.h.  `weight_r` is in engine layout; `temb` is a [N, temb_stride] view
     whose first `cout` columns (from its data pointer) are added per (n, cout)."""
     lib = _lib.load()
     n, c0, hin, win = src0.shape
     c1 = src1.shape[1] if src1 is not None else 0
-    cout = weight_r.shape[-1]
+    wstride = weight_r.shape[-1]
+    cout = cout or wstride
     hc, wc = (2 * hin, 2 * win) if upsample else (hin, win)
     pad = ksize // 2
     ho = (hc + 2 * pad - ksize) // stride + 1
     wo = (wc + 2 * pad - ksize) // stride + 1
     if out is None:
-        out = torch.empty((n, cout, ho, wo), dtype=torch.float32, device=src0.device)
+        out = torch.empty((n, cout, ho // 2, wo // 2) if pool2 else (n, cout, ho, wo), dtype=torch.float32,
+                          device=src0.device)
     a = _lib.ConvArgs()
     a.src0, a.src1 = _lib.ptr(src0), _lib.ptr(src1)
     a.c0, a.c1, a.n, a.hin, a.win = c0, c1, n, hin, win
     a.upsample, a.ksize, a.stride, a.cout = int(upsample), ksize, stride, cout
     a.weight, a.bias = _lib.ptr(weight_r), _lib.ptr(bias)
+    a.weight_cout_stride, a.pool2 = wstride, int(pool2)
     a.gn_scale_shift, a.silu = _lib.ptr(gn_scale_shift), int(silu)
     if temb is not None:
         if not temb.is_cuda:

@@ -56,18 +56,22 @@ typedef struct {
   const float* src1;            /* optional [N, c1, hin, win] concatenated after src0 on channels */
   int32_t c0, c1;
   int32_t n, hin, win;          /* source dims (before the optional upsample) */
-  int32_t upsample;             /* 1: nearest x2 of the source before the conv (Upsample2D) */
+  int32_t upsample;             /* 1: nearest x2 of the source before the conv (Upsample2D);
+                                   2: zero-stuffed x2 (source at even positions) -- the data gradient of a
+                                      stride-2 conv is a stride-1 conv over it */
   int32_t ksize;                /* 3 or 1; padding = ksize/2 */
   int32_t stride;               /* 1 or 2 (Downsample2D) */
   int32_t cout;
-  const float* weight;          /* [c0+c1][ksize*ksize][cout] */
+  const float* weight;          /* [c0+c1][ksize*ksize][weight_cout_stride] */
+  int32_t weight_cout_stride;   /* 0 = cout; >= cout when the matrix is zero-padded (conv_out: 4 -> 32) */
   const float* bias;            /* [cout] or NULL */
   const float* gn_scale_shift;  /* optional [N][c0+c1][2] */
   int32_t silu;                 /* 1: SiLU after the affine */
   const float* temb;            /* optional: temb[n*temb_stride + cout_index] added per (n, cout) */
   int32_t temb_stride;
   const float* residual;        /* optional [N, cout, hout, wout] */
-  float* dst;                   /* [N, cout, hout, wout] */
+  float* dst;                   /* [N, cout, hout, wout] ([N, cout, hout/2, wout/2] with pool2) */
+  int32_t pool2;                /* 1: 2x2 sum-pool of the result (adjoint of the nearest x2 upsample) */
 } dsg_conv_args;
 
 int dsg_conv2d_fwd(const dsg_conv_args* a, void* stream);
@@ -77,6 +81,10 @@ int dsg_conv2d_fwd(const dsg_conv_args* a, void* stream);
  * [out][in] are the k=1 case. */
 int dsg_conv_weight_relayout(const float* w_oihw, float* dst, int32_t cout, int32_t cin, int32_t ksize,
                              int32_t cout_total, int32_t cout_off, void* stream);
+/* OIHW -> [Cout][k*k flipped][cin_total]: the weight of the data-gradient convolution
+ * dX = conv(dY, W^T flipped) (backward of training_pipeline.py:84 through :86). */
+int dsg_conv_weight_relayout_dgrad(const float* w_oihw, float* dst, int32_t cout, int32_t cin, int32_t ksize,
+                                   int32_t cin_total, int32_t cin_off, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * GroupNorm (ResnetBlock2D.norm1/norm2, Attention.group_norm, conv_norm_out).
@@ -182,7 +190,7 @@ int dsg_prof_enable(int32_t on);
 int dsg_prof_summary(int32_t kernel_class, double* total_ms, double* total_flops, double* total_bytes,
                      int64_t* launches);
 int dsg_prof_dump(const char* csv_path);
-/* A/B switch for kernel variants (key 0: conv kernel 1 = single LDS buffer, 2 = double-buffered, default). */
+/* Tuning switch (key 1: K-chunk of the 3x3 conv kernel, 0 = by grid size | 4 | 8). */
 int dsg_set_tuning(int32_t key, int32_t value);
 
 #ifdef __cplusplus

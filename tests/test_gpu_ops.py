@@ -79,7 +79,8 @@ def test_conv_fused(case, batch):
     for direct in (False, True):
         got = ops.conv2d_fused(d(x0), wr, d(bias), src1=d(x1), ksize=k, stride=stride, upsample=ups,
                                gn_scale_shift=ss, silu=silu, temb=tp[:, 3:] if temb else None,
-                               temb_stride=tp.stride(0), residual=d(r) if res else None, direct=direct)
+                               temb_stride=tp.stride(0), residual=d(r) if res else None, direct=direct,
+                               cout=cout)
         _check(got, ref)
 
 
