@@ -40,6 +40,18 @@ class ConvArgs(C.Structure):
     ]
 
 
+class ConvWgradArgs(C.Structure):
+    """Mirror of ``dsg_conv_wgrad_args`` (include/dsg.h)."""
+    _fields_ = [
+        ("src0", C.c_void_p), ("src1", C.c_void_p),
+        ("c0", C.c_int32), ("c1", C.c_int32),
+        ("n", C.c_int32), ("hin", C.c_int32), ("win", C.c_int32),
+        ("upsample", C.c_int32), ("ksize", C.c_int32), ("stride", C.c_int32), ("cout", C.c_int32),
+        ("dy", C.c_void_p), ("gn_scale_shift", C.c_void_p), ("silu", C.c_int32),
+        ("dw", C.c_void_p), ("force_direct", C.c_int32),
+    ]
+
+
 class UNetConfig(C.Structure):
     """Mirror of ``dsg_unet_config`` (include/dsg.h)."""
     _fields_ = [
@@ -52,7 +64,7 @@ class UNetConfig(C.Structure):
     ]
 
 
-_vp, _i32, _i64, _f32, _sz = C.c_void_p, C.c_int32, C.c_int64, C.c_float, C.c_size_t
+_vp, _i32, _i64, _f32, _sz, _f64 = C.c_void_p, C.c_int32, C.c_int64, C.c_float, C.c_size_t, C.c_double
 
 # name -> argtypes; every function returns int32 status unless noted.  This table is the single
 # Python-side statement of the ABI; tests/test_abi.py checks it against include/dsg.h.
@@ -77,6 +89,20 @@ SIGNATURES = {
     "dsg_unet_param_name": [_vp, _i64, C.POINTER(C.c_char_p), C.POINTER(_i64)],
     "dsg_unet_workspace_bytes": [_vp, _i32, C.POINTER(_sz)],
     "dsg_unet_forward": [_vp, _vp, _vp, _vp, _i32, _vp, _sz, _vp],
+    "dsg_conv2d_wgrad": [C.POINTER(ConvWgradArgs), _vp],
+    "dsg_gn_finalize_train": [_vp, _vp, _vp, _i32, _i32, _i32, _i32, _f32, _vp, _vp, _vp],
+    "dsg_gn_bwd": [_vp, _i32, _vp, _i32, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp,
+                   _vp, _vp, _vp],
+    "dsg_channel_sums": [_vp, _i32, _i32, _i32, _vp, _vp],
+    "dsg_reduce_rows_add": [_vp, _i32, _i32, _i32, _vp, _vp],
+    "dsg_attention_fwd_train": [_vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp],
+    "dsg_attention_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp],
+    "dsg_linear_bwd": [_vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp],
+    "dsg_silu_bwd": [_vp, _vp, _i64, _vp, _vp],
+    "dsg_mse_loss": [_vp, _vp, _i64, _f32, _vp, _vp, _vp, _sz, _vp],
+    "dsg_l2_norm": [_vp, _i64, _vp, _vp, _sz, _vp],
+    "dsg_clip_scale": [_vp, _i64, _vp, _f32, _vp],
+    "dsg_adamw_step": [_vp, _vp, _vp, _vp, _i64, _f64, _f64, _f64, _f64, _f64, _i64, _vp, _f32, _vp],
     "dsg_prof_enable": [_i32],
     "dsg_set_tuning": [_i32, _i32],
     "dsg_prof_dump": [C.c_char_p],

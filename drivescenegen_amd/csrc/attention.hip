@@ -17,8 +17,8 @@ constexpr int ATT_LDS_FLOATS = 4096;  // per K and per V tile: 16 KiB each, keys
 constexpr int ATT_KB = 8;    // keys per online-softmax chunk
 
 template <int D, int QPT>
-__global__ __launch_bounds__(256) void attention_kernel(const float* __restrict__ qkv, float* __restrict__ out, int c,
-                                                        int heads, int l, float qscale) {
+__global__ __launch_bounds__(256) void attention_kernel(const float* __restrict__ qkv, float* __restrict__ out,
+                                                        float* __restrict__ lse, int c, int heads, int l, float qscale) {
   constexpr int ATT_KT = ATT_LDS_FLOATS / D;
   __shared__ __attribute__((aligned(16))) float KVl[2 * ATT_KT * D];
   float* Kl = KVl;
@@ -120,12 +120,14 @@ __global__ __launch_bounds__(256) void attention_kernel(const float* __restrict_
       const float inv = 1.0f / lsum[u];
 #pragma unroll
       for (int i = 0; i < D; ++i) op[(size_t)i * l + qi[u]] = o[u][i] * inv;
+      // log2-domain log-sum-exp of the scaled scores (training saves it for the backward recompute)
+      if (lse) lse[((size_t)n * heads + h) * l + qi[u]] = m[u] + log2f(lsum[u]);
     }
   }
 }
 
 template <int D>
-static int launch_attention(const float* qkv, float* out, int n, int c, int heads, int l, hipStream_t st) {
+static int launch_attention(const float* qkv, float* out, float* lse, int n, int c, int heads, int l, hipStream_t st) {
   // scores are kept in the log2 domain: q is pre-scaled by log2(e)/sqrt(D)
   const float qscale = 1.4426950408889634f / sqrtf((float)D);
   const long work = (long)n * heads * l;
@@ -136,24 +138,24 @@ static int launch_attention(const float* qkv, float* out, int n, int c, int head
   dim3 grid(cdiv(l, 256 * qpt), heads, n);
   if constexpr (D <= 16) {  // wider heads keep one query per thread (register budget)
     if (qpt == 4) {
-      hipLaunchKernelGGL((attention_kernel<D, 4>), grid, dim3(256), 0, st, qkv, out, c, heads, l, qscale);
+      hipLaunchKernelGGL((attention_kernel<D, 4>), grid, dim3(256), 0, st, qkv, out, lse, c, heads, l, qscale);
       DSG_LAUNCH_CHECK();
       return DSG_OK;
     }
     if (qpt == 2) {
-      hipLaunchKernelGGL((attention_kernel<D, 2>), grid, dim3(256), 0, st, qkv, out, c, heads, l, qscale);
+      hipLaunchKernelGGL((attention_kernel<D, 2>), grid, dim3(256), 0, st, qkv, out, lse, c, heads, l, qscale);
       DSG_LAUNCH_CHECK();
       return DSG_OK;
     }
   }
-  hipLaunchKernelGGL((attention_kernel<D, 1>), grid, dim3(256), 0, st, qkv, out, c, heads, l, qscale);
+  hipLaunchKernelGGL((attention_kernel<D, 1>), grid, dim3(256), 0, st, qkv, out, lse, c, heads, l, qscale);
   DSG_LAUNCH_CHECK();
   return DSG_OK;
 }
 
 }  // namespace dsg
 
-DSG_API int dsg_attention_fwd(const float* qkv, float* out, int32_t n, int32_t c, int32_t heads, int32_t l,
+static int attention_fwd_impl(const float* qkv, float* out, float* lse, int32_t n, int32_t c, int32_t heads, int32_t l,
                               void* stream) {
   DSG_CHECK_ARG(qkv && out, "dsg_attention_fwd: NULL pointer");
   DSG_CHECK_ARG(n > 0 && c > 0 && heads > 0 && l > 0, "dsg_attention_fwd: bad dims");
@@ -162,11 +164,205 @@ DSG_API int dsg_attention_fwd(const float* qkv, float* out, int32_t n, int32_t c
   const int d = c / heads;
   hipStream_t st = static_cast<hipStream_t>(stream);
   switch (d) {
-    case 8: return dsg::launch_attention<8>(qkv, out, n, c, heads, l, st);
-    case 16: return dsg::launch_attention<16>(qkv, out, n, c, heads, l, st);
-    case 32: return dsg::launch_attention<32>(qkv, out, n, c, heads, l, st);
-    case 64: return dsg::launch_attention<64>(qkv, out, n, c, heads, l, st);
+    case 8: return dsg::launch_attention<8>(qkv, out, lse, n, c, heads, l, st);
+    case 16: return dsg::launch_attention<16>(qkv, out, lse, n, c, heads, l, st);
+    case 32: return dsg::launch_attention<32>(qkv, out, lse, n, c, heads, l, st);
+    case 64: return dsg::launch_attention<64>(qkv, out, lse, n, c, heads, l, st);
     default:
       return dsg::fail(DSG_ERR_UNSUPPORTED_SHAPE, "dsg_attention_fwd: head_dim %d not in {8,16,32,64}", d);
+  }
+}
+
+DSG_API int dsg_attention_fwd(const float* qkv, float* out, int32_t n, int32_t c, int32_t heads, int32_t l,
+                              void* stream) {
+  return attention_fwd_impl(qkv, out, nullptr, n, c, heads, l, stream);
+}
+
+DSG_API int dsg_attention_fwd_train(const float* qkv, float* out, float* lse, int32_t n, int32_t c, int32_t heads,
+                                    int32_t l, void* stream) {
+  DSG_CHECK_ARG(lse != nullptr, "dsg_attention_fwd_train: lse is NULL");
+  return attention_fwd_impl(qkv, out, lse, n, c, heads, l, stream);
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Backward of the attention core (flash-style recompute from the saved log-sum-exp):
+//   P = exp2(s - lse), dP = dO . V, dS = P * (dP - D), D = rowsum(dO * O)
+//   dQ = dS K * scale, dK = dS^T Q * scale, dV = P^T dO
+// Kernel A: one thread per query row (keys/values streamed through LDS) -> dQ and D.
+// Kernel B: one thread per key row (queries / dO / lse / D streamed through LDS) -> dK, dV.
+// ---------------------------------------------------------------------------------------------------
+namespace dsg {
+
+template <int D>
+__global__ __launch_bounds__(256) void attention_bwd_dq_kernel(const float* __restrict__ qkv,
+                                                               const float* __restrict__ o,
+                                                               const float* __restrict__ dout,
+                                                               const float* __restrict__ lse, float* __restrict__ dqkv,
+                                                               float* __restrict__ dsum, int c, int heads, int l,
+                                                               float qscale) {
+  constexpr int KT = ATT_LDS_FLOATS / D;
+  __shared__ __attribute__((aligned(16))) float KVl[2 * KT * D];
+  float* Kl = KVl;
+  float* Vl = KVl + KT * D;
+  const int tid = threadIdx.x;
+  const int h = blockIdx.y, n = blockIdx.z;
+  const float* qp = qkv + ((size_t)n * 3 * c + h * D) * l;
+  const float* kp = qp + (size_t)c * l;
+  const float* vp = kp + (size_t)c * l;
+  const size_t obase = ((size_t)n * c + h * D) * l;
+  const int qi = blockIdx.x * 256 + tid;
+  const int qc = min(qi, l - 1);
+  float q[D], dO[D], dq[D];
+  float dd = 0.f;
+#pragma unroll
+  for (int i = 0; i < D; ++i) {
+    q[i] = qp[(size_t)i * l + qc] * qscale;
+    dO[i] = dout[obase + (size_t)i * l + qc];
+    dd = fmaf(dO[i], o[obase + (size_t)i * l + qc], dd);
+    dq[i] = 0.f;
+  }
+  const float ls = lse[((size_t)n * heads + h) * l + qc];
+  for (int j0 = 0; j0 < l; j0 += KT) {
+    const int kt = min(KT, l - j0);
+    __syncthreads();
+    for (int e = tid; e < KT * D; e += 256) {
+      const int i = e / KT, j = e - i * KT;
+      float kv = 0.f, vv = 0.f;
+      if (j < kt) {
+        kv = kp[(size_t)i * l + j0 + j];
+        vv = vp[(size_t)i * l + j0 + j];
+      }
+      Kl[j * D + i] = kv;
+      Vl[j * D + i] = vv;
+    }
+    __syncthreads();
+    for (int j = 0; j < kt; ++j) {
+      float s = 0.f, dp = 0.f;
+#pragma unroll
+      for (int i = 0; i < D; ++i) {
+        s = fmaf(q[i], Kl[j * D + i], s);
+        dp = fmaf(dO[i], Vl[j * D + i], dp);
+      }
+      const float pr = exp2f(s - ls);
+      const float ds = pr * (dp - dd);
+#pragma unroll
+      for (int i = 0; i < D; ++i) dq[i] = fmaf(ds, Kl[j * D + i], dq[i]);
+    }
+  }
+  if (qi < l) {
+    // qscale = log2(e)/sqrt(D); the softmax scale alone is 1/sqrt(D)
+    const float sm = qscale * 0.6931471805599453f;
+    float* dqp = dqkv + ((size_t)n * 3 * c + h * D) * l;
+#pragma unroll
+    for (int i = 0; i < D; ++i) dqp[(size_t)i * l + qi] = dq[i] * sm;
+    dsum[((size_t)n * heads + h) * l + qi] = dd;
+  }
+}
+
+template <int D>
+__global__ __launch_bounds__(256) void attention_bwd_dkv_kernel(const float* __restrict__ qkv,
+                                                                const float* __restrict__ dout,
+                                                                const float* __restrict__ lse,
+                                                                const float* __restrict__ dsum,
+                                                                float* __restrict__ dqkv, int c, int heads, int l,
+                                                                float qscale) {
+  constexpr int QT = ATT_LDS_FLOATS / (D + 1);  // queries per LDS tile: q[D], dO[D], lse, D-sum
+  __shared__ __attribute__((aligned(16))) float Sm[2 * QT * (D + 1)];
+  float* Ql = Sm;                  // [QT][D+1]: q (prescaled) then lse
+  float* Gl = Sm + QT * (D + 1);   // [QT][D+1]: dO then dsum
+  const int tid = threadIdx.x;
+  const int h = blockIdx.y, n = blockIdx.z;
+  const float* qp = qkv + ((size_t)n * 3 * c + h * D) * l;
+  const float* kp = qp + (size_t)c * l;
+  const float* vp = kp + (size_t)c * l;
+  const size_t obase = ((size_t)n * c + h * D) * l;
+  const size_t lbase = ((size_t)n * heads + h) * l;
+  const int ki = blockIdx.x * 256 + tid;
+  const int kc = min(ki, l - 1);
+  float k[D], v[D], dk[D], dv[D];
+#pragma unroll
+  for (int i = 0; i < D; ++i) {
+    k[i] = kp[(size_t)i * l + kc];
+    v[i] = vp[(size_t)i * l + kc];
+    dk[i] = 0.f;
+    dv[i] = 0.f;
+  }
+  for (int j0 = 0; j0 < l; j0 += QT) {
+    const int qt = min(QT, l - j0);
+    __syncthreads();
+    for (int e = tid; e < QT * (D + 1); e += 256) {
+      const int i = e / QT, j = e - i * QT;
+      float a = 0.f, b = 0.f;
+      if (j < qt) {
+        if (i < D) {
+          a = qp[(size_t)i * l + j0 + j] * qscale;
+          b = dout[obase + (size_t)i * l + j0 + j];
+        } else {
+          a = lse[lbase + j0 + j];
+          b = dsum[lbase + j0 + j];
+        }
+      }
+      Ql[j * (D + 1) + i] = a;
+      Gl[j * (D + 1) + i] = b;
+    }
+    __syncthreads();
+    for (int j = 0; j < qt; ++j) {
+      const float* qr = Ql + j * (D + 1);
+      const float* gr = Gl + j * (D + 1);
+      float s = 0.f, dp = 0.f;
+#pragma unroll
+      for (int i = 0; i < D; ++i) {
+        s = fmaf(qr[i], k[i], s);
+        dp = fmaf(gr[i], v[i], dp);
+      }
+      const float pr = exp2f(s - qr[D]);
+      const float ds = pr * (dp - gr[D]);
+#pragma unroll
+      for (int i = 0; i < D; ++i) {
+        dv[i] = fmaf(pr, gr[i], dv[i]);
+        dk[i] = fmaf(ds, qr[i], dk[i]);  // qr is prescaled by log2(e)/sqrt(D): undone below
+      }
+    }
+  }
+  if (ki < l) {
+    float* dkp = dqkv + ((size_t)n * 3 * c + c + h * D) * l;
+    float* dvp = dkp + (size_t)c * l;
+#pragma unroll
+    for (int i = 0; i < D; ++i) {
+      dkp[(size_t)i * l + ki] = dk[i] * 0.6931471805599453f;
+      dvp[(size_t)i * l + ki] = dv[i];
+    }
+  }
+}
+
+template <int D>
+static int launch_attention_bwd(const float* qkv, const float* o, const float* dout, const float* lse, float* dqkv,
+                                float* dsum, int n, int c, int heads, int l, hipStream_t st) {
+  const float qscale = 1.4426950408889634f / sqrtf((float)D);
+  dim3 grid(cdiv(l, 256), heads, n);
+  hipLaunchKernelGGL((attention_bwd_dq_kernel<D>), grid, dim3(256), 0, st, qkv, o, dout, lse, dqkv, dsum, c, heads, l,
+                     qscale);
+  DSG_LAUNCH_CHECK();
+  hipLaunchKernelGGL((attention_bwd_dkv_kernel<D>), grid, dim3(256), 0, st, qkv, dout, lse, dsum, dqkv, c, heads, l,
+                     qscale);
+  DSG_LAUNCH_CHECK();
+  return DSG_OK;
+}
+
+}  // namespace dsg
+
+DSG_API int dsg_attention_bwd(const float* qkv, const float* out, const float* dout, const float* lse, float* dqkv,
+                              float* dsum_ws, int32_t n, int32_t c, int32_t heads, int32_t l, void* stream) {
+  DSG_CHECK_ARG(qkv && out && dout && lse && dqkv && dsum_ws, "dsg_attention_bwd: NULL pointer");
+  DSG_CHECK_ARG(n > 0 && c > 0 && heads > 0 && l > 0 && c % heads == 0, "dsg_attention_bwd: bad dims");
+  DSG_CHECK_ARG(heads <= 65535 && n <= 65535, "dsg_attention_bwd: grid too large");
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  switch (c / heads) {
+    case 8: return dsg::launch_attention_bwd<8>(qkv, out, dout, lse, dqkv, dsum_ws, n, c, heads, l, st);
+    case 16: return dsg::launch_attention_bwd<16>(qkv, out, dout, lse, dqkv, dsum_ws, n, c, heads, l, st);
+    case 32: return dsg::launch_attention_bwd<32>(qkv, out, dout, lse, dqkv, dsum_ws, n, c, heads, l, st);
+    case 64: return dsg::launch_attention_bwd<64>(qkv, out, dout, lse, dqkv, dsum_ws, n, c, heads, l, st);
+    default:
+      return dsg::fail(DSG_ERR_UNSUPPORTED_SHAPE, "dsg_attention_bwd: head_dim %d not in {8,16,32,64}", c / heads);
   }
 }

@@ -61,7 +61,7 @@ __global__ __launch_bounds__(256) void gn_channel_stats_kernel(const float* __re
 // one thread per (n, c)
 __global__ void gn_finalize_kernel(const double* __restrict__ stats, const float* __restrict__ gamma,
                                    const float* __restrict__ beta, int n, int c, int groups, int hw, float eps,
-                                   float* __restrict__ out) {
+                                   float* __restrict__ out, float* __restrict__ mr) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n * c) return;
   const int ni = i / c, ci = i - ni * c;
@@ -82,6 +82,10 @@ __global__ void gn_finalize_kernel(const double* __restrict__ stats, const float
   const float sc = rstd * gamma[ci];
   out[2 * (size_t)i] = sc;
   out[2 * (size_t)i + 1] = beta[ci] - meanf * sc;
+  if (mr) {  // training keeps (mean, rstd) per (n, c) for the backward pass
+    mr[2 * (size_t)i] = meanf;
+    mr[2 * (size_t)i + 1] = rstd;
+  }
 }
 
 // grid = (ceil(hw/1024), c, n)
@@ -120,15 +124,28 @@ DSG_API int dsg_gn_channel_stats(const float* src0, int32_t c0, const float* src
   return DSG_OK;
 }
 
-DSG_API int dsg_gn_finalize(const double* chan_stats, const float* gamma, const float* beta, int32_t n, int32_t c,
-                            int32_t groups, int32_t hw, float eps, float* scale_shift, void* stream) {
+static int gn_finalize_impl(const double* chan_stats, const float* gamma, const float* beta, int32_t n, int32_t c,
+                            int32_t groups, int32_t hw, float eps, float* scale_shift, float* mean_rstd, void* stream) {
   DSG_CHECK_ARG(chan_stats && gamma && beta && scale_shift, "dsg_gn_finalize: NULL pointer");
   DSG_CHECK_ARG(n > 0 && c > 0 && groups > 0 && hw > 0, "dsg_gn_finalize: bad dims");
   DSG_CHECK_ARG(c % groups == 0, "dsg_gn_finalize: channels (%d) not divisible by groups (%d)", c, groups);
   hipLaunchKernelGGL(dsg::gn_finalize_kernel, dim3(dsg::cdiv(n * c, 256)), dim3(256), 0,
-                     static_cast<hipStream_t>(stream), chan_stats, gamma, beta, n, c, groups, hw, eps, scale_shift);
+                     static_cast<hipStream_t>(stream), chan_stats, gamma, beta, n, c, groups, hw, eps, scale_shift,
+                     mean_rstd);
   DSG_LAUNCH_CHECK();
   return DSG_OK;
+}
+
+DSG_API int dsg_gn_finalize(const double* chan_stats, const float* gamma, const float* beta, int32_t n, int32_t c,
+                            int32_t groups, int32_t hw, float eps, float* scale_shift, void* stream) {
+  return gn_finalize_impl(chan_stats, gamma, beta, n, c, groups, hw, eps, scale_shift, nullptr, stream);
+}
+
+DSG_API int dsg_gn_finalize_train(const double* chan_stats, const float* gamma, const float* beta, int32_t n, int32_t c,
+                                  int32_t groups, int32_t hw, float eps, float* scale_shift, float* mean_rstd,
+                                  void* stream) {
+  DSG_CHECK_ARG(mean_rstd != nullptr, "dsg_gn_finalize_train: mean_rstd is NULL");
+  return gn_finalize_impl(chan_stats, gamma, beta, n, c, groups, hw, eps, scale_shift, mean_rstd, stream);
 }
 
 DSG_API int dsg_gn_apply(const float* src, const float* scale_shift, int32_t silu, float* dst, int32_t n, int32_t c,

@@ -1,0 +1,373 @@
+// Backward / optimizer kernels of the DDPM training step for gfx950 (all HBM-bound streaming passes).
+//
+// Reference: DriveSceneGen/pipeline/training_pipeline.py:84-91 -- `F.mse_loss`, `accelerator.backward`,
+// `accelerator.clip_grad_norm_(model.parameters(), 1.0)`, `optimizer.step()` with torch.optim.AdamW
+// (DriveSceneGen/scripts/train.py:66); layer semantics SURVEY.md App. A.2 / A.6.
+//
+//  - GroupNorm(+SiLU) backward in two streaming passes over (x, dy): per-(n, c) sums -> per-group
+//    coefficients -> dx (the [x || skip] concat is split on the fly; an optional addend carries the
+//    residual-path gradient so no separate add pass exists);
+//  - per-(n, c) sums of a gradient tensor (bias and time-embedding gradients);
+//  - small linear-layer backward (time MLP, time_emb_proj), SiLU backward;
+//  - MSE loss forward+backward, global grad-norm (sum of squares), fused AdamW with the clip factor
+//    applied on the fly.
+#include "dsg_common.h"
+#include <cmath>
+
+namespace dsg {
+
+__device__ __forceinline__ double wave_sum_d(double v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+  return v;
+}
+
+__device__ __forceinline__ float dsilu(float u) {
+  const float s = 1.0f / (1.0f + expf(-u));
+  return s * (1.0f + u * (1.0f - s));
+}
+
+// block-wide sum of two doubles; result valid in thread 0
+__device__ __forceinline__ void block_sum2(double& a, double& b) {
+  __shared__ double red[2][4];
+  a = wave_sum_d(a);
+  b = wave_sum_d(b);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (lane == 0) {
+    red[0][wave] = a;
+    red[1][wave] = b;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    a = red[0][0] + red[0][1] + red[0][2] + red[0][3];
+    b = red[1][0] + red[1][1] + red[1][2] + red[1][3];
+  }
+}
+
+// grid = (c0 + c1, n).  s12[n][c] = (sum du, sum du * xhat), du = dy * silu'(u), u = x*sc + sh
+__global__ __launch_bounds__(256) void gn_bwd_stats_kernel(const float* __restrict__ src0, int c0,
+                                                           const float* __restrict__ src1, int c1,
+                                                           const float* __restrict__ dy, const float* __restrict__ ss,
+                                                           const float* __restrict__ mr, int silu, int hw,
+                                                           double* __restrict__ s12) {
+  const int c = blockIdx.x, n = blockIdx.y, ct = c0 + c1;
+  const float* xp = (c < c0) ? src0 + ((size_t)n * c0 + c) * hw : src1 + ((size_t)n * c1 + (c - c0)) * hw;
+  const float* dp = dy + ((size_t)n * ct + c) * hw;
+  const size_t k = ((size_t)n * ct + c) * 2;
+  const float sc = ss[k], sh = ss[k + 1], mean = mr[k], rstd = mr[k + 1];
+  double a = 0.0, b = 0.0;
+  for (int i = threadIdx.x; i < hw; i += 256) {
+    const float x = xp[i];
+    float du = dp[i];
+    if (silu) du *= dsilu(x * sc + sh);
+    a += du;
+    b += (double)du * ((x - mean) * rstd);
+  }
+  block_sum2(a, b);
+  if (threadIdx.x == 0) {
+    s12[k] = a;
+    s12[k + 1] = b;
+  }
+}
+
+// one thread per (n, c): coef[n][c] = (rstd*gamma, rstd*g1/M, rstd*g2/M); thread n == 0 of each c also folds
+// dgamma[c] += sum_n s2, dbeta[c] += sum_n s1
+__global__ void gn_bwd_finalize_kernel(const double* __restrict__ s12, const float* __restrict__ gamma,
+                                       const float* __restrict__ mr, int n, int c, int groups, int hw,
+                                       float* __restrict__ coef, float* __restrict__ dgamma,
+                                       float* __restrict__ dbeta) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n * c) return;
+  const int ni = i / c, ci = i - ni * c;
+  const int cpg = c / groups;
+  const int g0 = (ci / cpg) * cpg;
+  double g1 = 0.0, g2 = 0.0;
+  for (int k = 0; k < cpg; ++k) {
+    const double* p = s12 + ((size_t)ni * c + g0 + k) * 2;
+    g1 += (double)gamma[g0 + k] * p[0];
+    g2 += (double)gamma[g0 + k] * p[1];
+  }
+  const double m = (double)cpg * (double)hw;
+  const float rstd = mr[2 * (size_t)i + 1];
+  coef[3 * (size_t)i] = rstd * gamma[ci];
+  coef[3 * (size_t)i + 1] = (float)(rstd * g1 / m);
+  coef[3 * (size_t)i + 2] = (float)(rstd * g2 / m);
+  if (ni == 0) {
+    double dg = 0.0, db = 0.0;
+    for (int k = 0; k < n; ++k) {
+      db += s12[((size_t)k * c + ci) * 2];
+      dg += s12[((size_t)k * c + ci) * 2 + 1];
+    }
+    dgamma[ci] += (float)dg;
+    dbeta[ci] += (float)db;
+  }
+}
+
+// grid = (ceil(hw/256), c0+c1, n).  dx = a*du - b - xhat*c2 (+ addend)
+__global__ __launch_bounds__(256) void gn_bwd_apply_kernel(const float* __restrict__ src0, int c0,
+                                                           const float* __restrict__ src1, int c1,
+                                                           const float* __restrict__ dy, const float* __restrict__ ss,
+                                                           const float* __restrict__ mr,
+                                                           const float* __restrict__ coef, int silu, int hw,
+                                                           const float* __restrict__ add0,
+                                                           const float* __restrict__ add1, float* __restrict__ dx0,
+                                                           float* __restrict__ dx1) {
+  const int c = blockIdx.y, n = blockIdx.z, ct = c0 + c1;
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= hw) return;
+  const bool first = c < c0;
+  const size_t xo = first ? ((size_t)n * c0 + c) * hw + i : ((size_t)n * c1 + (c - c0)) * hw + i;
+  const float x = first ? src0[xo] : src1[xo];
+  const size_t k = (size_t)n * ct + c;
+  const float sc = ss[2 * k], sh = ss[2 * k + 1], mean = mr[2 * k], rstd = mr[2 * k + 1];
+  float du = dy[k * hw + i];
+  if (silu) du *= dsilu(x * sc + sh);
+  float v = coef[3 * k] * du - coef[3 * k + 1] - ((x - mean) * rstd) * coef[3 * k + 2];
+  if (first) {
+    if (add0) v += add0[xo];
+    dx0[xo] = v;
+  } else {
+    if (add1) v += add1[xo];
+    dx1[xo] = v;
+  }
+}
+
+// grid = (c, n): out[n][c] = sum_hw x[n][c][:]
+__global__ __launch_bounds__(256) void channel_sums_kernel(const float* __restrict__ x, int c, int hw,
+                                                           float* __restrict__ out) {
+  const int ci = blockIdx.x, n = blockIdx.y;
+  const float* xp = x + ((size_t)n * c + ci) * hw;
+  double a = 0.0, b = 0.0;
+  for (int i = threadIdx.x; i < hw; i += 256) a += xp[i];
+  block_sum2(a, b);
+  if (threadIdx.x == 0) out[(size_t)n * c + ci] = (float)a;
+}
+
+// dst[c] += sum_n src[n*stride + c]
+__global__ void reduce_rows_kernel(const float* __restrict__ src, int n, int c, int stride, float* __restrict__ dst) {
+  const int ci = blockIdx.x * blockDim.x + threadIdx.x;
+  if (ci >= c) return;
+  double s = 0.0;
+  for (int k = 0; k < n; ++k) s += src[(size_t)k * stride + ci];
+  dst[ci] += (float)s;
+}
+
+// dW[m][k] += sum_n dy[n][m] x[n][k]; one thread per (m, k)
+__global__ void linear_wgrad_kernel(const float* __restrict__ x, const float* __restrict__ dy, int n, int in_f, int out_f,
+                                    int dy_stride, float* __restrict__ dw) {
+  const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (i >= (int64_t)in_f * out_f) return;
+  const int k = (int)(i % in_f), m = (int)(i / in_f);
+  float s = 0.f;
+  for (int j = 0; j < n; ++j) s = fmaf(dy[(size_t)j * dy_stride + m], x[(size_t)j * in_f + k], s);
+  dw[i] += s;
+}
+
+// dx[n][k] = sum_m dy[n][m] W[m][k]; one thread per (n, k)
+__global__ void linear_dgrad_kernel(const float* __restrict__ dy, const float* __restrict__ w, int n, int in_f,
+                                    int out_f, int dy_stride, float* __restrict__ dx) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n * in_f) return;
+  const int k = i % in_f, j = i / in_f;
+  float s = 0.f;
+  for (int m = 0; m < out_f; ++m) s = fmaf(dy[(size_t)j * dy_stride + m], w[(size_t)m * in_f + k], s);
+  dx[i] = s;
+}
+
+// dz = dy * silu'(z)
+__global__ void silu_bwd_kernel(const float* __restrict__ z, const float* __restrict__ dy, int64_t numel,
+                                float* __restrict__ dz) {
+  const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (i < numel) dz[i] = dy[i] * dsilu(z[i]);
+}
+
+// partial[b] = sum over the block's grid-stride slice of (a-b)^2 (or a^2 when b == nullptr); optionally writes
+// dpred = coef * (a - b)
+__global__ __launch_bounds__(256) void sqdiff_partial_kernel(const float* __restrict__ a, const float* __restrict__ b,
+                                                             int64_t numel, float coef, float* __restrict__ dpred,
+                                                             double* __restrict__ partial) {
+  double s = 0.0, z = 0.0;
+  for (int64_t i = blockIdx.x * (int64_t)256 + threadIdx.x; i < numel; i += (int64_t)gridDim.x * 256) {
+    const float d = b ? a[i] - b[i] : a[i];
+    s += (double)d * d;
+    if (dpred) dpred[i] = coef * d;
+  }
+  block_sum2(s, z);
+  if (threadIdx.x == 0) partial[blockIdx.x] = s;
+}
+
+// out[0] = scale * sum(partial) (mode 0) or sqrt(sum(partial)) (mode 1); fixed order -> deterministic
+__global__ void finish_sum_kernel(const double* __restrict__ partial, int nb, double scale, int mode,
+                                  float* __restrict__ out) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  double s = 0.0;
+  for (int i = 0; i < nb; ++i) s += partial[i];
+  out[0] = mode == 0 ? (float)(s * scale) : (float)sqrt(s);
+}
+
+// torch.optim.AdamW single-tensor semantics (decoupled weight decay), gradient scaled on the fly by
+// min(1, max_norm / (total_norm + 1e-6)) (torch.nn.utils.clip_grad_norm_) when total_norm != nullptr.
+__global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const float* __restrict__ g,
+                                                    float* __restrict__ m, float* __restrict__ v, int64_t numel,
+                                                    float lr, float beta1, float beta2, float eps, float wd,
+                                                    float bc1, float bc2_sqrt, const float* __restrict__ total_norm,
+                                                    float max_norm) {
+  float gs = 1.f;
+  if (total_norm) {
+    const float cf = max_norm / (total_norm[0] + 1e-6f);
+    gs = cf < 1.f ? cf : 1.f;
+  }
+  const float step = lr / bc1;
+  for (int64_t i = blockIdx.x * (int64_t)256 + threadIdx.x; i < numel; i += (int64_t)gridDim.x * 256) {
+    const float gi = g[i] * gs;
+    float pi = p[i] * (1.f - lr * wd);
+    const float mi = m[i] + (gi - m[i]) * (1.f - beta1);   // lerp form, as torch
+    const float vi = v[i] * beta2 + (1.f - beta2) * gi * gi;
+    const float denom = sqrtf(vi) / bc2_sqrt + eps;
+    pi -= step * (mi / denom);
+    p[i] = pi;
+    m[i] = mi;
+    v[i] = vi;
+  }
+}
+
+// in-place scale by min(1, max_norm/(norm+1e-6)) -- the standalone form of clip_grad_norm_
+__global__ __launch_bounds__(256) void clip_scale_kernel(float* __restrict__ g, int64_t numel,
+                                                         const float* __restrict__ total_norm, float max_norm) {
+  const float cf = max_norm / (total_norm[0] + 1e-6f);
+  if (cf >= 1.f) return;
+  for (int64_t i = blockIdx.x * (int64_t)256 + threadIdx.x; i < numel; i += (int64_t)gridDim.x * 256) g[i] *= cf;
+}
+
+static inline int stream_blocks2(int64_t numel) {
+  int64_t b = cdiv64(numel, 256 * 4);
+  return (int)(b < 1 ? 1 : (b > 2048 ? 2048 : b));
+}
+
+}  // namespace dsg
+
+using dsg::cdiv;
+
+DSG_API int dsg_gn_bwd(const float* src0, int32_t c0, const float* src1, int32_t c1, const float* dy,
+                       const float* scale_shift, const float* mean_rstd, const float* gamma, int32_t silu, int32_t n,
+                       int32_t hw, int32_t groups, const float* add0, const float* add1, float* dx0, float* dx1,
+                       float* dgamma, float* dbeta, double* ws_s12, float* ws_coef, void* stream) {
+  DSG_CHECK_ARG(src0 && dy && scale_shift && mean_rstd && gamma && dx0 && dgamma && dbeta && ws_s12 && ws_coef,
+                "dsg_gn_bwd: NULL pointer");
+  DSG_CHECK_ARG(c0 > 0 && c1 >= 0 && n > 0 && hw > 0 && groups > 0, "dsg_gn_bwd: bad dims");
+  DSG_CHECK_ARG((c1 == 0) == (src1 == nullptr) && (c1 == 0 || dx1 != nullptr), "dsg_gn_bwd: src1/dx1/c1 mismatch");
+  const int c = c0 + c1;
+  DSG_CHECK_ARG(c % groups == 0, "dsg_gn_bwd: channels not divisible by groups");
+  DSG_CHECK_ARG(n <= 65535 && c <= 65535, "dsg_gn_bwd: grid too large");
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  hipLaunchKernelGGL(dsg::gn_bwd_stats_kernel, dim3(c, n), dim3(256), 0, st, src0, c0, src1, c1, dy, scale_shift,
+                     mean_rstd, silu, hw, ws_s12);
+  DSG_LAUNCH_CHECK();
+  hipLaunchKernelGGL(dsg::gn_bwd_finalize_kernel, dim3(cdiv(n * c, 256)), dim3(256), 0, st, ws_s12, gamma, mean_rstd, n,
+                     c, groups, hw, ws_coef, dgamma, dbeta);
+  DSG_LAUNCH_CHECK();
+  hipLaunchKernelGGL(dsg::gn_bwd_apply_kernel, dim3(cdiv(hw, 256), c, n), dim3(256), 0, st, src0, c0, src1, c1, dy,
+                     scale_shift, mean_rstd, ws_coef, silu, hw, add0, add1, dx0, dx1);
+  DSG_LAUNCH_CHECK();
+  return DSG_OK;
+}
+
+DSG_API int dsg_channel_sums(const float* x, int32_t n, int32_t c, int32_t hw, float* out_nc, void* stream) {
+  DSG_CHECK_ARG(x && out_nc, "dsg_channel_sums: NULL pointer");
+  DSG_CHECK_ARG(n > 0 && c > 0 && hw > 0 && n <= 65535, "dsg_channel_sums: bad dims");
+  hipLaunchKernelGGL(dsg::channel_sums_kernel, dim3(c, n), dim3(256), 0, static_cast<hipStream_t>(stream), x, c, hw,
+                     out_nc);
+  DSG_LAUNCH_CHECK();
+  return DSG_OK;
+}
+
+DSG_API int dsg_reduce_rows_add(const float* src, int32_t n, int32_t c, int32_t stride, float* dst, void* stream) {
+  DSG_CHECK_ARG(src && dst, "dsg_reduce_rows_add: NULL pointer");
+  DSG_CHECK_ARG(n > 0 && c > 0 && stride >= c, "dsg_reduce_rows_add: bad dims");
+  hipLaunchKernelGGL(dsg::reduce_rows_kernel, dim3(cdiv(c, 256)), dim3(256), 0, static_cast<hipStream_t>(stream), src, n,
+                     c, stride, dst);
+  DSG_LAUNCH_CHECK();
+  return DSG_OK;
+}
+
+DSG_API int dsg_linear_bwd(const float* x, const float* w, const float* dy, int32_t dy_stride, int32_t n, int32_t in_f,
+                           int32_t out_f, float* dw, float* db, float* dx, void* stream) {
+  DSG_CHECK_ARG(x && w && dy, "dsg_linear_bwd: NULL pointer");
+  DSG_CHECK_ARG(n > 0 && in_f > 0 && out_f > 0 && dy_stride >= out_f, "dsg_linear_bwd: bad dims");
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  if (dw) {
+    hipLaunchKernelGGL(dsg::linear_wgrad_kernel, dim3((unsigned)dsg::cdiv64((int64_t)in_f * out_f, 256)), dim3(256), 0,
+                       st, x, dy, n, in_f, out_f, dy_stride, dw);
+    DSG_LAUNCH_CHECK();
+  }
+  if (db) {
+    hipLaunchKernelGGL(dsg::reduce_rows_kernel, dim3(cdiv(out_f, 256)), dim3(256), 0, st, dy, n, out_f, dy_stride, db);
+    DSG_LAUNCH_CHECK();
+  }
+  if (dx) {
+    hipLaunchKernelGGL(dsg::linear_dgrad_kernel, dim3(cdiv(n * in_f, 256)), dim3(256), 0, st, dy, w, n, in_f, out_f,
+                       dy_stride, dx);
+    DSG_LAUNCH_CHECK();
+  }
+  return DSG_OK;
+}
+
+DSG_API int dsg_silu_bwd(const float* z, const float* dy, int64_t numel, float* dz, void* stream) {
+  DSG_CHECK_ARG(z && dy && dz && numel > 0, "dsg_silu_bwd: bad argument");
+  hipLaunchKernelGGL(dsg::silu_bwd_kernel, dim3((unsigned)dsg::cdiv64(numel, 256)), dim3(256), 0,
+                     static_cast<hipStream_t>(stream), z, dy, numel, dz);
+  DSG_LAUNCH_CHECK();
+  return DSG_OK;
+}
+
+DSG_API int dsg_mse_loss(const float* pred, const float* target, int64_t numel, float grad_scale, float* loss,
+                         float* dpred, double* ws, size_t ws_bytes, void* stream) {
+  DSG_CHECK_ARG(pred && target && loss && ws && numel > 0, "dsg_mse_loss: bad argument");
+  const int nb = dsg::stream_blocks2(numel);
+  if (ws_bytes < (size_t)nb * sizeof(double))
+    return dsg::fail(DSG_ERR_WORKSPACE_TOO_SMALL, "dsg_mse_loss: workspace %zu < %zu", ws_bytes, (size_t)nb * 8);
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  hipLaunchKernelGGL(dsg::sqdiff_partial_kernel, dim3(nb), dim3(256), 0, st, pred, target, numel,
+                     2.0f * grad_scale / (float)numel, dpred, ws);
+  DSG_LAUNCH_CHECK();
+  hipLaunchKernelGGL(dsg::finish_sum_kernel, dim3(1), dim3(64), 0, st, ws, nb, 1.0 / (double)numel, 0, loss);
+  DSG_LAUNCH_CHECK();
+  return DSG_OK;
+}
+
+DSG_API int dsg_l2_norm(const float* x, int64_t numel, float* norm, double* ws, size_t ws_bytes, void* stream) {
+  DSG_CHECK_ARG(x && norm && ws && numel > 0, "dsg_l2_norm: bad argument");
+  const int nb = dsg::stream_blocks2(numel);
+  if (ws_bytes < (size_t)nb * sizeof(double))
+    return dsg::fail(DSG_ERR_WORKSPACE_TOO_SMALL, "dsg_l2_norm: workspace %zu < %zu", ws_bytes, (size_t)nb * 8);
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  hipLaunchKernelGGL(dsg::sqdiff_partial_kernel, dim3(nb), dim3(256), 0, st, x, (const float*)nullptr, numel, 0.f,
+                     (float*)nullptr, ws);
+  DSG_LAUNCH_CHECK();
+  hipLaunchKernelGGL(dsg::finish_sum_kernel, dim3(1), dim3(64), 0, st, ws, nb, 1.0, 1, norm);
+  DSG_LAUNCH_CHECK();
+  return DSG_OK;
+}
+
+DSG_API int dsg_clip_scale(float* g, int64_t numel, const float* total_norm, float max_norm, void* stream) {
+  DSG_CHECK_ARG(g && total_norm && numel > 0 && max_norm > 0, "dsg_clip_scale: bad argument");
+  hipLaunchKernelGGL(dsg::clip_scale_kernel, dim3(dsg::stream_blocks2(numel)), dim3(256), 0,
+                     static_cast<hipStream_t>(stream), g, numel, total_norm, max_norm);
+  DSG_LAUNCH_CHECK();
+  return DSG_OK;
+}
+
+DSG_API int dsg_adamw_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t numel, double lr,
+                           double beta1, double beta2, double eps, double weight_decay, int64_t step,
+                           const float* total_norm, float max_norm, void* stream) {
+  DSG_CHECK_ARG(param && grad && exp_avg && exp_avg_sq && numel > 0 && step >= 1, "dsg_adamw_step: bad argument");
+  // hyper-parameters arrive as the Python doubles torch.optim.AdamW holds; bias corrections in fp64 like torch
+  const double bc1 = 1.0 - pow(beta1, (double)step);
+  const double bc2 = 1.0 - pow(beta2, (double)step);
+  hipLaunchKernelGGL(dsg::adamw_kernel, dim3(dsg::stream_blocks2(numel)), dim3(256), 0,
+                     static_cast<hipStream_t>(stream), param, grad, exp_avg, exp_avg_sq, numel, (float)lr,
+                     (float)beta1, (float)beta2, (float)eps, (float)weight_decay, (float)bc1, (float)sqrt(bc2),
+                     total_norm, max_norm);
+  DSG_LAUNCH_CHECK();
+  return DSG_OK;
+}

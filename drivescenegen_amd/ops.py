@@ -160,3 +160,164 @@ def postprocess(x, mode=0):
     with torch.cuda.device(x.device):
         _lib.check(_lib.load().dsg_postprocess(_lib.ptr(x.contiguous()), out.data_ptr(), b, c, h * w, mode, _st(x)))
     return out
+
+
+# ---------------------------------------------------------------------------------------------------
+# Training-step ops (backward / loss / optimizer); see include/dsg.h "Training step"
+# ---------------------------------------------------------------------------------------------------
+def conv_wgrad(src0, dy, dw, src1=None, ksize=3, stride=1, upsample=False, gn_scale_shift=None, silu=False,
+               direct=False):
+    """dw[cout][cin][k][k] += wgrad; the activation is recomputed from (src, gn_scale_shift)."""
+    n, c0, hin, win = src0.shape
+    a = _lib.ConvWgradArgs()
+    a.src0, a.src1 = _lib.ptr(src0), _lib.ptr(src1)
+    a.c0, a.c1 = c0, (src1.shape[1] if src1 is not None else 0)
+    a.n, a.hin, a.win = n, hin, win
+    a.upsample, a.ksize, a.stride, a.cout = int(upsample), ksize, stride, dy.shape[1]
+    a.dy, a.gn_scale_shift, a.silu = _lib.ptr(dy), _lib.ptr(gn_scale_shift), int(silu)
+    a.dw, a.force_direct = _lib.ptr(dw), int(direct)
+    with torch.cuda.device(src0.device):
+        _lib.check(_lib.load().dsg_conv2d_wgrad(C.byref(a), _st(src0)))
+    return dw
+
+
+def gn_scale_shift_train(src0, gamma, beta, groups, eps, src1=None):
+    """(scale_shift [N][C][2], mean_rstd [N][C][2]) of GroupNorm over cat(src0, src1)."""
+    lib = _lib.load()
+    n, c0 = src0.shape[0], src0.shape[1]
+    hw = src0.numel() // (n * c0)
+    c1 = src1.shape[1] if src1 is not None else 0
+    c = c0 + c1
+    stats = torch.empty((n, c, 2), dtype=torch.float64, device=src0.device)
+    ss = torch.empty((n, c, 2), dtype=torch.float32, device=src0.device)
+    mr = torch.empty((n, c, 2), dtype=torch.float32, device=src0.device)
+    with torch.cuda.device(src0.device):
+        _lib.check(lib.dsg_gn_channel_stats(_lib.ptr(src0), c0, _lib.ptr(src1), c1, n, hw, _lib.ptr(stats),
+                                            _st(src0)))
+        _lib.check(lib.dsg_gn_finalize_train(_lib.ptr(stats), _lib.ptr(gamma), _lib.ptr(beta), n, c, groups, hw,
+                                             float(eps), _lib.ptr(ss), _lib.ptr(mr), _st(src0)))
+    return ss, mr
+
+
+def gn_bwd(src0, dy, ss, mr, gamma, groups, silu, dgamma, dbeta, src1=None, add0=None, add1=None):
+    """Backward of silu?(GroupNorm(cat(src0, src1))); returns (dx0, dx1); dgamma/dbeta accumulated."""
+    n, c0 = src0.shape[0], src0.shape[1]
+    hw = src0.numel() // (n * c0)
+    c1 = src1.shape[1] if src1 is not None else 0
+    c = c0 + c1
+    dx0 = torch.empty_like(src0)
+    dx1 = torch.empty_like(src1) if src1 is not None else None
+    s12 = torch.empty((n, c, 2), dtype=torch.float64, device=src0.device)
+    coef = torch.empty((n, c, 3), dtype=torch.float32, device=src0.device)
+    with torch.cuda.device(src0.device):
+        _lib.check(_lib.load().dsg_gn_bwd(_lib.ptr(src0), c0, _lib.ptr(src1), c1, _lib.ptr(dy), _lib.ptr(ss),
+                                         _lib.ptr(mr), _lib.ptr(gamma), int(silu), n, hw, groups, _lib.ptr(add0),
+                                         _lib.ptr(add1), _lib.ptr(dx0), _lib.ptr(dx1), _lib.ptr(dgamma),
+                                         _lib.ptr(dbeta), _lib.ptr(s12), _lib.ptr(coef), _st(src0)))
+    return dx0, dx1
+
+
+def channel_sums(x):
+    """[N, C, ...] -> [N, C] sums over the trailing dims."""
+    n, c = x.shape[0], x.shape[1]
+    out = torch.empty((n, c), dtype=torch.float32, device=x.device)
+    with torch.cuda.device(x.device):
+        _lib.check(_lib.load().dsg_channel_sums(_lib.ptr(x), n, c, x.numel() // (n * c), _lib.ptr(out), _st(x)))
+    return out
+
+
+def reduce_rows_add(src, dst, stride=None):
+    """dst[c] += sum_n src[n, c]  (src rows `stride` floats apart)."""
+    n = src.shape[0]
+    c = dst.numel()
+    with torch.cuda.device(src.device):
+        _lib.check(_lib.load().dsg_reduce_rows_add(src.data_ptr(), n, c, stride or src.stride(0), _lib.ptr(dst),
+                                                   _st(src)))
+    return dst
+
+
+def attention_train(qkv, heads):
+    n, c3, l = qkv.shape
+    c = c3 // 3
+    out = torch.empty((n, c, l), dtype=torch.float32, device=qkv.device)
+    lse = torch.empty((n, heads, l), dtype=torch.float32, device=qkv.device)
+    with torch.cuda.device(qkv.device):
+        _lib.check(_lib.load().dsg_attention_fwd_train(_lib.ptr(qkv), _lib.ptr(out), _lib.ptr(lse), n, c, heads, l,
+                                                      _st(qkv)))
+    return out, lse
+
+
+def attention_bwd(qkv, out, dout, lse, heads):
+    n, c3, l = qkv.shape
+    c = c3 // 3
+    dqkv = torch.empty_like(qkv)
+    dsum = torch.empty((n, heads, l), dtype=torch.float32, device=qkv.device)
+    with torch.cuda.device(qkv.device):
+        _lib.check(_lib.load().dsg_attention_bwd(_lib.ptr(qkv), _lib.ptr(out), _lib.ptr(dout.contiguous()),
+                                                _lib.ptr(lse), _lib.ptr(dqkv), _lib.ptr(dsum), n, c, heads, l,
+                                                _st(qkv)))
+    return dqkv
+
+
+def linear_bwd(x, w, dy, dw=None, db=None, need_dx=True, dy_stride=None):
+    """Backward of y = x W^T + b; dw/db accumulated in place; returns dx or None."""
+    n, in_f = x.shape
+    out_f = w.shape[0]
+    dx = torch.empty((n, in_f), dtype=torch.float32, device=x.device) if need_dx else None
+    with torch.cuda.device(x.device):
+        _lib.check(_lib.load().dsg_linear_bwd(_lib.ptr(x), _lib.ptr(w), dy.data_ptr(), dy_stride or dy.stride(0), n,
+                                             in_f, out_f, _lib.ptr(dw), _lib.ptr(db), _lib.ptr(dx), _st(x)))
+    return dx
+
+
+def silu_bwd(z, dy):
+    dz = torch.empty_like(z)
+    with torch.cuda.device(z.device):
+        _lib.check(_lib.load().dsg_silu_bwd(_lib.ptr(z), _lib.ptr(dy.contiguous()), z.numel(), _lib.ptr(dz), _st(z)))
+    return dz
+
+
+_WS = {}
+
+
+def _reduce_ws(device):
+    key = str(device)
+    if key not in _WS:
+        _WS[key] = torch.empty(2048, dtype=torch.float64, device=device)
+    return _WS[key]
+
+
+def mse_loss(pred, target, grad_scale=1.0, need_grad=True):
+    """(loss [1] fp32 device tensor, dpred or None): F.mse_loss(pred, target) and its gradient * grad_scale."""
+    loss = torch.empty(1, dtype=torch.float32, device=pred.device)
+    dpred = torch.empty_like(pred) if need_grad else None
+    ws = _reduce_ws(pred.device)
+    with torch.cuda.device(pred.device):
+        _lib.check(_lib.load().dsg_mse_loss(_lib.ptr(pred.contiguous()), _lib.ptr(target.contiguous()), pred.numel(),
+                                           float(grad_scale), _lib.ptr(loss), _lib.ptr(dpred), _lib.ptr(ws),
+                                           ws.numel() * 8, _st(pred)))
+    return loss, dpred
+
+
+def l2_norm(x):
+    out = torch.empty(1, dtype=torch.float32, device=x.device)
+    ws = _reduce_ws(x.device)
+    with torch.cuda.device(x.device):
+        _lib.check(_lib.load().dsg_l2_norm(_lib.ptr(x), x.numel(), _lib.ptr(out), _lib.ptr(ws), ws.numel() * 8,
+                                          _st(x)))
+    return out
+
+
+def clip_scale_(g, total_norm, max_norm):
+    with torch.cuda.device(g.device):
+        _lib.check(_lib.load().dsg_clip_scale(_lib.ptr(g), g.numel(), _lib.ptr(total_norm), float(max_norm), _st(g)))
+    return g
+
+
+def adamw_step_(param, grad, exp_avg, exp_avg_sq, step, lr, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2,
+                total_norm=None, max_norm=0.0):
+    with torch.cuda.device(param.device):
+        _lib.check(_lib.load().dsg_adamw_step(_lib.ptr(param), _lib.ptr(grad), _lib.ptr(exp_avg),
+                                             _lib.ptr(exp_avg_sq), param.numel(), float(lr), float(betas[0]),
+                                             float(betas[1]), float(eps), float(weight_decay), int(step),
+                                             _lib.ptr(total_norm), float(max_norm), _st(param)))

@@ -181,6 +181,65 @@ int dsg_unet_forward(dsg_unet_t* h, const float* x, const int64_t* timesteps, fl
                      void* workspace, size_t workspace_bytes, void* stream);
 
 /* ------------------------------------------------------------------------------------------
+ * Training step (training_pipeline.py:70-97): backward of the layers above, loss, clip, optimizer.
+ *   loss = F.mse_loss(model(noisy, t), noise)      :84-85     dsg_mse_loss
+ *   accelerator.backward(loss)                      :86        dsg_conv2d_wgrad, dsg_conv2d_fwd with
+ *                                                              dsg_conv_weight_relayout_dgrad weights,
+ *                                                              dsg_gn_bwd, dsg_attention_bwd, dsg_linear_bwd,
+ *                                                              dsg_silu_bwd, dsg_channel_sums
+ *   accelerator.clip_grad_norm_(params, 1.0)        :88        dsg_l2_norm (+ dsg_clip_scale, or fused below)
+ *   optimizer.step()  (torch.optim.AdamW, train.py:66)  :89    dsg_adamw_step
+ * ---------------------------------------------------------------------------------------- */
+typedef struct {
+  const float* src0;            /* saved conv INPUT before norm/activation: [N, c0, hin, win] */
+  const float* src1;            /* optional second source (channel concat) */
+  int32_t c0, c1;
+  int32_t n, hin, win;
+  int32_t upsample;             /* 1: the conv ran on the nearest x2 upsampled source */
+  int32_t ksize, stride;
+  int32_t cout;
+  const float* dy;              /* [N, cout, hout, wout] */
+  const float* gn_scale_shift;  /* optional [N][c0+c1][2]: the activation is recomputed in the gather */
+  int32_t silu;
+  float* dw;                    /* [cout][c0+c1][k][k] (OIHW, checkpoint layout); ACCUMULATED into */
+  int32_t force_direct;         /* test hook: VALU reference kernel */
+} dsg_conv_wgrad_args;
+int dsg_conv2d_wgrad(const dsg_conv_wgrad_args* a, void* stream);
+
+/* GroupNorm(+SiLU) backward over cat(src0, src1).  dx = d/dx of silu?(gn(x)) . dy (+ add); dgamma/dbeta are
+ * accumulated.  ws_s12: [N][C][2] doubles, ws_coef: [N][C][3] floats. */
+int dsg_gn_finalize_train(const double* chan_stats, const float* gamma, const float* beta, int32_t n, int32_t c,
+                          int32_t groups, int32_t hw, float eps, float* scale_shift, float* mean_rstd /* [N][C][2] */,
+                          void* stream);
+int dsg_gn_bwd(const float* src0, int32_t c0, const float* src1, int32_t c1, const float* dy,
+               const float* scale_shift, const float* mean_rstd, const float* gamma, int32_t silu, int32_t n,
+               int32_t hw, int32_t groups, const float* add0, const float* add1, float* dx0, float* dx1,
+               float* dgamma, float* dbeta, double* ws_s12, float* ws_coef, void* stream);
+int dsg_channel_sums(const float* x, int32_t n, int32_t c, int32_t hw, float* out_nc, void* stream);
+int dsg_reduce_rows_add(const float* src, int32_t n, int32_t c, int32_t stride, float* dst, void* stream);
+/* attention: forward that also returns the log2-domain log-sum-exp [N][heads][L], and the backward
+ * (dqkv [N][3C][L]; dsum_ws [N][heads][L] scratch). */
+int dsg_attention_fwd_train(const float* qkv, float* out, float* lse, int32_t n, int32_t c, int32_t heads, int32_t l,
+                            void* stream);
+int dsg_attention_bwd(const float* qkv, const float* out, const float* dout, const float* lse, float* dqkv,
+                      float* dsum_ws, int32_t n, int32_t c, int32_t heads, int32_t l, void* stream);
+/* y = x W^T + b backward: dw [out][in] and db [out] are accumulated (skipped when NULL), dx [n][in] written. */
+int dsg_linear_bwd(const float* x, const float* w, const float* dy, int32_t dy_stride, int32_t n, int32_t in_f,
+                   int32_t out_f, float* dw, float* db, float* dx, void* stream);
+int dsg_silu_bwd(const float* z, const float* dy, int64_t numel, float* dz, void* stream);
+/* loss[0] = mean((pred-target)^2); dpred = grad_scale * 2 (pred-target) / numel (skipped when NULL).
+ * ws: >= 2048 doubles. */
+int dsg_mse_loss(const float* pred, const float* target, int64_t numel, float grad_scale, float* loss, float* dpred,
+                 double* ws, size_t ws_bytes, void* stream);
+int dsg_l2_norm(const float* x, int64_t numel, float* norm, double* ws, size_t ws_bytes, void* stream);
+int dsg_clip_scale(float* g, int64_t numel, const float* total_norm, float max_norm, void* stream);
+/* One fused AdamW update of a flat parameter slab (torch.optim.AdamW semantics: decoupled decay, lerp, bias
+ * corrections).  total_norm != NULL applies clip_grad_norm_'s factor min(1, max_norm/(norm+1e-6)) on the fly. */
+int dsg_adamw_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t numel, double lr,
+                   double beta1, double beta2, double eps, double weight_decay, int64_t step,
+                   const float* total_norm, float max_norm, void* stream);
+
+/* ------------------------------------------------------------------------------------------
  * Measurement plumbing (no reference counterpart): per-kernel-class HIP-event timing on the launch
  * stream, used by bench.py's roofline leg.  Classes: 0 conv3x3 stride-1, 1 conv3x3 on the nearest-x2
  * upsampled input, 2 conv3x3 stride-2, 3 conv1x1, 4 direct (VALU) conv.  FLOPs/bytes are the

@@ -1,0 +1,163 @@
+"""Parity of the backward / loss / optimizer kernels (through the C ABI) against torch-CPU autograd."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+from drivescenegen_amd import ops, synth  # noqa: E402
+from tests.common import max_abs, rel_l2  # noqa: E402
+
+DEV = "cuda"
+
+
+def _t(seed, shape, scale=1.0):
+    return torch.from_numpy((synth.normal(seed, shape) * float(scale)).astype(np.float32))
+
+
+def _close(got, want, rel=2e-5, ab=2e-5):
+    got = got.cpu()
+    assert got.shape == want.shape, (got.shape, want.shape)
+    assert torch.isfinite(got).all()
+    assert rel_l2(got, want) <= rel, rel_l2(got, want)
+    assert max_abs(got, want) <= ab * max(1.0, float(want.abs().max())), max_abs(got, want)
+
+
+WG_CASES = [
+    # name, c0, c1, cout, h, w, k, stride, ups, gn
+    ("res64", 64, 0, 64, 16, 32, 3, 1, False, True),
+    ("cat_straddle", 128, 64, 128, 8, 32, 3, 1, False, True),
+    ("cin32_cit1", 32, 0, 64, 16, 32, 3, 1, False, True),
+    ("upsample", 64, 0, 64, 8, 16, 3, 1, True, False),
+    ("stride2", 64, 0, 64, 16, 64, 3, 2, False, False),
+    ("shortcut_1x1", 96, 32, 64, 8, 32, 1, 1, False, False),
+    ("conv_in_c3", 3, 0, 32, 16, 32, 3, 1, False, False),
+    ("conv_out_c3", 64, 0, 3, 16, 32, 3, 1, False, True),
+    ("odd_direct", 16, 0, 8, 6, 10, 3, 1, False, True),
+]
+
+
+@pytest.mark.parametrize("case", WG_CASES, ids=[c[0] for c in WG_CASES])
+def test_conv_backward(case):
+    """wgrad (MFMA + VALU reference) and dgrad (forward kernel with transposed/flipped weights, zero-stuffed
+    gather for stride 2, 2x2 sum-pool for the upsampler) against torch autograd."""
+    name, c0, c1, cout, h, w, k, stride, ups, gn = case
+    batch, cin = 3, c0 + c1
+    x0 = _t(1, (batch, c0, h, w)).requires_grad_(True)
+    x1 = _t(2, (batch, c1, h, w)).requires_grad_(True) if c1 else None
+    wt = _t(3, (cout, cin, k, k), 1.0 / np.sqrt(cin * k * k)).requires_grad_(True)
+    groups = 8 if cin % 8 == 0 else 1
+    gamma, beta = 1 + _t(5, (cin,), 0.1), _t(6, (cin,), 0.1)
+    xin = torch.cat([x0, x1], 1) if c1 else x0
+    a = F.silu(F.group_norm(xin, groups, gamma, beta, 1e-5)) if gn else xin
+    a.retain_grad()
+    u = F.interpolate(a, scale_factor=2.0, mode="nearest") if ups else a
+    y = F.conv2d(u, wt, None, stride=stride, padding=k // 2)
+    dy = _t(9, tuple(y.shape))
+    y.backward(dy)
+
+    d = lambda t: None if t is None else t.detach().to(DEV)
+    ss = ops.gn_scale_shift(d(x0), d(gamma), d(beta), groups, 1e-5, src1=d(x1)) if gn else None
+    for direct in (False, True):
+        dw = torch.zeros_like(wt.detach()).to(DEV)
+        ops.conv_wgrad(d(x0), d(dy), dw, src1=d(x1), ksize=k, stride=stride, upsample=ups, gn_scale_shift=ss,
+                       silu=gn, direct=direct)
+        _close(dw, wt.grad, rel=3e-5, ab=3e-5)
+    # data gradient w.r.t. the conv input `a` (post-activation tensor)
+    wd = ops.relayout_conv_weight_dgrad(d(wt))
+    if stride == 2:
+        da = ops.conv2d_fused(d(dy), wd, ksize=k, stride=1, upsample=2, cout=cin)
+    elif ups:
+        da = ops.conv2d_fused(d(dy), wd, ksize=k, stride=1, cout=cin, pool2=True)
+    else:
+        da = ops.conv2d_fused(d(dy), wd, ksize=k, stride=1, cout=cin)
+    _close(da, a.grad, rel=3e-5, ab=3e-5)
+
+
+@pytest.mark.parametrize("c0,c1,groups,hw,silu", [(64, 0, 32, (16, 16), True), (128, 64, 32, (8, 16), True),
+                                                  (32, 0, 32, (8, 24), False), (64, 0, 32, (64, 64), True)])
+def test_groupnorm_backward(c0, c1, groups, hw, silu):
+    h, w = hw
+    x0 = (_t(21, (2, c0, h, w)) * 2 + 0.7).requires_grad_(True)
+    x1 = (_t(22, (2, c1, h, w)) - 0.3).requires_grad_(True) if c1 else None
+    c = c0 + c1
+    gamma = (1 + _t(23, (c,), 0.2)).requires_grad_(True)
+    beta = _t(24, (c,), 0.2).requires_grad_(True)
+    xin = torch.cat([x0, x1], 1) if c1 else x0
+    y = F.group_norm(xin, groups, gamma, beta, 1e-5)
+    y = F.silu(y) if silu else y
+    dy = _t(25, tuple(y.shape))
+    y.backward(dy)
+    d = lambda t: None if t is None else t.detach().to(DEV)
+    ss, mr = ops.gn_scale_shift_train(d(x0), d(gamma), d(beta), groups, 1e-5, src1=d(x1))
+    dg, db = torch.zeros(c, device=DEV), torch.zeros(c, device=DEV)
+    add0 = _t(26, tuple(x0.shape))
+    dx0, dx1 = ops.gn_bwd(d(x0), d(dy), ss, mr, d(gamma), groups, silu, dg, db, src1=d(x1), add0=d(add0))
+    _close(dx0, x0.grad + add0, rel=2e-5, ab=2e-5)
+    if c1:
+        _close(dx1, x1.grad, rel=2e-5, ab=2e-5)
+    _close(dg, gamma.grad, rel=2e-5, ab=1e-4)
+    _close(db, beta.grad, rel=2e-5, ab=1e-4)
+
+
+@pytest.mark.parametrize("n,c,heads,l", [(2, 64, 8, 1024), (1, 32, 4, 256), (1, 32, 2, 200)])
+def test_attention_backward(n, c, heads, l):
+    qkv = _t(31, (n, 3 * c, l), 1.2).requires_grad_(True)
+    dd = c // heads
+    q, k, v = [qkv[:, i * c:(i + 1) * c].view(n, heads, dd, l).transpose(2, 3) for i in range(3)]
+    o = F.scaled_dot_product_attention(q, k, v).transpose(2, 3).reshape(n, c, l)
+    do = _t(32, (n, c, l))
+    o.backward(do)
+    out, lse = ops.attention_train(qkv.detach().to(DEV), heads)
+    _close(out, o.detach(), rel=1e-5, ab=1e-5)
+    dqkv = ops.attention_bwd(qkv.detach().to(DEV), out, do.to(DEV), lse, heads)
+    _close(dqkv, qkv.grad, rel=2e-5, ab=2e-5)
+
+
+def test_linear_silu_backward_and_sums():
+    n, kf, mf = 5, 64, 96
+    x = _t(41, (n, kf)).requires_grad_(True)
+    w = _t(42, (mf, kf), 0.2).requires_grad_(True)
+    b = _t(43, (mf,), 0.1).requires_grad_(True)
+    z = F.linear(x, w, b)
+    y = F.silu(z)
+    dy = _t(44, (n, mf))
+    y.backward(dy)
+    dz = ops.silu_bwd(z.detach().to(DEV), dy.to(DEV))
+    dw, db = torch.zeros(mf, kf, device=DEV), torch.zeros(mf, device=DEV)
+    dx = ops.linear_bwd(x.detach().to(DEV), w.detach().to(DEV), dz, dw, db)
+    _close(dx, x.grad)
+    _close(dw, w.grad)
+    _close(db, b.grad)
+    t = _t(45, (3, 7, 9, 11))
+    _close(ops.channel_sums(t.to(DEV)), t.sum((2, 3)), rel=1e-6, ab=1e-5)
+    acc = torch.ones(7, device=DEV)
+    _close(ops.reduce_rows_add(ops.channel_sums(t.to(DEV)), acc), 1 + t.sum((0, 2, 3)), rel=1e-6, ab=1e-5)
+
+
+def test_mse_norm_adamw_match_torch():
+    pred, tgt = _t(51, (4, 3, 32, 32)).requires_grad_(True), _t(52, (4, 3, 32, 32))
+    loss = F.mse_loss(pred, tgt)
+    loss.backward()
+    gl, gd = ops.mse_loss(pred.detach().to(DEV), tgt.to(DEV))
+    assert abs(float(gl.cpu()) - float(loss)) <= 1e-6 * float(loss)
+    _close(gd, pred.grad, rel=1e-6, ab=1e-7)
+    # clip_grad_norm_ + AdamW over 3 steps on a flat slab vs torch.optim.AdamW (train.py:66 defaults, lr 1e-5)
+    p_ref = torch.nn.Parameter(_t(53, (5000,)))
+    opt = torch.optim.AdamW([p_ref], lr=1e-3)
+    p = p_ref.detach().clone().to(DEV)
+    m, v = torch.zeros_like(p), torch.zeros_like(p)
+    for step in range(1, 4):
+        g = _t(60 + step, (5000,), 3.0)
+        p_ref.grad = g.clone()
+        tn_ref = torch.nn.utils.clip_grad_norm_([p_ref], 1.0)
+        opt.step()
+        gg = g.to(DEV)
+        tn = ops.l2_norm(gg)
+        assert abs(float(tn.cpu()) - float(tn_ref)) <= 1e-5 * float(tn_ref)
+        ops.adamw_step_(p, gg, m, v, step, lr=1e-3, total_norm=tn, max_norm=1.0)
+        _close(p, p_ref.detach(), rel=1e-6, ab=1e-6)
+    gg = _t(70, (5000,), 3.0).to(DEV)
+    want = gg.cpu() * min(1.0, 1.0 / (float(gg.norm().cpu()) + 1e-6))
+    _close(ops.clip_scale_(gg, ops.l2_norm(gg), 1.0), want, rel=1e-6, ab=1e-6)
