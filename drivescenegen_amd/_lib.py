@@ -47,7 +47,8 @@ class ConvWgradArgs(C.Structure):
         ("c0", C.c_int32), ("c1", C.c_int32),
         ("n", C.c_int32), ("hin", C.c_int32), ("win", C.c_int32),
         ("upsample", C.c_int32), ("ksize", C.c_int32), ("stride", C.c_int32), ("cout", C.c_int32),
-        ("dy", C.c_void_p), ("gn_scale_shift", C.c_void_p), ("silu", C.c_int32),
+        ("dy", C.c_void_p), ("dy_ctotal", C.c_int32), ("dy_coff", C.c_int32),
+        ("gn_scale_shift", C.c_void_p), ("silu", C.c_int32),
         ("dw", C.c_void_p), ("force_direct", C.c_int32),
     ]
 
@@ -93,11 +94,15 @@ SIGNATURES = {
     "dsg_gn_finalize_train": [_vp, _vp, _vp, _i32, _i32, _i32, _i32, _f32, _vp, _vp, _vp],
     "dsg_gn_bwd": [_vp, _i32, _vp, _i32, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp,
                    _vp, _vp, _vp],
-    "dsg_channel_sums": [_vp, _i32, _i32, _i32, _vp, _vp],
+    "dsg_channel_sums": [_vp, _i32, _i32, _i32, _vp, _i32, _vp],
+    "dsg_add": [_vp, _vp, _i64, _vp, _vp],
+    "dsg_time_embed_fwd_train": [_vp, _vp, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "dsg_reduce_rows_add": [_vp, _i32, _i32, _i32, _vp, _vp],
     "dsg_attention_fwd_train": [_vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp],
     "dsg_attention_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp],
     "dsg_linear_bwd": [_vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp],
+    "dsg_scale": [_vp, _i64, _vp, _f32, _vp, _vp],
+    "dsg_silu_fwd": [_vp, _i64, _vp, _vp],
     "dsg_silu_bwd": [_vp, _vp, _i64, _vp, _vp],
     "dsg_mse_loss": [_vp, _vp, _i64, _f32, _vp, _vp, _vp, _sz, _vp],
     "dsg_l2_norm": [_vp, _i64, _vp, _vp, _sz, _vp],

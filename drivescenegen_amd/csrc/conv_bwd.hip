@@ -34,7 +34,8 @@ struct WgradP {
   int hc, wc;       // conv-input dims (after optional nearest upsample)
   int hout, wout;
   int cout;
-  const float* dy;  // [N, cout, hout, wout]
+  const float* dy;  // [N, dy_ctotal, hout, wout]; this conv's channels start at dy_coff
+  int dy_ctotal, dy_coff;
   const float* ss;  // optional [N][cin][2]
   int silu;
   float* dw;  // [cout][cin][taps], accumulated
@@ -148,7 +149,8 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(WgradP p) {
       const int gco = co0 + co;
       float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
       if (gco < p.cout)
-        v = *reinterpret_cast<const float4*>(p.dy + ((size_t)n * p.cout + gco) * oplane + (size_t)(oy0 + row) * p.wout +
+        v = *reinterpret_cast<const float4*>(p.dy + ((size_t)n * p.dy_ctotal + p.dy_coff + gco) * oplane +
+                                             (size_t)(oy0 + row) * p.wout +
                                              ox0 + q4 * 4);
       dr[i] = v;
     }
@@ -224,7 +226,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_direct_kernel(WgradP p, int ks
       sc = p.ss[((size_t)n * p.cin + ci) * 2];
       sh = p.ss[((size_t)n * p.cin + ci) * 2 + 1];
     }
-    const float* dp = p.dy + ((size_t)n * p.cout + co) * p.hout * p.wout;
+    const float* dp = p.dy + ((size_t)n * p.dy_ctotal + p.dy_coff + co) * p.hout * p.wout;
     for (int oy = 0; oy < p.hout; ++oy) {
       const int gy = oy * stride - pad + dyk;
       if (gy < 0 || gy >= p.hc) continue;
@@ -281,6 +283,8 @@ DSG_API int dsg_conv2d_wgrad(const dsg_conv_wgrad_args* a, void* stream) {
   DSG_CHECK_ARG(a->stride == 1 || a->stride == 2, "dsg_conv2d_wgrad: stride must be 1 or 2");
   DSG_CHECK_ARG(a->upsample == 0 || a->upsample == 1, "dsg_conv2d_wgrad: upsample must be 0 or 1");
   DSG_CHECK_ARG(!(a->upsample && a->stride != 1), "dsg_conv2d_wgrad: upsample requires stride 1");
+  DSG_CHECK_ARG(a->dy_coff >= 0 && (a->dy_ctotal == 0 || a->dy_coff + a->cout <= a->dy_ctotal),
+                "dsg_conv2d_wgrad: dy channel window out of range");
   hipStream_t st = static_cast<hipStream_t>(stream);
   WgradP p;
   p.src0 = a->src0; p.src1 = a->src1; p.c0 = a->c0; p.c1 = a->c1; p.cin = a->c0 + a->c1;
@@ -290,7 +294,8 @@ DSG_API int dsg_conv2d_wgrad(const dsg_conv_wgrad_args* a, void* stream) {
   const int pad = a->ksize / 2;
   p.hout = (p.hc + 2 * pad - a->ksize) / a->stride + 1;
   p.wout = (p.wc + 2 * pad - a->ksize) / a->stride + 1;
-  p.cout = a->cout; p.dy = a->dy; p.ss = a->gn_scale_shift; p.silu = a->silu; p.dw = a->dw;
+  p.cout = a->cout; p.dy = a->dy; p.dy_ctotal = a->dy_ctotal ? a->dy_ctotal : a->cout; p.dy_coff = a->dy_coff;
+  p.ss = a->gn_scale_shift; p.silu = a->silu; p.dw = a->dw;
   p.tiles_x = p.wout / 32; p.tiles_y = p.hout / WG_SR; p.ntiles = p.tiles_x * p.tiles_y * p.n; p.ci_blocks = 1;
   const bool tile_ok = (p.wout % 32 == 0) && (p.hout % WG_SR == 0) && !a->force_direct;
   if (tile_ok) {

@@ -14,7 +14,8 @@ __global__ __launch_bounds__(256) void time_embed_kernel(const int64_t* __restri
                                                          const float* __restrict__ freqs, int ch, int dim,
                                                          const float* __restrict__ w1, const float* __restrict__ b1,
                                                          const float* __restrict__ w2, const float* __restrict__ b2,
-                                                         float* __restrict__ act) {
+                                                         float* __restrict__ act, float* __restrict__ emb_out,
+                                                         float* __restrict__ z1_out, float* __restrict__ z2_out) {
   extern __shared__ __attribute__((aligned(16))) float sm[];
   float* e = sm;        // [ch] sinusoid, cos first (flip_sin_to_cos=True, freq_shift=0)
   float* h1 = sm + ch;  // [dim]
@@ -29,10 +30,13 @@ __global__ __launch_bounds__(256) void time_embed_kernel(const int64_t* __restri
     e[half + i] = sinf(a);
   }
   __syncthreads();
+  if (emb_out)
+    for (int i = threadIdx.x; i < ch; i += 256) emb_out[(size_t)n * ch + i] = e[i];
   for (int j = threadIdx.x; j < dim; j += 256) {
     const float* wr = w1 + (size_t)j * ch;
     float s = 0.f;
     for (int k = 0; k < ch; ++k) s = fmaf(wr[k], e[k], s);
+    if (z1_out) z1_out[(size_t)n * dim + j] = s + b1[j];
     h1[j] = silu_f(s + b1[j]);
   }
   __syncthreads();
@@ -40,6 +44,7 @@ __global__ __launch_bounds__(256) void time_embed_kernel(const int64_t* __restri
     const float* wr = w2 + (size_t)j * dim;
     float s = 0.f;
     for (int k = 0; k < dim; ++k) s = fmaf(wr[k], h1[k], s);
+    if (z2_out) z2_out[(size_t)n * dim + j] = s + b2[j];
     act[(size_t)n * dim + j] = silu_f(s + b2[j]);
   }
 }
@@ -65,17 +70,31 @@ __global__ __launch_bounds__(256) void linear_rows_kernel(const float* __restric
 
 }  // namespace dsg
 
-DSG_API int dsg_time_embed_fwd(const int64_t* timesteps, const float* freqs, int32_t n, int32_t ch, int32_t dim,
-                               const float* w1, const float* b1, const float* w2, const float* b2, float* act,
-                               void* stream) {
+static int time_embed_impl(const int64_t* timesteps, const float* freqs, int32_t n, int32_t ch, int32_t dim,
+                           const float* w1, const float* b1, const float* w2, const float* b2, float* act,
+                           float* emb, float* z1, float* z2, void* stream) {
   DSG_CHECK_ARG(timesteps && freqs && w1 && b1 && w2 && b2 && act, "dsg_time_embed_fwd: NULL pointer");
   DSG_CHECK_ARG(n > 0 && ch > 0 && (ch % 2) == 0 && dim > 0, "dsg_time_embed_fwd: bad dims");
   const size_t lds = (size_t)(ch + dim) * sizeof(float);
   DSG_CHECK_SHAPE(lds <= 64 * 1024, "dsg_time_embed_fwd: ch + dim too large (%d + %d)", ch, dim);
   hipLaunchKernelGGL(dsg::time_embed_kernel, dim3(n), dim3(256), lds, static_cast<hipStream_t>(stream), timesteps,
-                     freqs, ch, dim, w1, b1, w2, b2, act);
+                     freqs, ch, dim, w1, b1, w2, b2, act, emb, z1, z2);
   DSG_LAUNCH_CHECK();
   return DSG_OK;
+}
+
+DSG_API int dsg_time_embed_fwd(const int64_t* timesteps, const float* freqs, int32_t n, int32_t ch, int32_t dim,
+                               const float* w1, const float* b1, const float* w2, const float* b2, float* act,
+                               void* stream) {
+  return time_embed_impl(timesteps, freqs, n, ch, dim, w1, b1, w2, b2, act, nullptr, nullptr, nullptr, stream);
+}
+
+// Training variant: also returns the sinusoid [N][ch] and the two pre-activations [N][dim] for the backward.
+DSG_API int dsg_time_embed_fwd_train(const int64_t* timesteps, const float* freqs, int32_t n, int32_t ch, int32_t dim,
+                                     const float* w1, const float* b1, const float* w2, const float* b2, float* act,
+                                     float* emb, float* z1, float* z2, void* stream) {
+  DSG_CHECK_ARG(emb && z1 && z2, "dsg_time_embed_fwd_train: NULL pointer");
+  return time_embed_impl(timesteps, freqs, n, ch, dim, w1, b1, w2, b2, act, emb, z1, z2, stream);
 }
 
 DSG_API int dsg_linear_fwd(const float* x, const float* w, const float* b, float* y, int32_t n, int32_t in_f,

@@ -134,13 +134,13 @@ __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(const float* __restri
 
 // grid = (c, n): out[n][c] = sum_hw x[n][c][:]
 __global__ __launch_bounds__(256) void channel_sums_kernel(const float* __restrict__ x, int c, int hw,
-                                                           float* __restrict__ out) {
+                                                           float* __restrict__ out, int out_stride) {
   const int ci = blockIdx.x, n = blockIdx.y;
   const float* xp = x + ((size_t)n * c + ci) * hw;
   double a = 0.0, b = 0.0;
   for (int i = threadIdx.x; i < hw; i += 256) a += xp[i];
   block_sum2(a, b);
-  if (threadIdx.x == 0) out[(size_t)n * c + ci] = (float)a;
+  if (threadIdx.x == 0) out[(size_t)n * out_stride + ci] = (float)a;
 }
 
 // dst[c] += sum_n src[n*stride + c]
@@ -150,6 +150,13 @@ __global__ void reduce_rows_kernel(const float* __restrict__ src, int n, int c, 
   double s = 0.0;
   for (int k = 0; k < n; ++k) s += src[(size_t)k * stride + ci];
   dst[ci] += (float)s;
+}
+
+// out = a + b (gradient fan-in of a tensor with several consumers)
+__global__ __launch_bounds__(256) void add2_kernel(const float* __restrict__ a, const float* __restrict__ b,
+                                                   int64_t numel, float* __restrict__ out) {
+  for (int64_t i = blockIdx.x * (int64_t)256 + threadIdx.x; i < numel; i += (int64_t)gridDim.x * 256)
+    out[i] = a[i] + b[i];
 }
 
 // dW[m][k] += sum_n dy[n][m] x[n][k]; one thread per (m, k)
@@ -172,6 +179,11 @@ __global__ void linear_dgrad_kernel(const float* __restrict__ dy, const float* _
   float s = 0.f;
   for (int m = 0; m < out_f; ++m) s = fmaf(dy[(size_t)j * dy_stride + m], w[(size_t)m * in_f + k], s);
   dx[i] = s;
+}
+
+__global__ void silu_fwd_kernel(const float* __restrict__ z, int64_t numel, float* __restrict__ y) {
+  const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (i < numel) y[i] = silu_f(z[i]);
 }
 
 // dz = dy * silu'(z)
@@ -239,6 +251,14 @@ __global__ __launch_bounds__(256) void clip_scale_kernel(float* __restrict__ g, 
   for (int64_t i = blockIdx.x * (int64_t)256 + threadIdx.x; i < numel; i += (int64_t)gridDim.x * 256) g[i] *= cf;
 }
 
+// out = x * alpha[0] (alpha on the device: loss-scale / 1/world factors without a host sync)
+__global__ __launch_bounds__(256) void scale_kernel(const float* __restrict__ x, int64_t numel,
+                                                    const float* __restrict__ alpha, float mult,
+                                                    float* __restrict__ out) {
+  const float a = (alpha ? alpha[0] : 1.f) * mult;
+  for (int64_t i = blockIdx.x * (int64_t)256 + threadIdx.x; i < numel; i += (int64_t)gridDim.x * 256) out[i] = x[i] * a;
+}
+
 static inline int stream_blocks2(int64_t numel) {
   int64_t b = cdiv64(numel, 256 * 4);
   return (int)(b < 1 ? 1 : (b > 2048 ? 2048 : b));
@@ -272,11 +292,12 @@ DSG_API int dsg_gn_bwd(const float* src0, int32_t c0, const float* src1, int32_t
   return DSG_OK;
 }
 
-DSG_API int dsg_channel_sums(const float* x, int32_t n, int32_t c, int32_t hw, float* out_nc, void* stream) {
+DSG_API int dsg_channel_sums(const float* x, int32_t n, int32_t c, int32_t hw, float* out_nc, int32_t out_stride,
+                             void* stream) {
   DSG_CHECK_ARG(x && out_nc, "dsg_channel_sums: NULL pointer");
-  DSG_CHECK_ARG(n > 0 && c > 0 && hw > 0 && n <= 65535, "dsg_channel_sums: bad dims");
+  DSG_CHECK_ARG(n > 0 && c > 0 && hw > 0 && n <= 65535 && out_stride >= c, "dsg_channel_sums: bad dims");
   hipLaunchKernelGGL(dsg::channel_sums_kernel, dim3(c, n), dim3(256), 0, static_cast<hipStream_t>(stream), x, c, hw,
-                     out_nc);
+                     out_nc, out_stride);
   DSG_LAUNCH_CHECK();
   return DSG_OK;
 }
@@ -309,6 +330,30 @@ DSG_API int dsg_linear_bwd(const float* x, const float* w, const float* dy, int3
                        dy_stride, dx);
     DSG_LAUNCH_CHECK();
   }
+  return DSG_OK;
+}
+
+DSG_API int dsg_add(const float* a, const float* b, int64_t numel, float* out, void* stream) {
+  DSG_CHECK_ARG(a && b && out && numel > 0, "dsg_add: bad argument");
+  hipLaunchKernelGGL(dsg::add2_kernel, dim3(dsg::stream_blocks2(numel)), dim3(256), 0, static_cast<hipStream_t>(stream),
+                     a, b, numel, out);
+  DSG_LAUNCH_CHECK();
+  return DSG_OK;
+}
+
+DSG_API int dsg_scale(const float* x, int64_t numel, const float* alpha_dev, float mult, float* out, void* stream) {
+  DSG_CHECK_ARG(x && out && numel > 0, "dsg_scale: bad argument");
+  hipLaunchKernelGGL(dsg::scale_kernel, dim3(dsg::stream_blocks2(numel)), dim3(256), 0,
+                     static_cast<hipStream_t>(stream), x, numel, alpha_dev, mult, out);
+  DSG_LAUNCH_CHECK();
+  return DSG_OK;
+}
+
+DSG_API int dsg_silu_fwd(const float* z, int64_t numel, float* y, void* stream) {
+  DSG_CHECK_ARG(z && y && numel > 0, "dsg_silu_fwd: bad argument");
+  hipLaunchKernelGGL(dsg::silu_fwd_kernel, dim3((unsigned)dsg::cdiv64(numel, 256)), dim3(256), 0,
+                     static_cast<hipStream_t>(stream), z, numel, y);
+  DSG_LAUNCH_CHECK();
   return DSG_OK;
 }
 

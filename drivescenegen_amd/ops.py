@@ -51,13 +51,14 @@ def relayout_conv_weight_dgrad(w_oihw: torch.Tensor, out: torch.Tensor = None) -
 
 def conv2d_fused(src0, weight_r, bias=None, src1=None, ksize=3, stride=1, upsample=False, gn_scale_shift=None,
                  silu=False, temb=None, temb_stride=0, residual=None, out=None, direct=False, cout=None,
-                 pool2=False):
+                 pool2=False, wstride=None):
     """dsg_conv2d_fwd: see include/dsg.h.  `weight_r` is in engine layout; `temb` is a [N, temb_stride] view
     whose first `cout` columns (from its data pointer) are added per (n, cout)."""
     lib = _lib.load()
     n, c0, hin, win = src0.shape
     c1 = src1.shape[1] if src1 is not None else 0
-    wstride = weight_r.shape[-1]
+    wptr = weight_r.data_ptr() if wstride else _lib.ptr(weight_r)  # a column window of a wider matrix is allowed
+    wstride = wstride or weight_r.shape[-1]
     cout = cout or wstride
     hc, wc = (2 * hin, 2 * win) if upsample else (hin, win)
     pad = ksize // 2
@@ -70,7 +71,7 @@ def conv2d_fused(src0, weight_r, bias=None, src1=None, ksize=3, stride=1, upsamp
     a.src0, a.src1 = _lib.ptr(src0), _lib.ptr(src1)
     a.c0, a.c1, a.n, a.hin, a.win = c0, c1, n, hin, win
     a.upsample, a.ksize, a.stride, a.cout = int(upsample), ksize, stride, cout
-    a.weight, a.bias = _lib.ptr(weight_r), _lib.ptr(bias)
+    a.weight, a.bias = wptr, _lib.ptr(bias)
     a.weight_cout_stride, a.pool2 = wstride, int(pool2)
     a.gn_scale_shift, a.silu = _lib.ptr(gn_scale_shift), int(silu)
     if temb is not None:
@@ -166,15 +167,16 @@ def postprocess(x, mode=0):
 # Training-step ops (backward / loss / optimizer); see include/dsg.h "Training step"
 # ---------------------------------------------------------------------------------------------------
 def conv_wgrad(src0, dy, dw, src1=None, ksize=3, stride=1, upsample=False, gn_scale_shift=None, silu=False,
-               direct=False):
+               direct=False, cout=None, dy_coff=0):
     """dw[cout][cin][k][k] += wgrad; the activation is recomputed from (src, gn_scale_shift)."""
     n, c0, hin, win = src0.shape
     a = _lib.ConvWgradArgs()
     a.src0, a.src1 = _lib.ptr(src0), _lib.ptr(src1)
     a.c0, a.c1 = c0, (src1.shape[1] if src1 is not None else 0)
     a.n, a.hin, a.win = n, hin, win
-    a.upsample, a.ksize, a.stride, a.cout = int(upsample), ksize, stride, dy.shape[1]
+    a.upsample, a.ksize, a.stride, a.cout = int(upsample), ksize, stride, cout or dy.shape[1]
     a.dy, a.gn_scale_shift, a.silu = _lib.ptr(dy), _lib.ptr(gn_scale_shift), int(silu)
+    a.dy_ctotal, a.dy_coff = dy.shape[1], dy_coff
     a.dw, a.force_direct = _lib.ptr(dw), int(direct)
     with torch.cuda.device(src0.device):
         _lib.check(_lib.load().dsg_conv2d_wgrad(C.byref(a), _st(src0)))
@@ -217,13 +219,36 @@ def gn_bwd(src0, dy, ss, mr, gamma, groups, silu, dgamma, dbeta, src1=None, add0
     return dx0, dx1
 
 
-def channel_sums(x):
-    """[N, C, ...] -> [N, C] sums over the trailing dims."""
+def channel_sums(x, out=None, out_stride=None):
+    """[N, C, ...] -> [N, C] sums over the trailing dims (optionally into rows of a wider matrix)."""
     n, c = x.shape[0], x.shape[1]
-    out = torch.empty((n, c), dtype=torch.float32, device=x.device)
+    if out is None:
+        out = torch.empty((n, c), dtype=torch.float32, device=x.device)
     with torch.cuda.device(x.device):
-        _lib.check(_lib.load().dsg_channel_sums(_lib.ptr(x), n, c, x.numel() // (n * c), _lib.ptr(out), _st(x)))
+        _lib.check(_lib.load().dsg_channel_sums(_lib.ptr(x), n, c, x.numel() // (n * c), out.data_ptr(),
+                                               out_stride or out.stride(0), _st(x)))
     return out
+
+
+def add(a, b):
+    out = torch.empty_like(a)
+    with torch.cuda.device(a.device):
+        _lib.check(_lib.load().dsg_add(_lib.ptr(a), _lib.ptr(b), a.numel(), _lib.ptr(out), _st(a)))
+    return out
+
+
+def time_embed_train(timesteps, w1, b1, w2, b2, freqs):
+    """(act, emb, z1, z2) -- act = silu(z2), z2 = linear_2(silu(z1)), z1 = linear_1(emb)."""
+    n = timesteps.numel()
+    dim, ch = w1.shape
+    dev = w1.device
+    act, z1, z2 = (torch.empty((n, dim), dtype=torch.float32, device=dev) for _ in range(3))
+    emb = torch.empty((n, ch), dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        _lib.check(_lib.load().dsg_time_embed_fwd_train(_lib.ptr(timesteps), _lib.ptr(freqs), n, ch, dim, _lib.ptr(w1),
+                                                       _lib.ptr(b1), _lib.ptr(w2), _lib.ptr(b2), _lib.ptr(act),
+                                                       _lib.ptr(emb), _lib.ptr(z1), _lib.ptr(z2), _st(w1)))
+    return act, emb, z1, z2
 
 
 def reduce_rows_add(src, dst, stride=None):
@@ -268,6 +293,13 @@ def linear_bwd(x, w, dy, dw=None, db=None, need_dx=True, dy_stride=None):
         _lib.check(_lib.load().dsg_linear_bwd(_lib.ptr(x), _lib.ptr(w), dy.data_ptr(), dy_stride or dy.stride(0), n,
                                              in_f, out_f, _lib.ptr(dw), _lib.ptr(db), _lib.ptr(dx), _st(x)))
     return dx
+
+
+def silu_fwd(z):
+    y = torch.empty_like(z)
+    with torch.cuda.device(z.device):
+        _lib.check(_lib.load().dsg_silu_fwd(_lib.ptr(z), z.numel(), _lib.ptr(y), _st(z)))
+    return y
 
 
 def silu_bwd(z, dy):
@@ -321,3 +353,12 @@ def adamw_step_(param, grad, exp_avg, exp_avg_sq, step, lr, betas=(0.9, 0.999), 
                                              _lib.ptr(exp_avg_sq), param.numel(), float(lr), float(betas[0]),
                                              float(betas[1]), float(eps), float(weight_decay), int(step),
                                              _lib.ptr(total_norm), float(max_norm), _st(param)))
+
+
+def scale(x, alpha_dev=None, mult=1.0, out=None):
+    """out = x * alpha_dev[0] * mult (in place when out is x)."""
+    out = torch.empty_like(x) if out is None else out
+    with torch.cuda.device(x.device):
+        _lib.check(_lib.load().dsg_scale(_lib.ptr(x), x.numel(), _lib.ptr(alpha_dev), float(mult), _lib.ptr(out),
+                                        _st(x)))
+    return out

@@ -1,0 +1,408 @@
+"""Training-side counterparts of what DriveSceneGen's train loop takes from torch / accelerate.
+
+Reference: /root/reference/DriveSceneGen/pipeline/training_pipeline.py:46-107 and
+/root/reference/DriveSceneGen/scripts/train.py:66-71:
+    loss = F.mse_loss(noise_pred, noise)                       -> mse_loss
+    accelerator.backward(loss)                                 -> Accelerator.backward
+    accelerator.clip_grad_norm_(model.parameters(), 1.0)       -> clip_grad_norm_
+    optimizer = torch.optim.AdamW(model.parameters(), lr)      -> AdamW (fused, flat slabs)
+    Accelerator(mixed_precision, gradient_accumulation_steps, log_with, project_dir) + .prepare/.accumulate/
+    .log/.init_trackers/.unwrap_model/.is_main_process          -> Accelerator
+    (latent) DistributedDataParallel gradient averaging         -> GradBuckets over RCCL
+
+All arithmetic (loss, norms, clipping, optimizer update) runs in libdsg.so; this file is host logic.
+"""
+from __future__ import annotations
+
+import json
+import math
+import os
+import time
+from contextlib import contextmanager
+
+import torch
+import torch.distributed as dist
+
+from . import ops
+from .autograd import SLABS, get_train_state
+
+
+# ------------------------------------------------------------------------------------------------
+# loss
+# ------------------------------------------------------------------------------------------------
+class _MSEFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, pred, target):
+        loss, dpred = ops.mse_loss(pred.detach(), target.detach())
+        ctx.dpred = dpred
+        return loss.view(())
+
+    @staticmethod
+    def backward(ctx, gout):
+        # gout is 1 for a plain backward; loss scaling / accumulation factors stay on the device
+        d = ops.scale(ctx.dpred, gout.reshape(1).contiguous(), 1.0, out=ctx.dpred)
+        return d, None
+
+
+def mse_loss(pred, target):
+    """``F.mse_loss(pred, target)`` (mean reduction, training_pipeline.py:85) on the HIP engine."""
+    if not pred.is_cuda:
+        raise RuntimeError("drivescenegen_amd.mse_loss runs on the MI355X HIP engine only (got a CPU tensor)")
+    return _MSEFn.apply(pred, target)
+
+
+# ------------------------------------------------------------------------------------------------
+# gradient clipping + optimizer over flat slabs
+# ------------------------------------------------------------------------------------------------
+def _slab_of(params):
+    """If every parameter's .grad is a slice of ONE contiguous fp32 buffer (the UNet's TrainState slab),
+    return (flat_grad, [(param, offset, numel)])."""
+    params = [p for p in params if p.grad is not None]
+    if not params:
+        return None, []
+    base = params[0].grad.untyped_storage().data_ptr()
+    flat = SLABS.get(base)
+    if flat is None:
+        return None, []
+    rows = []
+    for p in params:
+        g = p.grad
+        if g.untyped_storage().data_ptr() != base or not g.is_contiguous() or g.dtype != torch.float32:
+            return None, []
+        rows.append((p, (g.data_ptr() - base) // 4, g.numel()))
+    return flat, rows
+
+
+def clip_grad_norm_(parameters, max_norm: float, norm_type: float = 2.0):
+    """``torch.nn.utils.clip_grad_norm_`` semantics (L2, eps 1e-6): returns the total norm (0-d device tensor)
+    and scales the gradients in place by min(1, max_norm / (norm + 1e-6))."""
+    if norm_type != 2.0:
+        raise NotImplementedError("clip_grad_norm_: only the L2 norm (the reference's default) is implemented")
+    params = [p for p in parameters if p.grad is not None]
+    if not params:
+        return torch.zeros(())
+    if not params[0].grad.is_cuda:
+        raise RuntimeError("drivescenegen_amd.clip_grad_norm_ runs on the MI355X HIP engine only")
+    flat, rows = _slab_of(params)
+    if flat is not None and sum(r[2] for r in rows) >= 0.5 * flat.numel():
+        total = ops.l2_norm(flat)  # slab padding is zero
+        ops.clip_scale_(flat, total, max_norm)
+    else:  # gradients living in separate tensors: one norm per tensor, combined on the device
+        sq = torch.stack([ops.l2_norm(p.grad.contiguous().view(-1)) for p in params]).view(-1).contiguous()
+        total = ops.l2_norm(sq)
+        for p in params:
+            ops.clip_scale_(p.grad.view(-1), total, max_norm)
+    return total.view(())
+
+
+class AdamW(torch.optim.Optimizer):
+    """``torch.optim.AdamW`` (decoupled weight decay; torch defaults betas (0.9, 0.999), eps 1e-8,
+    weight_decay 1e-2 -- train.py:66 passes only lr) with ONE fused kernel per step over flat
+    parameter / gradient / moment slabs when the parameters belong to a drivescenegen_amd UNet2DModel."""
+
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2):
+        if lr < 0 or eps < 0 or not 0 <= betas[0] < 1 or not 0 <= betas[1] < 1 or weight_decay < 0:
+            raise ValueError("AdamW: invalid hyper-parameter")
+        super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay))
+        self._flat = {}  # id(group) -> dict(param_flat, m, v, grad_flat, step)
+
+    def _flatten(self, group):
+        params = [p for p in group["params"] if p.grad is not None]
+        gflat, rows = _slab_of(params)
+        if gflat is None or len(params) != len(group["params"]):
+            return None
+        pflat = torch.zeros_like(gflat)
+        for p, off, n in rows:  # move the parameters into one slab laid out like the gradient slab
+            pflat[off:off + n].copy_(p.detach().reshape(-1))
+            p.data = pflat[off:off + n].view(p.shape)
+        return dict(param=pflat, grad=gflat, m=torch.zeros_like(gflat), v=torch.zeros_like(gflat), step=0)
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        loss = closure() if closure is not None else None
+        for group in self.param_groups:
+            key = id(group)
+            st = self._flat.get(key)
+            if st is None:
+                st = self._flatten(group) or False
+                self._flat[key] = st
+            if st:
+                st["step"] += 1
+                ops.adamw_step_(st["param"], st["grad"], st["m"], st["v"], st["step"], group["lr"], group["betas"],
+                                group["eps"], group["weight_decay"])
+                self._bump_versions(group["params"])
+                continue
+            for p in group["params"]:  # separate tensors: one launch per parameter
+                if p.grad is None:
+                    continue
+                if not p.is_cuda:
+                    raise RuntimeError("drivescenegen_amd.AdamW runs on the MI355X HIP engine only")
+                s = self.state[p]
+                if not s:
+                    s["step"], s["exp_avg"], s["exp_avg_sq"] = 0, torch.zeros_like(p), torch.zeros_like(p)
+                s["step"] += 1
+                ops.adamw_step_(p.data.view(-1), p.grad.contiguous().view(-1), s["exp_avg"].view(-1),
+                                s["exp_avg_sq"].view(-1), s["step"], group["lr"], group["betas"], group["eps"],
+                                group["weight_decay"])
+            self._bump_versions(group["params"])
+        return loss
+
+    @staticmethod
+    def _bump_versions(params):
+        # the update happened behind autograd's back (raw pointers): bump version counters so that cached
+        # engine-layout weights (UNet2DModel._plan_state / TrainState.versions) are refreshed
+        for p in params:
+            torch.autograd.graph.increment_version(p)
+
+    def zero_grad(self, set_to_none: bool = False):
+        """Keeps .grad attached to the flat slab (one memset) instead of dropping the tensors."""
+        done = set()
+        for group in self.param_groups:
+            flat, rows = _slab_of([p for p in group["params"] if p.grad is not None])
+            if flat is not None and flat.data_ptr() not in done:
+                flat.zero_()
+                done.add(flat.data_ptr())
+            elif flat is None:
+                for p in group["params"]:
+                    if p.grad is not None:
+                        p.grad.zero_()
+
+
+# ------------------------------------------------------------------------------------------------
+# data-parallel gradient averaging: reverse-order flat buckets, launched as they fill
+# ------------------------------------------------------------------------------------------------
+class GradBuckets:
+    """All-reduce(mean) of a flat gradient slab in ~bucket_mb buckets.  ``ready(name)`` is called by the
+    backward pass when a parameter's gradient is final; a bucket is launched asynchronously on the
+    communication stream the moment its last gradient lands (buckets fill back-to-front, so communication
+    overlaps the rest of backward).  ``finish()`` waits for the outstanding work."""
+
+    def __init__(self, flat, offsets: dict, group=None, bucket_mb: float = 25.0):
+        self.flat, self.group = flat, group
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        names = sorted(offsets, key=lambda k: offsets[k][0])
+        cap = int(bucket_mb * (1 << 20) / 4)
+        self.buckets, self.of = [], {}
+        lo, cnt, members = None, 0, []
+        for nm in names:
+            off, n = offsets[nm]
+            if lo is None:
+                lo = off
+            members.append(nm)
+            cnt = off + n - lo
+            if cnt >= cap:
+                self.buckets.append(dict(lo=lo, hi=off + n, names=members))
+                lo, members = None, []
+        if members:
+            self.buckets.append(dict(lo=lo, hi=offsets[members[-1]][0] + offsets[members[-1]][1], names=members))
+        for i, b in enumerate(self.buckets):
+            for nm in b["names"]:
+                self.of[nm] = i
+        backend = dist.get_backend(group) if dist.is_initialized() else "none"
+        self.avg_native = backend == "nccl"  # RCCL has ReduceOp.AVG; gloo does not
+        self.reset()
+
+    def reset(self):
+        self.pending = [len(b["names"]) for b in self.buckets]
+        self.seen = set()
+        self.works = []
+        self.launch_order = []
+
+    def ready(self, name):
+        if self.world == 1 or name in self.seen or name not in self.of:
+            return
+        self.seen.add(name)
+        i = self.of[name]
+        self.pending[i] -= 1
+        if self.pending[i] == 0:
+            self._launch(i)
+
+    def _launch(self, i):
+        b = self.buckets[i]
+        view = self.flat[b["lo"]:b["hi"]]
+        op = dist.ReduceOp.AVG if self.avg_native else dist.ReduceOp.SUM
+        self.works.append((dist.all_reduce(view, op=op, group=self.group, async_op=True), view))
+        self.launch_order.append(i)
+
+    def finish(self):
+        if self.world == 1:
+            return
+        for i, left in enumerate(self.pending):  # parameters that got no gradient this step
+            if left > 0:
+                self.pending[i] = 0
+                self._launch(i)
+        for work, view in self.works:
+            work.wait()
+            if not self.avg_native:
+                if view.is_cuda:
+                    ops.scale(view, None, 1.0 / self.world, out=view)
+                else:  # gloo on CPU tensors: only reachable from the host-logic tests
+                    view.div_(self.world)
+        self.reset()
+
+
+# ------------------------------------------------------------------------------------------------
+# accelerate.Accelerator, the subset training_pipeline.py:48-61,82-101 uses
+# ------------------------------------------------------------------------------------------------
+class _ShardedLoader:
+    """accelerate's prepared DataLoader: every rank sees its own batches of the full batch size
+    (rank r takes batches r, r+W, ...), tensors are moved to the device."""
+
+    def __init__(self, loader, device, rank, world):
+        self.loader, self.device, self.rank, self.world = loader, device, rank, world
+
+    def __len__(self):
+        return math.ceil(len(self.loader) / self.world)
+
+    def __iter__(self):
+        for i, batch in enumerate(self.loader):
+            if i % self.world != self.rank:
+                continue
+            yield batch.to(self.device, non_blocking=True) if torch.is_tensor(batch) else batch
+
+
+class _SteppedScheduler:
+    """accelerate's AcceleratedScheduler: one call advances the wrapped scheduler `world` times (the schedule
+    was sized on the unsharded loader, train.py:67-71) and is skipped when the optimizer step was skipped."""
+
+    def __init__(self, sched, world, accel):
+        self.sched, self.world, self.accel = sched, world, accel
+
+    def step(self, *a, **k):
+        if not self.accel.sync_gradients:
+            return
+        for _ in range(self.world):
+            self.sched.step(*a, **k)
+
+    def get_last_lr(self):
+        return self.sched.get_last_lr()
+
+    def __getattr__(self, n):
+        return getattr(self.sched, n)
+
+
+class Accelerator:
+    def __init__(self, mixed_precision="no", gradient_accumulation_steps=1, log_with=None, project_dir=None,
+                 device=None):
+        # The engine computes in fp32; 'fp16' (the reference's train.py:24) and 'bf16' are accepted and run
+        # fp32, which is >= the reference's precision (no GradScaler, so no skipped steps).
+        if mixed_precision not in ("no", "fp16", "bf16", None):
+            raise ValueError(f"mixed_precision={mixed_precision!r}")
+        self.mixed_precision = mixed_precision
+        self.gradient_accumulation_steps = int(gradient_accumulation_steps)
+        self.project_dir = project_dir
+        self.log_with = log_with
+        self.world = int(os.environ.get("WORLD_SIZE", "1"))
+        self.rank = int(os.environ.get("RANK", "0"))
+        self.local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+        if self.world > 1 and not dist.is_initialized():
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+            torch.cuda.set_device(self.local_rank)
+            dist.init_process_group("nccl")
+        self.device = torch.device(device) if device else torch.device("cuda", self.local_rank)
+        self.sync_gradients = True
+        self._accum = 0
+        self._buckets = None
+        self._model = None
+        self._log_file = None
+        self.trackers = []
+
+    @property
+    def is_main_process(self):
+        return self.rank == 0
+
+    @property
+    def is_local_main_process(self):
+        return self.local_rank == 0
+
+    @property
+    def num_processes(self):
+        return self.world
+
+    def init_trackers(self, project_name, config=None):
+        if self.project_dir and self.is_main_process:
+            os.makedirs(self.project_dir, exist_ok=True)
+            self._log_file = open(os.path.join(self.project_dir, f"{project_name}.jsonl"), "a")
+
+    def log(self, values, step=None):
+        if self._log_file:
+            rec = {"step": step, "time": time.time()}
+            rec.update({k: (float(v) if hasattr(v, "__float__") else v) for k, v in values.items()})
+            self._log_file.write(json.dumps(rec) + "\n")
+            self._log_file.flush()
+
+    def end_training(self):
+        if self._log_file:
+            self._log_file.close()
+            self._log_file = None
+
+    def wait_for_everyone(self):
+        if self.world > 1:
+            dist.barrier()
+
+    def unwrap_model(self, model):
+        return model
+
+    def prepare(self, *objs):
+        out = []
+        for o in objs:
+            if isinstance(o, torch.nn.Module):
+                o.to(self.device)
+                self._model = o
+                if self.world > 1:
+                    for p in o.parameters():  # identical replicas: rank 0's initial weights
+                        dist.broadcast(p.data, src=0)
+                out.append(o)
+            elif isinstance(o, torch.utils.data.DataLoader):
+                out.append(_ShardedLoader(o, self.device, self.rank, self.world))
+            elif isinstance(o, torch.optim.lr_scheduler.LRScheduler):
+                out.append(_SteppedScheduler(o, self.world, self))
+            else:
+                out.append(o)
+        return tuple(out) if len(out) > 1 else out[0]
+
+    @contextmanager
+    def accumulate(self, model=None):
+        self._accum += 1
+        self.sync_gradients = self._accum % self.gradient_accumulation_steps == 0
+        yield
+
+    def _ensure_buckets(self):
+        if self.world == 1 or self._model is None:
+            return None
+        st = get_train_state(self._model)
+        if self._buckets is None or self._buckets.flat.data_ptr() != st.grad_flat.data_ptr():
+            self._buckets = GradBuckets(st.grad_flat, st.offsets)
+            st.grad_ready_hooks[:] = [self._on_ready]
+        return self._buckets
+
+    def _on_ready(self, name):
+        if self.sync_gradients and self._buckets is not None:
+            self._buckets.ready(name)
+
+    def backward(self, loss):
+        b = self._ensure_buckets()
+        if self.gradient_accumulation_steps > 1:
+            loss = _ScaleLoss.apply(loss, 1.0 / self.gradient_accumulation_steps)
+        loss.backward()
+        if b is not None and self.sync_gradients:
+            b.finish()
+
+    def clip_grad_norm_(self, parameters, max_norm, norm_type=2):
+        if not self.sync_gradients:
+            return None
+        return clip_grad_norm_(parameters, max_norm, float(norm_type))
+
+
+class _ScaleLoss(torch.autograd.Function):
+    """loss / gradient_accumulation_steps without a torch arithmetic kernel on the path."""
+
+    @staticmethod
+    def forward(ctx, loss, mult):
+        ctx.mult = mult
+        return ops.scale(loss.detach().reshape(1).contiguous(), None, mult).view(())
+
+    @staticmethod
+    def backward(ctx, g):
+        return ops.scale(g.reshape(1).contiguous(), None, ctx.mult).view(()), None

@@ -198,7 +198,8 @@ typedef struct {
   int32_t upsample;             /* 1: the conv ran on the nearest x2 upsampled source */
   int32_t ksize, stride;
   int32_t cout;
-  const float* dy;              /* [N, cout, hout, wout] */
+  const float* dy;              /* [N, dy_ctotal, hout, wout]; this conv's cout channels start at dy_coff */
+  int32_t dy_ctotal, dy_coff;   /* dy_ctotal 0 = cout (fused q/k/v projections share one dqkv tensor) */
   const float* gn_scale_shift;  /* optional [N][c0+c1][2]: the activation is recomputed in the gather */
   int32_t silu;
   float* dw;                    /* [cout][c0+c1][k][k] (OIHW, checkpoint layout); ACCUMULATED into */
@@ -215,7 +216,12 @@ int dsg_gn_bwd(const float* src0, int32_t c0, const float* src1, int32_t c1, con
                const float* scale_shift, const float* mean_rstd, const float* gamma, int32_t silu, int32_t n,
                int32_t hw, int32_t groups, const float* add0, const float* add1, float* dx0, float* dx1,
                float* dgamma, float* dbeta, double* ws_s12, float* ws_coef, void* stream);
-int dsg_channel_sums(const float* x, int32_t n, int32_t c, int32_t hw, float* out_nc, void* stream);
+/* out_nc[n*out_stride + c] = sum over hw of x[n][c][:] (bias / time-embedding gradients) */
+int dsg_channel_sums(const float* x, int32_t n, int32_t c, int32_t hw, float* out_nc, int32_t out_stride, void* stream);
+int dsg_add(const float* a, const float* b, int64_t numel, float* out, void* stream);
+int dsg_time_embed_fwd_train(const int64_t* timesteps, const float* freqs, int32_t n, int32_t ch, int32_t dim,
+                             const float* w1, const float* b1, const float* w2, const float* b2, float* act,
+                             float* emb, float* z1, float* z2, void* stream);
 int dsg_reduce_rows_add(const float* src, int32_t n, int32_t c, int32_t stride, float* dst, void* stream);
 /* attention: forward that also returns the log2-domain log-sum-exp [N][heads][L], and the backward
  * (dqkv [N][3C][L]; dsum_ws [N][heads][L] scratch). */
@@ -226,6 +232,9 @@ int dsg_attention_bwd(const float* qkv, const float* out, const float* dout, con
 /* y = x W^T + b backward: dw [out][in] and db [out] are accumulated (skipped when NULL), dx [n][in] written. */
 int dsg_linear_bwd(const float* x, const float* w, const float* dy, int32_t dy_stride, int32_t n, int32_t in_f,
                    int32_t out_f, float* dw, float* db, float* dx, void* stream);
+/* out = x * alpha_dev[0] * mult (alpha_dev may be NULL) */
+int dsg_scale(const float* x, int64_t numel, const float* alpha_dev, float mult, float* out, void* stream);
+int dsg_silu_fwd(const float* z, int64_t numel, float* y, void* stream);
 int dsg_silu_bwd(const float* z, const float* dy, int64_t numel, float* dz, void* stream);
 /* loss[0] = mean((pred-target)^2); dpred = grad_scale * 2 (pred-target) / numel (skipped when NULL).
  * ws: >= 2048 doubles. */
