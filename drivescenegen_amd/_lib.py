@@ -50,6 +50,7 @@ class ConvWgradArgs(C.Structure):
         ("dy", C.c_void_p), ("dy_ctotal", C.c_int32), ("dy_coff", C.c_int32),
         ("gn_scale_shift", C.c_void_p), ("silu", C.c_int32),
         ("dw", C.c_void_p), ("force_direct", C.c_int32),
+        ("workspace", C.c_void_p), ("workspace_bytes", C.c_size_t),
     ]
 
 
@@ -91,6 +92,7 @@ SIGNATURES = {
     "dsg_unet_workspace_bytes": [_vp, _i32, C.POINTER(_sz)],
     "dsg_unet_forward": [_vp, _vp, _vp, _vp, _i32, _vp, _sz, _vp],
     "dsg_conv2d_wgrad": [C.POINTER(ConvWgradArgs), _vp],
+    "dsg_conv2d_wgrad_workspace_bytes": [C.POINTER(ConvWgradArgs), C.POINTER(_sz)],
     "dsg_gn_finalize_train": [_vp, _vp, _vp, _i32, _i32, _i32, _i32, _f32, _vp, _vp, _vp],
     "dsg_gn_bwd": [_vp, _i32, _vp, _i32, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp,
                    _vp, _vp, _vp],

@@ -39,6 +39,8 @@ struct WgradP {
   const float* ss;  // optional [N][cin][2]
   int silu;
   float* dw;  // [cout][cin][taps], accumulated
+  float* ws;  // split-K partials [nsplit][taps][cin_pad][cout_pad] (MFMA path)
+  int cin_pad, cout_pad;
   int tiles_x, tiles_y, ntiles;
   int ci_blocks;
 };
@@ -107,7 +109,10 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(WgradP p) {
   float xr[NE];
   float4 dr[4];
 
-  for (int t = blockIdx.y; t < p.ntiles; t += gridDim.y) {
+  // global -> registers for one pixel tile (issued one stage ahead of its use)
+  float sc = 1.f, sh = 0.f;
+  unsigned long long valid = 0;  // NE can exceed 32 (34 for 3x3, 41 for stride 2)
+  auto load_tile = [&](int t) {
     int tt = t;
     const int tx = tt % p.tiles_x;
     tt /= p.tiles_x;
@@ -115,17 +120,14 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(WgradP p) {
     const int n = tt / p.tiles_y;
     const int oy0 = ty * WG_SR, ox0 = tx * 32;
     const int iy0 = oy0 * STRIDE - KS / 2, ix0 = ox0 * STRIDE - KS / 2;
-
-    // ---- global loads (registers) ----
     const float* sp = from0 ? p.src0 + ((size_t)n * p.c0 + gcc) * plane
                             : p.src1 + ((size_t)n * p.c1 + (gcc - p.c0)) * plane;
-    float sc = 1.f, sh = 0.f;
     if (has_ss) {
       const float2 s2 = *reinterpret_cast<const float2*>(p.ss + ((size_t)n * p.cin + gcc) * 2);
       sc = s2.x;
       sh = s2.y;
     }
-    unsigned long long valid = 0;  // NE can exceed 32 (34 for 3x3, 41 for stride 2)
+    valid = 0;
 #pragma unroll
     for (int i = 0; i < NE; ++i) {
       const int r = tr + TPC * i;
@@ -150,10 +152,13 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(WgradP p) {
       float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
       if (gco < p.cout)
         v = *reinterpret_cast<const float4*>(p.dy + ((size_t)n * p.dy_ctotal + p.dy_coff + gco) * oplane +
-                                             (size_t)(oy0 + row) * p.wout +
-                                             ox0 + q4 * 4);
+                                             (size_t)(oy0 + row) * p.wout + ox0 + q4 * 4);
       dr[i] = v;
     }
+  };
+
+  if ((int)blockIdx.y < p.ntiles) load_tile(blockIdx.y);
+  for (int t = blockIdx.y; t < p.ntiles; t += gridDim.y) {
     __syncthreads();  // previous stage's MFMA phase is done with LDS
 #pragma unroll
     for (int i = 0; i < NE; ++i) {
@@ -172,6 +177,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(WgradP p) {
       d[0] = dr[i].x; d[1] = dr[i].y; d[2] = dr[i].z; d[3] = dr[i].w;
     }
     __syncthreads();
+    if (t + (int)gridDim.y < p.ntiles) load_tile(t + gridDim.y);  // next tile's loads fly under the MFMAs
 
     // ---- MFMA phase: 32 k-steps (pixel pairs) x TAPS ----
     const float* al = Al + (cit * 32 + l31) * PST;
@@ -193,17 +199,35 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(WgradP p) {
   }
 
   // ---- epilogue: D[i = ci][j = co]; lane holds co = l31, ci rows (r&3) + 8*(r>>2) + 4*half ----
+  // Partials go to the workspace slab of this K-split ([tap][ci][co], co contiguous -> 128-B stores); a second
+  // kernel sums the splits in a fixed order into dW (deterministic, and ~100x cheaper than 37 M fp32 atomics).
+  // CIT == 1 splits the k-steps over two wave pairs: the second pair adds into a second slab half.
   const int co = co0 + cot * 32 + l31;
-  if (co < p.cout) {
+  float* wsb = p.ws + ((size_t)blockIdx.y * (CIT == 2 ? 1 : 2) + khalf) * TAPS * p.cin_pad * p.cout_pad;
 #pragma unroll
-    for (int tp = 0; tp < TAPS; ++tp) {
+  for (int tp = 0; tp < TAPS; ++tp) {
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int ci = ci0 + cit * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-        if (ci < p.cin) atomicAdd(p.dw + ((size_t)co * p.cin + ci) * TAPS + tp, acc[tp][r]);
-      }
+    for (int r = 0; r < 16; ++r) {
+      const int ci = ci0 + cit * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+      wsb[((size_t)tp * p.cin_pad + ci) * p.cout_pad + co] = acc[tp][r];
     }
   }
+}
+
+// dw[co][ci][tp] += sum_s ws[s][tp][ci][co]; one thread per (tp, ci, co), co fastest (coalesced reads)
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ ws, int nslab, int taps, int cin,
+                                                           int cout, int cin_pad, int cout_pad,
+                                                           float* __restrict__ dw) {
+  const int64_t i = blockIdx.x * (int64_t)256 + threadIdx.x;
+  const int64_t slab = (int64_t)taps * cin_pad * cout_pad;
+  if (i >= slab) return;
+  const int co = (int)(i % cout_pad);
+  const int ci = (int)((i / cout_pad) % cin_pad);
+  const int tp = (int)(i / ((int64_t)cout_pad * cin_pad));
+  if (co >= cout || ci >= cin) return;
+  float s = 0.f;
+  for (int k = 0; k < nslab; ++k) s += ws[k * slab + i];
+  dw[((size_t)co * cin + ci) * taps + tp] += s;
 }
 
 // Generic VALU fallback (odd spatial sizes): one thread per (co, ci, tap), loops over all pixels.
@@ -245,13 +269,21 @@ __global__ __launch_bounds__(256) void conv_wgrad_direct_kernel(WgradP p, int ks
   p.dw[i] += s;
 }
 
+static int wgrad_nsplit(int pairs, int ntiles) { return std::max(1, std::min(ntiles, cdiv(1024, pairs))); }
+
 template <int KS, int STRIDE, int UPS, int CIT>
-static int launch_wgrad(WgradP p, hipStream_t st) {
+static int launch_wgrad(WgradP p, size_t ws_bytes, hipStream_t st) {
   using G = WgradGeom<KS, STRIDE, CIT>;
   p.ci_blocks = cdiv(p.cin, G::CIB);
   const int co_blocks = cdiv(p.cout, WG_CO);
   const int pairs = p.ci_blocks * co_blocks;
-  int nsplit = std::max(1, std::min(p.ntiles, cdiv(1024, pairs)));
+  const int nsplit = wgrad_nsplit(pairs, p.ntiles);
+  p.cin_pad = p.ci_blocks * G::CIB;
+  p.cout_pad = co_blocks * WG_CO;
+  const int nslab = nsplit * (CIT == 2 ? 1 : 2);
+  const size_t need = (size_t)nslab * G::TAPS * p.cin_pad * p.cout_pad * sizeof(float);
+  if (p.ws == nullptr || ws_bytes < need)
+    return fail(DSG_ERR_WORKSPACE_TOO_SMALL, "dsg_conv2d_wgrad: workspace %zu bytes < required %zu", ws_bytes, need);
   const size_t lds = (size_t)G::LDS_FLOATS * sizeof(float);
   auto kern = conv_wgrad_kernel<KS, STRIDE, UPS, CIT>;
   static bool raised = false;
@@ -265,9 +297,24 @@ static int launch_wgrad(WgradP p, hipStream_t st) {
     pi = prof_begin(5, 2.0 * p.n * p.hout * p.wout * (double)p.cout * p.cin * G::TAPS,
                     4.0 * ((double)p.n * p.cin * p.hin * p.win + (double)p.n * p.cout * p.hout * p.wout), st);
   hipLaunchKernelGGL(kern, dim3(pairs, nsplit), dim3(256), lds, st, p);
+  DSG_LAUNCH_CHECK();
+  const int64_t slab = (int64_t)G::TAPS * p.cin_pad * p.cout_pad;
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)cdiv64(slab, 256)), dim3(256), 0, st, p.ws, nslab, G::TAPS, p.cin,
+                     p.cout, p.cin_pad, p.cout_pad, p.dw);
   prof_end(pi, st);
   DSG_LAUNCH_CHECK();
   return DSG_OK;
+}
+
+// bytes of split-K workspace the MFMA path needs for these dims (0 for the VALU fallback)
+static size_t wgrad_ws_bytes(int cin, int cout, int ks, int stride, int hout, int wout, int n) {
+  if ((wout % 32) || (hout % WG_SR)) return 0;
+  const int cit = (ks == 3 && stride == 2) ? 1 : (cin <= 32 ? 1 : 2);
+  const int cib = 32 * cit;
+  const int ci_blocks = cdiv(cin, cib), co_blocks = cdiv(cout, WG_CO);
+  const int ntiles = (wout / 32) * (hout / WG_SR) * n;
+  const int nslab = wgrad_nsplit(ci_blocks * co_blocks, ntiles) * (cit == 2 ? 1 : 2);
+  return (size_t)nslab * ks * ks * ci_blocks * cib * co_blocks * WG_CO * sizeof(float);
 }
 
 }  // namespace dsg
@@ -294,6 +341,7 @@ DSG_API int dsg_conv2d_wgrad(const dsg_conv_wgrad_args* a, void* stream) {
   const int pad = a->ksize / 2;
   p.hout = (p.hc + 2 * pad - a->ksize) / a->stride + 1;
   p.wout = (p.wc + 2 * pad - a->ksize) / a->stride + 1;
+  p.ws = static_cast<float*>(a->workspace); p.cin_pad = p.cout_pad = 0;
   p.cout = a->cout; p.dy = a->dy; p.dy_ctotal = a->dy_ctotal ? a->dy_ctotal : a->cout; p.dy_coff = a->dy_coff;
   p.ss = a->gn_scale_shift; p.silu = a->silu; p.dw = a->dw;
   p.tiles_x = p.wout / 32; p.tiles_y = p.hout / WG_SR; p.ntiles = p.tiles_x * p.tiles_y * p.n; p.ci_blocks = 1;
@@ -301,14 +349,23 @@ DSG_API int dsg_conv2d_wgrad(const dsg_conv_wgrad_args* a, void* stream) {
   if (tile_ok) {
     const int k = a->ksize, s = a->stride, u = a->upsample;
     const bool small_ci = p.cin <= 32;
-    if (k == 3 && s == 1 && u == 0) return small_ci ? launch_wgrad<3, 1, 0, 1>(p, st) : launch_wgrad<3, 1, 0, 2>(p, st);
-    if (k == 3 && s == 1 && u == 1) return small_ci ? launch_wgrad<3, 1, 1, 1>(p, st) : launch_wgrad<3, 1, 1, 2>(p, st);
-    if (k == 3 && s == 2) return launch_wgrad<3, 2, 0, 1>(p, st);
-    if (k == 1 && s == 1 && u == 0) return small_ci ? launch_wgrad<1, 1, 0, 1>(p, st) : launch_wgrad<1, 1, 0, 2>(p, st);
+    if (k == 3 && s == 1 && u == 0) return small_ci ? launch_wgrad<3, 1, 0, 1>(p, a->workspace_bytes, st) : launch_wgrad<3, 1, 0, 2>(p, a->workspace_bytes, st);
+    if (k == 3 && s == 1 && u == 1) return small_ci ? launch_wgrad<3, 1, 1, 1>(p, a->workspace_bytes, st) : launch_wgrad<3, 1, 1, 2>(p, a->workspace_bytes, st);
+    if (k == 3 && s == 2) return launch_wgrad<3, 2, 0, 1>(p, a->workspace_bytes, st);
+    if (k == 1 && s == 1 && u == 0) return small_ci ? launch_wgrad<1, 1, 0, 1>(p, a->workspace_bytes, st) : launch_wgrad<1, 1, 0, 2>(p, a->workspace_bytes, st);
   }
   const int64_t total = (int64_t)p.cout * p.cin * a->ksize * a->ksize;
   hipLaunchKernelGGL(conv_wgrad_direct_kernel, dim3((unsigned)cdiv64(total, 256)), dim3(256), 0, st, p, a->ksize,
                      a->stride, a->upsample);
   DSG_LAUNCH_CHECK();
+  return DSG_OK;
+}
+
+DSG_API int dsg_conv2d_wgrad_workspace_bytes(const dsg_conv_wgrad_args* a, size_t* bytes) {
+  DSG_CHECK_ARG(a && bytes, "dsg_conv2d_wgrad_workspace_bytes: NULL argument");
+  const int hc = a->upsample ? 2 * a->hin : a->hin, wc = a->upsample ? 2 * a->win : a->win;
+  const int pad = a->ksize / 2;
+  const int hout = (hc + 2 * pad - a->ksize) / a->stride + 1, wout = (wc + 2 * pad - a->ksize) / a->stride + 1;
+  *bytes = a->force_direct ? 0 : dsg::wgrad_ws_bytes(a->c0 + a->c1, a->cout, a->ksize, a->stride, hout, wout, a->n);
   return DSG_OK;
 }

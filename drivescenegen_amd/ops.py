@@ -178,9 +178,29 @@ def conv_wgrad(src0, dy, dw, src1=None, ksize=3, stride=1, upsample=False, gn_sc
     a.dy, a.gn_scale_shift, a.silu = _lib.ptr(dy), _lib.ptr(gn_scale_shift), int(silu)
     a.dy_ctotal, a.dy_coff = dy.shape[1], dy_coff
     a.dw, a.force_direct = _lib.ptr(dw), int(direct)
+    lib = _lib.load()
+    need = C.c_size_t()
+    _lib.check(lib.dsg_conv2d_wgrad_workspace_bytes(C.byref(a), C.byref(need)))
+    ws = _wgrad_ws(src0.device, need.value)
+    a.workspace, a.workspace_bytes = (ws.data_ptr(), ws.numel()) if ws is not None else (None, 0)
     with torch.cuda.device(src0.device):
-        _lib.check(_lib.load().dsg_conv2d_wgrad(C.byref(a), _st(src0)))
+        _lib.check(lib.dsg_conv2d_wgrad(C.byref(a), _st(src0)))
     return dw
+
+
+_WGRAD_WS = {}
+
+
+def _wgrad_ws(device, nbytes):
+    """Cached split-K workspace (grows to the largest layer; stream order makes reuse across calls safe)."""
+    if nbytes == 0:
+        return None
+    key = str(device)
+    cur = _WGRAD_WS.get(key)
+    if cur is None or cur.numel() < nbytes:
+        cur = torch.empty(nbytes, dtype=torch.uint8, device=device)
+        _WGRAD_WS[key] = cur
+    return cur
 
 
 def gn_scale_shift_train(src0, gamma, beta, groups, eps, src1=None):

@@ -204,8 +204,11 @@ typedef struct {
   int32_t silu;
   float* dw;                    /* [cout][c0+c1][k][k] (OIHW, checkpoint layout); ACCUMULATED into */
   int32_t force_direct;         /* test hook: VALU reference kernel */
+  void* workspace;              /* split-K partial sums, summed in a fixed order (deterministic) */
+  size_t workspace_bytes;       /* >= dsg_conv2d_wgrad_workspace_bytes(args) */
 } dsg_conv_wgrad_args;
 int dsg_conv2d_wgrad(const dsg_conv_wgrad_args* a, void* stream);
+int dsg_conv2d_wgrad_workspace_bytes(const dsg_conv_wgrad_args* a, size_t* bytes);
 
 /* GroupNorm(+SiLU) backward over cat(src0, src1).  dx = d/dx of silu?(gn(x)) . dy (+ add); dgamma/dbeta are
  * accumulated.  ws_s12: [N][C][2] doubles, ws_coef: [N][C][3] floats. */
