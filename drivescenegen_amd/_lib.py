@@ -37,6 +37,7 @@ class ConvArgs(C.Structure):
         ("silu", C.c_int32),
         ("temb", C.c_void_p), ("temb_stride", C.c_int32),
         ("residual", C.c_void_p), ("dst", C.c_void_p), ("pool2", C.c_int32),
+        ("weight_h2", C.c_void_p),
     ]
 
 
@@ -75,6 +76,7 @@ SIGNATURES = {
     "dsg_conv2d_fwd_direct": [C.POINTER(ConvArgs), _vp],
     "dsg_conv_weight_relayout": [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp],
     "dsg_conv_weight_relayout_dgrad": [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp],
+    "dsg_conv_weight_relayout_h2": [_vp, _vp, _i32, _i32, _vp],
     "dsg_gn_channel_stats": [_vp, _i32, _vp, _i32, _i32, _i32, _vp, _vp],
     "dsg_gn_finalize": [_vp, _vp, _vp, _i32, _i32, _i32, _i32, _f32, _vp, _vp],
     "dsg_gn_apply": [_vp, _vp, _i32, _vp, _i32, _i32, _i32, _vp],

@@ -379,6 +379,10 @@ __global__ void weight_relayout_kernel(const float* __restrict__ w, float* __res
   }
 }
 
+bool conv_h2_eligible(const dsg_conv_args* a, int hout, int wout);
+int conv_h2_launch(const dsg_conv_args* a, int hout, int wout, hipStream_t st);
+void conv_h2_set_enabled(int on);
+
 static int g_conv_kc = 0;  // K-chunk of the 3x3 stride-1 kernel: 4 | 8 | 0 = by grid size (measured, r01)
 
 template <int KS, int STRIDE, int GM, int MT, int KC>
@@ -460,6 +464,8 @@ int conv2d_fwd_impl(const dsg_conv_args* a, hipStream_t st, int force_direct) {
   p.tiles_x = p.wout / TW; p.tiles_y = p.hout / TH;
   DSG_CHECK_ARG(!(p.pool && ((p.hout | p.wout) & 1)), "dsg_conv2d_fwd: pool2 needs even output dims");
 
+  if (!force_direct && conv_h2_eligible(a, p.hout, p.wout)) return conv_h2_launch(a, p.hout, p.wout, st);
+
   const bool tile_ok = (p.wout % TW == 0) && (p.hout % TH == 0) && (p.wstride % 32 == 0) && p.cin <= 2048 &&
                        (p.wstride >= ((p.cout + 31) / 32) * 32);
   const int s = a->stride, k = a->ksize, u = a->upsample;
@@ -495,10 +501,15 @@ int conv2d_fwd_impl(const dsg_conv_args* a, hipStream_t st, int force_direct) {
 
 }  // namespace dsg
 
-// Tuning / A-B switch (key 1: K-chunk of the 3x3 kernel, 0 = auto | 4 | 8).  Not part of the reference surface.
+// Tuning / A-B switches (key 1: K-chunk of the fp32 3x3 kernel, 0 = auto | 4 | 8; key 2: fp16x2-split 3x3 kernel
+// on/off).  Not part of the reference surface.
 DSG_API int dsg_set_tuning(int32_t key, int32_t value) {
   if (key == 1 && (value == 0 || value == 4 || value == 8)) {
     dsg::g_conv_kc = value;
+    return DSG_OK;
+  }
+  if (key == 2 && (value == 0 || value == 1)) {
+    dsg::conv_h2_set_enabled(value);
     return DSG_OK;
   }
   return dsg::fail(DSG_ERR_INVALID_ARG, "dsg_set_tuning: unknown key/value %d/%d", key, value);

@@ -1,0 +1,336 @@
+// 3x3 stride-1 convolution with fp32-equivalent accuracy on the fp16 matrix cores ("fp16x2 split").
+//
+// Same contract, tiling and fusions as conv.hip's conv_mfma_kernel (reference call sites: every 3x3
+// Conv2d of diffusers' UNet2DModel as built at DriveSceneGen/scripts/train.py:39-57 and run at
+// DriveSceneGen/pipeline/training_pipeline.py:84), but the contraction runs at the 16x-faster f16 MFMA
+// rate without giving up fp32 accuracy:
+//
+//   x = x1 + x2 * 2^-11,  x1 = fp16(x),  x2 = fp16((x - x1) * 2^11)      (|x - x1 - x2*2^-11| <= 2^-24 |x|)
+//   w = w1 + w2 * 2^-11   likewise (split once, at weight re-layout time)
+//   sum w*x  ~=  sum w1*x1  +  2^-11 * sum (w1*x2 + w2*x1)              (dropped w2*x2 term: 2^-24 relative)
+//
+// i.e. 3 v_mfma_f32_32x32x16_f16 per 16-deep k-step instead of 8 v_mfma_f32_32x32x2_f32: 5.3x fewer matrix
+// cycles.  fp16 x fp16 products are exact in the fp32 accumulator; the scaled low-order products go to a
+// second accumulator so that nothing is lost to fp16's narrow exponent (the 2^11 pre-scale keeps the low
+// parts normal).  Measured error vs fp64 is at or below that of a sequential fp32 fmaf chain
+// (tests/test_gpu_ops.py::test_conv_h2_*).  Inputs must satisfy |x| < 65504 (GroupNorm/SiLU outputs and
+// residual-stream activations do).
+//
+// LDS images (per K-chunk of 16 channels, double-buffered; same bytes as the fp32 kernel's):
+//   X[piece 2][g 2][pos 10x34][8 halfs]   -- lane = pixel reads one 16-B fragment (k-group g = lane>>5)
+//   W[piece 2][tap 9][g 2][cout 64][8]    -- lane = cout  reads one 16-B fragment; filled by LDS-DMA
+//                                            (global_load_lds_dwordx4: the pre-split weights need no math)
+// A and B use the same (g, j) <-> channel 8g+j map, so the MFMA's internal k order is irrelevant.
+#include "dsg_common.h"
+#include <algorithm>
+
+namespace dsg {
+
+bool prof_on();
+int prof_begin(int kid, double flops, double bytes, hipStream_t st);
+void prof_end(int idx, hipStream_t st);
+
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+
+struct ConvH2P {
+  const float* src0;
+  const float* src1;
+  int c0, c1, cin;
+  int n, hin, win;
+  int hc, wc;
+  int hout, wout;
+  int cout, cout_pad;
+  const _Float16* wh;  // [cin/16][2][9][2][cout_pad][8]
+  const float* bias;
+  const float* ss;
+  int silu;
+  const float* temb;
+  int temb_stride;
+  const float* res;
+  float* dst;
+  int tiles_x, tiles_y;
+};
+
+constexpr int H2_TH = 8, H2_TW = 32, H2_KC = 16, H2_BM = 64;
+constexpr int H2_PW = H2_TW + 2, H2_PH = H2_TH + 2, H2_PSZ = H2_PW * H2_PH;  // 34 x 10 = 340
+constexpr int H2_WHALFS = 2 * 9 * 2 * H2_BM * 8;                              // 18432 halfs = 36864 B
+constexpr int H2_XHALFS = 2 * 2 * H2_PSZ * 8;                                 // 10880 halfs = 21760 B
+constexpr int H2_BUF_BYTES = (H2_WHALFS + H2_XHALFS) * 2 + 64;                // + a dump slot for masked lanes
+constexpr int H2_NU = (2 * H2_PSZ + 255) / 256;                               // 3 staging units per thread
+
+__device__ __forceinline__ float silu_fast_h(float x) { return x * __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
+
+// GM: 0 plain, 1 nearest x2 gather
+template <int GM>
+__global__ __launch_bounds__(256, 1) void conv_h2_kernel(ConvH2P p) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int half = lane >> 5;
+  const int l31 = lane & 31;
+
+  int bid = blockIdx.x;
+  const int tx = bid % p.tiles_x;
+  bid /= p.tiles_x;
+  const int ty = bid % p.tiles_y;
+  const int n = bid / p.tiles_y;
+  const int m0 = blockIdx.y * H2_BM;
+  const int oy0 = ty * H2_TH, ox0 = tx * H2_TW;
+  const int plane = p.hin * p.win;
+  const int nq = p.cin / H2_KC;
+
+  // staging unit u = g * PSZ + pos: 8 channels (8g .. 8g+7) of one halo position
+  int goff[H2_NU], ug[H2_NU], xoff[H2_NU];
+  unsigned valid = 0;
+#pragma unroll
+  for (int i = 0; i < H2_NU; ++i) {
+    const int u = tid + 256 * i;
+    int off = 0, g = 0, xo = H2_WHALFS + H2_XHALFS;  // dump slot (in halfs) when u is past the patch
+    if (u < 2 * H2_PSZ) {
+      g = u >= H2_PSZ ? 1 : 0;
+      const int pos = u - g * H2_PSZ;
+      const int py = pos / H2_PW, px = pos - py * H2_PW;
+      const int gy = oy0 - 1 + py, gx = ox0 - 1 + px;
+      if (gy >= 0 && gy < p.hc && gx >= 0 && gx < p.wc) {
+        off = (GM ? (gy >> 1) : gy) * p.win + (GM ? (gx >> 1) : gx);
+        valid |= 1u << i;
+      }
+      xo = H2_WHALFS + (g * H2_PSZ + pos) * 8;  // piece 0; piece 1 is 2*PSZ*8 halfs further
+    }
+    goff[i] = off;
+    ug[i] = g;
+    xoff[i] = xo;
+  }
+  const bool has_ss = p.ss != nullptr;
+  const bool do_silu = has_ss && p.silu;
+  const float* ssg = has_ss ? p.ss + (size_t)n * p.cin * 2 : nullptr;
+
+  float xr[H2_NU][8];
+  float2 sr[H2_NU][8];
+
+  auto src_of = [&](int q) -> const float* {
+    const int cb = q * H2_KC;
+    return (cb < p.c0) ? p.src0 + ((size_t)n * p.c0 + cb) * plane
+                       : p.src1 + ((size_t)n * p.c1 + (cb - p.c0)) * plane;
+  };
+  auto load_unit = [&](int i, int q, const float* sp) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int c = ug[i] * 8 + j;
+      xr[i][j] = sp[c * plane + goff[i]];
+      if (has_ss) sr[i][j] = *reinterpret_cast<const float2*>(ssg + 2 * (q * H2_KC + c));
+    }
+  };
+  auto commit_unit = [&](int i, unsigned char* buf) {
+    half8 h1, h2;
+    const bool ok = (valid >> i) & 1u;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      float v = xr[i][j];
+      if (has_ss) v = v * sr[i][j].x + sr[i][j].y;
+      const float sv = silu_fast_h(v);
+      v = do_silu ? sv : v;
+      v = ok ? v : 0.f;
+      const _Float16 a = (_Float16)v;
+      h1[j] = a;
+      h2[j] = (_Float16)((v - (float)a) * 2048.0f);
+    }
+    _Float16* xb = reinterpret_cast<_Float16*>(buf);
+    *reinterpret_cast<half8*>(xb + xoff[i]) = h1;
+    *reinterpret_cast<half8*>(xb + xoff[i] + (xoff[i] < H2_WHALFS + H2_XHALFS ? 2 * H2_PSZ * 8 : 0)) = h2;
+  };
+  // weight slab of chunk q: 36 segments (piece, tap, g) of 64 couts x 16 B, moved global -> LDS by DMA;
+  // wave w moves segments w, w+4, ...
+  auto dma_weights = [&](int k, int q, unsigned char* buf) {
+    const int seg = wave + 4 * k;  // 0..35
+    const _Float16* gp = p.wh + (((size_t)q * 36 + seg) * p.cout_pad + m0 + lane) * 8;
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gp,
+                                     (__attribute__((address_space(3))) void*)(buf + seg * 1024), 16, 0, 0);
+  };
+
+  f32x16 acc_hi[2][2], acc_lo[2][2];
+#pragma unroll
+  for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        acc_hi[mt][nt][r] = 0.f;
+        acc_lo[mt][nt][r] = 0.f;
+      }
+
+  unsigned char* buf0 = smem_raw;
+  unsigned char* buf1 = smem_raw + H2_BUF_BYTES;
+
+  // prologue: chunk 0 -> buffer 0; chunk 1 -> registers
+  {
+    const float* sp = src_of(0);
+#pragma unroll
+    for (int i = 0; i < H2_NU; ++i) load_unit(i, 0, sp);
+#pragma unroll
+    for (int k = 0; k < 9; ++k) dma_weights(k, 0, buf0);
+#pragma unroll
+    for (int i = 0; i < H2_NU; ++i) commit_unit(i, buf0);
+    const int q1 = min(1, nq - 1);
+    const float* sp1 = src_of(q1);
+#pragma unroll
+    for (int i = 0; i < H2_NU; ++i) load_unit(i, q1, sp1);
+  }
+  __syncthreads();
+
+  for (int q = 0; q < nq; ++q) {
+    unsigned char* cur = (q & 1) ? buf1 : buf0;
+    unsigned char* nxt = (q & 1) ? buf0 : buf1;
+    const int qc = min(q + 1, nq - 1);  // chunk staged into nxt (registers hold its patch)
+    const int ql = min(q + 2, nq - 1);  // chunk whose patch is loaded into registers
+    const float* spn = src_of(ql);
+    const _Float16* wl = reinterpret_cast<const _Float16*>(cur);
+    const _Float16* xl = wl + H2_WHALFS;
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) {
+      dma_weights(tap, qc, nxt);
+      if (tap % 3 == 1) {
+        commit_unit(tap / 3, nxt);
+        load_unit(tap / 3, ql, spn);
+      }
+      const int dy = tap / 3, dx = tap % 3;
+      half8 a[2][2], b[2][2];  // [tile][piece]
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int pc = 0; pc < 2; ++pc)
+          a[mt][pc] = *reinterpret_cast<const half8*>(wl + (((pc * 9 + tap) * 2 + half) * H2_BM + mt * 32 + l31) * 8);
+#pragma unroll
+      for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+        for (int pc = 0; pc < 2; ++pc)
+          b[nt][pc] = *reinterpret_cast<const half8*>(
+              xl + ((pc * 2 + half) * H2_PSZ + (wave * 2 + nt + dy) * H2_PW + l31 + dx) * 8);
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) {
+          acc_hi[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[mt][0], b[nt][0], acc_hi[mt][nt], 0, 0, 0);
+          acc_lo[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[mt][0], b[nt][1], acc_lo[mt][nt], 0, 0, 0);
+          acc_lo[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[mt][1], b[nt][0], acc_lo[mt][nt], 0, 0, 0);
+        }
+    }
+    __syncthreads();  // (drains the DMA: nxt is complete; everyone is done reading cur)
+  }
+
+  // Epilogue: identical to the fp32 kernel after recombining the two accumulators.
+  const int x = ox0 + l31;
+  const bool has_t = p.temb != nullptr;
+#pragma unroll
+  for (int mt = 0; mt < 2; ++mt) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int co = m0 + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+      if (co < p.cout) {
+        const float add = p.bias ? p.bias[co] : 0.f;
+        const float tv = has_t ? p.temb[(size_t)n * p.temb_stride + co] : 0.f;
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) {
+          const int y = oy0 + wave * 2 + nt;
+          const size_t idx = (((size_t)n * p.cout + co) * p.hout + y) * p.wout + x;
+          float v = (acc_hi[mt][nt][r] + acc_lo[mt][nt][r] * (1.0f / 2048.0f)) + add;
+          if (has_t) v = v + tv;
+          if (p.res) v = v + p.res[idx];
+          p.dst[idx] = v;
+        }
+      }
+    }
+  }
+}
+
+// OIHW fp32 -> [cin/16][piece 2][tap 9][g 2][cout_pad][8] fp16 (hi, scaled lo); zero-padded couts.
+__global__ void weight_relayout_h2_kernel(const float* __restrict__ w, _Float16* __restrict__ dst, int cout, int cin,
+                                          int cout_pad) {
+  const int64_t total = (int64_t)(cin / 16) * 9 * 2 * cout_pad * 8;  // one thread per (chunk, tap, g, co, j)
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int j = (int)(i % 8);
+    int64_t r = i / 8;
+    const int co = (int)(r % cout_pad);
+    r /= cout_pad;
+    const int g = (int)(r % 2);
+    r /= 2;
+    const int tap = (int)(r % 9);
+    const int q = (int)(r / 9);
+    const int ci = q * 16 + g * 8 + j;
+    const float v = co < cout ? w[((int64_t)co * cin + ci) * 9 + tap] : 0.f;
+    const _Float16 h1 = (_Float16)v;
+    const _Float16 h2 = (_Float16)((v - (float)h1) * 2048.0f);
+    const int64_t base = ((((int64_t)q * 2 + 0) * 9 + tap) * 2 + g) * cout_pad + co;
+    const int64_t base1 = ((((int64_t)q * 2 + 1) * 9 + tap) * 2 + g) * cout_pad + co;
+    dst[base * 8 + j] = h1;
+    dst[base1 * 8 + j] = h2;
+  }
+}
+
+static int g_h2_enabled = 1;
+
+bool conv_h2_eligible(const dsg_conv_args* a, int hout, int wout) {
+  const int cin = a->c0 + a->c1;
+  return g_h2_enabled && a->weight_h2 != nullptr && a->ksize == 3 && a->stride == 1 && a->upsample <= 1 && !a->pool2 &&
+         cin % 16 == 0 && (a->c1 == 0 || a->c0 % 16 == 0) && (wout % H2_TW == 0) && (hout % H2_TH == 0);
+}
+
+int conv_h2_launch(const dsg_conv_args* a, int hout, int wout, hipStream_t st) {
+  ConvH2P p;
+  p.src0 = a->src0; p.src1 = a->src1; p.c0 = a->c0; p.c1 = a->c1; p.cin = a->c0 + a->c1;
+  p.n = a->n; p.hin = a->hin; p.win = a->win;
+  p.hc = a->upsample ? 2 * a->hin : a->hin;
+  p.wc = a->upsample ? 2 * a->win : a->win;
+  p.hout = hout; p.wout = wout; p.cout = a->cout; p.cout_pad = (a->cout + 63) / 64 * 64;
+  p.wh = static_cast<const _Float16*>(a->weight_h2);
+  p.bias = a->bias; p.ss = a->gn_scale_shift; p.silu = a->silu; p.temb = a->temb; p.temb_stride = a->temb_stride;
+  p.res = a->residual; p.dst = a->dst;
+  p.tiles_x = wout / H2_TW; p.tiles_y = hout / H2_TH;
+  const size_t lds = 2 * (size_t)H2_BUF_BYTES;
+  dim3 grid(p.tiles_x * p.tiles_y * p.n, p.cout_pad / H2_BM);
+  int pi = -1;
+  if (prof_on()) {
+    const double px = (double)p.n * hout * wout;
+    pi = prof_begin(a->upsample ? 1 : 0, 2.0 * px * p.cout * p.cin * 9,
+                    4.0 * ((double)p.n * p.cin * p.hin * p.win + (double)p.cin * 9 * p.cout +
+                           px * p.cout * (p.res ? 2.0 : 1.0)), st);
+  }
+  if (a->upsample) {
+    static bool r1 = false;
+    if (!r1) {
+      DSG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_h2_kernel<1>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+      r1 = true;
+    }
+    hipLaunchKernelGGL(conv_h2_kernel<1>, grid, dim3(256), lds, st, p);
+  } else {
+    static bool r0 = false;
+    if (!r0) {
+      DSG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_h2_kernel<0>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+      r0 = true;
+    }
+    hipLaunchKernelGGL(conv_h2_kernel<0>, grid, dim3(256), lds, st, p);
+  }
+  prof_end(pi, st);
+  DSG_LAUNCH_CHECK();
+  return DSG_OK;
+}
+
+void conv_h2_set_enabled(int on) { g_h2_enabled = on; }
+
+}  // namespace dsg
+
+DSG_API int dsg_conv_weight_relayout_h2(const float* w_oihw, void* dst_half, int32_t cout, int32_t cin, void* stream) {
+  DSG_CHECK_ARG(w_oihw && dst_half, "dsg_conv_weight_relayout_h2: NULL pointer");
+  DSG_CHECK_ARG(cout > 0 && cin > 0 && cin % 16 == 0, "dsg_conv_weight_relayout_h2: cin must be a positive multiple of 16");
+  const int cout_pad = (cout + 63) / 64 * 64;
+  const int64_t total = (int64_t)(cin / 16) * 9 * 2 * cout_pad * 8;
+  const int blocks = (int)std::min<int64_t>(dsg::cdiv64(total, 256), 4096);
+  hipLaunchKernelGGL(dsg::weight_relayout_h2_kernel, dim3(blocks), dim3(256), 0, static_cast<hipStream_t>(stream),
+                     w_oihw, static_cast<_Float16*>(dst_half), cout, cin, cout_pad);
+  DSG_LAUNCH_CHECK();
+  return DSG_OK;
+}

@@ -77,7 +77,7 @@ struct T {  // activation [N, c, h, w] (or any scratch when c/h/w are unused)
   int c = 0, h = 0, w = 0;
 };
 
-struct Conv { float* w = nullptr; float* b = nullptr; int cin = 0, cout = 0, k = 0, wstride = 0; };
+struct Conv { float* w = nullptr; float* b = nullptr; int cin = 0, cout = 0, k = 0, wstride = 0; void* wh = nullptr; };
 struct GN { float* g = nullptr; float* b = nullptr; int c = 0; };
 struct Res { GN n1; Conv c1; int toff = 0; GN n2; Conv c2; bool sc = false; Conv csc; int cin = 0, cout = 0; };
 struct Att { GN gn; Conv qkv; Conv out; int c = 0, heads = 0; };
@@ -91,6 +91,7 @@ struct Param {
   int64_t numel;
   int cout, cin, k, cout_total, cout_off;
   bool set;
+  void* wh;  // fp16x2-split copy of a 3x3 weight (conv_h2.hip), or nullptr
 };
 
 }  // namespace
@@ -121,7 +122,7 @@ struct dsg_unet {
   void add_param(const std::string& name, ParamKind kind, float* dst, int64_t numel, int cout = 0, int cin = 0,
                  int k = 0, int cout_total = 0, int cout_off = 0) {
     index[name] = (int)params.size();
-    params.push_back({name, kind, dst, numel, cout, cin, k, cout_total, cout_off, false});
+    params.push_back({name, kind, dst, numel, cout, cin, k, cout_total, cout_off, false, nullptr});
   }
   void reg_conv(const std::string& pre, Conv& c, int cin, int cout, int k) {
     c.cin = cin; c.cout = cout; c.k = k;
@@ -130,6 +131,11 @@ struct dsg_unet {
     if (c.w && c.wstride != cout) (void)hipMemset(c.w, 0, (size_t)cin * k * k * c.wstride * sizeof(float));
     c.b = dalloc(cout);
     add_param(pre + ".weight", P_CONV, c.w, (int64_t)cin * k * k * cout, cout, cin, k, c.wstride, 0);
+    if (k == 3 && cin % 16 == 0) {  // second copy, pre-split for the fp16x2 matrix-core kernel (same bytes as fp32)
+      const int64_t halfs = (int64_t)(cin / 16) * 2 * 9 * 2 * ((cout + 63) / 64 * 64) * 8;
+      c.wh = dalloc((halfs + 1) / 2);
+      params.back().wh = c.wh;
+    }
     add_param(pre + ".bias", P_COPY, c.b, cout);
   }
   void reg_gn(const std::string& pre, GN& g, int c) {
@@ -228,7 +234,7 @@ struct Runner {
       a.src0 = x.p; a.c0 = x.c;
       a.src1 = skip ? skip->p : nullptr; a.c1 = skip ? skip->c : 0;
       a.n = B; a.hin = x.h; a.win = x.w; a.upsample = ups; a.ksize = cv.k; a.stride = stride; a.cout = cv.cout;
-      a.weight = cv.w; a.weight_cout_stride = cv.wstride; a.bias = cv.b;
+      a.weight = cv.w; a.weight_cout_stride = cv.wstride; a.bias = cv.b; a.weight_h2 = cv.wh;
       a.gn_scale_shift = ss ? ss->p : nullptr; a.silu = silu;
       a.temb = temb; a.temb_stride = h->proj_total;
       a.residual = res ? res->p : nullptr;
@@ -469,8 +475,12 @@ DSG_API int dsg_unet_set_param(dsg_unet_t* h, const char* name, const float* dat
   if (p.kind == P_COPY) {
     DSG_HIP(hipMemcpyAsync(p.dst, data, (size_t)numel * sizeof(float), hipMemcpyDeviceToDevice, st));
   } else {
-    const int rc = dsg_conv_weight_relayout(data, p.dst, p.cout, p.cin, p.k, p.cout_total, p.cout_off, stream);
+    int rc = dsg_conv_weight_relayout(data, p.dst, p.cout, p.cin, p.k, p.cout_total, p.cout_off, stream);
     if (rc != DSG_OK) return rc;
+    if (p.wh) {
+      rc = dsg_conv_weight_relayout_h2(data, p.wh, p.cout, p.cin, stream);
+      if (rc != DSG_OK) return rc;
+    }
   }
   DSG_HIP(hipStreamSynchronize(st));
   p.set = true;

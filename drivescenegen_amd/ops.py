@@ -36,6 +36,17 @@ def relayout_conv_weight(w_oihw: torch.Tensor, out: torch.Tensor = None, cout_to
     return out
 
 
+def relayout_conv_weight_h2(w_oihw: torch.Tensor, out: torch.Tensor = None) -> torch.Tensor:
+    """OIHW 3x3 (cin % 16 == 0) -> fp16x2-split engine layout [Cin/16][2][9][2][cout_pad64][8] (float16)."""
+    w = w_oihw.contiguous()
+    cout, cin = w.shape[0], w.shape[1]
+    if out is None:
+        out = torch.empty((cin // 16, 2, 9, 2, (cout + 63) // 64 * 64, 8), dtype=torch.float16, device=w.device)
+    with torch.cuda.device(w.device):
+        _lib.check(_lib.load().dsg_conv_weight_relayout_h2(_lib.ptr(w), out.data_ptr(), cout, cin, _st(w)))
+    return out
+
+
 def relayout_conv_weight_dgrad(w_oihw: torch.Tensor, out: torch.Tensor = None) -> torch.Tensor:
     """OIHW -> [Cout][k*k flipped][Cin padded to 32]: weight of the data-gradient conv dX = conv(dY, .)."""
     w = w_oihw.contiguous()
@@ -51,7 +62,7 @@ def relayout_conv_weight_dgrad(w_oihw: torch.Tensor, out: torch.Tensor = None) -
 
 def conv2d_fused(src0, weight_r, bias=None, src1=None, ksize=3, stride=1, upsample=False, gn_scale_shift=None,
                  silu=False, temb=None, temb_stride=0, residual=None, out=None, direct=False, cout=None,
-                 pool2=False, wstride=None):
+                 pool2=False, wstride=None, weight_h2=None):
     """dsg_conv2d_fwd: see include/dsg.h.  `weight_r` is in engine layout; `temb` is a [N, temb_stride] view
     whose first `cout` columns (from its data pointer) are added per (n, cout)."""
     lib = _lib.load()
@@ -73,6 +84,7 @@ def conv2d_fused(src0, weight_r, bias=None, src1=None, ksize=3, stride=1, upsamp
     a.upsample, a.ksize, a.stride, a.cout = int(upsample), ksize, stride, cout
     a.weight, a.bias = wptr, _lib.ptr(bias)
     a.weight_cout_stride, a.pool2 = wstride, int(pool2)
+    a.weight_h2 = weight_h2.data_ptr() if weight_h2 is not None else None
     a.gn_scale_shift, a.silu = _lib.ptr(gn_scale_shift), int(silu)
     if temb is not None:
         if not temb.is_cuda:

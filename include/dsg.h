@@ -72,6 +72,8 @@ typedef struct {
   const float* residual;        /* optional [N, cout, hout, wout] */
   float* dst;                   /* [N, cout, hout, wout] ([N, cout, hout/2, wout/2] with pool2) */
   int32_t pool2;                /* 1: 2x2 sum-pool of the result (adjoint of the nearest x2 upsample) */
+  const void* weight_h2;        /* optional: the same weights pre-split for the fp16x2 matrix-core path
+                                   (dsg_conv_weight_relayout_h2); used for 3x3 stride-1 convs with cin % 16 == 0 */
 } dsg_conv_args;
 
 int dsg_conv2d_fwd(const dsg_conv_args* a, void* stream);
@@ -81,6 +83,9 @@ int dsg_conv2d_fwd(const dsg_conv_args* a, void* stream);
  * [out][in] are the k=1 case. */
 int dsg_conv_weight_relayout(const float* w_oihw, float* dst, int32_t cout, int32_t cin, int32_t ksize,
                              int32_t cout_total, int32_t cout_off, void* stream);
+/* OIHW (3x3) -> [Cin/16][2][9][2][cout padded to 64][8] fp16: hi part and 2^11-scaled lo part of every weight,
+ * so that w == hi + lo * 2^-11 to 2^-24 relative (fp32-equivalent contraction on the f16 MFMA, conv_h2.hip). */
+int dsg_conv_weight_relayout_h2(const float* w_oihw, void* dst_half, int32_t cout, int32_t cin, void* stream);
 /* OIHW -> [Cout][k*k flipped][cin_total]: the weight of the data-gradient convolution
  * dX = conv(dY, W^T flipped) (backward of training_pipeline.py:84 through :86). */
 int dsg_conv_weight_relayout_dgrad(const float* w_oihw, float* dst, int32_t cout, int32_t cin, int32_t ksize,
@@ -261,7 +266,8 @@ int dsg_prof_enable(int32_t on);
 int dsg_prof_summary(int32_t kernel_class, double* total_ms, double* total_flops, double* total_bytes,
                      int64_t* launches);
 int dsg_prof_dump(const char* csv_path);
-/* Tuning switch (key 1: K-chunk of the 3x3 conv kernel, 0 = by grid size | 4 | 8). */
+/* Tuning switches (key 1: K-chunk of the fp32 3x3 conv kernel, 0 = by grid size | 4 | 8; key 2: fp16x2-split
+ * 3x3 kernel 1 = on (default) | 0 = off, i.e. pure fp32 MFMA). */
 int dsg_set_tuning(int32_t key, int32_t value);
 
 #ifdef __cplusplus

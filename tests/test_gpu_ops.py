@@ -210,3 +210,52 @@ def test_errors_are_reported_not_fatal():
         ops.conv2d_fused(x, w, stride=3)
     with pytest.raises(_lib.DsgError, match="head_dim"):
         ops.attention(torch.zeros(1, 3 * 24, 16, device=DEV), 2)
+
+
+H2_CASES = [
+    # name, c0, c1, cout, h, w, ups, gn, temb, res
+    ("h2_res64", 64, 0, 64, 32, 64, False, True, True, False),
+    ("h2_resid_128", 64, 0, 128, 16, 32, False, True, False, True),
+    ("h2_concat_straddle", 128, 64, 128, 16, 32, False, True, True, False),
+    ("h2_upsample", 64, 0, 64, 16, 16, True, False, False, False),
+    ("h2_cout96_pad", 32, 0, 96, 8, 32, False, True, False, True),
+]
+
+
+@pytest.mark.parametrize("case", H2_CASES, ids=[c[0] for c in H2_CASES])
+def test_conv_h2_split_matches_fp32(case):
+    """fp16x2-split matrix-core path (conv_h2.hip): same contract as the fp32 kernel, fp32-class accuracy."""
+    name, c0, c1, cout, h, w, ups, gn, temb, res = case
+    batch, cin, k = 2, c0 + c1, 3
+    x0 = _t(1, (batch, c0, h, w), 1.7)
+    x1 = _t(2, (batch, c1, h, w)) if c1 else None
+    wt = _t(3, (cout, cin, k, k), 1.0 / np.sqrt(cin * k * k))
+    bias = _t(4, (cout,), 0.1)
+    gamma, beta = 1 + _t(5, (cin,), 0.1), _t(6, (cin,), 0.1)
+    xin = torch.cat([x0, x1], 1) if c1 else x0
+    ref = F.silu(F.group_norm(xin, 8, gamma, beta, 1e-5)) if gn else xin
+    ref = F.interpolate(ref, scale_factor=2.0, mode="nearest") if ups else ref
+    ref64 = F.conv2d(ref.double(), wt.double(), bias.double(), padding=1)
+    mag = F.conv2d(ref.double().abs(), wt.double().abs(), None, padding=1) + 1e-30
+    tproj = _t(7, (batch, cout + 5), 0.5)
+    r = _t(8, tuple(ref64.shape))
+    extra = torch.zeros_like(ref64)
+    if temb:
+        extra = extra + tproj[:, 3:3 + cout, None, None].double()
+    if res:
+        extra = extra + r.double()
+    d = lambda t: None if t is None else t.to(DEV)
+    wr, wh = ops.relayout_conv_weight(d(wt)), ops.relayout_conv_weight_h2(d(wt))
+    ss = ops.gn_scale_shift(d(x0), d(gamma), d(beta), 8, 1e-5, src1=d(x1)) if gn else None
+    tp = d(tproj)
+    kw = dict(src1=d(x1), ksize=3, upsample=ups, gn_scale_shift=ss, silu=gn, temb=tp[:, 3:] if temb else None,
+              temb_stride=tp.stride(0), residual=d(r) if res else None, cout=cout)
+    got32 = ops.conv2d_fused(d(x0), wr, d(bias), **kw).cpu()
+    goth2 = ops.conv2d_fused(d(x0), wr, d(bias), weight_h2=wh, **kw).cpu()
+    _check(goth2, (ref64 + extra).float())
+    e32 = float(((got32.double() - ref64 - extra).abs() / mag).max())
+    eh2 = float(((goth2.double() - ref64 - extra).abs() / mag).max())
+    # round-off class of the contraction: the split path is not worse than the fp32 chain (plus the shared
+    # staging error of the fast SiLU)
+    assert eh2 <= max(2 * e32, 3e-7), (eh2, e32)
+    assert not torch.equal(got32, goth2)  # the two kernels really are different code paths

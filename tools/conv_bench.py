@@ -42,8 +42,11 @@ for name, c0, c1, cout, h, k, s, ups, gn, res in SHAPES:
     ho = (2 * h if ups else h) // s
     r = torch.randn(B, cout, ho, ho, device=dev) if res else None
     out = torch.empty(B, cout, ho, ho, device=dev)
+    wh = None
+    if os.environ.get("H2") == "1" and k == 3 and s == 1:
+        wh = ops.relayout_conv_weight_h2(torch.randn(cout, cin, 3, 3, device=dev) * 0.05)
     f = lambda: ops.conv2d_fused(x0, w, bias, src1=x1, ksize=k, stride=s, upsample=ups, gn_scale_shift=ss, silu=gn,
-                                 residual=r, out=out)
+                                 residual=r, out=out, weight_h2=wh)
     for _ in range(3):
         f()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
