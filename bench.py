@@ -29,6 +29,7 @@ sys.path.insert(0, ROOT)
 import torch  # noqa: E402
 
 PEAK_F32_TFLOPS = 157.3  # /opt/skills/guides/MI355X_MICROARCH.md: f32 vector = f32 MFMA peak
+PEAK_F16_TFLOPS = 2500.0  # dense f16/bf16 MFMA peak (same guide)
 PEAK_HBM_GBS = 8000.0
 
 
@@ -53,6 +54,8 @@ def gpu_leg(args, rank, world):
     # x_T ~ N(0,1): each rank draws its own rows of the global batch (stream = rank)
     x = torch.from_numpy(synth.normal(14555, (b, cfg["in_channels"], 256, 256), stream=7 + rank)).to(dev)
     lib = _lib.load()
+    if args.pure_f32:
+        _lib.check(lib.dsg_set_tuning(2, 0))
 
     def step(i, x):
         t = ts[i % len(ts)]
@@ -83,7 +86,8 @@ def gpu_leg(args, rank, world):
     prof = {}
     if not args.no_prof:
         names = {0: "conv3x3_s1_mfma_f32", 1: "conv3x3_upsample_mfma_f32", 2: "conv3x3_s2_mfma_f32",
-                 3: "conv1x1_mfma_f32", 4: "conv_direct_valu"}
+                 3: "conv1x1_mfma_f32", 4: "conv_direct_valu", 6: "conv3x3_s1_mfma_f16x2split",
+                 7: "conv3x3_upsample_mfma_f16x2split"}
         for kid, nm in names.items():
             ms, fl, by, n = C.c_double(), C.c_double(), C.c_double(), C.c_int64()
             _lib.check(lib.dsg_prof_summary(kid, C.byref(ms), C.byref(fl), C.byref(by), C.byref(n)))
@@ -137,6 +141,8 @@ def main():
     ap.add_argument("--no-prof", action="store_true", help="disable the HIP-event roofline leg")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
     ap.add_argument("--prof-dump", default=None, help="write the per-launch HIP-event records (CSV) here")
+    ap.add_argument("--pure-f32", action="store_true",
+                    help="disable the fp16x2-split conv path: every contraction on the f32 MFMA (A/B reference)")
     ap.add_argument("--cpu-threads", type=int, default=16,
                     help="threads for the CPU oracle (16 is the fastest setting on the 2x64-core GPU box: "
                          "32/64/128/256 threads run 1.1x/2x/4.4x/36x slower)")
@@ -156,10 +162,24 @@ def main():
     if rank == 0:
         n_img_steps = args.batch * world * args.steps
         value = n_img_steps / dt
-        dom = prof.get("conv3x3_s1_mfma_f32")
         roofline = None
-        if dom:
-            roofline = dict(bound="mfma", kernel="dsg::conv_mfma_kernel<3,1,false,2,8>", achieved=dom["tflops"],
+        if "conv3x3_s1_mfma_f16x2split" in prof:
+            # dominant kernel: 3x3 conv with fp32-equivalent accuracy on the f16 matrix cores, 3 MFMA products per
+            # fp32-equivalent MAC -> the ceiling for ALGORITHMIC (fp32-equivalent) FLOPs is the dense f16 peak / 3
+            dom = prof["conv3x3_s1_mfma_f16x2split"]
+            peak = PEAK_F16_TFLOPS / 3.0
+            roofline = dict(bound="mfma", kernel="dsg::conv_h2_kernel<0>", achieved=dom["tflops"], peak=peak,
+                            unit="TFLOP/s", frac=dom["tflops"] / peak, traffic=None,
+                            peak_note="2500 TF/s dense f16 MFMA / 3 products per fp32-equivalent MAC (fp16x2 split); "
+                                      "issued MFMA rate = 3 x achieved; the pure-fp32 MFMA peak is 157.3",
+                            issued_mfma_tflops=3.0 * dom["tflops"],
+                            frac_of_f32_mfma_peak=dom["tflops"] / PEAK_F32_TFLOPS,
+                            avg_launch_ms=dom["avg_ms"], launches=dom["launches"],
+                            alg_flops_per_launch=dom["flops_per_launch"],
+                            alg_gbs=dom["alg_gbs"], time_share=dom["total_ms"] * 1e-3 / dt)
+        elif "conv3x3_s1_mfma_f32" in prof:
+            dom = prof["conv3x3_s1_mfma_f32"]
+            roofline = dict(bound="mfma", kernel="dsg::conv_mfma_kernel<3,1,0,2,*>", achieved=dom["tflops"],
                             peak=PEAK_F32_TFLOPS, unit="TFLOP/s", frac=dom["tflops"] / PEAK_F32_TFLOPS, traffic=None,
                             avg_launch_ms=dom["avg_ms"], launches=dom["launches"],
                             alg_flops_per_launch=dom["flops_per_launch"],
@@ -170,7 +190,10 @@ def main():
             "metric": "denoising-steps/sec (U-Net fwd) on 256x256 BEV rasters", "value": value,
             "unit": "image-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "vs_baseline": None,
+            "dtype": "f32 (3x3 convs: fp32-equivalent contraction as an fp16x2 split on the f16 MFMA, fp32 accumulate; "
+                     "everything else f32)" if "conv3x3_s1_mfma_f16x2split" in prof else "f32",
+            "data": "synthetic",
             "config": {"workload": "BASELINE configs[1]: 256x256x4 BEV raster, DriveSceneGen default U-Net "
                                    "(56,575,748 params), 50-step DDIM (eta=0), batch 16 per GPU, fp32",
                        "batch_per_gpu": args.batch, "global_batch": args.batch * world,

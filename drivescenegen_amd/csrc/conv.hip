@@ -73,7 +73,7 @@ __device__ __forceinline__ float silu_fast(float x) {
 // GM: gather mode 0 plain, 1 nearest x2 (source pixel [y>>1][x>>1]), 2 zero-stuffed x2 (source pixel
 // [y/2][x/2] at even (y, x), zero elsewhere)
 template <int KS, int STRIDE, int GM, int MT, int KC>
-__global__ __launch_bounds__(256, (KC == 4 && KS == 3 && STRIDE == 1) ? 3 : 2) void conv_mfma_kernel(ConvP p) {
+__global__ __launch_bounds__(256, 2) void conv_mfma_kernel(ConvP p) {
   using G = ConvGeom<KS, STRIDE, KC>;
   constexpr int TAPS = G::TAPS, PW = G::PW, PSZ = G::PSZ, XN = G::XN;
   constexpr int BM = MT * 32;
@@ -260,6 +260,20 @@ __global__ __launch_bounds__(256, (KC == 4 && KS == 3 && STRIDE == 1) ? 3 : 2) v
   const int x = ox0 + l31;
   const bool has_t = p.temb != nullptr;
   if (!p.pool) {
+    // all residual loads first (in flight together), then add + store
+    const bool has_r = p.res != nullptr;
+    float rv[MT][16][2];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int co = min(m0 + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * half, p.cout - 1);
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) {
+          const int y = oy0 + wave * 2 + nt;
+          rv[mt][r][nt] = has_r ? p.res[(((size_t)n * p.cout + co) * p.hout + y) * p.wout + x] : 0.f;
+        }
+      }
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
 #pragma unroll
@@ -274,7 +288,7 @@ __global__ __launch_bounds__(256, (KC == 4 && KS == 3 && STRIDE == 1) ? 3 : 2) v
             const size_t idx = (((size_t)n * p.cout + co) * p.hout + y) * p.wout + x;
             float v = acc[mt][nt][r] + add;
             if (has_t) v = v + tv;
-            if (p.res) v = v + p.res[idx];
+            if (has_r) v = v + rv[mt][r][nt];
             p.dst[idx] = v;
           }
         }

@@ -220,9 +220,24 @@ __global__ __launch_bounds__(256, 1) void conv_h2_kernel(ConvH2P p) {
     __syncthreads();  // (drains the DMA: nxt is complete; everyone is done reading cur)
   }
 
-  // Epilogue: identical to the fp32 kernel after recombining the two accumulators.
+  // Epilogue: identical to the fp32 kernel after recombining the two accumulators.  All residual loads are
+  // issued before the first use (64 in flight per lane): with one wave per SIMD a load->add->store chain per
+  // element would expose the full memory latency 64 times.
   const int x = ox0 + l31;
   const bool has_t = p.temb != nullptr;
+  const bool has_r = p.res != nullptr;
+  float rv[2][16][2];
+#pragma unroll
+  for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int co = min(m0 + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * half, p.cout - 1);
+#pragma unroll
+      for (int nt = 0; nt < 2; ++nt) {
+        const int y = oy0 + wave * 2 + nt;
+        rv[mt][r][nt] = has_r ? p.res[(((size_t)n * p.cout + co) * p.hout + y) * p.wout + x] : 0.f;
+      }
+    }
 #pragma unroll
   for (int mt = 0; mt < 2; ++mt) {
 #pragma unroll
@@ -237,7 +252,7 @@ __global__ __launch_bounds__(256, 1) void conv_h2_kernel(ConvH2P p) {
           const size_t idx = (((size_t)n * p.cout + co) * p.hout + y) * p.wout + x;
           float v = (acc_hi[mt][nt][r] + acc_lo[mt][nt][r] * (1.0f / 2048.0f)) + add;
           if (has_t) v = v + tv;
-          if (p.res) v = v + p.res[idx];
+          if (has_r) v = v + rv[mt][r][nt];
           p.dst[idx] = v;
         }
       }
@@ -293,7 +308,7 @@ int conv_h2_launch(const dsg_conv_args* a, int hout, int wout, hipStream_t st) {
   int pi = -1;
   if (prof_on()) {
     const double px = (double)p.n * hout * wout;
-    pi = prof_begin(a->upsample ? 1 : 0, 2.0 * px * p.cout * p.cin * 9,
+    pi = prof_begin(a->upsample ? 7 : 6, 2.0 * px * p.cout * p.cin * 9,
                     4.0 * ((double)p.n * p.cin * p.hin * p.win + (double)p.cin * 9 * p.cout +
                            px * p.cout * (p.res ? 2.0 : 1.0)), st);
   }

@@ -259,7 +259,8 @@ int dsg_adamw_step(float* param, const float* grad, float* exp_avg, float* exp_a
 /* ------------------------------------------------------------------------------------------
  * Measurement plumbing (no reference counterpart): per-kernel-class HIP-event timing on the launch
  * stream, used by bench.py's roofline leg.  Classes: 0 conv3x3 stride-1, 1 conv3x3 on the nearest-x2
- * upsampled input, 2 conv3x3 stride-2, 3 conv1x1, 4 direct (VALU) conv.  FLOPs/bytes are the
+ * upsampled input, 2 conv3x3 stride-2, 3 conv1x1, 4 direct (VALU) conv, 5 conv weight-gradient, 6 / 7 conv3x3
+ * stride-1 / upsampled on the fp16x2-split matrix-core path.  FLOPs/bytes are the
  * algorithmic figures of each launch (2*MACs; input + weights + output once).
  * ---------------------------------------------------------------------------------------- */
 int dsg_prof_enable(int32_t on);
