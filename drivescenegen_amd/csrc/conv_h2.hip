@@ -23,6 +23,7 @@
 // A and B use the same (g, j) <-> channel 8g+j map, so the MFMA's internal k order is irrelevant.
 #include "dsg_common.h"
 #include <algorithm>
+#include <type_traits>
 
 namespace dsg {
 
@@ -60,7 +61,12 @@ constexpr int H2_NU = (2 * H2_PSZ + 255) / 256;                               //
 
 __device__ __forceinline__ float silu_fast_h(float x) { return x * __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
 
-// GM: 0 plain, 1 nearest x2 gather
+// GM: 0 plain, 1 nearest x2 gather.
+// Staging units are arranged so that the k-group g (hence the channel plane and the GroupNorm scale/shift) of
+// every unit is WAVE-UNIFORM: channel-plane bases and scale/shift live in SGPRs (s_load / saddr-form global
+// loads), and the only per-lane address is the 32-bit halo offset computed once per tile.
+//   unit 0: g = 0, halo position tid          unit 1: g = 1, halo position tid
+//   unit 2: g = wave >> 1, halo position 256 + (tid & 127)   (84 of 128 lanes valid)
 template <int GM>
 __global__ __launch_bounds__(256, 1) void conv_h2_kernel(ConvH2P p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -80,17 +86,16 @@ __global__ __launch_bounds__(256, 1) void conv_h2_kernel(ConvH2P p) {
   const int oy0 = ty * H2_TH, ox0 = tx * H2_TW;
   const int plane = p.hin * p.win;
   const int nq = p.cin / H2_KC;
+  const int g2 = wave >> 1;  // k-group of unit 2 (uniform per wave)
 
-  // staging unit u = g * PSZ + pos: 8 channels (8g .. 8g+7) of one halo position
-  int goff[H2_NU], ug[H2_NU], xoff[H2_NU];
+  int goff[H2_NU], xoff[H2_NU];
   unsigned valid = 0;
 #pragma unroll
   for (int i = 0; i < H2_NU; ++i) {
-    const int u = tid + 256 * i;
-    int off = 0, g = 0, xo = H2_WHALFS + H2_XHALFS;  // dump slot (in halfs) when u is past the patch
-    if (u < 2 * H2_PSZ) {
-      g = u >= H2_PSZ ? 1 : 0;
-      const int pos = u - g * H2_PSZ;
+    const int g = i == 0 ? 0 : (i == 1 ? 1 : g2);
+    const int pos = i < 2 ? tid : 256 + (tid & 127);
+    int off = 0, xo = H2_WHALFS + H2_XHALFS;  // dump slot (in halfs) when the position is past the patch
+    if (pos < H2_PSZ) {
       const int py = pos / H2_PW, px = pos - py * H2_PW;
       const int gy = oy0 - 1 + py, gx = ox0 - 1 + px;
       if (gy >= 0 && gy < p.hc && gx >= 0 && gx < p.wc) {
@@ -100,7 +105,6 @@ __global__ __launch_bounds__(256, 1) void conv_h2_kernel(ConvH2P p) {
       xo = H2_WHALFS + (g * H2_PSZ + pos) * 8;  // piece 0; piece 1 is 2*PSZ*8 halfs further
     }
     goff[i] = off;
-    ug[i] = g;
     xoff[i] = xo;
   }
   const bool has_ss = p.ss != nullptr;
@@ -108,19 +112,22 @@ __global__ __launch_bounds__(256, 1) void conv_h2_kernel(ConvH2P p) {
   const float* ssg = has_ss ? p.ss + (size_t)n * p.cin * 2 : nullptr;
 
   float xr[H2_NU][8];
-  float2 sr[H2_NU][8];
+  float2 sr[H2_NU][8];  // GroupNorm (scale, shift) of the unit's 8 channels, fetched with the patch (one chunk ahead)
 
-  auto src_of = [&](int q) -> const float* {
+  auto src_of = [&](int q) -> const float* {  // uniform
     const int cb = q * H2_KC;
     return (cb < p.c0) ? p.src0 + ((size_t)n * p.c0 + cb) * plane
                        : p.src1 + ((size_t)n * p.c1 + (cb - p.c0)) * plane;
   };
+  auto unit_g = [&](int i) -> int { return i == 0 ? 0 : (i == 1 ? 1 : g2); };
   auto load_unit = [&](int i, int q, const float* sp) {
+    const float* spg = sp + (size_t)(unit_g(i) * 8) * plane;  // uniform
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      const int c = ug[i] * 8 + j;
-      xr[i][j] = sp[c * plane + goff[i]];
-      if (has_ss) sr[i][j] = *reinterpret_cast<const float2*>(ssg + 2 * (q * H2_KC + c));
+    for (int j = 0; j < 8; ++j) xr[i][j] = (spg + (size_t)j * plane)[goff[i]];
+    if (has_ss) {
+      const float* ssq = ssg + 2 * (q * H2_KC + unit_g(i) * 8);  // uniform address: one line, broadcast
+#pragma unroll
+      for (int j = 0; j < 8; ++j) sr[i][j] = *reinterpret_cast<const float2*>(ssq + 2 * j);
     }
   };
   auto commit_unit = [&](int i, unsigned char* buf) {
@@ -145,8 +152,8 @@ __global__ __launch_bounds__(256, 1) void conv_h2_kernel(ConvH2P p) {
   // wave w moves segments w, w+4, ...
   auto dma_weights = [&](int k, int q, unsigned char* buf) {
     const int seg = wave + 4 * k;  // 0..35
-    const _Float16* gp = p.wh + (((size_t)q * 36 + seg) * p.cout_pad + m0 + lane) * 8;
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gp,
+    const _Float16* gp = p.wh + (((size_t)q * 36 + seg) * p.cout_pad + m0) * 8;  // uniform
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gp + lane * 8),
                                      (__attribute__((address_space(3))) void*)(buf + seg * 1024), 16, 0, 0);
   };
 
@@ -173,27 +180,29 @@ __global__ __launch_bounds__(256, 1) void conv_h2_kernel(ConvH2P p) {
     for (int k = 0; k < 9; ++k) dma_weights(k, 0, buf0);
 #pragma unroll
     for (int i = 0; i < H2_NU; ++i) commit_unit(i, buf0);
-    const int q1 = min(1, nq - 1);
-    const float* sp1 = src_of(q1);
+    if (nq > 1) {
+      const float* sp1 = src_of(1);
 #pragma unroll
-    for (int i = 0; i < H2_NU; ++i) load_unit(i, q1, sp1);
+      for (int i = 0; i < H2_NU; ++i) load_unit(i, 1, sp1);
+    }
   }
   __syncthreads();
 
-  for (int q = 0; q < nq; ++q) {
+  // One K-chunk: MFMAs on `cur`; STAGE: chunk q+1 (patch in registers, weights by DMA) goes into `nxt`;
+  // LOAD: chunk q+2's patch is fetched into the registers just freed.
+  auto chunk = [&](int q, auto stage_tag, auto load_tag) {
+    constexpr bool STAGE = decltype(stage_tag)::value, LOAD = decltype(load_tag)::value;
     unsigned char* cur = (q & 1) ? buf1 : buf0;
     unsigned char* nxt = (q & 1) ? buf0 : buf1;
-    const int qc = min(q + 1, nq - 1);  // chunk staged into nxt (registers hold its patch)
-    const int ql = min(q + 2, nq - 1);  // chunk whose patch is loaded into registers
-    const float* spn = src_of(ql);
+    const float* spn = LOAD ? src_of(q + 2) : nullptr;
     const _Float16* wl = reinterpret_cast<const _Float16*>(cur);
     const _Float16* xl = wl + H2_WHALFS;
 #pragma unroll
     for (int tap = 0; tap < 9; ++tap) {
-      dma_weights(tap, qc, nxt);
+      if (STAGE) dma_weights(tap, q + 1, nxt);
       if (tap % 3 == 1) {
-        commit_unit(tap / 3, nxt);
-        load_unit(tap / 3, ql, spn);
+        if (STAGE) commit_unit(tap / 3, nxt);
+        if (LOAD) load_unit(tap / 3, q + 2, spn);
       }
       const int dy = tap / 3, dx = tap % 3;
       half8 a[2][2], b[2][2];  // [tile][piece]
@@ -218,42 +227,56 @@ __global__ __launch_bounds__(256, 1) void conv_h2_kernel(ConvH2P p) {
         }
     }
     __syncthreads();  // (drains the DMA: nxt is complete; everyone is done reading cur)
-  }
+  };
+  using T = std::true_type;
+  using F = std::false_type;
+  int q = 0;
+  for (; q + 2 < nq; ++q) chunk(q, T{}, T{});
+  if (q + 1 < nq) chunk(q++, T{}, F{});  // last staged chunk: nothing left to load
+  chunk(q, F{}, F{});                    // last chunk: MFMAs only
 
-  // Epilogue: identical to the fp32 kernel after recombining the two accumulators.  All residual loads are
-  // issued before the first use (64 in flight per lane): with one wave per SIMD a load->add->store chain per
-  // element would expose the full memory latency 64 times.
-  const int x = ox0 + l31;
+  // Epilogue.  Everything but the lane's (half, column) offset is wave-uniform, so row bases, bias and
+  // time-embedding values come through SGPRs; all residual loads are issued before the first use (with one
+  // wave per SIMD a load->add->store chain per element would expose the memory latency 64 times).
+  // (the host only dispatches here when cout % 8 == 0, so a 4-row half-group is never split by cout)
   const bool has_t = p.temb != nullptr;
   const bool has_r = p.res != nullptr;
+  const int oplane = p.hout * p.wout;
+  const int lane_off = 4 * half * oplane + l31;
   float rv[2][16][2];
 #pragma unroll
   for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-      const int co = min(m0 + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * half, p.cout - 1);
+      const int cou = min(m0 + mt * 32 + (r & 3) + 8 * (r >> 2), p.cout - 8 + (r & 3));  // uniform, in range
 #pragma unroll
       for (int nt = 0; nt < 2; ++nt) {
-        const int y = oy0 + wave * 2 + nt;
-        rv[mt][r][nt] = has_r ? p.res[(((size_t)n * p.cout + co) * p.hout + y) * p.wout + x] : 0.f;
+        const float* row = p.res + (((size_t)n * p.cout + cou) * p.hout + oy0 + wave * 2 + nt) * p.wout + ox0;
+        rv[mt][r][nt] = has_r ? row[lane_off] : 0.f;
       }
     }
 #pragma unroll
   for (int mt = 0; mt < 2; ++mt) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-      const int co = m0 + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-      if (co < p.cout) {
-        const float add = p.bias ? p.bias[co] : 0.f;
-        const float tv = has_t ? p.temb[(size_t)n * p.temb_stride + co] : 0.f;
+      const int cou = m0 + mt * 32 + (r & 3) + 8 * (r >> 2);  // uniform; this lane's cout is cou + 4*half
+      if (cou < p.cout) {
+        float add0 = 0.f, add1 = 0.f;
+        if (p.bias) {
+          add0 = p.bias[cou];
+          add1 = p.bias[cou + 4];
+        }
+        if (has_t) {
+          add0 += p.temb[(size_t)n * p.temb_stride + cou];
+          add1 += p.temb[(size_t)n * p.temb_stride + cou + 4];
+        }
+        const float add = half ? add1 : add0;
 #pragma unroll
         for (int nt = 0; nt < 2; ++nt) {
-          const int y = oy0 + wave * 2 + nt;
-          const size_t idx = (((size_t)n * p.cout + co) * p.hout + y) * p.wout + x;
+          float* row = p.dst + (((size_t)n * p.cout + cou) * p.hout + oy0 + wave * 2 + nt) * p.wout + ox0;
           float v = (acc_hi[mt][nt][r] + acc_lo[mt][nt][r] * (1.0f / 2048.0f)) + add;
-          if (has_t) v = v + tv;
           if (has_r) v = v + rv[mt][r][nt];
-          p.dst[idx] = v;
+          row[lane_off] = v;
         }
       }
     }
@@ -289,7 +312,8 @@ static int g_h2_enabled = 1;
 bool conv_h2_eligible(const dsg_conv_args* a, int hout, int wout) {
   const int cin = a->c0 + a->c1;
   return g_h2_enabled && a->weight_h2 != nullptr && a->ksize == 3 && a->stride == 1 && a->upsample <= 1 && !a->pool2 &&
-         cin % 16 == 0 && (a->c1 == 0 || a->c0 % 16 == 0) && (wout % H2_TW == 0) && (hout % H2_TH == 0);
+         cin % 16 == 0 && (a->c1 == 0 || a->c0 % 16 == 0) && (wout % H2_TW == 0) && (hout % H2_TH == 0) &&
+         a->cout % 8 == 0;
 }
 
 int conv_h2_launch(const dsg_conv_args* a, int hout, int wout, hipStream_t st) {

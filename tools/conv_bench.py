@@ -32,6 +32,8 @@ SHAPES = [
     ("qkv 512->1536@32", 512, 0, 1536, 32, 1, 1, False, True, False),
 ]
 tot_t = tot_f = 0.0
+if os.environ.get('ONLY'):
+    SHAPES = [s for s in SHAPES if os.environ['ONLY'] in s[0]]
 for name, c0, c1, cout, h, k, s, ups, gn, res in SHAPES:
     cin = c0 + c1
     x0 = torch.randn(B, c0, h, h, device=dev)
