@@ -1,0 +1,102 @@
+"""SURVEY "next" rows: f1 GPU input pipeline, f2 post-processing masks, f3 full training resume."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+import drivescenegen_amd as d  # noqa: E402
+from drivescenegen_amd import imageops, synth  # noqa: E402
+from drivescenegen_amd.checkpoint import load_training_state, save_training_state  # noqa: E402
+from oracle.postproc_oracle import agent_threshold, get_gray_mask  # noqa: E402
+from tests.common import CFG1, synth_weights  # noqa: E402
+
+DEV = "cuda"
+
+
+def _scene_u8(n, h, w, seed):
+    x = synth.synth_scene_rasters(n, 3, h, w, seed)
+    img = ((x.transpose(0, 2, 3, 1) * 0.5 + 0.5) * 255).round().astype(np.uint8)
+    noise = (synth.uniform01(seed, img.size, stream=5).reshape(img.shape) * 12).astype(np.uint8)
+    return np.clip(img.astype(int) + noise - 6, 0, 255).astype(np.uint8)
+
+
+@pytest.mark.parametrize("hs,ws,ho,wo", [(512, 512, 256, 256), (64, 48, 32, 32), (40, 40, 64, 96)])
+def test_f1_resize_normalize_matches_dataset(tmp_path, hs, ws, ho, wo):
+    """One kernel == ToTensor + Resize(antialias=False) + Normalize of dataset.py:21-24,43-45."""
+    from types import SimpleNamespace
+    from PIL import Image
+    from drivescenegen_amd.dataset import Image_Dataset
+    imgs = _scene_u8(3, hs, ws, 4)
+    for i in range(3):
+        Image.fromarray(imgs[i]).save(tmp_path / f"{i}.png")
+    ds = Image_Dataset(SimpleNamespace(dataset_name=str(tmp_path / "*.png"), patterns_size_height=ho,
+                                       patterns_size_width=wo))
+    want = torch.stack([ds[i] for i in range(3)])
+    order = [int(f.split("/")[-1].split(".")[0]) for f in ds.data_list]
+    got = imageops.resize_normalize(torch.from_numpy(imgs[order]).to(DEV), (ho, wo)).cpu()
+    assert got.shape == want.shape
+    assert float((got - want).abs().max()) <= 2e-6
+    # the loader yields the same tensors, batch by batch
+    ld = imageops.GpuImageLoader(str(tmp_path / "*.png"), (ho, wo), batch_size=2, shuffle=False)
+    assert len(ld) == 2
+    batches = [b.cpu() for b in ld]
+    assert [b.shape[0] for b in batches] == [2, 1]
+    assert float((torch.cat(batches) - torch.stack([ds[ds.data_list.index(f)] for f in ld.files])).abs().max()) <= 2e-6
+
+
+def test_f2_masks_bit_exact():
+    imgs = _scene_u8(4, 128, 128, 7)
+    dev = torch.from_numpy(imgs).to(DEV)
+    hist = imageops.histograms_u8(dev).cpu().numpy()
+    for c in range(3):
+        assert np.array_equal(hist[1, c], np.bincount(imgs[1, :, :, c].ravel(), minlength=256))
+    gm = imageops.gray_mask_batch(dev).cpu().numpy()
+    am = imageops.agent_mask_batch(dev).cpu().numpy()
+    for i in range(4):
+        assert np.array_equal(gm[i], get_gray_mask(imgs[i])), i
+        raw = (imgs[i].astype(np.float32) / np.float32(255)).transpose(2, 0, 1)  # ToTensor of the saved PNG
+        assert np.array_equal(am[i], agent_threshold(raw)), i
+    assert 0 < (gm == 255).mean() < 0.5 and 0 < (am == 255).mean() < 0.5
+
+
+def test_f3_training_resume(tmp_path):
+    """Stop after 2 steps, save, rebuild everything from disk, continue: identical to 4 uninterrupted steps."""
+    def make():
+        net = synth_weights(d.UNet2DModel(**CFG1)).to(DEV).train()
+        opt = d.AdamW(net.parameters(), lr=1e-3)
+        sch = d.get_cosine_schedule_with_warmup(opt, 2, 10)
+        return net, opt, sch
+
+    noise_sched = d.DDPMScheduler()
+
+    def step(net, opt, sch, k):
+        x0 = torch.from_numpy(synth.synth_scene_rasters(2, 3, 64, 64, 40 + k)).to(DEV)
+        nz = torch.from_numpy(synth.normal(50 + k, (2, 3, 64, 64))).to(DEV)
+        t = torch.tensor([10 + k, 700 - k], device=DEV)
+        d.mse_loss(net(noise_sched.add_noise(x0, nz, t), t, return_dict=False)[0], nz).backward()
+        d.clip_grad_norm_(net.parameters(), 1.0)
+        opt.step()
+        sch.step()
+        opt.zero_grad()
+
+    ref = make()
+    for k in range(4):
+        step(*ref, k)
+    a = make()
+    for k in range(2):
+        step(*a, k)
+    d.DDPMPipeline(unet=a[0], scheduler=noise_sched).save_pretrained(str(tmp_path))
+    save_training_state(str(tmp_path), a[1], a[2], epoch=0, global_step=2)
+    net = d.UNet2DModel.from_pretrained(str(tmp_path), subfolder="unet").to(DEV).train()
+    opt = d.AdamW(net.parameters(), lr=1e-3)
+    sch = d.get_cosine_schedule_with_warmup(opt, 2, 10)
+    from drivescenegen_amd.autograd import get_train_state
+    get_train_state(net)
+    epoch, gstep, _ = load_training_state(str(tmp_path), opt, sch)
+    assert (epoch, gstep) == (0, 2)
+    for k in range(2, 4):
+        step(net, opt, sch, k)
+    for (n1, p), (_, q) in zip(net.named_parameters(), ref[0].named_parameters()):
+        assert torch.equal(p.detach(), q.detach()), n1
+    assert sch.get_last_lr() == ref[2].get_last_lr()

@@ -103,3 +103,24 @@ def test_step_t0_has_no_noise_and_clamps():
     d.set_timesteps(50)
     out = d.step(eps, 0, x)
     assert torch.allclose(out.prev_sample, torch.ones_like(x))  # alpha_prev = 1 at the last step
+
+
+def test_postproc_oracle_known_answers():
+    """Pins for oracle/postproc_oracle.py (reference image_utils.py:6-43, extract_vehicles.py:136-148) on a
+    hand-checkable image: background (128,128) grey, a lane pixel far from the peak, an agent above threshold."""
+    import numpy as np
+    from oracle.postproc_oracle import agent_threshold, get_gray_mask
+    img = np.full((8, 8, 3), 128, np.uint8)
+    img[..., 2] = 0
+    img[2, 3] = (250, 128, 0)      # dx far from the background peak -> lane (255)
+    img[4, 4] = (128, 100, 0)      # |100/255 - peak| = 0.1098 -> 0.1 threshold exceeded (peak edge 128/256=0.5)
+    img[5, 5] = (140, 120, 200)    # within +-0.1 on both map channels -> background; agent channel 200 > 100
+    m = get_gray_mask(img)
+    assert m[2, 3] == 255 and m[4, 4] == 255 and m[5, 5] == 0 and m[0, 0] == 0 and int((m == 255).sum()) == 2
+    raw = (img.astype(np.float32) / np.float32(255)).transpose(2, 0, 1)
+    a = agent_threshold(raw)
+    assert a[5, 5] == 255 and int((a == 255).sum()) == 1
+    # the float32 round trip u/255*255 truncates some byte values one below (e.g. 101 -> 100): threshold is on those
+    u = np.arange(256, dtype=np.float32)
+    rt = ((u / np.float32(255)) * 255).astype(np.uint8)
+    assert (rt <= np.arange(256)).all() and (np.arange(256) - rt).max() <= 1
