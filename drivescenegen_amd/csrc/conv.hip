@@ -396,6 +396,7 @@ __global__ void weight_relayout_kernel(const float* __restrict__ w, float* __res
 bool conv_h2_eligible(const dsg_conv_args* a, int hout, int wout);
 int conv_h2_launch(const dsg_conv_args* a, int hout, int wout, hipStream_t st);
 void conv_h2_set_enabled(int on);
+void conv_h2_set_rows(int r);
 
 static int g_conv_kc = 0;  // K-chunk of the 3x3 stride-1 kernel: 4 | 8 | 0 = by grid size (measured, r01)
 
@@ -524,6 +525,10 @@ DSG_API int dsg_set_tuning(int32_t key, int32_t value) {
   }
   if (key == 2 && (value == 0 || value == 1)) {
     dsg::conv_h2_set_enabled(value);
+    return DSG_OK;
+  }
+  if (key == 3 && (value == 0 || value == 2 || value == 4)) {
+    dsg::conv_h2_set_rows(value);
     return DSG_OK;
   }
   return dsg::fail(DSG_ERR_INVALID_ARG, "dsg_set_tuning: unknown key/value %d/%d", key, value);

@@ -52,23 +52,38 @@ struct ConvH2P {
   int tiles_x, tiles_y;
 };
 
-constexpr int H2_TH = 8, H2_TW = 32, H2_KC = 16, H2_BM = 64;
-constexpr int H2_PW = H2_TW + 2, H2_PH = H2_TH + 2, H2_PSZ = H2_PW * H2_PH;  // 34 x 10 = 340
-constexpr int H2_WHALFS = 2 * 9 * 2 * H2_BM * 8;                              // 18432 halfs = 36864 B
-constexpr int H2_XHALFS = 2 * 2 * H2_PSZ * 8;                                 // 10880 halfs = 21760 B
-constexpr int H2_BUF_BYTES = (H2_WHALFS + H2_XHALFS) * 2 + 64;                // + a dump slot for masked lanes
-constexpr int H2_NU = (2 * H2_PSZ + 255) / 256;                               // 3 staging units per thread
+constexpr int H2_TW = 32, H2_KC = 16, H2_BM = 64;
+constexpr int H2_PW = H2_TW + 2;
+constexpr int H2_WHALFS = 2 * 9 * 2 * H2_BM * 8;  // 18432 halfs = 36864 B
+
+// NT = output rows per wave (2 or 4): a workgroup covers 4*NT rows x 32 cols.  NT = 4 halves the LDS operand
+// traffic per MFMA (each weight fragment feeds 4 pixel tiles) and the weight DMA per MFMA; it needs 256
+// accumulator registers (the kernel owns the SIMD: 1 wave, 512 registers).
+template <int NT>
+struct H2Geom {
+  static constexpr int TH = 4 * NT;
+  static constexpr int PH = TH + 2;
+  static constexpr int PSZ = H2_PW * PH;              // 340 (NT=2) / 612 (NT=4) halo positions
+  static constexpr int XHALFS = 2 * 2 * PSZ * 8;      // [piece][g][pos][8]
+  static constexpr int BUF_BYTES = (H2_WHALFS + XHALFS) * 2 + 64;  // + a dump slot for masked lanes
+  static constexpr int FULL = PSZ / 256;              // full 256-position slabs per k-group (1 / 2)
+  static constexpr int NU = 2 * FULL + 1;             // staging units per thread (3 / 5)
+  static constexpr int REM0 = FULL * 256;             // first position of the shared remainder unit
+};
 
 __device__ __forceinline__ float silu_fast_h(float x) { return x * __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
 
-// GM: 0 plain, 1 nearest x2 gather.
+// GM: 0 plain, 1 nearest x2 gather; NT: rows per wave.
 // Staging units are arranged so that the k-group g (hence the channel plane and the GroupNorm scale/shift) of
 // every unit is WAVE-UNIFORM: channel-plane bases and scale/shift live in SGPRs (s_load / saddr-form global
 // loads), and the only per-lane address is the 32-bit halo offset computed once per tile.
-//   unit 0: g = 0, halo position tid          unit 1: g = 1, halo position tid
-//   unit 2: g = wave >> 1, halo position 256 + (tid & 127)   (84 of 128 lanes valid)
-template <int GM>
+//   units 0..FULL-1: g = 0, halo positions tid + 256*i      units FULL..2*FULL-1: g = 1, same positions
+//   last unit: g = wave >> 1, halo position FULL*256 + (tid & 127)   (the remainder, valid where < PSZ)
+template <int GM, int NT>
 __global__ __launch_bounds__(256, 1) void conv_h2_kernel(ConvH2P p) {
+  using G = H2Geom<NT>;
+  constexpr int H2_TH = G::TH, H2_PSZ = G::PSZ, H2_XHALFS = G::XHALFS, H2_BUF_BYTES = G::BUF_BYTES, H2_NU = G::NU;
+  constexpr int FULL = G::FULL;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
 
   const int tid = threadIdx.x;
@@ -92,8 +107,8 @@ __global__ __launch_bounds__(256, 1) void conv_h2_kernel(ConvH2P p) {
   unsigned valid = 0;
 #pragma unroll
   for (int i = 0; i < H2_NU; ++i) {
-    const int g = i == 0 ? 0 : (i == 1 ? 1 : g2);
-    const int pos = i < 2 ? tid : 256 + (tid & 127);
+    const int g = i < FULL ? 0 : (i < 2 * FULL ? 1 : g2);
+    const int pos = i < 2 * FULL ? tid + 256 * (i % FULL) : G::REM0 + (tid & 127);
     int off = 0, xo = H2_WHALFS + H2_XHALFS;  // dump slot (in halfs) when the position is past the patch
     if (pos < H2_PSZ) {
       const int py = pos / H2_PW, px = pos - py * H2_PW;
@@ -119,7 +134,7 @@ __global__ __launch_bounds__(256, 1) void conv_h2_kernel(ConvH2P p) {
     return (cb < p.c0) ? p.src0 + ((size_t)n * p.c0 + cb) * plane
                        : p.src1 + ((size_t)n * p.c1 + (cb - p.c0)) * plane;
   };
-  auto unit_g = [&](int i) -> int { return i == 0 ? 0 : (i == 1 ? 1 : g2); };
+  auto unit_g = [&](int i) -> int { return i < FULL ? 0 : (i < 2 * FULL ? 1 : g2); };
   auto load_unit = [&](int i, int q, const float* sp) {
     const float* spg = sp + (size_t)(unit_g(i) * 8) * plane;  // uniform
 #pragma unroll
@@ -157,11 +172,11 @@ __global__ __launch_bounds__(256, 1) void conv_h2_kernel(ConvH2P p) {
                                      (__attribute__((address_space(3))) void*)(buf + seg * 1024), 16, 0, 0);
   };
 
-  f32x16 acc_hi[2][2], acc_lo[2][2];
+  f32x16 acc_hi[2][NT], acc_lo[2][NT];
 #pragma unroll
   for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
-    for (int nt = 0; nt < 2; ++nt)
+    for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         acc_hi[mt][nt][r] = 0.f;
@@ -200,27 +215,29 @@ __global__ __launch_bounds__(256, 1) void conv_h2_kernel(ConvH2P p) {
 #pragma unroll
     for (int tap = 0; tap < 9; ++tap) {
       if (STAGE) dma_weights(tap, q + 1, nxt);
-      if (tap % 3 == 1) {
-        if (STAGE) commit_unit(tap / 3, nxt);
-        if (LOAD) load_unit(tap / 3, q + 2, spn);
+      // NU = 3: units at taps 1, 4, 7;  NU = 5: units at taps 0, 2, 4, 6, 8
+      constexpr int UNIT_STRIDE = (H2_NU == 3) ? 3 : 2, UNIT_PHASE = (H2_NU == 3) ? 1 : 0;
+      if (tap % UNIT_STRIDE == UNIT_PHASE && tap / UNIT_STRIDE < H2_NU) {
+        if (STAGE) commit_unit(tap / UNIT_STRIDE, nxt);
+        if (LOAD) load_unit(tap / UNIT_STRIDE, q + 2, spn);
       }
       const int dy = tap / 3, dx = tap % 3;
-      half8 a[2][2], b[2][2];  // [tile][piece]
+      half8 a[2][2], b[NT][2];  // [tile][piece]
 #pragma unroll
       for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
         for (int pc = 0; pc < 2; ++pc)
           a[mt][pc] = *reinterpret_cast<const half8*>(wl + (((pc * 9 + tap) * 2 + half) * H2_BM + mt * 32 + l31) * 8);
 #pragma unroll
-      for (int nt = 0; nt < 2; ++nt)
+      for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
         for (int pc = 0; pc < 2; ++pc)
           b[nt][pc] = *reinterpret_cast<const half8*>(
-              xl + ((pc * 2 + half) * H2_PSZ + (wave * 2 + nt + dy) * H2_PW + l31 + dx) * 8);
+              xl + ((pc * 2 + half) * H2_PSZ + (wave * NT + nt + dy) * H2_PW + l31 + dx) * 8);
 #pragma unroll
       for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
-        for (int nt = 0; nt < 2; ++nt) {
+        for (int nt = 0; nt < NT; ++nt) {
           acc_hi[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[mt][0], b[nt][0], acc_hi[mt][nt], 0, 0, 0);
           acc_lo[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[mt][0], b[nt][1], acc_lo[mt][nt], 0, 0, 0);
           acc_lo[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[mt][1], b[nt][0], acc_lo[mt][nt], 0, 0, 0);
@@ -243,20 +260,18 @@ __global__ __launch_bounds__(256, 1) void conv_h2_kernel(ConvH2P p) {
   const bool has_r = p.res != nullptr;
   const int oplane = p.hout * p.wout;
   const int lane_off = 4 * half * oplane + l31;
-  float rv[2][16][2];
 #pragma unroll
-  for (int mt = 0; mt < 2; ++mt)
+  for (int mt = 0; mt < 2; ++mt) {
+    float rv[16][NT];  // residual values of this 32-cout slab, all in flight before the first use
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int cou = min(m0 + mt * 32 + (r & 3) + 8 * (r >> 2), p.cout - 8 + (r & 3));  // uniform, in range
 #pragma unroll
-      for (int nt = 0; nt < 2; ++nt) {
-        const float* row = p.res + (((size_t)n * p.cout + cou) * p.hout + oy0 + wave * 2 + nt) * p.wout + ox0;
-        rv[mt][r][nt] = has_r ? row[lane_off] : 0.f;
+      for (int nt = 0; nt < NT; ++nt) {
+        const float* row = p.res + (((size_t)n * p.cout + cou) * p.hout + oy0 + wave * NT + nt) * p.wout + ox0;
+        rv[r][nt] = has_r ? row[lane_off] : 0.f;
       }
     }
-#pragma unroll
-  for (int mt = 0; mt < 2; ++mt) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int cou = m0 + mt * 32 + (r & 3) + 8 * (r >> 2);  // uniform; this lane's cout is cou + 4*half
@@ -272,10 +287,10 @@ __global__ __launch_bounds__(256, 1) void conv_h2_kernel(ConvH2P p) {
         }
         const float add = half ? add1 : add0;
 #pragma unroll
-        for (int nt = 0; nt < 2; ++nt) {
-          float* row = p.dst + (((size_t)n * p.cout + cou) * p.hout + oy0 + wave * 2 + nt) * p.wout + ox0;
+        for (int nt = 0; nt < NT; ++nt) {
+          float* row = p.dst + (((size_t)n * p.cout + cou) * p.hout + oy0 + wave * NT + nt) * p.wout + ox0;
           float v = (acc_hi[mt][nt][r] + acc_lo[mt][nt][r] * (1.0f / 2048.0f)) + add;
-          if (has_r) v = v + rv[mt][r][nt];
+          if (has_r) v = v + rv[r][nt];
           row[lane_off] = v;
         }
       }
@@ -308,11 +323,12 @@ __global__ void weight_relayout_h2_kernel(const float* __restrict__ w, _Float16*
 }
 
 static int g_h2_enabled = 1;
+static int g_h2_rows = 0;  // rows per wave: 0 = by grid size, 2 | 4 forced (tuning key 3)
 
 bool conv_h2_eligible(const dsg_conv_args* a, int hout, int wout) {
   const int cin = a->c0 + a->c1;
   return g_h2_enabled && a->weight_h2 != nullptr && a->ksize == 3 && a->stride == 1 && a->upsample <= 1 && !a->pool2 &&
-         cin % 16 == 0 && (a->c1 == 0 || a->c0 % 16 == 0) && (wout % H2_TW == 0) && (hout % H2_TH == 0) &&
+         cin % 16 == 0 && (a->c1 == 0 || a->c0 % 16 == 0) && (wout % H2_TW == 0) && (hout % 8 == 0) &&
          a->cout % 8 == 0;
 }
 
@@ -326,8 +342,12 @@ int conv_h2_launch(const dsg_conv_args* a, int hout, int wout, hipStream_t st) {
   p.wh = static_cast<const _Float16*>(a->weight_h2);
   p.bias = a->bias; p.ss = a->gn_scale_shift; p.silu = a->silu; p.temb = a->temb; p.temb_stride = a->temb_stride;
   p.res = a->residual; p.dst = a->dst;
-  p.tiles_x = wout / H2_TW; p.tiles_y = hout / H2_TH;
-  const size_t lds = 2 * (size_t)H2_BUF_BYTES;
+  // 16-row tiles (NT = 4) when they still give every CU a workgroup; 8-row tiles otherwise
+  const int blocks16 = (hout % 16 == 0) ? (wout / H2_TW) * (hout / 16) * p.n * (p.cout_pad / H2_BM) : 0;
+  const bool nt4 = g_h2_rows != 2 && blocks16 >= (g_h2_rows == 4 ? 1 : 256);
+  const int th = nt4 ? 16 : 8;
+  p.tiles_x = wout / H2_TW; p.tiles_y = hout / th;
+  const size_t lds = 2 * (size_t)(nt4 ? H2Geom<4>::BUF_BYTES : H2Geom<2>::BUF_BYTES);
   dim3 grid(p.tiles_x * p.tiles_y * p.n, p.cout_pad / H2_BM);
   int pi = -1;
   if (prof_on()) {
@@ -336,22 +356,19 @@ int conv_h2_launch(const dsg_conv_args* a, int hout, int wout, hipStream_t st) {
                     4.0 * ((double)p.n * p.cin * p.hin * p.win + (double)p.cin * 9 * p.cout +
                            px * p.cout * (p.res ? 2.0 : 1.0)), st);
   }
+  static bool raised = false;
+  if (!raised) {
+    const void* ks[4] = {reinterpret_cast<const void*>(conv_h2_kernel<0, 2>), reinterpret_cast<const void*>(conv_h2_kernel<1, 2>),
+                         reinterpret_cast<const void*>(conv_h2_kernel<0, 4>), reinterpret_cast<const void*>(conv_h2_kernel<1, 4>)};
+    for (const void* k : ks) DSG_HIP(hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    raised = true;
+  }
   if (a->upsample) {
-    static bool r1 = false;
-    if (!r1) {
-      DSG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_h2_kernel<1>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-      r1 = true;
-    }
-    hipLaunchKernelGGL(conv_h2_kernel<1>, grid, dim3(256), lds, st, p);
+    if (nt4) hipLaunchKernelGGL((conv_h2_kernel<1, 4>), grid, dim3(256), lds, st, p);
+    else hipLaunchKernelGGL((conv_h2_kernel<1, 2>), grid, dim3(256), lds, st, p);
   } else {
-    static bool r0 = false;
-    if (!r0) {
-      DSG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_h2_kernel<0>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-      r0 = true;
-    }
-    hipLaunchKernelGGL(conv_h2_kernel<0>, grid, dim3(256), lds, st, p);
+    if (nt4) hipLaunchKernelGGL((conv_h2_kernel<0, 4>), grid, dim3(256), lds, st, p);
+    else hipLaunchKernelGGL((conv_h2_kernel<0, 2>), grid, dim3(256), lds, st, p);
   }
   prof_end(pi, st);
   DSG_LAUNCH_CHECK();
@@ -359,6 +376,7 @@ int conv_h2_launch(const dsg_conv_args* a, int hout, int wout, hipStream_t st) {
 }
 
 void conv_h2_set_enabled(int on) { g_h2_enabled = on; }
+void conv_h2_set_rows(int r) { g_h2_rows = r; }
 
 }  // namespace dsg
 

@@ -10,6 +10,9 @@ from drivescenegen_amd import _lib
 if os.environ.get("DSG_VARIANT"):
     _lib.check(_lib.load().dsg_set_tuning(0, int(os.environ["DSG_VARIANT"])))
     print("conv variant", os.environ["DSG_VARIANT"])
+if os.environ.get("DSG_ROWS"):
+    _lib.check(_lib.load().dsg_set_tuning(3, int(os.environ["DSG_ROWS"])))
+    print("h2 rows/wave", os.environ["DSG_ROWS"])
 if os.environ.get("DSG_KC"):
     _lib.check(_lib.load().dsg_set_tuning(1, int(os.environ["DSG_KC"])))
     print("kc", os.environ["DSG_KC"])
