@@ -214,12 +214,29 @@ __global__ __launch_bounds__(256, 1) void conv_h2_kernel(ConvH2P p) {
     const _Float16* xl = wl + H2_WHALFS;
 #pragma unroll
     for (int tap = 0; tap < 9; ++tap) {
-      if (STAGE) dma_weights(tap, q + 1, nxt);
       // NU = 3: units at taps 1, 4, 7;  NU = 5: units at taps 0, 2, 4, 6, 8
       constexpr int UNIT_STRIDE = (H2_NU == 3) ? 3 : 2, UNIT_PHASE = (H2_NU == 3) ? 1 : 0;
       if (tap % UNIT_STRIDE == UNIT_PHASE && tap / UNIT_STRIDE < H2_NU) {
         if (STAGE) commit_unit(tap / UNIT_STRIDE, nxt);
         if (LOAD) load_unit(tap / UNIT_STRIDE, q + 2, spn);
+      }
+      // The weight DMAs go AFTER this tap's commit: with a DMA in flight hipcc waits vmcnt(0) at every use of
+      // an ordinary load result, so a DMA issued just before a commit would stall it for the whole transfer.
+      if (STAGE) {
+        if (H2_NU == 5) {  // commits at even taps: two DMAs at each odd tap, the ninth after the last commit
+          if (tap & 1) {
+            dma_weights(tap - 1, q + 1, nxt);
+            dma_weights(tap, q + 1, nxt);
+          } else if (tap == 8) {
+            dma_weights(8, q + 1, nxt);
+          }
+        } else {  // commits at taps 1, 4, 7: three DMAs right after each
+          if (tap % 3 == 1) {
+            dma_weights(tap - 1, q + 1, nxt);
+            dma_weights(tap, q + 1, nxt);
+            dma_weights(tap + 1, q + 1, nxt);
+          }
+        }
       }
       const int dy = tap / 3, dx = tap % 3;
       half8 a[2][2], b[NT][2];  // [tile][piece]
