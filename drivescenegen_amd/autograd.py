@@ -40,6 +40,7 @@ class TrainState:
         SLABS[self.grad_flat.untyped_storage().data_ptr()] = self.grad_flat
         self.params = dict(self.items)
         self.wf, self.wd, self.versions = {}, {}, {}
+        self.wh, self.whd = {}, {}  # fp16x2-split copies (forward / data-gradient) of the eligible 3x3 weights
         self.freqs = ops.sinusoid_freqs(model.config.block_out_channels[0]).to(dev)
         self.grad_ready_hooks = []  # callables(name) fired when a parameter's gradient is final (DDP buckets)
         self.attach()
@@ -79,6 +80,12 @@ class TrainState:
                 self.wd[name] = torch.zeros((p.shape[0], k * k, ops._pad32(cin) + 64), dtype=torch.float32,
                                             device=p.device)
             ops.relayout_conv_weight_dgrad(p, out=self.wd[name])
+            if p.dim() == 4 and p.shape[2] == 3:
+                cout = p.shape[0]
+                if cin % 16 == 0 and cout % 64 == 0:   # forward conv on the fp16x2-split matrix-core path
+                    self.wh[name] = ops.relayout_conv_weight_h2(p, out=self.wh.get(name))
+                if cout % 16 == 0 and cin % 64 == 0:   # its data gradient (K = cout, N = cin)
+                    self.whd[name] = ops.relayout_conv_weight_h2_dgrad(p, out=self.whd.get(name))
         return self.wf[name], self.wd[name]
 
     def qkv_w(self, prefix):
@@ -185,9 +192,11 @@ def _forward(model, st: TrainState, tape: _Tape, sample, timesteps):
                                               src1=x1)
         y = ops.conv2d_fused(x0, wf, bias, src1=x1, ksize=k, stride=stride, upsample=ups, gn_scale_shift=ss,
                              silu=silu, temb=None if toff is None else tproj[:, toff:],
-                             temb_stride=tproj.stride(0), residual=res, cout=cout)
+                             temb_stride=tproj.stride(0), residual=res, cout=cout,
+                             weight_h2=st.wh.get(wname + ".weight"))
         tape.recs.append(dict(kind="conv", x0=x0, x1=x1, ss=ss, mr=mr, gn=gn, silu=silu, k=k, stride=stride, ups=ups,
-                              toff=toff, res=res, y=y, wname=wname, wd=wd, cout=cout, need_dx=need_dx))
+                              toff=toff, res=res, y=y, wname=wname, wd=wd, cout=cout, need_dx=need_dx,
+                              whd=st.whd.get(wname + ".weight")))
         return y
 
     def resnet(x, skip, pre):
@@ -275,8 +284,10 @@ def _backward(model, st: TrainState, tape: _Tape, dout):
             cin0, cin1 = x0.shape[1], (x1.shape[1] if x1 is not None else 0)
             wd = rec["wd"]
             up_mode = 2 if rec["stride"] == 2 else 0
+            whd = rec["whd"] if (rec["stride"] == 1 and not rec["ups"]) else None  # the split kernel has no pool / zero-stuff mode
             if rec["gn"] is not None:
-                da = ops.conv2d_fused(dy, wd, ksize=k, upsample=up_mode, cout=cin0 + cin1, pool2=rec["ups"])
+                da = ops.conv2d_fused(dy, wd, ksize=k, upsample=up_mode, cout=cin0 + cin1, pool2=rec["ups"],
+                                      weight_h2=whd)
                 gnn = rec["gn"]
                 dx0, dx1 = ops.gn_bwd(x0, da, rec["ss"], rec["mr"], P[gnn + ".weight"].detach(), groups, rec["silu"],
                                       st.grad(gnn + ".weight"), st.grad(gnn + ".bias"), src1=x1, add0=tape.g(x0),
@@ -289,7 +300,7 @@ def _backward(model, st: TrainState, tape: _Tape, dout):
                 # no norm in front: the data gradient lands on the source(s) directly (one conv per source,
                 # selecting that source's columns of the transposed weight; the fan-in add rides the epilogue)
                 tape.setg(x0, ops.conv2d_fused(dy, wd, ksize=k, upsample=up_mode, cout=cin0, pool2=rec["ups"],
-                                               residual=tape.g(x0)))
+                                               residual=tape.g(x0), weight_h2=whd if x1 is None else None))
                 if x1 is not None:
                     tape.setg(x1, ops.conv2d_fused(dy, wd[:, :, cin0:], ksize=k, upsample=up_mode, cout=cin1,
                                                    pool2=rec["ups"], residual=tape.g(x1), wstride=wd.shape[-1]))

@@ -316,8 +316,12 @@ __global__ __launch_bounds__(256, 1) void conv_h2_kernel(ConvH2P p) {
 }
 
 // OIHW fp32 -> [cin/16][piece 2][tap 9][g 2][cout_pad][8] fp16 (hi, scaled lo); zero-padded couts.
-__global__ void weight_relayout_h2_kernel(const float* __restrict__ w, _Float16* __restrict__ dst, int cout, int cin,
-                                          int cout_pad) {
+// mode 1 (data gradient): the conv dX = conv(dY, W^T flipped) has K = cout, N = cin: the same layout with the
+// roles of the two channel axes swapped and the taps reversed.
+__global__ void weight_relayout_h2_kernel(const float* __restrict__ w, _Float16* __restrict__ dst, int cout_w, int cin_w,
+                                          int cout_pad, int mode) {
+  const int cin = mode ? cout_w : cin_w;    // K axis of the conv this layout feeds
+  const int cout = mode ? cin_w : cout_w;   // N axis
   const int64_t total = (int64_t)(cin / 16) * 9 * 2 * cout_pad * 8;  // one thread per (chunk, tap, g, co, j)
   for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
     const int j = (int)(i % 8);
@@ -329,7 +333,8 @@ __global__ void weight_relayout_h2_kernel(const float* __restrict__ w, _Float16*
     const int tap = (int)(r % 9);
     const int q = (int)(r / 9);
     const int ci = q * 16 + g * 8 + j;
-    const float v = co < cout ? w[((int64_t)co * cin + ci) * 9 + tap] : 0.f;
+    float v = 0.f;
+    if (co < cout) v = mode ? w[((int64_t)ci * cin_w + co) * 9 + (8 - tap)] : w[((int64_t)co * cin_w + ci) * 9 + tap];
     const _Float16 h1 = (_Float16)v;
     const _Float16 h2 = (_Float16)((v - (float)h1) * 2048.0f);
     const int64_t base = ((((int64_t)q * 2 + 0) * 9 + tap) * 2 + g) * cout_pad + co;
@@ -397,14 +402,25 @@ void conv_h2_set_rows(int r) { g_h2_rows = r; }
 
 }  // namespace dsg
 
-DSG_API int dsg_conv_weight_relayout_h2(const float* w_oihw, void* dst_half, int32_t cout, int32_t cin, void* stream) {
+static int relayout_h2(const float* w_oihw, void* dst_half, int32_t cout, int32_t cin, int mode, void* stream) {
   DSG_CHECK_ARG(w_oihw && dst_half, "dsg_conv_weight_relayout_h2: NULL pointer");
-  DSG_CHECK_ARG(cout > 0 && cin > 0 && cin % 16 == 0, "dsg_conv_weight_relayout_h2: cin must be a positive multiple of 16");
-  const int cout_pad = (cout + 63) / 64 * 64;
-  const int64_t total = (int64_t)(cin / 16) * 9 * 2 * cout_pad * 8;
+  const int k_axis = mode ? cout : cin, n_axis = mode ? cin : cout;
+  DSG_CHECK_ARG(cout > 0 && cin > 0 && k_axis % 16 == 0,
+                "dsg_conv_weight_relayout_h2: the contraction axis (%d) must be a positive multiple of 16", k_axis);
+  const int cout_pad = (n_axis + 63) / 64 * 64;
+  const int64_t total = (int64_t)(k_axis / 16) * 9 * 2 * cout_pad * 8;
   const int blocks = (int)std::min<int64_t>(dsg::cdiv64(total, 256), 4096);
   hipLaunchKernelGGL(dsg::weight_relayout_h2_kernel, dim3(blocks), dim3(256), 0, static_cast<hipStream_t>(stream),
-                     w_oihw, static_cast<_Float16*>(dst_half), cout, cin, cout_pad);
+                     w_oihw, static_cast<_Float16*>(dst_half), cout, cin, cout_pad, mode);
   DSG_LAUNCH_CHECK();
   return DSG_OK;
+}
+
+DSG_API int dsg_conv_weight_relayout_h2(const float* w_oihw, void* dst_half, int32_t cout, int32_t cin, void* stream) {
+  return relayout_h2(w_oihw, dst_half, cout, cin, 0, stream);
+}
+
+DSG_API int dsg_conv_weight_relayout_h2_dgrad(const float* w_oihw, void* dst_half, int32_t cout, int32_t cin,
+                                              void* stream) {
+  return relayout_h2(w_oihw, dst_half, cout, cin, 1, stream);
 }

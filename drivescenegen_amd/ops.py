@@ -47,6 +47,17 @@ def relayout_conv_weight_h2(w_oihw: torch.Tensor, out: torch.Tensor = None) -> t
     return out
 
 
+def relayout_conv_weight_h2_dgrad(w_oihw: torch.Tensor, out: torch.Tensor = None) -> torch.Tensor:
+    """OIHW 3x3 (cout % 16 == 0) -> fp16x2-split layout of the data-gradient conv: [Cout/16][2][9][2][cin_pad64][8]."""
+    w = w_oihw.contiguous()
+    cout, cin = w.shape[0], w.shape[1]
+    if out is None:
+        out = torch.empty((cout // 16, 2, 9, 2, (cin + 63) // 64 * 64, 8), dtype=torch.float16, device=w.device)
+    with torch.cuda.device(w.device):
+        _lib.check(_lib.load().dsg_conv_weight_relayout_h2_dgrad(_lib.ptr(w), out.data_ptr(), cout, cin, _st(w)))
+    return out
+
+
 def relayout_conv_weight_dgrad(w_oihw: torch.Tensor, out: torch.Tensor = None) -> torch.Tensor:
     """OIHW -> [Cout][k*k flipped][Cin padded to 32]: weight of the data-gradient conv dX = conv(dY, .)."""
     w = w_oihw.contiguous()

@@ -86,6 +86,8 @@ int dsg_conv_weight_relayout(const float* w_oihw, float* dst, int32_t cout, int3
 /* OIHW (3x3) -> [Cin/16][2][9][2][cout padded to 64][8] fp16: hi part and 2^11-scaled lo part of every weight,
  * so that w == hi + lo * 2^-11 to 2^-24 relative (fp32-equivalent contraction on the f16 MFMA, conv_h2.hip). */
 int dsg_conv_weight_relayout_h2(const float* w_oihw, void* dst_half, int32_t cout, int32_t cin, void* stream);
+/* the same for the data-gradient conv (K = cout, N = cin padded to 64, taps reversed): [Cout/16][2][9][2][cin_pad][8] */
+int dsg_conv_weight_relayout_h2_dgrad(const float* w_oihw, void* dst_half, int32_t cout, int32_t cin, void* stream);
 /* OIHW -> [Cout][k*k flipped][cin_total]: the weight of the data-gradient convolution
  * dX = conv(dY, W^T flipped) (backward of training_pipeline.py:84 through :86). */
 int dsg_conv_weight_relayout_dgrad(const float* w_oihw, float* dst, int32_t cout, int32_t cin, int32_t ksize,
