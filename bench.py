@@ -87,7 +87,7 @@ def gpu_leg(args, rank, world):
     if not args.no_prof:
         names = {0: "conv3x3_s1_mfma_f32", 1: "conv3x3_upsample_mfma_f32", 2: "conv3x3_s2_mfma_f32",
                  3: "conv1x1_mfma_f32", 4: "conv_direct_valu", 6: "conv3x3_s1_mfma_f16x2split",
-                 7: "conv3x3_upsample_mfma_f16x2split"}
+                 7: "conv3x3_upsample_mfma_f16x2split", 8: "conv1x1_mfma_f16x2split"}
         for kid, nm in names.items():
             ms, fl, by, n = C.c_double(), C.c_double(), C.c_double(), C.c_int64()
             _lib.check(lib.dsg_prof_summary(kid, C.byref(ms), C.byref(fl), C.byref(by), C.byref(n)))

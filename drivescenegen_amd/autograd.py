@@ -80,12 +80,11 @@ class TrainState:
                 self.wd[name] = torch.zeros((p.shape[0], k * k, ops._pad32(cin) + 64), dtype=torch.float32,
                                             device=p.device)
             ops.relayout_conv_weight_dgrad(p, out=self.wd[name])
-            if p.dim() == 4 and p.shape[2] == 3:
-                cout = p.shape[0]
-                if cin % 16 == 0 and cout % 64 == 0:   # forward conv on the fp16x2-split matrix-core path
-                    self.wh[name] = ops.relayout_conv_weight_h2(p, out=self.wh.get(name))
-                if cout % 16 == 0 and cin % 64 == 0:   # its data gradient (K = cout, N = cin)
-                    self.whd[name] = ops.relayout_conv_weight_h2_dgrad(p, out=self.whd.get(name))
+            cout = p.shape[0]
+            if cin % 16 == 0 and cout % 64 == 0:   # forward conv on the fp16x2-split matrix-core path
+                self.wh[name] = ops.relayout_conv_weight_h2(p, out=self.wh.get(name))
+            if cout % 16 == 0 and cin % 64 == 0:   # its data gradient (K = cout, N = cin)
+                self.whd[name] = ops.relayout_conv_weight_h2_dgrad(p, out=self.whd.get(name))
         return self.wf[name], self.wd[name]
 
     def qkv_w(self, prefix):

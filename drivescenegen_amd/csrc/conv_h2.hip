@@ -53,37 +53,41 @@ struct ConvH2P {
 };
 
 constexpr int H2_TW = 32, H2_KC = 16, H2_BM = 64;
-constexpr int H2_PW = H2_TW + 2;
-constexpr int H2_WHALFS = 2 * 9 * 2 * H2_BM * 8;  // 18432 halfs = 36864 B
 
 // NT = output rows per wave (2 or 4): a workgroup covers 4*NT rows x 32 cols.  NT = 4 halves the LDS operand
 // traffic per MFMA (each weight fragment feeds 4 pixel tiles) and the weight DMA per MFMA; it needs 256
 // accumulator registers (the kernel owns the SIMD: 1 wave, 512 registers).
-template <int NT>
+// KS = 3 (halo of 1) or 1 (no halo; attention projections and resnet shortcuts)
+template <int NT, int KS>
 struct H2Geom {
+  static constexpr int TAPS = KS * KS;
   static constexpr int TH = 4 * NT;
-  static constexpr int PH = TH + 2;
-  static constexpr int PSZ = H2_PW * PH;              // 340 (NT=2) / 612 (NT=4) halo positions
+  static constexpr int PH = TH + KS - 1;
+  static constexpr int PW = H2_TW + KS - 1;
+  static constexpr int PSZ = PW * PH;                 // KS=3: 340 (NT=2) / 612 (NT=4); KS=1: 256 / 512
+  static constexpr int WHALFS = 2 * TAPS * 2 * H2_BM * 8;  // [piece][tap][g][cout][8]: 36864 B / 4096 B
   static constexpr int XHALFS = 2 * 2 * PSZ * 8;      // [piece][g][pos][8]
-  static constexpr int BUF_BYTES = (H2_WHALFS + XHALFS) * 2 + 64;  // + a dump slot for masked lanes
-  static constexpr int FULL = PSZ / 256;              // full 256-position slabs per k-group (1 / 2)
-  static constexpr int NU = 2 * FULL + 1;             // staging units per thread (3 / 5)
-  static constexpr int REM0 = FULL * 256;             // first position of the shared remainder unit
+  static constexpr int BUF_BYTES = (WHALFS + XHALFS) * 2 + 64;  // + a dump slot for masked lanes
+  static constexpr int FULL = PSZ / 256;              // full 256-position slabs per k-group
+  static constexpr bool HAS_REM = (PSZ % 256) != 0;   // KS=3 leaves a remainder slab shared by the two k-groups
+  static constexpr int NU = 2 * FULL + (HAS_REM ? 1 : 0);  // staging units per thread
+  static constexpr int REM0 = FULL * 256;             // first position of the remainder unit
+  static constexpr int NSEG = 4 * TAPS;               // 1-KB weight segments per chunk
 };
 
 __device__ __forceinline__ float silu_fast_h(float x) { return x * __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
 
-// GM: 0 plain, 1 nearest x2 gather; NT: rows per wave.
+// GM: 0 plain, 1 nearest x2 gather; NT: rows per wave; KS: 3 | 1.
 // Staging units are arranged so that the k-group g (hence the channel plane and the GroupNorm scale/shift) of
 // every unit is WAVE-UNIFORM: channel-plane bases and scale/shift live in SGPRs (s_load / saddr-form global
 // loads), and the only per-lane address is the 32-bit halo offset computed once per tile.
 //   units 0..FULL-1: g = 0, halo positions tid + 256*i      units FULL..2*FULL-1: g = 1, same positions
 //   last unit: g = wave >> 1, halo position FULL*256 + (tid & 127)   (the remainder, valid where < PSZ)
-template <int GM, int NT>
+template <int GM, int NT, int KS>
 __global__ __launch_bounds__(256, 1) void conv_h2_kernel(ConvH2P p) {
-  using G = H2Geom<NT>;
+  using G = H2Geom<NT, KS>;
   constexpr int H2_TH = G::TH, H2_PSZ = G::PSZ, H2_XHALFS = G::XHALFS, H2_BUF_BYTES = G::BUF_BYTES, H2_NU = G::NU;
-  constexpr int FULL = G::FULL;
+  constexpr int FULL = G::FULL, TAPS = G::TAPS, H2_PW = G::PW, H2_WHALFS = G::WHALFS, PADK = KS / 2;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
 
   const int tid = threadIdx.x;
@@ -112,7 +116,7 @@ __global__ __launch_bounds__(256, 1) void conv_h2_kernel(ConvH2P p) {
     int off = 0, xo = H2_WHALFS + H2_XHALFS;  // dump slot (in halfs) when the position is past the patch
     if (pos < H2_PSZ) {
       const int py = pos / H2_PW, px = pos - py * H2_PW;
-      const int gy = oy0 - 1 + py, gx = ox0 - 1 + px;
+      const int gy = oy0 - PADK + py, gx = ox0 - PADK + px;
       if (gy >= 0 && gy < p.hc && gx >= 0 && gx < p.wc) {
         off = (GM ? (gy >> 1) : gy) * p.win + (GM ? (gx >> 1) : gx);
         valid |= 1u << i;
@@ -166,8 +170,8 @@ __global__ __launch_bounds__(256, 1) void conv_h2_kernel(ConvH2P p) {
   // weight slab of chunk q: 36 segments (piece, tap, g) of 64 couts x 16 B, moved global -> LDS by DMA;
   // wave w moves segments w, w+4, ...
   auto dma_weights = [&](int k, int q, unsigned char* buf) {
-    const int seg = wave + 4 * k;  // 0..35
-    const _Float16* gp = p.wh + (((size_t)q * 36 + seg) * p.cout_pad + m0) * 8;  // uniform
+    const int seg = wave + 4 * k;  // 0..NSEG-1
+    const _Float16* gp = p.wh + (((size_t)q * G::NSEG + seg) * p.cout_pad + m0) * 8;  // uniform
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gp + lane * 8),
                                      (__attribute__((address_space(3))) void*)(buf + seg * 1024), 16, 0, 0);
   };
@@ -192,7 +196,7 @@ __global__ __launch_bounds__(256, 1) void conv_h2_kernel(ConvH2P p) {
 #pragma unroll
     for (int i = 0; i < H2_NU; ++i) load_unit(i, 0, sp);
 #pragma unroll
-    for (int k = 0; k < 9; ++k) dma_weights(k, 0, buf0);
+    for (int k = 0; k < TAPS; ++k) dma_weights(k, 0, buf0);
 #pragma unroll
     for (int i = 0; i < H2_NU; ++i) commit_unit(i, buf0);
     if (nq > 1) {
@@ -213,16 +217,24 @@ __global__ __launch_bounds__(256, 1) void conv_h2_kernel(ConvH2P p) {
     const _Float16* wl = reinterpret_cast<const _Float16*>(cur);
     const _Float16* xl = wl + H2_WHALFS;
 #pragma unroll
-    for (int tap = 0; tap < 9; ++tap) {
-      // NU = 3: units at taps 1, 4, 7;  NU = 5: units at taps 0, 2, 4, 6, 8
+    for (int tap = 0; tap < TAPS; ++tap) {
+      if (KS == 1) {  // one tap: all units and the four weight segments ride on it
+#pragma unroll
+        for (int u = 0; u < H2_NU; ++u) {
+          if (STAGE) commit_unit(u, nxt);
+          if (LOAD) load_unit(u, q + 2, spn);
+        }
+        if (STAGE) dma_weights(0, q + 1, nxt);
+      }
+      // KS = 3 -- NU = 3: units at taps 1, 4, 7;  NU = 5: units at taps 0, 2, 4, 6, 8
       constexpr int UNIT_STRIDE = (H2_NU == 3) ? 3 : 2, UNIT_PHASE = (H2_NU == 3) ? 1 : 0;
-      if (tap % UNIT_STRIDE == UNIT_PHASE && tap / UNIT_STRIDE < H2_NU) {
+      if (KS == 3 && tap % UNIT_STRIDE == UNIT_PHASE && tap / UNIT_STRIDE < H2_NU) {
         if (STAGE) commit_unit(tap / UNIT_STRIDE, nxt);
         if (LOAD) load_unit(tap / UNIT_STRIDE, q + 2, spn);
       }
       // The weight DMAs go AFTER this tap's commit: with a DMA in flight hipcc waits vmcnt(0) at every use of
       // an ordinary load result, so a DMA issued just before a commit would stall it for the whole transfer.
-      if (STAGE) {
+      if (STAGE && KS == 3) {
         if (H2_NU == 5) {  // commits at even taps: two DMAs at each odd tap, the ninth after the last commit
           if (tap & 1) {
             dma_weights(tap - 1, q + 1, nxt);
@@ -238,13 +250,13 @@ __global__ __launch_bounds__(256, 1) void conv_h2_kernel(ConvH2P p) {
           }
         }
       }
-      const int dy = tap / 3, dx = tap % 3;
+      const int dy = tap / KS, dx = tap % KS;
       half8 a[2][2], b[NT][2];  // [tile][piece]
 #pragma unroll
       for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
         for (int pc = 0; pc < 2; ++pc)
-          a[mt][pc] = *reinterpret_cast<const half8*>(wl + (((pc * 9 + tap) * 2 + half) * H2_BM + mt * 32 + l31) * 8);
+          a[mt][pc] = *reinterpret_cast<const half8*>(wl + (((pc * TAPS + tap) * 2 + half) * H2_BM + mt * 32 + l31) * 8);
 #pragma unroll
       for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
@@ -315,30 +327,30 @@ __global__ __launch_bounds__(256, 1) void conv_h2_kernel(ConvH2P p) {
   }
 }
 
-// OIHW fp32 -> [cin/16][piece 2][tap 9][g 2][cout_pad][8] fp16 (hi, scaled lo); zero-padded couts.
+// OIHW fp32 -> [cin/16][piece 2][tap k*k][g 2][cout_pad][8] fp16 (hi, scaled lo); zero-padded couts.
 // mode 1 (data gradient): the conv dX = conv(dY, W^T flipped) has K = cout, N = cin: the same layout with the
-// roles of the two channel axes swapped and the taps reversed.
+// roles of the two channel axes swapped and the taps reversed.  `cout_off` places this weight's N columns inside a
+// wider matrix (fused q/k/v projection).
 __global__ void weight_relayout_h2_kernel(const float* __restrict__ w, _Float16* __restrict__ dst, int cout_w, int cin_w,
-                                          int cout_pad, int mode) {
-  const int cin = mode ? cout_w : cin_w;    // K axis of the conv this layout feeds
-  const int cout = mode ? cin_w : cout_w;   // N axis
-  const int64_t total = (int64_t)(cin / 16) * 9 * 2 * cout_pad * 8;  // one thread per (chunk, tap, g, co, j)
+                                          int taps, int cout_pad, int cout_off, int mode) {
+  const int cin = mode ? cout_w : cin_w;   // K axis of the conv this layout feeds
+  const int cout = mode ? cin_w : cout_w;  // N axis (this weight's share of it)
+  const int64_t total = (int64_t)(cin / 16) * taps * 2 * cout * 8;  // one thread per (chunk, tap, g, co, j)
   for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
     const int j = (int)(i % 8);
     int64_t r = i / 8;
-    const int co = (int)(r % cout_pad);
-    r /= cout_pad;
+    const int co = (int)(r % cout);
+    r /= cout;
     const int g = (int)(r % 2);
     r /= 2;
-    const int tap = (int)(r % 9);
-    const int q = (int)(r / 9);
+    const int tap = (int)(r % taps);
+    const int q = (int)(r / taps);
     const int ci = q * 16 + g * 8 + j;
-    float v = 0.f;
-    if (co < cout) v = mode ? w[((int64_t)ci * cin_w + co) * 9 + (8 - tap)] : w[((int64_t)co * cin_w + ci) * 9 + tap];
+    const float v = mode ? w[((int64_t)ci * cin_w + co) * taps + (taps - 1 - tap)] : w[((int64_t)co * cin_w + ci) * taps + tap];
     const _Float16 h1 = (_Float16)v;
     const _Float16 h2 = (_Float16)((v - (float)h1) * 2048.0f);
-    const int64_t base = ((((int64_t)q * 2 + 0) * 9 + tap) * 2 + g) * cout_pad + co;
-    const int64_t base1 = ((((int64_t)q * 2 + 1) * 9 + tap) * 2 + g) * cout_pad + co;
+    const int64_t base = ((((int64_t)q * 2 + 0) * taps + tap) * 2 + g) * cout_pad + cout_off + co;
+    const int64_t base1 = ((((int64_t)q * 2 + 1) * taps + tap) * 2 + g) * cout_pad + cout_off + co;
     dst[base * 8 + j] = h1;
     dst[base1 * 8 + j] = h2;
   }
@@ -349,7 +361,10 @@ static int g_h2_rows = 0;  // rows per wave: 0 = by grid size, 2 | 4 forced (tun
 
 bool conv_h2_eligible(const dsg_conv_args* a, int hout, int wout) {
   const int cin = a->c0 + a->c1;
-  return g_h2_enabled && a->weight_h2 != nullptr && a->ksize == 3 && a->stride == 1 && a->upsample <= 1 && !a->pool2 &&
+  if (a->ksize == 1)  // pointwise: the map is re-tiled as (h*w/32) rows of 32 pixels, so only h*w matters
+    return g_h2_enabled && a->weight_h2 != nullptr && a->stride == 1 && !a->upsample && !a->pool2 && !a->temb &&
+           cin % 16 == 0 && (a->c1 == 0 || a->c0 % 16 == 0) && (hout * wout) % (8 * H2_TW) == 0 && a->cout % 8 == 0;
+  return g_h2_enabled && a->weight_h2 != nullptr && a->stride == 1 && a->upsample <= 1 && !a->pool2 &&
          cin % 16 == 0 && (a->c1 == 0 || a->c0 % 16 == 0) && (wout % H2_TW == 0) && (hout % 8 == 0) &&
          a->cout % 8 == 0;
 }
@@ -358,8 +373,12 @@ int conv_h2_launch(const dsg_conv_args* a, int hout, int wout, hipStream_t st) {
   ConvH2P p;
   p.src0 = a->src0; p.src1 = a->src1; p.c0 = a->c0; p.c1 = a->c1; p.cin = a->c0 + a->c1;
   p.n = a->n; p.hin = a->hin; p.win = a->win;
-  p.hc = a->upsample ? 2 * a->hin : a->hin;
-  p.wc = a->upsample ? 2 * a->win : a->win;
+  if (a->ksize == 1) {
+    hout = hout * wout / H2_TW; wout = H2_TW;
+    p.hin = hout; p.win = wout;
+  }
+  p.hc = a->upsample ? 2 * p.hin : p.hin;
+  p.wc = a->upsample ? 2 * p.win : p.win;
   p.hout = hout; p.wout = wout; p.cout = a->cout; p.cout_pad = (a->cout + 63) / 64 * 64;
   p.wh = static_cast<const _Float16*>(a->weight_h2);
   p.bias = a->bias; p.ss = a->gn_scale_shift; p.silu = a->silu; p.temb = a->temb; p.temb_stride = a->temb_stride;
@@ -369,28 +388,35 @@ int conv_h2_launch(const dsg_conv_args* a, int hout, int wout, hipStream_t st) {
   const bool nt4 = g_h2_rows != 2 && blocks16 >= (g_h2_rows == 4 ? 1 : 256);
   const int th = nt4 ? 16 : 8;
   p.tiles_x = wout / H2_TW; p.tiles_y = hout / th;
-  const size_t lds = 2 * (size_t)(nt4 ? H2Geom<4>::BUF_BYTES : H2Geom<2>::BUF_BYTES);
+  const bool k1 = a->ksize == 1;
+  const size_t lds = 2 * (size_t)(k1 ? (nt4 ? H2Geom<4, 1>::BUF_BYTES : H2Geom<2, 1>::BUF_BYTES)
+                                     : (nt4 ? H2Geom<4, 3>::BUF_BYTES : H2Geom<2, 3>::BUF_BYTES));
   dim3 grid(p.tiles_x * p.tiles_y * p.n, p.cout_pad / H2_BM);
   int pi = -1;
   if (prof_on()) {
     const double px = (double)p.n * hout * wout;
-    pi = prof_begin(a->upsample ? 7 : 6, 2.0 * px * p.cout * p.cin * 9,
-                    4.0 * ((double)p.n * p.cin * p.hin * p.win + (double)p.cin * 9 * p.cout +
+    const int taps = a->ksize * a->ksize;
+    pi = prof_begin(a->ksize == 1 ? 8 : (a->upsample ? 7 : 6), 2.0 * px * p.cout * p.cin * taps,
+                    4.0 * ((double)p.n * p.cin * p.hin * p.win + (double)p.cin * taps * p.cout +
                            px * p.cout * (p.res ? 2.0 : 1.0)), st);
   }
   static bool raised = false;
   if (!raised) {
-    const void* ks[4] = {reinterpret_cast<const void*>(conv_h2_kernel<0, 2>), reinterpret_cast<const void*>(conv_h2_kernel<1, 2>),
-                         reinterpret_cast<const void*>(conv_h2_kernel<0, 4>), reinterpret_cast<const void*>(conv_h2_kernel<1, 4>)};
+    const void* ks[6] = {reinterpret_cast<const void*>(conv_h2_kernel<0, 2, 3>), reinterpret_cast<const void*>(conv_h2_kernel<1, 2, 3>),
+                         reinterpret_cast<const void*>(conv_h2_kernel<0, 4, 3>), reinterpret_cast<const void*>(conv_h2_kernel<1, 4, 3>),
+                         reinterpret_cast<const void*>(conv_h2_kernel<0, 2, 1>), reinterpret_cast<const void*>(conv_h2_kernel<0, 4, 1>)};
     for (const void* k : ks) DSG_HIP(hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     raised = true;
   }
-  if (a->upsample) {
-    if (nt4) hipLaunchKernelGGL((conv_h2_kernel<1, 4>), grid, dim3(256), lds, st, p);
-    else hipLaunchKernelGGL((conv_h2_kernel<1, 2>), grid, dim3(256), lds, st, p);
+  if (k1) {
+    if (nt4) hipLaunchKernelGGL((conv_h2_kernel<0, 4, 1>), grid, dim3(256), lds, st, p);
+    else hipLaunchKernelGGL((conv_h2_kernel<0, 2, 1>), grid, dim3(256), lds, st, p);
+  } else if (a->upsample) {
+    if (nt4) hipLaunchKernelGGL((conv_h2_kernel<1, 4, 3>), grid, dim3(256), lds, st, p);
+    else hipLaunchKernelGGL((conv_h2_kernel<1, 2, 3>), grid, dim3(256), lds, st, p);
   } else {
-    if (nt4) hipLaunchKernelGGL((conv_h2_kernel<0, 4>), grid, dim3(256), lds, st, p);
-    else hipLaunchKernelGGL((conv_h2_kernel<0, 2>), grid, dim3(256), lds, st, p);
+    if (nt4) hipLaunchKernelGGL((conv_h2_kernel<0, 4, 3>), grid, dim3(256), lds, st, p);
+    else hipLaunchKernelGGL((conv_h2_kernel<0, 2, 3>), grid, dim3(256), lds, st, p);
   }
   prof_end(pi, st);
   DSG_LAUNCH_CHECK();
@@ -402,25 +428,31 @@ void conv_h2_set_rows(int r) { g_h2_rows = r; }
 
 }  // namespace dsg
 
-static int relayout_h2(const float* w_oihw, void* dst_half, int32_t cout, int32_t cin, int mode, void* stream) {
+static int relayout_h2(const float* w_oihw, void* dst_half, int32_t cout, int32_t cin, int32_t ksize, int32_t n_total,
+                       int32_t n_off, int mode, void* stream) {
   DSG_CHECK_ARG(w_oihw && dst_half, "dsg_conv_weight_relayout_h2: NULL pointer");
+  DSG_CHECK_ARG(ksize == 1 || ksize == 3, "dsg_conv_weight_relayout_h2: ksize must be 1 or 3");
   const int k_axis = mode ? cout : cin, n_axis = mode ? cin : cout;
   DSG_CHECK_ARG(cout > 0 && cin > 0 && k_axis % 16 == 0,
                 "dsg_conv_weight_relayout_h2: the contraction axis (%d) must be a positive multiple of 16", k_axis);
-  const int cout_pad = (n_axis + 63) / 64 * 64;
-  const int64_t total = (int64_t)(k_axis / 16) * 9 * 2 * cout_pad * 8;
+  if (n_total == 0) n_total = n_axis;
+  DSG_CHECK_ARG(n_off >= 0 && n_off + n_axis <= n_total, "dsg_conv_weight_relayout_h2: column window out of range");
+  const int cout_pad = (n_total + 63) / 64 * 64;
+  const int taps = ksize * ksize;
+  const int64_t total = (int64_t)(k_axis / 16) * taps * 2 * n_axis * 8;
   const int blocks = (int)std::min<int64_t>(dsg::cdiv64(total, 256), 4096);
   hipLaunchKernelGGL(dsg::weight_relayout_h2_kernel, dim3(blocks), dim3(256), 0, static_cast<hipStream_t>(stream),
-                     w_oihw, static_cast<_Float16*>(dst_half), cout, cin, cout_pad, mode);
+                     w_oihw, static_cast<_Float16*>(dst_half), cout, cin, taps, cout_pad, n_off, mode);
   DSG_LAUNCH_CHECK();
   return DSG_OK;
 }
 
-DSG_API int dsg_conv_weight_relayout_h2(const float* w_oihw, void* dst_half, int32_t cout, int32_t cin, void* stream) {
-  return relayout_h2(w_oihw, dst_half, cout, cin, 0, stream);
+DSG_API int dsg_conv_weight_relayout_h2(const float* w_oihw, void* dst_half, int32_t cout, int32_t cin, int32_t ksize,
+                                        int32_t cout_total, int32_t cout_off, void* stream) {
+  return relayout_h2(w_oihw, dst_half, cout, cin, ksize, cout_total, cout_off, 0, stream);
 }
 
 DSG_API int dsg_conv_weight_relayout_h2_dgrad(const float* w_oihw, void* dst_half, int32_t cout, int32_t cin,
-                                              void* stream) {
-  return relayout_h2(w_oihw, dst_half, cout, cin, 1, stream);
+                                              int32_t ksize, void* stream) {
+  return relayout_h2(w_oihw, dst_half, cout, cin, ksize, 0, 0, 1, stream);
 }

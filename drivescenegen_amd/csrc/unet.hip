@@ -131,8 +131,8 @@ struct dsg_unet {
     if (c.w && c.wstride != cout) (void)hipMemset(c.w, 0, (size_t)cin * k * k * c.wstride * sizeof(float));
     c.b = dalloc(cout);
     add_param(pre + ".weight", P_CONV, c.w, (int64_t)cin * k * k * cout, cout, cin, k, c.wstride, 0);
-    if (k == 3 && cin % 16 == 0) {  // second copy, pre-split for the fp16x2 matrix-core kernel (same bytes as fp32)
-      const int64_t halfs = (int64_t)(cin / 16) * 2 * 9 * 2 * ((cout + 63) / 64 * 64) * 8;
+    if (cin % 16 == 0 && cout % 64 == 0) {  // second copy, pre-split for the fp16x2 matrix-core kernel (same bytes)
+      const int64_t halfs = (int64_t)(cin / 16) * 2 * k * k * 2 * cout * 8;
       c.wh = dalloc((halfs + 1) / 2);
       params.back().wh = c.wh;
     }
@@ -163,9 +163,11 @@ struct dsg_unet {
     a.qkv.cin = c; a.qkv.cout = 3 * c; a.qkv.k = 1; a.qkv.wstride = 3 * c;
     a.qkv.w = dalloc((int64_t)c * 3 * c);
     a.qkv.b = dalloc(3 * c);
+    if (c % 64 == 0) a.qkv.wh = dalloc((int64_t)(c / 16) * 2 * 2 * 3 * c * 8 / 2);
     const char* names[3] = {"to_q", "to_k", "to_v"};
     for (int i = 0; i < 3; ++i) {
       add_param(pre + "." + names[i] + ".weight", P_CONV, a.qkv.w, (int64_t)c * c, c, c, 1, 3 * c, i * c);
+      params.back().wh = a.qkv.wh;
       add_param(pre + "." + names[i] + ".bias", P_COPY, a.qkv.b + i * c, c);
     }
     reg_conv(pre + ".to_out.0", a.out, c, c, 1);
@@ -478,7 +480,7 @@ DSG_API int dsg_unet_set_param(dsg_unet_t* h, const char* name, const float* dat
     int rc = dsg_conv_weight_relayout(data, p.dst, p.cout, p.cin, p.k, p.cout_total, p.cout_off, stream);
     if (rc != DSG_OK) return rc;
     if (p.wh) {
-      rc = dsg_conv_weight_relayout_h2(data, p.wh, p.cout, p.cin, stream);
+      rc = dsg_conv_weight_relayout_h2(data, p.wh, p.cout, p.cin, p.k, p.cout_total, p.cout_off, stream);
       if (rc != DSG_OK) return rc;
     }
   }

@@ -36,25 +36,31 @@ def relayout_conv_weight(w_oihw: torch.Tensor, out: torch.Tensor = None, cout_to
     return out
 
 
-def relayout_conv_weight_h2(w_oihw: torch.Tensor, out: torch.Tensor = None) -> torch.Tensor:
-    """OIHW 3x3 (cin % 16 == 0) -> fp16x2-split engine layout [Cin/16][2][9][2][cout_pad64][8] (float16)."""
+def relayout_conv_weight_h2(w_oihw: torch.Tensor, out: torch.Tensor = None, cout_total: int = None,
+                            cout_off: int = 0) -> torch.Tensor:
+    """OIHW 3x3 / 1x1 / Linear (cin % 16 == 0) -> fp16x2-split engine layout [Cin/16][2][k*k][2][cout_pad64][8]."""
     w = w_oihw.contiguous()
     cout, cin = w.shape[0], w.shape[1]
+    k = w.shape[2] if w.dim() == 4 else 1
+    cout_total = cout_total or cout
     if out is None:
-        out = torch.empty((cin // 16, 2, 9, 2, (cout + 63) // 64 * 64, 8), dtype=torch.float16, device=w.device)
+        out = torch.zeros((cin // 16, 2, k * k, 2, (cout_total + 63) // 64 * 64, 8), dtype=torch.float16,
+                          device=w.device)
     with torch.cuda.device(w.device):
-        _lib.check(_lib.load().dsg_conv_weight_relayout_h2(_lib.ptr(w), out.data_ptr(), cout, cin, _st(w)))
+        _lib.check(_lib.load().dsg_conv_weight_relayout_h2(_lib.ptr(w), out.data_ptr(), cout, cin, k, cout_total,
+                                                           cout_off, _st(w)))
     return out
 
 
 def relayout_conv_weight_h2_dgrad(w_oihw: torch.Tensor, out: torch.Tensor = None) -> torch.Tensor:
-    """OIHW 3x3 (cout % 16 == 0) -> fp16x2-split layout of the data-gradient conv: [Cout/16][2][9][2][cin_pad64][8]."""
+    """OIHW (cout % 16 == 0) -> fp16x2-split layout of the data-gradient conv: [Cout/16][2][k*k][2][cin_pad64][8]."""
     w = w_oihw.contiguous()
     cout, cin = w.shape[0], w.shape[1]
+    k = w.shape[2] if w.dim() == 4 else 1
     if out is None:
-        out = torch.empty((cout // 16, 2, 9, 2, (cin + 63) // 64 * 64, 8), dtype=torch.float16, device=w.device)
+        out = torch.zeros((cout // 16, 2, k * k, 2, (cin + 63) // 64 * 64, 8), dtype=torch.float16, device=w.device)
     with torch.cuda.device(w.device):
-        _lib.check(_lib.load().dsg_conv_weight_relayout_h2_dgrad(_lib.ptr(w), out.data_ptr(), cout, cin, _st(w)))
+        _lib.check(_lib.load().dsg_conv_weight_relayout_h2_dgrad(_lib.ptr(w), out.data_ptr(), cout, cin, k, _st(w)))
     return out
 
 

@@ -73,7 +73,7 @@ typedef struct {
   float* dst;                   /* [N, cout, hout, wout] ([N, cout, hout/2, wout/2] with pool2) */
   int32_t pool2;                /* 1: 2x2 sum-pool of the result (adjoint of the nearest x2 upsample) */
   const void* weight_h2;        /* optional: the same weights pre-split for the fp16x2 matrix-core path
-                                   (dsg_conv_weight_relayout_h2); used for 3x3 stride-1 convs with cin % 16 == 0 */
+                                   (dsg_conv_weight_relayout_h2); used for stride-1 3x3 / 1x1 convs with cin % 16 == 0, cout % 64 == 0 */
 } dsg_conv_args;
 
 int dsg_conv2d_fwd(const dsg_conv_args* a, void* stream);
@@ -83,11 +83,13 @@ int dsg_conv2d_fwd(const dsg_conv_args* a, void* stream);
  * [out][in] are the k=1 case. */
 int dsg_conv_weight_relayout(const float* w_oihw, float* dst, int32_t cout, int32_t cin, int32_t ksize,
                              int32_t cout_total, int32_t cout_off, void* stream);
-/* OIHW (3x3) -> [Cin/16][2][9][2][cout padded to 64][8] fp16: hi part and 2^11-scaled lo part of every weight,
+/* OIHW (3x3 or 1x1 / Linear) -> [Cin/16][2][k*k][2][cout_total padded to 64][8] fp16: hi part and 2^11-scaled lo part of every weight,
  * so that w == hi + lo * 2^-11 to 2^-24 relative (fp32-equivalent contraction on the f16 MFMA, conv_h2.hip). */
-int dsg_conv_weight_relayout_h2(const float* w_oihw, void* dst_half, int32_t cout, int32_t cin, void* stream);
-/* the same for the data-gradient conv (K = cout, N = cin padded to 64, taps reversed): [Cout/16][2][9][2][cin_pad][8] */
-int dsg_conv_weight_relayout_h2_dgrad(const float* w_oihw, void* dst_half, int32_t cout, int32_t cin, void* stream);
+int dsg_conv_weight_relayout_h2(const float* w_oihw, void* dst_half, int32_t cout, int32_t cin, int32_t ksize,
+                                int32_t cout_total /* 0 = cout */, int32_t cout_off, void* stream);
+/* the same for the data-gradient conv (K = cout, N = cin padded to 64, taps reversed): [Cout/16][2][k*k][2][cin_pad][8] */
+int dsg_conv_weight_relayout_h2_dgrad(const float* w_oihw, void* dst_half, int32_t cout, int32_t cin, int32_t ksize,
+                                      void* stream);
 /* OIHW -> [Cout][k*k flipped][cin_total]: the weight of the data-gradient convolution
  * dX = conv(dY, W^T flipped) (backward of training_pipeline.py:84 through :86). */
 int dsg_conv_weight_relayout_dgrad(const float* w_oihw, float* dst, int32_t cout, int32_t cin, int32_t ksize,
@@ -278,8 +280,8 @@ int dsg_mask_lut_u8(const uint8_t* img, int32_t n, int32_t hw, int32_t c, int32_
 /* ------------------------------------------------------------------------------------------
  * Measurement plumbing (no reference counterpart): per-kernel-class HIP-event timing on the launch
  * stream, used by bench.py's roofline leg.  Classes: 0 conv3x3 stride-1, 1 conv3x3 on the nearest-x2
- * upsampled input, 2 conv3x3 stride-2, 3 conv1x1, 4 direct (VALU) conv, 5 conv weight-gradient, 6 / 7 conv3x3
- * stride-1 / upsampled on the fp16x2-split matrix-core path.  FLOPs/bytes are the
+ * upsampled input, 2 conv3x3 stride-2, 3 conv1x1, 4 direct (VALU) conv, 5 conv weight-gradient, 6 / 7 / 8 conv3x3
+ * stride-1 / conv3x3 upsampled / conv1x1 on the fp16x2-split matrix-core path.  FLOPs/bytes are the
  * algorithmic figures of each launch (2*MACs; input + weights + output once).
  * ---------------------------------------------------------------------------------------- */
 int dsg_prof_enable(int32_t on);

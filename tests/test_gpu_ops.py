@@ -219,14 +219,18 @@ H2_CASES = [
     ("h2_concat_straddle", 128, 64, 128, 16, 32, False, True, True, False),
     ("h2_upsample", 64, 0, 64, 16, 16, True, False, False, False),
     ("h2_cout96_pad", 32, 0, 96, 8, 32, False, True, False, True),
+    # pointwise (shortcut / attention projections): k = 1 flagged by a trailing element
+    ("h2_1x1_shortcut_concat", 128, 64, 128, 16, 32, False, False, False, False, 1),
+    ("h2_1x1_gn_res_16x16", 64, 0, 192, 16, 16, False, True, False, True, 1),
+    ("h2_1x1_rows16", 32, 0, 64, 32, 32, False, False, False, True, 1),
 ]
 
 
 @pytest.mark.parametrize("case", H2_CASES, ids=[c[0] for c in H2_CASES])
 def test_conv_h2_split_matches_fp32(case):
     """fp16x2-split matrix-core path (conv_h2.hip): same contract as the fp32 kernel, fp32-class accuracy."""
-    name, c0, c1, cout, h, w, ups, gn, temb, res = case
-    batch, cin, k = 2, c0 + c1, 3
+    name, c0, c1, cout, h, w, ups, gn, temb, res = case[:10]
+    batch, cin, k = 2, c0 + c1, (case[10] if len(case) > 10 else 3)
     x0 = _t(1, (batch, c0, h, w), 1.7)
     x1 = _t(2, (batch, c1, h, w)) if c1 else None
     wt = _t(3, (cout, cin, k, k), 1.0 / np.sqrt(cin * k * k))
@@ -235,8 +239,8 @@ def test_conv_h2_split_matches_fp32(case):
     xin = torch.cat([x0, x1], 1) if c1 else x0
     ref = F.silu(F.group_norm(xin, 8, gamma, beta, 1e-5)) if gn else xin
     ref = F.interpolate(ref, scale_factor=2.0, mode="nearest") if ups else ref
-    ref64 = F.conv2d(ref.double(), wt.double(), bias.double(), padding=1)
-    mag = F.conv2d(ref.double().abs(), wt.double().abs(), None, padding=1) + 1e-30
+    ref64 = F.conv2d(ref.double(), wt.double(), bias.double(), padding=k // 2)
+    mag = F.conv2d(ref.double().abs(), wt.double().abs(), None, padding=k // 2) + 1e-30
     tproj = _t(7, (batch, cout + 5), 0.5)
     r = _t(8, tuple(ref64.shape))
     extra = torch.zeros_like(ref64)
@@ -248,7 +252,7 @@ def test_conv_h2_split_matches_fp32(case):
     wr, wh = ops.relayout_conv_weight(d(wt)), ops.relayout_conv_weight_h2(d(wt))
     ss = ops.gn_scale_shift(d(x0), d(gamma), d(beta), 8, 1e-5, src1=d(x1)) if gn else None
     tp = d(tproj)
-    kw = dict(src1=d(x1), ksize=3, upsample=ups, gn_scale_shift=ss, silu=gn, temb=tp[:, 3:] if temb else None,
+    kw = dict(src1=d(x1), ksize=k, upsample=ups, gn_scale_shift=ss, silu=gn, temb=tp[:, 3:] if temb else None,
               temb_stride=tp.stride(0), residual=d(r) if res else None, cout=cout)
     got32 = ops.conv2d_fused(d(x0), wr, d(bias), **kw).cpu()
     goth2 = ops.conv2d_fused(d(x0), wr, d(bias), weight_h2=wh, **kw).cpu()
