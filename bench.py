@@ -56,6 +56,8 @@ def gpu_leg(args, rank, world):
     lib = _lib.load()
     if args.pure_f32:
         _lib.check(lib.dsg_set_tuning(2, 0))
+    if args.separate_gn_stats:
+        _lib.check(lib.dsg_set_tuning(5, 0))
 
     def step(i, x):
         t = ts[i % len(ts)]
@@ -143,6 +145,8 @@ def main():
     ap.add_argument("--prof-dump", default=None, help="write the per-launch HIP-event records (CSV) here")
     ap.add_argument("--pure-f32", action="store_true",
                     help="disable the fp16x2-split conv path: every contraction on the f32 MFMA (A/B reference)")
+    ap.add_argument("--separate-gn-stats", action="store_true",
+                    help="GroupNorm statistics by a pass of their own instead of the producing conv's epilogue (A/B)")
     ap.add_argument("--cpu-threads", type=int, default=16,
                     help="threads for the CPU oracle (16 is the fastest setting on the 2x64-core GPU box: "
                          "32/64/128/256 threads run 1.1x/2x/4.4x/36x slower)")

@@ -38,6 +38,7 @@ class ConvArgs(C.Structure):
         ("temb", C.c_void_p), ("temb_stride", C.c_int32),
         ("residual", C.c_void_p), ("dst", C.c_void_p), ("pool2", C.c_int32),
         ("weight_h2", C.c_void_p),
+        ("stats_out", C.c_void_p),
     ]
 
 
@@ -72,6 +73,8 @@ _vp, _i32, _i64, _f32, _sz, _f64 = C.c_void_p, C.c_int32, C.c_int64, C.c_float, 
 # name -> argtypes; every function returns int32 status unless noted.  This table is the single
 # Python-side statement of the ABI; tests/test_abi.py checks it against include/dsg.h.
 SIGNATURES = {
+    "dsg_conv2d_stats_tiles": [_vp, _vp],
+    "dsg_gn_finalize_parts": [_vp, _i32, _i32, _vp, _i32, _i32, _vp, _vp, _i32, _i32, _i32, _f32, _vp, _vp],
     "dsg_conv2d_fwd": [C.POINTER(ConvArgs), _vp],
     "dsg_conv2d_fwd_direct": [C.POINTER(ConvArgs), _vp],
     "dsg_conv_weight_relayout": [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp],

@@ -395,8 +395,11 @@ __global__ void weight_relayout_kernel(const float* __restrict__ w, float* __res
 
 bool conv_h2_eligible(const dsg_conv_args* a, int hout, int wout);
 int conv_h2_launch(const dsg_conv_args* a, int hout, int wout, hipStream_t st);
+int conv_h2_stats_tiles(const dsg_conv_args* a, int hout, int wout);
 void conv_h2_set_enabled(int on);
 void conv_h2_set_rows(int r);
+void conv_h2_set_exp(int e);
+void conv_h2_set_stats(int on);
 
 static int g_conv_kc = 0;  // K-chunk of the 3x3 stride-1 kernel: 4 | 8 | 0 = by grid size (measured, r01)
 
@@ -480,6 +483,9 @@ int conv2d_fwd_impl(const dsg_conv_args* a, hipStream_t st, int force_direct) {
   DSG_CHECK_ARG(!(p.pool && ((p.hout | p.wout) & 1)), "dsg_conv2d_fwd: pool2 needs even output dims");
 
   if (!force_direct && conv_h2_eligible(a, p.hout, p.wout)) return conv_h2_launch(a, p.hout, p.wout, st);
+  DSG_CHECK_ARG(a->stats_out == nullptr,
+                "dsg_conv2d_fwd: stats_out given but this call is not served by the kernel that produces them "
+                "(dsg_conv2d_stats_tiles reports 0)");
 
   const bool tile_ok = (p.wout % TW == 0) && (p.hout % TH == 0) && (p.wstride % 32 == 0) && p.cin <= 2048 &&
                        (p.wstride >= ((p.cout + 31) / 32) * 32);
@@ -531,7 +537,26 @@ DSG_API int dsg_set_tuning(int32_t key, int32_t value) {
     dsg::conv_h2_set_rows(value);
     return DSG_OK;
   }
+  if (key == 4) {
+    dsg::conv_h2_set_exp(value);
+    return DSG_OK;
+  }
+  if (key == 5 && (value == 0 || value == 1)) {
+    dsg::conv_h2_set_stats(value);
+    return DSG_OK;
+  }
   return dsg::fail(DSG_ERR_INVALID_ARG, "dsg_set_tuning: unknown key/value %d/%d", key, value);
+}
+
+DSG_API int dsg_conv2d_stats_tiles(const dsg_conv_args* a, int32_t* tiles) {
+  DSG_CHECK_ARG(a != nullptr && tiles != nullptr, "dsg_conv2d_stats_tiles: NULL pointer");
+  DSG_CHECK_ARG(a->ksize == 3 || a->ksize == 1, "dsg_conv2d_stats_tiles: ksize must be 1 or 3");
+  DSG_CHECK_ARG(a->stride == 1 || a->stride == 2, "dsg_conv2d_stats_tiles: stride must be 1 or 2");
+  const int hc = a->upsample ? 2 * a->hin : a->hin, wc = a->upsample ? 2 * a->win : a->win;
+  const int pad = a->ksize / 2;
+  const int hout = (hc + 2 * pad - a->ksize) / a->stride + 1, wout = (wc + 2 * pad - a->ksize) / a->stride + 1;
+  *tiles = dsg::conv_h2_stats_tiles(a, hout, wout);
+  return DSG_OK;
 }
 
 DSG_API int dsg_conv2d_fwd(const dsg_conv_args* a, void* stream) {

@@ -49,6 +49,7 @@ struct ConvH2P {
   int temb_stride;
   const float* res;
   float* dst;
+  double* stats;  // optional [n][cout][hout/8 * wout/32][2]: per-tile (sum, sum of squares) of the values written
   int tiles_x, tiles_y;
 };
 
@@ -75,6 +76,22 @@ struct H2Geom {
   static constexpr int NSEG = 4 * TAPS;               // 1-KB weight segments per chunk
 };
 
+// x + (x of the lane selected by a DPP control): the building block of a fixed-order 32-lane tree sum
+template <int CTRL, int ROW_MASK = 0xF>
+__device__ __forceinline__ float dpp_add(float x) {
+  const int y = __builtin_amdgcn_update_dpp(0, __float_as_int(x), CTRL, ROW_MASK, 0xF, true);
+  return x + __int_as_float(y);
+}
+// after this, lanes 16..31 hold the sum over lanes 0..31 and lanes 48..63 the sum over lanes 32..63
+__device__ __forceinline__ float half_wave_sum(float x) {
+  x = dpp_add<0xB1>(x);        // quad_perm [1,0,3,2]
+  x = dpp_add<0x4E>(x);        // quad_perm [2,3,0,1]
+  x = dpp_add<0x141>(x);       // row_half_mirror
+  x = dpp_add<0x140>(x);       // row_mirror: every lane of a 16-row holds the row sum
+  x = dpp_add<0x142, 0xA>(x);  // row_bcast15 into rows 1 and 3
+  return x;
+}
+
 __device__ __forceinline__ float silu_fast_h(float x) { return x * __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
 
 // GM: 0 plain, 1 nearest x2 gather; NT: rows per wave; KS: 3 | 1.
@@ -83,7 +100,7 @@ __device__ __forceinline__ float silu_fast_h(float x) { return x * __builtin_amd
 // loads), and the only per-lane address is the 32-bit halo offset computed once per tile.
 //   units 0..FULL-1: g = 0, halo positions tid + 256*i      units FULL..2*FULL-1: g = 1, same positions
 //   last unit: g = wave >> 1, halo position FULL*256 + (tid & 127)   (the remainder, valid where < PSZ)
-template <int GM, int NT, int KS>
+template <int GM, int NT, int KS, int EXP = 0>
 __global__ __launch_bounds__(256, 1) void conv_h2_kernel(ConvH2P p) {
   using G = H2Geom<NT, KS>;
   constexpr int H2_TH = G::TH, H2_PSZ = G::PSZ, H2_XHALFS = G::XHALFS, H2_BUF_BYTES = G::BUF_BYTES, H2_NU = G::NU;
@@ -152,6 +169,14 @@ __global__ __launch_bounds__(256, 1) void conv_h2_kernel(ConvH2P p) {
   auto commit_unit = [&](int i, unsigned char* buf) {
     half8 h1, h2;
     const bool ok = (valid >> i) & 1u;
+    if (EXP == 1) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) h1[j] = (_Float16)xr[i][j];
+      _Float16* xb = reinterpret_cast<_Float16*>(buf);
+      *reinterpret_cast<half8*>(xb + xoff[i]) = h1;
+      *reinterpret_cast<half8*>(xb + xoff[i] + (xoff[i] < H2_WHALFS + H2_XHALFS ? 2 * H2_PSZ * 8 : 0)) = h1;
+      return;
+    }
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
       float v = xr[i][j];
@@ -228,7 +253,7 @@ __global__ __launch_bounds__(256, 1) void conv_h2_kernel(ConvH2P p) {
       }
       // KS = 3 -- NU = 3: units at taps 1, 4, 7;  NU = 5: units at taps 0, 2, 4, 6, 8
       constexpr int UNIT_STRIDE = (H2_NU == 3) ? 3 : 2, UNIT_PHASE = (H2_NU == 3) ? 1 : 0;
-      if (KS == 3 && tap % UNIT_STRIDE == UNIT_PHASE && tap / UNIT_STRIDE < H2_NU) {
+      if (EXP < 2 && KS == 3 && tap % UNIT_STRIDE == UNIT_PHASE && tap / UNIT_STRIDE < H2_NU) {
         if (STAGE) commit_unit(tap / UNIT_STRIDE, nxt);
         if (LOAD) load_unit(tap / UNIT_STRIDE, q + 2, spn);
       }
@@ -262,7 +287,7 @@ __global__ __launch_bounds__(256, 1) void conv_h2_kernel(ConvH2P p) {
 #pragma unroll
         for (int pc = 0; pc < 2; ++pc)
           b[nt][pc] = *reinterpret_cast<const half8*>(
-              xl + ((pc * 2 + half) * H2_PSZ + (wave * NT + nt + dy) * H2_PW + l31 + dx) * 8);
+              xl + ((pc * 2 + half) * H2_PSZ + (wave * NT + nt + (EXP == 3 ? 0 : dy)) * H2_PW + l31 + (EXP == 3 ? 0 : dx)) * 8);
 #pragma unroll
       for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
@@ -289,6 +314,8 @@ __global__ __launch_bounds__(256, 1) void conv_h2_kernel(ConvH2P p) {
   const bool has_r = p.res != nullptr;
   const int oplane = p.hout * p.wout;
   const int lane_off = 4 * half * oplane + l31;
+  const bool want_stats = p.stats != nullptr;
+  float* red = reinterpret_cast<float*>(smem_raw);  // [wave][sum | sumsq][cout 64] (the K loop is done with LDS)
 #pragma unroll
   for (int mt = 0; mt < 2; ++mt) {
     float rv[16][NT];  // residual values of this 32-cout slab, all in flight before the first use
@@ -315,12 +342,50 @@ __global__ __launch_bounds__(256, 1) void conv_h2_kernel(ConvH2P p) {
           add1 += p.temb[(size_t)n * p.temb_stride + cou + 4];
         }
         const float add = half ? add1 : add0;
+        float s1[NT / 2], s2[NT / 2];
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) {
           float* row = p.dst + (((size_t)n * p.cout + cou) * p.hout + oy0 + wave * NT + nt) * p.wout + ox0;
           float v = (acc_hi[mt][nt][r] + acc_lo[mt][nt][r] * (1.0f / 2048.0f)) + add;
           if (has_r) v = v + rv[r][nt];
           row[lane_off] = v;
+          if (nt & 1) {
+            s1[nt / 2] += v;
+            s2[nt / 2] += v * v;
+          } else {
+            s1[nt / 2] = v;
+            s2[nt / 2] = v * v;
+          }
+        }
+        if (want_stats) {  // GroupNorm statistics of the tensor just produced (the next layer's norm reads them)
+          const int cl = mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+#pragma unroll
+          for (int pr = 0; pr < NT / 2; ++pr) {  // one partial per pair of rows: the same summation tree for any NT
+            const float t1 = half_wave_sum(s1[pr]), t2 = half_wave_sum(s2[pr]);
+            if (l31 == 16) {
+              red[((wave * (NT / 2) + pr) * 2 + 0) * H2_BM + cl] = t1;
+              red[((wave * (NT / 2) + pr) * 2 + 1) * H2_BM + cl] = t2;
+            }
+          }
+        }
+      }
+    }
+  }
+  if (want_stats) {
+    // statistics tiles are 8 rows x 32 columns (4 row pairs, summed in row order in fp64) whatever NT is, so the
+    // values -- and everything downstream of the norm -- do not depend on the launch geometry
+    __syncthreads();
+    if (tid < 2 * H2_BM) {
+      const int cl = tid & (H2_BM - 1), which = tid >> 6;
+      if (m0 + cl < p.cout) {
+        const int ntile = p.tiles_x * p.tiles_y * (NT / 2);
+#pragma unroll
+        for (int e = 0; e < NT / 2; ++e) {
+          double t = 0.0;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) t += (double)red[((4 * e + j) * 2 + which) * H2_BM + cl];
+          const int tile8 = (ty * (NT / 2) + e) * p.tiles_x + tx;
+          p.stats[(((size_t)n * p.cout + m0 + cl) * ntile + tile8) * 2 + which] = t;
         }
       }
     }
@@ -357,6 +422,8 @@ __global__ void weight_relayout_h2_kernel(const float* __restrict__ w, _Float16*
 }
 
 static int g_h2_enabled = 1;
+static int g_h2_stats = 1;  // epilogue GroupNorm statistics (tuning key 5: A/B against the separate pass)
+static int g_h2_exp = 0;  // experiment variants (tools/ only)
 static int g_h2_rows = 0;  // rows per wave: 0 = by grid size, 2 | 4 forced (tuning key 3)
 
 bool conv_h2_eligible(const dsg_conv_args* a, int hout, int wout) {
@@ -369,8 +436,26 @@ bool conv_h2_eligible(const dsg_conv_args* a, int hout, int wout) {
          a->cout % 8 == 0;
 }
 
+// tile geometry shared by the launcher and dsg_conv2d_stats_tiles
+static bool conv_h2_rows16(const dsg_conv_args* a, int hout, int wout) {
+  if (a->ksize == 1) {
+    hout = hout * wout / H2_TW;
+    wout = H2_TW;
+  }
+  const int cout_pad = (a->cout + 63) / 64 * 64;
+  const int blocks16 = (hout % 16 == 0) ? (wout / H2_TW) * (hout / 16) * a->n * (cout_pad / H2_BM) : 0;
+  return g_h2_rows != 2 && blocks16 >= (g_h2_rows == 4 ? 1 : 256);
+}
+
+int conv_h2_stats_tiles(const dsg_conv_args* a, int hout, int wout) {
+  if (!g_h2_stats || !conv_h2_eligible(a, hout, wout)) return 0;
+  return hout * wout / (H2_TW * 8);  // 8-row x 32-column statistics tiles for either block height
+}
+
 int conv_h2_launch(const dsg_conv_args* a, int hout, int wout, hipStream_t st) {
+  const bool nt4 = conv_h2_rows16(a, hout, wout);
   ConvH2P p;
+  p.stats = a->stats_out;
   p.src0 = a->src0; p.src1 = a->src1; p.c0 = a->c0; p.c1 = a->c1; p.cin = a->c0 + a->c1;
   p.n = a->n; p.hin = a->hin; p.win = a->win;
   if (a->ksize == 1) {
@@ -384,8 +469,6 @@ int conv_h2_launch(const dsg_conv_args* a, int hout, int wout, hipStream_t st) {
   p.bias = a->bias; p.ss = a->gn_scale_shift; p.silu = a->silu; p.temb = a->temb; p.temb_stride = a->temb_stride;
   p.res = a->residual; p.dst = a->dst;
   // 16-row tiles (NT = 4) when they still give every CU a workgroup; 8-row tiles otherwise
-  const int blocks16 = (hout % 16 == 0) ? (wout / H2_TW) * (hout / 16) * p.n * (p.cout_pad / H2_BM) : 0;
-  const bool nt4 = g_h2_rows != 2 && blocks16 >= (g_h2_rows == 4 ? 1 : 256);
   const int th = nt4 ? 16 : 8;
   p.tiles_x = wout / H2_TW; p.tiles_y = hout / th;
   const bool k1 = a->ksize == 1;
@@ -402,7 +485,10 @@ int conv_h2_launch(const dsg_conv_args* a, int hout, int wout, hipStream_t st) {
   }
   static bool raised = false;
   if (!raised) {
-    const void* ks[6] = {reinterpret_cast<const void*>(conv_h2_kernel<0, 2, 3>), reinterpret_cast<const void*>(conv_h2_kernel<1, 2, 3>),
+    const void* ks[9] = {reinterpret_cast<const void*>(conv_h2_kernel<0, 4, 3, 1>),
+                         reinterpret_cast<const void*>(conv_h2_kernel<0, 4, 3, 2>),
+                         reinterpret_cast<const void*>(conv_h2_kernel<0, 4, 3, 3>),
+                         reinterpret_cast<const void*>(conv_h2_kernel<0, 2, 3>), reinterpret_cast<const void*>(conv_h2_kernel<1, 2, 3>),
                          reinterpret_cast<const void*>(conv_h2_kernel<0, 4, 3>), reinterpret_cast<const void*>(conv_h2_kernel<1, 4, 3>),
                          reinterpret_cast<const void*>(conv_h2_kernel<0, 2, 1>), reinterpret_cast<const void*>(conv_h2_kernel<0, 4, 1>)};
     for (const void* k : ks) DSG_HIP(hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
@@ -415,7 +501,10 @@ int conv_h2_launch(const dsg_conv_args* a, int hout, int wout, hipStream_t st) {
     if (nt4) hipLaunchKernelGGL((conv_h2_kernel<1, 4, 3>), grid, dim3(256), lds, st, p);
     else hipLaunchKernelGGL((conv_h2_kernel<1, 2, 3>), grid, dim3(256), lds, st, p);
   } else {
-    if (nt4) hipLaunchKernelGGL((conv_h2_kernel<0, 4, 3>), grid, dim3(256), lds, st, p);
+    if (nt4 && g_h2_exp == 1) hipLaunchKernelGGL((conv_h2_kernel<0, 4, 3, 1>), grid, dim3(256), lds, st, p);
+    else if (nt4 && g_h2_exp == 2) hipLaunchKernelGGL((conv_h2_kernel<0, 4, 3, 2>), grid, dim3(256), lds, st, p);
+    else if (nt4 && g_h2_exp == 3) hipLaunchKernelGGL((conv_h2_kernel<0, 4, 3, 3>), grid, dim3(256), lds, st, p);
+    else if (nt4) hipLaunchKernelGGL((conv_h2_kernel<0, 4, 3>), grid, dim3(256), lds, st, p);
     else hipLaunchKernelGGL((conv_h2_kernel<0, 2, 3>), grid, dim3(256), lds, st, p);
   }
   prof_end(pi, st);
@@ -425,6 +514,8 @@ int conv_h2_launch(const dsg_conv_args* a, int hout, int wout, hipStream_t st) {
 
 void conv_h2_set_enabled(int on) { g_h2_enabled = on; }
 void conv_h2_set_rows(int r) { g_h2_rows = r; }
+void conv_h2_set_exp(int e) { g_h2_exp = e; }
+void conv_h2_set_stats(int on) { g_h2_stats = on; }
 
 }  // namespace dsg
 

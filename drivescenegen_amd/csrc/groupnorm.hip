@@ -88,6 +88,46 @@ __global__ void gn_finalize_kernel(const double* __restrict__ stats, const float
   }
 }
 
+// One wave per (n, group): per-tile partial statistics of the group's channels (which may sit in either of two
+// concatenated sources) summed in a fixed order -- lane-strided over tiles, then a fixed butterfly.
+__global__ __launch_bounds__(64) void gn_finalize_parts_kernel(const double* __restrict__ st0, int c0, int t0,
+                                                              const double* __restrict__ st1, int c1, int t1,
+                                                              const float* __restrict__ gamma,
+                                                              const float* __restrict__ beta, int groups, int hw,
+                                                              float eps, float* __restrict__ out) {
+  const int c = c0 + c1, cpg = c / groups;
+  const int ni = blockIdx.x / groups, g = blockIdx.x - ni * groups;
+  const int lane = threadIdx.x;
+  double s = 0.0, ss = 0.0;
+  for (int k = 0; k < cpg; ++k) {
+    const int ch = g * cpg + k;
+    const bool first = ch < c0;
+    const int tiles = first ? t0 : t1;
+    const double* p = first ? st0 + ((size_t)ni * c0 + ch) * t0 * 2 : st1 + ((size_t)ni * c1 + (ch - c0)) * t1 * 2;
+    for (int t = lane; t < tiles; t += 64) {
+      s += p[2 * t];
+      ss += p[2 * t + 1];
+    }
+  }
+#pragma unroll
+  for (int m = 32; m >= 1; m >>= 1) {
+    s += __shfl_xor(s, m);
+    ss += __shfl_xor(ss, m);
+  }
+  const double cnt = (double)cpg * (double)hw;
+  const double mean = s / cnt;
+  double var = ss / cnt - mean * mean;
+  if (var < 0.0) var = 0.0;
+  const float rstd = (float)(1.0 / sqrt(var + (double)eps));
+  const float meanf = (float)mean;
+  for (int k = lane; k < cpg; k += 64) {
+    const int ch = g * cpg + k;
+    const float sc = rstd * gamma[ch];
+    out[2 * ((size_t)ni * c + ch)] = sc;
+    out[2 * ((size_t)ni * c + ch) + 1] = beta[ch] - meanf * sc;
+  }
+}
+
 // grid = (ceil(hw/1024), c, n)
 __global__ __launch_bounds__(256) void gn_apply_kernel(const float* __restrict__ src, const float* __restrict__ ssb,
                                                        int silu, float* __restrict__ dst, int c, int hw) {
@@ -146,6 +186,21 @@ DSG_API int dsg_gn_finalize_train(const double* chan_stats, const float* gamma, 
                                   void* stream) {
   DSG_CHECK_ARG(mean_rstd != nullptr, "dsg_gn_finalize_train: mean_rstd is NULL");
   return gn_finalize_impl(chan_stats, gamma, beta, n, c, groups, hw, eps, scale_shift, mean_rstd, stream);
+}
+
+DSG_API int dsg_gn_finalize_parts(const double* stats0, int32_t c0, int32_t tiles0, const double* stats1, int32_t c1,
+                                  int32_t tiles1, const float* gamma, const float* beta, int32_t n, int32_t groups,
+                                  int32_t hw, float eps, float* scale_shift, void* stream) {
+  DSG_CHECK_ARG(stats0 && gamma && beta && scale_shift, "dsg_gn_finalize_parts: NULL pointer");
+  DSG_CHECK_ARG((c1 == 0) == (stats1 == nullptr), "dsg_gn_finalize_parts: stats1/c1 mismatch");
+  DSG_CHECK_ARG(n > 0 && c0 > 0 && c1 >= 0 && groups > 0 && hw > 0 && tiles0 > 0 && (c1 == 0 || tiles1 > 0),
+                "dsg_gn_finalize_parts: bad dims");
+  DSG_CHECK_ARG((c0 + c1) % groups == 0, "dsg_gn_finalize_parts: channels (%d) not divisible by groups (%d)",
+                c0 + c1, groups);
+  hipLaunchKernelGGL(dsg::gn_finalize_parts_kernel, dim3(n * groups), dim3(64), 0, static_cast<hipStream_t>(stream),
+                     stats0, c0, tiles0, stats1, c1, tiles1, gamma, beta, groups, hw, eps, scale_shift);
+  DSG_LAUNCH_CHECK();
+  return DSG_OK;
 }
 
 DSG_API int dsg_gn_apply(const float* src, const float* scale_shift, int32_t silu, float* dst, int32_t n, int32_t c,

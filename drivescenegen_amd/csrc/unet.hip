@@ -75,6 +75,10 @@ struct T {  // activation [N, c, h, w] (or any scratch when c/h/w are unused)
   std::shared_ptr<Buf> b;
   float* p = nullptr;
   int c = 0, h = 0, w = 0;
+  // per-tile (sum, sum of squares) of every channel, written by the conv that produced the tensor
+  std::shared_ptr<Buf> sb;
+  double* stats = nullptr;
+  int stiles = 0;
 };
 
 struct Conv { float* w = nullptr; float* b = nullptr; int cin = 0, cout = 0, k = 0, wstride = 0; void* wh = nullptr; };
@@ -204,23 +208,37 @@ struct Runner {
   }
   bool ok() const { return rc == DSG_OK; }
 
-  // scale/shift of GroupNorm(gn) over cat(x, skip)
+  // scale/shift of GroupNorm(gn) over cat(x, skip).  Statistics come from the producing convs' epilogues where
+  // they wrote them; a tensor without them (conv_in, stride-2 convs, tiny maps) gets a pass of its own.
   T gn_ss(const T& x, const T* skip, const GN& gn) {
     const int c = x.c + (skip ? skip->c : 0);
-    T stats = alloc(0, 0, 0, (size_t)B * c * 2, sizeof(double));
     T ss = alloc(0, 0, 0, (size_t)B * c * 2);
-    if (!dry && ok()) {
-      rc = dsg_gn_channel_stats(x.p, x.c, skip ? skip->p : nullptr, skip ? skip->c : 0, B, x.h * x.w,
-                                reinterpret_cast<double*>(stats.p), st);
-      if (ok())
-        rc = dsg_gn_finalize(reinterpret_cast<double*>(stats.p), gn.g, gn.b, B, c, h->cfg.norm_num_groups,
-                             x.h * x.w, h->cfg.norm_eps, ss.p, st);
+    const T* src[2] = {&x, skip};
+    T tmp[2];
+    const double* sp[2] = {nullptr, nullptr};
+    int tl[2] = {0, 0};
+    for (int i = 0; i < 2; ++i) {
+      if (!src[i]) continue;
+      if (src[i]->stiles > 0) {
+        sp[i] = src[i]->stats;
+        tl[i] = src[i]->stiles;
+        continue;
+      }
+      tmp[i] = alloc(0, 0, 0, (size_t)B * src[i]->c * 2, sizeof(double));
+      sp[i] = reinterpret_cast<double*>(tmp[i].p);
+      tl[i] = 1;
+      if (!dry && ok())
+        rc = dsg_gn_channel_stats(src[i]->p, src[i]->c, nullptr, 0, B, x.h * x.w, reinterpret_cast<double*>(tmp[i].p), st);
     }
+    if (!dry && ok())
+      rc = dsg_gn_finalize_parts(sp[0], x.c, tl[0], sp[1], skip ? skip->c : 0, tl[1], gn.g, gn.b, B,
+                                 h->cfg.norm_num_groups, x.h * x.w, h->cfg.norm_eps, ss.p, st);
     return ss;
   }
 
+  // want_stats: the result feeds a GroupNorm -- have the conv write its per-tile statistics when it can
   T conv(const T& x, const T* skip, const Conv& cv, int stride, int ups, const T* ss, int silu, const float* temb,
-         const T* res, float* dst_override = nullptr) {
+         const T* res, float* dst_override = nullptr, bool want_stats = false) {
     const int hc = ups ? 2 * x.h : x.h, wc = ups ? 2 * x.w : x.w;
     const int pad = cv.k / 2;
     const int ho = (hc + 2 * pad - cv.k) / stride + 1, wo = (wc + 2 * pad - cv.k) / stride + 1;
@@ -230,33 +248,43 @@ struct Runner {
     } else {
       y = alloc(cv.cout, ho, wo);
     }
-    if (!dry && ok()) {
-      dsg_conv_args a;
-      std::memset(&a, 0, sizeof(a));
-      a.src0 = x.p; a.c0 = x.c;
-      a.src1 = skip ? skip->p : nullptr; a.c1 = skip ? skip->c : 0;
-      a.n = B; a.hin = x.h; a.win = x.w; a.upsample = ups; a.ksize = cv.k; a.stride = stride; a.cout = cv.cout;
-      a.weight = cv.w; a.weight_cout_stride = cv.wstride; a.bias = cv.b; a.weight_h2 = cv.wh;
-      a.gn_scale_shift = ss ? ss->p : nullptr; a.silu = silu;
-      a.temb = temb; a.temb_stride = h->proj_total;
-      a.residual = res ? res->p : nullptr;
-      a.dst = y.p;
-      rc = dsg::conv2d_fwd_impl(&a, st, 0);
+    dsg_conv_args a;
+    std::memset(&a, 0, sizeof(a));
+    a.src0 = x.p; a.c0 = x.c;
+    a.src1 = skip ? skip->p : nullptr; a.c1 = skip ? skip->c : 0;
+    a.n = B; a.hin = x.h; a.win = x.w; a.upsample = ups; a.ksize = cv.k; a.stride = stride; a.cout = cv.cout;
+    a.weight = cv.w; a.weight_cout_stride = cv.wstride; a.bias = cv.b; a.weight_h2 = cv.wh;
+    a.gn_scale_shift = ss ? ss->p : nullptr; a.silu = silu;
+    a.temb = temb; a.temb_stride = h->proj_total;
+    a.residual = res ? res->p : nullptr;
+    a.dst = y.p;
+    if (want_stats && ok()) {
+      int32_t tiles = 0;
+      rc = dsg_conv2d_stats_tiles(&a, &tiles);
+      if (ok() && tiles > 0) {
+        const size_t bytes = (size_t)B * cv.cout * tiles * 2 * sizeof(double);
+        const size_t off = arena.alloc(bytes);
+        y.sb = std::make_shared<Buf>(&arena, off, bytes);
+        y.stats = reinterpret_cast<double*>(ws + off);
+        y.stiles = tiles;
+        a.stats_out = y.stats;
+      }
     }
+    if (!dry && ok()) rc = dsg::conv2d_fwd_impl(&a, st, 0);
     return y;
   }
 
   T resnet(const T& x, const T* skip, const Res& r, const float* tproj) {
     T ss1 = gn_ss(x, skip, r.n1);
-    T hmid = conv(x, skip, r.c1, 1, 0, &ss1, 1, tproj + r.toff, nullptr);
+    T hmid = conv(x, skip, r.c1, 1, 0, &ss1, 1, tproj + r.toff, nullptr, nullptr, true);
     ss1 = T();
     T ss2 = gn_ss(hmid, nullptr, r.n2);
     T y;
     if (r.sc) {
       T sc = conv(x, skip, r.csc, 1, 0, nullptr, 0, nullptr, nullptr);
-      y = conv(hmid, nullptr, r.c2, 1, 0, &ss2, 1, nullptr, &sc);
+      y = conv(hmid, nullptr, r.c2, 1, 0, &ss2, 1, nullptr, &sc, nullptr, true);
     } else {
-      y = conv(hmid, nullptr, r.c2, 1, 0, &ss2, 1, nullptr, &x);
+      y = conv(hmid, nullptr, r.c2, 1, 0, &ss2, 1, nullptr, &x, nullptr, true);
     }
     return y;
   }
@@ -268,7 +296,7 @@ struct Runner {
     T o = alloc(x.c, x.h, x.w);
     if (!dry && ok()) rc = dsg_attention_fwd(qkv.p, o.p, B, x.c, at.heads, x.h * x.w, st);
     qkv = T();
-    return conv(o, nullptr, at.out, 1, 0, nullptr, 0, nullptr, &x);
+    return conv(o, nullptr, at.out, 1, 0, nullptr, 0, nullptr, &x, nullptr, true);
   }
 
   int run(const float* xin, const int64_t* t, float* out) {
@@ -306,7 +334,7 @@ struct Runner {
         x = resnet(x, &s, u.res[j], tproj.p);
         if (!u.att.empty()) x = attention(x, u.att[j]);
       }
-      if (u.resample) x = conv(x, nullptr, u.rconv, 1, 1, nullptr, 0, nullptr, nullptr);
+      if (u.resample) x = conv(x, nullptr, u.rconv, 1, 1, nullptr, 0, nullptr, nullptr, nullptr, true);
     }
     T ssf = gn_ss(x, nullptr, h->norm_out);
     conv(x, nullptr, h->conv_out, 1, 0, &ssf, 1, nullptr, nullptr, out);

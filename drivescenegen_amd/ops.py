@@ -79,9 +79,11 @@ def relayout_conv_weight_dgrad(w_oihw: torch.Tensor, out: torch.Tensor = None) -
 
 def conv2d_fused(src0, weight_r, bias=None, src1=None, ksize=3, stride=1, upsample=False, gn_scale_shift=None,
                  silu=False, temb=None, temb_stride=0, residual=None, out=None, direct=False, cout=None,
-                 pool2=False, wstride=None, weight_h2=None):
+                 pool2=False, wstride=None, weight_h2=None, want_stats=False):
     """dsg_conv2d_fwd: see include/dsg.h.  `weight_r` is in engine layout; `temb` is a [N, temb_stride] view
-    whose first `cout` columns (from its data pointer) are added per (n, cout)."""
+    whose first `cout` columns (from its data pointer) are added per (n, cout).
+    want_stats: also return the per-tile GroupNorm statistics [N][cout][tiles][2] (fp64) of the result, or None
+    when the kernel serving the call does not produce them."""
     lib = _lib.load()
     n, c0, hin, win = src0.shape
     c1 = src1.shape[1] if src1 is not None else 0
@@ -108,10 +110,30 @@ def conv2d_fused(src0, weight_r, bias=None, src1=None, ksize=3, stride=1, upsamp
             raise RuntimeError("temb must be a GPU tensor")
         a.temb, a.temb_stride = temb.data_ptr(), int(temb_stride or temb.stride(0))
     a.residual, a.dst = _lib.ptr(residual), _lib.ptr(out)
+    stats = None
+    if want_stats and not direct:
+        tiles = C.c_int32(0)
+        _lib.check(lib.dsg_conv2d_stats_tiles(C.byref(a), C.byref(tiles)))
+        if tiles.value > 0:
+            stats = torch.empty((n, cout, tiles.value, 2), dtype=torch.float64, device=src0.device)
+            a.stats_out = stats.data_ptr()
     fn = lib.dsg_conv2d_fwd_direct if direct else lib.dsg_conv2d_fwd
     with torch.cuda.device(src0.device):
         _lib.check(fn(C.byref(a), _st(src0)))
-    return out
+    return (out, stats) if want_stats else out
+
+
+def gn_scale_shift_from_parts(stats0, gamma, beta, groups, eps, hw, stats1=None):
+    """dsg_gn_finalize_parts: scale/shift of GroupNorm over cat(src0, src1) from per-tile partial statistics
+    [N][c_i][tiles_i][2] (conv2d_fused(want_stats=True), or channel statistics with tiles = 1)."""
+    n, c0, t0 = stats0.shape[0], stats0.shape[1], stats0.shape[2]
+    c1, t1 = (stats1.shape[1], stats1.shape[2]) if stats1 is not None else (0, 0)
+    ss = torch.empty((n, c0 + c1, 2), dtype=torch.float32, device=stats0.device)
+    with torch.cuda.device(stats0.device):
+        _lib.check(_lib.load().dsg_gn_finalize_parts(_lib.ptr(stats0), c0, t0, _lib.ptr(stats1), c1, t1,
+                                                     _lib.ptr(gamma), _lib.ptr(beta), n, groups, hw, float(eps),
+                                                     _lib.ptr(ss), _st(stats0)))
+    return ss
 
 
 def gn_scale_shift(src0, gamma, beta, groups, eps, src1=None):

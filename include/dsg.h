@@ -74,9 +74,15 @@ typedef struct {
   int32_t pool2;                /* 1: 2x2 sum-pool of the result (adjoint of the nearest x2 upsample) */
   const void* weight_h2;        /* optional: the same weights pre-split for the fp16x2 matrix-core path
                                    (dsg_conv_weight_relayout_h2); used for stride-1 3x3 / 1x1 convs with cin % 16 == 0, cout % 64 == 0 */
+  double* stats_out;            /* optional [N][cout][tiles][2]: per-tile (sum, sum of squares) of dst, so that the
+                                   GroupNorm that follows needs no pass of its own over dst (dsg_gn_finalize_parts).
+                                   Only where dsg_conv2d_stats_tiles reports tiles > 0. */
 } dsg_conv_args;
 
 int dsg_conv2d_fwd(const dsg_conv_args* a, void* stream);
+/* Number of spatial tiles per (n, cout) this call would write into stats_out; 0 when the kernel that serves the
+ * call cannot produce the statistics (then run dsg_gn_channel_stats on dst instead). Host-only. */
+int dsg_conv2d_stats_tiles(const dsg_conv_args* a, int32_t* tiles);
 
 /* OIHW (checkpoint layout) -> engine layout [Cin][k*k][cout_total], written at
  * column offset cout_off (used to fuse to_q/to_k/to_v into one projection). nn.Linear weights
@@ -106,6 +112,11 @@ int dsg_gn_channel_stats(const float* src0, int32_t c0, const float* src1, int32
 int dsg_gn_finalize(const double* chan_stats, const float* gamma, const float* beta, int32_t n,
                     int32_t c, int32_t groups, int32_t hw, float eps,
                     float* scale_shift /* [N][C][2] */, void* stream);
+/* finalize over cat(src0, src1) from per-tile partial statistics [N][c_i][tiles_i][2] (conv stats_out, or
+ * dsg_gn_channel_stats output with tiles = 1); fixed summation order, fp64 */
+int dsg_gn_finalize_parts(const double* stats0, int32_t c0, int32_t tiles0, const double* stats1, int32_t c1,
+                          int32_t tiles1, const float* gamma, const float* beta, int32_t n, int32_t groups,
+                          int32_t hw, float eps, float* scale_shift /* [N][c0+c1][2] */, void* stream);
 int dsg_gn_apply(const float* src, const float* scale_shift, int32_t silu, float* dst, int32_t n,
                  int32_t c, int32_t hw, void* stream);
 

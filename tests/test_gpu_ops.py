@@ -263,3 +263,47 @@ def test_conv_h2_split_matches_fp32(case):
     # staging error of the fast SiLU)
     assert eh2 <= max(2 * e32, 3e-7), (eh2, e32)
     assert not torch.equal(got32, goth2)  # the two kernels really are different code paths
+
+
+STATS_CASES = [
+    # name, c0, c1, cout, h, w, k, ups
+    ("stats_3x3_rows8", 32, 0, 64, 16, 32, 3, False),
+    ("stats_3x3_rows16_concat", 64, 32, 128, 32, 64, 3, False),
+    ("stats_1x1_16x16", 64, 0, 128, 16, 16, 1, False),
+    ("stats_upsample", 64, 0, 64, 16, 16, 3, True),
+]
+
+
+@pytest.mark.parametrize("case", STATS_CASES, ids=[c[0] for c in STATS_CASES])
+def test_conv_epilogue_groupnorm_statistics(case):
+    """stats_out of dsg_conv2d_fwd (per-tile sum / sum of squares of the tensor just written) gives the same
+    GroupNorm scale/shift as a statistics pass over that tensor (dsg_gn_channel_stats), also across a concat."""
+    name, c0, c1, cout, h, w, k, ups = case
+    batch, cin, groups = 2, c0 + c1, 8
+    x0 = _t(11, (batch, c0, h, w), 1.3).to(DEV)
+    x1 = _t(12, (batch, c1, h, w)).to(DEV) if c1 else None
+    wt = _t(13, (cout, cin, k, k), 1.0 / np.sqrt(cin * k * k)).to(DEV)
+    bias = _t(14, (cout,), 0.5).to(DEV)   # non-zero channel means: the variance has something to cancel
+    ho, wo = (2 * h, 2 * w) if ups else (h, w)
+    res = _t(15, (batch, cout, ho, wo)).to(DEV)
+    wr, wh = ops.relayout_conv_weight(wt), ops.relayout_conv_weight_h2(wt)
+    y, st = ops.conv2d_fused(x0, wr, bias, src1=x1, ksize=k, upsample=ups, residual=res, cout=cout, weight_h2=wh,
+                             want_stats=True)
+    assert st is not None and st.shape[:2] == (batch, cout)
+    tot = st.sum(dim=2).cpu()
+    ref = torch.stack([y.double().sum(dim=(2, 3)), (y.double() ** 2).sum(dim=(2, 3))], dim=-1).cpu()
+    assert torch.allclose(tot, ref, rtol=2e-6, atol=1e-4), float((tot - ref).abs().max())
+    gamma, beta = (1 + _t(16, (cout,), 0.1)).to(DEV), _t(17, (cout,), 0.1).to(DEV)
+    ss_ref = ops.gn_scale_shift(y, gamma, beta, groups, 1e-5)
+    ss = ops.gn_scale_shift_from_parts(st, gamma, beta, groups, 1e-5, ho * wo)
+    assert torch.allclose(ss, ss_ref, rtol=2e-6, atol=2e-6), float((ss - ss_ref).abs().max())
+    # the same tensor as the second half of a concat whose first half has plain channel statistics
+    z = _t(18, (batch, 24, ho, wo)).to(DEV)
+    g2, b2 = (1 + _t(19, (24 + cout,), 0.1)).to(DEV), _t(20, (24 + cout,), 0.1).to(DEV)
+    ss_ref2 = ops.gn_scale_shift(z, g2, b2, groups, 1e-5, src1=y)
+    zst = torch.stack([z.double().sum(dim=(2, 3)), (z.double() ** 2).sum(dim=(2, 3))], dim=-1).unsqueeze(2).contiguous()
+    ss2 = ops.gn_scale_shift_from_parts(zst, g2, b2, groups, 1e-5, ho * wo, stats1=st)
+    assert torch.allclose(ss2, ss_ref2, rtol=2e-6, atol=2e-6), float((ss2 - ss_ref2).abs().max())
+    # a conv the statistics kernel does not serve reports no tiles instead of writing nothing
+    _, none = ops.conv2d_fused(x0, wr, bias, src1=x1, ksize=k, upsample=ups, cout=cout, want_stats=True)
+    assert none is None
