@@ -12,7 +12,8 @@ import threading
 import torch  # noqa: F401  (imported first so libdsg.so binds to the HIP runtime torch already loaded)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libdsg.so")
+# DSG_LIB_PATH: an alternative build of the same ABI (kernel A/B comparisons in tools/); default is the in-tree build
+LIB_PATH = os.environ.get("DSG_LIB_PATH") or os.path.join(_HERE, "lib", "libdsg.so")
 
 OK = 0
 ERR_NAMES = {-1: "DSG_ERR_INVALID_ARG", -2: "DSG_ERR_UNSUPPORTED_SHAPE", -3: "DSG_ERR_WORKSPACE_TOO_SMALL",
@@ -148,6 +149,11 @@ def load():
             fn.argtypes = argtypes
             fn.restype = C.c_int32
         lib.dsg_version.restype = C.c_int32
+        # DSG_TUNING="key=value,...": kernel-selection knobs (dsg_set_tuning) for A/B runs of tests and tools
+        for kv in filter(None, os.environ.get("DSG_TUNING", "").split(",")):
+            k, v = kv.split("=")
+            if lib.dsg_set_tuning(int(k), int(v)) != 0:
+                raise RuntimeError(f"DSG_TUNING: bad entry {kv!r}")
         lib.dsg_version.argtypes = []
         lib.dsg_last_error.restype = C.c_char_p
         lib.dsg_last_error.argtypes = []

@@ -398,8 +398,8 @@ int conv_h2_launch(const dsg_conv_args* a, int hout, int wout, hipStream_t st);
 int conv_h2_stats_tiles(const dsg_conv_args* a, int hout, int wout);
 void conv_h2_set_enabled(int on);
 void conv_h2_set_rows(int r);
-void conv_h2_set_exp(int e);
 void conv_h2_set_stats(int on);
+void conv_h2_set_waves(int w);
 
 static int g_conv_kc = 0;  // K-chunk of the 3x3 stride-1 kernel: 4 | 8 | 0 = by grid size (measured, r01)
 
@@ -537,8 +537,8 @@ DSG_API int dsg_set_tuning(int32_t key, int32_t value) {
     dsg::conv_h2_set_rows(value);
     return DSG_OK;
   }
-  if (key == 4) {
-    dsg::conv_h2_set_exp(value);
+  if (key == 6 && (value == 4 || value == 8)) {
+    dsg::conv_h2_set_waves(value);
     return DSG_OK;
   }
   if (key == 5 && (value == 0 || value == 1)) {

@@ -59,21 +59,26 @@ constexpr int H2_TW = 32, H2_KC = 16, H2_BM = 64;
 // traffic per MFMA (each weight fragment feeds 4 pixel tiles) and the weight DMA per MFMA; it needs 256
 // accumulator registers (the kernel owns the SIMD: 1 wave, 512 registers).
 // KS = 3 (halo of 1) or 1 (no halo; attention projections and resnet shortcuts)
-template <int NT, int KS>
+// NW = waves per workgroup (4: one per SIMD with the whole register file; 8: two per SIMD with half of it each,
+// so that one wave's staging / LDS / wait time is covered by the other's MFMAs)
+template <int NT, int KS, int NW = 4>
 struct H2Geom {
+  static constexpr int NTH = 64 * NW;
   static constexpr int TAPS = KS * KS;
-  static constexpr int TH = 4 * NT;
+  static constexpr int TH = NW * NT;
   static constexpr int PH = TH + KS - 1;
   static constexpr int PW = H2_TW + KS - 1;
   static constexpr int PSZ = PW * PH;                 // KS=3: 340 (NT=2) / 612 (NT=4); KS=1: 256 / 512
   static constexpr int WHALFS = 2 * TAPS * 2 * H2_BM * 8;  // [piece][tap][g][cout][8]: 36864 B / 4096 B
   static constexpr int XHALFS = 2 * 2 * PSZ * 8;      // [piece][g][pos][8]
   static constexpr int BUF_BYTES = (WHALFS + XHALFS) * 2 + 64;  // + a dump slot for masked lanes
-  static constexpr int FULL = PSZ / 256;              // full 256-position slabs per k-group
-  static constexpr bool HAS_REM = (PSZ % 256) != 0;   // KS=3 leaves a remainder slab shared by the two k-groups
+  static constexpr int FULL = PSZ / NTH;              // full NTH-position slabs per k-group
+  static constexpr bool HAS_REM = (PSZ % NTH) != 0;   // KS=3 leaves a remainder slab shared by the two k-groups
   static constexpr int NU = 2 * FULL + (HAS_REM ? 1 : 0);  // staging units per thread
-  static constexpr int REM0 = FULL * 256;             // first position of the remainder unit
+  static constexpr int REM0 = FULL * NTH;             // first position of the remainder unit
   static constexpr int NSEG = 4 * TAPS;               // 1-KB weight segments per chunk
+  static constexpr int NDMA = (NSEG + NW - 1) / NW;   // weight DMAs per wave per chunk
+  static_assert(PSZ - REM0 <= NTH / 2, "the remainder slab must fit half the workgroup per k-group");
 };
 
 // x + (x of the lane selected by a DPP control): the building block of a fixed-order 32-lane tree sum
@@ -100,9 +105,11 @@ __device__ __forceinline__ float silu_fast_h(float x) { return x * __builtin_amd
 // loads), and the only per-lane address is the 32-bit halo offset computed once per tile.
 //   units 0..FULL-1: g = 0, halo positions tid + 256*i      units FULL..2*FULL-1: g = 1, same positions
 //   last unit: g = wave >> 1, halo position FULL*256 + (tid & 127)   (the remainder, valid where < PSZ)
-template <int GM, int NT, int KS, int EXP = 0>
-__global__ __launch_bounds__(256, 1) void conv_h2_kernel(ConvH2P p) {
-  using G = H2Geom<NT, KS>;
+// ACT: 0 the input is used as it is; 2 GroupNorm affine + SiLU; 3 decided at run time from p.ss / p.silu
+template <int GM, int NT, int KS, int ACT = 3, int NW = 4>
+__global__ __launch_bounds__(64 * NW, 1) void conv_h2_kernel(ConvH2P p) {
+  using G = H2Geom<NT, KS, NW>;
+  constexpr int NTH = G::NTH;
   constexpr int H2_TH = G::TH, H2_PSZ = G::PSZ, H2_XHALFS = G::XHALFS, H2_BUF_BYTES = G::BUF_BYTES, H2_NU = G::NU;
   constexpr int FULL = G::FULL, TAPS = G::TAPS, H2_PW = G::PW, H2_WHALFS = G::WHALFS, PADK = KS / 2;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -122,33 +129,43 @@ __global__ __launch_bounds__(256, 1) void conv_h2_kernel(ConvH2P p) {
   const int oy0 = ty * H2_TH, ox0 = tx * H2_TW;
   const int plane = p.hin * p.win;
   const int nq = p.cin / H2_KC;
-  const int g2 = wave >> 1;  // k-group of unit 2 (uniform per wave)
+  const int g2 = wave / (NW / 2);  // k-group of the remainder unit (uniform per wave)
 
-  int goff[H2_NU], xoff[H2_NU];
-  unsigned valid = 0;
+  // Per staging unit: global halo offset, and the LDS slots of its two pieces.  Positions outside the image (zero
+  // padding) or past the patch write to a dump slot instead; the real slots of padding positions are zeroed once.
+  int goff[H2_NU], xoff[H2_NU], xoff2[H2_NU], zoff[H2_NU];
 #pragma unroll
   for (int i = 0; i < H2_NU; ++i) {
     const int g = i < FULL ? 0 : (i < 2 * FULL ? 1 : g2);
-    const int pos = i < 2 * FULL ? tid + 256 * (i % FULL) : G::REM0 + (tid & 127);
-    int off = 0, xo = H2_WHALFS + H2_XHALFS;  // dump slot (in halfs) when the position is past the patch
+    const int pos = i < 2 * FULL ? tid + NTH * (i % FULL) : G::REM0 + (tid & (NTH / 2 - 1));
+    int off = 0, xo = H2_WHALFS + H2_XHALFS, xo2 = H2_WHALFS + H2_XHALFS, zo = -1;
     if (pos < H2_PSZ) {
       const int py = pos / H2_PW, px = pos - py * H2_PW;
       const int gy = oy0 - PADK + py, gx = ox0 - PADK + px;
+      const int slot = H2_WHALFS + (g * H2_PSZ + pos) * 8;  // piece 0; piece 1 is 2*PSZ*8 halfs further
       if (gy >= 0 && gy < p.hc && gx >= 0 && gx < p.wc) {
         off = (GM ? (gy >> 1) : gy) * p.win + (GM ? (gx >> 1) : gx);
-        valid |= 1u << i;
+        xo = slot;
+        xo2 = slot + 2 * H2_PSZ * 8;
+      } else {
+        zo = slot;
       }
-      xo = H2_WHALFS + (g * H2_PSZ + pos) * 8;  // piece 0; piece 1 is 2*PSZ*8 halfs further
     }
     goff[i] = off;
     xoff[i] = xo;
+    xoff2[i] = xo2;
+    zoff[i] = zo;
   }
-  const bool has_ss = p.ss != nullptr;
-  const bool do_silu = has_ss && p.silu;
+  const bool has_ss = ACT == 3 ? p.ss != nullptr : ACT != 0;
+  const bool do_silu = ACT == 3 ? (has_ss && p.silu) : ACT == 2;
   const float* ssg = has_ss ? p.ss + (size_t)n * p.cin * 2 : nullptr;
 
   float xr[H2_NU][8];
-  float2 sr[H2_NU][8];  // GroupNorm (scale, shift) of the unit's 8 channels, fetched with the patch (one chunk ahead)
+  // GroupNorm (scale, shift) of this image's channels: copied once into LDS behind the two K-chunk buffers; a commit
+  // reads its 8 channels from there (uniform address: a broadcast read) instead of carrying them in registers
+  float* ssl = reinterpret_cast<float*>(smem_raw + 2 * H2_BUF_BYTES);
+  if (has_ss)
+    for (int i = tid; i < 2 * p.cin; i += NTH) ssl[i] = ssg[i];
 
   auto src_of = [&](int q) -> const float* {  // uniform
     const int cb = q * H2_KC;
@@ -156,49 +173,55 @@ __global__ __launch_bounds__(256, 1) void conv_h2_kernel(ConvH2P p) {
                        : p.src1 + ((size_t)n * p.c1 + (cb - p.c0)) * plane;
   };
   auto unit_g = [&](int i) -> int { return i < FULL ? 0 : (i < 2 * FULL ? 1 : g2); };
+  // patch loads are buffer loads: descriptor = the chunk's 16 channel planes (uniform), soffset = the channel
+  // plane (uniform), voffset = the lane's halo offset (fixed for the whole tile) -- no per-load address math
+  int soff[8];  // byte offsets of the 8 channel planes of a k-group: loop-invariant SGPRs
+#pragma unroll
+  for (int j = 0; j < 8; ++j) soff[j] = __builtin_amdgcn_readfirstlane(j * plane * 4);
   auto load_unit = [&](int i, int q, const float* sp) {
-    const float* spg = sp + (size_t)(unit_g(i) * 8) * plane;  // uniform
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(sp + (size_t)(unit_g(i) * 8) * plane), 0, 8 * plane * 4, 0x00020000);
 #pragma unroll
-    for (int j = 0; j < 8; ++j) xr[i][j] = (spg + (size_t)j * plane)[goff[i]];
-    if (has_ss) {
-      const float* ssq = ssg + 2 * (q * H2_KC + unit_g(i) * 8);  // uniform address: one line, broadcast
-#pragma unroll
-      for (int j = 0; j < 8; ++j) sr[i][j] = *reinterpret_cast<const float2*>(ssq + 2 * j);
-    }
+    for (int j = 0; j < 8; ++j)
+      xr[i][j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, goff[i] * 4, soff[j], 0));
   };
-  auto commit_unit = [&](int i, unsigned char* buf) {
+  auto commit_unit = [&](int i, int q, unsigned char* buf) {  // q: the chunk being staged
     half8 h1, h2;
-    const bool ok = (valid >> i) & 1u;
-    if (EXP == 1) {
+    float4 sr[4];
+    if (has_ss) {
+      const float4* ssq = reinterpret_cast<const float4*>(ssl + 2 * (q * H2_KC + unit_g(i) * 8));
 #pragma unroll
-      for (int j = 0; j < 8; ++j) h1[j] = (_Float16)xr[i][j];
-      _Float16* xb = reinterpret_cast<_Float16*>(buf);
-      *reinterpret_cast<half8*>(xb + xoff[i]) = h1;
-      *reinterpret_cast<half8*>(xb + xoff[i] + (xoff[i] < H2_WHALFS + H2_XHALFS ? 2 * H2_PSZ * 8 : 0)) = h1;
-      return;
+      for (int j = 0; j < 4; ++j) sr[j] = ssq[j];
     }
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
       float v = xr[i][j];
-      if (has_ss) v = v * sr[i][j].x + sr[i][j].y;
+      if (has_ss) v = (j & 1) ? v * sr[j / 2].z + sr[j / 2].w : v * sr[j / 2].x + sr[j / 2].y;
       const float sv = silu_fast_h(v);
       v = do_silu ? sv : v;
-      v = ok ? v : 0.f;
       const _Float16 a = (_Float16)v;
       h1[j] = a;
       h2[j] = (_Float16)((v - (float)a) * 2048.0f);
     }
+    // (branch-free: a branch here would fence the instruction scheduler between staging and MFMAs)
     _Float16* xb = reinterpret_cast<_Float16*>(buf);
     *reinterpret_cast<half8*>(xb + xoff[i]) = h1;
-    *reinterpret_cast<half8*>(xb + xoff[i] + (xoff[i] < H2_WHALFS + H2_XHALFS ? 2 * H2_PSZ * 8 : 0)) = h2;
+    *reinterpret_cast<half8*>(xb + xoff2[i]) = h2;
   };
   // weight slab of chunk q: 36 segments (piece, tap, g) of 64 couts x 16 B, moved global -> LDS by DMA;
   // wave w moves segments w, w+4, ...
   auto dma_weights = [&](int k, int q, unsigned char* buf) {
-    const int seg = wave + 4 * k;  // 0..NSEG-1
-    const _Float16* gp = p.wh + (((size_t)q * G::NSEG + seg) * p.cout_pad + m0) * 8;  // uniform
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gp + lane * 8),
-                                     (__attribute__((address_space(3))) void*)(buf + seg * 1024), 16, 0, 0);
+    // (uniform; a wave whose last share falls past the end repeats the final segment: same bytes, no branch)
+    const int seg = min(wave + NW * k, G::NSEG - 1);
+    const _Float16* gp = p.wh + (((size_t)q * G::NSEG + seg) * p.cout_pad + m0) * 8 + lane * 8;  // uniform + lane
+    // Issued as inline asm on purpose: hipcc's wait-count pass cannot tell the DMA's LDS destination (the other
+    // buffer) from the fragment reads of this one, and with a DMA it knows of in flight it puts vmcnt(0) -- a wait
+    // for every outstanding patch load as well -- in front of each following ds_read.  Untracked VMEM operations
+    // only make the compiler's own counted vmcnt(N) waits stricter (the counter retires in order); the DMA's
+    // completion is waited for explicitly before the chunk's closing barrier.
+    const unsigned lds_addr =
+        (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)(buf + seg * 1024);
+    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off\n" ::"v"(gp), "s"(lds_addr) : "memory");
   };
 
   f32x16 acc_hi[2][NT], acc_lo[2][NT];
@@ -215,25 +238,47 @@ __global__ __launch_bounds__(256, 1) void conv_h2_kernel(ConvH2P p) {
   unsigned char* buf0 = smem_raw;
   unsigned char* buf1 = smem_raw + H2_BUF_BYTES;
 
+  // zero padding: halo positions outside the image are zeroed once in both buffers and never written again
+#pragma unroll
+  for (int i = 0; i < H2_NU; ++i) {
+    if (zoff[i] >= 0) {
+      half8 z;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) z[j] = (_Float16)0.f;
+      _Float16* b0 = reinterpret_cast<_Float16*>(buf0);
+      _Float16* b1 = reinterpret_cast<_Float16*>(buf1);
+      *reinterpret_cast<half8*>(b0 + zoff[i]) = z;
+      *reinterpret_cast<half8*>(b0 + zoff[i] + 2 * H2_PSZ * 8) = z;
+      *reinterpret_cast<half8*>(b1 + zoff[i]) = z;
+      *reinterpret_cast<half8*>(b1 + zoff[i] + 2 * H2_PSZ * 8) = z;
+    }
+  }
   // prologue: chunk 0 -> buffer 0; chunk 1 -> registers
   {
     const float* sp = src_of(0);
 #pragma unroll
     for (int i = 0; i < H2_NU; ++i) load_unit(i, 0, sp);
 #pragma unroll
-    for (int k = 0; k < TAPS; ++k) dma_weights(k, 0, buf0);
+    for (int k = 0; k < G::NDMA; ++k) dma_weights(k, 0, buf0);
+    if (has_ss) __syncthreads();  // the scale/shift table is in LDS
 #pragma unroll
-    for (int i = 0; i < H2_NU; ++i) commit_unit(i, buf0);
+    for (int i = 0; i < H2_NU; ++i) commit_unit(i, 0, buf0);
     if (nq > 1) {
       const float* sp1 = src_of(1);
 #pragma unroll
       for (int i = 0; i < H2_NU; ++i) load_unit(i, 1, sp1);
     }
   }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // chunk 0's weight DMAs
   __syncthreads();
 
   // One K-chunk: MFMAs on `cur`; STAGE: chunk q+1 (patch in registers, weights by DMA) goes into `nxt`;
   // LOAD: chunk q+2's patch is fetched into the registers just freed.
+#ifdef DSG_H2_TIMING
+  unsigned long long t_tap[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  unsigned long long t_vm = 0, t_bar = 0;
+  const unsigned long long rt_start = __builtin_amdgcn_s_memrealtime();  // 100 MHz, same base on every CU
+#endif
   auto chunk = [&](int q, auto stage_tag, auto load_tag) {
     constexpr bool STAGE = decltype(stage_tag)::value, LOAD = decltype(load_tag)::value;
     unsigned char* cur = (q & 1) ? buf1 : buf0;
@@ -241,70 +286,120 @@ __global__ __launch_bounds__(256, 1) void conv_h2_kernel(ConvH2P p) {
     const float* spn = LOAD ? src_of(q + 2) : nullptr;
     const _Float16* wl = reinterpret_cast<const _Float16*>(cur);
     const _Float16* xl = wl + H2_WHALFS;
-#pragma unroll
-    for (int tap = 0; tap < TAPS; ++tap) {
-      if (KS == 1) {  // one tap: all units and the four weight segments ride on it
-#pragma unroll
-        for (int u = 0; u < H2_NU; ++u) {
-          if (STAGE) commit_unit(u, nxt);
-          if (LOAD) load_unit(u, q + 2, spn);
-        }
-        if (STAGE) dma_weights(0, q + 1, nxt);
-      }
-      // KS = 3 -- NU = 3: units at taps 1, 4, 7;  NU = 5: units at taps 0, 2, 4, 6, 8
-      constexpr int UNIT_STRIDE = (H2_NU == 3) ? 3 : 2, UNIT_PHASE = (H2_NU == 3) ? 1 : 0;
-      if (EXP < 2 && KS == 3 && tap % UNIT_STRIDE == UNIT_PHASE && tap / UNIT_STRIDE < H2_NU) {
-        if (STAGE) commit_unit(tap / UNIT_STRIDE, nxt);
-        if (LOAD) load_unit(tap / UNIT_STRIDE, q + 2, spn);
-      }
-      // The weight DMAs go AFTER this tap's commit: with a DMA in flight hipcc waits vmcnt(0) at every use of
-      // an ordinary load result, so a DMA issued just before a commit would stall it for the whole transfer.
-      if (STAGE && KS == 3) {
-        if (H2_NU == 5) {  // commits at even taps: two DMAs at each odd tap, the ninth after the last commit
-          if (tap & 1) {
-            dma_weights(tap - 1, q + 1, nxt);
-            dma_weights(tap, q + 1, nxt);
-          } else if (tap == 8) {
-            dma_weights(8, q + 1, nxt);
-          }
-        } else {  // commits at taps 1, 4, 7: three DMAs right after each
-          if (tap % 3 == 1) {
-            dma_weights(tap - 1, q + 1, nxt);
-            dma_weights(tap, q + 1, nxt);
-            dma_weights(tap + 1, q + 1, nxt);
-          }
-        }
-      }
+    // Operand fragments are fetched one tap ahead into the other half of fa/fb: the reads of tap t+1 are issued
+    // BEFORE tap t's staging writes in program order, so tap t's MFMAs depend on registers only and the scheduler
+    // is free to interleave them with the staging work (LDS reads after a possibly-aliasing LDS write are not).
+    half8 fa[2][2][2], fb[2][NT][2];  // [parity][tile][piece]
+    auto load_frags = [&](int tap, int par) {
       const int dy = tap / KS, dx = tap % KS;
-      half8 a[2][2], b[NT][2];  // [tile][piece]
 #pragma unroll
       for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
         for (int pc = 0; pc < 2; ++pc)
-          a[mt][pc] = *reinterpret_cast<const half8*>(wl + (((pc * TAPS + tap) * 2 + half) * H2_BM + mt * 32 + l31) * 8);
+          fa[par][mt][pc] =
+              *reinterpret_cast<const half8*>(wl + (((pc * TAPS + tap) * 2 + half) * H2_BM + mt * 32 + l31) * 8);
 #pragma unroll
       for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
         for (int pc = 0; pc < 2; ++pc)
-          b[nt][pc] = *reinterpret_cast<const half8*>(
-              xl + ((pc * 2 + half) * H2_PSZ + (wave * NT + nt + (EXP == 3 ? 0 : dy)) * H2_PW + l31 + (EXP == 3 ? 0 : dx)) * 8);
+          fb[par][nt][pc] = *reinterpret_cast<const half8*>(
+              xl + ((pc * 2 + half) * H2_PSZ + (wave * NT + nt + dy) * H2_PW + l31 + dx) * 8);
+    };
+    load_frags(0, 0);
+#pragma unroll
+    for (int tap = 0; tap < TAPS; ++tap) {
+      __builtin_amdgcn_sched_barrier(0);
+#ifdef DSG_H2_TIMING
+      const unsigned long long tt0 = __builtin_readcyclecounter();
+      __builtin_amdgcn_sched_barrier(0);
+#endif
+      if (tap + 1 < TAPS) load_frags(tap + 1, (tap + 1) & 1);
+      if (KS == 1) {  // one tap: all units and the four weight segments ride on it
+#pragma unroll
+        for (int u = 0; u < H2_NU; ++u) {
+          if (STAGE) commit_unit(u, q + 1, nxt);
+          if (LOAD) load_unit(u, q + 2, spn);
+        }
+        if (STAGE) dma_weights(0, q + 1, nxt);  // (KS = 1: NSEG = 4 <= NW)
+      }
+      // KS = 3: unit u (commit of chunk q+1, then the load of chunk q+2 into the freed registers) and its share
+      // of the weight DMAs ride on tap u, so that everything has the rest of the chunk to land before the
+      // vmcnt(0) of the closing barrier.  The DMAs go AFTER the tap's commit: with a DMA in flight hipcc waits
+      // vmcnt(0) at every use of an ordinary load result.
+      if (KS == 3 && tap < H2_NU) {
+        if (STAGE) commit_unit(tap, q + 1, nxt);
+        if (LOAD) load_unit(tap, q + 2, spn);
+        if (STAGE) {
+          constexpr int PER = (G::NDMA + H2_NU - 1) / H2_NU;
+#pragma unroll
+          for (int k = tap * PER; k < (tap + 1) * PER && k < G::NDMA; ++k) dma_weights(k, q + 1, nxt);
+        }
+      }
+      const int par = tap & 1;
 #pragma unroll
       for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) {
-          acc_hi[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[mt][0], b[nt][0], acc_hi[mt][nt], 0, 0, 0);
-          acc_lo[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[mt][0], b[nt][1], acc_lo[mt][nt], 0, 0, 0);
-          acc_lo[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[mt][1], b[nt][0], acc_lo[mt][nt], 0, 0, 0);
+          acc_hi[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[par][mt][0], fb[par][nt][0], acc_hi[mt][nt], 0, 0, 0);
+          acc_lo[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[par][mt][0], fb[par][nt][1], acc_lo[mt][nt], 0, 0, 0);
+          acc_lo[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[par][mt][1], fb[par][nt][0], acc_lo[mt][nt], 0, 0, 0);
         }
+      // Issue order within the tap: with one wave per SIMD nothing else fills the matrix pipe while this wave
+      // issues staging work, so spread that work between the MFMAs (at most ~5 issues hide behind one MFMA)
+      // instead of leaving it in one block as the scheduler would.
+      if (KS == 3 && tap < H2_NU && (STAGE || LOAD)) {
+#pragma unroll
+        for (int m = 0; m < 6 * NT; ++m) {
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);  // 1 MFMA
+          __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);  // 4 VALU
+        }
+      }
+#ifdef DSG_H2_TIMING
+      __builtin_amdgcn_sched_barrier(0);
+      t_tap[tap] += __builtin_readcyclecounter() - tt0;
+#endif
     }
-    __syncthreads();  // (drains the DMA: nxt is complete; everyone is done reading cur)
+    __builtin_amdgcn_sched_barrier(0);
+#ifdef DSG_H2_TIMING  // tools/ only: where does a wave wait at the end of a chunk?  (p.stats = 4 counters)
+    const unsigned long long ta = __builtin_readcyclecounter();
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    const unsigned long long tb = __builtin_readcyclecounter();
+    __builtin_amdgcn_s_barrier();
+    const unsigned long long tc = __builtin_readcyclecounter();
+    t_vm += tb - ta;
+    t_bar += tc - tb;
+    __builtin_amdgcn_sched_barrier(0);
+#else
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the weight DMAs (not tracked by the compiler) have landed
+    __syncthreads();  // nxt is complete; everyone is done reading cur
+#endif
   };
   using T = std::true_type;
   using F = std::false_type;
+#ifdef DSG_H2_TIMING
+  const unsigned long long t_begin = __builtin_readcyclecounter();
+  const unsigned long long rt_loop = __builtin_amdgcn_s_memrealtime();
+#endif
   int q = 0;
   for (; q + 2 < nq; ++q) chunk(q, T{}, T{});
   if (q + 1 < nq) chunk(q++, T{}, F{});  // last staged chunk: nothing left to load
   chunk(q, F{}, F{});                    // last chunk: MFMAs only
+#ifdef DSG_H2_TIMING
+  if (p.stats && lane == 0) {
+    atomicAdd(&p.stats[0], (double)(__builtin_readcyclecounter() - t_begin));
+    atomicAdd(&p.stats[1], (double)t_vm);
+    atomicAdd(&p.stats[2], (double)t_bar);
+    atomicAdd(&p.stats[3], 1.0);
+    for (int t = 0; t < TAPS; ++t) atomicAdd(&p.stats[8 + 5 * (size_t)(gridDim.x * gridDim.y) + t], (double)t_tap[t]);
+    if (wave == 0) {  // per-block record: start / loop begin / loop end (10-ns ticks), loop cycles
+      double* rec = p.stats + 8 + 4 * (size_t)(blockIdx.x + gridDim.x * blockIdx.y);
+      rec[0] = (double)rt_start;
+      rec[1] = (double)rt_loop;
+      rec[2] = (double)__builtin_amdgcn_s_memrealtime();
+      rec[3] = (double)(__builtin_readcyclecounter() - t_begin);
+    }
+  }
+#endif
 
   // Epilogue.  Everything but the lane's (half, column) offset is wave-uniform, so row bases, bias and
   // time-embedding values come through SGPRs; all residual loads are issued before the first use (with one
@@ -376,20 +471,27 @@ __global__ __launch_bounds__(256, 1) void conv_h2_kernel(ConvH2P p) {
     // values -- and everything downstream of the norm -- do not depend on the launch geometry
     __syncthreads();
     if (tid < 2 * H2_BM) {
-      const int cl = tid & (H2_BM - 1), which = tid >> 6;
+      const int cl = tid & (H2_BM - 1), which = (tid >> 6) & 1;
       if (m0 + cl < p.cout) {
-        const int ntile = p.tiles_x * p.tiles_y * (NT / 2);
+        constexpr int NE = NW * NT / 8;  // 8-row statistics tiles per workgroup tile
+        const int ntile = p.tiles_x * p.tiles_y * NE;
 #pragma unroll
-        for (int e = 0; e < NT / 2; ++e) {
+        for (int e = 0; e < NE; ++e) {
           double t = 0.0;
 #pragma unroll
           for (int j = 0; j < 4; ++j) t += (double)red[((4 * e + j) * 2 + which) * H2_BM + cl];
-          const int tile8 = (ty * (NT / 2) + e) * p.tiles_x + tx;
+          const int tile8 = (ty * NE + e) * p.tiles_x + tx;
+#ifndef DSG_H2_TIMING
           p.stats[(((size_t)n * p.cout + m0 + cl) * ntile + tile8) * 2 + which] = t;
+#endif
         }
       }
     }
   }
+#ifdef DSG_H2_TIMING
+  if (p.stats && tid == 0) p.stats[8 + 4 * (size_t)(gridDim.x * gridDim.y) + (blockIdx.x + gridDim.x * blockIdx.y)] =
+      (double)__builtin_amdgcn_s_memrealtime();
+#endif
 }
 
 // OIHW fp32 -> [cin/16][piece 2][tap k*k][g 2][cout_pad][8] fp16 (hi, scaled lo); zero-padded couts.
@@ -422,15 +524,17 @@ __global__ void weight_relayout_h2_kernel(const float* __restrict__ w, _Float16*
 }
 
 static int g_h2_enabled = 1;
+static int g_h2_waves = 4;  // 16-row tiles: 4 waves x 4 rows or 8 waves x 2 rows (tuning key 6)
 static int g_h2_stats = 1;  // epilogue GroupNorm statistics (tuning key 5: A/B against the separate pass)
-static int g_h2_exp = 0;  // experiment variants (tools/ only)
 static int g_h2_rows = 0;  // rows per wave: 0 = by grid size, 2 | 4 forced (tuning key 3)
 
 bool conv_h2_eligible(const dsg_conv_args* a, int hout, int wout) {
   const int cin = a->c0 + a->c1;
+  if (cin > 1024) return false;  // the GroupNorm scale/shift table shares LDS with the K-chunk buffers
   if (a->ksize == 1)  // pointwise: the map is re-tiled as (h*w/32) rows of 32 pixels, so only h*w matters
     return g_h2_enabled && a->weight_h2 != nullptr && a->stride == 1 && !a->upsample && !a->pool2 && !a->temb &&
            cin % 16 == 0 && (a->c1 == 0 || a->c0 % 16 == 0) && (hout * wout) % (8 * H2_TW) == 0 && a->cout % 8 == 0;
+  if (a->gn_scale_shift && (!a->silu || a->upsample)) return false;  // combinations the U-Net does not have
   return g_h2_enabled && a->weight_h2 != nullptr && a->stride == 1 && a->upsample <= 1 && !a->pool2 &&
          cin % 16 == 0 && (a->c1 == 0 || a->c0 % 16 == 0) && (wout % H2_TW == 0) && (hout % 8 == 0) &&
          a->cout % 8 == 0;
@@ -473,7 +577,8 @@ int conv_h2_launch(const dsg_conv_args* a, int hout, int wout, hipStream_t st) {
   p.tiles_x = wout / H2_TW; p.tiles_y = hout / th;
   const bool k1 = a->ksize == 1;
   const size_t lds = 2 * (size_t)(k1 ? (nt4 ? H2Geom<4, 1>::BUF_BYTES : H2Geom<2, 1>::BUF_BYTES)
-                                     : (nt4 ? H2Geom<4, 3>::BUF_BYTES : H2Geom<2, 3>::BUF_BYTES));
+                                     : (nt4 ? H2Geom<4, 3>::BUF_BYTES : H2Geom<2, 3>::BUF_BYTES)) +
+                     (a->gn_scale_shift ? (size_t)p.cin * 2 * sizeof(float) : 0);  // + the scale/shift table
   dim3 grid(p.tiles_x * p.tiles_y * p.n, p.cout_pad / H2_BM);
   int pi = -1;
   if (prof_on()) {
@@ -485,28 +590,37 @@ int conv_h2_launch(const dsg_conv_args* a, int hout, int wout, hipStream_t st) {
   }
   static bool raised = false;
   if (!raised) {
-    const void* ks[9] = {reinterpret_cast<const void*>(conv_h2_kernel<0, 4, 3, 1>),
-                         reinterpret_cast<const void*>(conv_h2_kernel<0, 4, 3, 2>),
-                         reinterpret_cast<const void*>(conv_h2_kernel<0, 4, 3, 3>),
-                         reinterpret_cast<const void*>(conv_h2_kernel<0, 2, 3>), reinterpret_cast<const void*>(conv_h2_kernel<1, 2, 3>),
-                         reinterpret_cast<const void*>(conv_h2_kernel<0, 4, 3>), reinterpret_cast<const void*>(conv_h2_kernel<1, 4, 3>),
-                         reinterpret_cast<const void*>(conv_h2_kernel<0, 2, 1>), reinterpret_cast<const void*>(conv_h2_kernel<0, 4, 1>)};
-    for (const void* k : ks) DSG_HIP(hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    const void* ks[20] = {
+        reinterpret_cast<const void*>(conv_h2_kernel<0, 2, 3, 0, 8>), reinterpret_cast<const void*>(conv_h2_kernel<0, 2, 3, 2, 8>),
+        reinterpret_cast<const void*>(conv_h2_kernel<1, 2, 3, 0, 8>), reinterpret_cast<const void*>(conv_h2_kernel<0, 2, 1, 0, 8>),
+        reinterpret_cast<const void*>(conv_h2_kernel<0, 2, 1, 3, 8>),
+        reinterpret_cast<const void*>(conv_h2_kernel<0, 2, 3, 0>), reinterpret_cast<const void*>(conv_h2_kernel<0, 4, 3, 0>),
+        reinterpret_cast<const void*>(conv_h2_kernel<0, 2, 3, 2>), reinterpret_cast<const void*>(conv_h2_kernel<0, 4, 3, 2>),
+        reinterpret_cast<const void*>(conv_h2_kernel<1, 2, 3, 0>), reinterpret_cast<const void*>(conv_h2_kernel<1, 4, 3, 0>),
+        reinterpret_cast<const void*>(conv_h2_kernel<0, 2, 1, 0>), reinterpret_cast<const void*>(conv_h2_kernel<0, 4, 1, 0>),
+        reinterpret_cast<const void*>(conv_h2_kernel<0, 2, 1, 3>), reinterpret_cast<const void*>(conv_h2_kernel<0, 4, 1, 3>)};
+    for (const void* k : ks)
+      if (k) DSG_HIP(hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     raised = true;
   }
+  const int act = a->gn_scale_shift ? (a->silu ? 2 : 3) : 0;
+#define DSG_H2_LAUNCH(GM, KS, ACT)                                                                  \
+  do {                                                                                              \
+    if (nt4 && g_h2_waves == 8)                                                                     \
+      hipLaunchKernelGGL((conv_h2_kernel<GM, 2, KS, ACT, 8>), grid, dim3(512), lds, st, p);         \
+    else if (nt4) hipLaunchKernelGGL((conv_h2_kernel<GM, 4, KS, ACT>), grid, dim3(256), lds, st, p); \
+    else hipLaunchKernelGGL((conv_h2_kernel<GM, 2, KS, ACT>), grid, dim3(256), lds, st, p);         \
+  } while (0)
   if (k1) {
-    if (nt4) hipLaunchKernelGGL((conv_h2_kernel<0, 4, 1>), grid, dim3(256), lds, st, p);
-    else hipLaunchKernelGGL((conv_h2_kernel<0, 2, 1>), grid, dim3(256), lds, st, p);
+    if (act == 0) DSG_H2_LAUNCH(0, 1, 0);
+    else DSG_H2_LAUNCH(0, 1, 3);
   } else if (a->upsample) {
-    if (nt4) hipLaunchKernelGGL((conv_h2_kernel<1, 4, 3>), grid, dim3(256), lds, st, p);
-    else hipLaunchKernelGGL((conv_h2_kernel<1, 2, 3>), grid, dim3(256), lds, st, p);
+    DSG_H2_LAUNCH(1, 3, 0);
   } else {
-    if (nt4 && g_h2_exp == 1) hipLaunchKernelGGL((conv_h2_kernel<0, 4, 3, 1>), grid, dim3(256), lds, st, p);
-    else if (nt4 && g_h2_exp == 2) hipLaunchKernelGGL((conv_h2_kernel<0, 4, 3, 2>), grid, dim3(256), lds, st, p);
-    else if (nt4 && g_h2_exp == 3) hipLaunchKernelGGL((conv_h2_kernel<0, 4, 3, 3>), grid, dim3(256), lds, st, p);
-    else if (nt4) hipLaunchKernelGGL((conv_h2_kernel<0, 4, 3>), grid, dim3(256), lds, st, p);
-    else hipLaunchKernelGGL((conv_h2_kernel<0, 2, 3>), grid, dim3(256), lds, st, p);
+    if (act == 0) DSG_H2_LAUNCH(0, 3, 0);
+    else DSG_H2_LAUNCH(0, 3, 2);
   }
+#undef DSG_H2_LAUNCH
   prof_end(pi, st);
   DSG_LAUNCH_CHECK();
   return DSG_OK;
@@ -514,8 +628,8 @@ int conv_h2_launch(const dsg_conv_args* a, int hout, int wout, hipStream_t st) {
 
 void conv_h2_set_enabled(int on) { g_h2_enabled = on; }
 void conv_h2_set_rows(int r) { g_h2_rows = r; }
-void conv_h2_set_exp(int e) { g_h2_exp = e; }
 void conv_h2_set_stats(int on) { g_h2_stats = on; }
+void conv_h2_set_waves(int w) { g_h2_waves = w; }
 
 }  // namespace dsg
 

@@ -79,7 +79,7 @@ def relayout_conv_weight_dgrad(w_oihw: torch.Tensor, out: torch.Tensor = None) -
 
 def conv2d_fused(src0, weight_r, bias=None, src1=None, ksize=3, stride=1, upsample=False, gn_scale_shift=None,
                  silu=False, temb=None, temb_stride=0, residual=None, out=None, direct=False, cout=None,
-                 pool2=False, wstride=None, weight_h2=None, want_stats=False):
+                 pool2=False, wstride=None, weight_h2=None, want_stats=False, stats_buf=None):
     """dsg_conv2d_fwd: see include/dsg.h.  `weight_r` is in engine layout; `temb` is a [N, temb_stride] view
     whose first `cout` columns (from its data pointer) are added per (n, cout).
     want_stats: also return the per-tile GroupNorm statistics [N][cout][tiles][2] (fp64) of the result, or None
@@ -115,7 +115,8 @@ def conv2d_fused(src0, weight_r, bias=None, src1=None, ksize=3, stride=1, upsamp
         tiles = C.c_int32(0)
         _lib.check(lib.dsg_conv2d_stats_tiles(C.byref(a), C.byref(tiles)))
         if tiles.value > 0:
-            stats = torch.empty((n, cout, tiles.value, 2), dtype=torch.float64, device=src0.device)
+            stats = stats_buf if stats_buf is not None else torch.empty(
+                (n, cout, tiles.value, 2), dtype=torch.float64, device=src0.device)
             a.stats_out = stats.data_ptr()
     fn = lib.dsg_conv2d_fwd_direct if direct else lib.dsg_conv2d_fwd
     with torch.cuda.device(src0.device):

@@ -16,9 +16,9 @@ if os.environ.get("DSG_ROWS"):
 if os.environ.get("DSG_KC"):
     _lib.check(_lib.load().dsg_set_tuning(1, int(os.environ["DSG_KC"])))
     print("kc", os.environ["DSG_KC"])
-if os.environ.get("DSG_EXP"):
-    _lib.check(_lib.load().dsg_set_tuning(4, int(os.environ["DSG_EXP"])))
-    print("h2 experiment", os.environ["DSG_EXP"])
+if os.environ.get("DSG_WAVES"):
+    _lib.check(_lib.load().dsg_set_tuning(6, int(os.environ["DSG_WAVES"])))
+    print("h2 waves", os.environ["DSG_WAVES"])
 iters = int(sys.argv[1]) if len(sys.argv) > 1 else 20
 dev = "cuda"
 # name, c0, c1, cout, h, k, stride, ups, gn, res
