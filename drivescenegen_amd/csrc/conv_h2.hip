@@ -208,6 +208,41 @@ __global__ __launch_bounds__(64 * NW, 1) void conv_h2_kernel(ConvH2P p) {
     *reinterpret_cast<half8*>(xb + xoff[i]) = h1;
     *reinterpret_cast<half8*>(xb + xoff2[i]) = h2;
   };
+  // The same work in quarter-unit steps, so that a K-chunk's staging can be dealt out evenly over its taps: step P
+  // turns two channels (2jp, 2jp+1) of unit P/4 into fp16 pairs -- the unit's LDS write rides on its last step --
+  // and refills the two registers with chunk q+2's values.
+  half8 h1s[H2_NU], h2s[H2_NU];
+  auto stage_step = [&](int P, int qs, unsigned char* buf, bool stage, bool load, const float* spn) {
+    const int i = P / 4, jp = P % 4;
+    if (stage) {
+      float4 s4 = make_float4(1.f, 0.f, 1.f, 0.f);
+      if (has_ss) s4 = *reinterpret_cast<const float4*>(ssl + 2 * (qs * H2_KC + unit_g(i) * 8 + 2 * jp));
+#pragma unroll
+      for (int e = 0; e < 2; ++e) {
+        const int j = 2 * jp + e;
+        float v = xr[i][j];
+        if (has_ss) v = e ? v * s4.z + s4.w : v * s4.x + s4.y;
+        const float sv = silu_fast_h(v);
+        v = do_silu ? sv : v;
+        const _Float16 a = (_Float16)v;
+        h1s[i][j] = a;
+        h2s[i][j] = (_Float16)((v - (float)a) * 2048.0f);
+      }
+      if (jp == 3) {
+        _Float16* xb = reinterpret_cast<_Float16*>(buf);
+        *reinterpret_cast<half8*>(xb + xoff[i]) = h1s[i];
+        *reinterpret_cast<half8*>(xb + xoff2[i]) = h2s[i];
+      }
+    }
+    if (load) {
+      const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
+          const_cast<float*>(spn + (size_t)(unit_g(i) * 8) * plane), 0, 8 * plane * 4, 0x00020000);
+#pragma unroll
+      for (int e = 0; e < 2; ++e)
+        xr[i][2 * jp + e] =
+            __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, goff[i] * 4, soff[2 * jp + e], 0));
+    }
+  };
   // weight slab of chunk q: 36 segments (piece, tap, g) of 64 couts x 16 B, moved global -> LDS by DMA;
   // wave w moves segments w, w+4, ...
   auto dma_weights = [&](int k, int q, unsigned char* buf) {
@@ -322,17 +357,15 @@ __global__ __launch_bounds__(64 * NW, 1) void conv_h2_kernel(ConvH2P p) {
         }
         if (STAGE) dma_weights(0, q + 1, nxt);  // (KS = 1: NSEG = 4 <= NW)
       }
-      // KS = 3: unit u (commit of chunk q+1, then the load of chunk q+2 into the freed registers) and its share
-      // of the weight DMAs ride on tap u, so that everything has the rest of the chunk to land before the
-      // vmcnt(0) of the closing barrier.  The DMAs go AFTER the tap's commit: with a DMA in flight hipcc waits
-      // vmcnt(0) at every use of an ordinary load result.
-      if (KS == 3 && tap < H2_NU) {
-        if (STAGE) commit_unit(tap, q + 1, nxt);
-        if (LOAD) load_unit(tap, q + 2, spn);
-        if (STAGE) {
-          constexpr int PER = (G::NDMA + H2_NU - 1) / H2_NU;
+      // KS = 3: the chunk's staging steps and weight DMAs are dealt out evenly over taps 0..TAPS-2 (the last tap
+      // stays clear so that the newest loads have a tap's worth of MFMAs to land before the closing vmcnt(0))
+      if (KS == 3 && tap < TAPS - 1) {
+        constexpr int NSTEP = 4 * H2_NU, ST = TAPS - 1;
 #pragma unroll
-          for (int k = tap * PER; k < (tap + 1) * PER && k < G::NDMA; ++k) dma_weights(k, q + 1, nxt);
+        for (int P = tap * NSTEP / ST; P < (tap + 1) * NSTEP / ST; ++P) stage_step(P, q + 1, nxt, STAGE, LOAD, spn);
+        if (STAGE) {
+#pragma unroll
+          for (int k = tap * G::NDMA / ST; k < (tap + 1) * G::NDMA / ST; ++k) dma_weights(k, q + 1, nxt);
         }
       }
       const int par = tap & 1;
@@ -347,11 +380,11 @@ __global__ __launch_bounds__(64 * NW, 1) void conv_h2_kernel(ConvH2P p) {
       // Issue order within the tap: with one wave per SIMD nothing else fills the matrix pipe while this wave
       // issues staging work, so spread that work between the MFMAs (at most ~5 issues hide behind one MFMA)
       // instead of leaving it in one block as the scheduler would.
-      if (KS == 3 && tap < H2_NU && (STAGE || LOAD)) {
+      if (KS == 3 && tap < TAPS - 1 && (STAGE || LOAD)) {
 #pragma unroll
         for (int m = 0; m < 6 * NT; ++m) {
           __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);  // 1 MFMA
-          __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);  // 4 VALU
+          __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);  // 2 VALU
         }
       }
 #ifdef DSG_H2_TIMING
