@@ -113,6 +113,9 @@ __global__ __launch_bounds__(64 * NW, 1) void conv_h2_kernel(ConvH2P p) {
   constexpr int H2_TH = G::TH, H2_PSZ = G::PSZ, H2_XHALFS = G::XHALFS, H2_BUF_BYTES = G::BUF_BYTES, H2_NU = G::NU;
   constexpr int FULL = G::FULL, TAPS = G::TAPS, H2_PW = G::PW, H2_WHALFS = G::WHALFS, PADK = KS / 2;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+#ifdef DSG_H2_TIMING
+  const unsigned long long rt_entry = __builtin_amdgcn_s_memrealtime();
+#endif
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -418,65 +421,67 @@ __global__ __launch_bounds__(64 * NW, 1) void conv_h2_kernel(ConvH2P p) {
   if (q + 1 < nq) chunk(q++, T{}, F{});  // last staged chunk: nothing left to load
   chunk(q, F{}, F{});                    // last chunk: MFMAs only
 #ifdef DSG_H2_TIMING
-  if (p.stats && lane == 0) {
-    atomicAdd(&p.stats[0], (double)(__builtin_readcyclecounter() - t_begin));
-    atomicAdd(&p.stats[1], (double)t_vm);
-    atomicAdd(&p.stats[2], (double)t_bar);
-    atomicAdd(&p.stats[3], 1.0);
-    for (int t = 0; t < TAPS; ++t) atomicAdd(&p.stats[8 + 5 * (size_t)(gridDim.x * gridDim.y) + t], (double)t_tap[t]);
-    if (wave == 0) {  // per-block record: start / loop begin / loop end (10-ns ticks), loop cycles
-      double* rec = p.stats + 8 + 4 * (size_t)(blockIdx.x + gridDim.x * blockIdx.y);
-      rec[0] = (double)rt_start;
-      rec[1] = (double)rt_loop;
-      rec[2] = (double)__builtin_amdgcn_s_memrealtime();
-      rec[3] = (double)(__builtin_readcyclecounter() - t_begin);
-    }
-  }
+  const unsigned long long rt_loop_end = __builtin_amdgcn_s_memrealtime();
+  const unsigned long long t_loop_cycles = __builtin_readcyclecounter() - t_begin;
 #endif
 
-  // Epilogue.  Everything but the lane's (half, column) offset is wave-uniform, so row bases, bias and
-  // time-embedding values come through SGPRs; all residual loads are issued before the first use (with one
-  // wave per SIMD a load->add->store chain per element would expose the memory latency 64 times).
+  // Epilogue.  All global accesses are buffer operations on descriptors that start at this tile's first output
+  // channel: the per-lane offset (row, column, +4 channels for the upper half-wave) is one VGPR computed once, the
+  // (channel, row) part of each access is a scalar offset, and channels past cout fall outside the descriptor's
+  // range -- loads return 0, stores are dropped -- so there is neither address arithmetic nor a bounds branch per
+  // element.  The residual values of a 32-channel slab are all in flight before the first use (with one wave per
+  // SIMD a load->add->store chain per element would expose the memory latency 64 times).
   // (the host only dispatches here when cout % 8 == 0, so a 4-row half-group is never split by cout)
-  const bool has_t = p.temb != nullptr;
   const bool has_r = p.res != nullptr;
   const int oplane = p.hout * p.wout;
-  const int lane_off = 4 * half * oplane + l31;
   const bool want_stats = p.stats != nullptr;
   float* red = reinterpret_cast<float*>(smem_raw);  // [wave][sum | sumsq][cout 64] (the K loop is done with LDS)
+  const int nvalid = min(H2_BM, p.cout - m0);        // output channels of this tile that exist
+  const size_t tile_off = ((size_t)n * p.cout + m0) * oplane;
+  const int range = nvalid * oplane * 4;
+  const __amdgpu_buffer_rsrc_t dst_rs = __builtin_amdgcn_make_buffer_rsrc(p.dst + tile_off, 0, range, 0x00020000);
+  const __amdgpu_buffer_rsrc_t res_rs =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(has_r ? p.res + tile_off : p.dst), 0, has_r ? range : 0, 0x00020000);
+  const __amdgpu_buffer_rsrc_t bias_rs = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float*>(p.bias ? p.bias + m0 : p.dst), 0, p.bias ? nvalid * 4 : 0, 0x00020000);
+  const __amdgpu_buffer_rsrc_t temb_rs = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float*>(p.temb ? p.temb + (size_t)n * p.temb_stride + m0 : p.dst), 0, p.temb ? nvalid * 4 : 0, 0x00020000);
+  const int voff = (4 * half * oplane + (oy0 + wave * NT) * p.wout + ox0 + l31) * 4;  // bytes, per lane
+  const int oplane4 = __builtin_amdgcn_readfirstlane(oplane * 4), w4 = __builtin_amdgcn_readfirstlane(p.wout * 4);
+  auto epilogue = [&](auto stats_tag) {
+    constexpr bool STATS = decltype(stats_tag)::value;
 #pragma unroll
-  for (int mt = 0; mt < 2; ++mt) {
-    float rv[16][NT];  // residual values of this 32-cout slab, all in flight before the first use
+    for (int mt = 0; mt < 2; ++mt) {
+      float rv[16][NT], addv[16];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int cou = min(m0 + mt * 32 + (r & 3) + 8 * (r >> 2), p.cout - 8 + (r & 3));  // uniform, in range
-#pragma unroll
-      for (int nt = 0; nt < NT; ++nt) {
-        const float* row = p.res + (((size_t)n * p.cout + cou) * p.hout + oy0 + wave * NT + nt) * p.wout + ox0;
-        rv[r][nt] = has_r ? row[lane_off] : 0.f;
+      for (int r = 0; r < 16; ++r) {
+        const int crel = mt * 32 + (r & 3) + 8 * (r >> 2);  // this lane's channel is crel + 4*half
+        addv[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(bias_rs, 16 * half, crel * 4, 0)) +
+                  __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(temb_rs, 16 * half, crel * 4, 0));
       }
-    }
+      if (has_r) {
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int cou = m0 + mt * 32 + (r & 3) + 8 * (r >> 2);  // uniform; this lane's cout is cou + 4*half
-      if (cou < p.cout) {
-        float add0 = 0.f, add1 = 0.f;
-        if (p.bias) {
-          add0 = p.bias[cou];
-          add1 = p.bias[cou + 4];
-        }
-        if (has_t) {
-          add0 += p.temb[(size_t)n * p.temb_stride + cou];
-          add1 += p.temb[(size_t)n * p.temb_stride + cou + 4];
-        }
-        const float add = half ? add1 : add0;
+        for (int r = 0; r < 16; ++r)
+#pragma unroll
+          for (int nt = 0; nt < NT; ++nt) {
+            const int crel = mt * 32 + (r & 3) + 8 * (r >> 2);
+            rv[r][nt] = __builtin_bit_cast(
+                float, __builtin_amdgcn_raw_buffer_load_b32(res_rs, voff, crel * oplane4 + nt * w4, 0));
+          }
+      } else {
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+#pragma unroll
+          for (int nt = 0; nt < NT; ++nt) rv[r][nt] = 0.f;
+      }
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int crel = mt * 32 + (r & 3) + 8 * (r >> 2);
         float s1[NT / 2], s2[NT / 2];
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) {
-          float* row = p.dst + (((size_t)n * p.cout + cou) * p.hout + oy0 + wave * NT + nt) * p.wout + ox0;
-          float v = (acc_hi[mt][nt][r] + acc_lo[mt][nt][r] * (1.0f / 2048.0f)) + add;
-          if (has_r) v = v + rv[r][nt];
-          row[lane_off] = v;
+          const float v = ((acc_hi[mt][nt][r] + acc_lo[mt][nt][r] * (1.0f / 2048.0f)) + addv[r]) + rv[r][nt];
+          __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, v), dst_rs, voff, crel * oplane4 + nt * w4, 0);
           if (nt & 1) {
             s1[nt / 2] += v;
             s2[nt / 2] += v * v;
@@ -485,8 +490,8 @@ __global__ __launch_bounds__(64 * NW, 1) void conv_h2_kernel(ConvH2P p) {
             s2[nt / 2] = v * v;
           }
         }
-        if (want_stats) {  // GroupNorm statistics of the tensor just produced (the next layer's norm reads them)
-          const int cl = mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+        if (STATS) {  // GroupNorm statistics of the tensor just produced (the next layer's norm reads them)
+          const int cl = crel + 4 * half;
 #pragma unroll
           for (int pr = 0; pr < NT / 2; ++pr) {  // one partial per pair of rows: the same summation tree for any NT
             const float t1 = half_wave_sum(s1[pr]), t2 = half_wave_sum(s2[pr]);
@@ -498,7 +503,9 @@ __global__ __launch_bounds__(64 * NW, 1) void conv_h2_kernel(ConvH2P p) {
         }
       }
     }
-  }
+  };
+  if (want_stats) epilogue(T{});
+  else epilogue(F{});
   if (want_stats) {
     // statistics tiles are 8 rows x 32 columns (4 row pairs, summed in row order in fp64) whatever NT is, so the
     // values -- and everything downstream of the norm -- do not depend on the launch geometry
@@ -524,6 +531,22 @@ __global__ __launch_bounds__(64 * NW, 1) void conv_h2_kernel(ConvH2P p) {
 #ifdef DSG_H2_TIMING
   if (p.stats && tid == 0) p.stats[8 + 4 * (size_t)(gridDim.x * gridDim.y) + (blockIdx.x + gridDim.x * blockIdx.y)] =
       (double)__builtin_amdgcn_s_memrealtime();
+#endif
+#ifdef DSG_H2_TIMING
+  if (p.stats && lane == 0) {
+    atomicAdd(&p.stats[0], (double)t_loop_cycles);
+    atomicAdd(&p.stats[1], (double)t_vm);
+    atomicAdd(&p.stats[2], (double)t_bar);
+    atomicAdd(&p.stats[3], 1.0);
+    for (int t = 0; t < TAPS; ++t) atomicAdd(&p.stats[8 + 5 * (size_t)(gridDim.x * gridDim.y) + t], (double)t_tap[t]);
+    if (wave == 0) {  // per-block record: start / loop begin / loop end (10-ns ticks), loop cycles
+      double* rec = p.stats + 8 + 4 * (size_t)(blockIdx.x + gridDim.x * blockIdx.y);
+      rec[0] = (double)rt_entry;
+      rec[1] = (double)rt_loop;
+      rec[2] = (double)rt_loop_end;
+      rec[3] = (double)t_loop_cycles;
+    }
+  }
 #endif
 }
 

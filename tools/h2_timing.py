@@ -27,6 +27,7 @@ for name, c, h in (("res512@32", 512, 32), ("res256@64", 256, 64), ("res128@128"
     print(f"   blocks {nb}: start {us(rec[:,0]).min():.1f}..{us(rec[:,0]).max():.1f} us  loop-begin {us(rec[:,1]).min():.1f}..{us(rec[:,1]).max():.1f}"
           f"  loop-end {us(rec[:,2]).min():.1f}..{us(rec[:,2]).max():.1f}  block-end {us(end).min():.1f}..{us(end).max():.1f}"
           f"  loop cycles min/mean/max {rec[:,3].min():.0f}/{rec[:,3].mean():.0f}/{rec[:,3].max():.0f}"
+          f"  PHASES us: prologue {(rec[:,1]-rec[:,0]).mean()/100:.2f} loop {(rec[:,2]-rec[:,1]).mean()/100:.2f} epilogue {(end-rec[:,2]).mean()/100:.2f}"
           f"  loop us mean {(rec[:,2]-rec[:,1]).mean()/100:.1f} -> {rec[:,3].mean()/((rec[:,2]-rec[:,1]).mean()/100)/1e3:.2f} GHz")
     taps = st.flatten()[8 + 5 * nb:8 + 5 * nb + 9].cpu().numpy() / nw / (c // 16)
     print("   cycles per tap:", " ".join(f"{t:.0f}" for t in taps), " sum", f"{taps.sum():.0f}")
