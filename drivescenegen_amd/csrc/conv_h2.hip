@@ -123,12 +123,24 @@ __global__ __launch_bounds__(64 * NW, 1) void conv_h2_kernel(ConvH2P p) {
   const int half = lane >> 5;
   const int l31 = lane & 31;
 
-  int bid = blockIdx.x;
+  // Workgroup id -> (spatial tile, cout tile).  Consecutive ids go to the 8 XCDs in turn (each has its own L2), so
+  // a spatial tile stays on XCD (tile % 8) and its cout tiles get neighbouring ids on that XCD: the workgroups
+  // that read the same input patch run at the same time behind the same L2 and the patch comes from HBM once.
+  const int nct = p.cout_pad / H2_BM, nsp = p.tiles_x * p.tiles_y * p.n;
+  int bid, ct;
+  if ((nsp & 7) == 0) {
+    const int grp = blockIdx.x >> 3;
+    ct = grp % nct;
+    bid = (grp / nct) * 8 + (blockIdx.x & 7);
+  } else {
+    ct = blockIdx.x % nct;
+    bid = blockIdx.x / nct;
+  }
   const int tx = bid % p.tiles_x;
   bid /= p.tiles_x;
   const int ty = bid % p.tiles_y;
   const int n = bid / p.tiles_y;
-  const int m0 = blockIdx.y * H2_BM;
+  const int m0 = ct * H2_BM;
   const int oy0 = ty * H2_TH, ox0 = tx * H2_TW;
   const int plane = p.hin * p.win;
   const int nq = p.cin / H2_KC;
@@ -167,8 +179,6 @@ __global__ __launch_bounds__(64 * NW, 1) void conv_h2_kernel(ConvH2P p) {
   // GroupNorm (scale, shift) of this image's channels: copied once into LDS behind the two K-chunk buffers; a commit
   // reads its 8 channels from there (uniform address: a broadcast read) instead of carrying them in registers
   float* ssl = reinterpret_cast<float*>(smem_raw + 2 * H2_BUF_BYTES);
-  if (has_ss)
-    for (int i = tid; i < 2 * p.cin; i += NTH) ssl[i] = ssg[i];
 
   auto src_of = [&](int q) -> const float* {  // uniform
     const int cb = q * H2_KC;
@@ -181,13 +191,14 @@ __global__ __launch_bounds__(64 * NW, 1) void conv_h2_kernel(ConvH2P p) {
   int soff[8];  // byte offsets of the 8 channel planes of a k-group: loop-invariant SGPRs
 #pragma unroll
   for (int j = 0; j < 8; ++j) soff[j] = __builtin_amdgcn_readfirstlane(j * plane * 4);
-  auto load_unit = [&](int i, int q, const float* sp) {
+  auto load_unit_to = [&](float (&dst)[H2_NU][8], int i, const float* sp) {
     const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<float*>(sp + (size_t)(unit_g(i) * 8) * plane), 0, 8 * plane * 4, 0x00020000);
 #pragma unroll
     for (int j = 0; j < 8; ++j)
-      xr[i][j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, goff[i] * 4, soff[j], 0));
+      dst[i][j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, goff[i] * 4, soff[j], 0));
   };
+  auto load_unit = [&](int i, int q, const float* sp) { load_unit_to(xr, i, sp); };
   auto commit_unit = [&](int i, int q, unsigned char* buf) {  // q: the chunk being staged
     half8 h1, h2;
     float4 sr[4];
@@ -291,20 +302,32 @@ __global__ __launch_bounds__(64 * NW, 1) void conv_h2_kernel(ConvH2P p) {
       *reinterpret_cast<half8*>(b1 + zoff[i] + 2 * H2_PSZ * 8) = z;
     }
   }
-  // prologue: chunk 0 -> buffer 0; chunk 1 -> registers
+  // prologue: chunk 0 -> buffer 0; chunk 1 -> registers.  Everything that goes to memory is issued first and
+  // together (both chunks' patches, the weight DMAs, the scale/shift table), so the tile pays one memory round
+  // trip before its first MFMA, not one per dependent step.
   {
+    float xr1[H2_NU][8];
     const float* sp = src_of(0);
 #pragma unroll
-    for (int i = 0; i < H2_NU; ++i) load_unit(i, 0, sp);
-#pragma unroll
-    for (int k = 0; k < G::NDMA; ++k) dma_weights(k, 0, buf0);
-    if (has_ss) __syncthreads();  // the scale/shift table is in LDS
-#pragma unroll
-    for (int i = 0; i < H2_NU; ++i) commit_unit(i, 0, buf0);
+    for (int i = 0; i < H2_NU; ++i) load_unit_to(xr, i, sp);
     if (nq > 1) {
       const float* sp1 = src_of(1);
 #pragma unroll
-      for (int i = 0; i < H2_NU; ++i) load_unit(i, 1, sp1);
+      for (int i = 0; i < H2_NU; ++i) load_unit_to(xr1, i, sp1);
+    }
+#pragma unroll
+    for (int k = 0; k < G::NDMA; ++k) dma_weights(k, 0, buf0);
+    if (has_ss) {
+      for (int i = tid; i < 2 * p.cin; i += NTH) ssl[i] = ssg[i];
+      __syncthreads();  // the scale/shift table is in LDS
+    }
+#pragma unroll
+    for (int i = 0; i < H2_NU; ++i) commit_unit(i, 0, buf0);
+    if (nq > 1) {
+#pragma unroll
+      for (int i = 0; i < H2_NU; ++i)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) xr[i][j] = xr1[i][j];
     }
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // chunk 0's weight DMAs
@@ -529,7 +552,7 @@ __global__ __launch_bounds__(64 * NW, 1) void conv_h2_kernel(ConvH2P p) {
     }
   }
 #ifdef DSG_H2_TIMING
-  if (p.stats && tid == 0) p.stats[8 + 4 * (size_t)(gridDim.x * gridDim.y) + (blockIdx.x + gridDim.x * blockIdx.y)] =
+  if (p.stats && tid == 0) p.stats[8 + 4 * (size_t)gridDim.x + blockIdx.x] =
       (double)__builtin_amdgcn_s_memrealtime();
 #endif
 #ifdef DSG_H2_TIMING
@@ -538,9 +561,9 @@ __global__ __launch_bounds__(64 * NW, 1) void conv_h2_kernel(ConvH2P p) {
     atomicAdd(&p.stats[1], (double)t_vm);
     atomicAdd(&p.stats[2], (double)t_bar);
     atomicAdd(&p.stats[3], 1.0);
-    for (int t = 0; t < TAPS; ++t) atomicAdd(&p.stats[8 + 5 * (size_t)(gridDim.x * gridDim.y) + t], (double)t_tap[t]);
+    for (int t = 0; t < TAPS; ++t) atomicAdd(&p.stats[8 + 5 * (size_t)gridDim.x + t], (double)t_tap[t]);
     if (wave == 0) {  // per-block record: start / loop begin / loop end (10-ns ticks), loop cycles
-      double* rec = p.stats + 8 + 4 * (size_t)(blockIdx.x + gridDim.x * blockIdx.y);
+      double* rec = p.stats + 8 + 4 * (size_t)blockIdx.x;
       rec[0] = (double)rt_entry;
       rec[1] = (double)rt_loop;
       rec[2] = (double)rt_loop_end;
@@ -635,7 +658,7 @@ int conv_h2_launch(const dsg_conv_args* a, int hout, int wout, hipStream_t st) {
   const size_t lds = 2 * (size_t)(k1 ? (nt4 ? H2Geom<4, 1>::BUF_BYTES : H2Geom<2, 1>::BUF_BYTES)
                                      : (nt4 ? H2Geom<4, 3>::BUF_BYTES : H2Geom<2, 3>::BUF_BYTES)) +
                      (a->gn_scale_shift ? (size_t)p.cin * 2 * sizeof(float) : 0);  // + the scale/shift table
-  dim3 grid(p.tiles_x * p.tiles_y * p.n, p.cout_pad / H2_BM);
+  dim3 grid(p.tiles_x * p.tiles_y * p.n * (p.cout_pad / H2_BM));
   int pi = -1;
   if (prof_on()) {
     const double px = (double)p.n * hout * wout;
