@@ -123,15 +123,17 @@ __global__ __launch_bounds__(64 * NW, 1) void conv_h2_kernel(ConvH2P p) {
   const int half = lane >> 5;
   const int l31 = lane & 31;
 
-  // Workgroup id -> (spatial tile, cout tile).  Consecutive ids go to the 8 XCDs in turn (each has its own L2), so
-  // a spatial tile stays on XCD (tile % 8) and its cout tiles get neighbouring ids on that XCD: the workgroups
-  // that read the same input patch run at the same time behind the same L2 and the patch comes from HBM once.
+  // Workgroup id -> (spatial tile, cout tile).  Consecutive ids go to the 8 XCDs in turn, each with its own L2.
+  // XCD k gets a CONTIGUOUS eighth of the spatial tiles, walked in raster order with the cout tiles of one patch
+  // on neighbouring ids: workgroups that share input -- the same patch for another cout tile, or the 128-byte
+  // lines and halo rows a patch has in common with its left/right/upper/lower neighbours -- run at the same time
+  // behind the same L2, so that data comes from HBM once instead of once per XCD.
   const int nct = p.cout_pad / H2_BM, nsp = p.tiles_x * p.tiles_y * p.n;
   int bid, ct;
   if ((nsp & 7) == 0) {
     const int grp = blockIdx.x >> 3;
     ct = grp % nct;
-    bid = (grp / nct) * 8 + (blockIdx.x & 7);
+    bid = (blockIdx.x & 7) * (nsp >> 3) + grp / nct;
   } else {
     ct = blockIdx.x % nct;
     bid = blockIdx.x / nct;
@@ -469,8 +471,10 @@ __global__ __launch_bounds__(64 * NW, 1) void conv_h2_kernel(ConvH2P p) {
       const_cast<float*>(p.bias ? p.bias + m0 : p.dst), 0, p.bias ? nvalid * 4 : 0, 0x00020000);
   const __amdgpu_buffer_rsrc_t temb_rs = __builtin_amdgcn_make_buffer_rsrc(
       const_cast<float*>(p.temb ? p.temb + (size_t)n * p.temb_stride + m0 : p.dst), 0, p.temb ? nvalid * 4 : 0, 0x00020000);
-  const int voff = (4 * half * oplane + (oy0 + wave * NT) * p.wout + ox0 + l31) * 4;  // bytes, per lane
-  const int oplane4 = __builtin_amdgcn_readfirstlane(oplane * 4), w4 = __builtin_amdgcn_readfirstlane(p.wout * 4);
+  int voff[NT];  // bytes, per lane and row; the channel part of an address is the scalar offset
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) voff[nt] = (4 * half * oplane + (oy0 + wave * NT + nt) * p.wout + ox0 + l31) * 4;
+  const int oplane4 = __builtin_amdgcn_readfirstlane(oplane * 4);
   auto epilogue = [&](auto stats_tag) {
     constexpr bool STATS = decltype(stats_tag)::value;
 #pragma unroll
@@ -489,7 +493,7 @@ __global__ __launch_bounds__(64 * NW, 1) void conv_h2_kernel(ConvH2P p) {
           for (int nt = 0; nt < NT; ++nt) {
             const int crel = mt * 32 + (r & 3) + 8 * (r >> 2);
             rv[r][nt] = __builtin_bit_cast(
-                float, __builtin_amdgcn_raw_buffer_load_b32(res_rs, voff, crel * oplane4 + nt * w4, 0));
+                float, __builtin_amdgcn_raw_buffer_load_b32(res_rs, voff[nt], crel * oplane4, 0));
           }
       } else {
 #pragma unroll
@@ -504,7 +508,7 @@ __global__ __launch_bounds__(64 * NW, 1) void conv_h2_kernel(ConvH2P p) {
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) {
           const float v = ((acc_hi[mt][nt][r] + acc_lo[mt][nt][r] * (1.0f / 2048.0f)) + addv[r]) + rv[r][nt];
-          __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, v), dst_rs, voff, crel * oplane4 + nt * w4, 0);
+          __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, v), dst_rs, voff[nt], crel * oplane4, 0);
           if (nt & 1) {
             s1[nt / 2] += v;
             s2[nt / 2] += v * v;

@@ -51,8 +51,8 @@ for name, c0, c1, cout, h, k, s, ups, gn, res in SHAPES:
     r = torch.randn(B, cout, ho, ho, device=dev) if res else None
     out = torch.empty(B, cout, ho, ho, device=dev)
     wh = None
-    if os.environ.get("H2") == "1" and k == 3 and s == 1:
-        wh = ops.relayout_conv_weight_h2(torch.randn(cout, cin, 3, 3, device=dev) * 0.05)
+    if os.environ.get("H2") == "1" and s == 1 and cout % 64 == 0:
+        wh = ops.relayout_conv_weight_h2(torch.randn(cout, cin, k, k, device=dev) * 0.05)
     f = lambda: ops.conv2d_fused(x0, w, bias, src1=x1, ksize=k, stride=s, upsample=ups, gn_scale_shift=ss, silu=gn,
                                  residual=r, out=out, weight_h2=wh)
     for _ in range(3):
