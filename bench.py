@@ -133,6 +133,25 @@ def cpu_leg(args):
                        f"torch-CPU fp32 oracle, {cores} threads, {dt:.1f} s")
 
 
+def pmc_traffic(kernel):
+    """HBM bytes per launch of `kernel` from the committed PMC pass (tools/pmc_bench.sh -> profiles/*_pmc_traffic.json:
+    rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes over this same bench command line, FETCH_SIZE doubled as
+    the gfx950 guide prescribes).  bench.py cannot collect counters on itself; the newest committed file is quoted,
+    with its name, next to the live HIP-event numbers.  None when no such file travels with the repo."""
+    import glob
+    files = sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "*_pmc_traffic.json")))
+    if not files:
+        return dict(traffic=None)
+    try:
+        d = json.load(open(files[-1]))
+        k = d["kernels"][kernel]
+        return dict(traffic=k["hbm_bytes_per_launch"], traffic_unit="bytes/launch (HBM read + write, mean over launches)",
+                    traffic_read=k["fetch_bytes_per_launch"], traffic_write=k["write_bytes_per_launch"],
+                    traffic_source="profiles/" + os.path.basename(files[-1]))
+    except (KeyError, ValueError, OSError):
+        return dict(traffic=None)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -172,8 +191,8 @@ def main():
             # fp32-equivalent MAC -> the ceiling for ALGORITHMIC (fp32-equivalent) FLOPs is the dense f16 peak / 3
             dom = prof["conv3x3_s1_mfma_f16x2split"]
             peak = PEAK_F16_TFLOPS / 3.0
-            roofline = dict(bound="mfma", kernel="dsg::conv_h2_kernel<0>", achieved=dom["tflops"], peak=peak,
-                            unit="TFLOP/s", frac=dom["tflops"] / peak, traffic=None,
+            roofline = dict(bound="mfma", kernel="dsg::conv_h2_kernel<0, 4, 3, 2, 4>", achieved=dom["tflops"], peak=peak,
+                            unit="TFLOP/s", frac=dom["tflops"] / peak, **pmc_traffic("dsg::conv_h2_kernel<0, 4, 3, 2, 4>"),
                             peak_note="2500 TF/s dense f16 MFMA / 3 products per fp32-equivalent MAC (fp16x2 split); "
                                       "issued MFMA rate = 3 x achieved; the pure-fp32 MFMA peak is 157.3",
                             issued_mfma_tflops=3.0 * dom["tflops"],
@@ -195,8 +214,8 @@ def main():
             "unit": "image-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None,
-            "dtype": "f32 (3x3 convs: fp32-equivalent contraction as an fp16x2 split on the f16 MFMA, fp32 accumulate; "
-                     "everything else f32)" if "conv3x3_s1_mfma_f16x2split" in prof else "f32",
+            "dtype": "f32 (3x3 and 1x1 convs: fp32-equivalent contraction as an fp16x2 split on the f16 MFMA, fp32 "
+                     "accumulate; everything else f32)" if "conv3x3_s1_mfma_f16x2split" in prof else "f32",
             "data": "synthetic",
             "config": {"workload": "BASELINE configs[1]: 256x256x4 BEV raster, DriveSceneGen default U-Net "
                                    "(56,575,748 params), 50-step DDIM (eta=0), batch 16 per GPU, fp32",
