@@ -289,6 +289,16 @@ int dsg_mask_lut_u8(const uint8_t* img, int32_t n, int32_t hw, int32_t c, int32_
                     uint8_t on_value, uint8_t off_value, uint8_t* out, void* stream);
 
 /* ------------------------------------------------------------------------------------------
+ * Direct scene rasteriser: the reference's matplotlib drawing of lane way-points / segments
+ * (utils/datasets/rasterization.py:57-126) and agent rectangles (utils/datasets/visualization.py:283-296) as one
+ * pass over antialiased oriented boxes in pixel space, composited in list order.
+ *   boxes [nbox][9] = (cx, cy, ux, uy, hx, hy, r, g, b): centre, unit axis, half extents, colour
+ *   out   [3][h][w] fp32, initialised to the background colour
+ * ---------------------------------------------------------------------------------------- */
+int dsg_rasterize_boxes(const float* boxes, int32_t nbox, float* out, int32_t h, int32_t w, float bg0, float bg1,
+                        float bg2, void* stream);
+
+/* ------------------------------------------------------------------------------------------
  * Measurement plumbing (no reference counterpart): per-kernel-class HIP-event timing on the launch
  * stream, used by bench.py's roofline leg.  Classes: 0 conv3x3 stride-1, 1 conv3x3 on the nearest-x2
  * upsampled input, 2 conv3x3 stride-2, 3 conv1x1, 4 direct (VALU) conv, 5 conv weight-gradient, 6 / 7 / 8 conv3x3
