@@ -19,6 +19,7 @@
 // lane patterns of v_mfma_f32_32x32x2_f32 (A/B: 32 consecutive rows at a fixed k).
 #include "dsg_common.h"
 #include <algorithm>
+#include <type_traits>
 
 namespace dsg {
 
@@ -269,6 +270,279 @@ __global__ __launch_bounds__(256) void conv_wgrad_direct_kernel(WgradP p, int ks
   p.dw[i] += s;
 }
 
+
+// ---------------------------------------------------------------------------------------------------
+// The same weight gradient on the f16 matrix cores with fp32-class accuracy ("fp16x2 split", see conv_h2.hip):
+// both operands are activations here, so both are split on the way into LDS --
+//   A[ci][px] = act(gn(x)) = a1 + a2 * 2^-11,   dY[co][px] = b1 + b2 * 2^-11,
+//   dW += a1*b1 (acc_hi)  +  2^-11 * (a1*b2 + a2*b1) (acc_lo)        3 v_mfma_f32_32x32x16_f16 per 16 pixels
+// K is the pixel index: an MFMA's k-group of 8 is 8 consecutive pixels of a row, one 16-byte LDS read per lane.
+// A tap (dy, dx) reads the patch shifted by dx pixels, which would break that read's alignment, so the patch is kept
+// in LDS three times, pre-shifted by dx = 0, 1, 2 (each staging thread holds 10 consecutive pixels and writes the
+// three 8-pixel windows); dy only changes the row.
+// Workgroup: 32 ci x 64 co x 9 taps; wave w owns co tile (w & 1) and taps 0..4 (w < 2) or 5..8: 10 / 8 accumulator
+// tiles (hi + lo).  Stage = 2 output rows x 32 columns of one image (4 k-steps of 16 pixels); LDS is double-buffered
+// with one barrier per stage, the next tile's values are fetched a stage ahead and converted / written between the
+// MFMAs.  Row strides are padded by 16 bytes: the 16 lanes of a ds_read_b128 group fall on 16 different bank quads.
+// Split-K partials go to the same workspace layout as the fp32 kernel (one slab per grid.y), then wgrad_reduce_kernel.
+// ---------------------------------------------------------------------------------------------------
+typedef _Float16 whalf8 __attribute__((ext_vector_type(8)));
+typedef float wf32x16 __attribute__((ext_vector_type(16)));
+
+// A lives in a ring of 6 patch rows (4 in use by the current stage + the 2 being written for the next one): a
+// workgroup walks consecutive row pairs of one 32-column strip of one image, so every input row is converted once.
+constexpr int WH_SLOTS = 6;
+constexpr int WH_ASTR = WH_SLOTS * 32 + 8;          // halfs per (shift, piece, ci): 6 rows x 32 columns + pad
+constexpr int WH_A_HALFS = 3 * 2 * 32 * WH_ASTR;    // [shift 3][piece 2][ci 32]
+constexpr int WH_DSTR = 64 + 8;                     // halfs per (piece, co): 2 rows x 32 columns + pad
+constexpr int WH_D_HALFS = 2 * 64 * WH_DSTR;        // [piece 2][co 64], double-buffered
+constexpr int WH_LDS_BYTES = (WH_A_HALFS + 2 * WH_D_HALFS) * 2;
+
+// grid = (ci blocks x co blocks, strips x row splits); p.tiles_y = stages (row pairs) per image, p.ci_blocks as usual,
+// p.ntiles = row splits per strip (reused field), strips = n * tiles_x
+__global__ __launch_bounds__(256, 1) void conv_wgrad_h2_kernel(WgradP p) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char wsm[];
+  _Float16* ab = reinterpret_cast<_Float16*>(wsm);
+  _Float16* dbase = ab + WH_A_HALFS;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int half = lane >> 5;
+  const int l31 = lane & 31;
+  const int cot = wave & 1;
+  const bool first = wave < 2;  // taps 0..4; the other pair 5..8
+
+  const int cib = blockIdx.x % p.ci_blocks;
+  const int cob = blockIdx.x / p.ci_blocks;
+  const int ci0 = cib * 32, co0 = cob * WG_CO;
+  const int plane = p.hin * p.win;
+  const int oplane = p.hout * p.wout;
+  const bool has_ss = p.ss != nullptr;
+  const bool do_silu = has_ss && p.silu;
+
+  // this workgroup's run: strip (image n, column tile tx), stages [s0, s1)
+  const int nrs = p.ntiles;
+  const int strip = blockIdx.y / nrs, rs = blockIdx.y - strip * nrs;
+  const int n = strip / p.tiles_x, tx = strip - n * p.tiles_x;
+  const int ox0 = tx * 32;
+  const int per = (p.tiles_y + nrs - 1) / nrs;
+  const int s0 = rs * per, s1 = min(p.tiles_y, s0 + per);
+
+  // buffer descriptors (range-checked: reads before / past the tensor return 0, nothing faults) -- the ci block sits
+  // entirely in one of the two concatenated sources (c0 % 32 == 0)
+  const bool in0 = ci0 < p.c0;
+  const float* srcb = in0 ? p.src0 + ((size_t)n * p.c0 + ci0) * plane : p.src1 + ((size_t)n * p.c1 + (ci0 - p.c0)) * plane;
+  const float* src_all = in0 ? p.src0 : p.src1;
+  const size_t src_bytes = (size_t)p.n * (in0 ? p.c0 : p.c1) * plane * 4;
+  const int src_off = (int)((srcb - src_all) * 4);
+  const __amdgpu_buffer_rsrc_t a_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(src_all), 0, (int)src_bytes, 0x00020000);
+  const float* dyb = p.dy + ((size_t)n * p.dy_ctotal + p.dy_coff + co0) * oplane;
+  const __amdgpu_buffer_rsrc_t d_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(dyb), 0, WG_CO * oplane * 4, 0x00020000);
+  const __amdgpu_buffer_rsrc_t s_rs = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float*>(has_ss ? p.ss + ((size_t)n * p.cin + ci0) * 2 : p.dy), 0, has_ss ? 32 * 8 : 0, 0x00020000);
+
+  // staging items.  A: (ci, row of the pair, 8-column octet) -- one per thread; dY: (co, octet of the 2x32 stage) x 2
+  const int a_oct = tid & 3, a_rr = (tid >> 2) & 1, a_ci = tid >> 3;
+  const int a_voff = src_off + (a_ci * plane + a_rr * p.win + ox0 + a_oct * 8 - 1) * 4;  // + (2k-1)*win*4 per row pair
+  const unsigned a_colmask = 0x3FFu & ~((ox0 == 0 && a_oct == 0) ? 1u : 0u) & ~((ox0 + 32 == p.wc && a_oct == 3) ? 0x200u : 0u);
+  float sca = 1.f, sha = 0.f;
+  if (has_ss) {
+    const float2 s2 = __builtin_bit_cast(float2, __builtin_amdgcn_raw_buffer_load_b64(s_rs, a_ci * 8, 0, 0));
+    sca = s2.x;
+    sha = s2.y;
+  }
+  int d_voff[2], d_lds[2];
+#pragma unroll
+  for (int u = 0; u < 2; ++u) {
+    const int it = tid + 256 * u;
+    const int oct = it & 7, co = it >> 3;
+    d_voff[u] = (co * oplane + (oct >> 2) * p.wout + ox0 + (oct & 3) * 8) * 4;  // + 2s*wout*4 per stage
+    d_lds[u] = co * WH_DSTR + oct * 8;
+  }
+
+  float xa[10];
+  float4 xd[2][2];
+  unsigned va = 0;
+  auto load_rows = [&](int k) {  // input rows 2k-1, 2k of the strip
+    const int off = a_voff + (2 * k - 1) * p.win * 4;
+    // columns 0..7 of the octet as two aligned 16-byte loads, its left / right neighbours as single dwords (a
+    // 16-byte access that starts before the tensor would be dropped as a whole by the range check)
+    const float4 q0 = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(a_rs, off + 4, 0, 0));
+    const float4 q1 = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(a_rs, off + 20, 0, 0));
+    xa[0] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(a_rs, off, 0, 0));
+    xa[9] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(a_rs, off + 36, 0, 0));
+    xa[1] = q0.x; xa[2] = q0.y; xa[3] = q0.z; xa[4] = q0.w;
+    xa[5] = q1.x; xa[6] = q1.y; xa[7] = q1.z; xa[8] = q1.w;
+    va = ((unsigned)(2 * k - 1 + a_rr) < (unsigned)p.hc) ? a_colmask : 0u;
+  };
+  auto load_dy = [&](int s) {
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int off = d_voff[u] + 2 * s * p.wout * 4;
+      xd[u][0] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(d_rs, off, 0, 0));
+      xd[u][1] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(d_rs, off + 16, 0, 0));
+    }
+  };
+  auto split2 = [](float v0, float v1, unsigned& hi, unsigned& lo) {  // two values -> packed (hi, hi), (lo, lo)
+    const _Float16 a0 = (_Float16)v0, a1 = (_Float16)v1;
+    const _Float16 b0 = (_Float16)((v0 - (float)a0) * 2048.0f), b1 = (_Float16)((v1 - (float)a1) * 2048.0f);
+    hi = (unsigned)__builtin_bit_cast(unsigned short, a0) | ((unsigned)__builtin_bit_cast(unsigned short, a1) << 16);
+    lo = (unsigned)__builtin_bit_cast(unsigned short, b0) | ((unsigned)__builtin_bit_cast(unsigned short, b1) << 16);
+  };
+  auto commit_rows = [&](int k) {  // the values of load_rows(k) -> ring slots (2k) % 6, (2k + 1) % 6, three shifts
+    unsigned ph[5], pl[5];
+#pragma unroll
+    for (int j2 = 0; j2 < 5; ++j2) {
+      float v[2];
+#pragma unroll
+      for (int e = 0; e < 2; ++e) {
+        const int j = 2 * j2 + e;
+        float x = xa[j] * sca + sha;
+        const float sx = silu_fast_b(x);
+        x = do_silu ? sx : x;
+        v[e] = ((va >> j) & 1u) ? x : 0.f;
+      }
+      split2(v[0], v[1], ph[j2], pl[j2]);
+    }
+    const int slot = (2 * k) % WH_SLOTS + a_rr;  // (2k % 6 is even, so + rr stays inside the ring)
+    _Float16* dst = ab + a_ci * WH_ASTR + slot * 32 + a_oct * 8;
+#pragma unroll
+    for (int s = 0; s < 3; ++s) {
+      uint4 wh, wl;
+      if (s == 1) {
+        wh = make_uint4(__builtin_amdgcn_alignbit(ph[1], ph[0], 16), __builtin_amdgcn_alignbit(ph[2], ph[1], 16),
+                        __builtin_amdgcn_alignbit(ph[3], ph[2], 16), __builtin_amdgcn_alignbit(ph[4], ph[3], 16));
+        wl = make_uint4(__builtin_amdgcn_alignbit(pl[1], pl[0], 16), __builtin_amdgcn_alignbit(pl[2], pl[1], 16),
+                        __builtin_amdgcn_alignbit(pl[3], pl[2], 16), __builtin_amdgcn_alignbit(pl[4], pl[3], 16));
+      } else {
+        const int o = s >> 1;
+        wh = make_uint4(ph[o], ph[o + 1], ph[o + 2], ph[o + 3]);
+        wl = make_uint4(pl[o], pl[o + 1], pl[o + 2], pl[o + 3]);
+      }
+      *reinterpret_cast<uint4*>(dst + (s * 2 + 0) * 32 * WH_ASTR) = wh;
+      *reinterpret_cast<uint4*>(dst + (s * 2 + 1) * 32 * WH_ASTR) = wl;
+    }
+  };
+  auto commit_dy = [&](int par) {
+    _Float16* db = dbase + par * WH_D_HALFS;
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      uint4 dh, dl;
+      split2(xd[u][0].x, xd[u][0].y, dh.x, dl.x);
+      split2(xd[u][0].z, xd[u][0].w, dh.y, dl.y);
+      split2(xd[u][1].x, xd[u][1].y, dh.z, dl.z);
+      split2(xd[u][1].z, xd[u][1].w, dh.w, dl.w);
+      *reinterpret_cast<uint4*>(db + d_lds[u]) = dh;
+      *reinterpret_cast<uint4*>(db + 64 * WH_DSTR + d_lds[u]) = dl;
+    }
+  };
+
+  wf32x16 acc_hi[5], acc_lo[5];
+#pragma unroll
+  for (int t = 0; t < 5; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      acc_hi[t][r] = 0.f;
+      acc_lo[t][r] = 0.f;
+    }
+
+  // prologue: row pairs s0 and s0+1 and dY(s0) into LDS; row pair s0+2 and dY(s0+1) into registers
+  if (s0 < s1) {
+    load_rows(s0);
+    load_dy(s0);
+    commit_rows(s0);
+    load_rows(s0 + 1);
+    commit_dy(0);
+    commit_rows(s0 + 1);
+    load_rows(s0 + 2);               // (past the image: masked to zero)
+    if (s0 + 1 < s1) load_dy(s0 + 1);
+  }
+  __syncthreads();
+
+  const _Float16* a_lane = ab + l31 * WH_ASTR + half * 8;
+  const _Float16* d_lane = dbase + (cot * 32 + l31) * WH_DSTR + half * 8;
+  for (int s = s0; s < s1; ++s) {
+    const int par = (s - s0) & 1;
+    const bool more = s + 1 < s1;
+    // ring slots of the 4 input rows of this stage: row j (0..3) = input row 2s - 1 + j -> slot (2s + j) % 6
+    int slot_off[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) slot_off[j] = ((2 * s + j) % WH_SLOTS) * 32;
+    const _Float16* dl = d_lane + par * WH_D_HALFS;
+    auto stage = [&](auto first_tag) {
+      constexpr bool FIRST = decltype(first_tag)::value;
+      constexpr int T0 = FIRST ? 0 : 5, NTP = FIRST ? 5 : 4;
+      whalf8 fa[2][NTP][2], fb[2][2];
+      auto frags = [&](int kk, int fp) {
+        const int orow = kk >> 1, colg = (kk & 1) * 16;
+        fb[fp][0] = *reinterpret_cast<const whalf8*>(dl + orow * 32 + colg);
+        fb[fp][1] = *reinterpret_cast<const whalf8*>(dl + 64 * WH_DSTR + orow * 32 + colg);
+#pragma unroll
+        for (int tp = 0; tp < NTP; ++tp) {
+          const int dy = (T0 + tp) / 3, dx = (T0 + tp) % 3;
+          const _Float16* ap = a_lane + slot_off[orow + dy] + colg;
+          fa[fp][tp][0] = *reinterpret_cast<const whalf8*>(ap + (dx * 2 + 0) * 32 * WH_ASTR);
+          fa[fp][tp][1] = *reinterpret_cast<const whalf8*>(ap + (dx * 2 + 1) * 32 * WH_ASTR);
+        }
+      };
+      frags(0, 0);
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk) {
+        __builtin_amdgcn_sched_barrier(0);
+        if (kk < 3) frags(kk + 1, (kk + 1) & 1);  // operands one k-step ahead (before this step's LDS writes)
+        // next stage's staging rides on the MFMAs: rows at k-step 0, dY at 1, the fetches after them at 2
+        if (kk == 0) commit_rows(s + 2);
+        if (kk == 1 && more) commit_dy(par ^ 1);
+        if (kk == 2) {
+          load_rows(s + 3);
+          if (s + 2 < s1) load_dy(s + 2);
+        }
+        const int fp = kk & 1;
+#pragma unroll
+        for (int tp = 0; tp < NTP; ++tp) {
+          acc_hi[tp] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[fp][tp][0], fb[fp][0], acc_hi[tp], 0, 0, 0);
+          acc_lo[tp] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[fp][tp][0], fb[fp][1], acc_lo[tp], 0, 0, 0);
+          acc_lo[tp] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[fp][tp][1], fb[fp][0], acc_lo[tp], 0, 0, 0);
+        }
+        if (kk < 2) {
+#pragma unroll
+          for (int m = 0; m < 3 * NTP; ++m) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x002, 5, 0);
+          }
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    };
+    if (first) stage(std::true_type{});
+    else stage(std::false_type{});
+    __syncthreads();
+  }
+
+  // epilogue: D[ci][co = l31]; partials to this run's slab [tap][ci][co]
+  const int co = co0 + cot * 32 + l31;
+  float* wsb = p.ws + (size_t)blockIdx.y * 9 * p.cin_pad * p.cout_pad;
+  const int t0 = first ? 0 : 5, ntp = first ? 5 : 4;
+#pragma unroll
+  for (int tp = 0; tp < 5; ++tp) {
+    if (tp < ntp) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int ci = ci0 + (r & 3) + 8 * (r >> 2) + 4 * half;
+        wsb[((size_t)(t0 + tp) * p.cin_pad + ci) * p.cout_pad + co] = acc_hi[tp][r] + acc_lo[tp][r] * (1.0f / 2048.0f);
+      }
+    }
+  }
+}
+
+static int g_wgrad_h2 = 1;
+void wgrad_h2_set_enabled(int on) { g_wgrad_h2 = on; }
+
+static bool wgrad_h2_eligible(const WgradP& p, int ks, int stride, int ups) {
+  return g_wgrad_h2 && ks == 3 && stride == 1 && ups == 0 && p.cin % 32 == 0 && p.cout % 64 == 0 && p.wout % 32 == 0 &&
+         p.hout % 2 == 0 && (p.c1 == 0 || p.c0 % 32 == 0);
+}
+
 static int wgrad_nsplit(int pairs, int ntiles) { return std::max(1, std::min(ntiles, cdiv(1024, pairs))); }
 
 template <int KS, int STRIDE, int UPS, int CIT>
@@ -306,6 +580,48 @@ static int launch_wgrad(WgradP p, size_t ws_bytes, hipStream_t st) {
   return DSG_OK;
 }
 
+// runs of the fp16x2-split kernel: every (image, 32-column strip) is cut into `rsplit` runs of consecutive row pairs
+static void wgrad_h2_runs(int cin, int cout, int n, int hout, int wout, int* strips, int* rsplit) {
+  const int pairs = (cin / 32) * (cout / WG_CO);
+  *strips = n * (wout / 32);
+  const int stages = hout / 2;
+  const int want = std::max(1, cdiv(1024, pairs));            // workgroups wanted per (ci, co) pair
+  *rsplit = std::max(1, std::min(stages, cdiv(want, *strips)));
+}
+
+static int launch_wgrad_h2(WgradP p, size_t ws_bytes, hipStream_t st) {
+  p.ci_blocks = p.cin / 32;
+  const int co_blocks = p.cout / WG_CO;
+  const int pairs = p.ci_blocks * co_blocks;
+  int strips, rsplit;
+  wgrad_h2_runs(p.cin, p.cout, p.n, p.hout, p.wout, &strips, &rsplit);
+  const int nslab = strips * rsplit;
+  p.cin_pad = p.cin;
+  p.cout_pad = p.cout;
+  p.ntiles = rsplit;  // (field reused: row splits per strip)
+  const size_t need = (size_t)nslab * 9 * p.cin_pad * p.cout_pad * sizeof(float);
+  if (p.ws == nullptr || ws_bytes < need)
+    return fail(DSG_ERR_WORKSPACE_TOO_SMALL, "dsg_conv2d_wgrad: workspace %zu bytes < required %zu", ws_bytes, need);
+  static bool raised = false;
+  if (!raised) {
+    DSG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wgrad_h2_kernel),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    raised = true;
+  }
+  int pi = -1;
+  if (prof_on())
+    pi = prof_begin(9, 2.0 * p.n * p.hout * p.wout * (double)p.cout * p.cin * 9,
+                    4.0 * ((double)p.n * p.cin * p.hin * p.win + (double)p.n * p.cout * p.hout * p.wout), st);
+  hipLaunchKernelGGL(conv_wgrad_h2_kernel, dim3(pairs, nslab), dim3(256), (size_t)WH_LDS_BYTES, st, p);
+  DSG_LAUNCH_CHECK();
+  const int64_t slab = (int64_t)9 * p.cin_pad * p.cout_pad;
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)cdiv64(slab, 256)), dim3(256), 0, st, p.ws, nslab, 9, p.cin,
+                     p.cout, p.cin_pad, p.cout_pad, p.dw);
+  prof_end(pi, st);
+  DSG_LAUNCH_CHECK();
+  return DSG_OK;
+}
+
 // bytes of split-K workspace the MFMA path needs for these dims (0 for the VALU fallback)
 static size_t wgrad_ws_bytes(int cin, int cout, int ks, int stride, int hout, int wout, int n) {
   if ((wout % 32) || (hout % WG_SR)) return 0;
@@ -314,7 +630,13 @@ static size_t wgrad_ws_bytes(int cin, int cout, int ks, int stride, int hout, in
   const int ci_blocks = cdiv(cin, cib), co_blocks = cdiv(cout, WG_CO);
   const int ntiles = (wout / 32) * (hout / WG_SR) * n;
   const int nslab = wgrad_nsplit(ci_blocks * co_blocks, ntiles) * (cit == 2 ? 1 : 2);
-  return (size_t)nslab * ks * ks * ci_blocks * cib * co_blocks * WG_CO * sizeof(float);
+  size_t need = (size_t)nslab * ks * ks * ci_blocks * cib * co_blocks * WG_CO * sizeof(float);
+  if (ks == 3 && stride == 1 && cin % 32 == 0 && cout % 64 == 0) {  // the fp16x2-split kernel: one slab per run
+    int strips, rsplit;
+    wgrad_h2_runs(cin, cout, n, hout, wout, &strips, &rsplit);
+    need = std::max(need, (size_t)strips * rsplit * 9 * cin * cout * sizeof(float));
+  }
+  return need;
 }
 
 }  // namespace dsg
@@ -349,6 +671,7 @@ DSG_API int dsg_conv2d_wgrad(const dsg_conv_wgrad_args* a, void* stream) {
   if (tile_ok) {
     const int k = a->ksize, s = a->stride, u = a->upsample;
     const bool small_ci = p.cin <= 32;
+    if (wgrad_h2_eligible(p, k, s, u)) return launch_wgrad_h2(p, a->workspace_bytes, st);
     if (k == 3 && s == 1 && u == 0) return small_ci ? launch_wgrad<3, 1, 0, 1>(p, a->workspace_bytes, st) : launch_wgrad<3, 1, 0, 2>(p, a->workspace_bytes, st);
     if (k == 3 && s == 1 && u == 1) return small_ci ? launch_wgrad<3, 1, 1, 1>(p, a->workspace_bytes, st) : launch_wgrad<3, 1, 1, 2>(p, a->workspace_bytes, st);
     if (k == 3 && s == 2) return launch_wgrad<3, 2, 0, 1>(p, a->workspace_bytes, st);

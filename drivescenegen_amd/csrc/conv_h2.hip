@@ -307,6 +307,13 @@ __global__ __launch_bounds__(64 * NW, 1) void conv_h2_kernel(ConvH2P p) {
   // prologue: chunk 0 -> buffer 0; chunk 1 -> registers.  Everything that goes to memory is issued first and
   // together (both chunks' patches, the weight DMAs, the scale/shift table), so the tile pays one memory round
   // trip before its first MFMA, not one per dependent step.
+#ifdef DSG_H2_TIMING
+  unsigned long long rt_p[4];
+#define DSG_PT(i) do { __builtin_amdgcn_sched_barrier(0); rt_p[i] = __builtin_amdgcn_s_memrealtime(); __builtin_amdgcn_sched_barrier(0); } while (0)
+  DSG_PT(0);
+#else
+#define DSG_PT(i)
+#endif
   {
     float xr1[H2_NU][8];
     const float* sp = src_of(0);
@@ -319,12 +326,15 @@ __global__ __launch_bounds__(64 * NW, 1) void conv_h2_kernel(ConvH2P p) {
     }
 #pragma unroll
     for (int k = 0; k < G::NDMA; ++k) dma_weights(k, 0, buf0);
+    DSG_PT(1);
     if (has_ss) {
       for (int i = tid; i < 2 * p.cin; i += NTH) ssl[i] = ssg[i];
       __syncthreads();  // the scale/shift table is in LDS
     }
+    DSG_PT(2);
 #pragma unroll
     for (int i = 0; i < H2_NU; ++i) commit_unit(i, 0, buf0);
+    DSG_PT(3);
     if (nq > 1) {
 #pragma unroll
       for (int i = 0; i < H2_NU; ++i)
@@ -572,6 +582,8 @@ __global__ __launch_bounds__(64 * NW, 1) void conv_h2_kernel(ConvH2P p) {
       rec[1] = (double)rt_loop;
       rec[2] = (double)rt_loop_end;
       rec[3] = (double)t_loop_cycles;
+      double* pr = p.stats + 8 + 5 * (size_t)gridDim.x + 16 + 4 * (size_t)blockIdx.x;
+      for (int k = 0; k < 4; ++k) pr[k] = (double)rt_p[k];
     }
   }
 #endif

@@ -29,6 +29,8 @@ WG_CASES = [
     ("res64", 64, 0, 64, 16, 32, 3, 1, False, True),
     ("cat_straddle", 128, 64, 128, 8, 32, 3, 1, False, True),
     ("cin32_cit1", 32, 0, 64, 16, 32, 3, 1, False, True),
+    ("h2_tiles_plain", 64, 0, 128, 32, 64, 3, 1, False, False),   # 2x2 column/row tiles, no norm: fp16x2-split wgrad
+    ("h2_cat_even", 64, 64, 64, 8, 32, 3, 1, False, True),
     ("upsample", 64, 0, 64, 8, 16, 3, 1, True, False),
     ("stride2", 64, 0, 64, 16, 64, 3, 2, False, False),
     ("shortcut_1x1", 96, 32, 64, 8, 32, 1, 1, False, False),

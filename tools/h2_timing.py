@@ -31,3 +31,8 @@ for name, c, h in (("res512@32", 512, 32), ("res256@64", 256, 64), ("res128@128"
           f"  loop us mean {(rec[:,2]-rec[:,1]).mean()/100:.1f} -> {rec[:,3].mean()/((rec[:,2]-rec[:,1]).mean()/100)/1e3:.2f} GHz")
     taps = st.flatten()[8 + 5 * nb:8 + 5 * nb + 9].cpu().numpy() / nw / (c // 16)
     print("   cycles per tap:", " ".join(f"{t:.0f}" for t in taps), " sum", f"{taps.sum():.0f}")
+    pr = st.flatten()[8 + 5 * nb + 16:8 + 5 * nb + 16 + 4 * nb].reshape(nb, 4).cpu().numpy()
+    e = rec[:, 0]
+    print("   prologue us: entry->p0 %.2f  issue loads %.2f  ss+sync (first wait) %.2f  commit %.2f  final wait+barrier %.2f" % (
+        (pr[:, 0] - e).mean() / 100, (pr[:, 1] - pr[:, 0]).mean() / 100, (pr[:, 2] - pr[:, 1]).mean() / 100,
+        (pr[:, 3] - pr[:, 2]).mean() / 100, (rec[:, 1] - pr[:, 3]).mean() / 100))
