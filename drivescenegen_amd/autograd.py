@@ -275,13 +275,24 @@ def _backward(model, st: TrainState, tape: _Tape, dout):
                 ops.reduce_rows_add(ops.channel_sums(dy), st.grad(wname + ".bias"))
             if rec["res"] is not None:
                 tape.addg(rec["res"], dy)
-            ops.conv_wgrad(x0, dy, st.grad(wname + ".weight"), src1=x1, ksize=k, stride=rec["stride"],
-                           upsample=rec["ups"], gn_scale_shift=rec["ss"], silu=rec["silu"])
+            # up-sampler conv (no norm, one source): both gradients run at full resolution on the split matrix-core
+            # kernels -- the weight gradient from the materialised nearest-x2 input, the data gradient as a plain
+            # transposed conv followed by the upsample's adjoint (2x2 sum-pool)
+            ups_h2 = bool(rec["ups"]) and rec["whd"] is not None and x1 is None and rec["gn"] is None and k == 3
+            if ups_h2:
+                ops.conv_wgrad(ops.upsample_nearest2x(x0), dy, st.grad(wname + ".weight"), ksize=k)
+            else:
+                ops.conv_wgrad(x0, dy, st.grad(wname + ".weight"), src1=x1, ksize=k, stride=rec["stride"],
+                               upsample=rec["ups"], gn_scale_shift=rec["ss"], silu=rec["silu"])
             done(wname + ".weight", wname + ".bias")
             if not rec["need_dx"]:
                 continue
             cin0, cin1 = x0.shape[1], (x1.shape[1] if x1 is not None else 0)
             wd = rec["wd"]
+            if ups_h2:
+                dfull = ops.conv2d_fused(dy, wd, ksize=k, cout=cin0, weight_h2=rec["whd"])
+                tape.setg(x0, ops.sumpool2x2(dfull, add=tape.g(x0)))
+                continue
             up_mode = 2 if rec["stride"] == 2 else 0
             whd = rec["whd"] if (rec["stride"] == 1 and not rec["ups"]) else None  # the split kernel has no pool / zero-stuff mode
             if rec["gn"] is not None:

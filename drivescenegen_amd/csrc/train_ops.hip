@@ -333,6 +333,62 @@ DSG_API int dsg_linear_bwd(const float* x, const float* w, const float* dy, int3
   return DSG_OK;
 }
 
+namespace dsg {
+// dst[plane][2h][2w] = src[plane][h][w] (Upsample2D's nearest x2, materialised for the weight gradient of the
+// up-sampler conv); one thread per source pixel pair -> two float4 stores
+__global__ __launch_bounds__(256) void upsample2x_kernel(const float* __restrict__ src, float* __restrict__ dst, int h,
+                                                         int w, int64_t total2) {
+  const int64_t i = blockIdx.x * (int64_t)256 + threadIdx.x;  // index over (plane, y, x/2)
+  if (i >= total2) return;
+  const int w2 = w >> 1;
+  const int x2 = (int)(i % w2);
+  const int64_t r = i / w2;  // plane * h + y
+  const float2 v = *reinterpret_cast<const float2*>(src + r * w + 2 * x2);
+  const float4 o = make_float4(v.x, v.x, v.y, v.y);
+  float* d = dst + (r * 2) * (2 * (int64_t)w) + 4 * x2;
+  *reinterpret_cast<float4*>(d) = o;
+  *reinterpret_cast<float4*>(d + 2 * w) = o;
+}
+// dst[plane][h][w] = sum of the 2x2 block of src[plane][2h][2w] (+ add): the adjoint of the nearest x2 upsample
+__global__ __launch_bounds__(256) void sumpool2x2_kernel(const float* __restrict__ src, const float* __restrict__ add,
+                                                         float* __restrict__ dst, int h, int w, int64_t total2) {
+  const int64_t i = blockIdx.x * (int64_t)256 + threadIdx.x;  // index over (plane, y, x/2)
+  if (i >= total2) return;
+  const int w2 = w >> 1;
+  const int x2 = (int)(i % w2);
+  const int64_t r = i / w2;
+  const float* s0 = src + (r * 2) * (2 * (int64_t)w) + 4 * x2;
+  const float4 a = *reinterpret_cast<const float4*>(s0);
+  const float4 b = *reinterpret_cast<const float4*>(s0 + 2 * w);
+  float2 o = make_float2((a.x + a.y) + (b.x + b.y), (a.z + a.w) + (b.z + b.w));
+  if (add) {
+    const float2 e = *reinterpret_cast<const float2*>(add + r * w + 2 * x2);
+    o.x += e.x;
+    o.y += e.y;
+  }
+  *reinterpret_cast<float2*>(dst + r * w + 2 * x2) = o;
+}
+}  // namespace dsg
+
+DSG_API int dsg_upsample_nearest2x(const float* src, float* dst, int64_t planes, int32_t h, int32_t w, void* stream) {
+  DSG_CHECK_ARG(src && dst && planes > 0 && h > 0 && w > 0 && (w & 1) == 0, "dsg_upsample_nearest2x: bad argument (w even)");
+  const int64_t total2 = planes * h * (w / 2);
+  hipLaunchKernelGGL(dsg::upsample2x_kernel, dim3((unsigned)dsg::cdiv64(total2, 256)), dim3(256), 0,
+                     static_cast<hipStream_t>(stream), src, dst, h, w, total2);
+  DSG_LAUNCH_CHECK();
+  return DSG_OK;
+}
+
+DSG_API int dsg_sumpool2x2(const float* src, const float* add, float* dst, int64_t planes, int32_t h, int32_t w,
+                           void* stream) {
+  DSG_CHECK_ARG(src && dst && planes > 0 && h > 0 && w > 0 && (w & 1) == 0, "dsg_sumpool2x2: bad argument (w even)");
+  const int64_t total2 = planes * h * (w / 2);
+  hipLaunchKernelGGL(dsg::sumpool2x2_kernel, dim3((unsigned)dsg::cdiv64(total2, 256)), dim3(256), 0,
+                     static_cast<hipStream_t>(stream), src, add, dst, h, w, total2);
+  DSG_LAUNCH_CHECK();
+  return DSG_OK;
+}
+
 DSG_API int dsg_add(const float* a, const float* b, int64_t numel, float* out, void* stream) {
   DSG_CHECK_ARG(a && b && out && numel > 0, "dsg_add: bad argument");
   hipLaunchKernelGGL(dsg::add2_kernel, dim3(dsg::stream_blocks2(numel)), dim3(256), 0, static_cast<hipStream_t>(stream),

@@ -302,6 +302,24 @@ def channel_sums(x, out=None, out_stride=None):
     return out
 
 
+def upsample_nearest2x(x):
+    """[N, C, h, w] -> [N, C, 2h, 2w] (dsg_upsample_nearest2x)."""
+    n, c, h, w = x.shape
+    out = torch.empty((n, c, 2 * h, 2 * w), dtype=torch.float32, device=x.device)
+    with torch.cuda.device(x.device):
+        _lib.check(_lib.load().dsg_upsample_nearest2x(_lib.ptr(x), _lib.ptr(out), n * c, h, w, _st(x)))
+    return out
+
+
+def sumpool2x2(x, add=None):
+    """[N, C, 2h, 2w] -> [N, C, h, w] sums of 2x2 blocks (+ add): the adjoint of upsample_nearest2x."""
+    n, c, h2, w2 = x.shape
+    out = torch.empty((n, c, h2 // 2, w2 // 2), dtype=torch.float32, device=x.device)
+    with torch.cuda.device(x.device):
+        _lib.check(_lib.load().dsg_sumpool2x2(_lib.ptr(x), _lib.ptr(add), _lib.ptr(out), n * c, h2 // 2, w2 // 2, _st(x)))
+    return out
+
+
 def add(a, b):
     out = torch.empty_like(a)
     with torch.cuda.device(a.device):

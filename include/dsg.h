@@ -242,6 +242,11 @@ int dsg_gn_bwd(const float* src0, int32_t c0, const float* src1, int32_t c1, con
 /* out_nc[n*out_stride + c] = sum over hw of x[n][c][:] (bias / time-embedding gradients) */
 int dsg_channel_sums(const float* x, int32_t n, int32_t c, int32_t hw, float* out_nc, int32_t out_stride, void* stream);
 int dsg_add(const float* a, const float* b, int64_t numel, float* out, void* stream);
+/* Upsample2D's nearest x2 materialised ([planes][h][w] -> [planes][2h][2w]) and its adjoint, the 2x2 sum-pool
+ * ([planes][2h][2w] -> [planes][h][w], + add if non-NULL): the backward of the up-sampler conv (upsamplers.0.conv)
+ * runs its weight / data gradient through the matrix-core kernels at full resolution between these two. */
+int dsg_upsample_nearest2x(const float* src, float* dst, int64_t planes, int32_t h, int32_t w, void* stream);
+int dsg_sumpool2x2(const float* src, const float* add, float* dst, int64_t planes, int32_t h, int32_t w, void* stream);
 int dsg_time_embed_fwd_train(const int64_t* timesteps, const float* freqs, int32_t n, int32_t ch, int32_t dim,
                              const float* w1, const float* b1, const float* w2, const float* b2, float* act,
                              float* emb, float* z1, float* z2, void* stream);

@@ -163,3 +163,15 @@ def test_mse_norm_adamw_match_torch():
     gg = _t(70, (5000,), 3.0).to(DEV)
     want = gg.cpu() * min(1.0, 1.0 / (float(gg.norm().cpu()) + 1e-6))
     _close(ops.clip_scale_(gg, ops.l2_norm(gg), 1.0), want, rel=1e-6, ab=1e-6)
+
+
+def test_upsample_and_its_adjoint():
+    """dsg_upsample_nearest2x == F.interpolate(nearest, x2); dsg_sumpool2x2 is its adjoint (+ add)."""
+    x = _t(31, (2, 5, 6, 8))
+    up = ops.upsample_nearest2x(x.to(DEV)).cpu()
+    assert torch.equal(up, F.interpolate(x, scale_factor=2.0, mode="nearest"))
+    g, a = _t(32, (2, 5, 12, 16)), _t(33, (2, 5, 6, 8))
+    got = ops.sumpool2x2(g.to(DEV), add=a.to(DEV)).cpu()
+    want = F.avg_pool2d(g.double(), 2) * 4 + a.double()
+    assert torch.allclose(got.double(), want, rtol=0, atol=2e-6)
+    assert torch.allclose(ops.sumpool2x2(g.to(DEV)).cpu().double(), F.avg_pool2d(g.double(), 2) * 4, rtol=0, atol=2e-6)
