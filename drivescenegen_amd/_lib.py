@@ -39,6 +39,7 @@ class ConvArgs(C.Structure):
         ("temb", C.c_void_p), ("temb_stride", C.c_int32),
         ("residual", C.c_void_p), ("dst", C.c_void_p), ("pool2", C.c_int32),
         ("weight_h2", C.c_void_p),
+        ("weight_h2_cout_stride", C.c_int32),
         ("stats_out", C.c_void_p),
     ]
 

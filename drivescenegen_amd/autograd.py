@@ -310,10 +310,11 @@ def _backward(model, st: TrainState, tape: _Tape, dout):
                 # no norm in front: the data gradient lands on the source(s) directly (one conv per source,
                 # selecting that source's columns of the transposed weight; the fan-in add rides the epilogue)
                 tape.setg(x0, ops.conv2d_fused(dy, wd, ksize=k, upsample=up_mode, cout=cin0, pool2=rec["ups"],
-                                               residual=tape.g(x0), weight_h2=whd if x1 is None else None))
+                                               residual=tape.g(x0), weight_h2=whd))
                 if x1 is not None:
                     tape.setg(x1, ops.conv2d_fused(dy, wd[:, :, cin0:], ksize=k, upsample=up_mode, cout=cin1,
-                                                   pool2=rec["ups"], residual=tape.g(x1), wstride=wd.shape[-1]))
+                                                   pool2=rec["ups"], residual=tape.g(x1), wstride=wd.shape[-1],
+                                                   weight_h2=whd if cin0 % 8 == 0 else None, weight_h2_col=cin0))
         elif kind == "attn":
             do = tape.g(rec["o"])
             qkv = rec["qkv"]

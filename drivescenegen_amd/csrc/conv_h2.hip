@@ -41,7 +41,8 @@ struct ConvH2P {
   int hc, wc;
   int hout, wout;
   int cout, cout_pad;
-  const _Float16* wh;  // [cin/16][2][9][2][cout_pad][8]
+  int wh_stride;       // couts per weight row (>= cout_pad when `wh` is a column window of a wider matrix)
+  const _Float16* wh;  // [cin/16][2][9][2][wh_stride][8]
   const float* bias;
   const float* ss;
   int silu;
@@ -264,7 +265,7 @@ __global__ __launch_bounds__(64 * NW, 1) void conv_h2_kernel(ConvH2P p) {
   auto dma_weights = [&](int k, int q, unsigned char* buf) {
     // (uniform; a wave whose last share falls past the end repeats the final segment: same bytes, no branch)
     const int seg = min(wave + NW * k, G::NSEG - 1);
-    const _Float16* gp = p.wh + (((size_t)q * G::NSEG + seg) * p.cout_pad + m0) * 8 + lane * 8;  // uniform + lane
+    const _Float16* gp = p.wh + (((size_t)q * G::NSEG + seg) * p.wh_stride + m0) * 8 + lane * 8;  // uniform + lane
     // Issued as inline asm on purpose: hipcc's wait-count pass cannot tell the DMA's LDS destination (the other
     // buffer) from the fragment reads of this one, and with a DMA it knows of in flight it puts vmcnt(0) -- a wait
     // for every outstanding patch load as well -- in front of each following ds_read.  Untracked VMEM operations
@@ -625,6 +626,8 @@ static int g_h2_rows = 0;  // rows per wave: 0 = by grid size, 2 | 4 forced (tun
 
 bool conv_h2_eligible(const dsg_conv_args* a, int hout, int wout) {
   const int cin = a->c0 + a->c1;
+  if (a->weight_h2_cout_stride && (a->weight_h2_cout_stride % 64 || a->weight_h2_cout_stride < (a->cout + 63) / 64 * 64))
+    return false;
   if (cin > 1024) return false;  // the GroupNorm scale/shift table shares LDS with the K-chunk buffers
   if (a->ksize == 1)  // pointwise: the map is re-tiled as (h*w/32) rows of 32 pixels, so only h*w matters
     return g_h2_enabled && a->weight_h2 != nullptr && a->stride == 1 && !a->upsample && !a->pool2 && !a->temb &&
@@ -664,6 +667,7 @@ int conv_h2_launch(const dsg_conv_args* a, int hout, int wout, hipStream_t st) {
   p.hc = a->upsample ? 2 * p.hin : p.hin;
   p.wc = a->upsample ? 2 * p.win : p.win;
   p.hout = hout; p.wout = wout; p.cout = a->cout; p.cout_pad = (a->cout + 63) / 64 * 64;
+  p.wh_stride = a->weight_h2_cout_stride ? a->weight_h2_cout_stride : p.cout_pad;
   p.wh = static_cast<const _Float16*>(a->weight_h2);
   p.bias = a->bias; p.ss = a->gn_scale_shift; p.silu = a->silu; p.temb = a->temb; p.temb_stride = a->temb_stride;
   p.res = a->residual; p.dst = a->dst;

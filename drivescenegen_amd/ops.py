@@ -79,7 +79,7 @@ def relayout_conv_weight_dgrad(w_oihw: torch.Tensor, out: torch.Tensor = None) -
 
 def conv2d_fused(src0, weight_r, bias=None, src1=None, ksize=3, stride=1, upsample=False, gn_scale_shift=None,
                  silu=False, temb=None, temb_stride=0, residual=None, out=None, direct=False, cout=None,
-                 pool2=False, wstride=None, weight_h2=None, want_stats=False, stats_buf=None):
+                 pool2=False, wstride=None, weight_h2=None, want_stats=False, stats_buf=None, weight_h2_col=0):
     """dsg_conv2d_fwd: see include/dsg.h.  `weight_r` is in engine layout; `temb` is a [N, temb_stride] view
     whose first `cout` columns (from its data pointer) are added per (n, cout).
     want_stats: also return the per-tile GroupNorm statistics [N][cout][tiles][2] (fp64) of the result, or None
@@ -103,7 +103,9 @@ def conv2d_fused(src0, weight_r, bias=None, src1=None, ksize=3, stride=1, upsamp
     a.upsample, a.ksize, a.stride, a.cout = int(upsample), ksize, stride, cout
     a.weight, a.bias = wptr, _lib.ptr(bias)
     a.weight_cout_stride, a.pool2 = wstride, int(pool2)
-    a.weight_h2 = weight_h2.data_ptr() if weight_h2 is not None else None
+    if weight_h2 is not None:   # [K/16][2][taps][2][cout_total_pad][8] halfs; weight_h2_col selects a column window
+        a.weight_h2 = weight_h2.data_ptr() + 16 * int(weight_h2_col)
+        a.weight_h2_cout_stride = weight_h2.shape[-2] if weight_h2_col or weight_h2.shape[-2] != (cout + 63) // 64 * 64 else 0
     a.gn_scale_shift, a.silu = _lib.ptr(gn_scale_shift), int(silu)
     if temb is not None:
         if not temb.is_cuda:

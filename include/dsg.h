@@ -74,6 +74,9 @@ typedef struct {
   int32_t pool2;                /* 1: 2x2 sum-pool of the result (adjoint of the nearest x2 upsample) */
   const void* weight_h2;        /* optional: the same weights pre-split for the fp16x2 matrix-core path
                                    (dsg_conv_weight_relayout_h2); used for stride-1 3x3 / 1x1 convs with cin % 16 == 0, cout % 64 == 0 */
+  int32_t weight_h2_cout_stride; /* 0 = cout padded to 64; else the row length (in couts, a multiple of 64) of the wider
+                                   pre-split matrix that weight_h2 points into (a column window: weight_h2 =
+                                   matrix + 8 * first_column halfs) */
   double* stats_out;            /* optional [N][cout][tiles][2]: per-tile (sum, sum of squares) of dst, so that the
                                    GroupNorm that follows needs no pass of its own over dst (dsg_gn_finalize_parts).
                                    Only where dsg_conv2d_stats_tiles reports tiles > 0. */
