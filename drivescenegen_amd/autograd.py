@@ -314,7 +314,8 @@ def _backward(model, st: TrainState, tape: _Tape, dout):
                 if x1 is not None:
                     tape.setg(x1, ops.conv2d_fused(dy, wd[:, :, cin0:], ksize=k, upsample=up_mode, cout=cin1,
                                                    pool2=rec["ups"], residual=tape.g(x1), wstride=wd.shape[-1],
-                                                   weight_h2=whd if cin0 % 8 == 0 else None, weight_h2_col=cin0))
+                                                   weight_h2=whd if (cin0 % 8 == 0 and cin1 % 64 == 0) else None,
+                                                   weight_h2_col=cin0))  # (a window must end inside its row)
         elif kind == "attn":
             do = tape.g(rec["o"])
             qkv = rec["qkv"]

@@ -401,6 +401,7 @@ void conv_h2_set_rows(int r);
 void conv_h2_set_stats(int on);
 void conv_h2_set_waves(int w);
 void wgrad_h2_set_enabled(int on);
+void conv_h2_set_fold(int on);
 
 static int g_conv_kc = 0;  // K-chunk of the 3x3 stride-1 kernel: 4 | 8 | 0 = by grid size (measured, r01)
 
@@ -536,6 +537,10 @@ DSG_API int dsg_set_tuning(int32_t key, int32_t value) {
   }
   if (key == 3 && (value == 0 || value == 2 || value == 4)) {
     dsg::conv_h2_set_rows(value);
+    return DSG_OK;
+  }
+  if (key == 8 && (value == 0 || value == 1)) {
+    dsg::conv_h2_set_fold(value);
     return DSG_OK;
   }
   if (key == 7 && (value == 0 || value == 1)) {

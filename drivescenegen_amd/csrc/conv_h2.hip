@@ -62,10 +62,10 @@ constexpr int H2_TW = 32, H2_KC = 16, H2_BM = 64;
 // KS = 3 (halo of 1) or 1 (no halo; attention projections and resnet shortcuts)
 // NW = waves per workgroup (4: one per SIMD with the whole register file; 8: two per SIMD with half of it each,
 // so that one wave's staging / LDS / wait time is covered by the other's MFMAs)
-template <int NT, int KS, int NW = 4>
+template <int NT, int KS, int NW = 4, int TAPS_ = KS * KS>
 struct H2Geom {
   static constexpr int NTH = 64 * NW;
-  static constexpr int TAPS = KS * KS;
+  static constexpr int TAPS = TAPS_;                  // 4 in the folded up-sampler mode (2x2 taps of the 3x3 patch)
   static constexpr int TH = NW * NT;
   static constexpr int PH = TH + KS - 1;
   static constexpr int PW = H2_TW + KS - 1;
@@ -100,7 +100,12 @@ __device__ __forceinline__ float half_wave_sum(float x) {
 
 __device__ __forceinline__ float silu_fast_h(float x) { return x * __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
 
-// GM: 0 plain, 1 nearest x2 gather; NT: rows per wave; KS: 3 | 1.
+// GM: 0 plain, 1 nearest x2 gather, 2 nearest x2 FOLDED into the weights: Upsample2D + 3x3 conv is four 2x2 convs of
+// the low-resolution input, one per output phase (py, px) = (Y & 1, X & 1): rows {y-1: W0, y: W1+W2} for py = 0 and
+// {y: W0+W1, y+1: W2} for py = 1, likewise in x -- 16 tap products per input pixel instead of 36.  The kernel runs on
+// the low-resolution grid with the phase as an extra (outer) cout-tile index, walks the phase's 2x2 corner of the 3x3
+// patch and scatters its results to the (2y+py, 2x+px) pixels.
+// NT: rows per wave; KS: 3 | 1.
 // Staging units are arranged so that the k-group g (hence the channel plane and the GroupNorm scale/shift) of
 // every unit is WAVE-UNIFORM: channel-plane bases and scale/shift live in SGPRs (s_load / saddr-form global
 // loads), and the only per-lane address is the 32-bit halo offset computed once per tile.
@@ -109,7 +114,7 @@ __device__ __forceinline__ float silu_fast_h(float x) { return x * __builtin_amd
 // ACT: 0 the input is used as it is; 2 GroupNorm affine + SiLU; 3 decided at run time from p.ss / p.silu
 template <int GM, int NT, int KS, int ACT = 3, int NW = 4>
 __global__ __launch_bounds__(64 * NW, 1) void conv_h2_kernel(ConvH2P p) {
-  using G = H2Geom<NT, KS, NW>;
+  using G = H2Geom<NT, KS, NW, GM == 2 ? 4 : KS * KS>;
   constexpr int NTH = G::NTH;
   constexpr int H2_TH = G::TH, H2_PSZ = G::PSZ, H2_XHALFS = G::XHALFS, H2_BUF_BYTES = G::BUF_BYTES, H2_NU = G::NU;
   constexpr int FULL = G::FULL, TAPS = G::TAPS, H2_PW = G::PW, H2_WHALFS = G::WHALFS, PADK = KS / 2;
@@ -129,7 +134,7 @@ __global__ __launch_bounds__(64 * NW, 1) void conv_h2_kernel(ConvH2P p) {
   // on neighbouring ids: workgroups that share input -- the same patch for another cout tile, or the 128-byte
   // lines and halo rows a patch has in common with its left/right/upper/lower neighbours -- run at the same time
   // behind the same L2, so that data comes from HBM once instead of once per XCD.
-  const int nct = p.cout_pad / H2_BM, nsp = p.tiles_x * p.tiles_y * p.n;
+  const int nct = (p.cout_pad / H2_BM) * (GM == 2 ? 4 : 1), nsp = p.tiles_x * p.tiles_y * p.n;
   int bid, ct;
   if ((nsp & 7) == 0) {
     const int grp = blockIdx.x >> 3;
@@ -143,6 +148,8 @@ __global__ __launch_bounds__(64 * NW, 1) void conv_h2_kernel(ConvH2P p) {
   bid /= p.tiles_x;
   const int ty = bid % p.tiles_y;
   const int n = bid / p.tiles_y;
+  const int phase = GM == 2 ? ct / (p.cout_pad / H2_BM) : 0;  // (py, px) = (phase >> 1, phase & 1)
+  if (GM == 2) ct -= phase * (p.cout_pad / H2_BM);
   const int m0 = ct * H2_BM;
   const int oy0 = ty * H2_TH, ox0 = tx * H2_TW;
   const int plane = p.hin * p.win;
@@ -162,7 +169,7 @@ __global__ __launch_bounds__(64 * NW, 1) void conv_h2_kernel(ConvH2P p) {
       const int gy = oy0 - PADK + py, gx = ox0 - PADK + px;
       const int slot = H2_WHALFS + (g * H2_PSZ + pos) * 8;  // piece 0; piece 1 is 2*PSZ*8 halfs further
       if (gy >= 0 && gy < p.hc && gx >= 0 && gx < p.wc) {
-        off = (GM ? (gy >> 1) : gy) * p.win + (GM ? (gx >> 1) : gx);
+        off = (GM == 1 ? (gy >> 1) : gy) * p.win + (GM == 1 ? (gx >> 1) : gx);
         xo = slot;
         xo2 = slot + 2 * H2_PSZ * 8;
       } else {
@@ -265,7 +272,7 @@ __global__ __launch_bounds__(64 * NW, 1) void conv_h2_kernel(ConvH2P p) {
   auto dma_weights = [&](int k, int q, unsigned char* buf) {
     // (uniform; a wave whose last share falls past the end repeats the final segment: same bytes, no branch)
     const int seg = min(wave + NW * k, G::NSEG - 1);
-    const _Float16* gp = p.wh + (((size_t)q * G::NSEG + seg) * p.wh_stride + m0) * 8 + lane * 8;  // uniform + lane
+    const _Float16* gp = p.wh + ((((size_t)phase * nq + q) * G::NSEG + seg) * p.wh_stride + m0) * 8 + lane * 8;  // uniform + lane
     // Issued as inline asm on purpose: hipcc's wait-count pass cannot tell the DMA's LDS destination (the other
     // buffer) from the fragment reads of this one, and with a DMA it knows of in flight it puts vmcnt(0) -- a wait
     // for every outstanding patch load as well -- in front of each following ds_read.  Untracked VMEM operations
@@ -365,7 +372,8 @@ __global__ __launch_bounds__(64 * NW, 1) void conv_h2_kernel(ConvH2P p) {
     // is free to interleave them with the staging work (LDS reads after a possibly-aliasing LDS write are not).
     half8 fa[2][2][2], fb[2][NT][2];  // [parity][tile][piece]
     auto load_frags = [&](int tap, int par) {
-      const int dy = tap / KS, dx = tap % KS;
+      const int dy = GM == 2 ? (phase >> 1) + (tap >> 1) : tap / KS;   // folded: the phase's 2x2 corner of the patch
+      const int dx = GM == 2 ? (phase & 1) + (tap & 1) : tap % KS;
 #pragma unroll
       for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
@@ -469,7 +477,8 @@ __global__ __launch_bounds__(64 * NW, 1) void conv_h2_kernel(ConvH2P p) {
   // SIMD a load->add->store chain per element would expose the memory latency 64 times).
   // (the host only dispatches here when cout % 8 == 0, so a 4-row half-group is never split by cout)
   const bool has_r = p.res != nullptr;
-  const int oplane = p.hout * p.wout;
+  const int oscale = GM == 2 ? 2 : 1;  // folded mode: the output map is twice the tiled (low-resolution) grid
+  const int oplane = p.hout * p.wout * oscale * oscale;
   const bool want_stats = p.stats != nullptr;
   float* red = reinterpret_cast<float*>(smem_raw);  // [wave][sum | sumsq][cout 64] (the K loop is done with LDS)
   const int nvalid = min(H2_BM, p.cout - m0);        // output channels of this tile that exist
@@ -484,7 +493,10 @@ __global__ __launch_bounds__(64 * NW, 1) void conv_h2_kernel(ConvH2P p) {
       const_cast<float*>(p.temb ? p.temb + (size_t)n * p.temb_stride + m0 : p.dst), 0, p.temb ? nvalid * 4 : 0, 0x00020000);
   int voff[NT];  // bytes, per lane and row; the channel part of an address is the scalar offset
 #pragma unroll
-  for (int nt = 0; nt < NT; ++nt) voff[nt] = (4 * half * oplane + (oy0 + wave * NT + nt) * p.wout + ox0 + l31) * 4;
+  for (int nt = 0; nt < NT; ++nt)
+    voff[nt] = GM == 2 ? (4 * half * oplane + (2 * (oy0 + wave * NT + nt) + (phase >> 1)) * (2 * p.wout) +
+                          2 * (ox0 + l31) + (phase & 1)) * 4
+                       : (4 * half * oplane + (oy0 + wave * NT + nt) * p.wout + ox0 + l31) * 4;
   const int oplane4 = __builtin_amdgcn_readfirstlane(oplane * 4);
   auto epilogue = [&](auto stats_tag) {
     constexpr bool STATS = decltype(stats_tag)::value;
@@ -552,13 +564,14 @@ __global__ __launch_bounds__(64 * NW, 1) void conv_h2_kernel(ConvH2P p) {
       const int cl = tid & (H2_BM - 1), which = (tid >> 6) & 1;
       if (m0 + cl < p.cout) {
         constexpr int NE = NW * NT / 8;  // 8-row statistics tiles per workgroup tile
-        const int ntile = p.tiles_x * p.tiles_y * NE;
+        const int ntile1 = p.tiles_x * p.tiles_y * NE;           // entries per phase
+        const int ntile = ntile1 * (GM == 2 ? 4 : 1);
 #pragma unroll
         for (int e = 0; e < NE; ++e) {
           double t = 0.0;
 #pragma unroll
           for (int j = 0; j < 4; ++j) t += (double)red[((4 * e + j) * 2 + which) * H2_BM + cl];
-          const int tile8 = (ty * NE + e) * p.tiles_x + tx;
+          const int tile8 = phase * ntile1 + (ty * NE + e) * p.tiles_x + tx;
 #ifndef DSG_H2_TIMING
           p.stats[(((size_t)n * p.cout + m0 + cl) * ntile + tile8) * 2 + which] = t;
 #endif
@@ -621,11 +634,21 @@ __global__ void weight_relayout_h2_kernel(const float* __restrict__ w, _Float16*
 
 static int g_h2_enabled = 1;
 static int g_h2_waves = 4;  // 16-row tiles: 4 waves x 4 rows or 8 waves x 2 rows (tuning key 6)
+static int g_h2_fold = 1;   // folded up-sampler convs (tuning key 8: A/B against the x2 gather)
 static int g_h2_stats = 1;  // epilogue GroupNorm statistics (tuning key 5: A/B against the separate pass)
 static int g_h2_rows = 0;  // rows per wave: 0 = by grid size, 2 | 4 forced (tuning key 3)
 
+// folded up-sampler mode: nearest x2 + 3x3 as four 2x2 convs of the low-resolution input (weight_h2_fold)
+static bool conv_h2_fold(const dsg_conv_args* a) {
+  return g_h2_enabled && g_h2_fold && a->weight_h2_fold != nullptr && a->upsample == 1 && a->ksize == 3 && a->stride == 1 &&
+         !a->pool2 && !a->gn_scale_shift && !a->weight_h2_cout_stride && (a->c0 + a->c1) % 16 == 0 &&
+         (a->c1 == 0 || a->c0 % 16 == 0) && a->win % H2_TW == 0 && a->hin % 8 == 0 && a->cout % 8 == 0 &&
+         (a->c0 + a->c1) <= 1024;
+}
+
 bool conv_h2_eligible(const dsg_conv_args* a, int hout, int wout) {
   const int cin = a->c0 + a->c1;
+  if (conv_h2_fold(a)) return true;
   if (a->weight_h2_cout_stride && (a->weight_h2_cout_stride % 64 || a->weight_h2_cout_stride < (a->cout + 63) / 64 * 64))
     return false;
   if (cin > 1024) return false;  // the GroupNorm scale/shift table shares LDS with the K-chunk buffers
@@ -640,6 +663,11 @@ bool conv_h2_eligible(const dsg_conv_args* a, int hout, int wout) {
 
 // tile geometry shared by the launcher and dsg_conv2d_stats_tiles
 static bool conv_h2_rows16(const dsg_conv_args* a, int hout, int wout) {
+  if (conv_h2_fold(a)) {  // tiled on the low-resolution grid, four phases per cout tile
+    const int cp = (a->cout + 63) / 64 * 64;
+    const int b16 = (a->hin % 16 == 0) ? (a->win / H2_TW) * (a->hin / 16) * a->n * (cp / H2_BM) * 4 : 0;
+    return g_h2_rows != 2 && b16 >= (g_h2_rows == 4 ? 1 : 256);
+  }
   if (a->ksize == 1) {
     hout = hout * wout / H2_TW;
     wout = H2_TW;
@@ -664,11 +692,16 @@ int conv_h2_launch(const dsg_conv_args* a, int hout, int wout, hipStream_t st) {
     hout = hout * wout / H2_TW; wout = H2_TW;
     p.hin = hout; p.win = wout;
   }
-  p.hc = a->upsample ? 2 * p.hin : p.hin;
-  p.wc = a->upsample ? 2 * p.win : p.win;
+  const bool fold = conv_h2_fold(a);
+  if (fold) {  // the kernel tiles the LOW-resolution grid; outputs land at (2y + py, 2x + px)
+    hout = a->hin;
+    wout = a->win;
+  }
+  p.hc = (a->upsample && !fold) ? 2 * p.hin : p.hin;
+  p.wc = (a->upsample && !fold) ? 2 * p.win : p.win;
   p.hout = hout; p.wout = wout; p.cout = a->cout; p.cout_pad = (a->cout + 63) / 64 * 64;
   p.wh_stride = a->weight_h2_cout_stride ? a->weight_h2_cout_stride : p.cout_pad;
-  p.wh = static_cast<const _Float16*>(a->weight_h2);
+  p.wh = static_cast<const _Float16*>(fold ? a->weight_h2_fold : a->weight_h2);
   p.bias = a->bias; p.ss = a->gn_scale_shift; p.silu = a->silu; p.temb = a->temb; p.temb_stride = a->temb_stride;
   p.res = a->residual; p.dst = a->dst;
   // 16-row tiles (NT = 4) when they still give every CU a workgroup; 8-row tiles otherwise
@@ -678,10 +711,10 @@ int conv_h2_launch(const dsg_conv_args* a, int hout, int wout, hipStream_t st) {
   const size_t lds = 2 * (size_t)(k1 ? (nt4 ? H2Geom<4, 1>::BUF_BYTES : H2Geom<2, 1>::BUF_BYTES)
                                      : (nt4 ? H2Geom<4, 3>::BUF_BYTES : H2Geom<2, 3>::BUF_BYTES)) +
                      (a->gn_scale_shift ? (size_t)p.cin * 2 * sizeof(float) : 0);  // + the scale/shift table
-  dim3 grid(p.tiles_x * p.tiles_y * p.n * (p.cout_pad / H2_BM));
+  dim3 grid(p.tiles_x * p.tiles_y * p.n * (p.cout_pad / H2_BM) * (fold ? 4 : 1));
   int pi = -1;
   if (prof_on()) {
-    const double px = (double)p.n * hout * wout;
+    const double px = (double)p.n * hout * wout * (fold ? 4 : 1);  // output pixels; FLOPs are the reference op's
     const int taps = a->ksize * a->ksize;
     pi = prof_begin(a->ksize == 1 ? 8 : (a->upsample ? 7 : 6), 2.0 * px * p.cout * p.cin * taps,
                     4.0 * ((double)p.n * p.cin * p.hin * p.win + (double)p.cin * taps * p.cout +
@@ -697,7 +730,8 @@ int conv_h2_launch(const dsg_conv_args* a, int hout, int wout, hipStream_t st) {
         reinterpret_cast<const void*>(conv_h2_kernel<0, 2, 3, 2>), reinterpret_cast<const void*>(conv_h2_kernel<0, 4, 3, 2>),
         reinterpret_cast<const void*>(conv_h2_kernel<1, 2, 3, 0>), reinterpret_cast<const void*>(conv_h2_kernel<1, 4, 3, 0>),
         reinterpret_cast<const void*>(conv_h2_kernel<0, 2, 1, 0>), reinterpret_cast<const void*>(conv_h2_kernel<0, 4, 1, 0>),
-        reinterpret_cast<const void*>(conv_h2_kernel<0, 2, 1, 3>), reinterpret_cast<const void*>(conv_h2_kernel<0, 4, 1, 3>)};
+        reinterpret_cast<const void*>(conv_h2_kernel<0, 2, 1, 3>), reinterpret_cast<const void*>(conv_h2_kernel<0, 4, 1, 3>),
+        reinterpret_cast<const void*>(conv_h2_kernel<2, 2, 3, 0>), reinterpret_cast<const void*>(conv_h2_kernel<2, 4, 3, 0>)};
     for (const void* k : ks)
       if (k) DSG_HIP(hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     raised = true;
@@ -710,7 +744,10 @@ int conv_h2_launch(const dsg_conv_args* a, int hout, int wout, hipStream_t st) {
     else if (nt4) hipLaunchKernelGGL((conv_h2_kernel<GM, 4, KS, ACT>), grid, dim3(256), lds, st, p); \
     else hipLaunchKernelGGL((conv_h2_kernel<GM, 2, KS, ACT>), grid, dim3(256), lds, st, p);         \
   } while (0)
-  if (k1) {
+  if (fold) {
+    if (nt4) hipLaunchKernelGGL((conv_h2_kernel<2, 4, 3, 0>), grid, dim3(256), lds, st, p);
+    else hipLaunchKernelGGL((conv_h2_kernel<2, 2, 3, 0>), grid, dim3(256), lds, st, p);
+  } else if (k1) {
     if (act == 0) DSG_H2_LAUNCH(0, 1, 0);
     else DSG_H2_LAUNCH(0, 1, 3);
   } else if (a->upsample) {
@@ -728,9 +765,44 @@ int conv_h2_launch(const dsg_conv_args* a, int hout, int wout, hipStream_t st) {
 void conv_h2_set_enabled(int on) { g_h2_enabled = on; }
 void conv_h2_set_rows(int r) { g_h2_rows = r; }
 void conv_h2_set_stats(int on) { g_h2_stats = on; }
+void conv_h2_set_fold(int on) { g_h2_fold = on; }
 void conv_h2_set_waves(int w) { g_h2_waves = w; }
 
 }  // namespace dsg
+
+// OIHW 3x3 -> folded up-sampler weights [phase 4][cin/16][piece 2][tap 2x2][g 2][cout_pad][8]: for output phase
+// (py, px) the 2x2 taps are sums of the 3x3 taps that land on the same low-resolution pixel -- rows {0 | 1+2} for
+// py = 0, {0+1 | 2} for py = 1, the same in x (summed in fp32, dy outer / dx inner, then split hi / lo).
+__global__ void weight_fold_h2_kernel(const float* __restrict__ w, _Float16* __restrict__ dst, int cout, int cin,
+                                      int cout_pad) {
+  const int64_t per_phase = (int64_t)(cin / 16) * 4 * 2 * cout * 8;
+  const int64_t total = 4 * per_phase;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int j = (int)(i % 8);
+    int64_t r = i / 8;
+    const int co = (int)(r % cout);
+    r /= cout;
+    const int g = (int)(r % 2);
+    r /= 2;
+    const int tap = (int)(r % 4);
+    r /= 4;
+    const int q = (int)(r % (cin / 16));
+    const int phase = (int)(r / (cin / 16));
+    const int py = phase >> 1, px = phase & 1, tr = tap >> 1, tc = tap & 1;
+    const int dy0 = py == 0 ? (tr == 0 ? 0 : 1) : (tr == 0 ? 0 : 2), dy1 = py == 0 ? (tr == 0 ? 0 : 2) : (tr == 0 ? 1 : 2);
+    const int dx0 = px == 0 ? (tc == 0 ? 0 : 1) : (tc == 0 ? 0 : 2), dx1 = px == 0 ? (tc == 0 ? 0 : 2) : (tc == 0 ? 1 : 2);
+    const int ci = q * 16 + g * 8 + j;
+    const float* wp = w + ((int64_t)co * cin + ci) * 9;
+    float v = 0.f;
+    for (int dy = dy0; dy <= dy1; ++dy)
+      for (int dx = dx0; dx <= dx1; ++dx) v += wp[dy * 3 + dx];
+    const _Float16 h1 = (_Float16)v;
+    const _Float16 h2 = (_Float16)((v - (float)h1) * 2048.0f);
+    const int64_t pb = (int64_t)phase * (cin / 16) + q;
+    dst[((((pb * 2 + 0) * 4 + tap) * 2 + g) * cout_pad + co) * 8 + j] = h1;
+    dst[((((pb * 2 + 1) * 4 + tap) * 2 + g) * cout_pad + co) * 8 + j] = h2;
+  }
+}
 
 static int relayout_h2(const float* w_oihw, void* dst_half, int32_t cout, int32_t cin, int32_t ksize, int32_t n_total,
                        int32_t n_off, int mode, void* stream) {
@@ -754,6 +826,18 @@ static int relayout_h2(const float* w_oihw, void* dst_half, int32_t cout, int32_
 DSG_API int dsg_conv_weight_relayout_h2(const float* w_oihw, void* dst_half, int32_t cout, int32_t cin, int32_t ksize,
                                         int32_t cout_total, int32_t cout_off, void* stream) {
   return relayout_h2(w_oihw, dst_half, cout, cin, ksize, cout_total, cout_off, 0, stream);
+}
+
+DSG_API int dsg_conv_weight_relayout_h2_fold(const float* w_oihw, void* dst_half, int32_t cout, int32_t cin, void* stream) {
+  DSG_CHECK_ARG(w_oihw && dst_half, "dsg_conv_weight_relayout_h2_fold: NULL pointer");
+  DSG_CHECK_ARG(cout > 0 && cin > 0 && cin % 16 == 0, "dsg_conv_weight_relayout_h2_fold: cin (%d) must be a positive multiple of 16", cin);
+  const int cout_pad = (cout + 63) / 64 * 64;
+  const int64_t total = (int64_t)4 * (cin / 16) * 4 * 2 * cout * 8;
+  const int blocks = (int)std::min<int64_t>(dsg::cdiv64(total, 256), 4096);
+  hipLaunchKernelGGL(weight_fold_h2_kernel, dim3(blocks), dim3(256), 0, static_cast<hipStream_t>(stream), w_oihw,
+                     static_cast<_Float16*>(dst_half), cout, cin, cout_pad);
+  DSG_LAUNCH_CHECK();
+  return DSG_OK;
 }
 
 DSG_API int dsg_conv_weight_relayout_h2_dgrad(const float* w_oihw, void* dst_half, int32_t cout, int32_t cin,

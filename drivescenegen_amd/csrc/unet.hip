@@ -81,7 +81,7 @@ struct T {  // activation [N, c, h, w] (or any scratch when c/h/w are unused)
   int stiles = 0;
 };
 
-struct Conv { float* w = nullptr; float* b = nullptr; int cin = 0, cout = 0, k = 0, wstride = 0; void* wh = nullptr; };
+struct Conv { float* w = nullptr; float* b = nullptr; int cin = 0, cout = 0, k = 0, wstride = 0; void* wh = nullptr; void* whf = nullptr; };
 struct GN { float* g = nullptr; float* b = nullptr; int c = 0; };
 struct Res { GN n1; Conv c1; int toff = 0; GN n2; Conv c2; bool sc = false; Conv csc; int cin = 0, cout = 0; };
 struct Att { GN gn; Conv qkv; Conv out; int c = 0, heads = 0; };
@@ -95,7 +95,8 @@ struct Param {
   int64_t numel;
   int cout, cin, k, cout_total, cout_off;
   bool set;
-  void* wh;  // fp16x2-split copy of a 3x3 weight (conv_h2.hip), or nullptr
+  void* wh;   // fp16x2-split copy of a 3x3 weight (conv_h2.hip), or nullptr
+  void* whf;  // up-sampler convs: the same weight folded into four 2x2 phase kernels, or nullptr
 };
 
 }  // namespace
@@ -126,9 +127,9 @@ struct dsg_unet {
   void add_param(const std::string& name, ParamKind kind, float* dst, int64_t numel, int cout = 0, int cin = 0,
                  int k = 0, int cout_total = 0, int cout_off = 0) {
     index[name] = (int)params.size();
-    params.push_back({name, kind, dst, numel, cout, cin, k, cout_total, cout_off, false, nullptr});
+    params.push_back({name, kind, dst, numel, cout, cin, k, cout_total, cout_off, false, nullptr, nullptr});
   }
-  void reg_conv(const std::string& pre, Conv& c, int cin, int cout, int k) {
+  void reg_conv(const std::string& pre, Conv& c, int cin, int cout, int k, bool upsampler = false) {
     c.cin = cin; c.cout = cout; c.k = k;
     c.wstride = (cout + 31) / 32 * 32;  // zero-padded columns: every conv takes the matrix-core path
     c.w = dalloc((int64_t)cin * k * k * c.wstride);
@@ -139,6 +140,10 @@ struct dsg_unet {
       const int64_t halfs = (int64_t)(cin / 16) * 2 * k * k * 2 * cout * 8;
       c.wh = dalloc((halfs + 1) / 2);
       params.back().wh = c.wh;
+      if (upsampler && k == 3) {  // Upsample2D + conv as four 2x2 convs of the low-resolution map
+        c.whf = dalloc((int64_t)4 * (cin / 16) * 2 * 4 * 2 * cout * 8 / 2);
+        params.back().whf = c.whf;
+      }
     }
     add_param(pre + ".bias", P_COPY, c.b, cout);
   }
@@ -253,7 +258,7 @@ struct Runner {
     a.src0 = x.p; a.c0 = x.c;
     a.src1 = skip ? skip->p : nullptr; a.c1 = skip ? skip->c : 0;
     a.n = B; a.hin = x.h; a.win = x.w; a.upsample = ups; a.ksize = cv.k; a.stride = stride; a.cout = cv.cout;
-    a.weight = cv.w; a.weight_cout_stride = cv.wstride; a.bias = cv.b; a.weight_h2 = cv.wh;
+    a.weight = cv.w; a.weight_cout_stride = cv.wstride; a.bias = cv.b; a.weight_h2 = cv.wh; a.weight_h2_fold = cv.whf;
     a.gn_scale_shift = ss ? ss->p : nullptr; a.silu = silu;
     a.temb = temb; a.temb_stride = h->proj_total;
     a.residual = res ? res->p : nullptr;
@@ -436,7 +441,7 @@ DSG_API int dsg_unet_create(const dsg_unet_config* cfg, dsg_unet_t** out) {
       if (cfg->up_attn[i]) h->reg_att(pre + ".attentions." + std::to_string(j), u.att[j], out_ch);
     }
     u.resample = i != nb - 1;
-    if (u.resample) h->reg_conv(pre + ".upsamplers.0.conv", u.rconv, out_ch, out_ch, 3);
+    if (u.resample) h->reg_conv(pre + ".upsamplers.0.conv", u.rconv, out_ch, out_ch, 3, true);
   }
   h->reg_gn("conv_norm_out", h->norm_out, boc[0]);
   h->reg_conv("conv_out", h->conv_out, boc[0], cfg->out_channels, 3);
@@ -509,6 +514,10 @@ DSG_API int dsg_unet_set_param(dsg_unet_t* h, const char* name, const float* dat
     if (rc != DSG_OK) return rc;
     if (p.wh) {
       rc = dsg_conv_weight_relayout_h2(data, p.wh, p.cout, p.cin, p.k, p.cout_total, p.cout_off, stream);
+      if (rc != DSG_OK) return rc;
+    }
+    if (p.whf) {
+      rc = dsg_conv_weight_relayout_h2_fold(data, p.whf, p.cout, p.cin, stream);
       if (rc != DSG_OK) return rc;
     }
   }

@@ -76,7 +76,11 @@ typedef struct {
                                    (dsg_conv_weight_relayout_h2); used for stride-1 3x3 / 1x1 convs with cin % 16 == 0, cout % 64 == 0 */
   int32_t weight_h2_cout_stride; /* 0 = cout padded to 64; else the row length (in couts, a multiple of 64) of the wider
                                    pre-split matrix that weight_h2 points into (a column window: weight_h2 =
-                                   matrix + 8 * first_column halfs) */
+                                   matrix + 8 * first_column halfs; first_column + cout rounded up to 64 must not
+                                   exceed the row length -- whole 64-column tiles are read) */
+  const void* weight_h2_fold;   /* optional, upsample == 1 only: the 3x3 weights folded into four 2x2 phase kernels
+                                   (dsg_conv_weight_relayout_h2_fold); the conv then runs on the low-resolution
+                                   grid with 16 instead of 36 tap products per input pixel */
   double* stats_out;            /* optional [N][cout][tiles][2]: per-tile (sum, sum of squares) of dst, so that the
                                    GroupNorm that follows needs no pass of its own over dst (dsg_gn_finalize_parts).
                                    Only where dsg_conv2d_stats_tiles reports tiles > 0. */
@@ -96,6 +100,10 @@ int dsg_conv_weight_relayout(const float* w_oihw, float* dst, int32_t cout, int3
  * so that w == hi + lo * 2^-11 to 2^-24 relative (fp32-equivalent contraction on the f16 MFMA, conv_h2.hip). */
 int dsg_conv_weight_relayout_h2(const float* w_oihw, void* dst_half, int32_t cout, int32_t cin, int32_t ksize,
                                 int32_t cout_total /* 0 = cout */, int32_t cout_off, void* stream);
+/* OIHW 3x3 -> [phase 4][Cin/16][2][2x2 taps][2][cout padded to 64][8] fp16: Upsample2D (nearest x2) + this conv as
+ * four 2x2 convs of the low-resolution input, one per output-pixel parity; taps that land on the same source pixel
+ * are summed in fp32 before the split. */
+int dsg_conv_weight_relayout_h2_fold(const float* w_oihw, void* dst_half, int32_t cout, int32_t cin, void* stream);
 /* the same for the data-gradient conv (K = cout, N = cin padded to 64, taps reversed): [Cout/16][2][k*k][2][cin_pad][8] */
 int dsg_conv_weight_relayout_h2_dgrad(const float* w_oihw, void* dst_half, int32_t cout, int32_t cin, int32_t ksize,
                                       void* stream);

@@ -219,6 +219,8 @@ H2_CASES = [
     ("h2_concat_straddle", 128, 64, 128, 16, 32, False, True, True, False),
     ("h2_upsample", 64, 0, 64, 16, 16, True, False, False, False),
     ("h2_cout96_pad", 32, 0, 96, 8, 32, False, True, False, True),
+    ("h2_upsample_fold", 64, 0, 128, 16, 32, True, False, False, False, 3, True),   # x2 folded into 2x2 phase kernels
+    ("h2_upsample_fold_rows8", 32, 0, 64, 8, 32, True, False, False, True, 3, True),
     # pointwise (shortcut / attention projections): k = 1 flagged by a trailing element
     ("h2_1x1_shortcut_concat", 128, 64, 128, 16, 32, False, False, False, False, 1),
     ("h2_1x1_gn_res_16x16", 64, 0, 192, 16, 16, False, True, False, True, 1),
@@ -250,12 +252,17 @@ def test_conv_h2_split_matches_fp32(case):
         extra = extra + r.double()
     d = lambda t: None if t is None else t.to(DEV)
     wr, wh = ops.relayout_conv_weight(d(wt)), ops.relayout_conv_weight_h2(d(wt))
+    fold = len(case) > 11 and case[11]
+    whf = ops.relayout_conv_weight_h2_fold(d(wt)) if fold else None
     ss = ops.gn_scale_shift(d(x0), d(gamma), d(beta), 8, 1e-5, src1=d(x1)) if gn else None
     tp = d(tproj)
     kw = dict(src1=d(x1), ksize=k, upsample=ups, gn_scale_shift=ss, silu=gn, temb=tp[:, 3:] if temb else None,
               temb_stride=tp.stride(0), residual=d(r) if res else None, cout=cout)
     got32 = ops.conv2d_fused(d(x0), wr, d(bias), **kw).cpu()
-    goth2 = ops.conv2d_fused(d(x0), wr, d(bias), weight_h2=wh, **kw).cpu()
+    goth2 = ops.conv2d_fused(d(x0), wr, d(bias), weight_h2=wh, weight_h2_fold=whf, **kw).cpu()
+    if fold:  # really another code path than the gathered up-sampler conv, same result to fp32 round-off
+        gather = ops.conv2d_fused(d(x0), wr, d(bias), weight_h2=wh, **kw).cpu()
+        assert not torch.equal(gather, goth2) and (gather - goth2).abs().max() <= 1e-5 * max(1.0, float(gather.abs().max()))
     _check(goth2, (ref64 + extra).float())
     e32 = float(((got32.double() - ref64 - extra).abs() / mag).max())
     eh2 = float(((goth2.double() - ref64 - extra).abs() / mag).max())
@@ -271,6 +278,7 @@ STATS_CASES = [
     ("stats_3x3_rows16_concat", 64, 32, 128, 32, 64, 3, False),
     ("stats_1x1_16x16", 64, 0, 128, 16, 16, 1, False),
     ("stats_upsample", 64, 0, 64, 16, 16, 3, True),
+    ("stats_upsample_fold", 64, 0, 64, 16, 32, 3, True, True),
 ]
 
 
@@ -278,7 +286,7 @@ STATS_CASES = [
 def test_conv_epilogue_groupnorm_statistics(case):
     """stats_out of dsg_conv2d_fwd (per-tile sum / sum of squares of the tensor just written) gives the same
     GroupNorm scale/shift as a statistics pass over that tensor (dsg_gn_channel_stats), also across a concat."""
-    name, c0, c1, cout, h, w, k, ups = case
+    name, c0, c1, cout, h, w, k, ups = case[:8]
     batch, cin, groups = 2, c0 + c1, 8
     x0 = _t(11, (batch, c0, h, w), 1.3).to(DEV)
     x1 = _t(12, (batch, c1, h, w)).to(DEV) if c1 else None
@@ -287,8 +295,9 @@ def test_conv_epilogue_groupnorm_statistics(case):
     ho, wo = (2 * h, 2 * w) if ups else (h, w)
     res = _t(15, (batch, cout, ho, wo)).to(DEV)
     wr, wh = ops.relayout_conv_weight(wt), ops.relayout_conv_weight_h2(wt)
+    whf = ops.relayout_conv_weight_h2_fold(wt) if len(case) > 8 else None
     y, st = ops.conv2d_fused(x0, wr, bias, src1=x1, ksize=k, upsample=ups, residual=res, cout=cout, weight_h2=wh,
-                             want_stats=True)
+                             weight_h2_fold=whf, want_stats=True)
     assert st is not None and st.shape[:2] == (batch, cout)
     tot = st.sum(dim=2).cpu()
     ref = torch.stack([y.double().sum(dim=(2, 3)), (y.double() ** 2).sum(dim=(2, 3))], dim=-1).cpu()
