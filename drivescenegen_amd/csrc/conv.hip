@@ -271,7 +271,7 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(ConvP p) {
 #pragma unroll
         for (int nt = 0; nt < 2; ++nt) {
           const int y = oy0 + wave * 2 + nt;
-          rv[mt][r][nt] = has_r ? p.res[(((size_t)n * p.cout + co) * p.hout + y) * p.wout + x] : 0.f;
+          rv[mt][r][nt] = has_r ? p.res[(((size_t)n * p.cout + co) * p.hout + y) * p.wout + min(x, p.wout - 1)] : 0.f;
         }
       }
 #pragma unroll
@@ -279,7 +279,7 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(ConvP p) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int co = m0 + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-        if (co < p.cout) {
+        if (co < p.cout && x < p.wout) {  // (x >= wout only on maps narrower than a tile)
           const float add = p.bias ? p.bias[co] : 0.f;
           const float tv = has_t ? p.temb[(size_t)n * p.temb_stride + co] : 0.f;
 #pragma unroll
@@ -481,7 +481,7 @@ int conv2d_fwd_impl(const dsg_conv_args* a, hipStream_t st, int force_direct) {
   p.w = a->weight; p.bias = a->bias; p.ss = a->gn_scale_shift; p.silu = a->silu;
   p.temb = a->temb; p.temb_stride = a->temb_stride; p.res = a->residual; p.dst = a->dst;
   p.pool = a->pool2;
-  p.tiles_x = p.wout / TW; p.tiles_y = p.hout / TH;
+  p.tiles_x = (p.wout + TW - 1) / TW; p.tiles_y = p.hout / TH;
   DSG_CHECK_ARG(!(p.pool && ((p.hout | p.wout) & 1)), "dsg_conv2d_fwd: pool2 needs even output dims");
 
   if (!force_direct && conv_h2_eligible(a, p.hout, p.wout)) return conv_h2_launch(a, p.hout, p.wout, st);
@@ -489,7 +489,8 @@ int conv2d_fwd_impl(const dsg_conv_args* a, hipStream_t st, int force_direct) {
                 "dsg_conv2d_fwd: stats_out given but this call is not served by the kernel that produces them "
                 "(dsg_conv2d_stats_tiles reports 0)");
 
-  const bool tile_ok = (p.wout % TW == 0) && (p.hout % TH == 0) && (p.wstride % 32 == 0) && p.cin <= 2048 &&
+  const bool narrow = (p.wout == 16 || p.wout == 8) && !p.pool;  // less than one tile wide: the spare lanes idle
+  const bool tile_ok = (p.wout % TW == 0 || narrow) && (p.hout % TH == 0) && (p.wstride % 32 == 0) && p.cin <= 2048 &&
                        (p.wstride >= ((p.cout + 31) / 32) * 32);
   const int s = a->stride, k = a->ksize, u = a->upsample;
   if (!force_direct && tile_ok) {

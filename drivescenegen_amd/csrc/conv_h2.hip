@@ -496,10 +496,14 @@ __global__ __launch_bounds__(64 * NW, 1) void conv_h2_kernel(ConvH2P p) {
   for (int nt = 0; nt < NT; ++nt)
     voff[nt] = GM == 2 ? (4 * half * oplane + (2 * (oy0 + wave * NT + nt) + (phase >> 1)) * (2 * p.wout) +
                           2 * (ox0 + l31) + (phase & 1)) * 4
-                       : (4 * half * oplane + (oy0 + wave * NT + nt) * p.wout + ox0 + l31) * 4;
+                       : (ox0 + l31 < p.wout ? (4 * half * oplane + (oy0 + wave * NT + nt) * p.wout + ox0 + l31) * 4
+                                             : 0x7FFFFFF0);  // (narrow maps: past the last column -> out of range)
   const int oplane4 = __builtin_amdgcn_readfirstlane(oplane * 4);
-  auto epilogue = [&](auto stats_tag) {
-    constexpr bool STATS = decltype(stats_tag)::value;
+  // NARROW: maps less than one tile wide (16x16, 8x8): lanes past the last column store nothing (their offset is out
+  // of the descriptor's range) and count as zeros in the statistics
+  const bool lane_ok = ox0 + l31 < p.wout;
+  auto epilogue = [&](auto stats_tag, auto narrow_tag) {
+    constexpr bool STATS = decltype(stats_tag)::value, NARROW = decltype(narrow_tag)::value;
 #pragma unroll
     for (int mt = 0; mt < 2; ++mt) {
       float rv[16][NT], addv[16];
@@ -532,12 +536,13 @@ __global__ __launch_bounds__(64 * NW, 1) void conv_h2_kernel(ConvH2P p) {
         for (int nt = 0; nt < NT; ++nt) {
           const float v = ((acc_hi[mt][nt][r] + acc_lo[mt][nt][r] * (1.0f / 2048.0f)) + addv[r]) + rv[r][nt];
           __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, v), dst_rs, voff[nt], crel * oplane4, 0);
+          const float vs = (NARROW && !lane_ok) ? 0.f : v;
           if (nt & 1) {
-            s1[nt / 2] += v;
-            s2[nt / 2] += v * v;
+            s1[nt / 2] += vs;
+            s2[nt / 2] += vs * vs;
           } else {
-            s1[nt / 2] = v;
-            s2[nt / 2] = v * v;
+            s1[nt / 2] = vs;
+            s2[nt / 2] = vs * vs;
           }
         }
         if (STATS) {  // GroupNorm statistics of the tensor just produced (the next layer's norm reads them)
@@ -554,8 +559,13 @@ __global__ __launch_bounds__(64 * NW, 1) void conv_h2_kernel(ConvH2P p) {
       }
     }
   };
-  if (want_stats) epilogue(T{});
-  else epilogue(F{});
+  if (p.wout < H2_TW) {
+    if (want_stats) epilogue(T{}, T{});
+    else epilogue(F{}, T{});
+  } else {
+    if (want_stats) epilogue(T{}, F{});
+    else epilogue(F{}, F{});
+  }
   if (want_stats) {
     // statistics tiles are 8 rows x 32 columns (4 row pairs, summed in row order in fp64) whatever NT is, so the
     // values -- and everything downstream of the norm -- do not depend on the launch geometry
@@ -657,7 +667,7 @@ bool conv_h2_eligible(const dsg_conv_args* a, int hout, int wout) {
            cin % 16 == 0 && (a->c1 == 0 || a->c0 % 16 == 0) && (hout * wout) % (8 * H2_TW) == 0 && a->cout % 8 == 0;
   if (a->gn_scale_shift && (!a->silu || a->upsample)) return false;  // combinations the U-Net does not have
   return g_h2_enabled && a->weight_h2 != nullptr && a->stride == 1 && a->upsample <= 1 && !a->pool2 &&
-         cin % 16 == 0 && (a->c1 == 0 || a->c0 % 16 == 0) && (wout % H2_TW == 0) && (hout % 8 == 0) &&
+         cin % 16 == 0 && (a->c1 == 0 || a->c0 % 16 == 0) && (wout % H2_TW == 0 || wout == 16 || wout == 8) && (hout % 8 == 0) &&
          a->cout % 8 == 0;
 }
 
@@ -679,7 +689,8 @@ static bool conv_h2_rows16(const dsg_conv_args* a, int hout, int wout) {
 
 int conv_h2_stats_tiles(const dsg_conv_args* a, int hout, int wout) {
   if (!g_h2_stats || !conv_h2_eligible(a, hout, wout)) return 0;
-  return hout * wout / (H2_TW * 8);  // 8-row x 32-column statistics tiles for either block height
+  if (a->ksize == 1) return hout * wout / (8 * H2_TW);  // (pointwise: the map is re-tiled as rows of 32 pixels)
+  return (hout / 8) * ((wout + H2_TW - 1) / H2_TW);  // 8-row x 32-column statistics tiles for either block height
 }
 
 int conv_h2_launch(const dsg_conv_args* a, int hout, int wout, hipStream_t st) {
@@ -706,7 +717,7 @@ int conv_h2_launch(const dsg_conv_args* a, int hout, int wout, hipStream_t st) {
   p.res = a->residual; p.dst = a->dst;
   // 16-row tiles (NT = 4) when they still give every CU a workgroup; 8-row tiles otherwise
   const int th = nt4 ? 16 : 8;
-  p.tiles_x = wout / H2_TW; p.tiles_y = hout / th;
+  p.tiles_x = (wout + H2_TW - 1) / H2_TW; p.tiles_y = hout / th;
   const bool k1 = a->ksize == 1;
   const size_t lds = 2 * (size_t)(k1 ? (nt4 ? H2Geom<4, 1>::BUF_BYTES : H2Geom<2, 1>::BUF_BYTES)
                                      : (nt4 ? H2Geom<4, 3>::BUF_BYTES : H2Geom<2, 3>::BUF_BYTES)) +

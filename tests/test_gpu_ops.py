@@ -37,6 +37,8 @@ CONV_CASES = [
     ("concat_straddle", 128, 64, 128, 16, 32, 3, 1, False, True, True, True, False),
     ("upsample", 64, 0, 64, 16, 16, 3, 1, True, False, False, False, False),
     ("stride2", 64, 0, 64, 32, 64, 3, 2, False, False, False, False, False),
+    ("stride2_narrow_out16", 64, 0, 64, 32, 32, 3, 2, False, False, False, False, True),   # 16-wide result: idle lanes
+    ("narrow_16x16_f32", 24, 0, 32, 16, 16, 3, 1, False, True, True, True, True),
     ("shortcut_1x1_kc32", 128, 64, 64, 16, 32, 1, 1, False, False, False, False, False),
     ("proj_1x1_kc8", 40, 0, 64, 8, 32, 1, 1, False, True, False, False, True),
     ("conv_in_direct", 3, 0, 64, 32, 32, 3, 1, False, False, False, False, False),
@@ -219,6 +221,8 @@ H2_CASES = [
     ("h2_concat_straddle", 128, 64, 128, 16, 32, False, True, True, False),
     ("h2_upsample", 64, 0, 64, 16, 16, True, False, False, False),
     ("h2_cout96_pad", 32, 0, 96, 8, 32, False, True, False, True),
+    ("h2_narrow_16x16", 64, 0, 64, 16, 16, False, True, True, True),       # map narrower than a tile: masked lanes
+    ("h2_narrow_8x8_concat", 32, 32, 128, 8, 8, False, True, False, False),
     ("h2_upsample_fold", 64, 0, 128, 16, 32, True, False, False, False, 3, True),   # x2 folded into 2x2 phase kernels
     ("h2_upsample_fold_rows8", 32, 0, 64, 8, 32, True, False, False, True, 3, True),
     # pointwise (shortcut / attention projections): k = 1 flagged by a trailing element
@@ -279,6 +283,7 @@ STATS_CASES = [
     ("stats_1x1_16x16", 64, 0, 128, 16, 16, 1, False),
     ("stats_upsample", 64, 0, 64, 16, 16, 3, True),
     ("stats_upsample_fold", 64, 0, 64, 16, 32, 3, True, True),
+    ("stats_narrow_16x16", 32, 0, 64, 16, 16, 3, False),
 ]
 
 
