@@ -318,15 +318,21 @@ int dsg_rasterize_boxes(const float* boxes, int32_t nbox, float* out, int32_t h,
  * Measurement plumbing (no reference counterpart): per-kernel-class HIP-event timing on the launch
  * stream, used by bench.py's roofline leg.  Classes: 0 conv3x3 stride-1, 1 conv3x3 on the nearest-x2
  * upsampled input, 2 conv3x3 stride-2, 3 conv1x1, 4 direct (VALU) conv, 5 conv weight-gradient, 6 / 7 / 8 conv3x3
- * stride-1 / conv3x3 upsampled / conv1x1 on the fp16x2-split matrix-core path.  FLOPs/bytes are the
+ * stride-1 / conv3x3 upsampled / conv1x1 on the fp16x2-split matrix-core path, 9 its 3x3 weight gradient.  FLOPs/bytes are the
  * algorithmic figures of each launch (2*MACs; input + weights + output once).
  * ---------------------------------------------------------------------------------------- */
 int dsg_prof_enable(int32_t on);
 int dsg_prof_summary(int32_t kernel_class, double* total_ms, double* total_flops, double* total_bytes,
                      int64_t* launches);
 int dsg_prof_dump(const char* csv_path);
-/* Tuning switches (key 1: K-chunk of the fp32 3x3 conv kernel, 0 = by grid size | 4 | 8; key 2: fp16x2-split
- * 3x3 kernel 1 = on (default) | 0 = off, i.e. pure fp32 MFMA). */
+/* Kernel-selection switches for A/B measurements (defaults in brackets; python: env DSG_TUNING="key=value,..."):
+ *   1  K-chunk of the fp32 conv kernel: [0 = by grid size] | 4 | 8
+ *   2  fp16x2-split conv kernels: [1] | 0 = every contraction on the f32 MFMA
+ *   3  rows per wave of the split conv kernel: [0 = by grid size] | 2 | 4
+ *   5  GroupNorm statistics from the producing conv's epilogue: [1] | 0 = a pass of their own
+ *   6  waves per workgroup of the 16-row split conv: [4] | 8 (two per SIMD)
+ *   7  3x3 weight gradient on the split path: [1] | 0 = f32 MFMA
+ *   8  up-sampler convs folded into 2x2 phase convs: [1] | 0 = nearest-x2 gather */
 int dsg_set_tuning(int32_t key, int32_t value);
 
 #ifdef __cplusplus
