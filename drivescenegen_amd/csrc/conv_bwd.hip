@@ -461,6 +461,9 @@ __global__ __launch_bounds__(256, 1) void conv_wgrad_h2_kernel(WgradP p) {
 
   const _Float16* a_lane = ab + l31 * WH_ASTR + half * 8;
   const _Float16* d_lane = dbase + (cot * 32 + l31) * WH_DSTR + half * 8;
+  // (one loop per tap half, not one loop with a branch inside: with the branch inside, the accumulators of the two
+  // variants met in phi nodes and were copied between VGPRs and AGPRs every stage)
+  auto run = [&](auto first_tag) {
   for (int s = s0; s < s1; ++s) {
     const int par = (s - s0) & 1;
     const bool more = s + 1 < s1;
@@ -469,55 +472,53 @@ __global__ __launch_bounds__(256, 1) void conv_wgrad_h2_kernel(WgradP p) {
 #pragma unroll
     for (int j = 0; j < 4; ++j) slot_off[j] = ((2 * s + j) % WH_SLOTS) * 32;
     const _Float16* dl = d_lane + par * WH_D_HALFS;
-    auto stage = [&](auto first_tag) {
+    {
       constexpr bool FIRST = decltype(first_tag)::value;
       constexpr int T0 = FIRST ? 0 : 5, NTP = FIRST ? 5 : 4;
-      whalf8 fa[2][NTP][2], fb[2][2];
-      auto frags = [&](int kk, int fp) {
+      // Operands are fetched one (k-step, tap) step ahead into the other half of a small register double buffer
+      // (2 x 8 registers for the patch, 2 x 8 for dY): holding a whole k-step's fragments for all taps at once
+      // pushed the kernel past its register file (hundreds of accvgpr spill moves per stage).
+      whalf8 fa[2][2], fb[2][2];
+      constexpr int NSTEP = 4 * NTP;
+      auto fetch = [&](int i) {  // step i = (kk, tp)
+        const int kk = i / NTP, tp = i % NTP;
         const int orow = kk >> 1, colg = (kk & 1) * 16;
-        fb[fp][0] = *reinterpret_cast<const whalf8*>(dl + orow * 32 + colg);
-        fb[fp][1] = *reinterpret_cast<const whalf8*>(dl + 64 * WH_DSTR + orow * 32 + colg);
-#pragma unroll
-        for (int tp = 0; tp < NTP; ++tp) {
-          const int dy = (T0 + tp) / 3, dx = (T0 + tp) % 3;
-          const _Float16* ap = a_lane + slot_off[orow + dy] + colg;
-          fa[fp][tp][0] = *reinterpret_cast<const whalf8*>(ap + (dx * 2 + 0) * 32 * WH_ASTR);
-          fa[fp][tp][1] = *reinterpret_cast<const whalf8*>(ap + (dx * 2 + 1) * 32 * WH_ASTR);
+        if (tp == 0) {
+          fb[kk & 1][0] = *reinterpret_cast<const whalf8*>(dl + orow * 32 + colg);
+          fb[kk & 1][1] = *reinterpret_cast<const whalf8*>(dl + 64 * WH_DSTR + orow * 32 + colg);
         }
+        const int dy = (T0 + tp) / 3, dx = (T0 + tp) % 3;
+        const _Float16* ap = a_lane + slot_off[orow + dy] + colg;
+        fa[i & 1][0] = *reinterpret_cast<const whalf8*>(ap + (dx * 2 + 0) * 32 * WH_ASTR);
+        fa[i & 1][1] = *reinterpret_cast<const whalf8*>(ap + (dx * 2 + 1) * 32 * WH_ASTR);
       };
-      frags(0, 0);
+      fetch(0);
 #pragma unroll
-      for (int kk = 0; kk < 4; ++kk) {
+      for (int i = 0; i < NSTEP; ++i) {
+        const int kk = i / NTP, tp = i % NTP;
         __builtin_amdgcn_sched_barrier(0);
-        if (kk < 3) frags(kk + 1, (kk + 1) & 1);  // operands one k-step ahead (before this step's LDS writes)
-        // next stage's staging rides on the MFMAs: rows at k-step 0, dY at 1, the fetches after them at 2
-        if (kk == 0) commit_rows(s + 2);
-        if (kk == 1 && more) commit_dy(par ^ 1);
-        if (kk == 2) {
+        if (i + 1 < NSTEP) fetch(i + 1);  // (before this step's LDS writes in program order)
+        // next stage's staging rides on the MFMAs: rows at the first step, dY a k-step later; each is followed at
+        // once by the fetch of the stage after it into the registers just freed (a whole stage for the loads to land)
+        if (i == 0) {
+          commit_rows(s + 2);
           load_rows(s + 3);
+        }
+        if (i == NTP) {
+          if (more) commit_dy(par ^ 1);
           if (s + 2 < s1) load_dy(s + 2);
         }
-        const int fp = kk & 1;
-#pragma unroll
-        for (int tp = 0; tp < NTP; ++tp) {
-          acc_hi[tp] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[fp][tp][0], fb[fp][0], acc_hi[tp], 0, 0, 0);
-          acc_lo[tp] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[fp][tp][0], fb[fp][1], acc_lo[tp], 0, 0, 0);
-          acc_lo[tp] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[fp][tp][1], fb[fp][0], acc_lo[tp], 0, 0, 0);
-        }
-        if (kk < 2) {
-#pragma unroll
-          for (int m = 0; m < 3 * NTP; ++m) {
-            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-            __builtin_amdgcn_sched_group_barrier(0x002, 5, 0);
-          }
-        }
+        acc_hi[tp] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[i & 1][0], fb[kk & 1][0], acc_hi[tp], 0, 0, 0);
+        acc_lo[tp] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[i & 1][0], fb[kk & 1][1], acc_lo[tp], 0, 0, 0);
+        acc_lo[tp] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[i & 1][1], fb[kk & 1][0], acc_lo[tp], 0, 0, 0);
       }
       __builtin_amdgcn_sched_barrier(0);
-    };
-    if (first) stage(std::true_type{});
-    else stage(std::false_type{});
+    }
     __syncthreads();
   }
+  };
+  if (first) run(std::true_type{});
+  else run(std::false_type{});
 
   // epilogue: D[ci][co = l31]; partials to this run's slab [tap][ci][co]
   const int co = co0 + cot * 32 + l31;
