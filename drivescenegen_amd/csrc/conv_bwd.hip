@@ -389,10 +389,12 @@ __global__ __launch_bounds__(256, 1) void conv_wgrad_h2_kernel(WgradP p) {
     hi = (unsigned)__builtin_bit_cast(unsigned short, a0) | ((unsigned)__builtin_bit_cast(unsigned short, a1) << 16);
     lo = (unsigned)__builtin_bit_cast(unsigned short, b0) | ((unsigned)__builtin_bit_cast(unsigned short, b1) << 16);
   };
-  auto commit_rows = [&](int k) {  // the values of load_rows(k) -> ring slots (2k) % 6, (2k + 1) % 6, three shifts
-    unsigned ph[5], pl[5];
+  // the values of load_rows(k) -> ring slots (2k) % 6, (2k + 1) % 6, three shifts; in two parts so that the work can
+  // be dealt over two k-steps of MFMAs (part 0: element pairs 0..2, part 1: pairs 3..4, the shifts and the writes)
+  unsigned ph[5], pl[5];
+  auto commit_rows = [&](int k, int part) {
 #pragma unroll
-    for (int j2 = 0; j2 < 5; ++j2) {
+    for (int j2 = (part == 1 ? 3 : 0); j2 < (part == 0 ? 3 : 5); ++j2) {
       float v[2];
 #pragma unroll
       for (int e = 0; e < 2; ++e) {
@@ -404,6 +406,7 @@ __global__ __launch_bounds__(256, 1) void conv_wgrad_h2_kernel(WgradP p) {
       }
       split2(v[0], v[1], ph[j2], pl[j2]);
     }
+    if (part == 0) return;
     const int slot = (2 * k) % WH_SLOTS + a_rr;  // (2k % 6 is even, so + rr stays inside the ring)
     _Float16* dst = ab + a_ci * WH_ASTR + slot * 32 + a_oct * 8;
 #pragma unroll
@@ -423,10 +426,10 @@ __global__ __launch_bounds__(256, 1) void conv_wgrad_h2_kernel(WgradP p) {
       *reinterpret_cast<uint4*>(dst + (s * 2 + 1) * 32 * WH_ASTR) = wl;
     }
   };
-  auto commit_dy = [&](int par) {
+  auto commit_dy = [&](int par, int u0, int u1) {
     _Float16* db = dbase + par * WH_D_HALFS;
 #pragma unroll
-    for (int u = 0; u < 2; ++u) {
+    for (int u = u0; u < u1; ++u) {
       uint4 dh, dl;
       split2(xd[u][0].x, xd[u][0].y, dh.x, dl.x);
       split2(xd[u][0].z, xd[u][0].w, dh.y, dl.y);
@@ -450,10 +453,10 @@ __global__ __launch_bounds__(256, 1) void conv_wgrad_h2_kernel(WgradP p) {
   if (s0 < s1) {
     load_rows(s0);
     load_dy(s0);
-    commit_rows(s0);
+    commit_rows(s0, 2);
     load_rows(s0 + 1);
-    commit_dy(0);
-    commit_rows(s0 + 1);
+    commit_dy(0, 0, 2);
+    commit_rows(s0 + 1, 2);
     load_rows(s0 + 2);               // (past the image: masked to zero)
     if (s0 + 1 < s1) load_dy(s0 + 1);
   }
@@ -475,42 +478,53 @@ __global__ __launch_bounds__(256, 1) void conv_wgrad_h2_kernel(WgradP p) {
     {
       constexpr bool FIRST = decltype(first_tag)::value;
       constexpr int T0 = FIRST ? 0 : 5, NTP = FIRST ? 5 : 4;
-      // Operands are fetched one (k-step, tap) step ahead into the other half of a small register double buffer
-      // (2 x 8 registers for the patch, 2 x 8 for dY): holding a whole k-step's fragments for all taps at once
-      // pushed the kernel past its register file (hundreds of accvgpr spill moves per stage).
-      whalf8 fa[2][2], fb[2][2];
-      constexpr int NSTEP = 4 * NTP;
-      auto fetch = [&](int i) {  // step i = (kk, tp)
-        const int kk = i / NTP, tp = i % NTP;
+      // Operands are fetched one k-step ahead into the other half of a register double buffer: the reads of k-step
+      // kk+1 precede k-step kk's staging writes in program order, so kk's MFMAs depend on registers only and the
+      // scheduler may interleave them with the staging work (LDS reads after a possibly-aliasing write cannot move).
+      whalf8 fa[2][NTP][2], fb[2][2];
+      auto frags = [&](int kk, int fp) {
         const int orow = kk >> 1, colg = (kk & 1) * 16;
-        if (tp == 0) {
-          fb[kk & 1][0] = *reinterpret_cast<const whalf8*>(dl + orow * 32 + colg);
-          fb[kk & 1][1] = *reinterpret_cast<const whalf8*>(dl + 64 * WH_DSTR + orow * 32 + colg);
-        }
-        const int dy = (T0 + tp) / 3, dx = (T0 + tp) % 3;
-        const _Float16* ap = a_lane + slot_off[orow + dy] + colg;
-        fa[i & 1][0] = *reinterpret_cast<const whalf8*>(ap + (dx * 2 + 0) * 32 * WH_ASTR);
-        fa[i & 1][1] = *reinterpret_cast<const whalf8*>(ap + (dx * 2 + 1) * 32 * WH_ASTR);
-      };
-      fetch(0);
+        fb[fp][0] = *reinterpret_cast<const whalf8*>(dl + orow * 32 + colg);
+        fb[fp][1] = *reinterpret_cast<const whalf8*>(dl + 64 * WH_DSTR + orow * 32 + colg);
 #pragma unroll
-      for (int i = 0; i < NSTEP; ++i) {
-        const int kk = i / NTP, tp = i % NTP;
+        for (int tp = 0; tp < NTP; ++tp) {
+          const int dy = (T0 + tp) / 3, dx = (T0 + tp) % 3;
+          const _Float16* ap = a_lane + slot_off[orow + dy] + colg;
+          fa[fp][tp][0] = *reinterpret_cast<const whalf8*>(ap + (dx * 2 + 0) * 32 * WH_ASTR);
+          fa[fp][tp][1] = *reinterpret_cast<const whalf8*>(ap + (dx * 2 + 1) * 32 * WH_ASTR);
+        }
+      };
+      frags(0, 0);
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk) {
         __builtin_amdgcn_sched_barrier(0);
-        if (i + 1 < NSTEP) fetch(i + 1);  // (before this step's LDS writes in program order)
-        // next stage's staging rides on the MFMAs: rows at the first step, dY a k-step later; each is followed at
-        // once by the fetch of the stage after it into the registers just freed (a whole stage for the loads to land)
-        if (i == 0) {
-          commit_rows(s + 2);
+        if (kk < 3) frags(kk + 1, (kk + 1) & 1);
+        // next stage's staging is dealt over the four k-steps and pinned between their MFMAs: patch rows (two
+        // parts), then the two dY items; each fetch of the stage after it follows its commit at once
+        if (kk == 0) commit_rows(s + 2, 0);
+        if (kk == 1) {
+          commit_rows(s + 2, 1);
           load_rows(s + 3);
         }
-        if (i == NTP) {
-          if (more) commit_dy(par ^ 1);
-          if (s + 2 < s1) load_dy(s + 2);
+        // (unconditional: past the run's last stage the values are never read and the loads are range-checked to
+        // zero -- a branch here would fence the scheduler)
+        if (kk == 2) commit_dy(par ^ 1, 0, 1);
+        if (kk == 3) {
+          commit_dy(par ^ 1, 1, 2);
+          load_dy(s + 2);
         }
-        acc_hi[tp] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[i & 1][0], fb[kk & 1][0], acc_hi[tp], 0, 0, 0);
-        acc_lo[tp] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[i & 1][0], fb[kk & 1][1], acc_lo[tp], 0, 0, 0);
-        acc_lo[tp] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[i & 1][1], fb[kk & 1][0], acc_lo[tp], 0, 0, 0);
+        const int fp = kk & 1;
+#pragma unroll
+        for (int tp = 0; tp < NTP; ++tp) {
+          acc_hi[tp] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[fp][tp][0], fb[fp][0], acc_hi[tp], 0, 0, 0);
+          acc_lo[tp] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[fp][tp][0], fb[fp][1], acc_lo[tp], 0, 0, 0);
+          acc_lo[tp] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[fp][tp][1], fb[fp][0], acc_lo[tp], 0, 0, 0);
+        }
+#pragma unroll
+        for (int m = 0; m < 3 * NTP; ++m) {
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+          __builtin_amdgcn_sched_group_barrier(0x002, 5, 0);
+        }
       }
       __builtin_amdgcn_sched_barrier(0);
     }
