@@ -600,7 +600,7 @@ static void wgrad_h2_runs(int cin, int cout, int n, int hout, int wout, int* str
   const int pairs = (cin / 32) * (cout / WG_CO);
   *strips = n * (wout / 32);
   const int stages = hout / 2;
-  const int want = std::max(1, cdiv(1024, pairs));            // workgroups wanted per (ci, co) pair
+  const int want = std::max(1, cdiv(512, pairs));             // workgroups wanted per (ci, co) pair (2 per CU in all)
   *rsplit = std::max(1, std::min(stages, cdiv(want, *strips)));
 }
 

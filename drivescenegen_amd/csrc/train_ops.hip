@@ -170,15 +170,27 @@ __global__ void linear_wgrad_kernel(const float* __restrict__ x, const float* __
   dw[i] += s;
 }
 
-// dx[n][k] = sum_m dy[n][m] W[m][k]; one thread per (n, k)
-__global__ void linear_dgrad_kernel(const float* __restrict__ dy, const float* __restrict__ w, int n, int in_f,
-                                    int out_f, int dy_stride, float* __restrict__ dx) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n * in_f) return;
-  const int k = i % in_f, j = i / in_f;
+// dx[n][k] = sum_m dy[n][m] W[m][k]; a workgroup owns one n and 32 k's, its 8 wave-halves stride over m (the
+// all-time-embedding projection has 5824 rows: one thread per (n, k) walked them serially in a millisecond) and are
+// summed in a fixed order
+__global__ __launch_bounds__(256) void linear_dgrad_kernel(const float* __restrict__ dy, const float* __restrict__ w,
+                                                           int n, int in_f, int out_f, int dy_stride,
+                                                           float* __restrict__ dx) {
+  __shared__ float part[8][32];
+  const int kt = blockIdx.x, j = blockIdx.y;
+  const int kk = threadIdx.x & 31, ms = threadIdx.x >> 5;
+  const int k = kt * 32 + kk;
   float s = 0.f;
-  for (int m = 0; m < out_f; ++m) s = fmaf(dy[(size_t)j * dy_stride + m], w[(size_t)m * in_f + k], s);
-  dx[i] = s;
+  if (k < in_f)
+    for (int m = ms; m < out_f; m += 8) s = fmaf(dy[(size_t)j * dy_stride + m], w[(size_t)m * in_f + k], s);
+  part[ms][kk] = s;
+  __syncthreads();
+  if (ms == 0 && k < in_f) {
+    float t = part[0][kk];
+#pragma unroll
+    for (int i = 1; i < 8; ++i) t += part[i][kk];
+    dx[(size_t)j * in_f + k] = t;
+  }
 }
 
 __global__ void silu_fwd_kernel(const float* __restrict__ z, int64_t numel, float* __restrict__ y) {
@@ -326,7 +338,7 @@ DSG_API int dsg_linear_bwd(const float* x, const float* w, const float* dy, int3
     DSG_LAUNCH_CHECK();
   }
   if (dx) {
-    hipLaunchKernelGGL(dsg::linear_dgrad_kernel, dim3(cdiv(n * in_f, 256)), dim3(256), 0, st, dy, w, n, in_f, out_f,
+    hipLaunchKernelGGL(dsg::linear_dgrad_kernel, dim3(cdiv(in_f, 32), n), dim3(256), 0, st, dy, w, n, in_f, out_f,
                        dy_stride, dx);
     DSG_LAUNCH_CHECK();
   }
