@@ -4,8 +4,8 @@ import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from drivescenegen_amd import ops
-B = 16
-for name, c, h in (("res512@32", 512, 32), ("res256@64", 256, 64), ("res128@128", 128, 128), ("res64@256", 64, 256)):
+for name, c, h, B in (("res512@32", 512, 32, 16), ("res256@64", 256, 64, 16), ("res128@128", 128, 128, 16),
+                      ("res64@256", 64, 256, 16), ("res64@64 B=256", 64, 64, 256), ("res64@512 B=4", 64, 512, 4)):
     x = torch.randn(B, c, h, h, device="cuda")
     w = torch.randn(c, c, 3, 3, device="cuda") * 0.05
     wr, wh = ops.relayout_conv_weight(w), ops.relayout_conv_weight_h2(w)
