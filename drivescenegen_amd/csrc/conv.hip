@@ -403,6 +403,7 @@ void conv_h2_set_waves(int w);
 void wgrad_h2_set_enabled(int on);
 void conv_h2_set_fold(int on);
 
+static int g_conv_fewout = 1;  // VALU kernel for cout <= 4 (tuning key 10: A/B against the zero-padded MFMA tile)
 static int g_conv_kc = 0;  // K-chunk of the 3x3 stride-1 kernel: 4 | 8 | 0 = by grid size (measured, r01)
 
 template <int KS, int STRIDE, int GM, int MT, int KC>
@@ -429,6 +430,137 @@ static int launch_mfma(const ConvP& p, hipStream_t st) {
     pi = prof_begin(KS == 1 ? 3 : (STRIDE == 2 ? 2 : (GM ? 1 : 0)), flops, bytes, st);
   }
   hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, p);
+  prof_end(pi, st);
+  DSG_LAUNCH_CHECK();
+  return DSG_OK;
+}
+
+
+// conv_out (64 -> 3/4 channels, GroupNorm + SiLU in front): with so few output channels the matrix cores would
+// compute 8x more columns than exist, so this one runs on the VALU from an LDS-staged patch: a workgroup owns a
+// 16-row x 32-column tile, stages 16 channels of the activated 18 x 34 halo patch per step and every thread holds
+// 2 pixels x 4 output channels (each patch value read from LDS feeds 4 FMAs, each weight quad 2 pixels).
+// Weights are the engine layout [cin][9][wstride]; fp32 fmaf chains in channel-major order.
+constexpr int FO_TH = 16, FO_PW = 35, FO_PH = 18, FO_KC = 16, FO_CST = FO_PH * FO_PW;  // (35: odd row stride)
+
+__global__ __launch_bounds__(256, 2) void conv_fewout_kernel(ConvP p) {
+  __shared__ float xs[FO_KC * FO_CST];
+  __shared__ __attribute__((aligned(16))) float wsm[FO_KC * 9 * 4];
+  const int tid = threadIdx.x;
+  int bid = blockIdx.x;
+  const int tx = bid % p.tiles_x;
+  bid /= p.tiles_x;
+  const int ty = bid % p.tiles_y;
+  const int n = bid / p.tiles_y;
+  const int oy0 = ty * FO_TH, ox0 = tx * TW;
+  const int plane = p.hin * p.win;
+  const int col = tid & 31, r0 = tid >> 5;  // pixels (r0, col) and (r0 + 8, col)
+  float acc[2][4];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = 0.f;
+  const bool has_ss = p.ss != nullptr;
+  // this thread's (up to 3) patch positions: global offset, LDS offset, inside-the-image flag -- once per tile
+  int goff[3], loff[3];
+  bool ok[3];
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    const int pos = tid + 256 * k;
+    const int py = pos / 34, px = pos - py * 34;
+    const int gy = oy0 - 1 + py, gx = ox0 - 1 + px;
+    ok[k] = pos < FO_PH * 34 && gy >= 0 && gy < p.hc && gx >= 0 && gx < p.wc;
+    goff[k] = ok[k] ? gy * p.win + gx : 0;
+    loff[k] = pos < FO_PH * 34 ? py * FO_PW + px : -1;
+  }
+  // the raw values of the next 16 channels are fetched into registers while the current 16 are being used
+  float xr[FO_KC][3];
+  auto fetch = [&](int c0) {
+    const float* spb = (c0 < p.c0) ? p.src0 + ((size_t)n * p.c0 + c0) * plane
+                                   : p.src1 + ((size_t)n * p.c1 + (c0 - p.c0)) * plane;  // (uniform: c0 % 16 == 0)
+#pragma unroll
+    for (int c = 0; c < FO_KC; ++c)
+#pragma unroll
+      for (int k = 0; k < 3; ++k) xr[c][k] = spb[(size_t)c * plane + goff[k]];
+  };
+  fetch(0);
+  for (int c0 = 0; c0 < p.cin; c0 += FO_KC) {
+    __syncthreads();
+    // stage: 16 channels x 18 x 34 activated values (zero outside the image), and their 16 x 9 x 4 weights
+    const float* ssb = has_ss ? p.ss + ((size_t)n * p.cin + c0) * 2 : nullptr;
+#pragma unroll
+    for (int c = 0; c < FO_KC; ++c) {
+      float sc = 1.f, sh = 0.f;
+      if (has_ss) {
+        sc = ssb[2 * c];
+        sh = ssb[2 * c + 1];
+      }
+#pragma unroll
+      for (int k = 0; k < 3; ++k) {
+        if (loff[k] >= 0) {
+          float v = xr[c][k];
+          if (has_ss) {
+            v = v * sc + sh;
+            if (p.silu) v = silu_fast(v);
+          }
+          xs[c * FO_CST + loff[k]] = ok[k] ? v : 0.f;
+        }
+      }
+    }
+    for (int e = tid; e < FO_KC * 9 * 4; e += 256) {
+      const int j = e & 3, ct = e >> 2;  // ct = c * 9 + tap
+      wsm[e] = (j < p.cout) ? p.w[((size_t)c0 * 9 + ct) * p.wstride + j] : 0.f;
+    }
+    __syncthreads();
+    if (c0 + FO_KC < p.cin) fetch(c0 + FO_KC);
+#pragma unroll 2
+    for (int c = 0; c < FO_KC; ++c) {
+      const float* xp = xs + c * FO_CST + r0 * FO_PW + col;
+#pragma unroll
+      for (int t = 0; t < 9; ++t) {
+        typedef float f2 __attribute__((ext_vector_type(2)));
+        const float4 wq = *reinterpret_cast<const float4*>(wsm + (c * 9 + t) * 4);
+        const f2 w01 = {wq.x, wq.y}, w23 = {wq.z, wq.w};
+        const float a0 = xp[(t / 3) * FO_PW + (t % 3)], a1 = xp[(t / 3 + 8) * FO_PW + (t % 3)];
+        const f2 b0 = {a0, a0}, b1 = {a1, a1};
+        f2& c00 = *reinterpret_cast<f2*>(&acc[0][0]);
+        f2& c02 = *reinterpret_cast<f2*>(&acc[0][2]);
+        f2& c10 = *reinterpret_cast<f2*>(&acc[1][0]);
+        f2& c12 = *reinterpret_cast<f2*>(&acc[1][2]);
+        c00 = __builtin_elementwise_fma(w01, b0, c00);  // (v_pk_fma_f32: two output channels per instruction)
+        c02 = __builtin_elementwise_fma(w23, b0, c02);
+        c10 = __builtin_elementwise_fma(w01, b1, c10);
+        c12 = __builtin_elementwise_fma(w23, b1, c12);
+      }
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int y = oy0 + r0 + 8 * i, x = ox0 + col;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      if (j < p.cout) {
+        const size_t idx = (((size_t)n * p.cout + j) * p.hout + y) * p.wout + x;
+        float v = acc[i][j] + (p.bias ? p.bias[j] : 0.f);
+        if (p.temb) v = v + p.temb[(size_t)n * p.temb_stride + j];
+        if (p.res) v = v + p.res[idx];
+        p.dst[idx] = v;
+      }
+    }
+  }
+}
+
+static int launch_fewout(const ConvP& p, hipStream_t st) {
+  int pi = -1;
+  if (prof_on()) {
+    const double px = (double)p.n * p.hout * p.wout;
+    pi = prof_begin(4, 2.0 * px * p.cout * p.cin * 9,
+                    4.0 * ((double)p.n * p.cin * p.hin * p.win + (double)p.cin * 9 * p.cout + px * p.cout), st);
+  }
+  ConvP q = p;
+  q.tiles_x = p.wout / TW;
+  q.tiles_y = p.hout / FO_TH;
+  hipLaunchKernelGGL(conv_fewout_kernel, dim3(q.tiles_x * q.tiles_y * q.n), dim3(256), 0, st, q);
   prof_end(pi, st);
   DSG_LAUNCH_CHECK();
   return DSG_OK;
@@ -493,6 +625,9 @@ int conv2d_fwd_impl(const dsg_conv_args* a, hipStream_t st, int force_direct) {
   const bool tile_ok = (p.wout % TW == 0 || narrow) && (p.hout % TH == 0) && (p.wstride % 32 == 0) && p.cin <= 2048 &&
                        (p.wstride >= ((p.cout + 31) / 32) * 32);
   const int s = a->stride, k = a->ksize, u = a->upsample;
+  if (!force_direct && g_conv_fewout && k == 3 && s == 1 && u == 0 && !p.pool && p.cout <= 4 && p.cin % FO_KC == 0 &&
+      (p.c1 == 0 || p.c0 % FO_KC == 0) && p.wout % TW == 0 && p.hout % FO_TH == 0)
+    return launch_fewout(p, st);  // conv_out: too few output channels for the matrix cores
   if (!force_direct && tile_ok) {
     const bool mt2 = (p.wstride % 64 == 0) && p.cout > 32;
     const bool dual_ok4 = p.c1 == 0 || p.c0 % 4 == 0;
@@ -538,6 +673,10 @@ DSG_API int dsg_set_tuning(int32_t key, int32_t value) {
   }
   if (key == 3 && (value == 0 || value == 2 || value == 4)) {
     dsg::conv_h2_set_rows(value);
+    return DSG_OK;
+  }
+  if (key == 10 && (value == 0 || value == 1)) {
+    dsg::g_conv_fewout = value;
     return DSG_OK;
   }
   if (key == 8 && (value == 0 || value == 1)) {

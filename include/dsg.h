@@ -332,7 +332,8 @@ int dsg_prof_dump(const char* csv_path);
  *   5  GroupNorm statistics from the producing conv's epilogue: [1] | 0 = a pass of their own
  *   6  waves per workgroup of the 16-row split conv: [4] | 8 (two per SIMD)
  *   7  3x3 weight gradient on the split path: [1] | 0 = f32 MFMA
- *   8  up-sampler convs folded into 2x2 phase convs: [1] | 0 = nearest-x2 gather */
+ *   8  up-sampler convs folded into 2x2 phase convs: [1] | 0 = nearest-x2 gather
+ *  10  conv_out (cout <= 4) on the VALU kernel: [1] | 0 = zero-padded matrix-core tile */
 int dsg_set_tuning(int32_t key, int32_t value);
 
 #ifdef __cplusplus
