@@ -321,3 +321,58 @@ def test_conv_epilogue_groupnorm_statistics(case):
     # a conv the statistics kernel does not serve reports no tiles instead of writing nothing
     _, none = ops.conv2d_fused(x0, wr, bias, src1=x1, ksize=k, upsample=ups, cout=cout, want_stats=True)
     assert none is None
+
+
+def _rand_conv_cases(n=24, seed=14555):
+    """Seeded random draws over what the split-path dispatcher accepts: channel splits, padded cout tiles, tile-aligned
+    and narrow maps, 3x3 / 1x1, folded / gathered up-sampling, residual / temb / norm combinations, batch 1..3."""
+    rng = np.random.default_rng(seed)
+    out = []
+    while len(out) < n:
+        k = int(rng.choice([3, 3, 3, 1]))
+        ups = bool(k == 3 and rng.random() < 0.25)
+        c0 = int(rng.choice([16, 32, 48, 64, 96]))
+        c1 = int(rng.choice([0, 0, 16, 32, 64]))
+        cout = int(rng.choice([8, 24, 64, 72, 128, 192]))
+        h, w = [(8, 8), (16, 16), (8, 32), (16, 32), (24, 32), (16, 64), (32, 32)][int(rng.integers(7))]
+        if ups and w < 32 and 2 * w % 32:
+            continue
+        gn = bool(rng.random() < 0.6) and not ups
+        out.append((c0, c1, cout, h, w, k, ups, gn, bool(rng.random() < 0.4) and k == 3, bool(rng.random() < 0.5),
+                    int(rng.integers(1, 4)), bool(rng.random() < 0.5)))
+    return out
+
+
+@pytest.mark.parametrize("case", _rand_conv_cases(), ids=lambda c: "c%d+%d_o%d_%dx%d_k%d%s" % (c[:6] + ("u" if c[6] else "",)))
+def test_conv_split_path_random_shapes(case):
+    c0, c1, cout, h, w, k, ups, gn, temb, res, batch, fold = case
+    cin = c0 + c1
+    x0 = _t(41, (batch, c0, h, w), 1.5)
+    x1 = _t(42, (batch, c1, h, w)) if c1 else None
+    wt = _t(43, (cout, cin, k, k), 1.0 / np.sqrt(cin * k * k))
+    bias = _t(44, (cout,), 0.1)
+    gamma, beta = 1 + _t(45, (cin,), 0.1), _t(46, (cin,), 0.1)
+    xin = torch.cat([x0, x1], 1) if c1 else x0
+    a = F.silu(F.group_norm(xin, 8, gamma, beta, 1e-5)) if gn else xin
+    a = F.interpolate(a, scale_factor=2.0, mode="nearest") if ups else a
+    want = F.conv2d(a.double(), wt.double(), bias.double(), padding=k // 2)
+    mag = F.conv2d(a.double().abs(), wt.double().abs(), None, padding=k // 2) + 1e-30
+    tproj = _t(47, (batch, cout + 3), 0.5)
+    r = _t(48, tuple(want.shape))
+    if temb:
+        want = want + tproj[:, 1:1 + cout, None, None].double()
+    if res:
+        want = want + r.double()
+    d = lambda t: None if t is None else t.to(DEV)
+    wr, wh = ops.relayout_conv_weight(d(wt)), ops.relayout_conv_weight_h2(d(wt))
+    whf = ops.relayout_conv_weight_h2_fold(d(wt)) if (ups and fold) else None
+    ss = ops.gn_scale_shift(d(x0), d(gamma), d(beta), 8, 1e-5, src1=d(x1)) if gn else None
+    tp = d(tproj)
+    got, st = ops.conv2d_fused(d(x0), wr, d(bias), src1=d(x1), ksize=k, upsample=ups, gn_scale_shift=ss, silu=gn,
+                               temb=tp[:, 1:] if temb else None, temb_stride=tp.stride(0), residual=d(r) if res else None,
+                               cout=cout, weight_h2=wh, weight_h2_fold=whf, want_stats=True)
+    err = ((got.cpu().double() - want).abs() / mag).max().item()
+    assert err <= 6e-7, err   # fp32-class: a few ulps of sum |w||x| (plus the fast SiLU's staging error)
+    if st is not None:  # whenever the kernel offers statistics they must be those of the tensor it wrote
+        ref = torch.stack([got.double().sum(dim=(2, 3)), (got.double() ** 2).sum(dim=(2, 3))], dim=-1).cpu()
+        assert torch.allclose(st.sum(dim=2).cpu(), ref, rtol=3e-6, atol=1e-4)

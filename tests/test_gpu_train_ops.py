@@ -175,3 +175,36 @@ def test_upsample_and_its_adjoint():
     want = F.avg_pool2d(g.double(), 2) * 4 + a.double()
     assert torch.allclose(got.double(), want, rtol=0, atol=2e-6)
     assert torch.allclose(ops.sumpool2x2(g.to(DEV)).cpu().double(), F.avg_pool2d(g.double(), 2) * 4, rtol=0, atol=2e-6)
+
+
+def _rand_wgrad_cases(n=8, seed=14555):
+    rng = np.random.default_rng(seed)
+    out = []
+    for _ in range(n):
+        c0 = int(rng.choice([32, 64, 96]))
+        c1 = int(rng.choice([0, 0, 32, 64]))
+        cout = int(rng.choice([64, 128, 192]))
+        h, w = [(8, 32), (16, 32), (24, 64), (32, 32), (6, 32)][int(rng.integers(5))]
+        out.append((c0, c1, cout, h, w, bool(rng.random() < 0.6), int(rng.integers(1, 4))))
+    return out
+
+
+@pytest.mark.parametrize("case", _rand_wgrad_cases(), ids=lambda c: "c%d+%d_o%d_%dx%d" % c[:5])
+def test_wgrad_split_path_random_shapes(case):
+    """3x3 weight gradient on the split path (row ring, split-K runs) vs torch autograd on seeded random shapes."""
+    c0, c1, cout, h, w, gn, batch = case
+    cin = c0 + c1
+    x0 = _t(51, (batch, c0, h, w)).requires_grad_(True)
+    x1 = _t(52, (batch, c1, h, w)).requires_grad_(True) if c1 else None
+    wt = _t(53, (cout, cin, 3, 3), 1.0 / np.sqrt(cin * 9)).requires_grad_(True)
+    gamma, beta = 1 + _t(55, (cin,), 0.1), _t(56, (cin,), 0.1)
+    xin = torch.cat([x0, x1], 1) if c1 else x0
+    a = F.silu(F.group_norm(xin, 8, gamma, beta, 1e-5)) if gn else xin
+    y = F.conv2d(a, wt, None, padding=1)
+    dy = _t(59, tuple(y.shape))
+    y.backward(dy)
+    d = lambda t: None if t is None else t.detach().to(DEV)
+    ss = ops.gn_scale_shift(d(x0), d(gamma), d(beta), 8, 1e-5, src1=d(x1)) if gn else None
+    dw = torch.zeros_like(wt.detach()).to(DEV)
+    ops.conv_wgrad(d(x0), d(dy), dw, src1=d(x1), ksize=3, gn_scale_shift=ss, silu=gn)
+    _close(dw, wt.grad, rel=3e-5, ab=3e-5)
