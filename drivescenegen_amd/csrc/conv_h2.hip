@@ -209,7 +209,7 @@ __global__ __launch_bounds__(64 * NW, 1) void conv_h2_kernel(ConvH2P p) {
       dst[i][j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, goff[i] * 4, soff[j], 0));
   };
   auto load_unit = [&](int i, int q, const float* sp) { load_unit_to(xr, i, sp); };
-  auto commit_unit = [&](int i, int q, unsigned char* buf) {  // q: the chunk being staged
+  auto commit_unit_from = [&](const float (&src)[H2_NU][8], int i, int q, unsigned char* buf) {  // q: chunk staged
     half8 h1, h2;
     float4 sr[4];
     if (has_ss) {
@@ -219,7 +219,7 @@ __global__ __launch_bounds__(64 * NW, 1) void conv_h2_kernel(ConvH2P p) {
     }
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
-      float v = xr[i][j];
+      float v = src[i][j];
       if (has_ss) v = (j & 1) ? v * sr[j / 2].z + sr[j / 2].w : v * sr[j / 2].x + sr[j / 2].y;
       const float sv = silu_fast_h(v);
       v = do_silu ? sv : v;
@@ -267,6 +267,7 @@ __global__ __launch_bounds__(64 * NW, 1) void conv_h2_kernel(ConvH2P p) {
             __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, goff[i] * 4, soff[2 * jp + e], 0));
     }
   };
+  auto commit_unit = [&](int i, int q, unsigned char* buf) { commit_unit_from(xr, i, q, buf); };
   // weight slab of chunk q: 36 segments (piece, tap, g) of 64 couts x 16 B, moved global -> LDS by DMA;
   // wave w moves segments w, w+4, ...
   auto dma_weights = [&](int k, int q, unsigned char* buf) {
@@ -323,34 +324,41 @@ __global__ __launch_bounds__(64 * NW, 1) void conv_h2_kernel(ConvH2P p) {
 #define DSG_PT(i)
 #endif
   {
-    float xr1[H2_NU][8];
-    const float* sp = src_of(0);
+    // Issue order: weight DMAs, chunk 0's patch (into a scratch set), chunk 1's patch (into xr, where the K loop
+    // expects it).  The tile waits only for the DMAs and chunk 0 -- vmcnt retires in order, so a counted wait with
+    // chunk 1's loads still outstanding covers exactly those -- and chunk 1 lands under chunk 0's MFMAs.
+    float xr0[H2_NU][8];
+    float ssv[2048 / NTH];  // this thread's share of the image's scale/shift table (cin <= 1024): oldest loads
+    if (has_ss) {
 #pragma unroll
-    for (int i = 0; i < H2_NU; ++i) load_unit_to(xr, i, sp);
-    if (nq > 1) {
-      const float* sp1 = src_of(1);
-#pragma unroll
-      for (int i = 0; i < H2_NU; ++i) load_unit_to(xr1, i, sp1);
+      for (int k = 0; k < 2048 / NTH; ++k) ssv[k] = ssg[min(tid + NTH * k, 2 * p.cin - 1)];
     }
 #pragma unroll
     for (int k = 0; k < G::NDMA; ++k) dma_weights(k, 0, buf0);
+    const float* sp = src_of(0);
+#pragma unroll
+    for (int i = 0; i < H2_NU; ++i) load_unit_to(xr0, i, sp);
+    if (nq > 1) {
+      const float* sp1 = src_of(1);
+#pragma unroll
+      for (int i = 0; i < H2_NU; ++i) load_unit_to(xr, i, sp1);
+    }
     DSG_PT(1);
     if (has_ss) {
-      for (int i = tid; i < 2 * p.cin; i += NTH) ssl[i] = ssg[i];
+#pragma unroll
+      for (int k = 0; k < 2048 / NTH; ++k)
+        if (tid + NTH * k < 2 * p.cin) ssl[tid + NTH * k] = ssv[k];
       __syncthreads();  // the scale/shift table is in LDS
     }
     DSG_PT(2);
 #pragma unroll
-    for (int i = 0; i < H2_NU; ++i) commit_unit(i, 0, buf0);
+    for (int i = 0; i < H2_NU; ++i) commit_unit_from(xr0, i, 0, buf0);
     DSG_PT(3);
-    if (nq > 1) {
-#pragma unroll
-      for (int i = 0; i < H2_NU; ++i)
-#pragma unroll
-        for (int j = 0; j < 8; ++j) xr[i][j] = xr1[i][j];
-    }
   }
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // chunk 0's weight DMAs
+  // (the DMAs were issued before every patch load: once chunk 0's values have been used they have landed; 8 * NU
+  // loads of chunk 1 may still be in flight)
+  if (nq > 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(8 * H2_NU) : "memory");
+  else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
 
   // One K-chunk: MFMAs on `cur`; STAGE: chunk q+1 (patch in registers, weights by DMA) goes into `nxt`;
