@@ -680,19 +680,28 @@ bool conv_h2_eligible(const dsg_conv_args* a, int hout, int wout) {
 }
 
 // tile geometry shared by the launcher and dsg_conv2d_stats_tiles
+// 16-row tiles (4 rows per wave) are the efficient shape; 8-row tiles double the workgroup count.  The chip runs
+// 256 workgroups at a time, so what counts is the number of ROUNDS: an 8-row workgroup costs ~0.55 of a 16-row one
+// (half the MFMAs, the same fixed cost), and e.g. 320 workgroups of 16 rows (2 rounds) lose to 640 of 8 (3 x 0.55).
+static bool rows16_pays(int b16) {
+  if (g_h2_rows == 2 || b16 <= 0) return false;
+  if (g_h2_rows == 4) return true;
+  if (b16 < 256) return false;
+  const int r16 = (b16 + 255) / 256, r8 = (2 * b16 + 255) / 256;
+  return 100 * r16 <= 55 * r8;
+}
+
 static bool conv_h2_rows16(const dsg_conv_args* a, int hout, int wout) {
   if (conv_h2_fold(a)) {  // tiled on the low-resolution grid, four phases per cout tile
     const int cp = (a->cout + 63) / 64 * 64;
-    const int b16 = (a->hin % 16 == 0) ? (a->win / H2_TW) * (a->hin / 16) * a->n * (cp / H2_BM) * 4 : 0;
-    return g_h2_rows != 2 && b16 >= (g_h2_rows == 4 ? 1 : 256);
+    return rows16_pays((a->hin % 16 == 0) ? (a->win / H2_TW) * (a->hin / 16) * a->n * (cp / H2_BM) * 4 : 0);
   }
   if (a->ksize == 1) {
     hout = hout * wout / H2_TW;
     wout = H2_TW;
   }
   const int cout_pad = (a->cout + 63) / 64 * 64;
-  const int blocks16 = (hout % 16 == 0) ? (wout / H2_TW) * (hout / 16) * a->n * (cout_pad / H2_BM) : 0;
-  return g_h2_rows != 2 && blocks16 >= (g_h2_rows == 4 ? 1 : 256);
+  return rows16_pays((hout % 16 == 0) ? (wout / H2_TW) * (hout / 16) * a->n * (cout_pad / H2_BM) : 0);
 }
 
 int conv_h2_stats_tiles(const dsg_conv_args* a, int hout, int wout) {
