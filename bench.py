@@ -73,9 +73,13 @@ def gpu_leg(args, rank, world):
     for i in range(args.warmup):
         x = step(i, x)
     barrier()
+    # HIP events bracket the conv launches of every PROF_EVERY-th step of the timed region (all 50 DDIM timesteps run
+    # the same launches): the roofline figures are live, from inside the timed region, at ~1/5 of the event cost
     lib.dsg_prof_enable(1 if not args.no_prof else 0)
     t0 = time.perf_counter()
     for i in range(args.steps):
+        if not args.no_prof:
+            lib.dsg_prof_enable(3 if i % PROF_EVERY == 0 else 2)
         x = step(args.warmup + i, x)
     barrier()
     dt = time.perf_counter() - t0
@@ -131,6 +135,9 @@ def cpu_leg(args):
     return dict(value=bs * nsteps / dt, unit="image-steps/s", cores=cores, kind="port",
                 sample=f"{nsteps} DDIM steps at batch {bs} (after 1 warm-up) of the same 256x256x4 default U-Net, "
                        f"torch-CPU fp32 oracle, {cores} threads, {dt:.1f} s")
+
+
+PROF_EVERY = 5
 
 
 def pmc_traffic(kernel):
@@ -199,7 +206,8 @@ def main():
                             frac_of_f32_mfma_peak=dom["tflops"] / PEAK_F32_TFLOPS,
                             avg_launch_ms=dom["avg_ms"], launches=dom["launches"],
                             alg_flops_per_launch=dom["flops_per_launch"],
-                            alg_gbs=dom["alg_gbs"], time_share=dom["total_ms"] * 1e-3 / dt)
+                            alg_gbs=dom["alg_gbs"], sampled_every_nth_step=PROF_EVERY,
+                            time_share=dom["total_ms"] * 1e-3 * args.steps / len(range(0, args.steps, PROF_EVERY)) / dt)
         elif "conv3x3_s1_mfma_f32" in prof:
             dom = prof["conv3x3_s1_mfma_f32"]
             roofline = dict(bound="mfma", kernel="dsg::conv_mfma_kernel<3,1,0,2,*>", achieved=dom["tflops"],

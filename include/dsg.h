@@ -321,7 +321,7 @@ int dsg_rasterize_boxes(const float* boxes, int32_t nbox, float* out, int32_t h,
  * stride-1 / conv3x3 upsampled / conv1x1 on the fp16x2-split matrix-core path, 9 its 3x3 weight gradient.  FLOPs/bytes are the
  * algorithmic figures of each launch (2*MACs; input + weights + output once).
  * ---------------------------------------------------------------------------------------- */
-int dsg_prof_enable(int32_t on);
+int dsg_prof_enable(int32_t on); /* 1 start (clears), 0 stop (clears); 2 pause / 3 resume, keeping the records */
 int dsg_prof_summary(int32_t kernel_class, double* total_ms, double* total_flops, double* total_bytes,
                      int64_t* launches);
 int dsg_prof_dump(const char* csv_path);
