@@ -163,7 +163,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--batch", type=int, default=16, help="samples per GPU (BASELINE configs[1]: 16)")
     ap.add_argument("--ddim-steps", type=int, default=50)
     ap.add_argument("--no-prof", action="store_true", help="disable the HIP-event roofline leg")
