@@ -70,6 +70,10 @@ def gpu_leg(args, rank, world):
             torch.distributed.barrier()
         torch.cuda.synchronize(dev)
 
+    # untimed: the W warm-up steps, preceded by as many more as it takes to make 10 -- the first process on a freshly
+    # booted box needs ~0.2 s of load before the GPU reaches its steady clocks (3 steps: 1.5 % low; 12: same as later runs)
+    for i in range(max(0, 10 - args.warmup)):
+        x = step(i, x)
     for i in range(args.warmup):
         x = step(i, x)
     barrier()
