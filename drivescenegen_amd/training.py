@@ -320,6 +320,14 @@ class Accelerator:
     def num_processes(self):
         return self.world
 
+    @property
+    def process_index(self):        # (accelerate's names for rank / local rank)
+        return self.rank
+
+    @property
+    def local_process_index(self):
+        return self.local_rank
+
     def init_trackers(self, project_name, config=None):
         if self.project_dir and self.is_main_process:
             os.makedirs(self.project_dir, exist_ok=True)
