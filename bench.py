@@ -238,7 +238,7 @@ def main():
             "roofline": roofline,
             "kernels": prof,
         }
-        if not args.no_cpu:
+        if not args.no_cpu and world == 1:  # (rank 0 at N = 1 only: the other ranks of a multi-GPU run would wait for it)
             out["cpu_baseline"] = cpu_leg(args)
         print(json.dumps(out))
     if world > 1:
