@@ -489,6 +489,8 @@ __global__ __launch_bounds__(64 * NW, 1) void conv_h2_kernel(ConvH2P p) {
   const int oplane = p.hout * p.wout * oscale * oscale;
   const bool want_stats = p.stats != nullptr;
   float* red = reinterpret_cast<float*>(smem_raw);  // [wave][sum | sumsq][cout 64] (the K loop is done with LDS)
+  constexpr int RED_FLOATS = NW * (NT / 2) * 2 * H2_BM;
+  float* red_lane = (l31 == 16) ? red + 4 * half : red + RED_FLOATS + 64 + lane;  // (+ crel etc. per value)
   const int nvalid = min(H2_BM, p.cout - m0);        // output channels of this tile that exist
   const size_t tile_off = ((size_t)n * p.cout + m0) * oplane;
   const int range = nvalid * oplane * 4;
@@ -554,14 +556,13 @@ __global__ __launch_bounds__(64 * NW, 1) void conv_h2_kernel(ConvH2P p) {
           }
         }
         if (STATS) {  // GroupNorm statistics of the tensor just produced (the next layer's norm reads them)
-          const int cl = crel + 4 * half;
 #pragma unroll
           for (int pr = 0; pr < NT / 2; ++pr) {  // one partial per pair of rows: the same summation tree for any NT
             const float t1 = half_wave_sum(s1[pr]), t2 = half_wave_sum(s2[pr]);
-            if (l31 == 16) {
-              red[((wave * (NT / 2) + pr) * 2 + 0) * H2_BM + cl] = t1;
-              red[((wave * (NT / 2) + pr) * 2 + 1) * H2_BM + cl] = t2;
-            }
+            // every lane stores -- lanes 16 / 48 to the real slot, the others to a per-lane dump area behind it:
+            // a predicated store here is a branch, and 128 branches fence the scheduler between the DPP chains
+            red_lane[((wave * (NT / 2) + pr) * 2 + 0) * H2_BM + crel] = t1;
+            red_lane[((wave * (NT / 2) + pr) * 2 + 1) * H2_BM + crel] = t2;
           }
         }
       }
