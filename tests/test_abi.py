@@ -51,3 +51,21 @@ def test_cpu_tensor_is_refused_loudly(lib_built):
         m(torch.zeros(1, 3, 32, 32), 0)
     with pytest.raises(RuntimeError, match="HIP engine"):
         d.DDPMScheduler().add_noise(torch.zeros(1, 3, 8, 8), torch.zeros(1, 3, 8, 8), torch.tensor([1]))
+
+
+def test_product_never_touches_the_oracle():
+    """The oracle is test infrastructure: nothing under drivescenegen_amd/ (or the C sources) may import, call or
+    even name it, and bench.py only does so inside its cpu_baseline leg."""
+    import re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    pkg = os.path.join(root, "drivescenegen_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h")):
+                text = open(os.path.join(dirpath, f), errors="ignore").read()
+                assert not re.search(r"^\s*(from|import)\s+oracle\b", text, re.M), (dirpath, f)
+    bench = open(os.path.join(root, "bench.py")).read()
+    hits = [m.start() for m in re.finditer(r"^\s*from oracle\.", bench, re.M)]
+    leg = bench.index("def cpu_leg(")
+    end = bench.index("\ndef ", leg + 1)
+    assert hits and all(leg < h < end for h in hits)
