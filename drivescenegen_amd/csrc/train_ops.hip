@@ -56,12 +56,28 @@ __global__ __launch_bounds__(256) void gn_bwd_stats_kernel(const float* __restri
   const size_t k = ((size_t)n * ct + c) * 2;
   const float sc = ss[k], sh = ss[k + 1], mean = mr[k], rstd = mr[k + 1];
   double a = 0.0, b = 0.0;
-  for (int i = threadIdx.x; i < hw; i += 256) {
-    const float x = xp[i];
-    float du = dp[i];
-    if (silu) du *= dsilu(x * sc + sh);
-    a += du;
-    b += (double)du * ((x - mean) * rstd);
+  if ((hw & 3) == 0) {  // 16-byte loads; 4-term fp32 partials feed the fp64 sums
+    const float4* xp4 = reinterpret_cast<const float4*>(xp);
+    const float4* dp4 = reinterpret_cast<const float4*>(dp);
+    for (int i = threadIdx.x; i < (hw >> 2); i += 256) {
+      const float4 x = xp4[i];
+      float4 du = dp4[i];
+      if (silu) {
+        du.x *= dsilu(x.x * sc + sh); du.y *= dsilu(x.y * sc + sh);
+        du.z *= dsilu(x.z * sc + sh); du.w *= dsilu(x.w * sc + sh);
+      }
+      a += (double)((du.x + du.y) + (du.z + du.w));
+      b += (double)((du.x * ((x.x - mean) * rstd) + du.y * ((x.y - mean) * rstd)) +
+                    (du.z * ((x.z - mean) * rstd) + du.w * ((x.w - mean) * rstd)));
+    }
+  } else {
+    for (int i = threadIdx.x; i < hw; i += 256) {
+      const float x = xp[i];
+      float du = dp[i];
+      if (silu) du *= dsilu(x * sc + sh);
+      a += du;
+      b += (double)du * ((x - mean) * rstd);
+    }
   }
   block_sum2(a, b);
   if (threadIdx.x == 0) {
@@ -103,7 +119,8 @@ __global__ void gn_bwd_finalize_kernel(const double* __restrict__ s12, const flo
   }
 }
 
-// grid = (ceil(hw/256), c0+c1, n).  dx = a*du - b - xhat*c2 (+ addend)
+// grid = (ceil(hw/(256*V)), c0+c1, n), V = 4 (16-byte accesses) when hw % 4 == 0 else 1.  dx = a*du - b - xhat*c2 (+ addend)
+template <int V>
 __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(const float* __restrict__ src0, int c0,
                                                            const float* __restrict__ src1, int c1,
                                                            const float* __restrict__ dy, const float* __restrict__ ss,
@@ -113,23 +130,41 @@ __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(const float* __restri
                                                            const float* __restrict__ add1, float* __restrict__ dx0,
                                                            float* __restrict__ dx1) {
   const int c = blockIdx.y, n = blockIdx.z, ct = c0 + c1;
-  const int i = blockIdx.x * 256 + threadIdx.x;
+  const int i = (blockIdx.x * 256 + threadIdx.x) * V;
   if (i >= hw) return;
   const bool first = c < c0;
   const size_t xo = first ? ((size_t)n * c0 + c) * hw + i : ((size_t)n * c1 + (c - c0)) * hw + i;
-  const float x = first ? src0[xo] : src1[xo];
+  const float* xs = first ? src0 : src1;
+  const float* as = first ? add0 : add1;
+  float* ds = first ? dx0 : dx1;
   const size_t k = (size_t)n * ct + c;
   const float sc = ss[2 * k], sh = ss[2 * k + 1], mean = mr[2 * k], rstd = mr[2 * k + 1];
-  float du = dy[k * hw + i];
-  if (silu) du *= dsilu(x * sc + sh);
-  float v = coef[3 * k] * du - coef[3 * k + 1] - ((x - mean) * rstd) * coef[3 * k + 2];
-  if (first) {
-    if (add0) v += add0[xo];
-    dx0[xo] = v;
+  const float k0 = coef[3 * k], k1 = coef[3 * k + 1], k2 = coef[3 * k + 2];
+  float x[V], du[V], ad[V];
+  if (V == 4) {
+    const float4 x4 = *reinterpret_cast<const float4*>(xs + xo);
+    const float4 d4 = *reinterpret_cast<const float4*>(dy + k * hw + i);
+    x[0] = x4.x; x[1] = x4.y; x[2] = x4.z; x[3] = x4.w;
+    du[0] = d4.x; du[1] = d4.y; du[2] = d4.z; du[3] = d4.w;
+    if (as) {
+      const float4 a4 = *reinterpret_cast<const float4*>(as + xo);
+      ad[0] = a4.x; ad[1] = a4.y; ad[2] = a4.z; ad[3] = a4.w;
+    }
   } else {
-    if (add1) v += add1[xo];
-    dx1[xo] = v;
+    x[0] = xs[xo];
+    du[0] = dy[k * hw + i];
+    if (as) ad[0] = as[xo];
   }
+  float v[V];
+#pragma unroll
+  for (int e = 0; e < V; ++e) {
+    float d = du[e];
+    if (silu) d *= dsilu(x[e] * sc + sh);
+    v[e] = k0 * d - k1 - ((x[e] - mean) * rstd) * k2;
+    if (as) v[e] += ad[e];
+  }
+  if (V == 4) *reinterpret_cast<float4*>(ds + xo) = make_float4(v[0], v[1], v[2], v[3]);
+  else ds[xo] = v[0];
 }
 
 // grid = (c, n): out[n][c] = sum_hw x[n][c][:]
@@ -138,7 +173,15 @@ __global__ __launch_bounds__(256) void channel_sums_kernel(const float* __restri
   const int ci = blockIdx.x, n = blockIdx.y;
   const float* xp = x + ((size_t)n * c + ci) * hw;
   double a = 0.0, b = 0.0;
-  for (int i = threadIdx.x; i < hw; i += 256) a += xp[i];
+  if ((hw & 3) == 0) {
+    const float4* xp4 = reinterpret_cast<const float4*>(xp);
+    for (int i = threadIdx.x; i < (hw >> 2); i += 256) {
+      const float4 v = xp4[i];
+      a += (double)((v.x + v.y) + (v.z + v.w));
+    }
+  } else {
+    for (int i = threadIdx.x; i < hw; i += 256) a += xp[i];
+  }
   block_sum2(a, b);
   if (threadIdx.x == 0) out[(size_t)n * out_stride + ci] = (float)a;
 }
@@ -298,8 +341,12 @@ DSG_API int dsg_gn_bwd(const float* src0, int32_t c0, const float* src1, int32_t
   hipLaunchKernelGGL(dsg::gn_bwd_finalize_kernel, dim3(cdiv(n * c, 256)), dim3(256), 0, st, ws_s12, gamma, mean_rstd, n,
                      c, groups, hw, ws_coef, dgamma, dbeta);
   DSG_LAUNCH_CHECK();
-  hipLaunchKernelGGL(dsg::gn_bwd_apply_kernel, dim3(cdiv(hw, 256), c, n), dim3(256), 0, st, src0, c0, src1, c1, dy,
-                     scale_shift, mean_rstd, ws_coef, silu, hw, add0, add1, dx0, dx1);
+  if ((hw & 3) == 0)
+    hipLaunchKernelGGL(dsg::gn_bwd_apply_kernel<4>, dim3(cdiv(hw, 1024), c, n), dim3(256), 0, st, src0, c0, src1, c1, dy,
+                       scale_shift, mean_rstd, ws_coef, silu, hw, add0, add1, dx0, dx1);
+  else
+    hipLaunchKernelGGL(dsg::gn_bwd_apply_kernel<1>, dim3(cdiv(hw, 256), c, n), dim3(256), 0, st, src0, c0, src1, c1, dy,
+                       scale_shift, mean_rstd, ws_coef, silu, hw, add0, add1, dx0, dx1);
   DSG_LAUNCH_CHECK();
   return DSG_OK;
 }
