@@ -215,20 +215,28 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(WgradP p) {
   }
 }
 
-// dw[co][ci][tp] += sum_s ws[s][tp][ci][co]; one thread per (tp, ci, co), co fastest (coalesced reads)
+// dw[co][ci][tp] += sum_s ws[s][tp][ci][co]; one thread per (tp, ci, 4 consecutive co): 16-byte reads of every slab
+// (cout_pad is a multiple of 64), summed in slab order
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ ws, int nslab, int taps, int cin,
                                                            int cout, int cin_pad, int cout_pad,
                                                            float* __restrict__ dw) {
-  const int64_t i = blockIdx.x * (int64_t)256 + threadIdx.x;
+  const int64_t i4 = blockIdx.x * (int64_t)256 + threadIdx.x;
   const int64_t slab = (int64_t)taps * cin_pad * cout_pad;
-  if (i >= slab) return;
+  if (i4 * 4 >= slab) return;
+  const int64_t i = i4 * 4;
   const int co = (int)(i % cout_pad);
   const int ci = (int)((i / cout_pad) % cin_pad);
   const int tp = (int)(i / ((int64_t)cout_pad * cin_pad));
   if (co >= cout || ci >= cin) return;
-  float s = 0.f;
-  for (int k = 0; k < nslab; ++k) s += ws[k * slab + i];
-  dw[((size_t)co * cin + ci) * taps + tp] += s;
+  float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int k = 0; k < nslab; ++k) {
+    const float4 v = *reinterpret_cast<const float4*>(ws + k * slab + i);
+    s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+  }
+  const float sv[4] = {s.x, s.y, s.z, s.w};
+#pragma unroll
+  for (int e = 0; e < 4; ++e)
+    if (co + e < cout) dw[((size_t)(co + e) * cin + ci) * taps + tp] += sv[e];
 }
 
 // Generic VALU fallback (odd spatial sizes): one thread per (co, ci, tap), loops over all pixels.
@@ -588,7 +596,7 @@ static int launch_wgrad(WgradP p, size_t ws_bytes, hipStream_t st) {
   hipLaunchKernelGGL(kern, dim3(pairs, nsplit), dim3(256), lds, st, p);
   DSG_LAUNCH_CHECK();
   const int64_t slab = (int64_t)G::TAPS * p.cin_pad * p.cout_pad;
-  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)cdiv64(slab, 256)), dim3(256), 0, st, p.ws, nslab, G::TAPS, p.cin,
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)cdiv64(slab / 4, 256)), dim3(256), 0, st, p.ws, nslab, G::TAPS, p.cin,
                      p.cout, p.cin_pad, p.cout_pad, p.dw);
   prof_end(pi, st);
   DSG_LAUNCH_CHECK();
@@ -630,7 +638,7 @@ static int launch_wgrad_h2(WgradP p, size_t ws_bytes, hipStream_t st) {
   hipLaunchKernelGGL(conv_wgrad_h2_kernel, dim3(pairs, nslab), dim3(256), (size_t)WH_LDS_BYTES, st, p);
   DSG_LAUNCH_CHECK();
   const int64_t slab = (int64_t)9 * p.cin_pad * p.cout_pad;
-  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)cdiv64(slab, 256)), dim3(256), 0, st, p.ws, nslab, 9, p.cin,
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)cdiv64(slab / 4, 256)), dim3(256), 0, st, p.ws, nslab, 9, p.cin,
                      p.cout, p.cin_pad, p.cout_pad, p.dw);
   prof_end(pi, st);
   DSG_LAUNCH_CHECK();
