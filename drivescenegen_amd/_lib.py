@@ -82,6 +82,7 @@ SIGNATURES = {
     "dsg_sumpool2x2": [_vp, _vp, _vp, _i64, _i32, _i32, _vp],
     "dsg_rasterize_boxes": [_vp, _i32, _vp, _i32, _i32, _f32, _f32, _f32, _vp],
     "dsg_gn_finalize_parts": [_vp, _i32, _i32, _vp, _i32, _i32, _vp, _vp, _i32, _i32, _i32, _f32, _vp, _vp],
+    "dsg_gn_finalize_parts_train": [_vp, _i32, _i32, _vp, _i32, _i32, _vp, _vp, _i32, _i32, _i32, _f32, _vp, _vp, _vp],
     "dsg_conv2d_fwd": [C.POINTER(ConvArgs), _vp],
     "dsg_conv2d_fwd_direct": [C.POINTER(ConvArgs), _vp],
     "dsg_conv_weight_relayout": [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp],

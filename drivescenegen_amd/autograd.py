@@ -180,45 +180,60 @@ def _forward(model, st: TrainState, tape: _Tape, sample, timesteps):
     tape.temb = dict(act=act, emb=emb, z1=z1, z2=z2, wp=wp, dtproj=dtproj, toffs=toffs, resnets=resnets, w2=w2)
 
     # ---- fused conv op with tape record ----
+    pstats = {}  # id(tensor) -> per-tile GroupNorm statistics written by the conv that produced it
+
+    def norm_ss(x0, x1, gn):
+        """(scale_shift, mean_rstd) of GroupNorm `gn` over cat(x0, x1): from the producers' epilogue statistics where
+        every source has them, else by a statistics pass."""
+        g, b = P[gn + ".weight"].detach(), P[gn + ".bias"].detach()
+        s0 = pstats.get(id(x0))
+        s1 = pstats.get(id(x1)) if x1 is not None else None
+        if s0 is not None and (x1 is None or s1 is not None):
+            return ops.gn_scale_shift_from_parts_train(s0, g, b, groups, eps, x0.shape[2] * x0.shape[3], stats1=s1)
+        return ops.gn_scale_shift_train(x0, g, b, groups, eps, src1=x1)
+
     def conv(x0, wname, x1=None, gn=None, silu=False, k=3, stride=1, ups=False, toff=None, res=None,
-             need_dx=True):
+             need_dx=True, feeds_norm=False):
         wf, wd = st.conv_w(wname + ".weight")
         bias = P[wname + ".bias"].detach()
         cout = bias.numel()
         ss = mr = None
         if gn is not None:
-            ss, mr = ops.gn_scale_shift_train(x0, P[gn + ".weight"].detach(), P[gn + ".bias"].detach(), groups, eps,
-                                              src1=x1)
+            ss, mr = norm_ss(x0, x1, gn)
         y = ops.conv2d_fused(x0, wf, bias, src1=x1, ksize=k, stride=stride, upsample=ups, gn_scale_shift=ss,
                              silu=silu, temb=None if toff is None else tproj[:, toff:],
                              temb_stride=tproj.stride(0), residual=res, cout=cout,
-                             weight_h2=st.wh.get(wname + ".weight"))
+                             weight_h2=st.wh.get(wname + ".weight"), want_stats=feeds_norm)
+        if feeds_norm:
+            y, ystats = y
+            if ystats is not None:
+                pstats[id(y)] = ystats
         tape.recs.append(dict(kind="conv", x0=x0, x1=x1, ss=ss, mr=mr, gn=gn, silu=silu, k=k, stride=stride, ups=ups,
                               toff=toff, res=res, y=y, wname=wname, wd=wd, cout=cout, need_dx=need_dx,
                               whd=st.whd.get(wname + ".weight")))
         return y
 
     def resnet(x, skip, pre):
-        h = conv(x, pre + ".conv1", x1=skip, gn=pre + ".norm1", silu=True, toff=toffs[pre])
+        h = conv(x, pre + ".conv1", x1=skip, gn=pre + ".norm1", silu=True, toff=toffs[pre], feeds_norm=True)
         if (pre + ".conv_shortcut.weight") in P:
             sc = conv(x, pre + ".conv_shortcut", x1=skip, k=1)
         else:
             sc = x
-        return conv(h, pre + ".conv2", gn=pre + ".norm2", silu=True, res=sc)
+        return conv(h, pre + ".conv2", gn=pre + ".norm2", silu=True, res=sc, feeds_norm=True)
 
     def attention(x, pre):
         wf, wd, bias = st.qkv_w(pre)
         c = x.shape[1]
         heads = c // cfg.attention_head_dim
         gnn = pre + ".group_norm"
-        ss, mr = ops.gn_scale_shift_train(x, P[gnn + ".weight"].detach(), P[gnn + ".bias"].detach(), groups, eps)
+        ss, mr = norm_ss(x, None, gnn)
         qkv = ops.conv2d_fused(x, wf, bias, ksize=1, gn_scale_shift=ss, silu=False)
         n, _, hh, ww = x.shape
         o, lse = ops.attention_train(qkv.view(n, 3 * c, hh * ww), heads)
         o = o.view(n, c, hh, ww)
         tape.recs.append(dict(kind="qkv", x=x, ss=ss, mr=mr, gn=gnn, pre=pre, qkv=qkv, wd=wd))
         tape.recs.append(dict(kind="attn", qkv=qkv, o=o, lse=lse, heads=heads))
-        return conv(o, pre + ".to_out.0", k=1, res=x)
+        return conv(o, pre + ".to_out.0", k=1, res=x, feeds_norm=True)
 
     x = conv(sample, "conv_in", need_dx=False)
     skips = [x]
@@ -244,7 +259,7 @@ def _forward(model, st: TrainState, tape: _Tape, sample, timesteps):
             if hasattr(blk, "attentions"):
                 x = attention(x, f"{pre}.attentions.{j}")
         if hasattr(blk, "upsamplers"):
-            x = conv(x, f"{pre}.upsamplers.0.conv", ups=True)
+            x = conv(x, f"{pre}.upsamplers.0.conv", ups=True, feeds_norm=True)
     return conv(x, "conv_out", gn="conv_norm_out", silu=True)
 
 

@@ -94,7 +94,8 @@ __global__ __launch_bounds__(64) void gn_finalize_parts_kernel(const double* __r
                                                               const double* __restrict__ st1, int c1, int t1,
                                                               const float* __restrict__ gamma,
                                                               const float* __restrict__ beta, int groups, int hw,
-                                                              float eps, float* __restrict__ out) {
+                                                              float eps, float* __restrict__ out,
+                                                              float* __restrict__ mr) {
   const int c = c0 + c1, cpg = c / groups;
   const int ni = blockIdx.x / groups, g = blockIdx.x - ni * groups;
   const int lane = threadIdx.x;
@@ -125,6 +126,10 @@ __global__ __launch_bounds__(64) void gn_finalize_parts_kernel(const double* __r
     const float sc = rstd * gamma[ch];
     out[2 * ((size_t)ni * c + ch)] = sc;
     out[2 * ((size_t)ni * c + ch) + 1] = beta[ch] - meanf * sc;
+    if (mr) {  // training keeps (mean, rstd) per (n, c) for the backward pass
+      mr[2 * ((size_t)ni * c + ch)] = meanf;
+      mr[2 * ((size_t)ni * c + ch) + 1] = rstd;
+    }
   }
 }
 
@@ -188,9 +193,9 @@ DSG_API int dsg_gn_finalize_train(const double* chan_stats, const float* gamma, 
   return gn_finalize_impl(chan_stats, gamma, beta, n, c, groups, hw, eps, scale_shift, mean_rstd, stream);
 }
 
-DSG_API int dsg_gn_finalize_parts(const double* stats0, int32_t c0, int32_t tiles0, const double* stats1, int32_t c1,
+static int gn_finalize_parts_impl(const double* stats0, int32_t c0, int32_t tiles0, const double* stats1, int32_t c1,
                                   int32_t tiles1, const float* gamma, const float* beta, int32_t n, int32_t groups,
-                                  int32_t hw, float eps, float* scale_shift, void* stream) {
+                                  int32_t hw, float eps, float* scale_shift, float* mean_rstd, void* stream) {
   DSG_CHECK_ARG(stats0 && gamma && beta && scale_shift, "dsg_gn_finalize_parts: NULL pointer");
   DSG_CHECK_ARG((c1 == 0) == (stats1 == nullptr), "dsg_gn_finalize_parts: stats1/c1 mismatch");
   DSG_CHECK_ARG(n > 0 && c0 > 0 && c1 >= 0 && groups > 0 && hw > 0 && tiles0 > 0 && (c1 == 0 || tiles1 > 0),
@@ -198,9 +203,25 @@ DSG_API int dsg_gn_finalize_parts(const double* stats0, int32_t c0, int32_t tile
   DSG_CHECK_ARG((c0 + c1) % groups == 0, "dsg_gn_finalize_parts: channels (%d) not divisible by groups (%d)",
                 c0 + c1, groups);
   hipLaunchKernelGGL(dsg::gn_finalize_parts_kernel, dim3(n * groups), dim3(64), 0, static_cast<hipStream_t>(stream),
-                     stats0, c0, tiles0, stats1, c1, tiles1, gamma, beta, groups, hw, eps, scale_shift);
+                     stats0, c0, tiles0, stats1, c1, tiles1, gamma, beta, groups, hw, eps, scale_shift, mean_rstd);
   DSG_LAUNCH_CHECK();
   return DSG_OK;
+}
+
+DSG_API int dsg_gn_finalize_parts(const double* stats0, int32_t c0, int32_t tiles0, const double* stats1, int32_t c1,
+                                  int32_t tiles1, const float* gamma, const float* beta, int32_t n, int32_t groups,
+                                  int32_t hw, float eps, float* scale_shift, void* stream) {
+  return gn_finalize_parts_impl(stats0, c0, tiles0, stats1, c1, tiles1, gamma, beta, n, groups, hw, eps, scale_shift,
+                                nullptr, stream);
+}
+
+DSG_API int dsg_gn_finalize_parts_train(const double* stats0, int32_t c0, int32_t tiles0, const double* stats1,
+                                        int32_t c1, int32_t tiles1, const float* gamma, const float* beta, int32_t n,
+                                        int32_t groups, int32_t hw, float eps, float* scale_shift, float* mean_rstd,
+                                        void* stream) {
+  DSG_CHECK_ARG(mean_rstd != nullptr, "dsg_gn_finalize_parts_train: mean_rstd is NULL");
+  return gn_finalize_parts_impl(stats0, c0, tiles0, stats1, c1, tiles1, gamma, beta, n, groups, hw, eps, scale_shift,
+                                mean_rstd, stream);
 }
 
 DSG_API int dsg_gn_apply(const float* src, const float* scale_shift, int32_t silu, float* dst, int32_t n, int32_t c,

@@ -138,6 +138,19 @@ def conv2d_fused(src0, weight_r, bias=None, src1=None, ksize=3, stride=1, upsamp
     return (out, stats) if want_stats else out
 
 
+def gn_scale_shift_from_parts_train(stats0, gamma, beta, groups, eps, hw, stats1=None):
+    """dsg_gn_finalize_parts_train: (scale_shift, mean_rstd) from per-tile partial statistics."""
+    n, c0, t0 = stats0.shape[0], stats0.shape[1], stats0.shape[2]
+    c1, t1 = (stats1.shape[1], stats1.shape[2]) if stats1 is not None else (0, 0)
+    ss = torch.empty((n, c0 + c1, 2), dtype=torch.float32, device=stats0.device)
+    mr = torch.empty((n, c0 + c1, 2), dtype=torch.float32, device=stats0.device)
+    with torch.cuda.device(stats0.device):
+        _lib.check(_lib.load().dsg_gn_finalize_parts_train(_lib.ptr(stats0), c0, t0, _lib.ptr(stats1), c1, t1,
+                                                           _lib.ptr(gamma), _lib.ptr(beta), n, groups, hw, float(eps),
+                                                           _lib.ptr(ss), _lib.ptr(mr), _st(stats0)))
+    return ss, mr
+
+
 def gn_scale_shift_from_parts(stats0, gamma, beta, groups, eps, hw, stats1=None):
     """dsg_gn_finalize_parts: scale/shift of GroupNorm over cat(src0, src1) from per-tile partial statistics
     [N][c_i][tiles_i][2] (conv2d_fused(want_stats=True), or channel statistics with tiles = 1)."""

@@ -128,6 +128,10 @@ int dsg_gn_finalize(const double* chan_stats, const float* gamma, const float* b
 int dsg_gn_finalize_parts(const double* stats0, int32_t c0, int32_t tiles0, const double* stats1, int32_t c1,
                           int32_t tiles1, const float* gamma, const float* beta, int32_t n, int32_t groups,
                           int32_t hw, float eps, float* scale_shift /* [N][c0+c1][2] */, void* stream);
+/* the same, also returning (mean, rstd) per (n, c) for the backward pass (training forward) */
+int dsg_gn_finalize_parts_train(const double* stats0, int32_t c0, int32_t tiles0, const double* stats1, int32_t c1,
+                                int32_t tiles1, const float* gamma, const float* beta, int32_t n, int32_t groups,
+                                int32_t hw, float eps, float* scale_shift, float* mean_rstd, void* stream);
 int dsg_gn_apply(const float* src, const float* scale_shift, int32_t silu, float* dst, int32_t n,
                  int32_t c, int32_t hw, void* stream);
 
