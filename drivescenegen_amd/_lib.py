@@ -42,6 +42,7 @@ class ConvArgs(C.Structure):
         ("weight_h2_cout_stride", C.c_int32),
         ("weight_h2_fold", C.c_void_p),
         ("stats_out", C.c_void_p),
+        ("src_layout", C.c_int32), ("dst_layout", C.c_int32),
     ]
 
 
@@ -84,12 +85,14 @@ SIGNATURES = {
     "dsg_gn_finalize_parts": [_vp, _i32, _i32, _vp, _i32, _i32, _vp, _vp, _i32, _i32, _i32, _f32, _vp, _vp],
     "dsg_gn_finalize_parts_train": [_vp, _i32, _i32, _vp, _i32, _i32, _vp, _vp, _i32, _i32, _i32, _f32, _vp, _vp, _vp],
     "dsg_conv2d_fwd": [C.POINTER(ConvArgs), _vp],
+    "dsg_layout_convert": [_vp, _vp, _i32, _i32, _i32, _i32, _vp],
     "dsg_conv2d_fwd_direct": [C.POINTER(ConvArgs), _vp],
     "dsg_conv_weight_relayout": [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp],
     "dsg_conv_weight_relayout_dgrad": [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp],
     "dsg_conv_weight_relayout_h2": [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp],
     "dsg_conv_weight_relayout_h2_dgrad": [_vp, _vp, _i32, _i32, _i32, _vp],
     "dsg_gn_channel_stats": [_vp, _i32, _vp, _i32, _i32, _i32, _vp, _vp],
+    "dsg_gn_channel_stats_blocked": [_vp, _i32, _i32, _i32, _vp, _vp],
     "dsg_gn_finalize": [_vp, _vp, _vp, _i32, _i32, _i32, _i32, _f32, _vp, _vp],
     "dsg_gn_apply": [_vp, _vp, _i32, _vp, _i32, _i32, _i32, _vp],
     "dsg_attention_fwd": [_vp, _vp, _i32, _i32, _i32, _i32, _vp],

@@ -51,6 +51,7 @@ struct ConvP {
   float* dst;
   int pool;  // 1: 2x2 sum-pool in the epilogue; dst is [N, cout, hout/2, wout/2]
   int tiles_x, tiles_y;
+  int sblk, dblk;  // 1: sources / (dst, residual) are channel-blocked [N][C/8][H][W][8] (dsg_conv_args.*_layout)
 };
 
 constexpr int TH = 8;   // output rows per workgroup
@@ -125,7 +126,7 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(ConvP p) {
       if (ok) {
         const int sy = GM ? (gy >> 1) : gy;
         const int sx = GM ? (gx >> 1) : gx;
-        off = sy * p.win + sx;
+        off = (sy * p.win + sx) * (p.sblk ? 8 : 1);  // blocked: a pixel's 8 channels are adjacent
         valid |= 1u << i;
       }
     }
@@ -146,7 +147,15 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(ConvP p) {
     int c = q * KC + tc;
     ok = c < p.cin;
     c = min(c, p.cin - 1);
-    return (c < p.c0) ? p.src0 + ((size_t)n * p.c0 + c) * plane : p.src1 + ((size_t)n * p.c1 + (c - p.c0)) * plane;
+    const float* sp = p.src0;
+    int cs = p.c0;
+    if (c >= p.c0) {
+      sp = p.src1;
+      cs = p.c1;
+      c -= p.c0;
+    }
+    // blocked: channel c lives at offset c % 8 inside the block that starts where plane (c & ~7) would
+    return p.sblk ? sp + ((size_t)n * cs + (c & ~7)) * plane + (c & 7) : sp + ((size_t)n * cs + c) * plane;
   };
   auto w_of = [&](int q) -> const float* { return p.w + (size_t)q * (KC * TAPS) * p.wstride + m0; };
   const int wrow_max = p.cin * TAPS - 1;
@@ -259,6 +268,10 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(ConvP p) {
   // Epilogue. C/D layout of the 32x32 tile: col (pixel) = lane&31, row (cout) = (r&3) + 8*(r>>2) + 4*half.
   const int x = ox0 + l31;
   const bool has_t = p.temb != nullptr;
+  auto oidx = [&](int co, int y, int xx) -> size_t {
+    return p.dblk ? ((size_t)n * p.cout + (co & ~7)) * p.hout * p.wout + ((size_t)y * p.wout + xx) * 8 + (co & 7)
+                  : (((size_t)n * p.cout + co) * p.hout + y) * p.wout + xx;
+  };
   if (!p.pool) {
     // all residual loads first (in flight together), then add + store
     const bool has_r = p.res != nullptr;
@@ -271,7 +284,7 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(ConvP p) {
 #pragma unroll
         for (int nt = 0; nt < 2; ++nt) {
           const int y = oy0 + wave * 2 + nt;
-          rv[mt][r][nt] = has_r ? p.res[(((size_t)n * p.cout + co) * p.hout + y) * p.wout + min(x, p.wout - 1)] : 0.f;
+          rv[mt][r][nt] = has_r ? p.res[oidx(co, y, min(x, p.wout - 1))] : 0.f;
         }
       }
 #pragma unroll
@@ -285,7 +298,7 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(ConvP p) {
 #pragma unroll
           for (int nt = 0; nt < 2; ++nt) {
             const int y = oy0 + wave * 2 + nt;
-            const size_t idx = (((size_t)n * p.cout + co) * p.hout + y) * p.wout + x;
+            const size_t idx = oidx(co, y, x);
             float v = acc[mt][nt][r] + add;
             if (has_t) v = v + tv;
             if (has_r) v = v + rv[mt][r][nt];
@@ -400,6 +413,8 @@ void conv_h2_set_enabled(int on);
 void conv_h2_set_rows(int r);
 void conv_h2_set_stats(int on);
 void conv_h2_set_waves(int w);
+void conv_h2_set_pw_occ2(int v);
+void unet_set_blocked(int v);
 void wgrad_h2_set_enabled(int on);
 void conv_h2_set_fold(int on);
 
@@ -470,7 +485,7 @@ __global__ __launch_bounds__(256, 2) void conv_fewout_kernel(ConvP p) {
     const int py = pos / 34, px = pos - py * 34;
     const int gy = oy0 - 1 + py, gx = ox0 - 1 + px;
     ok[k] = pos < FO_PH * 34 && gy >= 0 && gy < p.hc && gx >= 0 && gx < p.wc;
-    goff[k] = ok[k] ? gy * p.win + gx : 0;
+    goff[k] = ok[k] ? (gy * p.win + gx) * (p.sblk ? 8 : 1) : 0;
     loff[k] = pos < FO_PH * 34 ? py * FO_PW + px : -1;
   }
   // the raw values of the next 16 channels are fetched into registers while the current 16 are being used
@@ -478,10 +493,12 @@ __global__ __launch_bounds__(256, 2) void conv_fewout_kernel(ConvP p) {
   auto fetch = [&](int c0) {
     const float* spb = (c0 < p.c0) ? p.src0 + ((size_t)n * p.c0 + c0) * plane
                                    : p.src1 + ((size_t)n * p.c1 + (c0 - p.c0)) * plane;  // (uniform: c0 % 16 == 0)
+    // (blocked sources: the 16-channel chunk starts at the same address; channel c is element c % 8 of block c / 8)
 #pragma unroll
     for (int c = 0; c < FO_KC; ++c)
 #pragma unroll
-      for (int k = 0; k < 3; ++k) xr[c][k] = spb[(size_t)c * plane + goff[k]];
+      for (int k = 0; k < 3; ++k)
+        xr[c][k] = spb[(p.sblk ? (size_t)(c >> 3) * 8 * plane + (c & 7) : (size_t)c * plane) + goff[k]];
   };
   fetch(0);
   for (int c0 = 0; c0 < p.cin; c0 += FO_KC) {
@@ -613,6 +630,13 @@ int conv2d_fwd_impl(const dsg_conv_args* a, hipStream_t st, int force_direct) {
   p.w = a->weight; p.bias = a->bias; p.ss = a->gn_scale_shift; p.silu = a->silu;
   p.temb = a->temb; p.temb_stride = a->temb_stride; p.res = a->residual; p.dst = a->dst;
   p.pool = a->pool2;
+  p.sblk = a->src_layout; p.dblk = a->dst_layout;
+  DSG_CHECK_ARG((a->src_layout | a->dst_layout) >= 0 && (a->src_layout | a->dst_layout) <= 1,
+                "dsg_conv2d_fwd: src_layout / dst_layout must be 0 or 1");
+  DSG_CHECK_ARG(!a->src_layout || (a->c0 % 8 == 0 && a->c1 % 8 == 0),
+                "dsg_conv2d_fwd: channel-blocked sources need c0 %% 8 == 0 and c1 %% 8 == 0");
+  DSG_CHECK_ARG(!a->dst_layout || (a->cout % 8 == 0 && !a->pool2),
+                "dsg_conv2d_fwd: a channel-blocked dst needs cout %% 8 == 0 and no pool2");
   p.tiles_x = (p.wout + TW - 1) / TW; p.tiles_y = p.hout / TH;
   DSG_CHECK_ARG(!(p.pool && ((p.hout | p.wout) & 1)), "dsg_conv2d_fwd: pool2 needs even output dims");
 
@@ -655,6 +679,9 @@ int conv2d_fwd_impl(const dsg_conv_args* a, hipStream_t st, int force_direct) {
   }
   DSG_CHECK_SHAPE(!p.pool, "dsg_conv2d_fwd: pool2 is only implemented on the MFMA path (shape %dx%d, cin %d)",
                   p.hout, p.wout, p.cin);
+  DSG_CHECK_SHAPE(!p.sblk && !p.dblk,
+                  "dsg_conv2d_fwd: channel-blocked tensors are only taken by the matrix-core and conv_out kernels "
+                  "(shape %dx%d, cin %d)", p.hout, p.wout, p.cin);
   return launch_direct(p, k, s, u, st);
 }
 
@@ -689,6 +716,14 @@ DSG_API int dsg_set_tuning(int32_t key, int32_t value) {
   }
   if (key == 6 && (value == 4 || value == 8)) {
     dsg::conv_h2_set_waves(value);
+    return DSG_OK;
+  }
+  if (key == 13 && (value == 0 || value == 1)) {
+    dsg::unet_set_blocked(value);
+    return DSG_OK;
+  }
+  if (key == 11 && (value == 0 || value == 1)) {
+    dsg::conv_h2_set_pw_occ2(value);
     return DSG_OK;
   }
   if (key == 5 && (value == 0 || value == 1)) {

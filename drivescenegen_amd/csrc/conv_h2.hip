@@ -112,8 +112,13 @@ __device__ __forceinline__ float silu_fast_h(float x) { return x * __builtin_amd
 //   units 0..FULL-1: g = 0, halo positions tid + 256*i      units FULL..2*FULL-1: g = 1, same positions
 //   last unit: g = wave >> 1, halo position FULL*256 + (tid & 127)   (the remainder, valid where < PSZ)
 // ACT: 0 the input is used as it is; 2 GroupNorm affine + SiLU; 3 decided at run time from p.ss / p.silu
-template <int GM, int NT, int KS, int ACT = 3, int NW = 4>
-__global__ __launch_bounds__(64 * NW, 1) void conv_h2_kernel(ConvH2P p) {
+// OCC: workgroups the kernel is compiled to fit per CU (register budget 512 / (OCC * NW / 4) per lane)
+// LAY: bit 0: the sources are channel-blocked [N][C/8][H][W][8] (a halo position's k-group is 32 contiguous bytes:
+//      two 16-byte loads instead of eight dword gathers from eight channel planes); bit 1: dst / residual are
+//      (a lane's four consecutive output channels are one 16-byte store; a wave instruction writes 1 KB contiguous)
+template <int GM, int NT, int KS, int ACT = 3, int NW = 4, int OCC = 1, int LAY = 0>
+__global__ __launch_bounds__(64 * NW, OCC * NW / 4) void conv_h2_kernel(ConvH2P p) {
+  constexpr bool SB = (LAY & 1) != 0, DB = (LAY & 2) != 0;
   using G = H2Geom<NT, KS, NW, GM == 2 ? 4 : KS * KS>;
   constexpr int NTH = G::NTH;
   constexpr int H2_TH = G::TH, H2_PSZ = G::PSZ, H2_XHALFS = G::XHALFS, H2_BUF_BYTES = G::BUF_BYTES, H2_NU = G::NU;
@@ -204,9 +209,16 @@ __global__ __launch_bounds__(64 * NW, 1) void conv_h2_kernel(ConvH2P p) {
   auto load_unit_to = [&](float (&dst)[H2_NU][8], int i, const float* sp) {
     const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<float*>(sp + (size_t)(unit_g(i) * 8) * plane), 0, 8 * plane * 4, 0x00020000);
+    if constexpr (SB) {  // (the k-group's 8 planes and its channel block start at the same address)
+      const float4 lo = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rs, goff[i] * 32, 0, 0));
+      const float4 hi = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rs, goff[i] * 32, 16, 0));
+      dst[i][0] = lo.x; dst[i][1] = lo.y; dst[i][2] = lo.z; dst[i][3] = lo.w;
+      dst[i][4] = hi.x; dst[i][5] = hi.y; dst[i][6] = hi.z; dst[i][7] = hi.w;
+    } else {
 #pragma unroll
-    for (int j = 0; j < 8; ++j)
-      dst[i][j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, goff[i] * 4, soff[j], 0));
+      for (int j = 0; j < 8; ++j)
+        dst[i][j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, goff[i] * 4, soff[j], 0));
+    }
   };
   auto load_unit = [&](int i, int q, const float* sp) { load_unit_to(xr, i, sp); };
   auto commit_unit_from = [&](const float (&src)[H2_NU][8], int i, int q, unsigned char* buf) {  // q: chunk staged
@@ -261,10 +273,18 @@ __global__ __launch_bounds__(64 * NW, 1) void conv_h2_kernel(ConvH2P p) {
     if (load) {
       const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
           const_cast<float*>(spn + (size_t)(unit_g(i) * 8) * plane), 0, 8 * plane * 4, 0x00020000);
+      if constexpr (SB) {  // four channels are free after every second step: one 16-byte load refills them
+        if (jp & 1) {
+          const float4 v4 =
+              __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rs, goff[i] * 32, 8 * (jp - 1), 0));
+          xr[i][2 * jp - 2] = v4.x; xr[i][2 * jp - 1] = v4.y; xr[i][2 * jp] = v4.z; xr[i][2 * jp + 1] = v4.w;
+        }
+      } else {
 #pragma unroll
-      for (int e = 0; e < 2; ++e)
-        xr[i][2 * jp + e] =
-            __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, goff[i] * 4, soff[2 * jp + e], 0));
+        for (int e = 0; e < 2; ++e)
+          xr[i][2 * jp + e] =
+              __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, goff[i] * 4, soff[2 * jp + e], 0));
+      }
     }
   };
   auto commit_unit = [&](int i, int q, unsigned char* buf) { commit_unit_from(xr, i, q, buf); };
@@ -357,7 +377,7 @@ __global__ __launch_bounds__(64 * NW, 1) void conv_h2_kernel(ConvH2P p) {
   }
   // (the DMAs were issued before every patch load: once chunk 0's values have been used they have landed; 8 * NU
   // loads of chunk 1 may still be in flight)
-  if (nq > 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(8 * H2_NU) : "memory");
+  if (nq > 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((SB ? 2 : 8) * H2_NU) : "memory");
   else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
 
@@ -503,15 +523,29 @@ __global__ __launch_bounds__(64 * NW, 1) void conv_h2_kernel(ConvH2P p) {
       const_cast<float*>(p.temb ? p.temb + (size_t)n * p.temb_stride + m0 : p.dst), 0, p.temb ? nvalid * 4 : 0, 0x00020000);
   int voff[NT];  // bytes, per lane and row; the channel part of an address is the scalar offset
 #pragma unroll
-  for (int nt = 0; nt < NT; ++nt)
-    voff[nt] = GM == 2 ? (4 * half * oplane + (2 * (oy0 + wave * NT + nt) + (phase >> 1)) * (2 * p.wout) +
-                          2 * (ox0 + l31) + (phase & 1)) * 4
-                       : (ox0 + l31 < p.wout ? (4 * half * oplane + (oy0 + wave * NT + nt) * p.wout + ox0 + l31) * 4
-                                             : 0x7FFFFFF0);  // (narrow maps: past the last column -> out of range)
+  for (int nt = 0; nt < NT; ++nt) {
+    if constexpr (DB) {  // [C/8][H][W][8]: pixel * 32 bytes + this half-wave's four channels
+      const int oy = GM == 2 ? 2 * (oy0 + wave * NT + nt) + (phase >> 1) : oy0 + wave * NT + nt;
+      const int ox = GM == 2 ? 2 * (ox0 + l31) + (phase & 1) : ox0 + l31;
+      voff[nt] = (GM == 2 || ox0 + l31 < p.wout) ? ((oy * (p.wout * oscale) + ox) * 8 + 4 * half) * 4 : 0x7FFFFFF0;
+    } else {
+      voff[nt] = GM == 2 ? (4 * half * oplane + (2 * (oy0 + wave * NT + nt) + (phase >> 1)) * (2 * p.wout) +
+                            2 * (ox0 + l31) + (phase & 1)) * 4
+                         : (ox0 + l31 < p.wout ? (4 * half * oplane + (oy0 + wave * NT + nt) * p.wout + ox0 + l31) * 4
+                                               : 0x7FFFFFF0);  // (narrow maps: past the last column -> out of range)
+    }
+  }
   const int oplane4 = __builtin_amdgcn_readfirstlane(oplane * 4);
   // NARROW: maps less than one tile wide (16x16, 8x8): lanes past the last column store nothing (their offset is out
   // of the descriptor's range) and count as zeros in the statistics
   const bool lane_ok = ox0 + l31 < p.wout;
+#ifdef DSG_H2_TIMING
+  unsigned long long rt_e[6] = {0, 0, 0, 0, 0, 0};
+#define DSG_ET(i) do { __builtin_amdgcn_sched_barrier(0); rt_e[i] = __builtin_amdgcn_s_memrealtime(); __builtin_amdgcn_sched_barrier(0); } while (0)
+#else
+#define DSG_ET(i)
+#endif
+  DSG_ET(0);
   auto epilogue = [&](auto stats_tag, auto narrow_tag) {
     constexpr bool STATS = decltype(stats_tag)::value, NARROW = decltype(narrow_tag)::value;
 #pragma unroll
@@ -524,48 +558,82 @@ __global__ __launch_bounds__(64 * NW, 1) void conv_h2_kernel(ConvH2P p) {
                   __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(temb_rs, 16 * half, crel * 4, 0));
       }
       if (has_r) {
+        if constexpr (DB) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r)
+          for (int rg = 0; rg < 4; ++rg)
 #pragma unroll
-          for (int nt = 0; nt < NT; ++nt) {
-            const int crel = mt * 32 + (r & 3) + 8 * (r >> 2);
-            rv[r][nt] = __builtin_bit_cast(
-                float, __builtin_amdgcn_raw_buffer_load_b32(res_rs, voff[nt], crel * oplane4, 0));
-          }
+            for (int nt = 0; nt < NT; ++nt) {
+              const float4 q = __builtin_bit_cast(
+                  float4, __builtin_amdgcn_raw_buffer_load_b128(res_rs, voff[nt], (mt * 4 + rg) * 8 * oplane4, 0));
+              rv[4 * rg][nt] = q.x; rv[4 * rg + 1][nt] = q.y; rv[4 * rg + 2][nt] = q.z; rv[4 * rg + 3][nt] = q.w;
+            }
+        } else {
+#pragma unroll
+          for (int r = 0; r < 16; ++r)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+              const int crel = mt * 32 + (r & 3) + 8 * (r >> 2);
+              rv[r][nt] = __builtin_bit_cast(
+                  float, __builtin_amdgcn_raw_buffer_load_b32(res_rs, voff[nt], crel * oplane4, 0));
+            }
+        }
       } else {
 #pragma unroll
         for (int r = 0; r < 16; ++r)
 #pragma unroll
           for (int nt = 0; nt < NT; ++nt) rv[r][nt] = 0.f;
       }
+#ifdef DSG_H2_TIMING
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (timing build: the slab's loads have landed)
+#endif
+      DSG_ET(1 + 2 * mt);
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int crel = mt * 32 + (r & 3) + 8 * (r >> 2);
-        float s1[NT / 2], s2[NT / 2];
+      for (int rg = 0; rg < 4; ++rg) {  // a register group = four consecutive output channels
+        float vv[4][NT];
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt) {
-          const float v = ((acc_hi[mt][nt][r] + acc_lo[mt][nt][r] * (1.0f / 2048.0f)) + addv[r]) + rv[r][nt];
-          __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, v), dst_rs, voff[nt], crel * oplane4, 0);
-          const float vs = (NARROW && !lane_ok) ? 0.f : v;
-          if (nt & 1) {
-            s1[nt / 2] += vs;
-            s2[nt / 2] += vs * vs;
-          } else {
-            s1[nt / 2] = vs;
-            s2[nt / 2] = vs * vs;
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+          for (int nt = 0; nt < NT; ++nt) {
+            const int r = 4 * rg + j;
+            vv[j][nt] = ((acc_hi[mt][nt][r] + acc_lo[mt][nt][r] * (1.0f / 2048.0f)) + addv[r]) + rv[r][nt];
           }
+        if constexpr (DB) {  // the group is 16 contiguous bytes of the pixel's channel block
+#pragma unroll
+          for (int nt = 0; nt < NT; ++nt) {
+            typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+            const float4 o = make_float4(vv[0][nt], vv[1][nt], vv[2][nt], vv[3][nt]);
+            // The channel-block offset goes into the VECTOR offset on purpose.  With an SGPR soffset hipcc 7.2 treats
+            // the 16-byte store as free of the "VALU overwrites store data" hazard and re-uses the data registers
+            // two or three instructions later; on gfx950 that corrupted the second dword of lanes 12..15 of every
+            // row (found by the bit-exact layout tests).  Without an soffset register it inserts the wait states.
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o), dst_rs,
+                                                   voff[nt] + (mt * 4 + rg) * 8 * oplane4, 0, 0);
+          }
+        } else {
+#pragma unroll
+          for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+              __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, vv[j][nt]), dst_rs, voff[nt],
+                                                    (mt * 32 + j + 8 * rg) * oplane4, 0);
         }
         if (STATS) {  // GroupNorm statistics of the tensor just produced (the next layer's norm reads them)
 #pragma unroll
-          for (int pr = 0; pr < NT / 2; ++pr) {  // one partial per pair of rows: the same summation tree for any NT
-            const float t1 = half_wave_sum(s1[pr]), t2 = half_wave_sum(s2[pr]);
-            // every lane stores -- lanes 16 / 48 to the real slot, the others to a per-lane dump area behind it:
-            // a predicated store here is a branch, and 128 branches fence the scheduler between the DPP chains
-            red_lane[((wave * (NT / 2) + pr) * 2 + 0) * H2_BM + crel] = t1;
-            red_lane[((wave * (NT / 2) + pr) * 2 + 1) * H2_BM + crel] = t2;
+          for (int j = 0; j < 4; ++j) {
+            const int crel = mt * 32 + j + 8 * rg;
+#pragma unroll
+            for (int pr = 0; pr < NT / 2; ++pr) {  // one partial per pair of rows: the same summation tree for any NT
+              const float a = (NARROW && !lane_ok) ? 0.f : vv[j][2 * pr], b = (NARROW && !lane_ok) ? 0.f : vv[j][2 * pr + 1];
+              const float t1 = half_wave_sum(a + b), t2 = half_wave_sum(a * a + b * b);
+              // every lane stores -- lanes 16 / 48 to the real slot, the others to a per-lane dump area behind it:
+              // a predicated store here is a branch, and 128 branches fence the scheduler between the DPP chains
+              red_lane[((wave * (NT / 2) + pr) * 2 + 0) * H2_BM + crel] = t1;
+              red_lane[((wave * (NT / 2) + pr) * 2 + 1) * H2_BM + crel] = t2;
+            }
           }
         }
       }
+      DSG_ET(2 + 2 * mt);
     }
   };
   if (p.wout < H2_TW) {
@@ -617,6 +685,9 @@ __global__ __launch_bounds__(64 * NW, 1) void conv_h2_kernel(ConvH2P p) {
       rec[3] = (double)t_loop_cycles;
       double* pr = p.stats + 8 + 5 * (size_t)gridDim.x + 16 + 4 * (size_t)blockIdx.x;
       for (int k = 0; k < 4; ++k) pr[k] = (double)rt_p[k];
+      double* er = p.stats + 8 + 9 * (size_t)gridDim.x + 16 + 6 * (size_t)blockIdx.x;
+      rt_e[5] = __builtin_amdgcn_s_memrealtime();
+      for (int k = 0; k < 6; ++k) er[k] = (double)rt_e[k];
     }
   }
 #endif
@@ -655,6 +726,7 @@ static int g_h2_enabled = 1;
 static int g_h2_waves = 4;  // 16-row tiles: 4 waves x 4 rows or 8 waves x 2 rows (tuning key 6)
 static int g_h2_fold = 1;   // folded up-sampler convs (tuning key 8: A/B against the x2 gather)
 static int g_h2_stats = 1;  // epilogue GroupNorm statistics (tuning key 5: A/B against the separate pass)
+static int g_h2_pw_occ2 = 1;  // pointwise convs: 8-row tiles compiled for two workgroups per CU (tuning key 11)
 static int g_h2_rows = 0;  // rows per wave: 0 = by grid size, 2 | 4 forced (tuning key 3)
 
 // folded up-sampler mode: nearest x2 + 3x3 as four 2x2 convs of the low-resolution input (weight_h2_fold)
@@ -667,6 +739,11 @@ static bool conv_h2_fold(const dsg_conv_args* a) {
 
 bool conv_h2_eligible(const dsg_conv_args* a, int hout, int wout) {
   const int cin = a->c0 + a->c1;
+  const int lay = (a->src_layout ? 1 : 0) | (a->dst_layout ? 2 : 0);
+  // channel-blocked tensors: 3x3 stride-1 convs (plain or folded up-sampler) with every tensor blocked; pointwise
+  // convs with any pair of layouts
+  if (lay && a->ksize == 3 && (lay != 3 || (a->upsample && !conv_h2_fold(a)))) return false;
+  if (lay && (a->c0 % 8 || a->c1 % 8 || a->cout % 8)) return false;
   if (conv_h2_fold(a)) return true;
   if (a->weight_h2_cout_stride && (a->weight_h2_cout_stride % 64 || a->weight_h2_cout_stride < (a->cout + 63) / 64 * 64))
     return false;
@@ -711,8 +788,23 @@ int conv_h2_stats_tiles(const dsg_conv_args* a, int hout, int wout) {
   return (hout / 8) * ((wout + H2_TW - 1) / H2_TW);  // 8-row x 32-column statistics tiles for either block height
 }
 
+template <int GM, int NT, int KS, int ACT, int NW = 4, int OCC = 1, int LAY = 0>
+static int h2_launch(dim3 grid, size_t lds, hipStream_t st, const ConvH2P& p) {
+  auto kern = conv_h2_kernel<GM, NT, KS, ACT, NW, OCC, LAY>;
+  static bool raised = false;
+  if (!raised) {
+    DSG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                160 * 1024));
+    raised = true;
+  }
+  hipLaunchKernelGGL(kern, grid, dim3(64 * NW), lds, st, p);
+  return DSG_OK;
+}
+
 int conv_h2_launch(const dsg_conv_args* a, int hout, int wout, hipStream_t st) {
-  const bool nt4 = conv_h2_rows16(a, hout, wout);
+  // pointwise: 8-row tiles, two workgroups per CU (the only pointwise kernels that take channel-blocked tensors)
+  const bool occ2 = a->ksize == 1 && (g_h2_pw_occ2 || a->src_layout || a->dst_layout);
+  const bool nt4 = !occ2 && conv_h2_rows16(a, hout, wout);
   ConvH2P p;
   p.stats = a->stats_out;
   p.src0 = a->src0; p.src1 = a->src1; p.c0 = a->c0; p.c1 = a->c1; p.cin = a->c0 + a->c1;
@@ -749,43 +841,50 @@ int conv_h2_launch(const dsg_conv_args* a, int hout, int wout, hipStream_t st) {
                     4.0 * ((double)p.n * p.cin * p.hin * p.win + (double)p.cin * taps * p.cout +
                            px * p.cout * (p.res ? 2.0 : 1.0)), st);
   }
-  static bool raised = false;
-  if (!raised) {
-    const void* ks[20] = {
-        reinterpret_cast<const void*>(conv_h2_kernel<0, 2, 3, 0, 8>), reinterpret_cast<const void*>(conv_h2_kernel<0, 2, 3, 2, 8>),
-        reinterpret_cast<const void*>(conv_h2_kernel<1, 2, 3, 0, 8>), reinterpret_cast<const void*>(conv_h2_kernel<0, 2, 1, 0, 8>),
-        reinterpret_cast<const void*>(conv_h2_kernel<0, 2, 1, 3, 8>),
-        reinterpret_cast<const void*>(conv_h2_kernel<0, 2, 3, 0>), reinterpret_cast<const void*>(conv_h2_kernel<0, 4, 3, 0>),
-        reinterpret_cast<const void*>(conv_h2_kernel<0, 2, 3, 2>), reinterpret_cast<const void*>(conv_h2_kernel<0, 4, 3, 2>),
-        reinterpret_cast<const void*>(conv_h2_kernel<1, 2, 3, 0>), reinterpret_cast<const void*>(conv_h2_kernel<1, 4, 3, 0>),
-        reinterpret_cast<const void*>(conv_h2_kernel<0, 2, 1, 0>), reinterpret_cast<const void*>(conv_h2_kernel<0, 4, 1, 0>),
-        reinterpret_cast<const void*>(conv_h2_kernel<0, 2, 1, 3>), reinterpret_cast<const void*>(conv_h2_kernel<0, 4, 1, 3>),
-        reinterpret_cast<const void*>(conv_h2_kernel<2, 2, 3, 0>), reinterpret_cast<const void*>(conv_h2_kernel<2, 4, 3, 0>)};
-    for (const void* k : ks)
-      if (k) DSG_HIP(hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    raised = true;
-  }
   const int act = a->gn_scale_shift ? (a->silu ? 2 : 3) : 0;
-#define DSG_H2_LAUNCH(GM, KS, ACT)                                                                  \
-  do {                                                                                              \
-    if (nt4 && g_h2_waves == 8)                                                                     \
-      hipLaunchKernelGGL((conv_h2_kernel<GM, 2, KS, ACT, 8>), grid, dim3(512), lds, st, p);         \
-    else if (nt4) hipLaunchKernelGGL((conv_h2_kernel<GM, 4, KS, ACT>), grid, dim3(256), lds, st, p); \
-    else hipLaunchKernelGGL((conv_h2_kernel<GM, 2, KS, ACT>), grid, dim3(256), lds, st, p);         \
+  const int lay = (a->src_layout ? 1 : 0) | (a->dst_layout ? 2 : 0);
+  int rc = DSG_OK;
+#define DSG_H2_LAUNCH(GM, KS, ACT)                                                  \
+  do {                                                                              \
+    if (nt4 && g_h2_waves == 8) rc = h2_launch<GM, 2, KS, ACT, 8>(grid, lds, st, p); \
+    else if (nt4) rc = h2_launch<GM, 4, KS, ACT>(grid, lds, st, p);                 \
+    else rc = h2_launch<GM, 2, KS, ACT>(grid, lds, st, p);                          \
+  } while (0)
+#define DSG_H2_LAUNCH_BLK(GM, KS, ACT) /* every tensor channel-blocked: four-wave kernels only */ \
+  do {                                                                              \
+    if (nt4) rc = h2_launch<GM, 4, KS, ACT, 4, 1, 3>(grid, lds, st, p);             \
+    else rc = h2_launch<GM, 2, KS, ACT, 4, 1, 3>(grid, lds, st, p);                 \
+  } while (0)
+#define DSG_H2_LAUNCH_PW(ACT) /* pointwise, two workgroups per CU: any layout pair */ \
+  do {                                                                              \
+    if (lay == 0) rc = h2_launch<0, 2, 1, ACT, 4, 2, 0>(grid, lds, st, p);          \
+    else if (lay == 1) rc = h2_launch<0, 2, 1, ACT, 4, 2, 1>(grid, lds, st, p);     \
+    else if (lay == 2) rc = h2_launch<0, 2, 1, ACT, 4, 2, 2>(grid, lds, st, p);     \
+    else rc = h2_launch<0, 2, 1, ACT, 4, 2, 3>(grid, lds, st, p);                   \
   } while (0)
   if (fold) {
-    if (nt4) hipLaunchKernelGGL((conv_h2_kernel<2, 4, 3, 0>), grid, dim3(256), lds, st, p);
-    else hipLaunchKernelGGL((conv_h2_kernel<2, 2, 3, 0>), grid, dim3(256), lds, st, p);
+    if (lay) DSG_H2_LAUNCH_BLK(2, 3, 0);
+    else if (nt4) rc = h2_launch<2, 4, 3, 0>(grid, lds, st, p);
+    else rc = h2_launch<2, 2, 3, 0>(grid, lds, st, p);
+  } else if (k1 && occ2) {
+    if (act == 0) DSG_H2_LAUNCH_PW(0);
+    else DSG_H2_LAUNCH_PW(3);
   } else if (k1) {
     if (act == 0) DSG_H2_LAUNCH(0, 1, 0);
     else DSG_H2_LAUNCH(0, 1, 3);
   } else if (a->upsample) {
     DSG_H2_LAUNCH(1, 3, 0);
+  } else if (lay) {
+    if (act == 0) DSG_H2_LAUNCH_BLK(0, 3, 0);
+    else DSG_H2_LAUNCH_BLK(0, 3, 2);
   } else {
     if (act == 0) DSG_H2_LAUNCH(0, 3, 0);
     else DSG_H2_LAUNCH(0, 3, 2);
   }
 #undef DSG_H2_LAUNCH
+#undef DSG_H2_LAUNCH_BLK
+#undef DSG_H2_LAUNCH_PW
+  if (rc != DSG_OK) return rc;
   prof_end(pi, st);
   DSG_LAUNCH_CHECK();
   return DSG_OK;
@@ -796,6 +895,7 @@ void conv_h2_set_rows(int r) { g_h2_rows = r; }
 void conv_h2_set_stats(int on) { g_h2_stats = on; }
 void conv_h2_set_fold(int on) { g_h2_fold = on; }
 void conv_h2_set_waves(int w) { g_h2_waves = w; }
+void conv_h2_set_pw_occ2(int v) { g_h2_pw_occ2 = v; }
 
 }  // namespace dsg
 

@@ -58,6 +58,42 @@ __global__ __launch_bounds__(256) void gn_channel_stats_kernel(const float* __re
   }
 }
 
+// The same statistics of a channel-blocked tensor [N][C/8][hw][8]: grid = (C/8, n); a thread walks pixels and keeps
+// the 8 channels of its block.
+__global__ __launch_bounds__(256) void gn_channel_stats_blk_kernel(const float* __restrict__ src, int c, int hw,
+                                                                   double* __restrict__ stats) {
+  const int cb = blockIdx.x, n = blockIdx.y;
+  const float4* sp = reinterpret_cast<const float4*>(src + ((size_t)n * c + cb * 8) * hw);
+  double s[8], ss[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) s[j] = ss[j] = 0.0;
+  for (int i = threadIdx.x; i < hw; i += 256) {
+    const float4 a = sp[2 * i], b = sp[2 * i + 1];
+    const float v[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      s[j] += (double)v[j];
+      ss[j] += (double)v[j] * v[j];
+    }
+  }
+  __shared__ double red[16][4];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const double a = wave_sum(s[j]), b = wave_sum(ss[j]);
+    if (lane == 0) {
+      red[2 * j][wave] = a;
+      red[2 * j + 1][wave] = b;
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x < 16) {
+    const int j = threadIdx.x >> 1, which = threadIdx.x & 1;
+    stats[((size_t)n * c + cb * 8 + j) * 2 + which] =
+        red[threadIdx.x][0] + red[threadIdx.x][1] + red[threadIdx.x][2] + red[threadIdx.x][3];
+  }
+}
+
 // one thread per (n, c)
 __global__ void gn_finalize_kernel(const double* __restrict__ stats, const float* __restrict__ gamma,
                                    const float* __restrict__ beta, int n, int c, int groups, int hw, float eps,
@@ -165,6 +201,17 @@ DSG_API int dsg_gn_channel_stats(const float* src0, int32_t c0, const float* src
   DSG_CHECK_ARG(n <= 65535, "dsg_gn_channel_stats: batch too large for one launch");
   hipLaunchKernelGGL(dsg::gn_channel_stats_kernel, dim3(c0 + c1, n), dim3(256), 0, static_cast<hipStream_t>(stream),
                      src0, c0, src1, c1, hw, chan_stats);
+  DSG_LAUNCH_CHECK();
+  return DSG_OK;
+}
+
+DSG_API int dsg_gn_channel_stats_blocked(const float* src, int32_t c, int32_t n, int32_t hw, double* chan_stats,
+                                         void* stream) {
+  DSG_CHECK_ARG(src && chan_stats, "dsg_gn_channel_stats_blocked: NULL pointer");
+  DSG_CHECK_ARG(c > 0 && c % 8 == 0 && n > 0 && hw > 0, "dsg_gn_channel_stats_blocked: bad dims (C %% 8 != 0?)");
+  DSG_CHECK_ARG(n <= 65535, "dsg_gn_channel_stats_blocked: batch too large for one launch");
+  hipLaunchKernelGGL(dsg::gn_channel_stats_blk_kernel, dim3(c / 8, n), dim3(256), 0, static_cast<hipStream_t>(stream),
+                     src, c, hw, chan_stats);
   DSG_LAUNCH_CHECK();
   return DSG_OK;
 }

@@ -65,6 +65,31 @@ __global__ __launch_bounds__(256) void mask_lut_kernel(const uint8_t* __restrict
   out[(size_t)n * hw + i] = b ? on : off;
 }
 
+
+// [N][C][hw] <-> [N][C/8][hw][8]: one thread per (n, c/8, pixel), eight channels each
+__global__ __launch_bounds__(256) void layout_convert_kernel(const float* __restrict__ src, float* __restrict__ dst, int c,
+                                                             int hw, int64_t total, int to_blocked) {
+  const int64_t i = blockIdx.x * (int64_t)256 + threadIdx.x;
+  if (i >= total) return;
+  const int px = (int)(i % hw);
+  const int64_t blk = i / hw;  // n * (c/8) + cb
+  const size_t plain = (size_t)blk * 8 * hw + px, blocked = ((size_t)blk * hw + px) * 8;
+  if (to_blocked) {
+    float v[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = src[plain + (size_t)j * hw];
+    float4* o = reinterpret_cast<float4*>(dst + blocked);
+    o[0] = make_float4(v[0], v[1], v[2], v[3]);
+    o[1] = make_float4(v[4], v[5], v[6], v[7]);
+  } else {
+    const float4* q = reinterpret_cast<const float4*>(src + blocked);
+    const float4 a = q[0], b = q[1];
+    const float v[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+#pragma unroll
+    for (int j = 0; j < 8; ++j) dst[plain + (size_t)j * hw] = v[j];
+  }
+}
+
 }  // namespace dsg
 
 DSG_API int dsg_resize_normalize_u8(const uint8_t* src, int32_t n, int32_t hs, int32_t ws, int32_t c, float* dst,
@@ -96,6 +121,17 @@ DSG_API int dsg_mask_lut_u8(const uint8_t* img, int32_t n, int32_t hw, int32_t c
   DSG_CHECK_ARG(n > 0 && hw > 0 && c > 0 && ch0 >= 0 && ch0 < c && ch1 < c && n <= 65535, "dsg_mask_lut_u8: bad dims");
   hipLaunchKernelGGL(dsg::mask_lut_kernel, dim3(dsg::cdiv(hw, 256), n), dim3(256), 0, static_cast<hipStream_t>(stream),
                      img, hw, c, ch0, ch1, lut, on_value, off_value, out);
+  DSG_LAUNCH_CHECK();
+  return DSG_OK;
+}
+
+DSG_API int dsg_layout_convert(const float* src, float* dst, int32_t n, int32_t c, int32_t hw, int32_t to_blocked,
+                               void* stream) {
+  DSG_CHECK_ARG(src && dst && src != dst, "dsg_layout_convert: NULL pointer or in-place");
+  DSG_CHECK_ARG(n > 0 && c > 0 && c % 8 == 0 && hw > 0, "dsg_layout_convert: bad dims (C %% 8 != 0?)");
+  const int64_t total = (int64_t)n * (c / 8) * hw;
+  hipLaunchKernelGGL(dsg::layout_convert_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0,
+                     static_cast<hipStream_t>(stream), src, dst, c, hw, total, to_blocked);
   DSG_LAUNCH_CHECK();
   return DSG_OK;
 }

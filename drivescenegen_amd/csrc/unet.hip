@@ -75,6 +75,7 @@ struct T {  // activation [N, c, h, w] (or any scratch when c/h/w are unused)
   std::shared_ptr<Buf> b;
   float* p = nullptr;
   int c = 0, h = 0, w = 0;
+  int blk = 0;  // 1: channel-blocked [N][c/8][h][w][8] (dsg_conv_args.*_layout); the net's intermediates are
   // per-tile (sum, sum of squares) of every channel, written by the conv that produced the tensor
   std::shared_ptr<Buf> sb;
   double* stats = nullptr;
@@ -100,6 +101,13 @@ struct Param {
 };
 
 }  // namespace
+
+namespace dsg {
+// intermediates of dsg_unet_forward in the channel-blocked layout (tuning key 13: A/B against [N,C,H,W])
+static int g_unet_blocked = 1;
+int unet_blocked() { return g_unet_blocked; }
+void unet_set_blocked(int v) { g_unet_blocked = v; }
+}  // namespace dsg
 
 struct dsg_unet {
   dsg_unet_config cfg;
@@ -200,6 +208,7 @@ struct Runner {
   hipStream_t st;
   Arena arena;
   int rc = DSG_OK;
+  bool blocked = false;  // intermediates channel-blocked (every channel count a multiple of 8; tuning key 13)
 
   T alloc(int c, int hh, int w, size_t elems = 0, size_t esz = sizeof(float)) {
     T t;
@@ -233,7 +242,10 @@ struct Runner {
       sp[i] = reinterpret_cast<double*>(tmp[i].p);
       tl[i] = 1;
       if (!dry && ok())
-        rc = dsg_gn_channel_stats(src[i]->p, src[i]->c, nullptr, 0, B, x.h * x.w, reinterpret_cast<double*>(tmp[i].p), st);
+        rc = src[i]->blk ? dsg_gn_channel_stats_blocked(src[i]->p, src[i]->c, B, x.h * x.w,
+                                                        reinterpret_cast<double*>(tmp[i].p), st)
+                         : dsg_gn_channel_stats(src[i]->p, src[i]->c, nullptr, 0, B, x.h * x.w,
+                                                reinterpret_cast<double*>(tmp[i].p), st);
     }
     if (!dry && ok())
       rc = dsg_gn_finalize_parts(sp[0], x.c, tl[0], sp[1], skip ? skip->c : 0, tl[1], gn.g, gn.b, B,
@@ -242,8 +254,12 @@ struct Runner {
   }
 
   // want_stats: the result feeds a GroupNorm -- have the conv write its per-tile statistics when it can
+  // dst_blk: layout of the result (-1: the net's default for intermediates)
   T conv(const T& x, const T* skip, const Conv& cv, int stride, int ups, const T* ss, int silu, const float* temb,
-         const T* res, float* dst_override = nullptr, bool want_stats = false) {
+         const T* res, float* dst_override = nullptr, bool want_stats = false, int dst_blk = -1) {
+    if (dst_blk < 0) dst_blk = blocked ? 1 : 0;
+    if (ok() && ((skip && skip->blk != x.blk) || (res && res->blk != dst_blk)))
+      rc = dsg::fail(DSG_ERR_INVALID_ARG, "dsg_unet_forward: mixed activation layouts in one conv (internal)");
     const int hc = ups ? 2 * x.h : x.h, wc = ups ? 2 * x.w : x.w;
     const int pad = cv.k / 2;
     const int ho = (hc + 2 * pad - cv.k) / stride + 1, wo = (wc + 2 * pad - cv.k) / stride + 1;
@@ -263,6 +279,8 @@ struct Runner {
     a.temb = temb; a.temb_stride = h->proj_total;
     a.residual = res ? res->p : nullptr;
     a.dst = y.p;
+    a.src_layout = x.blk; a.dst_layout = dst_blk;
+    y.blk = dst_blk;
     if (want_stats && ok()) {
       int32_t tiles = 0;
       rc = dsg_conv2d_stats_tiles(&a, &tiles);
@@ -296,7 +314,7 @@ struct Runner {
 
   T attention(const T& x, const Att& at) {
     T ss = gn_ss(x, nullptr, at.gn);
-    T qkv = conv(x, nullptr, at.qkv, 1, 0, &ss, 0, nullptr, nullptr);
+    T qkv = conv(x, nullptr, at.qkv, 1, 0, &ss, 0, nullptr, nullptr, nullptr, false, 0);  // (the attention kernel reads [N,3C,L])
     ss = T();
     T o = alloc(x.c, x.h, x.w);
     if (!dry && ok()) rc = dsg_attention_fwd(qkv.p, o.p, B, x.c, at.heads, x.h * x.w, st);
@@ -306,6 +324,8 @@ struct Runner {
 
   int run(const float* xin, const int64_t* t, float* out) {
     const dsg_unet_config& cfg = h->cfg;
+    blocked = dsg::unet_blocked() != 0;
+    for (int i = 0; i < cfg.num_blocks; ++i) blocked = blocked && cfg.block_out_channels[i] % 8 == 0;
     T act = alloc(0, 0, 0, (size_t)B * h->temb_dim);
     T tproj = alloc(0, 0, 0, (size_t)B * h->proj_total);
     if (!dry) {
@@ -342,7 +362,7 @@ struct Runner {
       if (u.resample) x = conv(x, nullptr, u.rconv, 1, 1, nullptr, 0, nullptr, nullptr, nullptr, true);
     }
     T ssf = gn_ss(x, nullptr, h->norm_out);
-    conv(x, nullptr, h->conv_out, 1, 0, &ssf, 1, nullptr, nullptr, out);
+    conv(x, nullptr, h->conv_out, 1, 0, &ssf, 1, nullptr, nullptr, out, false, 0);
     return rc;
   }
 };
@@ -551,11 +571,12 @@ DSG_API int dsg_unet_param_name(const dsg_unet_t* h, int64_t index, const char**
 DSG_API int dsg_unet_workspace_bytes(dsg_unet_t* h, int32_t batch, size_t* bytes) {
   DSG_CHECK_ARG(h && bytes, "dsg_unet_workspace_bytes: NULL argument");
   DSG_CHECK_ARG(batch > 0, "dsg_unet_workspace_bytes: batch must be positive");
-  auto it = h->ws_cache.find(batch);
+  const int key = 2 * batch + (dsg::unet_blocked() ? 1 : 0);  // (the layout decides which convs write statistics)
+  auto it = h->ws_cache.find(key);
   if (it == h->ws_cache.end()) {
     Runner r{h, batch, nullptr, true, nullptr};
     r.run(nullptr, nullptr, nullptr);
-    it = h->ws_cache.emplace(batch, r.arena.high).first;
+    it = h->ws_cache.emplace(key, r.arena.high).first;
   }
   *bytes = it->second;
   return DSG_OK;

@@ -90,14 +90,21 @@ def relayout_conv_weight_dgrad(w_oihw: torch.Tensor, out: torch.Tensor = None) -
 
 def conv2d_fused(src0, weight_r, bias=None, src1=None, ksize=3, stride=1, upsample=False, gn_scale_shift=None,
                  silu=False, temb=None, temb_stride=0, residual=None, out=None, direct=False, cout=None,
-                 pool2=False, wstride=None, weight_h2=None, want_stats=False, stats_buf=None, weight_h2_col=0, weight_h2_fold=None):
+                 pool2=False, wstride=None, weight_h2=None, want_stats=False, stats_buf=None, weight_h2_col=0, weight_h2_fold=None,
+                 src_blocked=False, dst_blocked=False):
     """dsg_conv2d_fwd: see include/dsg.h.  `weight_r` is in engine layout; `temb` is a [N, temb_stride] view
     whose first `cout` columns (from its data pointer) are added per (n, cout).
     want_stats: also return the per-tile GroupNorm statistics [N][cout][tiles][2] (fp64) of the result, or None
-    when the kernel serving the call does not produce them."""
+    when the kernel serving the call does not produce them.
+    src_blocked / dst_blocked: the sources / (result, residual) are channel-blocked [N, C/8, H, W, 8] tensors."""
     lib = _lib.load()
-    n, c0, hin, win = src0.shape
-    c1 = src1.shape[1] if src1 is not None else 0
+    if src_blocked:
+        n, cb0, hin, win, _ = src0.shape
+        c0 = 8 * cb0
+        c1 = 8 * src1.shape[1] if src1 is not None else 0
+    else:
+        n, c0, hin, win = src0.shape
+        c1 = src1.shape[1] if src1 is not None else 0
     wptr = weight_r.data_ptr() if wstride else _lib.ptr(weight_r)  # a column window of a wider matrix is allowed
     wstride = wstride or weight_r.shape[-1]
     cout = cout or wstride
@@ -106,9 +113,12 @@ def conv2d_fused(src0, weight_r, bias=None, src1=None, ksize=3, stride=1, upsamp
     ho = (hc + 2 * pad - ksize) // stride + 1
     wo = (wc + 2 * pad - ksize) // stride + 1
     if out is None:
-        out = torch.empty((n, cout, ho // 2, wo // 2) if pool2 else (n, cout, ho, wo), dtype=torch.float32,
-                          device=src0.device)
+        shape = (n, cout, ho // 2, wo // 2) if pool2 else (n, cout, ho, wo)
+        if dst_blocked:
+            shape = (n, cout // 8, shape[2], shape[3], 8)
+        out = torch.empty(shape, dtype=torch.float32, device=src0.device)
     a = _lib.ConvArgs()
+    a.src_layout, a.dst_layout = int(src_blocked), int(dst_blocked)
     a.src0, a.src1 = _lib.ptr(src0), _lib.ptr(src1)
     a.c0, a.c1, a.n, a.hin, a.win = c0, c1, n, hin, win
     a.upsample, a.ksize, a.stride, a.cout = int(upsample), ksize, stride, cout
@@ -136,6 +146,33 @@ def conv2d_fused(src0, weight_r, bias=None, src1=None, ksize=3, stride=1, upsamp
     with torch.cuda.device(src0.device):
         _lib.check(fn(C.byref(a), _st(src0)))
     return (out, stats) if want_stats else out
+
+
+def to_blocked(x):
+    """[N, C, H, W] -> channel-blocked [N, C/8, H, W, 8] (dsg_layout_convert)."""
+    n, c, h, w = x.shape
+    out = torch.empty((n, c // 8, h, w, 8), dtype=torch.float32, device=x.device)
+    with torch.cuda.device(x.device):
+        _lib.check(_lib.load().dsg_layout_convert(_lib.ptr(x), _lib.ptr(out), n, c, h * w, 1, _st(x)))
+    return out
+
+
+def from_blocked(x):
+    """channel-blocked [N, C/8, H, W, 8] -> [N, C, H, W]."""
+    n, cb, h, w, _ = x.shape
+    out = torch.empty((n, cb * 8, h, w), dtype=torch.float32, device=x.device)
+    with torch.cuda.device(x.device):
+        _lib.check(_lib.load().dsg_layout_convert(_lib.ptr(x), _lib.ptr(out), n, cb * 8, h * w, 0, _st(x)))
+    return out
+
+
+def gn_channel_stats_blocked(x):
+    """dsg_gn_channel_stats_blocked: per-(n, c) (sum, sum of squares) of a channel-blocked tensor, fp64 [N][C][2]."""
+    n, cb, h, w, _ = x.shape
+    st = torch.empty((n, cb * 8, 2), dtype=torch.float64, device=x.device)
+    with torch.cuda.device(x.device):
+        _lib.check(_lib.load().dsg_gn_channel_stats_blocked(_lib.ptr(x), cb * 8, n, h * w, _lib.ptr(st), _st(x)))
+    return st
 
 
 def gn_scale_shift_from_parts_train(stats0, gamma, beta, groups, eps, hw, stats1=None):

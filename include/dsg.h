@@ -84,9 +84,17 @@ typedef struct {
   double* stats_out;            /* optional [N][cout][tiles][2]: per-tile (sum, sum of squares) of dst, so that the
                                    GroupNorm that follows needs no pass of its own over dst (dsg_gn_finalize_parts).
                                    Only where dsg_conv2d_stats_tiles reports tiles > 0. */
+  int32_t src_layout;           /* layout of src0 / src1: 0 = [N, C, H, W]; 1 = channel-blocked [N, C/8, H, W, 8] (C % 8
+                                   == 0): the 8 channels of a pixel are 32 contiguous bytes, so a conv's halo-patch
+                                   gather is two 16-byte loads per pixel instead of eight 4-byte ones (measured 5.4x
+                                   on the load side, tools/membench.hip).  dsg_unet_forward keeps its intermediate
+                                   activations in this layout; the public tensors stay [N, C, H, W]. */
+  int32_t dst_layout;           /* the same for dst and residual */
 } dsg_conv_args;
 
 int dsg_conv2d_fwd(const dsg_conv_args* a, void* stream);
+/* [N, C, H, W] <-> [N, C/8, H, W, 8] (to_blocked: 1 | 0); C % 8 == 0; src != dst */
+int dsg_layout_convert(const float* src, float* dst, int32_t n, int32_t c, int32_t hw, int32_t to_blocked, void* stream);
 /* Number of spatial tiles per (n, cout) this call would write into stats_out; 0 when the kernel that serves the
  * call cannot produce the statistics (then run dsg_gn_channel_stats on dst instead). Host-only. */
 int dsg_conv2d_stats_tiles(const dsg_conv_args* a, int32_t* tiles);
@@ -120,6 +128,9 @@ int dsg_conv_weight_relayout_dgrad(const float* w_oihw, float* dst, int32_t cout
  * ---------------------------------------------------------------------------------------- */
 int dsg_gn_channel_stats(const float* src0, int32_t c0, const float* src1, int32_t c1, int32_t n,
                          int32_t hw, double* chan_stats /* [N][c0+c1][2] */, void* stream);
+/* the same statistics of one channel-blocked tensor [N][C/8][hw][8] (dsg_conv_args.dst_layout == 1) */
+int dsg_gn_channel_stats_blocked(const float* src, int32_t c, int32_t n, int32_t hw, double* chan_stats /* [N][C][2] */,
+                                 void* stream);
 int dsg_gn_finalize(const double* chan_stats, const float* gamma, const float* beta, int32_t n,
                     int32_t c, int32_t groups, int32_t hw, float eps,
                     float* scale_shift /* [N][C][2] */, void* stream);
@@ -337,7 +348,10 @@ int dsg_prof_dump(const char* csv_path);
  *   6  waves per workgroup of the 16-row split conv: [4] | 8 (two per SIMD)
  *   7  3x3 weight gradient on the split path: [1] | 0 = f32 MFMA
  *   8  up-sampler convs folded into 2x2 phase convs: [1] | 0 = nearest-x2 gather
- *  10  conv_out (cout <= 4) on the VALU kernel: [1] | 0 = zero-padded matrix-core tile */
+ *  10  conv_out (cout <= 4) on the VALU kernel: [1] | 0 = zero-padded matrix-core tile
+ *  11  pointwise split convs as 8-row tiles, two workgroups per CU: [1] | 0 = the 3x3 kernel's geometry
+ *  13  dsg_unet_forward keeps its intermediate activations channel-blocked [N,C/8,H,W,8]: [1] | 0 = [N,C,H,W]
+ *      (query dsg_unet_workspace_bytes again after changing it) */
 int dsg_set_tuning(int32_t key, int32_t value);
 
 #ifdef __cplusplus

@@ -232,6 +232,103 @@ H2_CASES = [
 ]
 
 
+def test_layout_convert_round_trip_and_blocked_stats():
+    """[N,C,H,W] <-> [N,C/8,H,W,8] (dsg_layout_convert) and the GroupNorm statistics of a blocked tensor."""
+    x = _t(11, (3, 24, 5, 7), 2.0).to(DEV)
+    xb = ops.to_blocked(x)
+    want = x.view(3, 3, 8, 5, 7).permute(0, 1, 3, 4, 2).contiguous()
+    assert torch.equal(xb, want)
+    assert torch.equal(ops.from_blocked(xb), x)
+    st = ops.gn_channel_stats_blocked(xb).cpu()
+    ref = torch.stack([x.double().sum((2, 3)), (x.double() ** 2).sum((2, 3))], -1).cpu()
+    assert torch.allclose(st, ref, rtol=1e-12, atol=1e-12)
+
+
+F32_BLOCKED_CASES = [
+    # name, c0, c1, cout, h, w, k, stride, ups, gn, src_blocked, dst_blocked
+    ("conv_in_4ch_to_blocked", 4, 0, 64, 16, 32, 3, 1, False, False, False, True),
+    ("downsample_s2_blocked", 32, 0, 32, 16, 64, 3, 2, False, False, True, True),
+    ("f32_3x3_concat_gn_res_blocked", 24, 8, 40, 8, 32, 3, 1, False, True, True, True),
+    ("f32_gather_x2_blocked", 16, 0, 32, 8, 16, 3, 1, True, False, True, True),
+    ("f32_1x1_blocked_to_plain", 48, 0, 96, 8, 32, 1, 1, False, True, True, False),
+    ("conv_out_fewout_from_blocked", 64, 0, 4, 16, 32, 3, 1, False, True, True, False),
+    # the layers of the tiny (32, 64)-channel net that the split path does not take (cout % 64 != 0)
+    ("tiny_conv_in_3_to_32", 3, 0, 32, 64, 64, 3, 1, False, False, False, True),
+    ("tiny_res32_gn_temb", 32, 0, 32, 64, 64, 3, 1, False, True, True, True, True),
+    ("tiny_up_96_to_32_concat_temb", 64, 32, 32, 64, 64, 3, 1, False, True, True, True, True),
+    ("tiny_up_96_to_32_shortcut_1x1", 64, 32, 32, 64, 64, 1, 1, False, False, True, True),
+    ("tiny_conv_out_32_to_3", 32, 0, 3, 64, 64, 3, 1, False, True, True, False),
+]
+
+
+@pytest.mark.parametrize("case", F32_BLOCKED_CASES, ids=[c[0] for c in F32_BLOCKED_CASES])
+def test_conv_f32_kernels_take_blocked_layouts(case):
+    """The f32 matrix-core kernel (conv_in, stride-2 down-samplers, fallback shapes) and the conv_out kernel with
+    channel-blocked sources / results: bit-identical to their [N,C,H,W] calls."""
+    name, c0, c1, cout, h, w, k, stride, ups, gn, sb, db = case[:12]
+    temb = len(case) > 12 and case[12]
+    batch, cin = 2, c0 + c1
+    d = lambda t: None if t is None else t.to(DEV)
+    x0, x1 = d(_t(1, (batch, c0, h, w), 1.7)), (d(_t(2, (batch, c1, h, w))) if c1 else None)
+    wt = d(_t(3, (cout, cin, k, k), 1.0 / np.sqrt(cin * k * k)))
+    bias = d(_t(4, (cout,), 0.1))
+    gamma, beta = d(1 + _t(5, (cin,), 0.1)), d(_t(6, (cin,), 0.1))
+    hc, wc = (2 * h, 2 * w) if ups else (h, w)
+    ho, wo = (hc + 2 * (k // 2) - k) // stride + 1, (wc + 2 * (k // 2) - k) // stride + 1
+    res = name.startswith("f32_3x3")
+    r = d(_t(8, (batch, cout, ho, wo))) if res else None
+    wr = ops.relayout_conv_weight(wt)  # (cout is zero-padded to a multiple of 32 columns)
+    ss = ops.gn_scale_shift(x0, gamma, beta, 8, 1e-5, src1=x1) if gn else None
+    tp = d(_t(7, (batch, cout + 5), 0.5))
+    kw = dict(ksize=k, stride=stride, upsample=ups, gn_scale_shift=ss, silu=gn, cout=cout,
+              temb=tp[:, 3:] if temb else None, temb_stride=tp.stride(0))
+    want = ops.conv2d_fused(x0, wr, bias, src1=x1, residual=r, **kw)
+    b = lambda t: None if t is None else ops.to_blocked(t)
+    got = ops.conv2d_fused(b(x0) if sb else x0, wr, bias, src1=b(x1) if sb else x1, residual=b(r) if db else r,
+                           src_blocked=sb, dst_blocked=db, **kw)
+    got = ops.from_blocked(got) if db else got
+    assert torch.equal(got, want), (name, float((got - want).abs().max()))
+
+
+@pytest.mark.parametrize("case", H2_CASES, ids=[c[0] for c in H2_CASES])
+def test_conv_h2_blocked_layout_is_bit_identical(case):
+    """Channel-blocked activations (dsg_conv_args.src_layout / dst_layout = 1): the same arithmetic in the same
+    order as the [N,C,H,W] call of the split path, so the results are equal bit for bit -- every supported pair of
+    layouts (3x3: all tensors blocked; pointwise: any pair)."""
+    name, c0, c1, cout, h, w, ups, gn, temb, res = case[:10]
+    batch, cin, k = 2, c0 + c1, (case[10] if len(case) > 10 else 3)
+    fold = len(case) > 11 and case[11]
+    if (ups and not fold) or cout % 8 or c0 % 8 or c1 % 8:
+        pytest.skip("no blocked variant of this call")
+    d = lambda t: None if t is None else t.to(DEV)
+    x0, x1 = d(_t(1, (batch, c0, h, w), 1.7)), (d(_t(2, (batch, c1, h, w))) if c1 else None)
+    wt = d(_t(3, (cout, cin, k, k), 1.0 / np.sqrt(cin * k * k)))
+    bias = d(_t(4, (cout,), 0.1))
+    gamma, beta = d(1 + _t(5, (cin,), 0.1)), d(_t(6, (cin,), 0.1))
+    ho, wo = (2 * h, 2 * w) if ups else (h, w)
+    tp = d(_t(7, (batch, cout + 5), 0.5))
+    r = d(_t(8, (batch, cout, ho, wo))) if res else None
+    wr, wh = ops.relayout_conv_weight(wt), ops.relayout_conv_weight_h2(wt)
+    whf = ops.relayout_conv_weight_h2_fold(wt) if fold else None
+    ss = ops.gn_scale_shift(x0, gamma, beta, 8, 1e-5, src1=x1) if gn else None
+    kw = dict(ksize=k, upsample=ups, gn_scale_shift=ss, silu=gn, temb=tp[:, 3:] if temb else None,
+              temb_stride=tp.stride(0), cout=cout, weight_h2=wh, weight_h2_fold=whf)
+    want, wstats = ops.conv2d_fused(x0, wr, bias, src1=x1, residual=r, want_stats=True, **kw)
+    b = lambda t: None if t is None else ops.to_blocked(t)
+    pairs = [(True, True)] + ([(True, False), (False, True)] if k == 1 else [])
+    for sb, db in pairs:
+        for stats in (True, False):  # (the epilogue has a code path of its own for each)
+            got = ops.conv2d_fused(b(x0) if sb else x0, wr, bias, src1=b(x1) if sb else x1,
+                                   residual=b(r) if db else r, src_blocked=sb, dst_blocked=db, want_stats=stats, **kw)
+            got, gstats = got if stats else (got, None)
+            got = ops.from_blocked(got) if db else got
+            assert torch.equal(got, want), (name, sb, db, stats, float((got - want).abs().max()))
+            if stats:
+                assert (wstats is None) == (gstats is None)
+                if wstats is not None and gstats.shape == wstats.shape:
+                    assert torch.equal(gstats, wstats)
+
+
 @pytest.mark.parametrize("case", H2_CASES, ids=[c[0] for c in H2_CASES])
 def test_conv_h2_split_matches_fp32(case):
     """fp16x2-split matrix-core path (conv_h2.hip): same contract as the fp32 kernel, fp32-class accuracy."""

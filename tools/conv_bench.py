@@ -53,8 +53,11 @@ for name, c0, c1, cout, h, k, s, ups, gn, res in SHAPES:
     wh = None
     if os.environ.get("H2") == "1" and s == 1 and cout % 64 == 0:
         wh = ops.relayout_conv_weight_h2(torch.randn(cout, cin, k, k, device=dev) * 0.05)
+    blk = os.environ.get("BLOCKED") == "1" and not (ups and k == 3 and True) and s == 1 and cout % 8 == 0
+    if blk:  # channel-blocked tensors (same bytes, [N, C/8, H, W, 8])
+        x0, x1, r, out = ops.to_blocked(x0), (ops.to_blocked(x1) if c1 else None), (ops.to_blocked(r) if res else None), ops.to_blocked(out)
     f = lambda: ops.conv2d_fused(x0, w, bias, src1=x1, ksize=k, stride=s, upsample=ups, gn_scale_shift=ss, silu=gn,
-                                 residual=r, out=out, weight_h2=wh)
+                                 residual=r, out=out, weight_h2=wh, src_blocked=blk, dst_blocked=blk)
     for _ in range(3):
         f()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

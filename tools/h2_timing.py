@@ -6,14 +6,17 @@ import torch
 from drivescenegen_amd import ops
 for name, c, h, B in (("res512@32", 512, 32, 16), ("res256@64", 256, 64, 16), ("res128@128", 128, 128, 16),
                       ("res64@256", 64, 256, 16), ("res64@64 B=256", 64, 64, 256), ("res64@512 B=4", 64, 512, 4)):
+    blk = os.environ.get("BLOCKED") == "1"
     x = torch.randn(B, c, h, h, device="cuda")
+    if blk:
+        x = ops.to_blocked(x)
     w = torch.randn(c, c, 3, 3, device="cuda") * 0.05
     wr, wh = ops.relayout_conv_weight(w), ops.relayout_conv_weight_h2(w)
     ss = torch.randn(B, c, 2, device="cuda")
-    _, st = ops.conv2d_fused(x, wr, None, gn_scale_shift=ss, silu=True, weight_h2=wh, want_stats=True)
+    _, st = ops.conv2d_fused(x, wr, None, gn_scale_shift=ss, silu=True, weight_h2=wh, want_stats=True, src_blocked=blk, dst_blocked=blk)
     torch.cuda.synchronize()
     st.zero_()
-    ops.conv2d_fused(x, wr, None, gn_scale_shift=ss, silu=True, weight_h2=wh, want_stats=True, stats_buf=st)
+    ops.conv2d_fused(x, wr, None, gn_scale_shift=ss, silu=True, weight_h2=wh, want_stats=True, stats_buf=st, src_blocked=blk, dst_blocked=blk)
     torch.cuda.synchronize()
     tot, vm, bar, nw = st.flatten()[:4].tolist()
     print(f"{name}: waves {nw:.0f}  cycles/wave {tot / nw:.0f}  wait-vmcnt {100 * vm / tot:.1f}%  barrier {100 * bar / tot:.1f}%  "
@@ -36,3 +39,7 @@ for name, c, h, B in (("res512@32", 512, 32, 16), ("res256@64", 256, 64, 16), ("
     print("   prologue us: entry->p0 %.2f  issue loads %.2f  ss+sync (first wait) %.2f  commit %.2f  final wait+barrier %.2f" % (
         (pr[:, 0] - e).mean() / 100, (pr[:, 1] - pr[:, 0]).mean() / 100, (pr[:, 2] - pr[:, 1]).mean() / 100,
         (pr[:, 3] - pr[:, 2]).mean() / 100, (rec[:, 1] - pr[:, 3]).mean() / 100))
+    er = st.flatten()[8 + 9 * nb + 16:8 + 9 * nb + 16 + 6 * nb].reshape(nb, 6).cpu().numpy()
+    d = lambda a, b: (er[:, b] - er[:, a]).mean() / 100
+    print("   epilogue us: slab0 loads land %.2f  slab0 math+stores %.2f  slab1 loads land %.2f  slab1 math+stores %.2f  stats tail %.2f" % (
+        d(0, 1), d(1, 2), d(2, 3), d(3, 4), d(4, 5)))
