@@ -92,7 +92,7 @@ SIGNATURES = {
     "dsg_conv_weight_relayout_h2": [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp],
     "dsg_conv_weight_relayout_h2_dgrad": [_vp, _vp, _i32, _i32, _i32, _vp],
     "dsg_gn_channel_stats": [_vp, _i32, _vp, _i32, _i32, _i32, _vp, _vp],
-    "dsg_gn_channel_stats_blocked": [_vp, _i32, _i32, _i32, _vp, _vp],
+    "dsg_gn_channel_stats_blocked": [_vp, _i32, _i32, _i32, _i32, _vp, _vp],
     "dsg_gn_finalize": [_vp, _vp, _vp, _i32, _i32, _i32, _i32, _f32, _vp, _vp],
     "dsg_gn_apply": [_vp, _vp, _i32, _vp, _i32, _i32, _i32, _vp],
     "dsg_attention_fwd": [_vp, _vp, _i32, _i32, _i32, _i32, _vp],

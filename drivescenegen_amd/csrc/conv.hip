@@ -287,6 +287,35 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(ConvP p) {
           rv[mt][r][nt] = has_r ? p.res[oidx(co, y, min(x, p.wout - 1))] : 0.f;
         }
       }
+    if (p.dblk) {
+      // channel-blocked dst: a register group (r >> 2) is four consecutive channels of one pixel = one 16-byte store
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int rg = 0; rg < 4; ++rg) {
+          const int co0 = m0 + mt * 32 + 8 * rg + 4 * half;
+          if (co0 < p.cout && x < p.wout) {  // (cout % 8 == 0: the group is valid as a whole)
+            float add[4], tv[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+              add[j] = p.bias ? p.bias[co0 + j] : 0.f;
+              tv[j] = has_t ? p.temb[(size_t)n * p.temb_stride + co0 + j] : 0.f;
+            }
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt) {
+              const int y = oy0 + wave * 2 + nt;
+              float v[4];
+#pragma unroll
+              for (int j = 0; j < 4; ++j) {  // (the same order of additions as the [N,C,H,W] branch)
+                v[j] = acc[mt][nt][4 * rg + j] + add[j];
+                if (has_t) v[j] = v[j] + tv[j];
+                if (has_r) v[j] = v[j] + rv[mt][4 * rg + j][nt];
+              }
+              *reinterpret_cast<float4*>(p.dst + oidx(co0, y, x)) = make_float4(v[0], v[1], v[2], v[3]);
+            }
+          }
+        }
+    } else {
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
 #pragma unroll
@@ -306,6 +335,7 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(ConvP p) {
           }
         }
       }
+    }
     }
   } else {
     // 2x2 sum-pool: the wave's two rows are one pooled row; column pairs are adjacent lanes
@@ -493,12 +523,24 @@ __global__ __launch_bounds__(256, 2) void conv_fewout_kernel(ConvP p) {
   auto fetch = [&](int c0) {
     const float* spb = (c0 < p.c0) ? p.src0 + ((size_t)n * p.c0 + c0) * plane
                                    : p.src1 + ((size_t)n * p.c1 + (c0 - p.c0)) * plane;  // (uniform: c0 % 16 == 0)
-    // (blocked sources: the 16-channel chunk starts at the same address; channel c is element c % 8 of block c / 8)
+    if (p.sblk) {
+      // blocked sources: the 16-channel chunk starts at the same address and is two channel blocks; a position's 8
+      // channels are two 16-byte loads
 #pragma unroll
-    for (int c = 0; c < FO_KC; ++c)
+      for (int b = 0; b < 2; ++b)
 #pragma unroll
-      for (int k = 0; k < 3; ++k)
-        xr[c][k] = spb[(p.sblk ? (size_t)(c >> 3) * 8 * plane + (c & 7) : (size_t)c * plane) + goff[k]];
+        for (int k = 0; k < 3; ++k) {
+          const float4* q = reinterpret_cast<const float4*>(spb + (size_t)b * 8 * plane + goff[k]);
+          const float4 lo = q[0], hi = q[1];
+          xr[8 * b + 0][k] = lo.x; xr[8 * b + 1][k] = lo.y; xr[8 * b + 2][k] = lo.z; xr[8 * b + 3][k] = lo.w;
+          xr[8 * b + 4][k] = hi.x; xr[8 * b + 5][k] = hi.y; xr[8 * b + 6][k] = hi.z; xr[8 * b + 7][k] = hi.w;
+        }
+    } else {
+#pragma unroll
+      for (int c = 0; c < FO_KC; ++c)
+#pragma unroll
+        for (int k = 0; k < 3; ++k) xr[c][k] = spb[(size_t)c * plane + goff[k]];
+    }
   };
   fetch(0);
   for (int c0 = 0; c0 < p.cin; c0 += FO_KC) {

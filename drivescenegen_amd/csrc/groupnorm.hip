@@ -58,12 +58,13 @@ __global__ __launch_bounds__(256) void gn_channel_stats_kernel(const float* __re
   }
 }
 
-// The same statistics of a channel-blocked tensor [N][C/8][hw][8]: grid = (C/8, n); a thread walks pixels and keeps
-// the 8 channels of its block.
-__global__ __launch_bounds__(256) void gn_channel_stats_blk_kernel(const float* __restrict__ src, int c, int hw,
+// The same statistics of a channel-blocked tensor [N][C/8][hw][8]: grid = (C/8, n, splits); a thread walks the
+// pixels of its split and keeps the 8 channels of its block; one partial per split, [N][C][splits][2].
+__global__ __launch_bounds__(256) void gn_channel_stats_blk_kernel(const float* __restrict__ src, int c, int hw_total,
                                                                    double* __restrict__ stats) {
-  const int cb = blockIdx.x, n = blockIdx.y;
-  const float4* sp = reinterpret_cast<const float4*>(src + ((size_t)n * c + cb * 8) * hw);
+  const int cb = blockIdx.x, n = blockIdx.y, sp_i = blockIdx.z, splits = gridDim.z;
+  const int hw = hw_total / splits;
+  const float4* sp = reinterpret_cast<const float4*>(src + (((size_t)n * c + cb * 8) * hw_total + (size_t)sp_i * hw * 8));
   double s[8], ss[8];
 #pragma unroll
   for (int j = 0; j < 8; ++j) s[j] = ss[j] = 0.0;
@@ -89,7 +90,7 @@ __global__ __launch_bounds__(256) void gn_channel_stats_blk_kernel(const float* 
   __syncthreads();
   if (threadIdx.x < 16) {
     const int j = threadIdx.x >> 1, which = threadIdx.x & 1;
-    stats[((size_t)n * c + cb * 8 + j) * 2 + which] =
+    stats[(((size_t)n * c + cb * 8 + j) * splits + sp_i) * 2 + which] =
         red[threadIdx.x][0] + red[threadIdx.x][1] + red[threadIdx.x][2] + red[threadIdx.x][3];
   }
 }
@@ -205,13 +206,15 @@ DSG_API int dsg_gn_channel_stats(const float* src0, int32_t c0, const float* src
   return DSG_OK;
 }
 
-DSG_API int dsg_gn_channel_stats_blocked(const float* src, int32_t c, int32_t n, int32_t hw, double* chan_stats,
-                                         void* stream) {
+DSG_API int dsg_gn_channel_stats_blocked(const float* src, int32_t c, int32_t n, int32_t hw, int32_t splits,
+                                         double* chan_stats, void* stream) {
   DSG_CHECK_ARG(src && chan_stats, "dsg_gn_channel_stats_blocked: NULL pointer");
   DSG_CHECK_ARG(c > 0 && c % 8 == 0 && n > 0 && hw > 0, "dsg_gn_channel_stats_blocked: bad dims (C %% 8 != 0?)");
+  DSG_CHECK_ARG(splits >= 1 && splits <= 65535 && hw % splits == 0,
+                "dsg_gn_channel_stats_blocked: splits must divide hw (%d, %d)", splits, hw);
   DSG_CHECK_ARG(n <= 65535, "dsg_gn_channel_stats_blocked: batch too large for one launch");
-  hipLaunchKernelGGL(dsg::gn_channel_stats_blk_kernel, dim3(c / 8, n), dim3(256), 0, static_cast<hipStream_t>(stream),
-                     src, c, hw, chan_stats);
+  hipLaunchKernelGGL(dsg::gn_channel_stats_blk_kernel, dim3(c / 8, n, splits), dim3(256), 0,
+                     static_cast<hipStream_t>(stream), src, c, hw, chan_stats);
   DSG_LAUNCH_CHECK();
   return DSG_OK;
 }

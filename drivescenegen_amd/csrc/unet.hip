@@ -238,11 +238,15 @@ struct Runner {
         tl[i] = src[i]->stiles;
         continue;
       }
-      tmp[i] = alloc(0, 0, 0, (size_t)B * src[i]->c * 2, sizeof(double));
+      // (blocked tensors have only C/8 * N channel blocks to spread over the chip: split the pixels as well)
+      int splits = 1;
+      if (src[i]->blk)
+        while (splits < 16 && (x.h * x.w) % (2 * splits) == 0 && (x.h * x.w) / (2 * splits) >= 2048) splits *= 2;
+      tmp[i] = alloc(0, 0, 0, (size_t)B * src[i]->c * splits * 2, sizeof(double));
       sp[i] = reinterpret_cast<double*>(tmp[i].p);
-      tl[i] = 1;
+      tl[i] = splits;
       if (!dry && ok())
-        rc = src[i]->blk ? dsg_gn_channel_stats_blocked(src[i]->p, src[i]->c, B, x.h * x.w,
+        rc = src[i]->blk ? dsg_gn_channel_stats_blocked(src[i]->p, src[i]->c, B, x.h * x.w, splits,
                                                         reinterpret_cast<double*>(tmp[i].p), st)
                          : dsg_gn_channel_stats(src[i]->p, src[i]->c, nullptr, 0, B, x.h * x.w,
                                                 reinterpret_cast<double*>(tmp[i].p), st);

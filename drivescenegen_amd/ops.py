@@ -166,12 +166,13 @@ def from_blocked(x):
     return out
 
 
-def gn_channel_stats_blocked(x):
-    """dsg_gn_channel_stats_blocked: per-(n, c) (sum, sum of squares) of a channel-blocked tensor, fp64 [N][C][2]."""
+def gn_channel_stats_blocked(x, splits=1):
+    """dsg_gn_channel_stats_blocked: per-(n, c) (sum, sum of squares) of a channel-blocked tensor as `splits` partial
+    sums over equal runs of pixels, fp64 [N][C][splits][2]."""
     n, cb, h, w, _ = x.shape
-    st = torch.empty((n, cb * 8, 2), dtype=torch.float64, device=x.device)
+    st = torch.empty((n, cb * 8, splits, 2), dtype=torch.float64, device=x.device)
     with torch.cuda.device(x.device):
-        _lib.check(_lib.load().dsg_gn_channel_stats_blocked(_lib.ptr(x), cb * 8, n, h * w, _lib.ptr(st), _st(x)))
+        _lib.check(_lib.load().dsg_gn_channel_stats_blocked(_lib.ptr(x), cb * 8, n, h * w, splits, _lib.ptr(st), _st(x)))
     return st
 
 

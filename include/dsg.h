@@ -128,9 +128,10 @@ int dsg_conv_weight_relayout_dgrad(const float* w_oihw, float* dst, int32_t cout
  * ---------------------------------------------------------------------------------------- */
 int dsg_gn_channel_stats(const float* src0, int32_t c0, const float* src1, int32_t c1, int32_t n,
                          int32_t hw, double* chan_stats /* [N][c0+c1][2] */, void* stream);
-/* the same statistics of one channel-blocked tensor [N][C/8][hw][8] (dsg_conv_args.dst_layout == 1) */
-int dsg_gn_channel_stats_blocked(const float* src, int32_t c, int32_t n, int32_t hw, double* chan_stats /* [N][C][2] */,
-                                 void* stream);
+/* the same statistics of one channel-blocked tensor [N][C/8][hw][8] (dsg_conv_args.dst_layout == 1), as `splits`
+ * partial sums over equal runs of pixels (splits divides hw): feed dsg_gn_finalize_parts with tiles = splits */
+int dsg_gn_channel_stats_blocked(const float* src, int32_t c, int32_t n, int32_t hw, int32_t splits,
+                                 double* chan_stats /* [N][C][splits][2] */, void* stream);
 int dsg_gn_finalize(const double* chan_stats, const float* gamma, const float* beta, int32_t n,
                     int32_t c, int32_t groups, int32_t hw, float eps,
                     float* scale_shift /* [N][C][2] */, void* stream);

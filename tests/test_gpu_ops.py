@@ -239,9 +239,13 @@ def test_layout_convert_round_trip_and_blocked_stats():
     want = x.view(3, 3, 8, 5, 7).permute(0, 1, 3, 4, 2).contiguous()
     assert torch.equal(xb, want)
     assert torch.equal(ops.from_blocked(xb), x)
-    st = ops.gn_channel_stats_blocked(xb).cpu()
     ref = torch.stack([x.double().sum((2, 3)), (x.double() ** 2).sum((2, 3))], -1).cpu()
-    assert torch.allclose(st, ref, rtol=1e-12, atol=1e-12)
+    for splits in (1, 5, 7):
+        st = ops.gn_channel_stats_blocked(xb, splits).cpu()
+        assert st.shape == (3, 24, splits, 2)
+        assert torch.allclose(st.sum(2), ref, rtol=1e-12, atol=1e-12)
+    part = x.double()[:, :, :1, :5].reshape(3, 24, -1)  # the first of 7 splits = the first 5 pixels
+    assert torch.allclose(ops.gn_channel_stats_blocked(xb, 7)[:, :, 0, 0].cpu(), part.sum(-1).cpu(), rtol=1e-12, atol=1e-12)
 
 
 F32_BLOCKED_CASES = [
