@@ -232,7 +232,7 @@ __global__ __launch_bounds__(64 * NW, OCC * NW / 4) void conv_h2_kernel(ConvH2P 
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
       float v = src[i][j];
-      if (has_ss) v = (j & 1) ? v * sr[j / 2].z + sr[j / 2].w : v * sr[j / 2].x + sr[j / 2].y;
+      if (has_ss) v = (j & 1) ? v * sr[j / 2].y + sr[j / 2].w : v * sr[j / 2].x + sr[j / 2].z;
       const float sv = silu_fast_h(v);
       v = do_silu ? sv : v;
       const _Float16 a = (_Float16)v;
@@ -251,13 +251,13 @@ __global__ __launch_bounds__(64 * NW, OCC * NW / 4) void conv_h2_kernel(ConvH2P 
   auto stage_step = [&](int P, int qs, unsigned char* buf, bool stage, bool load, const float* spn) {
     const int i = P / 4, jp = P % 4;
     if (stage) {
-      float4 s4 = make_float4(1.f, 0.f, 1.f, 0.f);
+      float4 s4 = make_float4(1.f, 1.f, 0.f, 0.f);
       if (has_ss) s4 = *reinterpret_cast<const float4*>(ssl + 2 * (qs * H2_KC + unit_g(i) * 8 + 2 * jp));
 #pragma unroll
       for (int e = 0; e < 2; ++e) {
         const int j = 2 * jp + e;
         float v = xr[i][j];
-        if (has_ss) v = e ? v * s4.z + s4.w : v * s4.x + s4.y;
+        if (has_ss) v = e ? v * s4.y + s4.w : v * s4.x + s4.z;
         const float sv = silu_fast_h(v);
         v = do_silu ? sv : v;
         const _Float16 a = (_Float16)v;
@@ -290,10 +290,20 @@ __global__ __launch_bounds__(64 * NW, OCC * NW / 4) void conv_h2_kernel(ConvH2P 
   auto commit_unit = [&](int i, int q, unsigned char* buf) { commit_unit_from(xr, i, q, buf); };
   // weight slab of chunk q: 36 segments (piece, tap, g) of 64 couts x 16 B, moved global -> LDS by DMA;
   // wave w moves segments w, w+4, ...
-  auto dma_weights = [&](int k, int q, unsigned char* buf) {
+  // Addressing is split so that a DMA costs one 64-bit scalar add: the tile's weight base and the byte offset of each
+  // of this wave's segments are loop-invariant scalars, the chunk offset is added once per chunk by the caller, and
+  // the only vector operand is the constant lane * 16.
+  const unsigned segb = (unsigned)p.wh_stride * 16u;  // bytes of one (piece, tap, g) segment row in global memory
+  const unsigned chunkb = G::NSEG * segb;             // bytes of one K-chunk's weights
+  const char* wtile = reinterpret_cast<const char*>(p.wh + ((size_t)phase * nq * G::NSEG * p.wh_stride + m0) * 8);
+  int segoff[G::NDMA];
+#pragma unroll
+  for (int k = 0; k < G::NDMA; ++k)
+    segoff[k] = __builtin_amdgcn_readfirstlane(min(wave + NW * k, G::NSEG - 1) * (int)segb);
+  const int lane16 = lane * 16;
+  auto dma_weights = [&](int k, const char* wq, unsigned char* buf) {  // wq: wtile + chunk * chunkb (uniform)
     // (uniform; a wave whose last share falls past the end repeats the final segment: same bytes, no branch)
     const int seg = min(wave + NW * k, G::NSEG - 1);
-    const _Float16* gp = p.wh + ((((size_t)phase * nq + q) * G::NSEG + seg) * p.wh_stride + m0) * 8 + lane * 8;  // uniform + lane
     // Issued as inline asm on purpose: hipcc's wait-count pass cannot tell the DMA's LDS destination (the other
     // buffer) from the fragment reads of this one, and with a DMA it knows of in flight it puts vmcnt(0) -- a wait
     // for every outstanding patch load as well -- in front of each following ds_read.  Untracked VMEM operations
@@ -301,7 +311,9 @@ __global__ __launch_bounds__(64 * NW, OCC * NW / 4) void conv_h2_kernel(ConvH2P 
     // completion is waited for explicitly before the chunk's closing barrier.
     const unsigned lds_addr =
         (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)(buf + seg * 1024);
-    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off\n" ::"v"(gp), "s"(lds_addr) : "memory");
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1\n" ::"v"(lane16), "s"(wq + segoff[k]),
+                 "s"(lds_addr)
+                 : "memory");
   };
 
   f32x16 acc_hi[2][NT], acc_lo[2][NT];
@@ -354,7 +366,7 @@ __global__ __launch_bounds__(64 * NW, OCC * NW / 4) void conv_h2_kernel(ConvH2P 
       for (int k = 0; k < 2048 / NTH; ++k) ssv[k] = ssg[min(tid + NTH * k, 2 * p.cin - 1)];
     }
 #pragma unroll
-    for (int k = 0; k < G::NDMA; ++k) dma_weights(k, 0, buf0);
+    for (int k = 0; k < G::NDMA; ++k) dma_weights(k, wtile, buf0);
     const float* sp = src_of(0);
 #pragma unroll
     for (int i = 0; i < H2_NU; ++i) load_unit_to(xr0, i, sp);
@@ -367,7 +379,12 @@ __global__ __launch_bounds__(64 * NW, OCC * NW / 4) void conv_h2_kernel(ConvH2P 
     if (has_ss) {
 #pragma unroll
       for (int k = 0; k < 2048 / NTH; ++k)
-        if (tid + NTH * k < 2 * p.cin) ssl[tid + NTH * k] = ssv[k];
+        if (tid + NTH * k < 2 * p.cin) {
+          // global [c][scale | shift] -> LDS per channel PAIR (sc0, sc1, sh0, sh1): a staging step's two channels
+          // then take their scales and shifts as register pairs (one packed FMA, no shuffling moves)
+          const int idx = tid + NTH * k, c = idx >> 1, which = idx & 1;
+          ssl[4 * (c >> 1) + 2 * which + (c & 1)] = ssv[k];
+        }
       __syncthreads();  // the scale/shift table is in LDS
     }
     DSG_PT(2);
@@ -393,6 +410,7 @@ __global__ __launch_bounds__(64 * NW, OCC * NW / 4) void conv_h2_kernel(ConvH2P 
     unsigned char* cur = (q & 1) ? buf1 : buf0;
     unsigned char* nxt = (q & 1) ? buf0 : buf1;
     const float* spn = LOAD ? src_of(q + 2) : nullptr;
+    const char* wqn = wtile + (size_t)(q + 1) * chunkb;  // the staged chunk's weights
     const _Float16* wl = reinterpret_cast<const _Float16*>(cur);
     const _Float16* xl = wl + H2_WHALFS;
     // Operand fragments are fetched one tap ahead into the other half of fa/fb: the reads of tap t+1 are issued
@@ -430,7 +448,7 @@ __global__ __launch_bounds__(64 * NW, OCC * NW / 4) void conv_h2_kernel(ConvH2P 
           if (STAGE) commit_unit(u, q + 1, nxt);
           if (LOAD) load_unit(u, q + 2, spn);
         }
-        if (STAGE) dma_weights(0, q + 1, nxt);  // (KS = 1: NSEG = 4 <= NW)
+        if (STAGE) dma_weights(0, wqn, nxt);  // (KS = 1: NSEG = 4 <= NW)
       }
       // KS = 3: the chunk's staging steps and weight DMAs are dealt out evenly over taps 0..TAPS-2 (the last tap
       // stays clear so that the newest loads have a tap's worth of MFMAs to land before the closing vmcnt(0))
@@ -440,7 +458,7 @@ __global__ __launch_bounds__(64 * NW, OCC * NW / 4) void conv_h2_kernel(ConvH2P 
         for (int P = tap * NSTEP / ST; P < (tap + 1) * NSTEP / ST; ++P) stage_step(P, q + 1, nxt, STAGE, LOAD, spn);
         if (STAGE) {
 #pragma unroll
-          for (int k = tap * G::NDMA / ST; k < (tap + 1) * G::NDMA / ST; ++k) dma_weights(k, q + 1, nxt);
+          for (int k = tap * G::NDMA / ST; k < (tap + 1) * G::NDMA / ST; ++k) dma_weights(k, wqn, nxt);
         }
       }
       const int par = tap & 1;
@@ -507,7 +525,11 @@ __global__ __launch_bounds__(64 * NW, OCC * NW / 4) void conv_h2_kernel(ConvH2P 
   const bool has_r = p.res != nullptr;
   const int oscale = GM == 2 ? 2 : 1;  // folded mode: the output map is twice the tiled (low-resolution) grid
   const int oplane = p.hout * p.wout * oscale * oscale;
+#ifdef DSG_H2_TIMING_NOSTATS
+  const bool want_stats = false;  // (timing experiment: the record buffer is p.stats, the statistics path stays off)
+#else
   const bool want_stats = p.stats != nullptr;
+#endif
   float* red = reinterpret_cast<float*>(smem_raw);  // [wave][sum | sumsq][cout 64] (the K loop is done with LDS)
   constexpr int RED_FLOATS = NW * (NT / 2) * 2 * H2_BM;
   float* red_lane = (l31 == 16) ? red + 4 * half : red + RED_FLOATS + 64 + lane;  // (+ crel etc. per value)
@@ -606,8 +628,12 @@ __global__ __launch_bounds__(64 * NW, OCC * NW / 4) void conv_h2_kernel(ConvH2P 
             // the 16-byte store as free of the "VALU overwrites store data" hazard and re-uses the data registers
             // two or three instructions later; on gfx950 that corrupted the second dword of lanes 12..15 of every
             // row (found by the bit-exact layout tests).  Without an soffset register it inserts the wait states.
+#ifndef DSG_H2_TIMING_NOSTORE
             __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o), dst_rs,
                                                    voff[nt] + (mt * 4 + rg) * 8 * oplane4, 0, 0);
+#else
+            if (o.x == 1234.5f) red[lane] = o.y + o.z + o.w;  // (timing experiment: keep the math, drop the stores)
+#endif
           }
         } else {
 #pragma unroll

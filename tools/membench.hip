@@ -7,7 +7,11 @@
 #include <cstdlib>
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); exit(1); } } while (0)
 
-constexpr int H = 256, W = 256, C = 64, NB = 16, TH = 16, TW = 32, PH = 18, PW = 34;
+#ifndef MB_H
+#define MB_H 256
+#define MB_C 64
+#endif
+constexpr int H = MB_H, W = MB_H, C = MB_C, NB = 16, TH = 16, TW = 32, PH = 18, PW = 34;  // (-DMB_H=32 -DMB_C=512: the deep layers)
 
 // MODE 0: dword loads over the 612 halo positions (tid + 256 k), dword stores, lanes along x
 // MODE 1: 16-byte loads of the interior (8 per row) + dword halo columns, 16-byte stores
@@ -18,16 +22,18 @@ __global__ __launch_bounds__(256, 1) void tile_walk(const float* __restrict__ sr
   const int tid = threadIdx.x;
   for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
     // same XCD-banded order as the conv
-    const int nsp = ntiles;
-    int bid = (tile & 7) * (nsp >> 3) + (tile >> 3);
+    constexpr int NCT = C / 64;
+    const int nsp = ntiles / NCT;
+    const int grp = tile >> 3, ct = grp % NCT;
+    int bid = (tile & 7) * (nsp >> 3) + grp / NCT;
     const int tx = bid % (W / TW); bid /= (W / TW);
     const int ty = bid % (H / TH);
     const int n = bid / (H / TH);
     const float* s = src + (size_t)n * C * H * W;
-    float* d = dst + (size_t)n * C * H * W;
+    float* d = dst + ((size_t)n * C + ct * 64) * H * W;
     float acc = 0.f;
     if (LOADS) {
-      for (int q = 0; q < C / 16; ++q) {
+      for (int q = 0; q < 4; ++q) {  // (four K-chunks per tile whatever C is: the load side is sized for C = 64)
         if (MODE == 0) {
           float v[3][16];
 #pragma unroll
@@ -153,7 +159,7 @@ int main() {
   float *src, *dst;
   CK(hipMalloc(&src, n * 4)); CK(hipMalloc(&dst, n * 4));
   CK(hipMemset(src, 0, n * 4));
-  const int ntiles = NB * (H / TH) * (W / TW);
+  const int ntiles = NB * (H / TH) * (W / TW) * (C / 64);
   const double b = n * 4.0;
   for (int grid : {ntiles, 256}) {
     run<0, true, true>("dword loads + dword stores", src, dst, grid, ntiles, 2 * b);
