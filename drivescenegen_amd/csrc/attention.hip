@@ -126,10 +126,169 @@ __global__ __launch_bounds__(256) void attention_kernel(const float* __restrict_
   }
 }
 
+
+// ---------------------------------------------------------------------------------------------------
+// head_dim 8 on the matrix cores (the mid-block / Attn*Block2D case of the reference nets: 64 heads x 8).
+// K = d = 8 is exactly one v_mfma_f32_32x32x8_f16 step, and the C/D layout of the 32x32 tile (lane = column,
+// register r = row (r & 3) + 8 (r >> 2) + 4 (lane >> 5)) is, for r = 4b .. 4b + 3, exactly the B-operand layout of
+// the next 8-deep step.  So with S^T = K^T Q (rows = keys, columns = queries):
+//   * a lane owns ONE query and 16 of the tile's 32 keys: the softmax is per lane, one exchange with lane ^ 32;
+//   * P^T stays in registers and feeds O = V P as B operands (two 16-deep steps, V read in the matching key order)
+//     -- no shuffles, no LDS round trip;
+//   * V is the A operand with rows = the 8 head dims, a row of ONES (row 8 of the tile) accumulates the softmax
+//     denominator of exactly the P that was multiplied, the other rows are padding.
+// fp32-class accuracy as in conv_h2.hip: q, k, v and p are split x = hi + lo * 2^-11 (two fp16 parts), three MFMAs
+// per product, the 2^11-scaled cross terms in a second accumulator.
+// Workgroup = 8 waves x 32 queries of one (image, head); its K and V (fp16 pairs) sit in LDS, KT keys at a time.
+// ---------------------------------------------------------------------------------------------------
+typedef _Float16 att_half4 __attribute__((ext_vector_type(4)));
+typedef _Float16 att_half8 __attribute__((ext_vector_type(8)));
+constexpr int ATM_KT = 512;                  // keys per LDS tile (35 KB of LDS: four workgroups per CU)
+constexpr int ATM_VSTR = ATM_KT + 4;         // V row stride in halfs (+8 bytes: rows fall into different banks)
+
+constexpr int ATM_NW = 8;                    // waves per workgroup: 256 queries share one conversion of K and V
+__global__ __launch_bounds__(64 * ATM_NW, 4) void attention_mfma8_kernel(const float* __restrict__ qkv, float* __restrict__ out,
+                                                                 float* __restrict__ lse, int c, int heads, int l,
+                                                                 float qscale) {
+  __shared__ __attribute__((aligned(16))) _Float16 Kh[ATM_KT * 8], Kl[ATM_KT * 8];          // [key][d]
+  __shared__ __attribute__((aligned(16))) _Float16 Vh[9 * ATM_VSTR], Vl[9 * ATM_VSTR];      // [d | ones][key]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, l31 = lane & 31;
+  const int h = blockIdx.y, n = blockIdx.z;
+  const float* qp = qkv + ((size_t)n * 3 * c + h * 8) * l;
+  const float* kp = qp + (size_t)c * l;
+  const float* vp = kp + (size_t)c * l;
+  const int q0 = (blockIdx.x * ATM_NW + wave) * 32;  // this wave's 32 queries (l % 32 == 0; a wave past the end idles)
+  const bool active = q0 < l;
+  const int qi = min(q0 + l31, l - 1);
+
+  // B operand of S^T = K^T Q: lane (query l31, half) holds d = 4 half .. 4 half + 3, pre-scaled into the log2 domain
+  att_half4 qh, ql;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const float v = qp[(size_t)(4 * half + i) * l + qi] * qscale;
+    const _Float16 a = (_Float16)v;
+    qh[i] = a;
+    ql[i] = (_Float16)((v - (float)a) * 2048.0f);
+  }
+  f32x16 o_hi, o_lo;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) o_hi[r] = o_lo[r] = 0.f;
+  float m = -1e30f;
+  const int vrow = min(l31, 8);  // A operand of O = V P: row = head dim (8 = the ones row, beyond: its copy, ignored)
+
+  for (int j0 = 0; j0 < l; j0 += ATM_KT) {
+    const int kt = min(ATM_KT, l - j0);
+    __syncthreads();
+    for (int e = tid; e < 8 * ATM_KT; e += 64 * ATM_NW) {
+      const int i = e / ATM_KT, j = e - i * ATM_KT;  // coalesced along the keys
+      float kv = 0.f, vv = 0.f;
+      if (j < kt) {
+        kv = kp[(size_t)i * l + j0 + j];
+        vv = vp[(size_t)i * l + j0 + j];
+      }
+      const _Float16 ka = (_Float16)kv, va = (_Float16)vv;
+      Kh[j * 8 + i] = ka;
+      Kl[j * 8 + i] = (_Float16)((kv - (float)ka) * 2048.0f);
+      Vh[i * ATM_VSTR + j] = va;
+      Vl[i * ATM_VSTR + j] = (_Float16)((vv - (float)va) * 2048.0f);
+    }
+    for (int j = tid; j < ATM_KT; j += 64 * ATM_NW) {
+      Vh[8 * ATM_VSTR + j] = (_Float16)(j < kt ? 1.0f : 0.0f);
+      Vl[8 * ATM_VSTR + j] = (_Float16)0.0f;
+    }
+    __syncthreads();
+    if (!active) continue;
+    // S^T tile = 32 keys x 32 queries; the NEXT tile's three MFMAs are issued before this tile's softmax arithmetic
+    // so that the matrix pipe works under it
+    auto s_tile = [&](int t, f32x16& s_hi, f32x16& s_lo) {
+      const att_half4 kh = *reinterpret_cast<const att_half4*>(&Kh[(t + l31) * 8 + 4 * half]);
+      const att_half4 kl = *reinterpret_cast<const att_half4*>(&Kl[(t + l31) * 8 + 4 * half]);
+      const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+      s_hi = __builtin_amdgcn_mfma_f32_32x32x8f16(kh, qh, zero, 0, 0, 0);  // (C = the inline constant 0)
+      s_lo = __builtin_amdgcn_mfma_f32_32x32x8f16(kh, ql, zero, 0, 0, 0);
+      s_lo = __builtin_amdgcn_mfma_f32_32x32x8f16(kl, qh, s_lo, 0, 0, 0);
+    };
+    // one tile's softmax and O += V P from the scores in (s_hi, s_lo)
+    auto pv_tile = [&](int t, const f32x16& s_hi, const f32x16& s_lo) {
+      float sv[16];
+      float mx = -1e30f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        sv[r] = s_hi[r] + s_lo[r] * (1.0f / 2048.0f);
+        mx = fmaxf(mx, sv[r]);
+      }
+      mx = fmaxf(mx, __shfl_xor(mx, 32, 64));  // the query's other 16 keys live in lane ^ 32
+      const float mn = fmaxf(m, mx);
+      const float sc = __builtin_amdgcn_exp2f(m - mn);  // (bare v_exp_f32: arguments <= 0, a flushed denormal is 0)
+      m = mn;
+#pragma unroll
+      for (int r = 0; r < 5; ++r) {  // rows 0..3 (+4 half) = the head dims, row 8 (r = 4, half 0) = the denominator
+        o_hi[r] *= sc;
+        o_lo[r] *= sc;
+      }
+#pragma unroll
+      for (int b = 0; b < 2; ++b) {
+        // Registers 8 b .. 8 b + 7 are keys {0..3, 8..11} + 4 half of the tile's b-th 16 keys: as the B operand of a
+        // 16-deep MFMA step they only need V (the A operand) read in the same key order.
+        att_half8 ph, pl;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          const float pv = __builtin_amdgcn_exp2f(sv[8 * b + i] - mn);
+          const _Float16 a = (_Float16)pv;
+          ph[i] = a;
+          pl[i] = (_Float16)((pv - (float)a) * 2048.0f);
+        }
+        const _Float16* vhp = &Vh[vrow * ATM_VSTR + t + 16 * b + 4 * half];
+        const _Float16* vlp = &Vl[vrow * ATM_VSTR + t + 16 * b + 4 * half];
+        const att_half4 vh0 = *reinterpret_cast<const att_half4*>(vhp), vh1 = *reinterpret_cast<const att_half4*>(vhp + 8);
+        const att_half4 vl0 = *reinterpret_cast<const att_half4*>(vlp), vl1 = *reinterpret_cast<const att_half4*>(vlp + 8);
+        const att_half8 vh = {vh0[0], vh0[1], vh0[2], vh0[3], vh1[0], vh1[1], vh1[2], vh1[3]};
+        const att_half8 vl = {vl0[0], vl0[1], vl0[2], vl0[3], vl1[0], vl1[1], vl1[2], vl1[3]};
+        o_hi = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh, ph, o_hi, 0, 0, 0);
+        o_lo = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh, pl, o_lo, 0, 0, 0);
+        o_lo = __builtin_amdgcn_mfma_f32_32x32x16_f16(vl, ph, o_lo, 0, 0, 0);
+      }
+    };
+    // two score sets alternate (no register copies): while one tile's arithmetic runs, the other's MFMAs are in flight
+    f32x16 a_hi, a_lo, b_hi, b_lo;
+    s_tile(0, a_hi, a_lo);
+    int t = 0;
+    for (; t + 64 <= kt; t += 64) {  // (kt % 32 == 0)
+      s_tile(t + 32, b_hi, b_lo);
+      pv_tile(t, a_hi, a_lo);
+      s_tile(min(t + 64, kt - 32), a_hi, a_lo);  // (past the end: a tile that is not used)
+      pv_tile(t + 32, b_hi, b_lo);
+    }
+    if (t < kt) pv_tile(t, a_hi, a_lo);  // odd tile count
+  }
+  if (!active) return;
+  // row 8 of the tile (register 4 of the lower half-wave) is the denominator; the upper half-wave fetches it
+  const float den_lo = o_hi[4] + o_lo[4] * (1.0f / 2048.0f);  // (meaningful in the lower half-wave only)
+  const float den_x = __shfl_xor(den_lo, 32, 64);
+  const float den = half ? den_x : den_lo;
+  const float inv = 1.0f / den;
+  float* op = out + ((size_t)n * c + h * 8) * l;
+  if (q0 + l31 < l) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+      op[(size_t)(r + 4 * half) * l + q0 + l31] = (o_hi[r] + o_lo[r] * (1.0f / 2048.0f)) * inv;
+    if (lse && half == 0) lse[((size_t)n * heads + h) * l + q0 + l31] = m + log2f(den);
+  }
+}
+
+static int g_att_mfma = 1;  // head_dim 8 on the matrix cores (tuning key 14: A/B against the VALU kernel)
+void attention_set_mfma(int v) { g_att_mfma = v; }
+
 template <int D>
 static int launch_attention(const float* qkv, float* out, float* lse, int n, int c, int heads, int l, hipStream_t st) {
   // scores are kept in the log2 domain: q is pre-scaled by log2(e)/sqrt(D)
   const float qscale = 1.4426950408889634f / sqrtf((float)D);
+  if (D == 8 && g_att_mfma && l % 32 == 0) {
+    hipLaunchKernelGGL(attention_mfma8_kernel, dim3(cdiv(l, 32 * ATM_NW), heads, n), dim3(64 * ATM_NW), 0, st, qkv, out, lse, c, heads, l,
+                       qscale);
+    DSG_LAUNCH_CHECK();
+    return DSG_OK;
+  }
   const long work = (long)n * heads * l;
   int qpt = 4;
   if (work / (256 * 4) < 512) qpt = 2;

@@ -445,6 +445,7 @@ void conv_h2_set_stats(int on);
 void conv_h2_set_waves(int w);
 void conv_h2_set_pw_occ2(int v);
 void unet_set_blocked(int v);
+void attention_set_mfma(int v);
 void wgrad_h2_set_enabled(int on);
 void conv_h2_set_fold(int on);
 
@@ -758,6 +759,10 @@ DSG_API int dsg_set_tuning(int32_t key, int32_t value) {
   }
   if (key == 6 && (value == 4 || value == 8)) {
     dsg::conv_h2_set_waves(value);
+    return DSG_OK;
+  }
+  if (key == 14 && (value == 0 || value == 1)) {
+    dsg::attention_set_mfma(value);
     return DSG_OK;
   }
   if (key == 13 && (value == 0 || value == 1)) {

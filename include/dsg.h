@@ -352,7 +352,8 @@ int dsg_prof_dump(const char* csv_path);
  *  10  conv_out (cout <= 4) on the VALU kernel: [1] | 0 = zero-padded matrix-core tile
  *  11  pointwise split convs as 8-row tiles, two workgroups per CU: [1] | 0 = the 3x3 kernel's geometry
  *  13  dsg_unet_forward keeps its intermediate activations channel-blocked [N,C/8,H,W,8]: [1] | 0 = [N,C,H,W]
- *      (query dsg_unet_workspace_bytes again after changing it) */
+ *      (query dsg_unet_workspace_bytes again after changing it)
+ *  14  attention with head_dim 8 on the matrix cores (fp16x2 split): [1] | 0 = the VALU kernel */
 int dsg_set_tuning(int32_t key, int32_t value);
 
 #ifdef __cplusplus

@@ -117,7 +117,10 @@ def test_groupnorm(c0, c1, groups, hw):
 
 
 @pytest.mark.parametrize("n,c,heads,l", [(2, 64, 8, 1024), (1, 512, 64, 1024), (3, 32, 4, 256), (1, 32, 2, 200),
-                                         (1, 64, 2, 64)])
+                                         (1, 64, 2, 64),
+                                         (1, 16, 2, 2048),   # head_dim 8: two LDS key tiles on the matrix-core kernel
+                                         (2, 24, 3, 96),     # ... a partial key tile, a query block with idle waves
+                                         (1, 8, 1, 100)])    # ... l % 32 != 0: the VALU kernel
 def test_attention(n, c, heads, l):
     qkv = _t(31, (n, 3 * c, l), 1.5)
     d = c // heads

@@ -129,6 +129,26 @@ def test_attn_blocks_forward_vs_oracle():
     _assert_close(net(x.to(DEV), t.to(DEV)).sample, want)
 
 
+@pytest.mark.parametrize("cfg", [CFG1, CFG4_SMALL], ids=["cfg1_tiny", "cfg4_attention_small"])
+def test_blocked_and_plain_intermediates_agree(cfg):
+    """dsg_unet_forward keeps its intermediates channel-blocked ([N,C/8,H,W,8], dsg_set_tuning key 13); the same
+    plan run with [N,C,H,W] intermediates gives the same result to round-off (same kernels' arithmetic; only the
+    summation order of the fallback GroupNorm statistics differs)."""
+    from drivescenegen_amd import _lib
+    net, _ = _pair(cfg)
+    x = noisy_inputs(cfg, 2).to(DEV)
+    lib = _lib.load()
+    try:
+        with torch.no_grad():
+            _lib.check(lib.dsg_set_tuning(13, 0))
+            plain = net(x, 321).sample.clone()
+            _lib.check(lib.dsg_set_tuning(13, 1))
+            blocked = net(x, 321).sample.clone()
+    finally:
+        lib.dsg_set_tuning(13, 1)
+    assert rel_l2(blocked.cpu(), plain.cpu()) <= 2e-6
+
+
 def test_default_unet_256_forward_vs_oracle():
     """The train.py:39-57 network itself (56,574,595 params), B=1, 256x256x3."""
     net, ora = _pair(DEFAULT3)
