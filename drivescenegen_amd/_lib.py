@@ -43,6 +43,7 @@ class ConvArgs(C.Structure):
         ("weight_h2_fold", C.c_void_p),
         ("stats_out", C.c_void_p),
         ("src_layout", C.c_int32), ("dst_layout", C.c_int32),
+        ("weight_h2_s2", C.c_void_p),
     ]
 
 
@@ -79,6 +80,7 @@ _vp, _i32, _i64, _f32, _sz, _f64 = C.c_void_p, C.c_int32, C.c_int64, C.c_float, 
 SIGNATURES = {
     "dsg_conv2d_stats_tiles": [_vp, _vp],
     "dsg_conv_weight_relayout_h2_fold": [_vp, _vp, _i32, _i32, _vp],
+    "dsg_conv_weight_relayout_h2_s2": [_vp, _vp, _i32, _i32, _vp],
     "dsg_upsample_nearest2x": [_vp, _vp, _i64, _i32, _i32, _vp],
     "dsg_sumpool2x2": [_vp, _vp, _vp, _i64, _i32, _i32, _vp],
     "dsg_rasterize_boxes": [_vp, _i32, _vp, _i32, _i32, _f32, _f32, _f32, _vp],

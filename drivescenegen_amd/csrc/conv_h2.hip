@@ -100,6 +100,11 @@ __device__ __forceinline__ float half_wave_sum(float x) {
 
 __device__ __forceinline__ float silu_fast_h(float x) { return x * __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
 
+// GM: 3 STRIDE-2 3x3 conv (Downsample2D) as a 2x2 conv over the space-to-depth image, which for channel-blocked
+// sources is pure addressing: k-group (cb, py, px) of the 4C "channels" is channel block cb read at pixels
+// (2y + py, 2x + px); output row oy needs input rows 2oy-1 (y' = oy-1, py = 1), 2oy (oy, 0), 2oy+1 (oy, 1), i.e. the
+// 2x2 corner {y'-1, y'} x {x'-1, x'} of the low-resolution patch with zero weights where no 3x3 tap lands (7 of the
+// 16 (tap, phase) pairs): 16/9 of the useful products, on the pipe that is 5x faster than the f32 one.
 // GM: 0 plain, 1 nearest x2 gather, 2 nearest x2 FOLDED into the weights: Upsample2D + 3x3 conv is four 2x2 convs of
 // the low-resolution input, one per output phase (py, px) = (Y & 1, X & 1): rows {y-1: W0, y: W1+W2} for py = 0 and
 // {y: W0+W1, y+1: W2} for py = 1, likewise in x -- 16 tap products per input pixel instead of 36.  The kernel runs on
@@ -119,7 +124,7 @@ __device__ __forceinline__ float silu_fast_h(float x) { return x * __builtin_amd
 template <int GM, int NT, int KS, int ACT = 3, int NW = 4, int OCC = 1, int LAY = 0>
 __global__ __launch_bounds__(64 * NW, OCC * NW / 4) void conv_h2_kernel(ConvH2P p) {
   constexpr bool SB = (LAY & 1) != 0, DB = (LAY & 2) != 0;
-  using G = H2Geom<NT, KS, NW, GM == 2 ? 4 : KS * KS>;
+  using G = H2Geom<NT, KS, NW, (GM == 2 || GM == 3) ? 4 : KS * KS>;
   constexpr int NTH = G::NTH;
   constexpr int H2_TH = G::TH, H2_PSZ = G::PSZ, H2_XHALFS = G::XHALFS, H2_BUF_BYTES = G::BUF_BYTES, H2_NU = G::NU;
   constexpr int FULL = G::FULL, TAPS = G::TAPS, H2_PW = G::PW, H2_WHALFS = G::WHALFS, PADK = KS / 2;
@@ -174,7 +179,7 @@ __global__ __launch_bounds__(64 * NW, OCC * NW / 4) void conv_h2_kernel(ConvH2P 
       const int gy = oy0 - PADK + py, gx = ox0 - PADK + px;
       const int slot = H2_WHALFS + (g * H2_PSZ + pos) * 8;  // piece 0; piece 1 is 2*PSZ*8 halfs further
       if (gy >= 0 && gy < p.hc && gx >= 0 && gx < p.wc) {
-        off = (GM == 1 ? (gy >> 1) : gy) * p.win + (GM == 1 ? (gx >> 1) : gx);
+        off = GM == 3 ? (2 * gy) * p.win + 2 * gx : (GM == 1 ? (gy >> 1) : gy) * p.win + (GM == 1 ? (gx >> 1) : gx);
         xo = slot;
         xo2 = slot + 2 * H2_PSZ * 8;
       } else {
@@ -206,9 +211,20 @@ __global__ __launch_bounds__(64 * NW, OCC * NW / 4) void conv_h2_kernel(ConvH2P 
   int soff[8];  // byte offsets of the 8 channel planes of a k-group: loop-invariant SGPRs
 #pragma unroll
   for (int j = 0; j < 8; ++j) soff[j] = __builtin_amdgcn_readfirstlane(j * plane * 4);
-  auto load_unit_to = [&](float (&dst)[H2_NU][8], int i, const float* sp) {
-    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<float*>(sp + (size_t)(unit_g(i) * 8) * plane), 0, 8 * plane * 4, 0x00020000);
+  // descriptor of k-group g of chunk q: its 8 channel planes / its channel block (uniform)
+  auto grp_rs = [&](const float* sp, int q, int g) -> __amdgpu_buffer_rsrc_t {
+    if constexpr (GM == 3) {  // group (cb, py, px) of the space-to-depth image: block cb, first pixel (py, px)
+      const int gi = 2 * q + g, cb = gi >> 2, pp = gi & 3;
+      const int first = ((pp >> 1) * p.win + (pp & 1)) * 8;
+      return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.src0 + ((size_t)n * p.c0 + cb * 8) * plane + first), 0,
+                                               (8 * plane - first) * 4, 0x00020000);
+    } else {
+      return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(sp + (size_t)(g * 8) * plane), 0, 8 * plane * 4,
+                                               0x00020000);
+    }
+  };
+  auto load_unit_to = [&](float (&dst)[H2_NU][8], int i, const float* sp, int q) {
+    const __amdgpu_buffer_rsrc_t rs = grp_rs(sp, q, unit_g(i));
     if constexpr (SB) {  // (the k-group's 8 planes and its channel block start at the same address)
       const float4 lo = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rs, goff[i] * 32, 0, 0));
       const float4 hi = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rs, goff[i] * 32, 16, 0));
@@ -220,7 +236,7 @@ __global__ __launch_bounds__(64 * NW, OCC * NW / 4) void conv_h2_kernel(ConvH2P 
         dst[i][j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, goff[i] * 4, soff[j], 0));
     }
   };
-  auto load_unit = [&](int i, int q, const float* sp) { load_unit_to(xr, i, sp); };
+  auto load_unit = [&](int i, int q, const float* sp) { load_unit_to(xr, i, sp, q); };
   auto commit_unit_from = [&](const float (&src)[H2_NU][8], int i, int q, unsigned char* buf) {  // q: chunk staged
     half8 h1, h2;
     float4 sr[4];
@@ -248,7 +264,7 @@ __global__ __launch_bounds__(64 * NW, OCC * NW / 4) void conv_h2_kernel(ConvH2P 
   // turns two channels (2jp, 2jp+1) of unit P/4 into fp16 pairs -- the unit's LDS write rides on its last step --
   // and refills the two registers with chunk q+2's values.
   half8 h1s[H2_NU], h2s[H2_NU];
-  auto stage_step = [&](int P, int qs, unsigned char* buf, bool stage, bool load, const float* spn) {
+  auto stage_step = [&](int P, int qs, unsigned char* buf, bool stage, bool load, const float* spn) {  // (loads: chunk qs + 1)
     const int i = P / 4, jp = P % 4;
     if (stage) {
       float4 s4 = make_float4(1.f, 1.f, 0.f, 0.f);
@@ -271,8 +287,7 @@ __global__ __launch_bounds__(64 * NW, OCC * NW / 4) void conv_h2_kernel(ConvH2P 
       }
     }
     if (load) {
-      const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
-          const_cast<float*>(spn + (size_t)(unit_g(i) * 8) * plane), 0, 8 * plane * 4, 0x00020000);
+      const __amdgpu_buffer_rsrc_t rs = grp_rs(spn, qs + 1, unit_g(i));
       if constexpr (SB) {  // four channels are free after every second step: one 16-byte load refills them
         if (jp & 1) {
           const float4 v4 =
@@ -369,11 +384,11 @@ __global__ __launch_bounds__(64 * NW, OCC * NW / 4) void conv_h2_kernel(ConvH2P 
     for (int k = 0; k < G::NDMA; ++k) dma_weights(k, wtile, buf0);
     const float* sp = src_of(0);
 #pragma unroll
-    for (int i = 0; i < H2_NU; ++i) load_unit_to(xr0, i, sp);
+    for (int i = 0; i < H2_NU; ++i) load_unit_to(xr0, i, sp, 0);
     if (nq > 1) {
       const float* sp1 = src_of(1);
 #pragma unroll
-      for (int i = 0; i < H2_NU; ++i) load_unit_to(xr, i, sp1);
+      for (int i = 0; i < H2_NU; ++i) load_unit_to(xr, i, sp1, 1);
     }
     DSG_PT(1);
     if (has_ss) {
@@ -418,8 +433,9 @@ __global__ __launch_bounds__(64 * NW, OCC * NW / 4) void conv_h2_kernel(ConvH2P 
     // is free to interleave them with the staging work (LDS reads after a possibly-aliasing LDS write are not).
     half8 fa[2][2][2], fb[2][NT][2];  // [parity][tile][piece]
     auto load_frags = [&](int tap, int par) {
-      const int dy = GM == 2 ? (phase >> 1) + (tap >> 1) : tap / KS;   // folded: the phase's 2x2 corner of the patch
-      const int dx = GM == 2 ? (phase & 1) + (tap & 1) : tap % KS;
+      // folded up-sampler: the phase's 2x2 corner of the patch; stride 2: the {y-1, y} x {x-1, x} corner
+      const int dy = GM == 2 ? (phase >> 1) + (tap >> 1) : (GM == 3 ? (tap >> 1) : tap / KS);
+      const int dx = GM == 2 ? (phase & 1) + (tap & 1) : (GM == 3 ? (tap & 1) : tap % KS);
 #pragma unroll
       for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
@@ -752,6 +768,7 @@ static int g_h2_enabled = 1;
 static int g_h2_waves = 4;  // 16-row tiles: 4 waves x 4 rows or 8 waves x 2 rows (tuning key 6)
 static int g_h2_fold = 1;   // folded up-sampler convs (tuning key 8: A/B against the x2 gather)
 static int g_h2_stats = 1;  // epilogue GroupNorm statistics (tuning key 5: A/B against the separate pass)
+static int g_h2_s2 = 1;  // stride-2 convs on the split path (tuning key 15: A/B against the f32 MFMA kernel)
 static int g_h2_pw_occ2 = 1;  // pointwise convs: 8-row tiles compiled for two workgroups per CU (tuning key 11)
 static int g_h2_rows = 0;  // rows per wave: 0 = by grid size, 2 | 4 forced (tuning key 3)
 
@@ -763,8 +780,17 @@ static bool conv_h2_fold(const dsg_conv_args* a) {
          (a->c0 + a->c1) <= 1024;
 }
 
+// stride-2 3x3 conv as a 2x2 conv over the space-to-depth image (GM = 3): channel-blocked tensors only
+static bool conv_h2_s2(const dsg_conv_args* a, int hout, int wout) {
+  return g_h2_enabled && g_h2_s2 && a->weight_h2_s2 != nullptr && a->stride == 2 && a->ksize == 3 && !a->upsample &&
+         !a->pool2 && !a->gn_scale_shift && a->src_layout == 1 && a->dst_layout == 1 && a->c1 == 0 && a->c0 % 8 == 0 &&
+         a->cout % 8 == 0 && a->hin % 2 == 0 && a->win % 2 == 0 && hout % 8 == 0 && wout % H2_TW == 0;
+}
+
 bool conv_h2_eligible(const dsg_conv_args* a, int hout, int wout) {
   const int cin = a->c0 + a->c1;
+  if (conv_h2_s2(a, hout, wout)) return true;
+  if (a->stride != 1) return false;
   const int lay = (a->src_layout ? 1 : 0) | (a->dst_layout ? 2 : 0);
   // channel-blocked tensors: 3x3 stride-1 convs (plain or folded up-sampler) with every tensor blocked; pointwise
   // convs with any pair of layouts
@@ -840,15 +866,21 @@ int conv_h2_launch(const dsg_conv_args* a, int hout, int wout, hipStream_t st) {
     p.hin = hout; p.win = wout;
   }
   const bool fold = conv_h2_fold(a);
+  const bool s2 = conv_h2_s2(a, hout, wout);
   if (fold) {  // the kernel tiles the LOW-resolution grid; outputs land at (2y + py, 2x + px)
     hout = a->hin;
     wout = a->win;
   }
   p.hc = (a->upsample && !fold) ? 2 * p.hin : p.hin;
   p.wc = (a->upsample && !fold) ? 2 * p.win : p.win;
+  if (s2) {  // the patch lives on the output grid; its 4 C "channels" are (channel block, pixel parity) groups
+    p.hc = hout;
+    p.wc = wout;
+    p.cin = 4 * a->c0;
+  }
   p.hout = hout; p.wout = wout; p.cout = a->cout; p.cout_pad = (a->cout + 63) / 64 * 64;
   p.wh_stride = a->weight_h2_cout_stride ? a->weight_h2_cout_stride : p.cout_pad;
-  p.wh = static_cast<const _Float16*>(fold ? a->weight_h2_fold : a->weight_h2);
+  p.wh = static_cast<const _Float16*>(fold ? a->weight_h2_fold : (s2 ? a->weight_h2_s2 : a->weight_h2));
   p.bias = a->bias; p.ss = a->gn_scale_shift; p.silu = a->silu; p.temb = a->temb; p.temb_stride = a->temb_stride;
   p.res = a->residual; p.dst = a->dst;
   // 16-row tiles (NT = 4) when they still give every CU a workgroup; 8-row tiles otherwise
@@ -863,8 +895,9 @@ int conv_h2_launch(const dsg_conv_args* a, int hout, int wout, hipStream_t st) {
   if (prof_on()) {
     const double px = (double)p.n * hout * wout * (fold ? 4 : 1);  // output pixels; FLOPs are the reference op's
     const int taps = a->ksize * a->ksize;
-    pi = prof_begin(a->ksize == 1 ? 8 : (a->upsample ? 7 : 6), 2.0 * px * p.cout * p.cin * taps,
-                    4.0 * ((double)p.n * p.cin * p.hin * p.win + (double)p.cin * taps * p.cout +
+    const double cin_ref = a->c0 + a->c1;  // (stride 2: the kernel's 4 C x 4 taps are the reference op's C x 9)
+    pi = prof_begin(s2 ? 2 : (a->ksize == 1 ? 8 : (a->upsample ? 7 : 6)), 2.0 * px * p.cout * cin_ref * taps,
+                    4.0 * ((double)p.n * cin_ref * p.hin * p.win + cin_ref * taps * p.cout +
                            px * p.cout * (p.res ? 2.0 : 1.0)), st);
   }
   const int act = a->gn_scale_shift ? (a->silu ? 2 : 3) : 0;
@@ -888,7 +921,9 @@ int conv_h2_launch(const dsg_conv_args* a, int hout, int wout, hipStream_t st) {
     else if (lay == 2) rc = h2_launch<0, 2, 1, ACT, 4, 2, 2>(grid, lds, st, p);     \
     else rc = h2_launch<0, 2, 1, ACT, 4, 2, 3>(grid, lds, st, p);                   \
   } while (0)
-  if (fold) {
+  if (s2) {
+    DSG_H2_LAUNCH_BLK(3, 3, 0);
+  } else if (fold) {
     if (lay) DSG_H2_LAUNCH_BLK(2, 3, 0);
     else if (nt4) rc = h2_launch<2, 4, 3, 0>(grid, lds, st, p);
     else rc = h2_launch<2, 2, 3, 0>(grid, lds, st, p);
@@ -922,6 +957,7 @@ void conv_h2_set_stats(int on) { g_h2_stats = on; }
 void conv_h2_set_fold(int on) { g_h2_fold = on; }
 void conv_h2_set_waves(int w) { g_h2_waves = w; }
 void conv_h2_set_pw_occ2(int v) { g_h2_pw_occ2 = v; }
+void conv_h2_set_s2(int v) { g_h2_s2 = v; }
 
 }  // namespace dsg
 
@@ -959,6 +995,32 @@ __global__ void weight_fold_h2_kernel(const float* __restrict__ w, _Float16* __r
   }
 }
 
+// OIHW 3x3 -> stride-2 weights over the space-to-depth image [4 cin/16][piece 2][tap 2x2][g 2][cout_pad][8]:
+// k' = (channel block cb, parity (py, px), channel j of the block); tap (ty, tx) of parity (py, px) is the 3x3 tap
+// (2 ty + py - 1, 2 tx + px - 1) where that exists, zero where it does not.
+__global__ void weight_s2_h2_kernel(const float* __restrict__ w, _Float16* __restrict__ dst, int cout, int cin,
+                                    int cout_pad) {
+  const int nq = 4 * cin / 16;
+  const int64_t total = (int64_t)nq * 4 * 2 * cout * 8;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int j = (int)(i % 8);
+    int64_t r = i / 8;
+    const int co = (int)(r % cout);
+    r /= cout;
+    const int g = (int)(r % 2);
+    r /= 2;
+    const int tap = (int)(r % 4);
+    const int q = (int)(r / 4);
+    const int gi = 2 * q + g, cb = gi >> 2, pp = gi & 3;
+    const int dy = 2 * (tap >> 1) + (pp >> 1) - 1, dx = 2 * (tap & 1) + (pp & 1) - 1;
+    const float v = (dy >= 0 && dx >= 0) ? w[((int64_t)co * cin + cb * 8 + j) * 9 + dy * 3 + dx] : 0.f;  // (dy, dx <= 2)
+    const _Float16 h1 = (_Float16)v;
+    const _Float16 h2 = (_Float16)((v - (float)h1) * 2048.0f);
+    dst[(((((int64_t)q * 2 + 0) * 4 + tap) * 2 + g) * cout_pad + co) * 8 + j] = h1;
+    dst[(((((int64_t)q * 2 + 1) * 4 + tap) * 2 + g) * cout_pad + co) * 8 + j] = h2;
+  }
+}
+
 static int relayout_h2(const float* w_oihw, void* dst_half, int32_t cout, int32_t cin, int32_t ksize, int32_t n_total,
                        int32_t n_off, int mode, void* stream) {
   DSG_CHECK_ARG(w_oihw && dst_half, "dsg_conv_weight_relayout_h2: NULL pointer");
@@ -990,6 +1052,18 @@ DSG_API int dsg_conv_weight_relayout_h2_fold(const float* w_oihw, void* dst_half
   const int64_t total = (int64_t)4 * (cin / 16) * 4 * 2 * cout * 8;
   const int blocks = (int)std::min<int64_t>(dsg::cdiv64(total, 256), 4096);
   hipLaunchKernelGGL(weight_fold_h2_kernel, dim3(blocks), dim3(256), 0, static_cast<hipStream_t>(stream), w_oihw,
+                     static_cast<_Float16*>(dst_half), cout, cin, cout_pad);
+  DSG_LAUNCH_CHECK();
+  return DSG_OK;
+}
+
+DSG_API int dsg_conv_weight_relayout_h2_s2(const float* w_oihw, void* dst_half, int32_t cout, int32_t cin, void* stream) {
+  DSG_CHECK_ARG(w_oihw && dst_half, "dsg_conv_weight_relayout_h2_s2: NULL pointer");
+  DSG_CHECK_ARG(cout > 0 && cin > 0 && cin % 8 == 0, "dsg_conv_weight_relayout_h2_s2: cin (%d) must be a positive multiple of 8", cin);
+  const int cout_pad = (cout + 63) / 64 * 64;
+  const int64_t total = (int64_t)(4 * cin / 16) * 4 * 2 * cout * 8;
+  const int blocks = (int)std::min<int64_t>(dsg::cdiv64(total, 256), 4096);
+  hipLaunchKernelGGL(weight_s2_h2_kernel, dim3(blocks), dim3(256), 0, static_cast<hipStream_t>(stream), w_oihw,
                      static_cast<_Float16*>(dst_half), cout, cin, cout_pad);
   DSG_LAUNCH_CHECK();
   return DSG_OK;

@@ -82,7 +82,7 @@ struct T {  // activation [N, c, h, w] (or any scratch when c/h/w are unused)
   int stiles = 0;
 };
 
-struct Conv { float* w = nullptr; float* b = nullptr; int cin = 0, cout = 0, k = 0, wstride = 0; void* wh = nullptr; void* whf = nullptr; };
+struct Conv { float* w = nullptr; float* b = nullptr; int cin = 0, cout = 0, k = 0, wstride = 0; void* wh = nullptr; void* whf = nullptr; void* whs = nullptr; };
 struct GN { float* g = nullptr; float* b = nullptr; int c = 0; };
 struct Res { GN n1; Conv c1; int toff = 0; GN n2; Conv c2; bool sc = false; Conv csc; int cin = 0, cout = 0; };
 struct Att { GN gn; Conv qkv; Conv out; int c = 0, heads = 0; };
@@ -98,6 +98,7 @@ struct Param {
   bool set;
   void* wh;   // fp16x2-split copy of a 3x3 weight (conv_h2.hip), or nullptr
   void* whf;  // up-sampler convs: the same weight folded into four 2x2 phase kernels, or nullptr
+  void* whs;  // down-sampler convs: the same weight over the space-to-depth image (stride 2 on the split path), or nullptr
 };
 
 }  // namespace
@@ -135,9 +136,10 @@ struct dsg_unet {
   void add_param(const std::string& name, ParamKind kind, float* dst, int64_t numel, int cout = 0, int cin = 0,
                  int k = 0, int cout_total = 0, int cout_off = 0) {
     index[name] = (int)params.size();
-    params.push_back({name, kind, dst, numel, cout, cin, k, cout_total, cout_off, false, nullptr, nullptr});
+    params.push_back({name, kind, dst, numel, cout, cin, k, cout_total, cout_off, false, nullptr, nullptr, nullptr});
   }
-  void reg_conv(const std::string& pre, Conv& c, int cin, int cout, int k, bool upsampler = false) {
+  void reg_conv(const std::string& pre, Conv& c, int cin, int cout, int k, bool upsampler = false,
+                bool downsampler = false) {
     c.cin = cin; c.cout = cout; c.k = k;
     c.wstride = (cout + 31) / 32 * 32;  // zero-padded columns: every conv takes the matrix-core path
     c.w = dalloc((int64_t)cin * k * k * c.wstride);
@@ -148,6 +150,10 @@ struct dsg_unet {
       const int64_t halfs = (int64_t)(cin / 16) * 2 * k * k * 2 * cout * 8;
       c.wh = dalloc((halfs + 1) / 2);
       params.back().wh = c.wh;
+      if (downsampler && k == 3) {  // Downsample2D: 2x2 conv over the space-to-depth image (4 cin, 4 of 9 taps)
+        c.whs = dalloc((int64_t)(4 * cin / 16) * 2 * 4 * 2 * cout * 8 / 2);
+        params.back().whs = c.whs;
+      }
       if (upsampler && k == 3) {  // Upsample2D + conv as four 2x2 convs of the low-resolution map
         c.whf = dalloc((int64_t)4 * (cin / 16) * 2 * 4 * 2 * cout * 8 / 2);
         params.back().whf = c.whf;
@@ -278,7 +284,7 @@ struct Runner {
     a.src0 = x.p; a.c0 = x.c;
     a.src1 = skip ? skip->p : nullptr; a.c1 = skip ? skip->c : 0;
     a.n = B; a.hin = x.h; a.win = x.w; a.upsample = ups; a.ksize = cv.k; a.stride = stride; a.cout = cv.cout;
-    a.weight = cv.w; a.weight_cout_stride = cv.wstride; a.bias = cv.b; a.weight_h2 = cv.wh; a.weight_h2_fold = cv.whf;
+    a.weight = cv.w; a.weight_cout_stride = cv.wstride; a.bias = cv.b; a.weight_h2 = cv.wh; a.weight_h2_fold = cv.whf; a.weight_h2_s2 = cv.whs;
     a.gn_scale_shift = ss ? ss->p : nullptr; a.silu = silu;
     a.temb = temb; a.temb_stride = h->proj_total;
     a.residual = res ? res->p : nullptr;
@@ -349,7 +355,7 @@ struct Runner {
         skips.push_back(x);
       }
       if (d.resample) {
-        x = conv(x, nullptr, d.rconv, 2, 0, nullptr, 0, nullptr, nullptr);
+        x = conv(x, nullptr, d.rconv, 2, 0, nullptr, 0, nullptr, nullptr, nullptr, true);
         skips.push_back(x);
       }
     }
@@ -433,7 +439,7 @@ DSG_API int dsg_unet_create(const dsg_unet_config* cfg, dsg_unet_t** out) {
       if (cfg->down_attn[i]) h->reg_att(pre + ".attentions." + std::to_string(j), d.att[j], out_ch);
     }
     d.resample = i != nb - 1;
-    if (d.resample) h->reg_conv(pre + ".downsamplers.0.conv", d.rconv, out_ch, out_ch, 3);
+    if (d.resample) h->reg_conv(pre + ".downsamplers.0.conv", d.rconv, out_ch, out_ch, 3, false, true);
   }
   h->reg_res("mid_block.resnets.0", h->mid0, boc[nb - 1], boc[nb - 1]);
   h->mid_attn = cfg->add_attention != 0;
@@ -542,6 +548,10 @@ DSG_API int dsg_unet_set_param(dsg_unet_t* h, const char* name, const float* dat
     }
     if (p.whf) {
       rc = dsg_conv_weight_relayout_h2_fold(data, p.whf, p.cout, p.cin, stream);
+      if (rc != DSG_OK) return rc;
+    }
+    if (p.whs) {
+      rc = dsg_conv_weight_relayout_h2_s2(data, p.whs, p.cout, p.cin, stream);
       if (rc != DSG_OK) return rc;
     }
   }

@@ -63,6 +63,18 @@ def relayout_conv_weight_h2_fold(w_oihw: torch.Tensor, out: torch.Tensor = None)
     return out
 
 
+def relayout_conv_weight_h2_s2(w_oihw: torch.Tensor, out: torch.Tensor = None) -> torch.Tensor:
+    """OIHW 3x3 (cin % 8 == 0) -> the stride-2 conv's weights over the space-to-depth image
+    [4 Cin/16][2][2x2][2][cout_pad64][8] fp16 (dsg_conv_args.weight_h2_s2)."""
+    w = w_oihw.contiguous()
+    cout, cin = w.shape[0], w.shape[1]
+    if out is None:
+        out = torch.zeros((4 * cin // 16, 2, 4, 2, (cout + 63) // 64 * 64, 8), dtype=torch.float16, device=w.device)
+    with torch.cuda.device(w.device):
+        _lib.check(_lib.load().dsg_conv_weight_relayout_h2_s2(_lib.ptr(w), out.data_ptr(), cout, cin, _st(w)))
+    return out
+
+
 def relayout_conv_weight_h2_dgrad(w_oihw: torch.Tensor, out: torch.Tensor = None) -> torch.Tensor:
     """OIHW (cout % 16 == 0) -> fp16x2-split layout of the data-gradient conv: [Cout/16][2][k*k][2][cin_pad64][8]."""
     w = w_oihw.contiguous()
@@ -91,7 +103,7 @@ def relayout_conv_weight_dgrad(w_oihw: torch.Tensor, out: torch.Tensor = None) -
 def conv2d_fused(src0, weight_r, bias=None, src1=None, ksize=3, stride=1, upsample=False, gn_scale_shift=None,
                  silu=False, temb=None, temb_stride=0, residual=None, out=None, direct=False, cout=None,
                  pool2=False, wstride=None, weight_h2=None, want_stats=False, stats_buf=None, weight_h2_col=0, weight_h2_fold=None,
-                 src_blocked=False, dst_blocked=False):
+                 src_blocked=False, dst_blocked=False, weight_h2_s2=None):
     """dsg_conv2d_fwd: see include/dsg.h.  `weight_r` is in engine layout; `temb` is a [N, temb_stride] view
     whose first `cout` columns (from its data pointer) are added per (n, cout).
     want_stats: also return the per-tile GroupNorm statistics [N][cout][tiles][2] (fp64) of the result, or None
@@ -128,6 +140,7 @@ def conv2d_fused(src0, weight_r, bias=None, src1=None, ksize=3, stride=1, upsamp
         a.weight_h2 = weight_h2.data_ptr() + 16 * int(weight_h2_col)
         a.weight_h2_cout_stride = weight_h2.shape[-2] if weight_h2_col or weight_h2.shape[-2] != (cout + 63) // 64 * 64 else 0
     a.weight_h2_fold = weight_h2_fold.data_ptr() if weight_h2_fold is not None else None
+    a.weight_h2_s2 = weight_h2_s2.data_ptr() if weight_h2_s2 is not None else None
     a.gn_scale_shift, a.silu = _lib.ptr(gn_scale_shift), int(silu)
     if temb is not None:
         if not temb.is_cuda:

@@ -90,6 +90,9 @@ typedef struct {
                                    on the load side, tools/membench.hip).  dsg_unet_forward keeps its intermediate
                                    activations in this layout; the public tensors stay [N, C, H, W]. */
   int32_t dst_layout;           /* the same for dst and residual */
+  const void* weight_h2_s2;     /* optional, stride == 2 with channel-blocked src and dst only: the 3x3 weights laid out for
+                                   the 2x2 conv over the space-to-depth image (dsg_conv_weight_relayout_h2_s2); the
+                                   down-sampler conv then runs on the split path too */
 } dsg_conv_args;
 
 int dsg_conv2d_fwd(const dsg_conv_args* a, void* stream);
@@ -112,6 +115,10 @@ int dsg_conv_weight_relayout_h2(const float* w_oihw, void* dst_half, int32_t cou
  * four 2x2 convs of the low-resolution input, one per output-pixel parity; taps that land on the same source pixel
  * are summed in fp32 before the split. */
 int dsg_conv_weight_relayout_h2_fold(const float* w_oihw, void* dst_half, int32_t cout, int32_t cin, void* stream);
+/* OIHW 3x3 -> [4 Cin/16][2][2x2 taps][2][cout padded to 64][8] fp16 for dsg_conv_args.weight_h2_s2 (cin % 8 == 0):
+ * contraction index = (channel block, pixel parity (py, px), channel in block); zero where a (tap, parity) pair has
+ * no 3x3 tap. */
+int dsg_conv_weight_relayout_h2_s2(const float* w_oihw, void* dst_half, int32_t cout, int32_t cin, void* stream);
 /* the same for the data-gradient conv (K = cout, N = cin padded to 64, taps reversed): [Cout/16][2][k*k][2][cin_pad][8] */
 int dsg_conv_weight_relayout_h2_dgrad(const float* w_oihw, void* dst_half, int32_t cout, int32_t cin, int32_t ksize,
                                       void* stream);
@@ -353,6 +360,7 @@ int dsg_prof_dump(const char* csv_path);
  *  11  pointwise split convs as 8-row tiles, two workgroups per CU: [1] | 0 = the 3x3 kernel's geometry
  *  13  dsg_unet_forward keeps its intermediate activations channel-blocked [N,C/8,H,W,8]: [1] | 0 = [N,C,H,W]
  *      (query dsg_unet_workspace_bytes again after changing it)
+ *  15  stride-2 convs of channel-blocked tensors on the split path: [1] | 0 = the f32 MFMA kernel
  *  14  attention with head_dim 8 on the matrix cores (fp16x2 split): [1] | 0 = the VALU kernel */
 int dsg_set_tuning(int32_t key, int32_t value);
 

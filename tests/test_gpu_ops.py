@@ -297,6 +297,33 @@ def test_conv_f32_kernels_take_blocked_layouts(case):
     assert torch.equal(got, want), (name, float((got - want).abs().max()))
 
 
+@pytest.mark.parametrize("c,cout,h,w", [(32, 64, 16, 64), (64, 128, 32, 64), (8, 72, 16, 64)])
+def test_conv_h2_stride2_space_to_depth(c, cout, h, w):
+    """Downsample2D's stride-2 3x3 conv on the split path: a 2x2 conv over the space-to-depth image, addressed
+    straight out of the channel-blocked tensor (dsg_conv_args.weight_h2_s2).  Against torch in fp64, with the round-off
+    class of the other split convs; the f32-MFMA kernel on the same call as the yardstick; epilogue statistics."""
+    batch = 2
+    d = lambda t: t.to(DEV)
+    x = _t(41, (batch, c, h, w), 1.3)
+    wt = _t(42, (cout, c, 3, 3), 1.0 / np.sqrt(9 * c))
+    bias = _t(43, (cout,), 0.1)
+    ref64 = F.conv2d(x.double(), wt.double(), bias.double(), stride=2, padding=1)
+    mag = F.conv2d(x.double().abs(), wt.double().abs(), None, stride=2, padding=1) + 1e-30
+    wr, ws2 = ops.relayout_conv_weight(d(wt)), ops.relayout_conv_weight_h2_s2(d(wt))
+    xb = ops.to_blocked(d(x))
+    kw = dict(ksize=3, stride=2, cout=cout, src_blocked=True, dst_blocked=True)
+    got32 = ops.from_blocked(ops.conv2d_fused(xb, wr, d(bias), **kw)).cpu()
+    got, stats = ops.conv2d_fused(xb, wr, d(bias), weight_h2_s2=ws2, want_stats=True, **kw)
+    got = ops.from_blocked(got).cpu()
+    assert not torch.equal(got, got32)  # (another kernel really ran)
+    e32 = float(((got32.double() - ref64).abs() / mag).max())
+    eh2 = float(((got.double() - ref64).abs() / mag).max())
+    assert eh2 <= max(2 * e32, 3e-7), (eh2, e32)
+    assert stats is not None and stats.shape[:2] == (batch, cout)
+    want_st = torch.stack([got.double().sum((2, 3)), (got.double() ** 2).sum((2, 3))], -1)
+    assert torch.allclose(stats.sum(2).cpu(), want_st, rtol=1e-5, atol=1e-5)
+
+
 @pytest.mark.parametrize("case", H2_CASES, ids=[c[0] for c in H2_CASES])
 def test_conv_h2_blocked_layout_is_bit_identical(case):
     """Channel-blocked activations (dsg_conv_args.src_layout / dst_layout = 1): the same arithmetic in the same
