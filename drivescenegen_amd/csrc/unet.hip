@@ -230,36 +230,35 @@ struct Runner {
 
   // scale/shift of GroupNorm(gn) over cat(x, skip).  Statistics come from the producing convs' epilogues where
   // they wrote them; a tensor without them (conv_in, stride-2 convs, tiny maps) gets a pass of its own.
-  T gn_ss(const T& x, const T* skip, const GN& gn) {
-    const int c = x.c + (skip ? skip->c : 0);
-    T ss = alloc(0, 0, 0, (size_t)B * c * 2);
-    const T* src[2] = {&x, skip};
-    T tmp[2];
-    const double* sp[2] = {nullptr, nullptr};
-    int tl[2] = {0, 0};
-    for (int i = 0; i < 2; ++i) {
-      if (!src[i]) continue;
-      if (src[i]->stiles > 0) {
-        sp[i] = src[i]->stats;
-        tl[i] = src[i]->stiles;
-        continue;
-      }
-      // (blocked tensors have only C/8 * N channel blocks to spread over the chip: split the pixels as well)
-      int splits = 1;
-      if (src[i]->blk)
-        while (splits < 16 && (x.h * x.w) % (2 * splits) == 0 && (x.h * x.w) / (2 * splits) >= 2048) splits *= 2;
-      tmp[i] = alloc(0, 0, 0, (size_t)B * src[i]->c * splits * 2, sizeof(double));
-      sp[i] = reinterpret_cast<double*>(tmp[i].p);
-      tl[i] = splits;
-      if (!dry && ok())
-        rc = src[i]->blk ? dsg_gn_channel_stats_blocked(src[i]->p, src[i]->c, B, x.h * x.w, splits,
-                                                        reinterpret_cast<double*>(tmp[i].p), st)
-                         : dsg_gn_channel_stats(src[i]->p, src[i]->c, nullptr, 0, B, x.h * x.w,
-                                                reinterpret_cast<double*>(tmp[i].p), st);
-    }
+  // Statistics pass for a tensor whose producer could not write them (conv_in, shapes the split kernels do not
+  // take): run once, kept with the tensor -- a skip connection is normalised a second time on the way up.
+  void ensure_stats(T& t) {
+    if (t.stiles > 0) return;
+    const int hw = t.h * t.w;
+    // (blocked tensors have only C/8 * N channel blocks to spread over the chip: split the pixels as well)
+    int splits = 1;
+    if (t.blk)
+      while (splits < 16 && hw % (2 * splits) == 0 && hw / (2 * splits) >= 2048) splits *= 2;
+    const size_t bytes = (size_t)B * t.c * splits * 2 * sizeof(double);
+    const size_t off = arena.alloc(bytes);
+    t.sb = std::make_shared<Buf>(&arena, off, bytes);
+    t.stats = reinterpret_cast<double*>(ws + off);
+    t.stiles = splits;
     if (!dry && ok())
-      rc = dsg_gn_finalize_parts(sp[0], x.c, tl[0], sp[1], skip ? skip->c : 0, tl[1], gn.g, gn.b, B,
-                                 h->cfg.norm_num_groups, x.h * x.w, h->cfg.norm_eps, ss.p, st);
+      rc = t.blk ? dsg_gn_channel_stats_blocked(t.p, t.c, B, hw, splits, t.stats, st)
+                 : dsg_gn_channel_stats(t.p, t.c, nullptr, 0, B, hw, t.stats, st);
+  }
+
+  // scale/shift of GroupNorm(gn) over cat(x, skip) from the per-tile statistics both tensors carry
+  T gn_ss(T& x, T* skip, const GN& gn) {
+    const int c = x.c + (skip ? skip->c : 0);
+    ensure_stats(x);
+    if (skip) ensure_stats(*skip);
+    T ss = alloc(0, 0, 0, (size_t)B * c * 2);
+    if (!dry && ok())
+      rc = dsg_gn_finalize_parts(x.stats, x.c, x.stiles, skip ? skip->stats : nullptr, skip ? skip->c : 0,
+                                 skip ? skip->stiles : 0, gn.g, gn.b, B, h->cfg.norm_num_groups, x.h * x.w,
+                                 h->cfg.norm_eps, ss.p, st);
     return ss;
   }
 
@@ -307,7 +306,7 @@ struct Runner {
     return y;
   }
 
-  T resnet(const T& x, const T* skip, const Res& r, const float* tproj) {
+  T resnet(T& x, T* skip, const Res& r, const float* tproj) {
     T ss1 = gn_ss(x, skip, r.n1);
     T hmid = conv(x, skip, r.c1, 1, 0, &ss1, 1, tproj + r.toff, nullptr, nullptr, true);
     ss1 = T();
@@ -322,7 +321,7 @@ struct Runner {
     return y;
   }
 
-  T attention(const T& x, const Att& at) {
+  T attention(T& x, const Att& at) {
     T ss = gn_ss(x, nullptr, at.gn);
     T qkv = conv(x, nullptr, at.qkv, 1, 0, &ss, 0, nullptr, nullptr, nullptr, false, 0);  // (the attention kernel reads [N,3C,L])
     ss = T();
@@ -347,15 +346,18 @@ struct Runner {
     x0.p = const_cast<float*>(xin); x0.c = cfg.in_channels; x0.h = cfg.sample_h; x0.w = cfg.sample_w;
     T x = conv(x0, nullptr, h->conv_in, 1, 0, nullptr, 0, nullptr, nullptr);
     std::vector<T> skips;
+    ensure_stats(x);  // (before the copy: the skip connection then carries them)
     skips.push_back(x);
     for (auto& d : h->down) {
       for (size_t j = 0; j < d.res.size(); ++j) {
         x = resnet(x, nullptr, d.res[j], tproj.p);
         if (!d.att.empty()) x = attention(x, d.att[j]);
+        ensure_stats(x);
         skips.push_back(x);
       }
       if (d.resample) {
         x = conv(x, nullptr, d.rconv, 2, 0, nullptr, 0, nullptr, nullptr, nullptr, true);
+        ensure_stats(x);
         skips.push_back(x);
       }
     }
