@@ -445,6 +445,7 @@ void conv_h2_set_stats(int on);
 void conv_h2_set_waves(int w);
 void conv_h2_set_pw_occ2(int v);
 void conv_h2_set_s2(int v);
+void conv_h2_set_bm32(int v);
 void unet_set_blocked(int v);
 void attention_set_mfma(int v);
 void wgrad_h2_set_enabled(int on);
@@ -760,6 +761,10 @@ DSG_API int dsg_set_tuning(int32_t key, int32_t value) {
   }
   if (key == 6 && (value == 4 || value == 8)) {
     dsg::conv_h2_set_waves(value);
+    return DSG_OK;
+  }
+  if (key == 16 && value >= 0) {
+    dsg::conv_h2_set_bm32(value);
     return DSG_OK;
   }
   if (key == 15 && (value == 0 || value == 1)) {

@@ -62,23 +62,25 @@ constexpr int H2_TW = 32, H2_KC = 16, H2_BM = 64;
 // KS = 3 (halo of 1) or 1 (no halo; attention projections and resnet shortcuts)
 // NW = waves per workgroup (4: one per SIMD with the whole register file; 8: two per SIMD with half of it each,
 // so that one wave's staging / LDS / wait time is covered by the other's MFMAs)
-template <int NT, int KS, int NW = 4, int TAPS_ = KS * KS>
+template <int NT, int KS, int NW = 4, int TAPS_ = KS * KS, int BM_ = 64>
 struct H2Geom {
+  static constexpr int BM = BM_;                      // output channels per workgroup: 64, or 32 (two workgroups per CU)
   static constexpr int NTH = 64 * NW;
   static constexpr int TAPS = TAPS_;                  // 4 in the folded up-sampler mode (2x2 taps of the 3x3 patch)
   static constexpr int TH = NW * NT;
   static constexpr int PH = TH + KS - 1;
   static constexpr int PW = H2_TW + KS - 1;
   static constexpr int PSZ = PW * PH;                 // KS=3: 340 (NT=2) / 612 (NT=4); KS=1: 256 / 512
-  static constexpr int WHALFS = 2 * TAPS * 2 * H2_BM * 8;  // [piece][tap][g][cout][8]: 36864 B / 4096 B
+  static constexpr int WHALFS = 2 * TAPS * 2 * BM * 8;  // [piece][tap][g][cout][8]: 36864 B / 4096 B at BM = 64
   static constexpr int XHALFS = 2 * 2 * PSZ * 8;      // [piece][g][pos][8]
   static constexpr int BUF_BYTES = (WHALFS + XHALFS) * 2 + 64;  // + a dump slot for masked lanes
   static constexpr int FULL = PSZ / NTH;              // full NTH-position slabs per k-group
   static constexpr bool HAS_REM = (PSZ % NTH) != 0;   // KS=3 leaves a remainder slab shared by the two k-groups
   static constexpr int NU = 2 * FULL + (HAS_REM ? 1 : 0);  // staging units per thread
   static constexpr int REM0 = FULL * NTH;             // first position of the remainder unit
-  static constexpr int NSEG = 4 * TAPS;               // 1-KB weight segments per chunk
-  static constexpr int NDMA = (NSEG + NW - 1) / NW;   // weight DMAs per wave per chunk
+  static constexpr int NSEG = 4 * TAPS;               // (piece, tap, g) weight segments per chunk, BM x 16 bytes each
+  static constexpr int NUNIT = NSEG * BM / 64;        // 1-KB DMA units per chunk (a unit = 64 / BM segments)
+  static constexpr int NDMA = (NUNIT + NW - 1) / NW;  // weight DMAs per wave per chunk
   static_assert(PSZ - REM0 <= NTH / 2, "the remainder slab must fit half the workgroup per k-group");
 };
 
@@ -121,10 +123,14 @@ __device__ __forceinline__ float silu_fast_h(float x) { return x * __builtin_amd
 // LAY: bit 0: the sources are channel-blocked [N][C/8][H][W][8] (a halo position's k-group is 32 contiguous bytes:
 //      two 16-byte loads instead of eight dword gathers from eight channel planes); bit 1: dst / residual are
 //      (a lane's four consecutive output channels are one 16-byte store; a wave instruction writes 1 KB contiguous)
-template <int GM, int NT, int KS, int ACT = 3, int NW = 4, int OCC = 1, int LAY = 0>
+// BM: output channels per workgroup.  32 (with NT = 2, OCC = 2) is the small-workgroup geometry for the shallow levels:
+//     80 KB of LDS and half the register file, so two workgroups share a CU and one's patch loads and output stores
+//     run under the other's MFMAs (a workgroup that owns the CU runs those phases back to back).
+template <int GM, int NT, int KS, int ACT = 3, int NW = 4, int OCC = 1, int LAY = 0, int BM = 64>
 __global__ __launch_bounds__(64 * NW, OCC * NW / 4) void conv_h2_kernel(ConvH2P p) {
   constexpr bool SB = (LAY & 1) != 0, DB = (LAY & 2) != 0;
-  using G = H2Geom<NT, KS, NW, (GM == 2 || GM == 3) ? 4 : KS * KS>;
+  constexpr int MTN = BM / 32;  // 32-channel MFMA tiles per workgroup
+  using G = H2Geom<NT, KS, NW, (GM == 2 || GM == 3) ? 4 : KS * KS, BM>;
   constexpr int NTH = G::NTH;
   constexpr int H2_TH = G::TH, H2_PSZ = G::PSZ, H2_XHALFS = G::XHALFS, H2_BUF_BYTES = G::BUF_BYTES, H2_NU = G::NU;
   constexpr int FULL = G::FULL, TAPS = G::TAPS, H2_PW = G::PW, H2_WHALFS = G::WHALFS, PADK = KS / 2;
@@ -144,7 +150,7 @@ __global__ __launch_bounds__(64 * NW, OCC * NW / 4) void conv_h2_kernel(ConvH2P 
   // on neighbouring ids: workgroups that share input -- the same patch for another cout tile, or the 128-byte
   // lines and halo rows a patch has in common with its left/right/upper/lower neighbours -- run at the same time
   // behind the same L2, so that data comes from HBM once instead of once per XCD.
-  const int nct = (p.cout_pad / H2_BM) * (GM == 2 ? 4 : 1), nsp = p.tiles_x * p.tiles_y * p.n;
+  const int nct = (p.cout_pad / BM) * (GM == 2 ? 4 : 1), nsp = p.tiles_x * p.tiles_y * p.n;
   int bid, ct;
   if ((nsp & 7) == 0) {
     const int grp = blockIdx.x >> 3;
@@ -158,9 +164,9 @@ __global__ __launch_bounds__(64 * NW, OCC * NW / 4) void conv_h2_kernel(ConvH2P 
   bid /= p.tiles_x;
   const int ty = bid % p.tiles_y;
   const int n = bid / p.tiles_y;
-  const int phase = GM == 2 ? ct / (p.cout_pad / H2_BM) : 0;  // (py, px) = (phase >> 1, phase & 1)
-  if (GM == 2) ct -= phase * (p.cout_pad / H2_BM);
-  const int m0 = ct * H2_BM;
+  const int phase = GM == 2 ? ct / (p.cout_pad / BM) : 0;  // (py, px) = (phase >> 1, phase & 1)
+  if (GM == 2) ct -= phase * (p.cout_pad / BM);
+  const int m0 = ct * BM;
   const int oy0 = ty * H2_TH, ox0 = tx * H2_TW;
   const int plane = p.hin * p.win;
   const int nq = p.cin / H2_KC;
@@ -311,29 +317,31 @@ __global__ __launch_bounds__(64 * NW, OCC * NW / 4) void conv_h2_kernel(ConvH2P 
   const unsigned segb = (unsigned)p.wh_stride * 16u;  // bytes of one (piece, tap, g) segment row in global memory
   const unsigned chunkb = G::NSEG * segb;             // bytes of one K-chunk's weights
   const char* wtile = reinterpret_cast<const char*>(p.wh + ((size_t)phase * nq * G::NSEG * p.wh_stride + m0) * 8);
+  // a DMA moves 1 KB = 64 / BM segments of BM couts x 16 B: LDS [segment][cout][8 halfs] is contiguous, in global
+  // memory the segments are `segb` apart
   int segoff[G::NDMA];
 #pragma unroll
   for (int k = 0; k < G::NDMA; ++k)
-    segoff[k] = __builtin_amdgcn_readfirstlane(min(wave + NW * k, G::NSEG - 1) * (int)segb);
-  const int lane16 = lane * 16;
+    segoff[k] = __builtin_amdgcn_readfirstlane(min(wave + NW * k, G::NUNIT - 1) * (64 / BM) * (int)segb);
+  const int lane16 = (lane % BM) * 16 + (lane / BM) * (int)segb;
   auto dma_weights = [&](int k, const char* wq, unsigned char* buf) {  // wq: wtile + chunk * chunkb (uniform)
-    // (uniform; a wave whose last share falls past the end repeats the final segment: same bytes, no branch)
-    const int seg = min(wave + NW * k, G::NSEG - 1);
+    // (uniform; a wave whose last share falls past the end repeats the final unit: same bytes, no branch)
+    const int unit = min(wave + NW * k, G::NUNIT - 1);
     // Issued as inline asm on purpose: hipcc's wait-count pass cannot tell the DMA's LDS destination (the other
     // buffer) from the fragment reads of this one, and with a DMA it knows of in flight it puts vmcnt(0) -- a wait
     // for every outstanding patch load as well -- in front of each following ds_read.  Untracked VMEM operations
     // only make the compiler's own counted vmcnt(N) waits stricter (the counter retires in order); the DMA's
     // completion is waited for explicitly before the chunk's closing barrier.
     const unsigned lds_addr =
-        (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)(buf + seg * 1024);
+        (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)(buf + unit * 1024);
     asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1\n" ::"v"(lane16), "s"(wq + segoff[k]),
-                 "s"(lds_addr)
+                 "s"(__builtin_amdgcn_readfirstlane(lds_addr))  // (uniform by construction)
                  : "memory");
   };
 
-  f32x16 acc_hi[2][NT], acc_lo[2][NT];
+  f32x16 acc_hi[MTN][NT], acc_lo[MTN][NT];
 #pragma unroll
-  for (int mt = 0; mt < 2; ++mt)
+  for (int mt = 0; mt < MTN; ++mt)
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
@@ -431,17 +439,17 @@ __global__ __launch_bounds__(64 * NW, OCC * NW / 4) void conv_h2_kernel(ConvH2P 
     // Operand fragments are fetched one tap ahead into the other half of fa/fb: the reads of tap t+1 are issued
     // BEFORE tap t's staging writes in program order, so tap t's MFMAs depend on registers only and the scheduler
     // is free to interleave them with the staging work (LDS reads after a possibly-aliasing LDS write are not).
-    half8 fa[2][2][2], fb[2][NT][2];  // [parity][tile][piece]
+    half8 fa[2][MTN][2], fb[2][NT][2];  // [parity][tile][piece]
     auto load_frags = [&](int tap, int par) {
       // folded up-sampler: the phase's 2x2 corner of the patch; stride 2: the {y-1, y} x {x-1, x} corner
       const int dy = GM == 2 ? (phase >> 1) + (tap >> 1) : (GM == 3 ? (tap >> 1) : tap / KS);
       const int dx = GM == 2 ? (phase & 1) + (tap & 1) : (GM == 3 ? (tap & 1) : tap % KS);
 #pragma unroll
-      for (int mt = 0; mt < 2; ++mt)
+      for (int mt = 0; mt < MTN; ++mt)
 #pragma unroll
         for (int pc = 0; pc < 2; ++pc)
           fa[par][mt][pc] =
-              *reinterpret_cast<const half8*>(wl + (((pc * TAPS + tap) * 2 + half) * H2_BM + mt * 32 + l31) * 8);
+              *reinterpret_cast<const half8*>(wl + (((pc * TAPS + tap) * 2 + half) * BM + mt * 32 + l31) * 8);
 #pragma unroll
       for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
@@ -479,7 +487,7 @@ __global__ __launch_bounds__(64 * NW, OCC * NW / 4) void conv_h2_kernel(ConvH2P 
       }
       const int par = tap & 1;
 #pragma unroll
-      for (int mt = 0; mt < 2; ++mt)
+      for (int mt = 0; mt < MTN; ++mt)
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) {
           acc_hi[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[par][mt][0], fb[par][nt][0], acc_hi[mt][nt], 0, 0, 0);
@@ -491,7 +499,7 @@ __global__ __launch_bounds__(64 * NW, OCC * NW / 4) void conv_h2_kernel(ConvH2P 
       // instead of leaving it in one block as the scheduler would.
       if (KS == 3 && tap < TAPS - 1 && (STAGE || LOAD)) {
 #pragma unroll
-        for (int m = 0; m < 6 * NT; ++m) {
+        for (int m = 0; m < 3 * MTN * NT; ++m) {
           __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);  // 1 MFMA
           __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);  // 2 VALU
         }
@@ -547,9 +555,9 @@ __global__ __launch_bounds__(64 * NW, OCC * NW / 4) void conv_h2_kernel(ConvH2P 
   const bool want_stats = p.stats != nullptr;
 #endif
   float* red = reinterpret_cast<float*>(smem_raw);  // [wave][sum | sumsq][cout 64] (the K loop is done with LDS)
-  constexpr int RED_FLOATS = NW * (NT / 2) * 2 * H2_BM;
+  constexpr int RED_FLOATS = NW * (NT / 2) * 2 * BM;
   float* red_lane = (l31 == 16) ? red + 4 * half : red + RED_FLOATS + 64 + lane;  // (+ crel etc. per value)
-  const int nvalid = min(H2_BM, p.cout - m0);        // output channels of this tile that exist
+  const int nvalid = min(BM, p.cout - m0);        // output channels of this tile that exist
   const size_t tile_off = ((size_t)n * p.cout + m0) * oplane;
   const int range = nvalid * oplane * 4;
   const __amdgpu_buffer_rsrc_t dst_rs = __builtin_amdgcn_make_buffer_rsrc(p.dst + tile_off, 0, range, 0x00020000);
@@ -587,7 +595,7 @@ __global__ __launch_bounds__(64 * NW, OCC * NW / 4) void conv_h2_kernel(ConvH2P 
   auto epilogue = [&](auto stats_tag, auto narrow_tag) {
     constexpr bool STATS = decltype(stats_tag)::value, NARROW = decltype(narrow_tag)::value;
 #pragma unroll
-    for (int mt = 0; mt < 2; ++mt) {
+    for (int mt = 0; mt < MTN; ++mt) {
       float rv[16][NT], addv[16];
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
@@ -669,8 +677,8 @@ __global__ __launch_bounds__(64 * NW, OCC * NW / 4) void conv_h2_kernel(ConvH2P 
               const float t1 = half_wave_sum(a + b), t2 = half_wave_sum(a * a + b * b);
               // every lane stores -- lanes 16 / 48 to the real slot, the others to a per-lane dump area behind it:
               // a predicated store here is a branch, and 128 branches fence the scheduler between the DPP chains
-              red_lane[((wave * (NT / 2) + pr) * 2 + 0) * H2_BM + crel] = t1;
-              red_lane[((wave * (NT / 2) + pr) * 2 + 1) * H2_BM + crel] = t2;
+              red_lane[((wave * (NT / 2) + pr) * 2 + 0) * BM + crel] = t1;
+              red_lane[((wave * (NT / 2) + pr) * 2 + 1) * BM + crel] = t2;
             }
           }
         }
@@ -689,8 +697,8 @@ __global__ __launch_bounds__(64 * NW, OCC * NW / 4) void conv_h2_kernel(ConvH2P 
     // statistics tiles are 8 rows x 32 columns (4 row pairs, summed in row order in fp64) whatever NT is, so the
     // values -- and everything downstream of the norm -- do not depend on the launch geometry
     __syncthreads();
-    if (tid < 2 * H2_BM) {
-      const int cl = tid & (H2_BM - 1), which = (tid >> 6) & 1;
+    if (tid < 2 * BM) {
+      const int cl = tid & (BM - 1), which = (tid / BM) & 1;
       if (m0 + cl < p.cout) {
         constexpr int NE = NW * NT / 8;  // 8-row statistics tiles per workgroup tile
         const int ntile1 = p.tiles_x * p.tiles_y * NE;           // entries per phase
@@ -699,7 +707,7 @@ __global__ __launch_bounds__(64 * NW, OCC * NW / 4) void conv_h2_kernel(ConvH2P 
         for (int e = 0; e < NE; ++e) {
           double t = 0.0;
 #pragma unroll
-          for (int j = 0; j < 4; ++j) t += (double)red[((4 * e + j) * 2 + which) * H2_BM + cl];
+          for (int j = 0; j < 4; ++j) t += (double)red[((4 * e + j) * 2 + which) * BM + cl];
           const int tile8 = phase * ntile1 + (ty * NE + e) * p.tiles_x + tx;
 #ifndef DSG_H2_TIMING
           p.stats[(((size_t)n * p.cout + m0 + cl) * ntile + tile8) * 2 + which] = t;
@@ -768,6 +776,9 @@ static int g_h2_enabled = 1;
 static int g_h2_waves = 4;  // 16-row tiles: 4 waves x 4 rows or 8 waves x 2 rows (tuning key 6)
 static int g_h2_fold = 1;   // folded up-sampler convs (tuning key 8: A/B against the x2 gather)
 static int g_h2_stats = 1;  // epilogue GroupNorm statistics (tuning key 5: A/B against the separate pass)
+static int g_h2_bm32 = 0;      // 32-cout x 8-row workgroups, two per CU, for the shallow levels (tuning key 16; measured
+                               // slower than the 64 x 16 geometry: 0.356 vs 0.302 ms at 64 channels / 256^2 -- off)
+static int g_h2_bm32_min = 512;  // ... when the 64-cout x 16-row grid has at least this many workgroups
 static int g_h2_s2 = 1;  // stride-2 convs on the split path (tuning key 15: A/B against the f32 MFMA kernel)
 static int g_h2_pw_occ2 = 1;  // pointwise convs: 8-row tiles compiled for two workgroups per CU (tuning key 11)
 static int g_h2_rows = 0;  // rows per wave: 0 = by grid size, 2 | 4 forced (tuning key 3)
@@ -840,9 +851,9 @@ int conv_h2_stats_tiles(const dsg_conv_args* a, int hout, int wout) {
   return (hout / 8) * ((wout + H2_TW - 1) / H2_TW);  // 8-row x 32-column statistics tiles for either block height
 }
 
-template <int GM, int NT, int KS, int ACT, int NW = 4, int OCC = 1, int LAY = 0>
+template <int GM, int NT, int KS, int ACT, int NW = 4, int OCC = 1, int LAY = 0, int BM = 64>
 static int h2_launch(dim3 grid, size_t lds, hipStream_t st, const ConvH2P& p) {
-  auto kern = conv_h2_kernel<GM, NT, KS, ACT, NW, OCC, LAY>;
+  auto kern = conv_h2_kernel<GM, NT, KS, ACT, NW, OCC, LAY, BM>;
   static bool raised = false;
   if (!raised) {
     DSG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -921,6 +932,8 @@ int conv_h2_launch(const dsg_conv_args* a, int hout, int wout, hipStream_t st) {
     else if (lay == 2) rc = h2_launch<0, 2, 1, ACT, 4, 2, 2>(grid, lds, st, p);     \
     else rc = h2_launch<0, 2, 1, ACT, 4, 2, 3>(grid, lds, st, p);                   \
   } while (0)
+  const bool bm32 = g_h2_bm32 && lay == 3 && !fold && !s2 && !k1 && !a->upsample && p.cin <= 128 && wout % H2_TW == 0 &&
+                    (int)grid.x >= g_h2_bm32_min;
   if (s2) {
     DSG_H2_LAUNCH_BLK(3, 3, 0);
   } else if (fold) {
@@ -935,6 +948,14 @@ int conv_h2_launch(const dsg_conv_args* a, int hout, int wout, hipStream_t st) {
     else DSG_H2_LAUNCH(0, 1, 3);
   } else if (a->upsample) {
     DSG_H2_LAUNCH(1, 3, 0);
+  } else if (bm32) {
+    // shallow levels: 32 couts x 8 rows x 32 columns per workgroup, two workgroups per CU
+    const dim3 g32(((wout + H2_TW - 1) / H2_TW) * (hout / 8) * p.n * (p.cout_pad / 32));
+    const size_t lds32 = 2 * (size_t)H2Geom<2, 3, 4, 9, 32>::BUF_BYTES + (a->gn_scale_shift ? (size_t)p.cin * 2 * sizeof(float) : 0);
+    ConvH2P q = p;
+    q.tiles_y = hout / 8;
+    if (act == 0) rc = h2_launch<0, 2, 3, 0, 4, 2, 3, 32>(g32, lds32, st, q);
+    else rc = h2_launch<0, 2, 3, 2, 4, 2, 3, 32>(g32, lds32, st, q);
   } else if (lay) {
     if (act == 0) DSG_H2_LAUNCH_BLK(0, 3, 0);
     else DSG_H2_LAUNCH_BLK(0, 3, 2);
@@ -958,6 +979,7 @@ void conv_h2_set_fold(int on) { g_h2_fold = on; }
 void conv_h2_set_waves(int w) { g_h2_waves = w; }
 void conv_h2_set_pw_occ2(int v) { g_h2_pw_occ2 = v; }
 void conv_h2_set_s2(int v) { g_h2_s2 = v; }
+void conv_h2_set_bm32(int v) { g_h2_bm32 = v != 0; if (v > 1) g_h2_bm32_min = v; }
 
 }  // namespace dsg
 

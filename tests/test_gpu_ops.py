@@ -297,6 +297,40 @@ def test_conv_f32_kernels_take_blocked_layouts(case):
     assert torch.equal(got, want), (name, float((got - want).abs().max()))
 
 
+@pytest.mark.parametrize("case", [c for c in H2_CASES if (len(c) <= 10 or c[10] == 3) and not c[6] and c[1] + c[2] <= 128
+                                  and c[5] % 32 == 0], ids=lambda c: c[0])
+def test_conv_h2_small_workgroup_geometry_is_bit_identical(case):
+    """The shallow levels' geometry (32 couts x 8 rows per workgroup, two workgroups per CU; dsg_set_tuning key 16):
+    the same contraction order per output, so results and epilogue statistics equal the 64 x 16 geometry's bit for
+    bit."""
+    from drivescenegen_amd import _lib
+    name, c0, c1, cout, h, w, ups, gn, temb, res = case[:10]
+    batch, cin = 2, c0 + c1
+    d = lambda t: None if t is None else t.to(DEV)
+    b = lambda t: None if t is None else ops.to_blocked(t)
+    x0, x1 = d(_t(1, (batch, c0, h, w), 1.7)), (d(_t(2, (batch, c1, h, w))) if c1 else None)
+    wt = d(_t(3, (cout, cin, 3, 3), 1.0 / np.sqrt(cin * 9)))
+    bias = d(_t(4, (cout,), 0.1))
+    gamma, beta = d(1 + _t(5, (cin,), 0.1)), d(_t(6, (cin,), 0.1))
+    tp = d(_t(7, (batch, cout + 5), 0.5))
+    r = d(_t(8, (batch, cout, h, w))) if res else None
+    wr, wh = ops.relayout_conv_weight(wt), ops.relayout_conv_weight_h2(wt)
+    ss = ops.gn_scale_shift(x0, gamma, beta, 8, 1e-5, src1=x1) if gn else None
+    kw = dict(src1=b(x1), ksize=3, gn_scale_shift=ss, silu=gn, temb=tp[:, 3:] if temb else None,
+              temb_stride=tp.stride(0), residual=b(r), cout=cout, weight_h2=wh, src_blocked=True, dst_blocked=True,
+              want_stats=True)
+    lib = _lib.load()
+    try:
+        _lib.check(lib.dsg_set_tuning(16, 0))
+        want, wstats = ops.conv2d_fused(b(x0), wr, bias, **kw)
+        _lib.check(lib.dsg_set_tuning(16, 2))  # (2: take the small geometry whatever the grid size)
+        got, gstats = ops.conv2d_fused(b(x0), wr, bias, **kw)
+    finally:
+        lib.dsg_set_tuning(16, 0)
+    assert torch.equal(got, want), float((got - want).abs().max())
+    assert torch.equal(gstats, wstats)
+
+
 @pytest.mark.parametrize("c,cout,h,w", [(32, 64, 16, 64), (64, 128, 32, 64), (8, 72, 16, 64)])
 def test_conv_h2_stride2_space_to_depth(c, cout, h, w):
     """Downsample2D's stride-2 3x3 conv on the split path: a 2x2 conv over the space-to-depth image, addressed
