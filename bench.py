@@ -203,8 +203,8 @@ def main():
             # fp32-equivalent MAC -> the ceiling for ALGORITHMIC (fp32-equivalent) FLOPs is the dense f16 peak / 3
             dom = prof["conv3x3_s1_mfma_f16x2split"]
             peak = PEAK_F16_TFLOPS / 3.0
-            roofline = dict(bound="mfma", kernel="dsg::conv_h2_kernel<0, 4, 3, 2, 4, 1, 3>", achieved=dom["tflops"], peak=peak,
-                            unit="TFLOP/s", frac=dom["tflops"] / peak, **pmc_traffic("dsg::conv_h2_kernel<0, 4, 3, 2, 4, 1, 3>"),
+            roofline = dict(bound="mfma", kernel="dsg::conv_h2_kernel<0, 4, 3, 2, 4, 1, 3, 64>", achieved=dom["tflops"], peak=peak,
+                            unit="TFLOP/s", frac=dom["tflops"] / peak, **pmc_traffic("dsg::conv_h2_kernel<0, 4, 3, 2, 4, 1, 3, 64>"),
                             peak_note="2500 TF/s dense f16 MFMA / 3 products per fp32-equivalent MAC (fp16x2 split); "
                                       "issued MFMA rate = 3 x achieved; the pure-fp32 MFMA peak is 157.3",
                             issued_mfma_tflops=3.0 * dom["tflops"],
