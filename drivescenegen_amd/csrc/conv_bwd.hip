@@ -215,28 +215,50 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(WgradP p) {
   }
 }
 
-// dw[co][ci][tp] += sum_s ws[s][tp][ci][co]; one thread per (tp, ci, 4 consecutive co): 16-byte reads of every slab
-// (cout_pad is a multiple of 64), summed in slab order
+// dw[co][ci][tp] += sum_s ws[s][tp][ci][co]; 16-byte reads (cout_pad is a multiple of 64).  A workgroup owns 64
+// consecutive float4 elements; its four waves each sum every fourth slab (four loads in flight per lane), the four
+// partial sums meet in LDS and are added in a fixed order -- deterministic, and the small layers (9 K elements, up to
+// 256 slabs) still put four times as many waves on the chip as one thread per element would.
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ ws, int nslab, int taps, int cin,
                                                            int cout, int cin_pad, int cout_pad,
                                                            float* __restrict__ dw) {
-  const int64_t i4 = blockIdx.x * (int64_t)256 + threadIdx.x;
+  __shared__ float4 part[4][64];
+  const int e = threadIdx.x & 63, sl = threadIdx.x >> 6;
+  const int64_t i4 = blockIdx.x * (int64_t)64 + e;
   const int64_t slab = (int64_t)taps * cin_pad * cout_pad;
-  if (i4 * 4 >= slab) return;
-  const int64_t i = i4 * 4;
+  const bool in = i4 * 4 < slab;
+  const int64_t i = in ? i4 * 4 : 0;
+  float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (in) {
+    int k = sl;
+    for (; k + 12 < nslab; k += 16) {  // four of this wave's slabs at a time
+      const float4 a = *reinterpret_cast<const float4*>(ws + (int64_t)k * slab + i);
+      const float4 b = *reinterpret_cast<const float4*>(ws + (int64_t)(k + 4) * slab + i);
+      const float4 c = *reinterpret_cast<const float4*>(ws + (int64_t)(k + 8) * slab + i);
+      const float4 d = *reinterpret_cast<const float4*>(ws + (int64_t)(k + 12) * slab + i);
+      s.x += a.x; s.y += a.y; s.z += a.z; s.w += a.w;
+      s.x += b.x; s.y += b.y; s.z += b.z; s.w += b.w;
+      s.x += c.x; s.y += c.y; s.z += c.z; s.w += c.w;
+      s.x += d.x; s.y += d.y; s.z += d.z; s.w += d.w;
+    }
+    for (; k < nslab; k += 4) {
+      const float4 v = *reinterpret_cast<const float4*>(ws + (int64_t)k * slab + i);
+      s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+    }
+  }
+  part[sl][e] = s;
+  __syncthreads();
+  if (sl != 0 || !in) return;
+  const float4 p0 = part[0][e], p1 = part[1][e], p2 = part[2][e], p3 = part[3][e];
+  const float sv[4] = {(p0.x + p1.x) + (p2.x + p3.x), (p0.y + p1.y) + (p2.y + p3.y), (p0.z + p1.z) + (p2.z + p3.z),
+                       (p0.w + p1.w) + (p2.w + p3.w)};
   const int co = (int)(i % cout_pad);
   const int ci = (int)((i / cout_pad) % cin_pad);
   const int tp = (int)(i / ((int64_t)cout_pad * cin_pad));
   if (co >= cout || ci >= cin) return;
-  float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
-  for (int k = 0; k < nslab; ++k) {
-    const float4 v = *reinterpret_cast<const float4*>(ws + k * slab + i);
-    s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
-  }
-  const float sv[4] = {s.x, s.y, s.z, s.w};
 #pragma unroll
-  for (int e = 0; e < 4; ++e)
-    if (co + e < cout) dw[((size_t)(co + e) * cin + ci) * taps + tp] += sv[e];
+  for (int q = 0; q < 4; ++q)
+    if (co + q < cout) dw[((size_t)(co + q) * cin + ci) * taps + tp] += sv[q];
 }
 
 // Generic VALU fallback (odd spatial sizes): one thread per (co, ci, tap), loops over all pixels.
@@ -596,7 +618,7 @@ static int launch_wgrad(WgradP p, size_t ws_bytes, hipStream_t st) {
   hipLaunchKernelGGL(kern, dim3(pairs, nsplit), dim3(256), lds, st, p);
   DSG_LAUNCH_CHECK();
   const int64_t slab = (int64_t)G::TAPS * p.cin_pad * p.cout_pad;
-  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)cdiv64(slab / 4, 256)), dim3(256), 0, st, p.ws, nslab, G::TAPS, p.cin,
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)cdiv64(slab / 4, 64)), dim3(256), 0, st, p.ws, nslab, G::TAPS, p.cin,
                      p.cout, p.cin_pad, p.cout_pad, p.dw);
   prof_end(pi, st);
   DSG_LAUNCH_CHECK();
@@ -638,7 +660,7 @@ static int launch_wgrad_h2(WgradP p, size_t ws_bytes, hipStream_t st) {
   hipLaunchKernelGGL(conv_wgrad_h2_kernel, dim3(pairs, nslab), dim3(256), (size_t)WH_LDS_BYTES, st, p);
   DSG_LAUNCH_CHECK();
   const int64_t slab = (int64_t)9 * p.cin_pad * p.cout_pad;
-  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)cdiv64(slab / 4, 256)), dim3(256), 0, st, p.ws, nslab, 9, p.cin,
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)cdiv64(slab / 4, 64)), dim3(256), 0, st, p.ws, nslab, 9, p.cin,
                      p.cout, p.cin_pad, p.cout_pad, p.dw);
   prof_end(pi, st);
   DSG_LAUNCH_CHECK();
