@@ -164,6 +164,22 @@ def pmc_traffic(kernel):
         return dict(traffic=None)
 
 
+def pmc_mfma(kernel):
+    """Matrix-pipe utilisation of `kernel` from the committed SQ-counter pass (tools/pmc_mfma.sh ->
+    profiles/*_pmc_mfma.json): MFMA instructions issued x 32 cycles / (GPU cycles x 1024 SIMDs), independent of the
+    clock the chip throttles to.  Quoted next to the live figures like the HBM traffic; {} when no file travels."""
+    import glob
+    files = sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "*_pmc_mfma.json")))
+    if not files:
+        return {}
+    try:
+        d = json.load(open(files[-1]))
+        k = next(v for name, v in sorted(d["kernels"].items()) if name.startswith(kernel.rstrip(">")))
+        return dict(mfma_pipe_util=k["mfma_util_issued"], mfma_pipe_util_source="profiles/" + os.path.basename(files[-1]))
+    except (KeyError, ValueError, OSError, StopIteration):
+        return {}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -205,6 +221,7 @@ def main():
             peak = PEAK_F16_TFLOPS / 3.0
             roofline = dict(bound="mfma", kernel="dsg::conv_h2_kernel<0, 4, 3, 2, 4, 1, 3, 64>", achieved=dom["tflops"], peak=peak,
                             unit="TFLOP/s", frac=dom["tflops"] / peak, **pmc_traffic("dsg::conv_h2_kernel<0, 4, 3, 2, 4, 1, 3, 64>"),
+                            **pmc_mfma("dsg::conv_h2_kernel<0, 4, 3, 2, 4, 1, 3, 64>"),
                             peak_note="2500 TF/s dense f16 MFMA / 3 products per fp32-equivalent MAC (fp16x2 split); "
                                       "issued MFMA rate = 3 x achieved; the pure-fp32 MFMA peak is 157.3",
                             issued_mfma_tflops=3.0 * dom["tflops"],
