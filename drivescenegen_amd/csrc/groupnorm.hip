@@ -136,15 +136,27 @@ __global__ __launch_bounds__(64) void gn_finalize_parts_kernel(const double* __r
   const int c = c0 + c1, cpg = c / groups;
   const int ni = blockIdx.x / groups, g = blockIdx.x - ni * groups;
   const int lane = threadIdx.x;
+  // A group's channels are consecutive, hence its partials are one contiguous run of (sum, sum of squares) pairs per
+  // source: the 64 lanes stride over that run (the deep levels have 16-32 channels x 4 tiles per group -- a loop
+  // over channels with 4 active lanes would be 32 dependent round trips).  Fixed order for a given shape.
   double s = 0.0, ss = 0.0;
-  for (int k = 0; k < cpg; ++k) {
-    const int ch = g * cpg + k;
-    const bool first = ch < c0;
-    const int tiles = first ? t0 : t1;
-    const double* p = first ? st0 + ((size_t)ni * c0 + ch) * t0 * 2 : st1 + ((size_t)ni * c1 + (ch - c0)) * t1 * 2;
-    for (int t = lane; t < tiles; t += 64) {
-      s += p[2 * t];
-      ss += p[2 * t + 1];
+  const int ch0 = g * cpg, ch1 = ch0 + cpg;
+  {
+    const int a = min(ch0, c0), b = min(ch1, c0);  // the group's channels that live in source 0
+    const double2* p = reinterpret_cast<const double2*>(st0 + ((size_t)ni * c0 + a) * t0 * 2);
+    for (int i = lane; i < (b - a) * t0; i += 64) {
+      const double2 v = p[i];
+      s += v.x;
+      ss += v.y;
+    }
+  }
+  if (c1 > 0) {
+    const int a = max(ch0, c0) - c0, b = max(ch1, c0) - c0;  // ... and in source 1
+    const double2* p = reinterpret_cast<const double2*>(st1 + ((size_t)ni * c1 + a) * t1 * 2);
+    for (int i = lane; i < (b - a) * t1; i += 64) {
+      const double2 v = p[i];
+      s += v.x;
+      ss += v.y;
     }
   }
 #pragma unroll
