@@ -779,6 +779,8 @@ static int g_h2_stats = 1;  // epilogue GroupNorm statistics (tuning key 5: A/B 
 static int g_h2_bm32 = 0;      // 32-cout x 8-row workgroups, two per CU, for the shallow levels (tuning key 16; measured
                                // slower than the 64 x 16 geometry: 0.356 vs 0.302 ms at 64 channels / 256^2 -- off)
 static int g_h2_bm32_min = 512;  // ... when the 64-cout x 16-row grid has at least this many workgroups
+static int g_h2_bm32_small = 1;  // 32-cout workgroups for grids of at most half the CUs (tuning key 17)
+constexpr int H2_CUS = 256;
 static int g_h2_s2 = 1;  // stride-2 convs on the split path (tuning key 15: A/B against the f32 MFMA kernel)
 static int g_h2_pw_occ2 = 1;  // pointwise convs: 8-row tiles compiled for two workgroups per CU (tuning key 11)
 static int g_h2_rows = 0;  // rows per wave: 0 = by grid size, 2 | 4 forced (tuning key 3)
@@ -932,8 +934,11 @@ int conv_h2_launch(const dsg_conv_args* a, int hout, int wout, hipStream_t st) {
     else if (lay == 2) rc = h2_launch<0, 2, 1, ACT, 4, 2, 2>(grid, lds, st, p);     \
     else rc = h2_launch<0, 2, 1, ACT, 4, 2, 3>(grid, lds, st, p);                   \
   } while (0)
-  const bool bm32 = g_h2_bm32 && lay == 3 && !fold && !s2 && !k1 && !a->upsample && p.cin <= 128 && wout % H2_TW == 0 &&
-                    (int)grid.x >= g_h2_bm32_min;
+  // 32-cout workgroups: (a) optional, two per CU on the shallow levels (cin <= 128: LDS); (b) small batches: when
+  // even the 8-row x 64-cout grid leaves more than half of the CUs idle, halve the cout tile to double the grid
+  const bool bm32_ok = lay == 3 && !fold && !s2 && !k1 && !a->upsample && wout % H2_TW == 0;
+  const bool bm32 = bm32_ok && ((g_h2_bm32 && p.cin <= 128 && (int)grid.x >= g_h2_bm32_min) ||
+                                (g_h2_bm32_small && !nt4 && (int)grid.x <= H2_CUS / 2));
   if (s2) {
     DSG_H2_LAUNCH_BLK(3, 3, 0);
   } else if (fold) {
@@ -979,6 +984,7 @@ void conv_h2_set_fold(int on) { g_h2_fold = on; }
 void conv_h2_set_waves(int w) { g_h2_waves = w; }
 void conv_h2_set_pw_occ2(int v) { g_h2_pw_occ2 = v; }
 void conv_h2_set_s2(int v) { g_h2_s2 = v; }
+void conv_h2_set_bm32_small(int v) { g_h2_bm32_small = v; }
 void conv_h2_set_bm32(int v) { g_h2_bm32 = v != 0; if (v > 1) g_h2_bm32_min = v; }
 
 }  // namespace dsg

@@ -360,6 +360,8 @@ int dsg_prof_dump(const char* csv_path);
  *  11  pointwise split convs as 8-row tiles, two workgroups per CU: [1] | 0 = the 3x3 kernel's geometry
  *  13  dsg_unet_forward keeps its intermediate activations channel-blocked [N,C/8,H,W,8]: [1] | 0 = [N,C,H,W]
  *      (query dsg_unet_workspace_bytes again after changing it)
+ *  17  blocked 3x3 convs whose 8-row x 64-cout grid covers at most half the CUs (small batches) as 32-cout
+ *      workgroups: [1] | 0
  *  16  blocked 3x3 convs with cin <= 128 as 32-cout x 8-row workgroups, two per CU: [0] | 1 | n > 1 = when the
  *      64-cout x 16-row grid has at least n workgroups (1 = 512); bit-identical results, measured slower
  *  15  stride-2 convs of channel-blocked tensors on the split path: [1] | 0 = the f32 MFMA kernel
