@@ -34,14 +34,14 @@ PEAK_HBM_GBS = 8000.0
 
 
 def _cfg():
-    from tests.common import CFG2
+    from drivescenegen_amd.configs import CFG2
     return CFG2
 
 
 def gpu_leg(args, rank, world):
     import drivescenegen_amd as d
     from drivescenegen_amd import _lib, synth
-    from tests.common import synth_weights
+    from drivescenegen_amd.configs import synth_weights
 
     cfg = _cfg()
     dev = torch.device("cuda", int(os.environ.get("LOCAL_RANK", 0)))
@@ -118,7 +118,7 @@ def cpu_leg(args):
     from oracle.scheduler_oracle import OracleDDIMScheduler
     from oracle.unet_oracle import OracleUNet2DModel
     from drivescenegen_amd import synth
-    from tests.common import synth_weights
+    from drivescenegen_amd.configs import synth_weights
 
     cores = max(1, min(os.cpu_count() or 1, args.cpu_threads))
     torch.set_num_threads(cores)
@@ -237,7 +237,6 @@ def main():
                             avg_launch_ms=dom["avg_ms"], launches=dom["launches"],
                             alg_flops_per_launch=dom["flops_per_launch"],
                             time_share=dom["total_ms"] * 1e-3 / dt)
-        from tests.common import CFG2  # noqa: F401
         flops_img = 352.98e9  # SURVEY 8d, cfg2 forward
         out = {
             "metric": "denoising-steps/sec (U-Net fwd) on 256x256 BEV rasters", "value": value,

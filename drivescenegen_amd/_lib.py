@@ -44,6 +44,7 @@ class ConvArgs(C.Structure):
         ("stats_out", C.c_void_p),
         ("src_layout", C.c_int32), ("dst_layout", C.c_int32),
         ("weight_h2_s2", C.c_void_p),
+        ("compute_dtype", C.c_int32),
     ]
 
 
@@ -70,15 +71,26 @@ class UNetConfig(C.Structure):
         ("block_out_channels", C.c_int32 * 8), ("down_attn", C.c_int32 * 8), ("up_attn", C.c_int32 * 8),
         ("norm_num_groups", C.c_int32), ("norm_eps", C.c_float),
         ("attention_head_dim", C.c_int32), ("add_attention", C.c_int32),
+        ("compute_dtype", C.c_int32),
     ]
 
 
 _vp, _i32, _i64, _f32, _sz, _f64 = C.c_void_p, C.c_int32, C.c_int64, C.c_float, C.c_size_t, C.c_double
 
+# dsg_dtype (include/dsg.h): arithmetic type of the matrix-core products / storage type of channel-blocked tensors
+DSG_F32, DSG_BF16, DSG_F16 = 0, 1, 2
+DTYPE_CODES = {"fp32": DSG_F32, "bf16": DSG_BF16, "fp16": DSG_F16}
+TORCH_DTYPES = {DSG_F32: torch.float32, DSG_BF16: torch.bfloat16, DSG_F16: torch.float16}
+
 # name -> argtypes; every function returns int32 status unless noted.  This table is the single
 # Python-side statement of the ABI; tests/test_abi.py checks it against include/dsg.h.
 SIGNATURES = {
     "dsg_conv2d_stats_tiles": [_vp, _vp],
+    "dsg_conv_weight_pack": [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp],
+    "dsg_conv_weight_pack_bytes": [_i32, _i32, _i32, _i32, _i32, _i32, C.POINTER(_sz)],
+    "dsg_layout_convert_dt": [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp],
+    "dsg_gn_channel_stats_blocked_dt": [_vp, _i32, _i32, _i32, _i32, _vp, _i32, _vp],
+    "dsg_unscale_check": [_vp, _i64, _f32, _vp, _vp],
     "dsg_conv_weight_relayout_h2_fold": [_vp, _vp, _i32, _i32, _vp],
     "dsg_conv_weight_relayout_h2_s2": [_vp, _vp, _i32, _i32, _vp],
     "dsg_upsample_nearest2x": [_vp, _vp, _i64, _i32, _i32, _vp],

@@ -19,7 +19,8 @@ import torch
 from . import ops
 
 
-SLABS = {}  # storage data_ptr -> flat gradient slab (lets the optimizer / clipper recognise slab-backed grads)
+SLABS = {}  # storage data_ptr -> (flat gradient slab, number of parameter slices): lets the optimizer / clipper
+            # recognise slab-backed gradients and tell the whole parameter set from a subset
 
 
 class TrainState:
@@ -37,7 +38,7 @@ class TrainState:
             off += (n + 63) // 64 * 64  # 256-B aligned slices
         self.total = off
         self.grad_flat = torch.zeros(off, dtype=torch.float32, device=dev)
-        SLABS[self.grad_flat.untyped_storage().data_ptr()] = self.grad_flat
+        SLABS[self.grad_flat.untyped_storage().data_ptr()] = (self.grad_flat, len(self.items))
         self.params = dict(self.items)
         self.wf, self.wd, self.versions = {}, {}, {}
         self.wh, self.whd = {}, {}  # fp16x2-split copies (forward / data-gradient) of the eligible 3x3 weights

@@ -14,7 +14,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
 SOURCES = ["common.hip", "conv.hip", "groupnorm.hip", "attention.hip", "temb.hip", "scheduler.hip", "unet.hip", "prof.hip",
-           "conv_bwd.hip", "train_ops.hip", "conv_h2.hip", "imageops.hip", "raster.hip"]
+           "conv_bwd.hip", "train_ops.hip", "conv_h2.hip", "conv_h2_bf16.hip", "conv_h2_f16.hip", "imageops.hip", "raster.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fvisibility=hidden", "-Wall", "-Wno-unused-function"]
 # scheduler.hip must round every fp32 operation individually (bit parity with the reference's torch-CPU
 # expressions); the in-source pragma alone does not stop the backend from forming v_pk_fma_f32.
@@ -30,7 +30,7 @@ def build(force=False, verbose=True):
     bdir = os.path.join(HERE, "build")
     os.makedirs(bdir, exist_ok=True)
     os.makedirs(os.path.dirname(LIB), exist_ok=True)
-    hdrs = [os.path.join(HERE, "dsg_common.h"), os.path.join(ROOT, "..", "include", "dsg.h")]
+    hdrs = [os.path.join(HERE, h) for h in os.listdir(HERE) if h.endswith(".h")] + [os.path.join(ROOT, "..", "include", "dsg.h")]
     jobs = []
     for s in SOURCES:
         src = os.path.join(HERE, s)

@@ -23,7 +23,7 @@
 // into padded LDS slabs) so it stays ONE basic block and the scheduler runs ds_reads ahead of the MFMAs.
 // Epilogue: + bias (+ time-embedding column) (+ residual), 128-B row stores; optional 2x2 sum-pool
 // (the adjoint of the nearest-x2 upsample).
-#include "dsg_common.h"
+#include "dsg_h16.h"
 #include <algorithm>
 
 namespace dsg {
@@ -52,6 +52,7 @@ struct ConvP {
   int pool;  // 1: 2x2 sum-pool in the epilogue; dst is [N, cout, hout/2, wout/2]
   int tiles_x, tiles_y;
   int sblk, dblk;  // 1: sources / (dst, residual) are channel-blocked [N][C/8][H][W][8] (dsg_conv_args.*_layout)
+  int dt;          // dsg_dtype of the channel-blocked tensors: 0 fp32, 1 bf16, 2 fp16 ([N,C,H,W] tensors are always fp32)
 };
 
 constexpr int TH = 8;   // output rows per workgroup
@@ -73,8 +74,12 @@ __device__ __forceinline__ float silu_fast(float x) {
 
 // GM: gather mode 0 plain, 1 nearest x2 (source pixel [y>>1][x>>1]), 2 zero-stuffed x2 (source pixel
 // [y/2][x/2] at even (y, x), zero elsewhere)
-template <int KS, int STRIDE, int GM, int MT, int KC>
+// IO16: bit 0: the (channel-blocked) sources are 16-bit values of type p.dt; bit 1: dst / residual are.  The arithmetic
+// stays the exact fp32 MFMA chain: this is how conv_in (fp32 [N,C,H,W] image -> 16-bit blocked activations) and the
+// shapes the split kernels do not take run in the mixed-precision modes.
+template <int KS, int STRIDE, int GM, int MT, int KC, int IO16 = 0>
 __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(ConvP p) {
+  constexpr bool S16 = (IO16 & 1) != 0, D16 = (IO16 & 2) != 0;
   using G = ConvGeom<KS, STRIDE, KC>;
   constexpr int TAPS = G::TAPS, PW = G::PW, PSZ = G::PSZ, XN = G::XN;
   constexpr int BM = MT * 32;
@@ -155,14 +160,17 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(ConvP p) {
       c -= p.c0;
     }
     // blocked: channel c lives at offset c % 8 inside the block that starts where plane (c & ~7) would
-    return p.sblk ? sp + ((size_t)n * cs + (c & ~7)) * plane + (c & 7) : sp + ((size_t)n * cs + c) * plane;
+    // (16-bit sources: the returned pointer is used as an unsigned short*, so the element offset is the same)
+    const size_t eo = p.sblk ? ((size_t)n * cs + (c & ~7)) * plane + (c & 7) : ((size_t)n * cs + c) * plane;
+    return S16 ? reinterpret_cast<const float*>(reinterpret_cast<const unsigned short*>(sp) + eo) : sp + eo;
   };
   auto w_of = [&](int q) -> const float* { return p.w + (size_t)q * (KC * TAPS) * p.wstride + m0; };
   const int wrow_max = p.cin * TAPS - 1;
   // piece pc < NE: one patch element per thread; pc >= NE: one float4 of the weight slab
   auto load_piece = [&](int pc, int q, const float* sp, const float* wp) {
     if (pc < NE) {
-      xr[pc] = sp[goff[pc]];
+      if constexpr (S16) xr[pc] = ld16(reinterpret_cast<const unsigned short*>(sp) + goff[pc], p.dt);
+      else xr[pc] = sp[goff[pc]];
     } else {
       const int i = pc - NE;
       const int idx = min(tid + 256 * i, WN4 - 1);
@@ -284,7 +292,10 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(ConvP p) {
 #pragma unroll
         for (int nt = 0; nt < 2; ++nt) {
           const int y = oy0 + wave * 2 + nt;
-          rv[mt][r][nt] = has_r ? p.res[oidx(co, y, min(x, p.wout - 1))] : 0.f;
+          if constexpr (D16)
+            rv[mt][r][nt] = has_r ? ld16(reinterpret_cast<const unsigned short*>(p.res) + oidx(co, y, min(x, p.wout - 1)), p.dt) : 0.f;
+          else
+            rv[mt][r][nt] = has_r ? p.res[oidx(co, y, min(x, p.wout - 1))] : 0.f;
         }
       }
     if (p.dblk) {
@@ -311,7 +322,11 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(ConvP p) {
                 if (has_t) v[j] = v[j] + tv[j];
                 if (has_r) v[j] = v[j] + rv[mt][4 * rg + j][nt];
               }
-              *reinterpret_cast<float4*>(p.dst + oidx(co0, y, x)) = make_float4(v[0], v[1], v[2], v[3]);
+              if constexpr (D16)
+                *reinterpret_cast<uint2*>(reinterpret_cast<unsigned short*>(p.dst) + oidx(co0, y, x)) =
+                    make_uint2(word_pack(v[0], v[1], p.dt), word_pack(v[2], v[3], p.dt));
+              else
+                *reinterpret_cast<float4*>(p.dst + oidx(co0, y, x)) = make_float4(v[0], v[1], v[2], v[3]);
             }
           }
         }
@@ -455,14 +470,14 @@ void conv_h2_set_fold(int on);
 static int g_conv_fewout = 1;  // VALU kernel for cout <= 4 (tuning key 10: A/B against the zero-padded MFMA tile)
 static int g_conv_kc = 0;  // K-chunk of the 3x3 stride-1 kernel: 4 | 8 | 0 = by grid size (measured, r01)
 
-template <int KS, int STRIDE, int GM, int MT, int KC>
+template <int KS, int STRIDE, int GM, int MT, int KC, int IO16 = 0>
 static int launch_mfma(const ConvP& p, hipStream_t st) {
   using G = ConvGeom<KS, STRIDE, KC>;
   constexpr int NW = (KC * G::TAPS * MT * 32 / 4 + 255) / 256;
   constexpr int XSZ = (G::XN + 4 + 3) & ~3;
   const size_t lds = (size_t)(2 * (NW * 1024 + XSZ)) * sizeof(float);
   dim3 grid(p.tiles_x * p.tiles_y * p.n, (p.cout + MT * 32 - 1) / (MT * 32));
-  auto kern = conv_mfma_kernel<KS, STRIDE, GM, MT, KC>;
+  auto kern = conv_mfma_kernel<KS, STRIDE, GM, MT, KC, IO16>;
   static bool raised = false;
   if (!raised) {
     DSG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -527,7 +542,21 @@ __global__ __launch_bounds__(256, 2) void conv_fewout_kernel(ConvP p) {
   auto fetch = [&](int c0) {
     const float* spb = (c0 < p.c0) ? p.src0 + ((size_t)n * p.c0 + c0) * plane
                                    : p.src1 + ((size_t)n * p.c1 + (c0 - p.c0)) * plane;  // (uniform: c0 % 16 == 0)
-    if (p.sblk) {
+    if (p.sblk && p.dt) {
+      // 16-bit blocked sources (mixed-precision modes): a position's 8 channels are one 16-byte load
+      const unsigned short* sph = reinterpret_cast<const unsigned short*>((c0 < p.c0) ? p.src0 : p.src1) +
+                                  ((c0 < p.c0) ? ((size_t)n * p.c0 + c0) : ((size_t)n * p.c1 + (c0 - p.c0))) * plane;
+#pragma unroll
+      for (int b = 0; b < 2; ++b)
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+          const uint4 q = *reinterpret_cast<const uint4*>(sph + (size_t)b * 8 * plane + goff[k]);
+          xr[8 * b + 0][k] = word_lo(q.x, p.dt); xr[8 * b + 1][k] = word_hi(q.x, p.dt);
+          xr[8 * b + 2][k] = word_lo(q.y, p.dt); xr[8 * b + 3][k] = word_hi(q.y, p.dt);
+          xr[8 * b + 4][k] = word_lo(q.z, p.dt); xr[8 * b + 5][k] = word_hi(q.z, p.dt);
+          xr[8 * b + 6][k] = word_lo(q.w, p.dt); xr[8 * b + 7][k] = word_hi(q.w, p.dt);
+        }
+    } else if (p.sblk) {
       // blocked sources: the 16-channel chunk starts at the same address and is two channel blocks; a position's 8
       // channels are two 16-byte loads
 #pragma unroll
@@ -677,6 +706,11 @@ int conv2d_fwd_impl(const dsg_conv_args* a, hipStream_t st, int force_direct) {
   p.temb = a->temb; p.temb_stride = a->temb_stride; p.res = a->residual; p.dst = a->dst;
   p.pool = a->pool2;
   p.sblk = a->src_layout; p.dblk = a->dst_layout;
+  p.dt = a->compute_dtype;
+  DSG_CHECK_ARG(a->compute_dtype >= DSG_F32 && a->compute_dtype <= DSG_F16,
+                "dsg_conv2d_fwd: compute_dtype must be DSG_F32, DSG_BF16 or DSG_F16 (got %d)", a->compute_dtype);
+  // mixed-precision modes: the channel-blocked tensors are 16-bit, [N,C,H,W] tensors fp32
+  const int io16 = a->compute_dtype ? ((a->src_layout ? 1 : 0) | (a->dst_layout ? 2 : 0)) : 0;
   DSG_CHECK_ARG((a->src_layout | a->dst_layout) >= 0 && (a->src_layout | a->dst_layout) <= 1,
                 "dsg_conv2d_fwd: src_layout / dst_layout must be 0 or 1");
   DSG_CHECK_ARG(!a->src_layout || (a->c0 % 8 == 0 && a->c1 % 8 == 0),
@@ -698,6 +732,20 @@ int conv2d_fwd_impl(const dsg_conv_args* a, hipStream_t st, int force_direct) {
   if (!force_direct && g_conv_fewout && k == 3 && s == 1 && u == 0 && !p.pool && p.cout <= 4 && p.cin % FO_KC == 0 &&
       (p.c1 == 0 || p.c0 % FO_KC == 0) && p.wout % TW == 0 && p.hout % FO_TH == 0)
     return launch_fewout(p, st);  // conv_out: too few output channels for the matrix cores
+  if (io16 == 2 && !force_direct && tile_ok && k == 3 && s == 1 && u == 0 && !p.pool) {
+    // conv_in of the mixed-precision modes: fp32 [N,C,H,W] image -> 16-bit channel-blocked activations
+    const bool mt2 = (p.wstride % 64 == 0) && p.cout > 32;
+    const bool kc4 = p.cin <= 4 || !(p.c1 == 0 || p.c0 % 8 == 0);
+    if (kc4 && (p.c1 == 0 || p.c0 % 4 == 0))
+      return mt2 ? launch_mfma<3, 1, 0, 2, 4, 2>(p, st) : launch_mfma<3, 1, 0, 1, 4, 2>(p, st);
+    if (p.c1 == 0 || p.c0 % 8 == 0)
+      return mt2 ? launch_mfma<3, 1, 0, 2, 8, 2>(p, st) : launch_mfma<3, 1, 0, 1, 8, 2>(p, st);
+  }
+  DSG_CHECK_SHAPE(io16 == 0,
+                  "dsg_conv2d_fwd: no %s kernel serves this call with channel-blocked tensors (k %d, stride %d, "
+                  "upsample %d, cin %d, cout %d, %dx%d); the 16-bit modes take the shapes of dsg_conv2d_fwd's "
+                  "matrix-core path, conv_in and conv_out only", a->compute_dtype == DSG_BF16 ? "bf16" : "fp16", k, s, u,
+                  p.cin, p.cout, p.hout, p.wout);
   if (!force_direct && tile_ok) {
     const bool mt2 = (p.wstride % 64 == 0) && p.cout > 32;
     const bool dual_ok4 = p.c1 == 0 || p.c0 % 4 == 0;

@@ -1,0 +1,815 @@
+// 3x3 stride-1 convolution with fp32-equivalent accuracy on the fp16 matrix cores ("fp16x2 split").
+//
+// Same contract, tiling and fusions as conv.hip's conv_mfma_kernel (reference call sites: every 3x3
+// Conv2d of diffusers' UNet2DModel as built at DriveSceneGen/scripts/train.py:39-57 and run at
+// DriveSceneGen/pipeline/training_pipeline.py:84), but the contraction runs at the 16x-faster f16 MFMA
+// rate without giving up fp32 accuracy:
+//
+//   x = x1 + x2 * 2^-11,  x1 = fp16(x),  x2 = fp16((x - x1) * 2^11)      (|x - x1 - x2*2^-11| <= 2^-24 |x|)
+//   w = w1 + w2 * 2^-11   likewise (split once, at weight re-layout time)
+//   sum w*x  ~=  sum w1*x1  +  2^-11 * sum (w1*x2 + w2*x1)              (dropped w2*x2 term: 2^-24 relative)
+//
+// i.e. 3 v_mfma_f32_32x32x16_f16 per 16-deep k-step instead of 8 v_mfma_f32_32x32x2_f32: 5.3x fewer matrix
+// cycles.  fp16 x fp16 products are exact in the fp32 accumulator; the scaled low-order products go to a
+// second accumulator so that nothing is lost to fp16's narrow exponent (the 2^11 pre-scale keeps the low
+// parts normal).  Measured error vs fp64 is at or below that of a sequential fp32 fmaf chain
+// (tests/test_gpu_ops.py::test_conv_h2_*).  Inputs must satisfy |x| < 65504 (GroupNorm/SiLU outputs and
+// residual-stream activations do).
+//
+// LDS images (per K-chunk of 16 channels, double-buffered; same bytes as the fp32 kernel's):
+//   X[piece 2][g 2][pos 10x34][8 halfs]   -- lane = pixel reads one 16-B fragment (k-group g = lane>>5)
+//   W[piece 2][tap 9][g 2][cout 64][8]    -- lane = cout  reads one 16-B fragment; filled by LDS-DMA
+//                                            (global_load_lds_dwordx4: the pre-split weights need no math)
+// A and B use the same (g, j) <-> channel 8g+j map, so the MFMA's internal k order is irrelevant.
+#pragma once
+#include "dsg_h16.h"
+#include <algorithm>
+#include <type_traits>
+
+namespace dsg {
+
+bool prof_on();
+int prof_begin(int kid, double flops, double bytes, hipStream_t st);
+void prof_end(int idx, hipStream_t st);
+
+struct ConvH2P {
+  const void* src0;  // fp32, or the 16-bit type of PREC when channel-blocked (see dsg_h16.h)
+  const void* src1;
+  int c0, c1, cin;
+  int n, hin, win;
+  int hc, wc;
+  int hout, wout;
+  int cout, cout_pad;
+  int wh_stride;       // couts per weight row (>= cout_pad when `wh` is a column window of a wider matrix)
+  const void* wh;      // [cin/16][pieces][9][2][wh_stride][8] 16-bit values; pieces = 2 (hi, scaled lo) for PREC 0, else 1
+  const float* bias;
+  const float* ss;
+  int silu;
+  const float* temb;
+  int temb_stride;
+  const void* res;
+  void* dst;
+  double* stats;  // optional [n][cout][hout/8 * wout/32][2]: per-tile (sum, sum of squares) of the values written
+  int tiles_x, tiles_y;
+};
+
+constexpr int H2_TW = 32, H2_KC = 16, H2_BM = 64;
+
+// NT = output rows per wave (2 or 4): a workgroup covers 4*NT rows x 32 cols.  NT = 4 halves the LDS operand
+// traffic per MFMA (each weight fragment feeds 4 pixel tiles) and the weight DMA per MFMA; it needs 256
+// accumulator registers (the kernel owns the SIMD: 1 wave, 512 registers).
+// KS = 3 (halo of 1) or 1 (no halo; attention projections and resnet shortcuts)
+// NW = waves per workgroup (4: one per SIMD with the whole register file; 8: two per SIMD with half of it each,
+// so that one wave's staging / LDS / wait time is covered by the other's MFMAs)
+template <int NT, int KS, int NW = 4, int TAPS_ = KS * KS, int BM_ = 64, int NP_ = 2>
+struct H2Geom {
+  static constexpr int NP = NP_;                      // operand pieces: 2 (hi + scaled lo, fp16x2 split) or 1 (bf16 / fp16)
+  static constexpr int BM = BM_;                      // output channels per workgroup: 64, or 32 (two workgroups per CU)
+  static constexpr int NTH = 64 * NW;
+  static constexpr int TAPS = TAPS_;                  // 4 in the folded up-sampler mode (2x2 taps of the 3x3 patch)
+  static constexpr int TH = NW * NT;
+  static constexpr int PH = TH + KS - 1;
+  static constexpr int PW = H2_TW + KS - 1;
+  static constexpr int PSZ = PW * PH;                 // KS=3: 340 (NT=2) / 612 (NT=4); KS=1: 256 / 512
+  static constexpr int WHALFS = NP * TAPS * 2 * BM * 8;  // [piece][tap][g][cout][8]: 36864 B / 4096 B at BM = 64, NP = 2
+  static constexpr int XHALFS = NP * 2 * PSZ * 8;     // [piece][g][pos][8]
+  static constexpr int BUF_BYTES = (WHALFS + XHALFS) * 2 + 64;  // + a dump slot for masked lanes
+  static constexpr int FULL = PSZ / NTH;              // full NTH-position slabs per k-group
+  static constexpr bool HAS_REM = (PSZ % NTH) != 0;   // KS=3 leaves a remainder slab shared by the two k-groups
+  static constexpr int NU = 2 * FULL + (HAS_REM ? 1 : 0);  // staging units per thread
+  static constexpr int REM0 = FULL * NTH;             // first position of the remainder unit
+  static constexpr int NSEG = 2 * NP * TAPS;          // (piece, tap, g) weight segments per chunk, BM x 16 bytes each
+  static constexpr int NUNIT = NSEG * BM / 64;        // 1-KB DMA units per chunk (a unit = 64 / BM segments)
+  static constexpr int NDMA = (NUNIT + NW - 1) / NW;  // weight DMAs per wave per chunk
+  static_assert(PSZ - REM0 <= NTH / 2, "the remainder slab must fit half the workgroup per k-group");
+};
+
+// x + (x of the lane selected by a DPP control): the building block of a fixed-order 32-lane tree sum
+template <int CTRL, int ROW_MASK = 0xF>
+__device__ __forceinline__ float dpp_add(float x) {
+  const int y = __builtin_amdgcn_update_dpp(0, __float_as_int(x), CTRL, ROW_MASK, 0xF, true);
+  return x + __int_as_float(y);
+}
+// after this, lanes 16..31 hold the sum over lanes 0..31 and lanes 48..63 the sum over lanes 32..63
+__device__ __forceinline__ float half_wave_sum(float x) {
+  x = dpp_add<0xB1>(x);        // quad_perm [1,0,3,2]
+  x = dpp_add<0x4E>(x);        // quad_perm [2,3,0,1]
+  x = dpp_add<0x141>(x);       // row_half_mirror
+  x = dpp_add<0x140>(x);       // row_mirror: every lane of a 16-row holds the row sum
+  x = dpp_add<0x142, 0xA>(x);  // row_bcast15 into rows 1 and 3
+  return x;
+}
+
+__device__ __forceinline__ float silu_fast_h(float x) { return x * __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
+
+// GM: 3 STRIDE-2 3x3 conv (Downsample2D) as a 2x2 conv over the space-to-depth image, which for channel-blocked
+// sources is pure addressing: k-group (cb, py, px) of the 4C "channels" is channel block cb read at pixels
+// (2y + py, 2x + px); output row oy needs input rows 2oy-1 (y' = oy-1, py = 1), 2oy (oy, 0), 2oy+1 (oy, 1), i.e. the
+// 2x2 corner {y'-1, y'} x {x'-1, x'} of the low-resolution patch with zero weights where no 3x3 tap lands (7 of the
+// 16 (tap, phase) pairs): 16/9 of the useful products, on the pipe that is 5x faster than the f32 one.
+// GM: 0 plain, 1 nearest x2 gather, 2 nearest x2 FOLDED into the weights: Upsample2D + 3x3 conv is four 2x2 convs of
+// the low-resolution input, one per output phase (py, px) = (Y & 1, X & 1): rows {y-1: W0, y: W1+W2} for py = 0 and
+// {y: W0+W1, y+1: W2} for py = 1, likewise in x -- 16 tap products per input pixel instead of 36.  The kernel runs on
+// the low-resolution grid with the phase as an extra (outer) cout-tile index, walks the phase's 2x2 corner of the 3x3
+// patch and scatters its results to the (2y+py, 2x+px) pixels.
+// NT: rows per wave; KS: 3 | 1.
+// Staging units are arranged so that the k-group g (hence the channel plane and the GroupNorm scale/shift) of
+// every unit is WAVE-UNIFORM: channel-plane bases and scale/shift live in SGPRs (s_load / saddr-form global
+// loads), and the only per-lane address is the 32-bit halo offset computed once per tile.
+//   units 0..FULL-1: g = 0, halo positions tid + 256*i      units FULL..2*FULL-1: g = 1, same positions
+//   last unit: g = wave >> 1, halo position FULL*256 + (tid & 127)   (the remainder, valid where < PSZ)
+// ACT: 0 the input is used as it is; 2 GroupNorm affine + SiLU; 3 decided at run time from p.ss / p.silu
+// OCC: workgroups the kernel is compiled to fit per CU (register budget 512 / (OCC * NW / 4) per lane)
+// LAY: bit 0: the sources are channel-blocked [N][C/8][H][W][8] (a halo position's k-group is 32 contiguous bytes:
+//      two 16-byte loads instead of eight dword gathers from eight channel planes); bit 1: dst / residual are
+//      (a lane's four consecutive output channels are one 16-byte store; a wave instruction writes 1 KB contiguous)
+// BM: output channels per workgroup.  32 (with NT = 2, OCC = 2) is the small-workgroup geometry for the shallow levels:
+//     80 KB of LDS and half the register file, so two workgroups share a CU and one's patch loads and output stores
+//     run under the other's MFMAs (a workgroup that owns the CU runs those phases back to back).
+// PREC: 0 fp32 tensors, fp16x2-split products; 1 bf16 / 2 fp16: channel-blocked tensors are 16-bit in HBM, one MFMA per
+//       product, fp32 accumulate, GroupNorm affine + SiLU in fp32 before the operand is rounded ([N,C,H,W] tensors stay fp32)
+template <int GM, int NT, int KS, int ACT = 3, int NW = 4, int OCC = 1, int LAY = 0, int BM = 64, int PREC = 0>
+__global__ __launch_bounds__(64 * NW, OCC * NW / 4) void conv_h2_kernel(ConvH2P p) {
+  constexpr bool SB = (LAY & 1) != 0, DB = (LAY & 2) != 0;
+  constexpr int NP = PREC ? 1 : 2;              // operand pieces
+  constexpr bool S16 = PREC != 0 && SB;         // 16-bit sources (8 channels of a pixel = one 16-byte load)
+  constexpr int ESS = S16 ? 2 : 4;              // bytes per source element
+  constexpr int ESD = (PREC != 0 && DB) ? 2 : 4;  // bytes per dst / residual element
+  constexpr int MTN = BM / 32;  // 32-channel MFMA tiles per workgroup
+  using G = H2Geom<NT, KS, NW, (GM == 2 || GM == 3) ? 4 : KS * KS, BM, NP>;
+  constexpr int NTH = G::NTH;
+  constexpr int H2_TH = G::TH, H2_PSZ = G::PSZ, H2_XHALFS = G::XHALFS, H2_BUF_BYTES = G::BUF_BYTES, H2_NU = G::NU;
+  constexpr int FULL = G::FULL, TAPS = G::TAPS, H2_PW = G::PW, H2_WHALFS = G::WHALFS, PADK = KS / 2;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+#ifdef DSG_H2_TIMING
+  const unsigned long long rt_entry = __builtin_amdgcn_s_memrealtime();
+#endif
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int half = lane >> 5;
+  const int l31 = lane & 31;
+
+  // Workgroup id -> (spatial tile, cout tile).  Consecutive ids go to the 8 XCDs in turn, each with its own L2.
+  // XCD k gets a CONTIGUOUS eighth of the spatial tiles, walked in raster order with the cout tiles of one patch
+  // on neighbouring ids: workgroups that share input -- the same patch for another cout tile, or the 128-byte
+  // lines and halo rows a patch has in common with its left/right/upper/lower neighbours -- run at the same time
+  // behind the same L2, so that data comes from HBM once instead of once per XCD.
+  const int nct = (p.cout_pad / BM) * (GM == 2 ? 4 : 1), nsp = p.tiles_x * p.tiles_y * p.n;
+  int bid, ct;
+  if ((nsp & 7) == 0) {
+    const int grp = blockIdx.x >> 3;
+    ct = grp % nct;
+    bid = (blockIdx.x & 7) * (nsp >> 3) + grp / nct;
+  } else {
+    ct = blockIdx.x % nct;
+    bid = blockIdx.x / nct;
+  }
+  const int tx = bid % p.tiles_x;
+  bid /= p.tiles_x;
+  const int ty = bid % p.tiles_y;
+  const int n = bid / p.tiles_y;
+  const int phase = GM == 2 ? ct / (p.cout_pad / BM) : 0;  // (py, px) = (phase >> 1, phase & 1)
+  if (GM == 2) ct -= phase * (p.cout_pad / BM);
+  const int m0 = ct * BM;
+  const int oy0 = ty * H2_TH, ox0 = tx * H2_TW;
+  const int plane = p.hin * p.win;
+  const int nq = p.cin / H2_KC;
+  const int g2 = wave / (NW / 2);  // k-group of the remainder unit (uniform per wave)
+
+  // Per staging unit: global halo offset, and the LDS slots of its pieces.  Positions outside the image (zero
+  // padding) or past the patch write to a dump slot instead; the real slots of padding positions are zeroed once.
+  int goff[H2_NU], xoff[H2_NU], xoff2[H2_NU], zoff[H2_NU];
+#pragma unroll
+  for (int i = 0; i < H2_NU; ++i) {
+    const int g = i < FULL ? 0 : (i < 2 * FULL ? 1 : g2);
+    const int pos = i < 2 * FULL ? tid + NTH * (i % FULL) : G::REM0 + (tid & (NTH / 2 - 1));
+    int off = 0, xo = H2_WHALFS + H2_XHALFS, xo2 = H2_WHALFS + H2_XHALFS, zo = -1;
+    if (pos < H2_PSZ) {
+      const int py = pos / H2_PW, px = pos - py * H2_PW;
+      const int gy = oy0 - PADK + py, gx = ox0 - PADK + px;
+      const int slot = H2_WHALFS + (g * H2_PSZ + pos) * 8;  // piece 0; piece 1 is 2*PSZ*8 halfs further
+      if (gy >= 0 && gy < p.hc && gx >= 0 && gx < p.wc) {
+        off = GM == 3 ? (2 * gy) * p.win + 2 * gx : (GM == 1 ? (gy >> 1) : gy) * p.win + (GM == 1 ? (gx >> 1) : gx);
+        xo = slot;
+        xo2 = NP == 2 ? slot + 2 * H2_PSZ * 8 : slot;
+      } else {
+        zo = slot;
+      }
+    }
+    goff[i] = off;
+    xoff[i] = xo;
+    xoff2[i] = xo2;
+    zoff[i] = zo;
+  }
+  const bool has_ss = ACT == 3 ? p.ss != nullptr : ACT != 0;
+  const bool do_silu = ACT == 3 ? (has_ss && p.silu) : ACT == 2;
+  const float* ssg = has_ss ? p.ss + (size_t)n * p.cin * 2 : nullptr;
+
+  // raw patch values of one K-chunk: fp32 (8 registers per unit), or the 8 16-bit channels of a pixel as loaded (4)
+  struct Patch {
+    float f[S16 ? 1 : H2_NU][8];
+    unsigned q[S16 ? H2_NU : 1][4];
+  };
+  Patch xr;
+  // GroupNorm (scale, shift) of this image's channels: copied once into LDS behind the two K-chunk buffers; a commit
+  // reads its 8 channels from there (uniform address: a broadcast read) instead of carrying them in registers
+  float* ssl = reinterpret_cast<float*>(smem_raw + 2 * H2_BUF_BYTES);
+
+  const char* src0b = static_cast<const char*>(p.src0);
+  const char* src1b = static_cast<const char*>(p.src1);
+  auto src_of = [&](int q) -> const char* {  // uniform
+    const int cb = q * H2_KC;
+    return (cb < p.c0) ? src0b + ((size_t)n * p.c0 + cb) * plane * ESS
+                       : src1b + ((size_t)n * p.c1 + (cb - p.c0)) * plane * ESS;
+  };
+  auto unit_g = [&](int i) -> int { return i < FULL ? 0 : (i < 2 * FULL ? 1 : g2); };
+  // patch loads are buffer loads: descriptor = the chunk's 16 channel planes (uniform), soffset = the channel
+  // plane (uniform), voffset = the lane's halo offset (fixed for the whole tile) -- no per-load address math
+  int soff[8];  // byte offsets of the 8 channel planes of a k-group: loop-invariant SGPRs
+#pragma unroll
+  for (int j = 0; j < 8; ++j) soff[j] = __builtin_amdgcn_readfirstlane(j * plane * 4);
+  // descriptor of k-group g of chunk q: its 8 channel planes / its channel block (uniform)
+  auto grp_rs = [&](const char* sp, int q, int g) -> __amdgpu_buffer_rsrc_t {
+    if constexpr (GM == 3) {  // group (cb, py, px) of the space-to-depth image: block cb, first pixel (py, px)
+      const int gi = 2 * q + g, cb = gi >> 2, pp = gi & 3;
+      const int first = ((pp >> 1) * p.win + (pp & 1)) * 8;
+      return __builtin_amdgcn_make_buffer_rsrc(
+          const_cast<char*>(src0b + (((size_t)n * p.c0 + cb * 8) * plane + first) * ESS), 0, (8 * plane - first) * ESS,
+          0x00020000);
+    } else {
+      return __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(sp + (size_t)(g * 8) * plane * ESS), 0,
+                                               8 * plane * ESS, 0x00020000);
+    }
+  };
+  auto load_unit_to = [&](Patch& dst, int i, const char* sp, int q) {
+    const __amdgpu_buffer_rsrc_t rs = grp_rs(sp, q, unit_g(i));
+    if constexpr (S16) {  // the pixel's 8 channels are 16 contiguous bytes
+      typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+      const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rs, goff[i] * 16, 0, 0);
+      dst.q[i][0] = v.x; dst.q[i][1] = v.y; dst.q[i][2] = v.z; dst.q[i][3] = v.w;
+    } else if constexpr (SB) {  // (the k-group's 8 planes and its channel block start at the same address)
+      const float4 lo = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rs, goff[i] * 32, 0, 0));
+      const float4 hi = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rs, goff[i] * 32, 16, 0));
+      dst.f[i][0] = lo.x; dst.f[i][1] = lo.y; dst.f[i][2] = lo.z; dst.f[i][3] = lo.w;
+      dst.f[i][4] = hi.x; dst.f[i][5] = hi.y; dst.f[i][6] = hi.z; dst.f[i][7] = hi.w;
+    } else {
+#pragma unroll
+      for (int j = 0; j < 8; ++j)
+        dst.f[i][j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, goff[i] * 4, soff[j], 0));
+    }
+  };
+  auto load_unit = [&](int i, int q, const char* sp) { load_unit_to(xr, i, sp, q); };
+  // channels (2 jp, 2 jp + 1) of unit i as fp32
+  auto pair_of = [&](const Patch& src, int i, int jp, float& a, float& b) {
+    if constexpr (S16) {
+      a = lo16<PREC>(src.q[i][jp]);
+      b = hi16<PREC>(src.q[i][jp]);
+    } else {
+      a = src.f[i][2 * jp];
+      b = src.f[i][2 * jp + 1];
+    }
+  };
+  // the pair after GroupNorm affine (sc0, sc1, sh0, sh1) + SiLU -> operand words: (hi, scaled lo) fp16 pairs of the
+  // split, or one rounded pair in the 16-bit type
+  auto to_operand = [&](float a, float b, const float4& s4, unsigned& w1, unsigned& w2) {
+    if (has_ss) {
+      a = a * s4.x + s4.z;
+      b = b * s4.y + s4.w;
+    }
+    const float sa = silu_fast_h(a), sb = silu_fast_h(b);
+    a = do_silu ? sa : a;
+    b = do_silu ? sb : b;
+    if constexpr (PREC == 0) {
+      const _Float16 a1 = (_Float16)a, b1 = (_Float16)b;
+      const half2v h = {a1, b1};
+      const half2v l = {(_Float16)((a - (float)a1) * 2048.0f), (_Float16)((b - (float)b1) * 2048.0f)};
+      w1 = __builtin_bit_cast(unsigned, h);
+      w2 = __builtin_bit_cast(unsigned, l);
+    } else {
+      w1 = pack2<PREC>(a, b);
+      w2 = 0;
+    }
+  };
+  typedef unsigned st_u32x4 __attribute__((ext_vector_type(4)));
+  auto commit_unit_from = [&](const Patch& src, int i, int q, unsigned char* buf) {  // q: chunk staged
+    unsigned w1[4], w2[4];
+    float4 sr[4];
+    if (has_ss) {
+      const float4* ssq = reinterpret_cast<const float4*>(ssl + 2 * (q * H2_KC + unit_g(i) * 8));
+#pragma unroll
+      for (int j = 0; j < 4; ++j) sr[j] = ssq[j];
+    }
+#pragma unroll
+    for (int jp = 0; jp < 4; ++jp) {
+      float a, b;
+      pair_of(src, i, jp, a, b);
+      to_operand(a, b, sr[jp], w1[jp], w2[jp]);
+    }
+    // (branch-free: a branch here would fence the instruction scheduler between staging and MFMAs)
+    _Float16* xb = reinterpret_cast<_Float16*>(buf);
+    *reinterpret_cast<st_u32x4*>(xb + xoff[i]) = st_u32x4{w1[0], w1[1], w1[2], w1[3]};
+    if constexpr (NP == 2) *reinterpret_cast<st_u32x4*>(xb + xoff2[i]) = st_u32x4{w2[0], w2[1], w2[2], w2[3]};
+  };
+  // The same work in quarter-unit steps, so that a K-chunk's staging can be dealt out evenly over its taps: step P
+  // turns two channels (2jp, 2jp+1) of unit P/4 into operand words -- the unit's LDS write rides on its last step --
+  // and refills the registers just freed with chunk q+2's values.
+  unsigned w1s[H2_NU][4], w2s[H2_NU][4];
+  auto stage_step = [&](int P, int qs, unsigned char* buf, bool stage, bool load, const char* spn) {  // (loads: chunk qs + 1)
+    const int i = P / 4, jp = P % 4;
+    if (stage) {
+      float4 s4 = make_float4(1.f, 1.f, 0.f, 0.f);
+      if (has_ss) s4 = *reinterpret_cast<const float4*>(ssl + 2 * (qs * H2_KC + unit_g(i) * 8 + 2 * jp));
+      float a, b;
+      pair_of(xr, i, jp, a, b);
+      to_operand(a, b, s4, w1s[i][jp], w2s[i][jp]);
+      if (jp == 3) {
+        _Float16* xb = reinterpret_cast<_Float16*>(buf);
+        *reinterpret_cast<st_u32x4*>(xb + xoff[i]) = st_u32x4{w1s[i][0], w1s[i][1], w1s[i][2], w1s[i][3]};
+        if constexpr (NP == 2)
+          *reinterpret_cast<st_u32x4*>(xb + xoff2[i]) = st_u32x4{w2s[i][0], w2s[i][1], w2s[i][2], w2s[i][3]};
+      }
+    }
+    if (load) {
+      const __amdgpu_buffer_rsrc_t rs = grp_rs(spn, qs + 1, unit_g(i));
+      if constexpr (S16) {  // the unit's four words are free after its last step: one 16-byte load refills them
+        if (jp == 3) {
+          typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+          const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rs, goff[i] * 16, 0, 0);
+          xr.q[i][0] = v.x; xr.q[i][1] = v.y; xr.q[i][2] = v.z; xr.q[i][3] = v.w;
+        }
+      } else if constexpr (SB) {  // four channels are free after every second step: one 16-byte load refills them
+        if (jp & 1) {
+          const float4 v4 =
+              __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rs, goff[i] * 32, 8 * (jp - 1), 0));
+          xr.f[i][2 * jp - 2] = v4.x; xr.f[i][2 * jp - 1] = v4.y; xr.f[i][2 * jp] = v4.z; xr.f[i][2 * jp + 1] = v4.w;
+        }
+      } else {
+#pragma unroll
+        for (int e = 0; e < 2; ++e)
+          xr.f[i][2 * jp + e] =
+              __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, goff[i] * 4, soff[2 * jp + e], 0));
+      }
+    }
+  };
+  auto commit_unit = [&](int i, int q, unsigned char* buf) { commit_unit_from(xr, i, q, buf); };
+  // weight slab of chunk q: 36 segments (piece, tap, g) of 64 couts x 16 B, moved global -> LDS by DMA;
+  // wave w moves segments w, w+4, ...
+  // Addressing is split so that a DMA costs one 64-bit scalar add: the tile's weight base and the byte offset of each
+  // of this wave's segments are loop-invariant scalars, the chunk offset is added once per chunk by the caller, and
+  // the only vector operand is the constant lane * 16.
+  const unsigned segb = (unsigned)p.wh_stride * 16u;  // bytes of one (piece, tap, g) segment row in global memory
+  const unsigned chunkb = G::NSEG * segb;             // bytes of one K-chunk's weights
+  const char* wtile = static_cast<const char*>(p.wh) + ((size_t)phase * nq * G::NSEG * p.wh_stride + m0) * 16;
+  // a DMA moves 1 KB = 64 / BM segments of BM couts x 16 B: LDS [segment][cout][8 halfs] is contiguous, in global
+  // memory the segments are `segb` apart
+  int segoff[G::NDMA];
+#pragma unroll
+  for (int k = 0; k < G::NDMA; ++k)
+    segoff[k] = __builtin_amdgcn_readfirstlane(min(wave + NW * k, G::NUNIT - 1) * (64 / BM) * (int)segb);
+  const int lane16 = (lane % BM) * 16 + (lane / BM) * (int)segb;
+  auto dma_weights = [&](int k, const char* wq, unsigned char* buf) {  // wq: wtile + chunk * chunkb (uniform)
+    // (uniform; a wave whose last share falls past the end repeats the final unit: same bytes, no branch)
+    const int unit = min(wave + NW * k, G::NUNIT - 1);
+    // Issued as inline asm on purpose: hipcc's wait-count pass cannot tell the DMA's LDS destination (the other
+    // buffer) from the fragment reads of this one, and with a DMA it knows of in flight it puts vmcnt(0) -- a wait
+    // for every outstanding patch load as well -- in front of each following ds_read.  Untracked VMEM operations
+    // only make the compiler's own counted vmcnt(N) waits stricter (the counter retires in order); the DMA's
+    // completion is waited for explicitly before the chunk's closing barrier.
+    const unsigned lds_addr =
+        (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)(buf + unit * 1024);
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1\n" ::"v"(lane16), "s"(wq + segoff[k]),
+                 "s"(__builtin_amdgcn_readfirstlane(lds_addr))  // (uniform by construction)
+                 : "memory");
+  };
+
+  f32x16 acc_hi[MTN][NT], acc_lo[NP == 2 ? MTN : 1][NP == 2 ? NT : 1];  // (acc_lo: the split's scaled low-order products)
+#pragma unroll
+  for (int mt = 0; mt < MTN; ++mt)
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        acc_hi[mt][nt][r] = 0.f;
+        if constexpr (NP == 2) acc_lo[mt][nt][r] = 0.f;
+      }
+
+  unsigned char* buf0 = smem_raw;
+  unsigned char* buf1 = smem_raw + H2_BUF_BYTES;
+
+  // zero padding: halo positions outside the image are zeroed once in both buffers and never written again
+#pragma unroll
+  for (int i = 0; i < H2_NU; ++i) {
+    if (zoff[i] >= 0) {
+      half8 z;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) z[j] = (_Float16)0.f;
+      _Float16* b0 = reinterpret_cast<_Float16*>(buf0);
+      _Float16* b1 = reinterpret_cast<_Float16*>(buf1);
+      *reinterpret_cast<half8*>(b0 + zoff[i]) = z;
+      *reinterpret_cast<half8*>(b1 + zoff[i]) = z;
+      if constexpr (NP == 2) {
+        *reinterpret_cast<half8*>(b0 + zoff[i] + 2 * H2_PSZ * 8) = z;
+        *reinterpret_cast<half8*>(b1 + zoff[i] + 2 * H2_PSZ * 8) = z;
+      }
+    }
+  }
+  // prologue: chunk 0 -> buffer 0; chunk 1 -> registers.  Everything that goes to memory is issued first and
+  // together (both chunks' patches, the weight DMAs, the scale/shift table), so the tile pays one memory round
+  // trip before its first MFMA, not one per dependent step.
+#ifdef DSG_H2_TIMING
+  unsigned long long rt_p[4];
+#define DSG_PT(i) do { __builtin_amdgcn_sched_barrier(0); rt_p[i] = __builtin_amdgcn_s_memrealtime(); __builtin_amdgcn_sched_barrier(0); } while (0)
+  DSG_PT(0);
+#else
+#define DSG_PT(i)
+#endif
+  {
+    // Issue order: weight DMAs, chunk 0's patch (into a scratch set), chunk 1's patch (into xr, where the K loop
+    // expects it).  The tile waits only for the DMAs and chunk 0 -- vmcnt retires in order, so a counted wait with
+    // chunk 1's loads still outstanding covers exactly those -- and chunk 1 lands under chunk 0's MFMAs.
+    Patch xr0;
+    float ssv[2048 / NTH];  // this thread's share of the image's scale/shift table (cin <= 1024): oldest loads
+    if (has_ss) {
+#pragma unroll
+      for (int k = 0; k < 2048 / NTH; ++k) ssv[k] = ssg[min(tid + NTH * k, 2 * p.cin - 1)];
+    }
+#pragma unroll
+    for (int k = 0; k < G::NDMA; ++k) dma_weights(k, wtile, buf0);
+    const char* sp = src_of(0);
+#pragma unroll
+    for (int i = 0; i < H2_NU; ++i) load_unit_to(xr0, i, sp, 0);
+    if (nq > 1) {
+      const char* sp1 = src_of(1);
+#pragma unroll
+      for (int i = 0; i < H2_NU; ++i) load_unit_to(xr, i, sp1, 1);
+    }
+    DSG_PT(1);
+    if (has_ss) {
+#pragma unroll
+      for (int k = 0; k < 2048 / NTH; ++k)
+        if (tid + NTH * k < 2 * p.cin) {
+          // global [c][scale | shift] -> LDS per channel PAIR (sc0, sc1, sh0, sh1): a staging step's two channels
+          // then take their scales and shifts as register pairs (one packed FMA, no shuffling moves)
+          const int idx = tid + NTH * k, c = idx >> 1, which = idx & 1;
+          ssl[4 * (c >> 1) + 2 * which + (c & 1)] = ssv[k];
+        }
+      __syncthreads();  // the scale/shift table is in LDS
+    }
+    DSG_PT(2);
+#pragma unroll
+    for (int i = 0; i < H2_NU; ++i) commit_unit_from(xr0, i, 0, buf0);
+    DSG_PT(3);
+  }
+  // (the DMAs were issued before every patch load: once chunk 0's values have been used they have landed; 8 * NU
+  // loads of chunk 1 may still be in flight)
+  if (nq > 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((S16 ? 1 : (SB ? 2 : 8)) * H2_NU) : "memory");
+  else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+
+  // One K-chunk: MFMAs on `cur`; STAGE: chunk q+1 (patch in registers, weights by DMA) goes into `nxt`;
+  // LOAD: chunk q+2's patch is fetched into the registers just freed.
+#ifdef DSG_H2_TIMING
+  unsigned long long t_tap[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  unsigned long long t_vm = 0, t_bar = 0;
+  const unsigned long long rt_start = __builtin_amdgcn_s_memrealtime();  // 100 MHz, same base on every CU
+#endif
+  auto chunk = [&](int q, auto stage_tag, auto load_tag) {
+    constexpr bool STAGE = decltype(stage_tag)::value, LOAD = decltype(load_tag)::value;
+    unsigned char* cur = (q & 1) ? buf1 : buf0;
+    unsigned char* nxt = (q & 1) ? buf0 : buf1;
+    const char* spn = LOAD ? src_of(q + 2) : nullptr;
+    const char* wqn = wtile + (size_t)(q + 1) * chunkb;  // the staged chunk's weights
+    const _Float16* wl = reinterpret_cast<const _Float16*>(cur);
+    const _Float16* xl = wl + H2_WHALFS;
+    // Operand fragments are fetched one tap ahead into the other half of fa/fb: the reads of tap t+1 are issued
+    // BEFORE tap t's staging writes in program order, so tap t's MFMAs depend on registers only and the scheduler
+    // is free to interleave them with the staging work (LDS reads after a possibly-aliasing LDS write are not).
+    half8 fa[2][MTN][NP], fb[2][NT][NP];  // [parity][tile][piece]
+    auto load_frags = [&](int tap, int par) {
+      // folded up-sampler: the phase's 2x2 corner of the patch; stride 2: the {y-1, y} x {x-1, x} corner
+      const int dy = GM == 2 ? (phase >> 1) + (tap >> 1) : (GM == 3 ? (tap >> 1) : tap / KS);
+      const int dx = GM == 2 ? (phase & 1) + (tap & 1) : (GM == 3 ? (tap & 1) : tap % KS);
+#pragma unroll
+      for (int mt = 0; mt < MTN; ++mt)
+#pragma unroll
+        for (int pc = 0; pc < NP; ++pc)
+          fa[par][mt][pc] =
+              *reinterpret_cast<const half8*>(wl + (((pc * TAPS + tap) * 2 + half) * BM + mt * 32 + l31) * 8);
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int pc = 0; pc < NP; ++pc)
+          fb[par][nt][pc] = *reinterpret_cast<const half8*>(
+              xl + ((pc * 2 + half) * H2_PSZ + (wave * NT + nt + dy) * H2_PW + l31 + dx) * 8);
+    };
+    load_frags(0, 0);
+#pragma unroll
+    for (int tap = 0; tap < TAPS; ++tap) {
+      __builtin_amdgcn_sched_barrier(0);
+#ifdef DSG_H2_TIMING
+      const unsigned long long tt0 = __builtin_readcyclecounter();
+      __builtin_amdgcn_sched_barrier(0);
+#endif
+      if (tap + 1 < TAPS) load_frags(tap + 1, (tap + 1) & 1);
+      if (KS == 1) {  // one tap: all units and the four weight segments ride on it
+#pragma unroll
+        for (int u = 0; u < H2_NU; ++u) {
+          if (STAGE) commit_unit(u, q + 1, nxt);
+          if (LOAD) load_unit(u, q + 2, spn);
+        }
+        if (STAGE) dma_weights(0, wqn, nxt);  // (KS = 1: NSEG = 4 <= NW)
+      }
+      // KS = 3: the chunk's staging steps and weight DMAs are dealt out evenly over taps 0..TAPS-2 (the last tap
+      // stays clear so that the newest loads have a tap's worth of MFMAs to land before the closing vmcnt(0))
+      if (KS == 3 && tap < TAPS - 1) {
+        constexpr int NSTEP = 4 * H2_NU, ST = TAPS - 1;
+#pragma unroll
+        for (int P = tap * NSTEP / ST; P < (tap + 1) * NSTEP / ST; ++P) stage_step(P, q + 1, nxt, STAGE, LOAD, spn);
+        if (STAGE) {
+#pragma unroll
+          for (int k = tap * G::NDMA / ST; k < (tap + 1) * G::NDMA / ST; ++k) dma_weights(k, wqn, nxt);
+        }
+      }
+      const int par = tap & 1;
+#pragma unroll
+      for (int mt = 0; mt < MTN; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+          if constexpr (NP == 2) {
+            acc_hi[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[par][mt][0], fb[par][nt][0], acc_hi[mt][nt], 0, 0, 0);
+            acc_lo[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[par][mt][0], fb[par][nt][1], acc_lo[mt][nt], 0, 0, 0);
+            acc_lo[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[par][mt][1], fb[par][nt][0], acc_lo[mt][nt], 0, 0, 0);
+          } else {
+            acc_hi[mt][nt] = mma16<PREC>(fa[par][mt][0], fb[par][nt][0], acc_hi[mt][nt]);
+          }
+        }
+      // Issue order within the tap: with one wave per SIMD nothing else fills the matrix pipe while this wave
+      // issues staging work, so spread that work between the MFMAs (at most ~5 issues hide behind one MFMA)
+      // instead of leaving it in one block as the scheduler would.
+      if (KS == 3 && tap < TAPS - 1 && (STAGE || LOAD)) {
+#pragma unroll
+        for (int m = 0; m < (NP == 2 ? 3 : 1) * MTN * NT; ++m) {
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);               // 1 MFMA
+          __builtin_amdgcn_sched_group_barrier(0x002, NP == 2 ? 2 : 5, 0);  // 2 VALU (a third of the MFMAs: 5)
+        }
+      }
+#ifdef DSG_H2_TIMING
+      __builtin_amdgcn_sched_barrier(0);
+      t_tap[tap] += __builtin_readcyclecounter() - tt0;
+#endif
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#ifdef DSG_H2_TIMING  // tools/ only: where does a wave wait at the end of a chunk?  (p.stats = 4 counters)
+    const unsigned long long ta = __builtin_readcyclecounter();
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    const unsigned long long tb = __builtin_readcyclecounter();
+    __builtin_amdgcn_s_barrier();
+    const unsigned long long tc = __builtin_readcyclecounter();
+    t_vm += tb - ta;
+    t_bar += tc - tb;
+    __builtin_amdgcn_sched_barrier(0);
+#else
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the weight DMAs (not tracked by the compiler) have landed
+    __syncthreads();  // nxt is complete; everyone is done reading cur
+#endif
+  };
+  using T = std::true_type;
+  using F = std::false_type;
+#ifdef DSG_H2_TIMING
+  const unsigned long long t_begin = __builtin_readcyclecounter();
+  const unsigned long long rt_loop = __builtin_amdgcn_s_memrealtime();
+#endif
+  int q = 0;
+  for (; q + 2 < nq; ++q) chunk(q, T{}, T{});
+  if (q + 1 < nq) chunk(q++, T{}, F{});  // last staged chunk: nothing left to load
+  chunk(q, F{}, F{});                    // last chunk: MFMAs only
+#ifdef DSG_H2_TIMING
+  const unsigned long long rt_loop_end = __builtin_amdgcn_s_memrealtime();
+  const unsigned long long t_loop_cycles = __builtin_readcyclecounter() - t_begin;
+#endif
+
+  // Epilogue.  All global accesses are buffer operations on descriptors that start at this tile's first output
+  // channel: the per-lane offset (row, column, +4 channels for the upper half-wave) is one VGPR computed once, the
+  // (channel, row) part of each access is a scalar offset, and channels past cout fall outside the descriptor's
+  // range -- loads return 0, stores are dropped -- so there is neither address arithmetic nor a bounds branch per
+  // element.  The residual values of a 32-channel slab are all in flight before the first use (with one wave per
+  // SIMD a load->add->store chain per element would expose the memory latency 64 times).
+  // (the host only dispatches here when cout % 8 == 0, so a 4-row half-group is never split by cout)
+  const bool has_r = p.res != nullptr;
+  const int oscale = GM == 2 ? 2 : 1;  // folded mode: the output map is twice the tiled (low-resolution) grid
+  const int oplane = p.hout * p.wout * oscale * oscale;
+#ifdef DSG_H2_TIMING_NOSTATS
+  const bool want_stats = false;  // (timing experiment: the record buffer is p.stats, the statistics path stays off)
+#else
+  const bool want_stats = p.stats != nullptr;
+#endif
+  float* red = reinterpret_cast<float*>(smem_raw);  // [wave][sum | sumsq][cout 64] (the K loop is done with LDS)
+  constexpr int RED_FLOATS = NW * (NT / 2) * 2 * BM;
+  float* red_lane = (l31 == 16) ? red + 4 * half : red + RED_FLOATS + 64 + lane;  // (+ crel etc. per value)
+  const int nvalid = min(BM, p.cout - m0);        // output channels of this tile that exist
+  const size_t tile_off = ((size_t)n * p.cout + m0) * oplane * ESD;  // bytes
+  const int range = nvalid * oplane * ESD;
+  char* dstb = static_cast<char*>(p.dst);
+  const __amdgpu_buffer_rsrc_t dst_rs = __builtin_amdgcn_make_buffer_rsrc(dstb + tile_off, 0, range, 0x00020000);
+  const __amdgpu_buffer_rsrc_t res_rs = __builtin_amdgcn_make_buffer_rsrc(
+      has_r ? const_cast<char*>(static_cast<const char*>(p.res)) + tile_off : dstb, 0, has_r ? range : 0, 0x00020000);
+  const __amdgpu_buffer_rsrc_t bias_rs = __builtin_amdgcn_make_buffer_rsrc(
+      p.bias ? const_cast<float*>(p.bias + m0) : reinterpret_cast<float*>(dstb), 0, p.bias ? nvalid * 4 : 0, 0x00020000);
+  const __amdgpu_buffer_rsrc_t temb_rs = __builtin_amdgcn_make_buffer_rsrc(
+      p.temb ? const_cast<float*>(p.temb + (size_t)n * p.temb_stride + m0) : reinterpret_cast<float*>(dstb), 0,
+      p.temb ? nvalid * 4 : 0, 0x00020000);
+  int voff[NT];  // bytes, per lane and row; the channel part of an address is the scalar offset
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) {
+    if constexpr (DB) {  // [C/8][H][W][8]: pixel * 32 bytes + this half-wave's four channels
+      const int oy = GM == 2 ? 2 * (oy0 + wave * NT + nt) + (phase >> 1) : oy0 + wave * NT + nt;
+      const int ox = GM == 2 ? 2 * (ox0 + l31) + (phase & 1) : ox0 + l31;
+      voff[nt] = (GM == 2 || ox0 + l31 < p.wout) ? ((oy * (p.wout * oscale) + ox) * 8 + 4 * half) * ESD : 0x7FFFFFF0;
+    } else {
+      voff[nt] = GM == 2 ? (4 * half * oplane + (2 * (oy0 + wave * NT + nt) + (phase >> 1)) * (2 * p.wout) +
+                            2 * (ox0 + l31) + (phase & 1)) * 4
+                         : (ox0 + l31 < p.wout ? (4 * half * oplane + (oy0 + wave * NT + nt) * p.wout + ox0 + l31) * 4
+                                               : 0x7FFFFFF0);  // (narrow maps: past the last column -> out of range)
+    }
+  }
+  const int oplane4 = __builtin_amdgcn_readfirstlane(oplane * ESD);  // bytes of one channel plane of dst
+  // NARROW: maps less than one tile wide (16x16, 8x8): lanes past the last column store nothing (their offset is out
+  // of the descriptor's range) and count as zeros in the statistics
+  const bool lane_ok = ox0 + l31 < p.wout;
+#ifdef DSG_H2_TIMING
+  unsigned long long rt_e[6] = {0, 0, 0, 0, 0, 0};
+#define DSG_ET(i) do { __builtin_amdgcn_sched_barrier(0); rt_e[i] = __builtin_amdgcn_s_memrealtime(); __builtin_amdgcn_sched_barrier(0); } while (0)
+#else
+#define DSG_ET(i)
+#endif
+  DSG_ET(0);
+  auto epilogue = [&](auto stats_tag, auto narrow_tag) {
+    constexpr bool STATS = decltype(stats_tag)::value, NARROW = decltype(narrow_tag)::value;
+#pragma unroll
+    for (int mt = 0; mt < MTN; ++mt) {
+      float rv[16][NT], addv[16];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int crel = mt * 32 + (r & 3) + 8 * (r >> 2);  // this lane's channel is crel + 4*half
+        addv[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(bias_rs, 16 * half, crel * 4, 0)) +
+                  __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(temb_rs, 16 * half, crel * 4, 0));
+      }
+      if (has_r) {
+        if constexpr (DB) {
+#pragma unroll
+          for (int rg = 0; rg < 4; ++rg)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+              if constexpr (ESD == 2) {  // four 16-bit channels: 8 bytes
+                typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+                const u32x2 q = __builtin_amdgcn_raw_buffer_load_b64(res_rs, voff[nt], (mt * 4 + rg) * 8 * oplane4, 0);
+                rv[4 * rg][nt] = lo16<PREC>(q.x); rv[4 * rg + 1][nt] = hi16<PREC>(q.x);
+                rv[4 * rg + 2][nt] = lo16<PREC>(q.y); rv[4 * rg + 3][nt] = hi16<PREC>(q.y);
+              } else {
+                const float4 q = __builtin_bit_cast(
+                    float4, __builtin_amdgcn_raw_buffer_load_b128(res_rs, voff[nt], (mt * 4 + rg) * 8 * oplane4, 0));
+                rv[4 * rg][nt] = q.x; rv[4 * rg + 1][nt] = q.y; rv[4 * rg + 2][nt] = q.z; rv[4 * rg + 3][nt] = q.w;
+              }
+            }
+        } else {
+#pragma unroll
+          for (int r = 0; r < 16; ++r)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+              const int crel = mt * 32 + (r & 3) + 8 * (r >> 2);
+              rv[r][nt] = __builtin_bit_cast(
+                  float, __builtin_amdgcn_raw_buffer_load_b32(res_rs, voff[nt], crel * oplane4, 0));
+            }
+        }
+      } else {
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+#pragma unroll
+          for (int nt = 0; nt < NT; ++nt) rv[r][nt] = 0.f;
+      }
+#ifdef DSG_H2_TIMING
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (timing build: the slab's loads have landed)
+#endif
+      DSG_ET(1 + 2 * mt);
+#pragma unroll
+      for (int rg = 0; rg < 4; ++rg) {  // a register group = four consecutive output channels
+        float vv[4][NT];
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+          for (int nt = 0; nt < NT; ++nt) {
+            const int r = 4 * rg + j;
+            if constexpr (NP == 2)
+              vv[j][nt] = ((acc_hi[mt][nt][r] + acc_lo[mt][nt][r] * (1.0f / 2048.0f)) + addv[r]) + rv[r][nt];
+            else
+              vv[j][nt] = (acc_hi[mt][nt][r] + addv[r]) + rv[r][nt];
+          }
+        if constexpr (DB) {  // the group is 16 contiguous bytes of the pixel's channel block
+#pragma unroll
+          for (int nt = 0; nt < NT; ++nt) {
+            typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+            const float4 o = make_float4(vv[0][nt], vv[1][nt], vv[2][nt], vv[3][nt]);
+            // The channel-block offset goes into the VECTOR offset on purpose.  With an SGPR soffset hipcc 7.2 treats
+            // the 16-byte store as free of the "VALU overwrites store data" hazard and re-uses the data registers
+            // two or three instructions later; on gfx950 that corrupted the second dword of lanes 12..15 of every
+            // row (found by the bit-exact layout tests).  Without an soffset register it inserts the wait states.
+#ifndef DSG_H2_TIMING_NOSTORE
+            if constexpr (ESD == 2) {  // rounded to the 16-bit type: the group is 8 bytes
+              typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+              const u32x2 o2 = {pack2<PREC>(o.x, o.y), pack2<PREC>(o.z, o.w)};
+              __builtin_amdgcn_raw_buffer_store_b64(o2, dst_rs, voff[nt] + (mt * 4 + rg) * 8 * oplane4, 0, 0);
+            } else {
+              __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o), dst_rs,
+                                                     voff[nt] + (mt * 4 + rg) * 8 * oplane4, 0, 0);
+            }
+#else
+            if (o.x == 1234.5f) red[lane] = o.y + o.z + o.w;  // (timing experiment: keep the math, drop the stores)
+#endif
+          }
+        } else {
+#pragma unroll
+          for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+              __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, vv[j][nt]), dst_rs, voff[nt],
+                                                    (mt * 32 + j + 8 * rg) * oplane4, 0);
+        }
+        if (STATS) {  // GroupNorm statistics of the tensor just produced (the next layer's norm reads them)
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const int crel = mt * 32 + j + 8 * rg;
+#pragma unroll
+            for (int pr = 0; pr < NT / 2; ++pr) {  // one partial per pair of rows: the same summation tree for any NT
+              const float a = (NARROW && !lane_ok) ? 0.f : vv[j][2 * pr], b = (NARROW && !lane_ok) ? 0.f : vv[j][2 * pr + 1];
+              const float t1 = half_wave_sum(a + b), t2 = half_wave_sum(a * a + b * b);
+              // every lane stores -- lanes 16 / 48 to the real slot, the others to a per-lane dump area behind it:
+              // a predicated store here is a branch, and 128 branches fence the scheduler between the DPP chains
+              red_lane[((wave * (NT / 2) + pr) * 2 + 0) * BM + crel] = t1;
+              red_lane[((wave * (NT / 2) + pr) * 2 + 1) * BM + crel] = t2;
+            }
+          }
+        }
+      }
+      DSG_ET(2 + 2 * mt);
+    }
+  };
+  if (p.wout < H2_TW) {
+    if (want_stats) epilogue(T{}, T{});
+    else epilogue(F{}, T{});
+  } else {
+    if (want_stats) epilogue(T{}, F{});
+    else epilogue(F{}, F{});
+  }
+  if (want_stats) {
+    // statistics tiles are 8 rows x 32 columns (4 row pairs, summed in row order in fp64) whatever NT is, so the
+    // values -- and everything downstream of the norm -- do not depend on the launch geometry
+    __syncthreads();
+    if (tid < 2 * BM) {
+      const int cl = tid & (BM - 1), which = (tid / BM) & 1;
+      if (m0 + cl < p.cout) {
+        constexpr int NE = NW * NT / 8;  // 8-row statistics tiles per workgroup tile
+        const int ntile1 = p.tiles_x * p.tiles_y * NE;           // entries per phase
+        const int ntile = ntile1 * (GM == 2 ? 4 : 1);
+#pragma unroll
+        for (int e = 0; e < NE; ++e) {
+          double t = 0.0;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) t += (double)red[((4 * e + j) * 2 + which) * BM + cl];
+          const int tile8 = phase * ntile1 + (ty * NE + e) * p.tiles_x + tx;
+#ifndef DSG_H2_TIMING
+          p.stats[(((size_t)n * p.cout + m0 + cl) * ntile + tile8) * 2 + which] = t;
+#endif
+        }
+      }
+    }
+  }
+#ifdef DSG_H2_TIMING
+  if (p.stats && tid == 0) p.stats[8 + 4 * (size_t)gridDim.x + blockIdx.x] =
+      (double)__builtin_amdgcn_s_memrealtime();
+#endif
+#ifdef DSG_H2_TIMING
+  if (p.stats && lane == 0) {
+    atomicAdd(&p.stats[0], (double)t_loop_cycles);
+    atomicAdd(&p.stats[1], (double)t_vm);
+    atomicAdd(&p.stats[2], (double)t_bar);
+    atomicAdd(&p.stats[3], 1.0);
+    for (int t = 0; t < TAPS; ++t) atomicAdd(&p.stats[8 + 5 * (size_t)gridDim.x + t], (double)t_tap[t]);
+    if (wave == 0) {  // per-block record: start / loop begin / loop end (10-ns ticks), loop cycles
+      double* rec = p.stats + 8 + 4 * (size_t)blockIdx.x;
+      rec[0] = (double)rt_entry;
+      rec[1] = (double)rt_loop;
+      rec[2] = (double)rt_loop_end;
+      rec[3] = (double)t_loop_cycles;
+      double* pr = p.stats + 8 + 5 * (size_t)gridDim.x + 16 + 4 * (size_t)blockIdx.x;
+      for (int k = 0; k < 4; ++k) pr[k] = (double)rt_p[k];
+      double* er = p.stats + 8 + 9 * (size_t)gridDim.x + 16 + 6 * (size_t)blockIdx.x;
+      rt_e[5] = __builtin_amdgcn_s_memrealtime();
+      for (int k = 0; k < 6; ++k) er[k] = (double)rt_e[k];
+    }
+  }
+#endif
+}
+
+}  // namespace dsg

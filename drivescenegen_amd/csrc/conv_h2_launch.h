@@ -1,0 +1,169 @@
+// Launch logic of conv_h2_kernel, shared by the three translation units that instantiate it:
+// conv_h2.hip (PREC 0: fp32 tensors, fp16x2-split products), conv_h2_bf16.hip (PREC 1), conv_h2_f16.hip (PREC 2).
+#pragma once
+#include "conv_h2_kernel.h"
+
+namespace dsg {
+
+// kernel-selection switches (dsg_set_tuning); defined in conv_h2.hip
+struct H2Tuning {
+  int enabled = 1;
+  int waves = 4;        // 16-row tiles: 4 waves x 4 rows or 8 waves x 2 rows (tuning key 6)
+  int fold = 1;         // folded up-sampler convs (key 8: A/B against the x2 gather)
+  int stats = 1;        // epilogue GroupNorm statistics (key 5: A/B against the separate pass)
+  int bm32 = 0;         // 32-cout x 8-row workgroups, two per CU, for the shallow levels (key 16; measured slower than
+                        // the 64 x 16 geometry: 0.356 vs 0.302 ms at 64 channels / 256^2 -- off)
+  int bm32_min = 512;   // ... when the 64-cout x 16-row grid has at least this many workgroups
+  int bm32_small = 1;   // 32-cout workgroups for grids of at most half the CUs (key 17)
+  int s2 = 1;           // stride-2 convs on the split path (key 15: A/B against the f32 MFMA kernel)
+  int pw_occ2 = 1;      // pointwise convs: 8-row tiles compiled for two workgroups per CU (key 11)
+  int rows = 0;         // rows per wave: 0 = by grid size, 2 | 4 forced (key 3)
+  int epoch = 0;        // bumped by every change: plans key their cached workspace sizes on it
+};
+extern H2Tuning g_h2;
+constexpr int H2_CUS = 256;
+
+bool conv_h2_fold(const dsg_conv_args* a);
+bool conv_h2_s2(const dsg_conv_args* a, int hout, int wout);
+bool conv_h2_rows16(const dsg_conv_args* a, int hout, int wout);
+
+template <int GM, int NT, int KS, int ACT, int NW = 4, int OCC = 1, int LAY = 0, int BM = 64, int PREC = 0>
+static int h2_launch(dim3 grid, size_t lds, hipStream_t st, const ConvH2P& p) {
+  auto kern = conv_h2_kernel<GM, NT, KS, ACT, NW, OCC, LAY, BM, PREC>;
+  static bool raised = false;
+  if (!raised) {
+    DSG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                160 * 1024));
+    raised = true;
+  }
+  hipLaunchKernelGGL(kern, grid, dim3(64 * NW), lds, st, p);
+  return DSG_OK;
+}
+
+// PREC 0 serves every (layout, gather mode, geometry) combination conv_h2_eligible admits; the 16-bit modes serve
+// channel-blocked tensors only (3x3: every tensor blocked, or blocked sources -> fp32 [N,C,H,W] result for conv_out;
+// pointwise: any pair with at least one blocked side).
+template <int PREC>
+int conv_h2_launch_t(const dsg_conv_args* a, int hout, int wout, hipStream_t st) {
+  constexpr int NP = PREC ? 1 : 2;
+  // pointwise: 8-row tiles, two workgroups per CU (the only pointwise kernels that take channel-blocked tensors)
+  const bool occ2 = a->ksize == 1 && (g_h2.pw_occ2 || a->src_layout || a->dst_layout);
+  const bool nt4 = !occ2 && conv_h2_rows16(a, hout, wout);
+  ConvH2P p;
+  p.stats = a->stats_out;
+  p.src0 = a->src0; p.src1 = a->src1; p.c0 = a->c0; p.c1 = a->c1; p.cin = a->c0 + a->c1;
+  p.n = a->n; p.hin = a->hin; p.win = a->win;
+  if (a->ksize == 1) {
+    hout = hout * wout / H2_TW; wout = H2_TW;
+    p.hin = hout; p.win = wout;
+  }
+  const bool fold = conv_h2_fold(a);
+  const bool s2 = conv_h2_s2(a, hout, wout);
+  if (fold) {  // the kernel tiles the LOW-resolution grid; outputs land at (2y + py, 2x + px)
+    hout = a->hin;
+    wout = a->win;
+  }
+  p.hc = (a->upsample && !fold) ? 2 * p.hin : p.hin;
+  p.wc = (a->upsample && !fold) ? 2 * p.win : p.win;
+  if (s2) {  // the patch lives on the output grid; its 4 C "channels" are (channel block, pixel parity) groups
+    p.hc = hout;
+    p.wc = wout;
+    p.cin = 4 * a->c0;
+  }
+  p.hout = hout; p.wout = wout; p.cout = a->cout; p.cout_pad = (a->cout + 63) / 64 * 64;
+  p.wh_stride = a->weight_h2_cout_stride ? a->weight_h2_cout_stride : p.cout_pad;
+  p.wh = fold ? a->weight_h2_fold : (s2 ? a->weight_h2_s2 : a->weight_h2);
+  p.bias = a->bias; p.ss = a->gn_scale_shift; p.silu = a->silu; p.temb = a->temb; p.temb_stride = a->temb_stride;
+  p.res = a->residual; p.dst = a->dst;
+  // 16-row tiles (NT = 4) when they still give every CU a workgroup; 8-row tiles otherwise
+  const int th = nt4 ? 16 : 8;
+  p.tiles_x = (wout + H2_TW - 1) / H2_TW; p.tiles_y = hout / th;
+  const bool k1 = a->ksize == 1;
+  const size_t lds = 2 * (size_t)(k1 ? (nt4 ? H2Geom<4, 1, 4, 1, 64, NP>::BUF_BYTES : H2Geom<2, 1, 4, 1, 64, NP>::BUF_BYTES)
+                                     : (nt4 ? H2Geom<4, 3, 4, 9, 64, NP>::BUF_BYTES : H2Geom<2, 3, 4, 9, 64, NP>::BUF_BYTES)) +
+                     (a->gn_scale_shift ? (size_t)p.cin * 2 * sizeof(float) : 0);  // + the scale/shift table
+  dim3 grid(p.tiles_x * p.tiles_y * p.n * (p.cout_pad / H2_BM) * (fold ? 4 : 1));
+  const int lay = (a->src_layout ? 1 : 0) | (a->dst_layout ? 2 : 0);
+  int pi = -1;
+  if (prof_on()) {
+    const double px = (double)p.n * hout * wout * (fold ? 4 : 1);  // output pixels; FLOPs are the reference op's
+    const int taps = a->ksize * a->ksize;
+    const double cin_ref = a->c0 + a->c1;  // (stride 2: the kernel's 4 C x 4 taps are the reference op's C x 9)
+    const double es = (PREC && (lay & 1)) ? 2.0 : 4.0, ed = (PREC && (lay & 2)) ? 2.0 : 4.0, ew = PREC ? 2.0 : 4.0;
+    pi = prof_begin((PREC ? 20 : 0) + (s2 ? 2 : (a->ksize == 1 ? 8 : (a->upsample ? 7 : 6))), 2.0 * px * p.cout * cin_ref * taps,
+                    es * (double)p.n * cin_ref * p.hin * p.win + ew * cin_ref * taps * p.cout +
+                        ed * px * p.cout * (p.res ? 2.0 : 1.0), st);
+  }
+  const int act = a->gn_scale_shift ? (a->silu ? 2 : 3) : 0;
+  int rc = DSG_OK;
+#define DSG_H2_LAUNCH(GM, KS, ACT)                                                  \
+  do {                                                                              \
+    if (nt4 && g_h2.waves == 8) rc = h2_launch<GM, 2, KS, ACT, 8>(grid, lds, st, p); \
+    else if (nt4) rc = h2_launch<GM, 4, KS, ACT>(grid, lds, st, p);                 \
+    else rc = h2_launch<GM, 2, KS, ACT>(grid, lds, st, p);                          \
+  } while (0)
+#define DSG_H2_LAUNCH_BLK(GM, KS, ACT, LAY) /* channel-blocked: four-wave kernels only */ \
+  do {                                                                              \
+    if (nt4) rc = h2_launch<GM, 4, KS, ACT, 4, 1, LAY, 64, PREC>(grid, lds, st, p);  \
+    else rc = h2_launch<GM, 2, KS, ACT, 4, 1, LAY, 64, PREC>(grid, lds, st, p);      \
+  } while (0)
+#define DSG_H2_LAUNCH_PW(ACT) /* pointwise, two workgroups per CU: any layout pair */ \
+  do {                                                                              \
+    if (lay == 1) rc = h2_launch<0, 2, 1, ACT, 4, 2, 1, 64, PREC>(grid, lds, st, p); \
+    else if (lay == 2) rc = h2_launch<0, 2, 1, ACT, 4, 2, 2, 64, PREC>(grid, lds, st, p); \
+    else if (lay == 3) rc = h2_launch<0, 2, 1, ACT, 4, 2, 3, 64, PREC>(grid, lds, st, p); \
+    else if constexpr (PREC == 0) rc = h2_launch<0, 2, 1, ACT, 4, 2, 0>(grid, lds, st, p); \
+    else rc = fail(DSG_ERR_UNSUPPORTED_SHAPE, "dsg_conv2d_fwd: 16-bit pointwise conv needs a channel-blocked side"); \
+  } while (0)
+  // 32-cout workgroups: (a) optional, two per CU on the shallow levels (cin <= 128: LDS); (b) small batches: when
+  // even the 8-row x 64-cout grid leaves more than half of the CUs idle, halve the cout tile to double the grid
+  const bool bm32_ok = lay == 3 && !fold && !s2 && !k1 && !a->upsample && wout % H2_TW == 0;
+  const bool bm32 = bm32_ok && ((g_h2.bm32 && p.cin <= 128 && (int)grid.x >= g_h2.bm32_min) ||
+                                (g_h2.bm32_small && !nt4 && (int)grid.x <= H2_CUS / 2));
+  if (s2) {
+    DSG_H2_LAUNCH_BLK(3, 3, 0, 3);
+  } else if (fold) {
+    if (lay) DSG_H2_LAUNCH_BLK(2, 3, 0, 3);
+    else if constexpr (PREC == 0) {
+      if (nt4) rc = h2_launch<2, 4, 3, 0>(grid, lds, st, p);
+      else rc = h2_launch<2, 2, 3, 0>(grid, lds, st, p);
+    }
+  } else if (k1 && occ2) {
+    if (act == 0) DSG_H2_LAUNCH_PW(0);
+    else DSG_H2_LAUNCH_PW(3);
+  } else if (k1) {
+    if constexpr (PREC == 0) {
+      if (act == 0) DSG_H2_LAUNCH(0, 1, 0);
+      else DSG_H2_LAUNCH(0, 1, 3);
+    }
+  } else if (a->upsample) {
+    if constexpr (PREC == 0) DSG_H2_LAUNCH(1, 3, 0);
+  } else if (bm32) {
+    // shallow levels: 32 couts x 8 rows x 32 columns per workgroup, two workgroups per CU
+    const dim3 g32(((wout + H2_TW - 1) / H2_TW) * (hout / 8) * p.n * (p.cout_pad / 32));
+    const size_t lds32 = 2 * (size_t)H2Geom<2, 3, 4, 9, 32, NP>::BUF_BYTES + (a->gn_scale_shift ? (size_t)p.cin * 2 * sizeof(float) : 0);
+    ConvH2P q = p;
+    q.tiles_y = hout / 8;
+    if (act == 0) rc = h2_launch<0, 2, 3, 0, 4, 2, 3, 32, PREC>(g32, lds32, st, q);
+    else rc = h2_launch<0, 2, 3, 2, 4, 2, 3, 32, PREC>(g32, lds32, st, q);
+  } else if (lay == 3) {
+    if (act == 0) DSG_H2_LAUNCH_BLK(0, 3, 0, 3);
+    else DSG_H2_LAUNCH_BLK(0, 3, 2, 3);
+  } else if (lay == 1) {  // 16-bit modes only (conv_out: blocked 16-bit sources -> fp32 [N,C,H,W])
+    if constexpr (PREC != 0) DSG_H2_LAUNCH_BLK(0, 3, 2, 1);
+  } else {
+    if constexpr (PREC == 0) {
+      if (act == 0) DSG_H2_LAUNCH(0, 3, 0);
+      else DSG_H2_LAUNCH(0, 3, 2);
+    }
+  }
+#undef DSG_H2_LAUNCH
+#undef DSG_H2_LAUNCH_BLK
+#undef DSG_H2_LAUNCH_PW
+  if (rc != DSG_OK) return rc;
+  prof_end(pi, st);
+  DSG_LAUNCH_CHECK();
+  return DSG_OK;
+}
+
+}  // namespace dsg

@@ -8,7 +8,7 @@
 //
 // Statistics are kept per CHANNEL (sum, sum of squares, fp64) so that a group straddling the
 // [x || skip] concat of the up path (6 of the 12 up-resnet norm1's) needs no concat tensor.
-#include "dsg_common.h"
+#include "dsg_h16.h"
 
 namespace dsg {
 
@@ -60,17 +60,27 @@ __global__ __launch_bounds__(256) void gn_channel_stats_kernel(const float* __re
 
 // The same statistics of a channel-blocked tensor [N][C/8][hw][8]: grid = (C/8, n, splits); a thread walks the
 // pixels of its split and keeps the 8 channels of its block; one partial per split, [N][C][splits][2].
-__global__ __launch_bounds__(256) void gn_channel_stats_blk_kernel(const float* __restrict__ src, int c, int hw_total,
-                                                                   double* __restrict__ stats) {
+// (dt: dsg_dtype of the tensor -- 0 fp32, 1 bf16, 2 fp16)
+__global__ __launch_bounds__(256) void gn_channel_stats_blk_kernel(const void* __restrict__ srcv, int c, int hw_total,
+                                                                   double* __restrict__ stats, int dt) {
   const int cb = blockIdx.x, n = blockIdx.y, sp_i = blockIdx.z, splits = gridDim.z;
   const int hw = hw_total / splits;
-  const float4* sp = reinterpret_cast<const float4*>(src + (((size_t)n * c + cb * 8) * hw_total + (size_t)sp_i * hw * 8));
+  const size_t base = ((size_t)n * c + cb * 8) * hw_total + (size_t)sp_i * hw * 8;
+  const float4* sp = reinterpret_cast<const float4*>(static_cast<const float*>(srcv) + base);
+  const uint4* sp16 = reinterpret_cast<const uint4*>(static_cast<const unsigned short*>(srcv) + base);
   double s[8], ss[8];
 #pragma unroll
   for (int j = 0; j < 8; ++j) s[j] = ss[j] = 0.0;
   for (int i = threadIdx.x; i < hw; i += 256) {
-    const float4 a = sp[2 * i], b = sp[2 * i + 1];
-    const float v[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+    float v[8];
+    if (dt) {
+      const uint4 q = sp16[i];
+      v[0] = word_lo(q.x, dt); v[1] = word_hi(q.x, dt); v[2] = word_lo(q.y, dt); v[3] = word_hi(q.y, dt);
+      v[4] = word_lo(q.z, dt); v[5] = word_hi(q.z, dt); v[6] = word_lo(q.w, dt); v[7] = word_hi(q.w, dt);
+    } else {
+      const float4 a = sp[2 * i], b = sp[2 * i + 1];
+      v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+    }
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
       s[j] += (double)v[j];
@@ -220,13 +230,19 @@ DSG_API int dsg_gn_channel_stats(const float* src0, int32_t c0, const float* src
 
 DSG_API int dsg_gn_channel_stats_blocked(const float* src, int32_t c, int32_t n, int32_t hw, int32_t splits,
                                          double* chan_stats, void* stream) {
+  return dsg_gn_channel_stats_blocked_dt(src, c, n, hw, splits, chan_stats, DSG_F32, stream);
+}
+
+DSG_API int dsg_gn_channel_stats_blocked_dt(const void* src, int32_t c, int32_t n, int32_t hw, int32_t splits,
+                                            double* chan_stats, int32_t dtype, void* stream) {
   DSG_CHECK_ARG(src && chan_stats, "dsg_gn_channel_stats_blocked: NULL pointer");
+  DSG_CHECK_ARG(dtype >= DSG_F32 && dtype <= DSG_F16, "dsg_gn_channel_stats_blocked: bad dtype %d", dtype);
   DSG_CHECK_ARG(c > 0 && c % 8 == 0 && n > 0 && hw > 0, "dsg_gn_channel_stats_blocked: bad dims (C %% 8 != 0?)");
   DSG_CHECK_ARG(splits >= 1 && splits <= 65535 && hw % splits == 0,
                 "dsg_gn_channel_stats_blocked: splits must divide hw (%d, %d)", splits, hw);
   DSG_CHECK_ARG(n <= 65535, "dsg_gn_channel_stats_blocked: batch too large for one launch");
   hipLaunchKernelGGL(dsg::gn_channel_stats_blk_kernel, dim3(c / 8, n, splits), dim3(256), 0,
-                     static_cast<hipStream_t>(stream), src, c, hw, chan_stats);
+                     static_cast<hipStream_t>(stream), src, c, hw, chan_stats, dtype);
   DSG_LAUNCH_CHECK();
   return DSG_OK;
 }

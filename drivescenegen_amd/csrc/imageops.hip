@@ -8,7 +8,7 @@
 //      the +-0.1 background mask; extract_agents' threshold (vectorization/direct/extract_vehicles.py:136-148).
 //      Both masks are byte look-ups: the host builds the 256-entry tables with the reference's own float
 //      arithmetic, so results are bit-identical by construction.
-#include "dsg_common.h"
+#include "dsg_h16.h"
 #include <algorithm>
 
 namespace dsg {
@@ -66,25 +66,40 @@ __global__ __launch_bounds__(256) void mask_lut_kernel(const uint8_t* __restrict
 }
 
 
-// [N][C][hw] <-> [N][C/8][hw][8]: one thread per (n, c/8, pixel), eight channels each
-__global__ __launch_bounds__(256) void layout_convert_kernel(const float* __restrict__ src, float* __restrict__ dst, int c,
-                                                             int hw, int64_t total, int to_blocked) {
+// [N][C][hw] fp32 <-> [N][C/8][hw][8] (fp32, or the 16-bit type dt: 1 bf16, 2 fp16): one thread per (n, c/8, pixel),
+// eight channels each
+__global__ __launch_bounds__(256) void layout_convert_kernel(const void* __restrict__ srcv, void* __restrict__ dstv, int c,
+                                                             int hw, int64_t total, int to_blocked, int dt) {
   const int64_t i = blockIdx.x * (int64_t)256 + threadIdx.x;
   if (i >= total) return;
   const int px = (int)(i % hw);
   const int64_t blk = i / hw;  // n * (c/8) + cb
   const size_t plain = (size_t)blk * 8 * hw + px, blocked = ((size_t)blk * hw + px) * 8;
   if (to_blocked) {
+    const float* src = static_cast<const float*>(srcv);
     float v[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) v[j] = src[plain + (size_t)j * hw];
-    float4* o = reinterpret_cast<float4*>(dst + blocked);
-    o[0] = make_float4(v[0], v[1], v[2], v[3]);
-    o[1] = make_float4(v[4], v[5], v[6], v[7]);
+    if (dt) {
+      *reinterpret_cast<uint4*>(static_cast<unsigned short*>(dstv) + blocked) =
+          make_uint4(word_pack(v[0], v[1], dt), word_pack(v[2], v[3], dt), word_pack(v[4], v[5], dt), word_pack(v[6], v[7], dt));
+    } else {
+      float4* o = reinterpret_cast<float4*>(static_cast<float*>(dstv) + blocked);
+      o[0] = make_float4(v[0], v[1], v[2], v[3]);
+      o[1] = make_float4(v[4], v[5], v[6], v[7]);
+    }
   } else {
-    const float4* q = reinterpret_cast<const float4*>(src + blocked);
-    const float4 a = q[0], b = q[1];
-    const float v[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+    float* dst = static_cast<float*>(dstv);
+    float v[8];
+    if (dt) {
+      const uint4 q = *reinterpret_cast<const uint4*>(static_cast<const unsigned short*>(srcv) + blocked);
+      v[0] = word_lo(q.x, dt); v[1] = word_hi(q.x, dt); v[2] = word_lo(q.y, dt); v[3] = word_hi(q.y, dt);
+      v[4] = word_lo(q.z, dt); v[5] = word_hi(q.z, dt); v[6] = word_lo(q.w, dt); v[7] = word_hi(q.w, dt);
+    } else {
+      const float4* q = reinterpret_cast<const float4*>(static_cast<const float*>(srcv) + blocked);
+      const float4 a = q[0], b = q[1];
+      v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+    }
 #pragma unroll
     for (int j = 0; j < 8; ++j) dst[plain + (size_t)j * hw] = v[j];
   }
@@ -125,13 +140,19 @@ DSG_API int dsg_mask_lut_u8(const uint8_t* img, int32_t n, int32_t hw, int32_t c
   return DSG_OK;
 }
 
-DSG_API int dsg_layout_convert(const float* src, float* dst, int32_t n, int32_t c, int32_t hw, int32_t to_blocked,
-                               void* stream) {
+DSG_API int dsg_layout_convert_dt(const void* src, void* dst, int32_t n, int32_t c, int32_t hw, int32_t to_blocked,
+                                  int32_t blocked_dtype, void* stream) {
   DSG_CHECK_ARG(src && dst && src != dst, "dsg_layout_convert: NULL pointer or in-place");
   DSG_CHECK_ARG(n > 0 && c > 0 && c % 8 == 0 && hw > 0, "dsg_layout_convert: bad dims (C %% 8 != 0?)");
+  DSG_CHECK_ARG(blocked_dtype >= DSG_F32 && blocked_dtype <= DSG_F16, "dsg_layout_convert: bad blocked_dtype %d", blocked_dtype);
   const int64_t total = (int64_t)n * (c / 8) * hw;
   hipLaunchKernelGGL(dsg::layout_convert_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0,
-                     static_cast<hipStream_t>(stream), src, dst, c, hw, total, to_blocked);
+                     static_cast<hipStream_t>(stream), src, dst, c, hw, total, to_blocked, blocked_dtype);
   DSG_LAUNCH_CHECK();
   return DSG_OK;
+}
+
+DSG_API int dsg_layout_convert(const float* src, float* dst, int32_t n, int32_t c, int32_t hw, int32_t to_blocked,
+                               void* stream) {
+  return dsg_layout_convert_dt(src, dst, n, c, hw, to_blocked, DSG_F32, stream);
 }

@@ -306,6 +306,19 @@ __global__ __launch_bounds__(256) void clip_scale_kernel(float* __restrict__ g, 
   for (int64_t i = blockIdx.x * (int64_t)256 + threadIdx.x; i < numel; i += (int64_t)gridDim.x * 256) g[i] *= cf;
 }
 
+// GradScaler.unscale_: g *= inv in place; *found |= any(!isfinite(g)) (checked on the scaled-back value, like torch's
+// _amp_foreach_non_finite_check_and_unscale_)
+__global__ __launch_bounds__(256) void unscale_check_kernel(float* __restrict__ g, int64_t numel, float inv,
+                                                            int* __restrict__ found) {
+  bool bad = false;
+  for (int64_t i = blockIdx.x * (int64_t)256 + threadIdx.x; i < numel; i += (int64_t)gridDim.x * 256) {
+    const float v = g[i];
+    bad = bad || !isfinite(v);
+    g[i] = v * inv;
+  }
+  if (__any(bad) && (threadIdx.x & 63) == 0) atomicOr(found, 1);
+}
+
 // out = x * alpha[0] (alpha on the device: loss-scale / 1/world factors without a host sync)
 __global__ __launch_bounds__(256) void scale_kernel(const float* __restrict__ x, int64_t numel,
                                                     const float* __restrict__ alpha, float mult,
@@ -513,6 +526,14 @@ DSG_API int dsg_clip_scale(float* g, int64_t numel, const float* total_norm, flo
   DSG_CHECK_ARG(g && total_norm && numel > 0 && max_norm > 0, "dsg_clip_scale: bad argument");
   hipLaunchKernelGGL(dsg::clip_scale_kernel, dim3(dsg::stream_blocks2(numel)), dim3(256), 0,
                      static_cast<hipStream_t>(stream), g, numel, total_norm, max_norm);
+  DSG_LAUNCH_CHECK();
+  return DSG_OK;
+}
+
+DSG_API int dsg_unscale_check(float* g, int64_t numel, float inv_scale, int32_t* found_inf, void* stream) {
+  DSG_CHECK_ARG(g && found_inf && numel > 0, "dsg_unscale_check: bad argument");
+  hipLaunchKernelGGL(dsg::unscale_check_kernel, dim3(dsg::stream_blocks2(numel)), dim3(256), 0,
+                     static_cast<hipStream_t>(stream), g, numel, inv_scale, found_inf);
   DSG_LAUNCH_CHECK();
   return DSG_OK;
 }

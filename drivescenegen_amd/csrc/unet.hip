@@ -19,10 +19,12 @@
 #include <map>
 #include <memory>
 #include <string>
+#include <tuple>
 #include <vector>
 
 namespace dsg {
 int conv2d_fwd_impl(const dsg_conv_args* a, hipStream_t st, int force_direct);
+int conv_h2_tuning_epoch();
 }
 
 namespace {
@@ -124,8 +126,14 @@ struct dsg_unet {
   Res mid0, mid1;
   bool mid_attn = false;
   Att mid_att;
-  std::map<int, size_t> ws_cache;
+  std::map<std::tuple<int, int, int>, size_t> ws_cache;  // (batch, blocked layout, tuning epoch) -> workspace bytes
   std::string err;
+  int dt() const { return cfg.compute_dtype; }  // dsg_dtype of the channel-blocked intermediates / matrix-core products
+
+  ~dsg_unet() {
+    for (void* p : allocs)
+      if (p) (void)hipFree(p);
+  }
 
   float* dalloc(int64_t numel) {
     void* p = nullptr;
@@ -146,16 +154,24 @@ struct dsg_unet {
     if (c.w && c.wstride != cout) (void)hipMemset(c.w, 0, (size_t)cin * k * k * c.wstride * sizeof(float));
     c.b = dalloc(cout);
     add_param(pre + ".weight", P_CONV, c.w, (int64_t)cin * k * k * cout, cout, cin, k, c.wstride, 0);
-    if (cin % 16 == 0 && cout % 64 == 0) {  // second copy, pre-split for the fp16x2 matrix-core kernel (same bytes)
-      const int64_t halfs = (int64_t)(cin / 16) * 2 * k * k * 2 * cout * 8;
-      c.wh = dalloc((halfs + 1) / 2);
+    // second copy, packed for the matrix-core kernel: pre-split fp16 pairs (the same bytes as the fp32 copy), or the
+    // weights rounded to the 16-bit compute type (conv_out's 4 / 8 columns are zero-padded to a 64-column tile there)
+    if (cin % 16 == 0 && (cout % 64 == 0 || (dt() != DSG_F32 && cout % 8 == 0))) {
+      auto packed = [&](int kind) -> void* {
+        size_t bytes = 0;
+        if (dsg_conv_weight_pack_bytes(cout, cin, k, kind, dt(), 0, &bytes) != DSG_OK) return nullptr;
+        float* p = dalloc((int64_t)(bytes + 3) / 4);
+        if (p && cout % 64) (void)hipMemset(p, 0, bytes);  // (the padding columns are read by the cout tile)
+        return p;
+      };
+      c.wh = packed(0);
       params.back().wh = c.wh;
       if (downsampler && k == 3) {  // Downsample2D: 2x2 conv over the space-to-depth image (4 cin, 4 of 9 taps)
-        c.whs = dalloc((int64_t)(4 * cin / 16) * 2 * 4 * 2 * cout * 8 / 2);
+        c.whs = packed(2);
         params.back().whs = c.whs;
       }
       if (upsampler && k == 3) {  // Upsample2D + conv as four 2x2 convs of the low-resolution map
-        c.whf = dalloc((int64_t)4 * (cin / 16) * 2 * 4 * 2 * cout * 8 / 2);
+        c.whf = packed(1);
         params.back().whf = c.whf;
       }
     }
@@ -186,7 +202,10 @@ struct dsg_unet {
     a.qkv.cin = c; a.qkv.cout = 3 * c; a.qkv.k = 1; a.qkv.wstride = 3 * c;
     a.qkv.w = dalloc((int64_t)c * 3 * c);
     a.qkv.b = dalloc(3 * c);
-    if (c % 64 == 0) a.qkv.wh = dalloc((int64_t)(c / 16) * 2 * 2 * 3 * c * 8 / 2);
+    if (c % 64 == 0) {
+      size_t bytes = 0;
+      if (dsg_conv_weight_pack_bytes(c, c, 1, 0, dt(), 3 * c, &bytes) == DSG_OK) a.qkv.wh = dalloc((int64_t)(bytes + 3) / 4);
+    }
     const char* names[3] = {"to_q", "to_k", "to_v"};
     for (int i = 0; i < 3; ++i) {
       add_param(pre + "." + names[i] + ".weight", P_CONV, a.qkv.w, (int64_t)c * c, c, c, 1, 3 * c, i * c);
@@ -215,6 +234,10 @@ struct Runner {
   Arena arena;
   int rc = DSG_OK;
   bool blocked = false;  // intermediates channel-blocked (every channel count a multiple of 8; tuning key 13)
+
+  int dt() const { return h->cfg.compute_dtype; }
+  // bytes per element of an activation: channel-blocked intermediates are 16-bit in the mixed-precision modes
+  size_t esz_of(int blk) const { return (blk && dt() != DSG_F32) ? 2 : sizeof(float); }
 
   T alloc(int c, int hh, int w, size_t elems = 0, size_t esz = sizeof(float)) {
     T t;
@@ -245,7 +268,7 @@ struct Runner {
     t.stats = reinterpret_cast<double*>(ws + off);
     t.stiles = splits;
     if (!dry && ok())
-      rc = t.blk ? dsg_gn_channel_stats_blocked(t.p, t.c, B, hw, splits, t.stats, st)
+      rc = t.blk ? dsg_gn_channel_stats_blocked_dt(t.p, t.c, B, hw, splits, t.stats, dt(), st)
                  : dsg_gn_channel_stats(t.p, t.c, nullptr, 0, B, hw, t.stats, st);
   }
 
@@ -276,7 +299,7 @@ struct Runner {
     if (dst_override) {
       y.p = dst_override; y.c = cv.cout; y.h = ho; y.w = wo;
     } else {
-      y = alloc(cv.cout, ho, wo);
+      y = alloc(cv.cout, ho, wo, 0, esz_of(dst_blk));
     }
     dsg_conv_args a;
     std::memset(&a, 0, sizeof(a));
@@ -289,6 +312,7 @@ struct Runner {
     a.residual = res ? res->p : nullptr;
     a.dst = y.p;
     a.src_layout = x.blk; a.dst_layout = dst_blk;
+    a.compute_dtype = dt();
     y.blk = dst_blk;
     if (want_stats && ok()) {
       int32_t tiles = 0;
@@ -325,7 +349,7 @@ struct Runner {
     T ss = gn_ss(x, nullptr, at.gn);
     T qkv = conv(x, nullptr, at.qkv, 1, 0, &ss, 0, nullptr, nullptr, nullptr, false, 0);  // (the attention kernel reads [N,3C,L])
     ss = T();
-    T o = alloc(x.c, x.h, x.w);
+    T o = alloc(x.c, x.h, x.w);  // ([N,C,L] fp32 in every mode, like q/k/v: softmax(QK^T)V runs in fp32-equivalent arithmetic)
     if (!dry && ok()) rc = dsg_attention_fwd(qkv.p, o.p, B, x.c, at.heads, x.h * x.w, st);
     qkv = T();
     return conv(o, nullptr, at.out, 1, 0, nullptr, 0, nullptr, &x, nullptr, true);
@@ -333,8 +357,10 @@ struct Runner {
 
   int run(const float* xin, const int64_t* t, float* out) {
     const dsg_unet_config& cfg = h->cfg;
-    blocked = dsg::unet_blocked() != 0;
+    blocked = dsg::unet_blocked() != 0 || dt() != DSG_F32;  // (the 16-bit modes exist for channel-blocked tensors only)
     for (int i = 0; i < cfg.num_blocks; ++i) blocked = blocked && cfg.block_out_channels[i] % 8 == 0;
+    if (dt() != DSG_F32 && !blocked)
+      return rc = dsg::fail(DSG_ERR_UNSUPPORTED_SHAPE, "dsg_unet_forward: the bf16 / fp16 modes need block_out_channels %% 8 == 0");
     T act = alloc(0, 0, 0, (size_t)B * h->temb_dim);
     T tproj = alloc(0, 0, 0, (size_t)B * h->proj_total);
     if (!dry) {
@@ -393,6 +419,8 @@ int check_cfg(const dsg_unet_config* c) {
                   "dsg_unet_create: block_out_channels[%d]=%d not a positive multiple of norm_num_groups=%d", i, ch,
                   c->norm_num_groups);
   }
+  DSG_CHECK_ARG(c->compute_dtype >= DSG_F32 && c->compute_dtype <= DSG_F16,
+                "dsg_unet_create: compute_dtype must be DSG_F32, DSG_BF16 or DSG_F16 (got %d)", c->compute_dtype);
   const int f = 1 << (c->num_blocks - 1);
   DSG_CHECK_ARG(c->sample_h % f == 0 && c->sample_w % f == 0,
                 "dsg_unet_create: sample size %dx%d not divisible by 2^(num_blocks-1)=%d", c->sample_h, c->sample_w,
@@ -508,12 +536,7 @@ DSG_API int dsg_unet_create(const dsg_unet_config* cfg, dsg_unet_t** out) {
   return DSG_OK;
 }
 
-DSG_API void dsg_unet_destroy(dsg_unet_t* h) {
-  if (!h) return;
-  for (void* p : h->allocs)
-    if (p) (void)hipFree(p);
-  delete h;
-}
+DSG_API void dsg_unet_destroy(dsg_unet_t* h) { delete h; }  // (~dsg_unet frees the plan's device memory)
 
 DSG_API int dsg_unet_set_param(dsg_unet_t* h, const char* name, const float* data, int64_t numel, void* stream) {
   DSG_CHECK_ARG(h && name && data, "dsg_unet_set_param: NULL argument");
@@ -544,16 +567,18 @@ DSG_API int dsg_unet_set_param(dsg_unet_t* h, const char* name, const float* dat
   } else {
     int rc = dsg_conv_weight_relayout(data, p.dst, p.cout, p.cin, p.k, p.cout_total, p.cout_off, stream);
     if (rc != DSG_OK) return rc;
-    if (p.wh) {
-      rc = dsg_conv_weight_relayout_h2(data, p.wh, p.cout, p.cin, p.k, p.cout_total, p.cout_off, stream);
+    const int dt = h->dt();
+    if (p.wh) {  // (a column window only where the packed matrix is wider than this weight: the fused q/k/v projection)
+      const bool window = p.cout_off != 0 || p.cout_total > (p.cout + 63) / 64 * 64;
+      rc = dsg_conv_weight_pack(data, p.wh, p.cout, p.cin, p.k, 0, dt, window ? p.cout_total : 0, p.cout_off, stream);
       if (rc != DSG_OK) return rc;
     }
     if (p.whf) {
-      rc = dsg_conv_weight_relayout_h2_fold(data, p.whf, p.cout, p.cin, stream);
+      rc = dsg_conv_weight_pack(data, p.whf, p.cout, p.cin, 3, 1, dt, 0, 0, stream);
       if (rc != DSG_OK) return rc;
     }
     if (p.whs) {
-      rc = dsg_conv_weight_relayout_h2_s2(data, p.whs, p.cout, p.cin, stream);
+      rc = dsg_conv_weight_pack(data, p.whs, p.cout, p.cin, 3, 2, dt, 0, 0, stream);
       if (rc != DSG_OK) return rc;
     }
   }
@@ -587,11 +612,13 @@ DSG_API int dsg_unet_param_name(const dsg_unet_t* h, int64_t index, const char**
 DSG_API int dsg_unet_workspace_bytes(dsg_unet_t* h, int32_t batch, size_t* bytes) {
   DSG_CHECK_ARG(h && bytes, "dsg_unet_workspace_bytes: NULL argument");
   DSG_CHECK_ARG(batch > 0, "dsg_unet_workspace_bytes: batch must be positive");
-  const int key = 2 * batch + (dsg::unet_blocked() ? 1 : 0);  // (the layout decides which convs write statistics)
+  // (the layout and the kernel-selection switches decide which convs write statistics, hence the arena's layout)
+  const auto key = std::make_tuple((int)batch, dsg::unet_blocked() ? 1 : 0, dsg::conv_h2_tuning_epoch());
   auto it = h->ws_cache.find(key);
   if (it == h->ws_cache.end()) {
     Runner r{h, batch, nullptr, true, nullptr};
-    r.run(nullptr, nullptr, nullptr);
+    const int rc = r.run(nullptr, nullptr, nullptr);
+    if (rc != DSG_OK) return rc;
     it = h->ws_cache.emplace(key, r.arena.high).first;
   }
   *bytes = it->second;
@@ -611,5 +638,9 @@ DSG_API int dsg_unet_forward(dsg_unet_t* h, const float* x, const int64_t* times
     return fail(DSG_ERR_WORKSPACE_TOO_SMALL, "dsg_unet_forward: workspace %zu bytes < required %zu", workspace_bytes,
                 need);
   Runner r{h, batch, static_cast<char*>(workspace), false, static_cast<hipStream_t>(stream)};
-  return r.run(x, timesteps, out);
+  rc = r.run(x, timesteps, out);
+  if (rc == DSG_OK && r.arena.high > workspace_bytes)  // (cannot happen while the dry run and the live run agree)
+    return fail(DSG_ERR_WORKSPACE_TOO_SMALL, "dsg_unet_forward: the run carved %zu bytes from a %zu-byte workspace",
+                r.arena.high, workspace_bytes);
+  return rc;
 }

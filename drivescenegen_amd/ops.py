@@ -36,6 +36,38 @@ def relayout_conv_weight(w_oihw: torch.Tensor, out: torch.Tensor = None, cout_to
     return out
 
 
+_DT_OF = {torch.float32: _lib.DSG_F32, torch.bfloat16: _lib.DSG_BF16, torch.float16: _lib.DSG_F16}
+PACK_FWD, PACK_FOLD, PACK_S2, PACK_DGRAD, PACK_DGRAD_S2 = 0, 1, 2, 3, 4
+
+
+def dtype_code(dtype) -> int:
+    """"fp32" | "bf16" | "fp16" | torch dtype | dsg_dtype code -> dsg_dtype code (include/dsg.h)."""
+    if isinstance(dtype, int):
+        return dtype
+    if dtype in _DT_OF:
+        return _DT_OF[dtype]
+    return _lib.DTYPE_CODES[dtype or "fp32"]
+
+
+def pack_conv_weight(w_oihw: torch.Tensor, kind: int = PACK_FWD, dtype=0, n_total: int = 0, n_off: int = 0,
+                     out: torch.Tensor = None) -> torch.Tensor:
+    """dsg_conv_weight_pack: OIHW fp32 -> the matrix-core operand image for `kind` (PACK_*) in dsg_dtype `dtype`
+    (DSG_F32: (hi, scaled lo) fp16 pairs of the fp32-equivalent split; DSG_BF16 / DSG_F16: rounded once).
+    Returns a flat int16 buffer (the layout is the kernel's, see include/dsg.h)."""
+    w = w_oihw.contiguous()
+    cout, cin = w.shape[0], w.shape[1]
+    k = w.shape[2] if w.dim() == 4 else 1
+    dt = dtype_code(dtype)
+    lib = _lib.load()
+    if out is None:
+        nbytes = C.c_size_t()
+        _lib.check(lib.dsg_conv_weight_pack_bytes(cout, cin, k, kind, dt, n_total, C.byref(nbytes)))
+        out = torch.zeros(nbytes.value // 2, dtype=torch.int16, device=w.device)
+    with torch.cuda.device(w.device):
+        _lib.check(lib.dsg_conv_weight_pack(_lib.ptr(w), out.data_ptr(), cout, cin, k, kind, dt, n_total, n_off, _st(w)))
+    return out
+
+
 def relayout_conv_weight_h2(w_oihw: torch.Tensor, out: torch.Tensor = None, cout_total: int = None,
                             cout_off: int = 0) -> torch.Tensor:
     """OIHW 3x3 / 1x1 / Linear (cin % 16 == 0) -> fp16x2-split engine layout [Cin/16][2][k*k][2][cout_pad64][8]."""
@@ -103,13 +135,21 @@ def relayout_conv_weight_dgrad(w_oihw: torch.Tensor, out: torch.Tensor = None) -
 def conv2d_fused(src0, weight_r, bias=None, src1=None, ksize=3, stride=1, upsample=False, gn_scale_shift=None,
                  silu=False, temb=None, temb_stride=0, residual=None, out=None, direct=False, cout=None,
                  pool2=False, wstride=None, weight_h2=None, want_stats=False, stats_buf=None, weight_h2_col=0, weight_h2_fold=None,
-                 src_blocked=False, dst_blocked=False, weight_h2_s2=None):
+                 src_blocked=False, dst_blocked=False, weight_h2_s2=None, compute_dtype=0, weight_h2_stride=0):
     """dsg_conv2d_fwd: see include/dsg.h.  `weight_r` is in engine layout; `temb` is a [N, temb_stride] view
     whose first `cout` columns (from its data pointer) are added per (n, cout).
     want_stats: also return the per-tile GroupNorm statistics [N][cout][tiles][2] (fp64) of the result, or None
     when the kernel serving the call does not produce them.
-    src_blocked / dst_blocked: the sources / (result, residual) are channel-blocked [N, C/8, H, W, 8] tensors."""
+    src_blocked / dst_blocked: the sources / (result, residual) are channel-blocked [N, C/8, H, W, 8] tensors.
+    compute_dtype: dsg_dtype ("bf16" / "fp16" / code): the channel-blocked tensors are then torch.bfloat16 / float16 and
+    weight_h2* must come from pack_conv_weight(..., dtype=the same); [N, C, H, W] tensors stay fp32."""
     lib = _lib.load()
+    cdt = dtype_code(compute_dtype)
+    blk_dtype = _lib.TORCH_DTYPES[cdt]
+    for t, blocked in ((src0, src_blocked), (src1, src_blocked), (residual, dst_blocked), (out, dst_blocked)):
+        if t is not None and t.dtype != (blk_dtype if blocked else torch.float32):
+            raise RuntimeError(f"conv2d_fused: tensor dtype {t.dtype} does not match compute_dtype / layout "
+                               f"(channel-blocked: {blk_dtype}, [N,C,H,W]: float32)")
     if src_blocked:
         n, cb0, hin, win, _ = src0.shape
         c0 = 8 * cb0
@@ -128,17 +168,21 @@ def conv2d_fused(src0, weight_r, bias=None, src1=None, ksize=3, stride=1, upsamp
         shape = (n, cout, ho // 2, wo // 2) if pool2 else (n, cout, ho, wo)
         if dst_blocked:
             shape = (n, cout // 8, shape[2], shape[3], 8)
-        out = torch.empty(shape, dtype=torch.float32, device=src0.device)
+        out = torch.empty(shape, dtype=blk_dtype if dst_blocked else torch.float32, device=src0.device)
     a = _lib.ConvArgs()
+    a.compute_dtype = cdt
     a.src_layout, a.dst_layout = int(src_blocked), int(dst_blocked)
     a.src0, a.src1 = _lib.ptr(src0), _lib.ptr(src1)
     a.c0, a.c1, a.n, a.hin, a.win = c0, c1, n, hin, win
     a.upsample, a.ksize, a.stride, a.cout = int(upsample), ksize, stride, cout
     a.weight, a.bias = wptr, _lib.ptr(bias)
     a.weight_cout_stride, a.pool2 = wstride, int(pool2)
-    if weight_h2 is not None:   # [K/16][2][taps][2][cout_total_pad][8] halfs; weight_h2_col selects a column window
+    if weight_h2 is not None:   # [K/16][pieces][taps][2][cout_total_pad][8] halfs; weight_h2_col selects a column window
         a.weight_h2 = weight_h2.data_ptr() + 16 * int(weight_h2_col)
-        a.weight_h2_cout_stride = weight_h2.shape[-2] if weight_h2_col or weight_h2.shape[-2] != (cout + 63) // 64 * 64 else 0
+        if weight_h2_stride:    # flat buffers from pack_conv_weight: the row length is given
+            a.weight_h2_cout_stride = int(weight_h2_stride)
+        elif weight_h2.dim() >= 2:
+            a.weight_h2_cout_stride = weight_h2.shape[-2] if weight_h2_col or weight_h2.shape[-2] != (cout + 63) // 64 * 64 else 0
     a.weight_h2_fold = weight_h2_fold.data_ptr() if weight_h2_fold is not None else None
     a.weight_h2_s2 = weight_h2_s2.data_ptr() if weight_h2_s2 is not None else None
     a.gn_scale_shift, a.silu = _lib.ptr(gn_scale_shift), int(silu)
@@ -161,31 +205,34 @@ def conv2d_fused(src0, weight_r, bias=None, src1=None, ksize=3, stride=1, upsamp
     return (out, stats) if want_stats else out
 
 
-def to_blocked(x):
-    """[N, C, H, W] -> channel-blocked [N, C/8, H, W, 8] (dsg_layout_convert)."""
+def to_blocked(x, dtype=0):
+    """fp32 [N, C, H, W] -> channel-blocked [N, C/8, H, W, 8] stored as dsg_dtype `dtype` (dsg_layout_convert_dt)."""
     n, c, h, w = x.shape
-    out = torch.empty((n, c // 8, h, w, 8), dtype=torch.float32, device=x.device)
+    dt = dtype_code(dtype)
+    out = torch.empty((n, c // 8, h, w, 8), dtype=_lib.TORCH_DTYPES[dt], device=x.device)
     with torch.cuda.device(x.device):
-        _lib.check(_lib.load().dsg_layout_convert(_lib.ptr(x), _lib.ptr(out), n, c, h * w, 1, _st(x)))
+        _lib.check(_lib.load().dsg_layout_convert_dt(_lib.ptr(x), _lib.ptr(out), n, c, h * w, 1, dt, _st(x)))
     return out
 
 
 def from_blocked(x):
-    """channel-blocked [N, C/8, H, W, 8] -> [N, C, H, W]."""
+    """channel-blocked [N, C/8, H, W, 8] (fp32 / bf16 / fp16) -> fp32 [N, C, H, W]."""
     n, cb, h, w, _ = x.shape
     out = torch.empty((n, cb * 8, h, w), dtype=torch.float32, device=x.device)
     with torch.cuda.device(x.device):
-        _lib.check(_lib.load().dsg_layout_convert(_lib.ptr(x), _lib.ptr(out), n, cb * 8, h * w, 0, _st(x)))
+        _lib.check(_lib.load().dsg_layout_convert_dt(_lib.ptr(x), _lib.ptr(out), n, cb * 8, h * w, 0, _DT_OF[x.dtype],
+                                                     _st(x)))
     return out
 
 
 def gn_channel_stats_blocked(x, splits=1):
-    """dsg_gn_channel_stats_blocked: per-(n, c) (sum, sum of squares) of a channel-blocked tensor as `splits` partial
-    sums over equal runs of pixels, fp64 [N][C][splits][2]."""
+    """dsg_gn_channel_stats_blocked_dt: per-(n, c) (sum, sum of squares) of a channel-blocked tensor (fp32 / bf16 /
+    fp16) as `splits` partial sums over equal runs of pixels, fp64 [N][C][splits][2]."""
     n, cb, h, w, _ = x.shape
     st = torch.empty((n, cb * 8, splits, 2), dtype=torch.float64, device=x.device)
     with torch.cuda.device(x.device):
-        _lib.check(_lib.load().dsg_gn_channel_stats_blocked(_lib.ptr(x), cb * 8, n, h * w, splits, _lib.ptr(st), _st(x)))
+        _lib.check(_lib.load().dsg_gn_channel_stats_blocked_dt(_lib.ptr(x), cb * 8, n, h * w, splits, _lib.ptr(st),
+                                                               _DT_OF[x.dtype], _st(x)))
     return st
 
 
@@ -506,6 +553,13 @@ def l2_norm(x):
         _lib.check(_lib.load().dsg_l2_norm(_lib.ptr(x), x.numel(), _lib.ptr(out), _lib.ptr(ws), ws.numel() * 8,
                                           _st(x)))
     return out
+
+
+def unscale_check_(g, inv_scale, found_inf):
+    """GradScaler.unscale_: g *= inv_scale in place; found_inf (device int32 [1]) |= any non-finite element."""
+    with torch.cuda.device(g.device):
+        _lib.check(_lib.load().dsg_unscale_check(_lib.ptr(g), g.numel(), float(inv_scale), found_inf.data_ptr(), _st(g)))
+    return g
 
 
 def clip_scale_(g, total_norm, max_norm):

@@ -64,6 +64,7 @@ def _slab_of(params):
     flat = SLABS.get(base)
     if flat is None:
         return None, []
+    flat = flat[0]
     rows = []
     for p in params:
         g = p.grad
@@ -84,7 +85,9 @@ def clip_grad_norm_(parameters, max_norm: float, norm_type: float = 2.0):
     if not params[0].grad.is_cuda:
         raise RuntimeError("drivescenegen_amd.clip_grad_norm_ runs on the MI355X HIP engine only")
     flat, rows = _slab_of(params)
-    if flat is not None and sum(r[2] for r in rows) >= 0.5 * flat.numel():
+    # the one-kernel path is taken only when the passed parameters are EVERY slice of the slab: for a proper subset
+    # (frozen layers, param groups) the norm must not see -- and the scaling must not touch -- the other gradients
+    if flat is not None and len(rows) == SLABS[flat.untyped_storage().data_ptr()][1]:
         total = ops.l2_norm(flat)  # slab padding is zero
         ops.clip_scale_(flat, total, max_norm)
     else:  # gradients living in separate tensors: one norm per tensor, combined on the device
@@ -245,20 +248,81 @@ class GradBuckets:
 # accelerate.Accelerator, the subset training_pipeline.py:48-61,82-101 uses
 # ------------------------------------------------------------------------------------------------
 class _ShardedLoader:
-    """accelerate's prepared DataLoader: every rank sees its own batches of the full batch size
-    (rank r takes batches r, r+W, ...), tensors are moved to the device."""
+    """accelerate's prepared DataLoader (``BatchSamplerShard`` with ``even_batches=True`` + ``synchronize_rng_states``):
+    every rank gets its own batches of the FULL batch size -- rank r takes batches r, r+W, ... of one global batch
+    order that is identical on all ranks -- and every rank runs the SAME number of steps per epoch: when the batch
+    count is not a multiple of the world size (or the last batch is short) the tail is completed with samples from
+    the start of the epoch's order, so no rank waits in a collective that the others never join.
+
+    The global order comes from the loader's own sampler when it is sequential; for a shuffling loader
+    (train.py:35 ``shuffle=True``) rank 0 draws a seed from the global CPU generator and broadcasts it, and every
+    rank builds the same permutation from it -- the shards are then a partition of the dataset."""
 
     def __init__(self, loader, device, rank, world):
         self.loader, self.device, self.rank, self.world = loader, device, rank, world
+        self.dataset = getattr(loader, "dataset", None)
+        self.batch_size = getattr(loader, "batch_size", None)
+        self.drop_last = bool(getattr(loader, "drop_last", False))
+        sampler = getattr(loader, "sampler", None)
+        self.shuffle = isinstance(sampler, torch.utils.data.RandomSampler)
+        self.index_mode = (self.dataset is not None and self.batch_size is not None and hasattr(self.dataset, "__getitem__")
+                           and isinstance(sampler, (torch.utils.data.RandomSampler, torch.utils.data.SequentialSampler)))
+        self.epoch_seed = None  # the seed the current epoch's permutation was built from (tests / resume)
+
+    def _num_batches(self):
+        n, b = len(self.dataset), self.batch_size
+        return n // b if self.drop_last else math.ceil(n / b)
 
     def __len__(self):
-        return math.ceil(len(self.loader) / self.world)
+        nb = self._num_batches() if self.index_mode else len(self.loader)
+        return math.ceil(nb / self.world)
+
+    def _to_device(self, batch):
+        return batch.to(self.device, non_blocking=True) if torch.is_tensor(batch) else batch
+
+    def _global_order(self):
+        n = len(self.dataset)
+        if not self.shuffle:
+            return list(range(n))
+        seed = torch.zeros(1, dtype=torch.int64)
+        if self.rank == 0:
+            seed = torch.randint(0, 2 ** 62, (1,), dtype=torch.int64)  # global CPU generator, like RandomSampler
+        if self.world > 1 and dist.is_initialized():
+            if dist.get_backend() == "nccl":
+                dev_seed = seed.to(self.device)
+                dist.broadcast(dev_seed, src=0)
+                seed = dev_seed.cpu()
+            else:
+                dist.broadcast(seed, src=0)
+        self.epoch_seed = int(seed.item())
+        g = torch.Generator()
+        g.manual_seed(self.epoch_seed)
+        return torch.randperm(n, generator=g).tolist()
 
     def __iter__(self):
-        for i, batch in enumerate(self.loader):
-            if i % self.world != self.rank:
-                continue
-            yield batch.to(self.device, non_blocking=True) if torch.is_tensor(batch) else batch
+        if not self.index_mode:  # opaque loader: rank r keeps every W-th batch, the tail wraps to the first batches
+            head, count = [], 0
+            for i, batch in enumerate(self.loader):
+                if i < self.world:
+                    head.append(batch)
+                count += 1
+                if i % self.world == self.rank:
+                    yield self._to_device(batch)
+            for j in range(count, math.ceil(count / self.world) * self.world):
+                if j % self.world == self.rank:
+                    yield self._to_device(head[(j - count) % len(head)])
+            return
+        order, b = self._global_order(), self.batch_size
+        if self.drop_last:
+            order = order[:len(order) // b * b]
+        per_round = b * self.world
+        if order and len(order) % per_round:  # even_batches: complete the last round from the start of the order
+            need = per_round - len(order) % per_round
+            order = order + [order[i % len(order)] for i in range(need)]
+        collate = self.loader.collate_fn
+        for k in range(self.rank, len(order) // b, self.world):
+            idx = order[k * b:(k + 1) * b]
+            yield self._to_device(collate([self.dataset[i] for i in idx]))
 
 
 class _SteppedScheduler:
@@ -269,7 +333,7 @@ class _SteppedScheduler:
         self.sched, self.world, self.accel = sched, world, accel
 
     def step(self, *a, **k):
-        if not self.accel.sync_gradients:
+        if not self.accel.sync_gradients or self.accel.optimizer_step_was_skipped:
             return
         for _ in range(self.world):
             self.sched.step(*a, **k)
@@ -281,14 +345,114 @@ class _SteppedScheduler:
         return getattr(self.sched, n)
 
 
+class GradScaler:
+    """``torch.cuda.amp.GradScaler`` as accelerate drives it under ``mixed_precision='fp16'`` (train.py:24; SURVEY
+    App. A.6): the loss is multiplied by ``scale`` before backward, gradients are un-scaled (and checked for
+    inf / nan) before clipping, a step whose gradients are not finite is SKIPPED and halves the scale, 2000 clean
+    steps in a row double it.  The arithmetic (scaling, the finite check) runs in libdsg.so."""
+
+    def __init__(self, init_scale=65536.0, growth_factor=2.0, backoff_factor=0.5, growth_interval=2000):
+        self.scale = float(init_scale)
+        self.growth_factor, self.backoff_factor, self.growth_interval = growth_factor, backoff_factor, growth_interval
+        self._growth_tracker = 0
+        self._unscaled = False
+        self._found = None  # device int32 flag of the current step
+
+    def get_scale(self):
+        return self.scale
+
+    def unscale_(self, params):
+        if self._unscaled:
+            return
+        params = [p for p in params if p.grad is not None]
+        if not params:
+            return
+        dev = params[0].grad.device
+        self._found = torch.zeros(1, dtype=torch.int32, device=dev)
+        flat, rows = _slab_of(params)
+        if flat is not None and len(rows) == SLABS[flat.untyped_storage().data_ptr()][1]:
+            ops.unscale_check_(flat, 1.0 / self.scale, self._found)
+        else:
+            for p in params:
+                ops.unscale_check_(p.grad.view(-1), 1.0 / self.scale, self._found)
+        self._unscaled = True
+
+    def step(self, optimizer, params):
+        """Runs ``optimizer.step()`` unless this step's gradients hold an inf / nan; returns True when skipped."""
+        self.unscale_(params)
+        skipped = self._found is not None and bool(self._found.item())  # (one D2H sync per step, as torch's scaler)
+        if not skipped:
+            optimizer.step()
+        return skipped
+
+    def update(self, skipped):
+        if skipped:
+            self.scale *= self.backoff_factor
+            self._growth_tracker = 0
+        else:
+            self._growth_tracker += 1
+            if self._growth_tracker == self.growth_interval:
+                self.scale *= self.growth_factor
+                self._growth_tracker = 0
+        self._unscaled, self._found = False, None
+
+    def state_dict(self):
+        return {"scale": self.scale, "growth_tracker": self._growth_tracker}
+
+    def load_state_dict(self, sd):
+        self.scale, self._growth_tracker = float(sd["scale"]), int(sd["growth_tracker"])
+
+
+class _PreparedOptimizer:
+    """accelerate's ``AcceleratedOptimizer``: ``step`` / ``zero_grad`` do nothing on micro-batches whose gradients
+    are still being accumulated (``accelerator.sync_gradients`` False), and under fp16 the step goes through the
+    GradScaler (skipped when the gradients are not finite -- the LR scheduler then skips too)."""
+
+    def __init__(self, optimizer, accel):
+        self.optimizer, self.accel = optimizer, accel
+
+    def _params(self):
+        return [p for g in self.optimizer.param_groups for p in g["params"]]
+
+    def step(self, closure=None):
+        a = self.accel
+        if not a.sync_gradients:
+            return None
+        if a.scaler is not None:
+            skipped = a.scaler.step(self.optimizer, self._params())
+            a.scaler.update(skipped)
+            a.optimizer_step_was_skipped = skipped
+            return None
+        a.optimizer_step_was_skipped = False
+        return self.optimizer.step(closure) if closure is not None else self.optimizer.step()
+
+    def zero_grad(self, set_to_none=None):
+        if self.accel.sync_gradients:
+            self.optimizer.zero_grad()
+
+    @property
+    def step_was_skipped(self):
+        return self.accel.optimizer_step_was_skipped
+
+    def __getattr__(self, n):
+        return getattr(self.optimizer, n)
+
+
+_MIXED = {"no": "fp32", None: "fp32", "fp16": "fp16", "bf16": "bf16"}
+
+
 class Accelerator:
     def __init__(self, mixed_precision="no", gradient_accumulation_steps=1, log_with=None, project_dir=None,
                  device=None):
-        # The engine computes in fp32; 'fp16' (the reference's train.py:24) and 'bf16' are accepted and run
-        # fp32, which is >= the reference's precision (no GradScaler, so no skipped steps).
-        if mixed_precision not in ("no", "fp16", "bf16", None):
+        # mixed_precision (train.py:24 ships 'fp16'; BASELINE configs[4] names bf16): the prepared model runs its
+        # convolutions / projections on the f16 / bf16 matrix cores with 16-bit activations in HBM and fp32
+        # GroupNorm statistics, softmax, accumulators, master weights and optimizer -- torch.autocast's split.
+        # 'fp16' adds the GradScaler (skipped steps on inf / nan); 'bf16' needs none; 'no' is the fp32-equivalent engine.
+        if mixed_precision not in _MIXED:
             raise ValueError(f"mixed_precision={mixed_precision!r}")
-        self.mixed_precision = mixed_precision
+        self.mixed_precision = mixed_precision or "no"
+        self.scaler = GradScaler() if self.mixed_precision == "fp16" else None
+        self.optimizer_step_was_skipped = False
         self.gradient_accumulation_steps = int(gradient_accumulation_steps)
         self.project_dir = project_dir
         self.log_with = log_with
@@ -358,12 +522,16 @@ class Accelerator:
             if isinstance(o, torch.nn.Module):
                 o.to(self.device)
                 self._model = o
+                if hasattr(o, "set_compute_dtype"):
+                    o.set_compute_dtype(_MIXED[self.mixed_precision])
                 if self.world > 1:
                     for p in o.parameters():  # identical replicas: rank 0's initial weights
                         dist.broadcast(p.data, src=0)
                 out.append(o)
             elif isinstance(o, torch.utils.data.DataLoader):
                 out.append(_ShardedLoader(o, self.device, self.rank, self.world))
+            elif isinstance(o, torch.optim.Optimizer):
+                out.append(_PreparedOptimizer(o, self))
             elif isinstance(o, torch.optim.lr_scheduler.LRScheduler):
                 out.append(_SteppedScheduler(o, self.world, self))
             else:
@@ -391,8 +559,11 @@ class Accelerator:
 
     def backward(self, loss):
         b = self._ensure_buckets()
-        if self.gradient_accumulation_steps > 1:
-            loss = _ScaleLoss.apply(loss, 1.0 / self.gradient_accumulation_steps)
+        mult = 1.0 / self.gradient_accumulation_steps
+        if self.scaler is not None:
+            mult *= self.scaler.get_scale()
+        if mult != 1.0:
+            loss = _ScaleLoss.apply(loss, mult)
         loss.backward()
         if b is not None and self.sync_gradients:
             b.finish()
@@ -400,6 +571,9 @@ class Accelerator:
     def clip_grad_norm_(self, parameters, max_norm, norm_type=2):
         if not self.sync_gradients:
             return None
+        parameters = list(parameters)
+        if self.scaler is not None:  # accelerate: scaler.unscale_(optimizer) before the clip
+            self.scaler.unscale_(parameters)
         return clip_grad_norm_(parameters, max_norm, float(norm_type))
 
 

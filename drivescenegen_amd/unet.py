@@ -169,6 +169,7 @@ class UNet2DModel(nn.Module):
         self.conv_norm_out = nn.GroupNorm(g, boc[0], eps=eps)
         self.conv_out = nn.Conv2d(boc[0], c.out_channels, 3, padding=1)
 
+        self.compute_dtype = "fp32"  # "fp32" | "bf16" | "fp16": see set_compute_dtype
         self._plan = None          # dsg_unet_t* (c_void_p)
         self._plan_state = {}      # name -> (data_ptr, version) last pushed
         self._plan_device = None
@@ -191,6 +192,18 @@ class UNet2DModel(nn.Module):
             return ss, ss
         return int(ss[0]), int(ss[1])
 
+    def set_compute_dtype(self, dtype):
+        """Arithmetic of the convolutions / projections: "fp32" (fp32-equivalent, the default), "bf16" or "fp16" --
+        what ``torch.autocast`` does to this network under accelerate's ``mixed_precision`` (train.py:24,
+        training_pipeline.py:48-49): 16-bit matrix-core products and 16-bit activations between layers, fp32
+        parameters / GroupNorm statistics / softmax / accumulators / outputs.  torch dtypes are accepted too."""
+        names = {torch.float32: "fp32", torch.bfloat16: "bf16", torch.float16: "fp16", "no": "fp32", None: "fp32"}
+        dtype = names.get(dtype, dtype)
+        if dtype not in _lib.DTYPE_CODES:
+            raise ValueError(f"compute dtype {dtype!r} not in {sorted(_lib.DTYPE_CODES)}")
+        self.compute_dtype = dtype
+        return self
+
     # ---- plan management -----------------------------------------------------------------------
     def _destroy_plan(self):
         if self._plan is not None:
@@ -206,7 +219,7 @@ class UNet2DModel(nn.Module):
 
     def _ensure_plan(self, h, w, device):
         lib = _lib.load()
-        key = (h, w, str(device))
+        key = (h, w, str(device), self.compute_dtype)
         if self._plan is None or self._plan_device != key:
             self._destroy_plan()
             c = self.config
@@ -223,6 +236,7 @@ class UNet2DModel(nn.Module):
             cfg.norm_eps = c.norm_eps
             cfg.attention_head_dim = c.attention_head_dim
             cfg.add_attention = int(bool(c.add_attention))
+            cfg.compute_dtype = _lib.DTYPE_CODES[self.compute_dtype]
             hnd = C.c_void_p()
             with torch.cuda.device(device):
                 _lib.check(lib.dsg_unet_create(C.byref(cfg), C.byref(hnd)))
@@ -344,6 +358,8 @@ class UNet2DModel(nn.Module):
         for k, v in sd.items():
             for a, b in legacy.items():
                 k = k.replace(a, b)
-            fixed[k] = v.float() if torch_dtype is None else v.to(torch_dtype)
+            fixed[k] = v.float()  # parameters are fp32 master copies in every mode
         model.load_state_dict(fixed, strict=True)
+        if torch_dtype is not None:  # diffusers casts the module; here the dtype selects the engine's arithmetic
+            model.set_compute_dtype(torch_dtype)
         return model

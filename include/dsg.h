@@ -9,7 +9,11 @@
  *
  * Conventions
  *  - every tensor is a raw DEVICE pointer, fp32, contiguous; activations NCHW, as the reference's
- *    checkpoints and call sites use (train.py:39-57, training_pipeline.py:84);
+ *    checkpoints and call sites use (train.py:39-57, training_pipeline.py:84).  The mixed-precision modes
+ *    (dsg_dtype: the reference trains under Accelerator(mixed_precision='fp16'), train.py:24 /
+ *    training_pipeline.py:48-49; BASELINE.json configs[4] names bf16) keep that boundary: parameters,
+ *    [N,C,H,W] tensors, GroupNorm statistics, softmax, accumulators and the optimizer stay fp32, only the
+ *    engine's channel-blocked intermediates and the matrix-core operands are 16-bit (torch.autocast's split);
  *  - the caller owns every buffer, including workspaces; nothing is allocated per call; only
  *    dsg_unet_* handles own device memory (their re-laid-out weights) until dsg_unet_destroy;
  *  - `stream` is a hipStream_t passed as void*; calls enqueue and return without synchronising;
@@ -34,6 +38,12 @@ typedef enum {
   DSG_ERR_HIP = -4,
   DSG_ERR_NOT_READY = -5
 } dsg_status;
+
+/* Arithmetic type of the matrix-core products (and storage type of channel-blocked tensors):
+ *   DSG_F32   fp32-equivalent: fp32 tensors; products as an fp16x2 split on the f16 matrix cores, or the f32 MFMA
+ *   DSG_BF16  bf16 operands / tensors, fp32 accumulate             (BASELINE.json configs[4])
+ *   DSG_F16   fp16 operands / tensors, fp32 accumulate             (train.py:24 mixed_precision='fp16') */
+typedef enum { DSG_F32 = 0, DSG_BF16 = 1, DSG_F16 = 2 } dsg_dtype;
 
 int dsg_version(void);
 const char* dsg_last_error(void);
@@ -93,11 +103,22 @@ typedef struct {
   const void* weight_h2_s2;     /* optional, stride == 2 with channel-blocked src and dst only: the 3x3 weights laid out for
                                    the 2x2 conv over the space-to-depth image (dsg_conv_weight_relayout_h2_s2); the
                                    down-sampler conv then runs on the split path too */
+  int32_t compute_dtype;        /* dsg_dtype.  DSG_F32 (0): everything above as described.  DSG_BF16 / DSG_F16: the
+                                   channel-blocked tensors (src_layout / dst_layout == 1: src0, src1 / dst, residual) are
+                                   stored in that 16-bit type, [N, C, H, W] tensors stay fp32; products run once on the
+                                   bf16 / f16 matrix cores with fp32 accumulation; GroupNorm affine + SiLU are evaluated in
+                                   fp32 before the operand is rounded; bias / temb / scale_shift / stats stay fp32 / fp64.
+                                   weight_h2* must then come from dsg_conv_weight_pack(..., the same dtype).  Served:
+                                   the matrix-core shapes with at least one channel-blocked side, conv_in (fp32 image ->
+                                   blocked) and conv_out (blocked -> fp32 image); anything else is DSG_ERR_UNSUPPORTED_SHAPE. */
 } dsg_conv_args;
 
 int dsg_conv2d_fwd(const dsg_conv_args* a, void* stream);
 /* [N, C, H, W] <-> [N, C/8, H, W, 8] (to_blocked: 1 | 0); C % 8 == 0; src != dst */
 int dsg_layout_convert(const float* src, float* dst, int32_t n, int32_t c, int32_t hw, int32_t to_blocked, void* stream);
+/* the same with the channel-blocked side stored as blocked_dtype (the [N, C, H, W] side is always fp32) */
+int dsg_layout_convert_dt(const void* src, void* dst, int32_t n, int32_t c, int32_t hw, int32_t to_blocked,
+                          int32_t blocked_dtype, void* stream);
 /* Number of spatial tiles per (n, cout) this call would write into stats_out; 0 when the kernel that serves the
  * call cannot produce the statistics (then run dsg_gn_channel_stats on dst instead). Host-only. */
 int dsg_conv2d_stats_tiles(const dsg_conv_args* a, int32_t* tiles);
@@ -111,6 +132,17 @@ int dsg_conv_weight_relayout(const float* w_oihw, float* dst, int32_t cout, int3
  * so that w == hi + lo * 2^-11 to 2^-24 relative (fp32-equivalent contraction on the f16 MFMA, conv_h2.hip). */
 int dsg_conv_weight_relayout_h2(const float* w_oihw, void* dst_half, int32_t cout, int32_t cin, int32_t ksize,
                                 int32_t cout_total /* 0 = cout */, int32_t cout_off, void* stream);
+/* Generic form of the four *_h2* packers below, for every dsg_dtype: OIHW fp32 -> the matrix-core operand image
+ * [phase][K/16][pieces][taps][2][n_total padded to 64][8] of 16-bit values; pieces = 2 (hi, 2^11-scaled lo fp16) for DSG_F32,
+ * 1 rounded value for DSG_BF16 / DSG_F16.  kind: 0 forward conv (dsg_conv_args.weight_h2); 1 folded up-sampler
+ * (weight_h2_fold); 2 stride-2 conv over the space-to-depth image (weight_h2_s2); 3 data gradient (K = cout, N = cin,
+ * taps reversed: weight_h2 of the conv dX = conv(dY, .)); 4 data gradient of a stride-2 conv as four 2x2 phase convs of
+ * the low-resolution dY (weight_h2_fold of a call with upsample == 1: the adjoint of kind 2).  n_total / n_off place
+ * this weight's N columns inside a wider matrix (kinds 0 and 3; 0 = no window). */
+int dsg_conv_weight_pack(const float* w_oihw, void* dst, int32_t cout, int32_t cin, int32_t ksize, int32_t kind,
+                         int32_t dtype, int32_t n_total, int32_t n_off, void* stream);
+int dsg_conv_weight_pack_bytes(int32_t cout, int32_t cin, int32_t ksize, int32_t kind, int32_t dtype, int32_t n_total,
+                               size_t* bytes);
 /* OIHW 3x3 -> [phase 4][Cin/16][2][2x2 taps][2][cout padded to 64][8] fp16: Upsample2D (nearest x2) + this conv as
  * four 2x2 convs of the low-resolution input, one per output-pixel parity; taps that land on the same source pixel
  * are summed in fp32 before the split. */
@@ -139,6 +171,9 @@ int dsg_gn_channel_stats(const float* src0, int32_t c0, const float* src1, int32
  * partial sums over equal runs of pixels (splits divides hw): feed dsg_gn_finalize_parts with tiles = splits */
 int dsg_gn_channel_stats_blocked(const float* src, int32_t c, int32_t n, int32_t hw, int32_t splits,
                                  double* chan_stats /* [N][C][splits][2] */, void* stream);
+/* the same for a channel-blocked tensor stored as `dtype` (dsg_dtype) */
+int dsg_gn_channel_stats_blocked_dt(const void* src, int32_t c, int32_t n, int32_t hw, int32_t splits,
+                                    double* chan_stats, int32_t dtype, void* stream);
 int dsg_gn_finalize(const double* chan_stats, const float* gamma, const float* beta, int32_t n,
                     int32_t c, int32_t groups, int32_t hw, float eps,
                     float* scale_shift /* [N][C][2] */, void* stream);
@@ -216,6 +251,9 @@ typedef struct {
   float norm_eps;
   int32_t attention_head_dim;
   int32_t add_attention;            /* mid-block attention */
+  int32_t compute_dtype;            /* dsg_dtype: DSG_F32 = the fp32-equivalent engine; DSG_BF16 / DSG_F16 = the intermediate
+                                       activations are 16-bit channel-blocked tensors and every conv / projection runs
+                                       once on the bf16 / f16 matrix cores (x, eps, parameters, statistics stay fp32) */
 } dsg_unet_config;
 
 int dsg_unet_create(const dsg_unet_config* cfg, dsg_unet_t** out);
@@ -304,6 +342,9 @@ int dsg_mse_loss(const float* pred, const float* target, int64_t numel, float gr
                  double* ws, size_t ws_bytes, void* stream);
 int dsg_l2_norm(const float* x, int64_t numel, float* norm, double* ws, size_t ws_bytes, void* stream);
 int dsg_clip_scale(float* g, int64_t numel, const float* total_norm, float max_norm, void* stream);
+/* GradScaler.unscale_ (accelerate's fp16 path, training_pipeline.py:86-91 under train.py:24): g *= inv_scale in place;
+ * *found_inf (device int32, caller-zeroed, OR-ed into) becomes 1 when any element is inf or nan. */
+int dsg_unscale_check(float* g, int64_t numel, float inv_scale, int32_t* found_inf, void* stream);
 /* One fused AdamW update of a flat parameter slab (torch.optim.AdamW semantics: decoupled decay, lerp, bias
  * corrections).  total_norm != NULL applies clip_grad_norm_'s factor min(1, max_norm/(norm+1e-6)) on the fly. */
 int dsg_adamw_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t numel, double lr,

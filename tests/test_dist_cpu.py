@@ -46,18 +46,56 @@ def _worker(rank, world, port, q):
         b.finish()
         for nm, (o, n) in offsets.items():  # (slab padding between buckets carries no gradient and is not reduced)
             assert torch.allclose(flat[o:o + n], torch.full((n,), 0.5)), nm
-        # --- dataloader sharding: disjoint batches of the full batch size per rank ---
-        ds = torch.arange(40, dtype=torch.float32).view(20, 2)
-        dl = torch.utils.data.DataLoader(ds, batch_size=4, shuffle=False)
-        mine = [x for x in _ShardedLoader(dl, "cpu", rank, world)]
-        assert len(mine) == len(_ShardedLoader(dl, "cpu", rank, world)) or len(mine) + 1 == 3
-        got = torch.cat(mine).flatten()
-        allv = [torch.zeros(40) for _ in range(world)]
-        pad = torch.zeros(40)
-        pad[:got.numel()] = got + 1
-        dist.all_gather(allv, pad)
-        seen = torch.cat([v[v > 0] - 1 for v in allv]).sort().values
-        assert torch.equal(seen, torch.arange(40, dtype=torch.float32))
+        # --- dataloader sharding (accelerate's even_batches + synchronised shuffle): every rank runs the same number
+        #     of full-size batches; the shards partition the dataset, the ragged tail wraps to the epoch's start ---
+        ds = torch.arange(40, dtype=torch.float32).view(20, 2)   # 20 samples, batch 4 -> 5 batches: odd for world 2
+        for shuffle in (False, True):
+            dl = torch.utils.data.DataLoader(ds, batch_size=4, shuffle=shuffle)
+            sl = _ShardedLoader(dl, "cpu", rank, world)
+            for _epoch in range(2):
+                mine = [x for x in sl]
+                assert len(mine) == len(sl) == 3 and all(x.shape == (4, 2) for x in mine)
+                got = torch.cat(mine)[:, 0] / 2                   # sample ids of this rank, in order
+                allv = [torch.zeros(12) for _ in range(world)]
+                dist.all_gather(allv, got)
+                flat = torch.stack(allv)                          # [rank][3 batches x 4]
+                order = torch.stack([flat[r].view(3, 4) for r in range(world)], 1).reshape(-1)  # batch k of rank r = global batch k*W + r
+                assert torch.equal(order[:20].sort().values, torch.arange(20, dtype=torch.float32))  # a partition
+                assert torch.equal(order[20:], order[:4])          # the tail is the start of the same order
+                if shuffle:
+                    seeds = [torch.zeros(1, dtype=torch.int64) for _ in range(world)]
+                    dist.all_gather(seeds, torch.tensor([sl.epoch_seed]))
+                    assert seeds[0].item() == seeds[1].item()
+                else:
+                    assert torch.equal(order[:20], torch.arange(20, dtype=torch.float32))
+        # drop_last: 22 samples, batch 4 -> 5 full batches, the 2 left-over samples are never seen
+        dl = torch.utils.data.DataLoader(torch.arange(22, dtype=torch.float32).view(22, 1), batch_size=4, drop_last=True)
+        assert sum(x.shape[0] for x in _ShardedLoader(dl, "cpu", rank, world)) == 12
+        # --- gradient accumulation: the prepared optimizer steps / zeroes only on the synchronising micro-batch ---
+        from drivescenegen_amd.training import Accelerator, _PreparedOptimizer
+
+        class CountingOpt:
+            param_groups = []
+            steps = zeros = 0
+
+            def step(self):
+                self.steps += 1
+
+            def zero_grad(self):
+                self.zeros += 1
+        acc = Accelerator.__new__(Accelerator)
+        acc.gradient_accumulation_steps, acc._accum, acc.sync_gradients = 3, 0, True
+        acc.scaler, acc.optimizer_step_was_skipped = None, False
+        copt = CountingOpt()
+        popt = _PreparedOptimizer(copt, acc)
+        sched_steps = []
+        lam = _SteppedScheduler(type("S", (), {"step": lambda self: sched_steps.append(1)})(), world, acc)
+        for micro in range(6):
+            with acc.accumulate():
+                popt.step()
+                lam.step()
+                popt.zero_grad()
+        assert copt.steps == 2 and copt.zeros == 2 and len(sched_steps) == 2 * world
         # --- accelerate semantics: one lr_scheduler.step() advances the schedule `world` times ---
         from drivescenegen_amd.optimization import get_cosine_schedule_with_warmup
         opt = torch.optim.SGD([torch.nn.Parameter(torch.zeros(1))], lr=1.0)
@@ -65,6 +103,7 @@ def _worker(rank, world, port, q):
 
         class A:
             sync_gradients = True
+            optimizer_step_was_skipped = False
         st = _SteppedScheduler(sch, world, A())
         opt.step()
         st.step()
@@ -119,3 +158,28 @@ def test_dataset_png_and_pkl(tmp_path):
         assert x.shape == (3, 16, 16) and x.dtype == torch.float32
         assert torch.allclose(x, want, atol=1e-6)
         assert float(x.min()) >= -1 and float(x.max()) <= 1
+
+
+def test_grad_scaler_state_machine():
+    """GradScaler bookkeeping (host logic; the unscale / finite check kernel is covered by the gpu tests): a skipped
+    step halves the scale and resets the streak, `growth_interval` clean steps double it (torch defaults 65536 /
+    2.0 / 0.5 / 2000)."""
+    from drivescenegen_amd.training import GradScaler
+    sc = GradScaler(growth_interval=3)
+    assert sc.get_scale() == 65536.0
+    sc.update(skipped=True)
+    assert sc.get_scale() == 32768.0
+    for _ in range(2):
+        sc.update(skipped=False)
+    assert sc.get_scale() == 32768.0
+    sc.update(skipped=False)
+    assert sc.get_scale() == 65536.0
+    sc.update(skipped=False)
+    sc.update(skipped=True)   # a skip in the middle of a streak restarts it
+    for _ in range(2):
+        sc.update(skipped=False)
+    assert sc.get_scale() == 32768.0
+    sd = sc.state_dict()
+    other = GradScaler()
+    other.load_state_dict(sd)
+    assert other.get_scale() == sc.get_scale() and other._growth_tracker == sc._growth_tracker
