@@ -144,6 +144,150 @@ def cpu_leg(args):
 PROF_EVERY = 5
 
 
+def _prof_rows(lib, _lib, names):
+    rows = {}
+    for kid, nm in names.items():
+        ms, fl, by, n = C.c_double(), C.c_double(), C.c_double(), C.c_int64()
+        _lib.check(lib.dsg_prof_summary(kid, C.byref(ms), C.byref(fl), C.byref(by), C.byref(n)))
+        if n.value:
+            rows[nm] = dict(launches=n.value, total_ms=ms.value, avg_ms=ms.value / n.value,
+                            tflops=fl.value / (ms.value * 1e-3) / 1e12, alg_gbs=by.value / (ms.value * 1e-3) / 1e9,
+                            flops_per_launch=fl.value / n.value, bytes_per_launch=by.value / n.value)
+    return rows
+
+
+def mixed_leg(args, dtype="bf16"):
+    """Extra record: BASELINE configs[4]'s network (256x256x8 raster, default U-Net, 56,580,360 parameters) in mixed
+    precision -- bf16 matrix-core products, 16-bit channel-blocked activations, fp32 statistics / accumulators --
+    as denoising steps (dsg_unet_forward + dsg_ddim_step) at --mixed-batch samples.  Its dominant kernel is priced against
+    BOTH roofs: 2.5 PF/s dense bf16 MFMA and 8 TB/s HBM (the 64 / 128-channel layers are HBM-bound in 16 bits)."""
+    import drivescenegen_amd as d
+    from drivescenegen_amd import _lib, synth
+    from drivescenegen_amd.configs import CFG5, synth_weights
+    dev = torch.device("cuda", int(os.environ.get("LOCAL_RANK", 0)))
+    net = synth_weights(d.UNet2DModel(**CFG5)).to(dev).eval().requires_grad_(False).set_compute_dtype(dtype)
+    sch = d.DDIMScheduler()
+    sch.set_timesteps(args.ddim_steps)
+    ts = [int(t) for t in sch.timesteps]
+    b, steps = args.mixed_batch, args.mixed_steps
+    x = torch.from_numpy(synth.normal(14555, (b, 8, 256, 256), stream=11)).to(dev)
+    lib = _lib.load()
+
+    def step(i, x):
+        t = ts[i % len(ts)]
+        return sch.step(net(x, t).sample, t, x).prev_sample
+    for i in range(4):
+        x = step(i, x)
+    torch.cuda.synchronize(dev)
+    lib.dsg_prof_enable(1)
+    t0 = time.perf_counter()
+    for i in range(steps):
+        lib.dsg_prof_enable(3 if i % PROF_EVERY == 0 else 2)
+        x = step(4 + i, x)
+    torch.cuda.synchronize(dev)
+    dt = time.perf_counter() - t0
+    assert torch.isfinite(x).all()
+    rows = _prof_rows(lib, _lib, {26: "conv3x3_s1_mfma_16bit", 27: "conv3x3_upsample_mfma_16bit", 22: "conv3x3_s2_mfma_16bit",
+                                   28: "conv1x1_mfma_16bit", 0: "conv3x3_s1_mfma_f32", 4: "conv_direct_valu"})
+    lib.dsg_prof_enable(0)
+    del net
+    flops_img = 353.58e9  # SURVEY 8d, cfg5 forward
+    rec = {"metric": "denoising-steps/sec (U-Net fwd)", "value": b * steps / dt, "unit": "image-steps/s",
+           "ms_per_step": dt / steps * 1e3, "steps": steps, "dtype": dtype,
+           "config": {"workload": "BASELINE configs[4] network: 256x256x8 map+agent raster, default U-Net (56,580,360 params), "
+                                  f"mixed {dtype}, DDIM step, batch {b} on 1 GPU", "batch": b},
+           "whole_net_tflops": b * steps / dt * flops_img / 1e12, "kernels": rows}
+    dom = rows.get("conv3x3_s1_mfma_16bit")
+    if dom:
+        t_mfma = dom["flops_per_launch"] / (PEAK_F16_TFLOPS * 1e12)
+        t_hbm = dom["bytes_per_launch"] / (PEAK_HBM_GBS * 1e9)
+        bound = "hbm" if t_hbm > t_mfma else "mfma"
+        rec["roofline"] = dict(
+            bound=bound, kernel="dsg::conv_h2_kernel<0, *, 3, 2, 4, 1, 3, 64, 1>",
+            achieved=dom["alg_gbs"] if bound == "hbm" else dom["tflops"],
+            peak=PEAK_HBM_GBS if bound == "hbm" else PEAK_F16_TFLOPS, unit="GB/s" if bound == "hbm" else "TFLOP/s",
+            frac=max(t_mfma, t_hbm) / (dom["avg_ms"] * 1e-3), mfma_tflops=dom["tflops"], mfma_frac=dom["tflops"] / PEAK_F16_TFLOPS,
+            alg_gbs=dom["alg_gbs"], hbm_frac=dom["alg_gbs"] / PEAK_HBM_GBS, avg_launch_ms=dom["avg_ms"],
+            launches=dom["launches"], traffic=None,
+            note="mean over the 44 resnet convs of a step: frac = max(alg FLOPs / 2.5 PF, alg bytes / 8 TB/s) / measured time")
+    return rec
+
+
+def train_leg(args, dtype="fp32", batch=16, steps=3):
+    """Extra record: optimizer steps of the training loop (training_pipeline.py:70-91: add_noise, U-Net forward, MSE,
+    backward, clip 1.0, AdamW, cosine LR) on BASELINE configs[2]'s network at `batch` samples on one GPU; images/s."""
+    import drivescenegen_amd as d
+    from drivescenegen_amd import synth
+    from drivescenegen_amd.configs import CFG3, CFG5, synth_weights
+    cfg = CFG3 if dtype == "fp32" else CFG5
+    dev = torch.device("cuda", int(os.environ.get("LOCAL_RANK", 0)))
+    net = synth_weights(d.UNet2DModel(**cfg)).to(dev).train().set_compute_dtype(dtype)
+    opt = d.AdamW(net.parameters(), lr=1e-5)
+    lrs = d.get_cosine_schedule_with_warmup(optimizer=opt, num_warmup_steps=500, num_training_steps=50000)
+    sch = d.DDPMScheduler()
+    c = cfg["in_channels"]
+    x0 = torch.from_numpy(synth.synth_scene_rasters(batch, c, 256, 256, 14555)).to(dev)
+    noise = torch.from_numpy(synth.normal(14556, (batch, c, 256, 256))).to(dev)
+    t = torch.from_numpy((synth.uniform01(14557, batch) * 1000).astype("int64")).to(dev)
+
+    def one():
+        noisy = sch.add_noise(x0, noise, t)
+        loss = d.mse_loss(net(noisy, t, return_dict=False)[0], noise)
+        loss.backward()
+        d.clip_grad_norm_(net.parameters(), 1.0)
+        opt.step()
+        lrs.step()
+        opt.zero_grad()
+        return loss
+    for _ in range(2):
+        one()
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        loss = one()
+    torch.cuda.synchronize(dev)
+    dt = time.perf_counter() - t0
+    assert torch.isfinite(loss.detach()).all()
+    peak_gib = torch.cuda.max_memory_allocated(dev) / 2 ** 30
+    del net, opt
+    torch.cuda.empty_cache()
+    return {"metric": "training images/sec (fwd + bwd + clip + AdamW)", "value": batch * steps / dt, "unit": "images/s",
+            "ms_per_step": dt / steps * 1e3, "steps": steps, "dtype": dtype, "peak_mem_gib": peak_gib,
+            "config": {"workload": f"BASELINE configs[{2 if dtype == 'fp32' else 4}] network at 256x256x{c}, DDPM training step, "
+                                   f"batch {batch} on 1 GPU, {dtype}", "batch": batch}}
+
+
+def small_batch_leg(args):
+    """Extra record: the reference's own sampling calls -- DDPM ancestral steps at batch 1 (training_pipeline.py:26-32)
+    and batch 5 (generation.py:12-20) of the 3-channel default network; ms per denoising step."""
+    import drivescenegen_amd as d
+    from drivescenegen_amd import synth
+    from drivescenegen_amd.configs import DEFAULT3, synth_weights
+    dev = torch.device("cuda", int(os.environ.get("LOCAL_RANK", 0)))
+    net = synth_weights(d.UNet2DModel(**DEFAULT3)).to(dev).eval().requires_grad_(False)
+    sch = d.DDPMScheduler()
+    sch.set_timesteps(750)
+    out = {}
+    for b in (1, 5):
+        x = torch.from_numpy(synth.normal(14555, (b, 3, 256, 256), stream=3)).to(dev)
+        nz = torch.from_numpy(synth.normal(14555, (b, 3, 256, 256), stream=4)).to(dev)
+        ts = [int(t) for t in sch.timesteps[:30]]
+
+        def step(t, x):
+            return sch.step(net(x, t).sample, t, x, variance_noise=nz).prev_sample
+        for t in ts[:5]:
+            x = step(t, x)
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        for t in ts[5:]:
+            x = step(t, x)
+        torch.cuda.synchronize(dev)
+        out[f"batch{b}_ms_per_step"] = (time.perf_counter() - t0) / len(ts[5:]) * 1e3
+    out["config"] = {"workload": "DriveSceneGen default U-Net (train.py:39-57, 3 channels), 750-step DDPM, batch 1 "
+                                 "(evaluate) and batch 5 (generation.py), fp32-equivalent"}
+    return out
+
+
 def pmc_traffic(kernel):
     """HBM bytes per launch of `kernel` from the committed PMC pass (tools/pmc_bench.sh -> profiles/*_pmc_traffic.json:
     rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes over this same bench command line, FETCH_SIZE doubled as
@@ -197,7 +341,27 @@ def main():
     ap.add_argument("--cpu-threads", type=int, default=16,
                     help="threads for the CPU oracle (16 is the fastest setting on the 2x64-core GPU box: "
                          "32/64/128/256 threads run 1.1x/2x/4.4x/36x slower)")
+    ap.add_argument("--no-extras", action="store_true",
+                    help="skip the extra records (mixed-precision forward, training step, small-batch sampling)")
+    ap.add_argument("--mixed-batch", type=int, default=64)
+    ap.add_argument("--mixed-steps", type=int, default=20)
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # asked for N GPUs without a launcher: start one rank per GPU ourselves (the same command line the driver uses)
+        import socket
+        import subprocess
+        have = torch.cuda.device_count()
+        if have < args.gpus:
+            sys.exit(f"bench.py: --gpus {args.gpus} but only {have} GPU(s) visible")
+        sock = socket.socket()
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+        sock.close()
+        env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+               "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        sys.exit(subprocess.call(cmd, env=env))
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -255,6 +419,16 @@ def main():
             "roofline": roofline,
             "kernels": prof,
         }
+        if not args.no_extras and world == 1:  # bounded extra legs, N = 1 only; a failure is reported, never hidden
+            extras = {}
+            for name, fn in (("mixed_bf16", lambda: mixed_leg(args, "bf16")), ("train_fp32", lambda: train_leg(args, "fp32")),
+                             ("train_bf16", lambda: train_leg(args, "bf16", batch=32)),
+                             ("small_batch_sampling", lambda: small_batch_leg(args))):
+                try:
+                    extras[name] = fn()
+                except Exception as e:  # noqa: BLE001
+                    extras[name] = {"error": f"{type(e).__name__}: {e}"}
+            out["extra_records"] = extras
         if not args.no_cpu and world == 1:  # (rank 0 at N = 1 only: the other ranks of a multi-GPU run would wait for it)
             out["cpu_baseline"] = cpu_leg(args)
         print(json.dumps(out))

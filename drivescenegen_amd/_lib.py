@@ -59,6 +59,7 @@ class ConvWgradArgs(C.Structure):
         ("gn_scale_shift", C.c_void_p), ("silu", C.c_int32),
         ("dw", C.c_void_p), ("force_direct", C.c_int32),
         ("workspace", C.c_void_p), ("workspace_bytes", C.c_size_t),
+        ("compute_dtype", C.c_int32),
     ]
 
 
@@ -91,6 +92,13 @@ SIGNATURES = {
     "dsg_layout_convert_dt": [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp],
     "dsg_gn_channel_stats_blocked_dt": [_vp, _i32, _i32, _i32, _i32, _vp, _i32, _vp],
     "dsg_unscale_check": [_vp, _i64, _f32, _vp, _vp],
+    "dsg_gn_bwd_blocked": [_vp, _i32, _vp, _i32, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp,
+                           _vp, _vp, _i32, _vp],
+    "dsg_gn_bwd_blocked_splits": [_i32],
+    "dsg_channel_sums_blocked": [_vp, _i32, _i32, _i32, _vp, _i32, _i32, _vp],
+    "dsg_add_dt": [_vp, _vp, _i64, _vp, _i32, _vp],
+    "dsg_upsample_nearest2x_blocked": [_vp, _vp, _i64, _i32, _i32, _i32, _vp],
+    "dsg_sumpool2x2_blocked": [_vp, _vp, _vp, _i64, _i32, _i32, _i32, _vp],
     "dsg_conv_weight_relayout_h2_fold": [_vp, _vp, _i32, _i32, _vp],
     "dsg_conv_weight_relayout_h2_s2": [_vp, _vp, _i32, _i32, _vp],
     "dsg_upsample_nearest2x": [_vp, _vp, _i64, _i32, _i32, _vp],

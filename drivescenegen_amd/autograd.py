@@ -14,9 +14,11 @@ gather, exactly as they are folded into the forward gather.
 """
 from __future__ import annotations
 
+import math
+
 import torch
 
-from . import ops
+from . import _lib, ops
 
 
 SLABS = {}  # storage data_ptr -> (flat gradient slab, number of parameter slices): lets the optimizer / clipper
@@ -44,6 +46,9 @@ class TrainState:
         self.wh, self.whd = {}, {}  # fp16x2-split copies (forward / data-gradient) of the eligible 3x3 weights
         self.freqs = ops.sinusoid_freqs(model.config.block_out_channels[0]).to(dev)
         self.grad_ready_hooks = []  # callables(name) fired when a parameter's gradient is final (DDP buckets)
+        self.post_backward = []     # callables() run when the backward walk is complete, before the internal loss scale
+        #                             is taken back out of the slab (the bucketed all-reduce finishes here)
+        self.packs16 = {}           # dsg_dtype -> _Packs: 16-bit operand images for the mixed-precision tape
         self.attach()
 
     def grad(self, name):
@@ -356,7 +361,12 @@ def _backward(model, st: TrainState, tape: _Tape, dout):
             done(gnn + ".weight", gnn + ".bias")
             tape.setg(x, dx)
 
-    # ---- timestep path ----
+    _backward_temb(st, tb, done)
+
+
+def _backward_temb(st, tb, done):
+    """Backward of the timestep path (sinusoid -> MLP -> all time_emb_proj), shared by both tapes (fp32 throughout)."""
+    P = st.params
     dtproj, act = tb["dtproj"], tb["act"]
     for pre in tb["resnets"]:
         o = tb["toffs"][pre]
@@ -382,17 +392,44 @@ class _UNetTrainFn(torch.autograd.Function):
     def forward(ctx, anchor, model, sample, timesteps):
         st = get_train_state(model)
         tape = _Tape()
-        out = _forward(model, st, tape, sample, timesteps)
-        ctx.model, ctx.st, ctx.tape, ctx.out_ref = model, st, tape, out
+        dt = _lib.DTYPE_CODES[getattr(model, "compute_dtype", "fp32")]
+        if dt == _lib.DSG_F32:
+            out = _forward(model, st, tape, sample, timesteps)
+        else:
+            out = _forward16(model, st, tape, sample, timesteps, dt)
+        ctx.model, ctx.st, ctx.tape, ctx.out_ref, ctx.dt = model, st, tape, out, dt
         return out.view_as(out)  # a fresh tensor object for autograd; `out` keys the tape
 
     @staticmethod
     def backward(ctx, dout):
         st, tape = ctx.st, ctx.tape
         st.attach()
-        tape.setg(ctx.out_ref, dout.contiguous())
-        _backward(ctx.model, st, tape, dout)
+        dout = dout.contiguous()
+        if ctx.dt != _lib.DSG_F32:
+            # bf16 has fp32's exponent range; fp16 gets its range from the GradScaler (Accelerator), as in the reference
+            tape.setg(ctx.out_ref, dout)
+            _backward16(ctx.model, st, tape, dout)
+            scale = 1.0
+        else:
+            # The gradient of a mean-reduced loss is O(1 / numel) per element (1e-7 at 256^2 x B = 16): below the range in
+            # which the fp16 pairs of the split path keep fp32's precision.  The walk therefore runs on S * dout with
+            # S = 2^floor(log2(numel)) -- activations' gradients are O(1) -- and the parameter gradients, which accumulate
+            # in the slab, are brought back by 1 / S at the end: powers of two, exact, so what is in p.grad is what an
+            # unscaled fp32 backward would have produced.  Gradients already in the slab (accumulation over
+            # micro-batches) are taken along by the same factor first.
+            scale = 2.0 ** math.floor(math.log2(max(1, dout.numel())))
+            ops.scale(st.grad_flat, None, scale, out=st.grad_flat)
+            tape.setg(ctx.out_ref, ops.scale(dout, None, scale))
+            _backward(ctx.model, st, tape, dout)
         ctx.tape = None
+
+        def finish():
+            for hook in st.post_backward:
+                hook()
+            if scale != 1.0:
+                ops.scale(st.grad_flat, None, 1.0 / scale, out=st.grad_flat)
+        # after the whole autograd pass (this node is its last consumer of GPU work): finish collectives, remove the scale
+        torch.autograd.Variable._execution_engine.queue_callback(finish)
         return None, None, None, None
 
 
@@ -404,3 +441,334 @@ def unet_forward_train(model, sample, timestep):
         anchor = torch.zeros(1, device=sample.device, requires_grad=True)
         model._grad_anchor = anchor
     return _UNetTrainFn.apply(anchor, model, sample.contiguous(), t)
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# Mixed-precision tape (Accelerator(mixed_precision='bf16' | 'fp16'); reference: train.py:24, training_pipeline.py:48-49,
+# SURVEY App. A.6).  Same walk as above on the engine's 16-bit channel-blocked tensors [N, C/8, H, W, 8]: every conv /
+# projection and its two gradients run once on the bf16 / f16 matrix cores with fp32 accumulation; GroupNorm statistics,
+# the attention core (q, k, v, softmax: fp32 [N, C, L]), the loss, parameter gradients, master weights and the
+# optimizer stay fp32 -- torch.autocast's split.  Shapes the 16-bit kernels do not take (conv_in / conv_out, pointwise
+# and stride-2 weight gradients, maps under one tile) go through dsg_layout_convert_dt and the fp32 kernels.
+# ------------------------------------------------------------------------------------------------------------------
+class _Packs:
+    """Per-parameter 16-bit operand images (dsg_conv_weight_pack), refreshed when the parameter changes."""
+
+    def __init__(self, st, dt):
+        self.st, self.dt, self.cache, self.sig = st, dt, {}, {}
+
+    def get(self, name, kind):
+        p = self.st.params[name]
+        sig = (p.data_ptr(), p._version)
+        key = (name, kind)
+        if self.sig.get(key) != sig:
+            self.cache[key] = ops.pack_conv_weight(p.detach(), kind, self.dt, out=self.cache.get(key))
+            self.sig[key] = sig
+        return self.cache[key]
+
+    def qkv(self, prefix, kind):
+        """Fused q/k/v projection: forward = three column windows of one [C] x [3C] image; data gradient = the three
+        [C -> C] images back to back along K."""
+        names = [f"{prefix}.{t}.weight" for t in ("to_q", "to_k", "to_v")]
+        sig = tuple((self.st.params[n].data_ptr(), self.st.params[n]._version) for n in names)
+        key = (prefix, "qkv", kind)
+        if self.sig.get(key) != sig:
+            ws = [self.st.params[n].detach() for n in names]
+            c = ws[0].shape[0]
+            if kind == ops.PACK_FWD:
+                buf = self.cache.get(key)
+                for i, w in enumerate(ws):
+                    buf = ops.pack_conv_weight(w, ops.PACK_FWD, self.dt, n_total=3 * c, n_off=i * c, out=buf)
+            else:
+                one = ops.pack_conv_weight(ws[0], ops.PACK_DGRAD, self.dt)
+                buf = self.cache.get(key)
+                if buf is None:
+                    buf = torch.zeros(3 * one.numel(), dtype=torch.int16, device=one.device)
+                for i, w in enumerate(ws):
+                    ops.pack_conv_weight(w, ops.PACK_DGRAD, self.dt, out=buf[i * one.numel():(i + 1) * one.numel()])
+            self.cache[key] = buf
+            self.sig[key] = sig
+        return self.cache[key]
+
+
+def _pad64(c):
+    return (c + 63) // 64 * 64
+
+
+def _forward16(model, st: TrainState, tape: _Tape, sample, timesteps, dt):
+    cfg = model.config
+    P = st.params
+    groups, eps = cfg.norm_num_groups, cfg.norm_eps
+    if any(c % 8 for c in cfg.block_out_channels):
+        raise NotImplementedError("mixed-precision training needs block_out_channels % 8 == 0 (channel-blocked tensors)")
+    packs = st.packs16.setdefault(dt, _Packs(st, dt))
+    tape.packs, tape.dt = packs, dt
+
+    resnets, toffs, proj_total = [], {}, 0
+    for pre in _resnet_prefixes(model):
+        toffs[pre] = proj_total
+        proj_total += P[pre + ".time_emb_proj.bias"].numel()
+        resnets.append(pre)
+
+    # ---- timestep path (fp32, as in the fp32 tape) ----
+    w1, b1 = P["time_embedding.linear_1.weight"].detach(), P["time_embedding.linear_1.bias"].detach()
+    w2, b2 = P["time_embedding.linear_2.weight"].detach(), P["time_embedding.linear_2.bias"].detach()
+    act, emb, z1, z2 = ops.time_embed_train(timesteps, w1, b1, w2, b2, st.freqs)
+    dim = w1.shape[0]
+    if "_tproj" not in st.wf:
+        st.wf["_tproj"] = torch.empty((proj_total, dim), dtype=torch.float32, device=sample.device)
+        st.wf["_tproj.bias"] = torch.empty(proj_total, dtype=torch.float32, device=sample.device)
+    wp, bp = st.wf["_tproj"], st.wf["_tproj.bias"]
+    for pre in resnets:
+        o = toffs[pre]
+        w = P[pre + ".time_emb_proj.weight"].detach()
+        wp[o:o + w.shape[0]].copy_(w)
+        bp[o:o + w.shape[0]].copy_(P[pre + ".time_emb_proj.bias"].detach())
+    tproj = ops.linear(act, wp, bp)
+    dtproj = torch.zeros_like(tproj)
+    tape.temb = dict(act=act, emb=emb, z1=z1, z2=z2, wp=wp, dtproj=dtproj, toffs=toffs, resnets=resnets, w2=w2)
+
+    pstats = {}
+
+    def hw_of(x):
+        return x.shape[2] * x.shape[3]
+
+    def chans(x):
+        return x.shape[1] * 8 if x.dim() == 5 else x.shape[1]
+
+    def norm_ss(x0, x1, gn):
+        g, b = P[gn + ".weight"].detach(), P[gn + ".bias"].detach()
+        s0 = pstats.get(id(x0))
+        if s0 is None:   # the producer could not write its statistics: one pass over the 16-bit tensor, kept with it
+            s0 = pstats[id(x0)] = ops.gn_channel_stats_blocked(x0)
+        s1 = None
+        if x1 is not None:
+            s1 = pstats.get(id(x1))
+            if s1 is None:
+                s1 = pstats[id(x1)] = ops.gn_channel_stats_blocked(x1)
+        return ops.gn_scale_shift_from_parts_train(s0, g, b, groups, eps, hw_of(x0), stats1=s1)
+
+    def conv(x0, wname, x1=None, gn=None, silu=False, k=3, stride=1, ups=False, toff=None, res=None, need_dx=True,
+             feeds_norm=False, dst_blocked=True):
+        wf, _ = st.conv_w(wname + ".weight")
+        bias = P[wname + ".bias"].detach()
+        cout = bias.numel()
+        src_blocked = x0.dim() == 5
+        ss = mr = None
+        if gn is not None:
+            ss, mr = norm_ss(x0, x1, gn)
+        cin = chans(x0) + (chans(x1) if x1 is not None else 0)
+        kw = {}
+        if cin % 16 == 0 and cout % 8 == 0 and (src_blocked or dst_blocked):
+            if stride == 2:
+                kw["weight_h2_s2"] = packs.get(wname + ".weight", ops.PACK_S2)
+            elif ups:
+                kw["weight_h2_fold"] = packs.get(wname + ".weight", ops.PACK_FOLD)
+            else:
+                kw["weight_h2"] = packs.get(wname + ".weight", ops.PACK_FWD)
+                kw["weight_h2_stride"] = _pad64(cout)
+        y = ops.conv2d_fused(x0, wf, bias, src1=x1, ksize=k, stride=stride, upsample=ups, gn_scale_shift=ss, silu=silu,
+                             temb=None if toff is None else tproj[:, toff:], temb_stride=tproj.stride(0), residual=res,
+                             cout=cout, want_stats=feeds_norm, src_blocked=src_blocked, dst_blocked=dst_blocked,
+                             compute_dtype=dt, **kw)
+        if feeds_norm:
+            y, ystats = y
+            if ystats is not None:
+                pstats[id(y)] = ystats
+        tape.recs.append(dict(kind="conv", x0=x0, x1=x1, ss=ss, mr=mr, gn=gn, silu=silu, k=k, stride=stride, ups=ups,
+                              toff=toff, res=res, y=y, wname=wname, cout=cout, need_dx=need_dx))
+        return y
+
+    def resnet(x, skip, pre):
+        h = conv(x, pre + ".conv1", x1=skip, gn=pre + ".norm1", silu=True, toff=toffs[pre], feeds_norm=True)
+        sc = conv(x, pre + ".conv_shortcut", x1=skip, k=1) if (pre + ".conv_shortcut.weight") in P else x
+        return conv(h, pre + ".conv2", gn=pre + ".norm2", silu=True, res=sc, feeds_norm=True)
+
+    def attention(x, pre):
+        wf, _, bias = st.qkv_w(pre)
+        c = chans(x)
+        heads = c // cfg.attention_head_dim
+        gnn = pre + ".group_norm"
+        ss, mr = norm_ss(x, None, gnn)
+        n, _, hh, ww, _ = x.shape
+        qkv = ops.conv2d_fused(x, wf, bias, ksize=1, gn_scale_shift=ss, silu=False, cout=3 * c, src_blocked=True,
+                               dst_blocked=False, compute_dtype=dt, weight_h2=packs.qkv(pre, ops.PACK_FWD),
+                               weight_h2_stride=_pad64(3 * c))
+        o, lse = ops.attention_train(qkv.view(n, 3 * c, hh * ww), heads)
+        o = o.view(n, c, hh, ww)
+        tape.recs.append(dict(kind="qkv", x=x, ss=ss, mr=mr, gn=gnn, pre=pre, qkv=qkv))
+        tape.recs.append(dict(kind="attn", qkv=qkv, o=o, lse=lse, heads=heads))
+        return conv(o, pre + ".to_out.0", k=1, res=x, feeds_norm=True)
+
+    x = conv(sample, "conv_in", need_dx=False)
+    skips = [x]
+    for i, blk in enumerate(model.down_blocks):
+        pre = f"down_blocks.{i}"
+        for j in range(len(blk.resnets)):
+            x = resnet(x, None, f"{pre}.resnets.{j}")
+            if hasattr(blk, "attentions"):
+                x = attention(x, f"{pre}.attentions.{j}")
+            skips.append(x)
+        if hasattr(blk, "downsamplers"):
+            x = conv(x, f"{pre}.downsamplers.0.conv", stride=2, feeds_norm=True)
+            skips.append(x)
+    x = resnet(x, None, "mid_block.resnets.0")
+    if hasattr(model.mid_block, "attentions"):
+        x = attention(x, "mid_block.attentions.0")
+    x = resnet(x, None, "mid_block.resnets.1")
+    for i, blk in enumerate(model.up_blocks):
+        pre = f"up_blocks.{i}"
+        for j in range(len(blk.resnets)):
+            s = skips.pop()
+            x = resnet(x, s, f"{pre}.resnets.{j}")
+            if hasattr(blk, "attentions"):
+                x = attention(x, f"{pre}.attentions.{j}")
+        if hasattr(blk, "upsamplers"):
+            x = conv(x, f"{pre}.upsamplers.0.conv", ups=True, feeds_norm=True)
+    return conv(x, "conv_out", gn="conv_norm_out", silu=True, dst_blocked=False)
+
+
+def _resnet_prefixes(model):
+    for i, blk in enumerate(model.down_blocks):
+        for j in range(len(blk.resnets)):
+            yield f"down_blocks.{i}.resnets.{j}"
+    yield "mid_block.resnets.0"
+    yield "mid_block.resnets.1"
+    for i, blk in enumerate(model.up_blocks):
+        for j in range(len(blk.resnets)):
+            yield f"up_blocks.{i}.resnets.{j}"
+
+
+def _backward16(model, st: TrainState, tape: _Tape, dout):
+    P = st.params
+    groups = model.config.norm_num_groups
+    tb, packs, dt = tape.temb, tape.packs, tape.dt
+    fire = st.grad_ready_hooks
+
+    def done(*names):
+        for h in fire:
+            for nm in names:
+                h(nm)
+
+    def blocked(t):
+        return t.dim() == 5
+
+    def chans(t):
+        return t.shape[1] * 8 if blocked(t) else t.shape[1]
+
+    def f32(t):   # [N, C, H, W] fp32 view of a tape tensor (conversion pass for the shapes the 16-bit kernels skip)
+        return ops.from_blocked(t) if blocked(t) else t
+
+    def wgrad(x0, x1, dy, wname, k, stride, ups, ss, silu, cout=None, dy_coff=0):
+        c0, c1 = chans(x0), (chans(x1) if x1 is not None else 0)
+        co = cout or chans(dy)
+        if blocked(x0) and blocked(dy) and ops.wgrad16_supported(c0, c1, co, x0.shape[2], x0.shape[3], k, stride, ups, dy_coff):
+            ops.conv_wgrad(x0, dy, st.grad(wname), src1=x1, ksize=k, gn_scale_shift=ss, silu=silu, cout=co, dy_coff=dy_coff)
+        else:
+            ops.conv_wgrad(f32(x0), f32(dy), st.grad(wname), src1=None if x1 is None else f32(x1), ksize=k, stride=stride,
+                           upsample=ups, gn_scale_shift=ss, silu=silu, cout=co, dy_coff=dy_coff)
+
+    def dgrad(dy, wname, k, cout, stride=1, residual=None, col0=0, ncols=None, dst_blocked=True):
+        """dX = conv(dY, W^T flipped) for columns [col0, col0 + ncols) of the conv's input channels; + residual."""
+        _, wd = st.conv_w(wname)
+        ncols = ncols or cout
+        full = col0 == 0 and ncols == cout
+        src_blocked = blocked(dy)
+        kdim = chans(dy)
+        use16 = kdim % 16 == 0 and ncols % 8 == 0 and (src_blocked or dst_blocked) and (full or (col0 % 8 == 0 and ncols % 64 == 0))
+        if stride == 2:   # the adjoint of the space-to-depth conv: four 2x2 phase convs of the low-resolution dY
+            ok = use16 and full and src_blocked and dst_blocked and dy.shape[3] % 32 == 0 and dy.shape[2] % 8 == 0
+            if ok:
+                return ops.conv2d_fused(dy, wd, ksize=3, upsample=True, cout=cout, residual=residual, src_blocked=True,
+                                        dst_blocked=True, compute_dtype=dt, weight_h2_fold=packs.get(wname, ops.PACK_DGRAD_S2))
+            g = ops.conv2d_fused(f32(dy), wd, ksize=3, upsample=2, cout=cout, residual=None if residual is None else f32(residual))
+            return ops.to_blocked(g, dt)
+        if use16:
+            return ops.conv2d_fused(dy, wd if full else wd[:, :, col0:], ksize=k, cout=ncols, residual=residual,
+                                    wstride=None if full else wd.shape[-1], src_blocked=src_blocked, dst_blocked=dst_blocked,
+                                    compute_dtype=dt, weight_h2=packs.get(wname, ops.PACK_DGRAD), weight_h2_col=col0,
+                                    weight_h2_stride=_pad64(cout))
+        # no 16-bit kernel for this shape (conv_out's 8-channel dY, narrow channel windows): the fp32 kernels
+        if not src_blocked and dst_blocked and full and k == 3:   # fp32 [N,C,H,W] dY -> 16-bit blocked dX directly
+            return ops.conv2d_fused(dy, wd, ksize=k, cout=cout, residual=residual, dst_blocked=True, compute_dtype=dt)
+        g = ops.conv2d_fused(f32(dy), wd if full else wd[:, :, col0:], ksize=k, cout=ncols,
+                             residual=None if residual is None else f32(residual), wstride=None if full else wd.shape[-1])
+        return ops.to_blocked(g, dt) if dst_blocked else g
+
+    for rec in reversed(tape.recs):
+        kind = rec["kind"]
+        if kind == "conv":
+            dy = tape.g(rec["y"])
+            if dy is None:
+                continue
+            wname, cout, k = rec["wname"], rec["cout"], rec["k"]
+            x0, x1 = rec["x0"], rec["x1"]
+            if rec["toff"] is not None:
+                sums = ops.channel_sums(dy, out=tb["dtproj"][:, rec["toff"]:], out_stride=tb["dtproj"].stride(0))
+                ops.reduce_rows_add(sums, st.grad(wname + ".bias"), stride=tb["dtproj"].stride(0))
+            else:
+                ops.reduce_rows_add(ops.channel_sums(dy), st.grad(wname + ".bias"))
+            if rec["res"] is not None:
+                tape.addg(rec["res"], dy)
+            if rec["ups"]:   # weight gradient from the materialised nearest-x2 input, data gradient at full resolution
+                wgrad(ops.upsample_nearest2x(x0), None, dy, wname + ".weight", k, 1, False, None, False)
+            else:
+                wgrad(x0, x1, dy, wname + ".weight", k, rec["stride"], False, rec["ss"], rec["silu"])
+            done(wname + ".weight", wname + ".bias")
+            if not rec["need_dx"]:
+                continue
+            cin0, cin1 = chans(x0), (chans(x1) if x1 is not None else 0)
+            wn = wname + ".weight"
+            if rec["ups"]:
+                dfull = dgrad(dy, wn, k, cin0)
+                tape.setg(x0, ops.sumpool2x2(dfull, add=tape.g(x0)))
+                continue
+            if rec["gn"] is not None:
+                da = dgrad(dy, wn, k, cin0 + cin1, stride=rec["stride"])
+                gnn = rec["gn"]
+                dx0, dx1 = ops.gn_bwd_blocked(x0, da, rec["ss"], rec["mr"], P[gnn + ".weight"].detach(), groups, rec["silu"],
+                                              st.grad(gnn + ".weight"), st.grad(gnn + ".bias"), src1=x1, add0=tape.g(x0),
+                                              add1=tape.g(x1) if x1 is not None else None)
+                done(gnn + ".weight", gnn + ".bias")
+                tape.setg(x0, dx0)
+                if x1 is not None:
+                    tape.setg(x1, dx1)
+            elif x1 is None:
+                tape.setg(x0, dgrad(dy, wn, k, cin0, stride=rec["stride"], residual=tape.g(x0), dst_blocked=blocked(x0)))
+            elif cin0 % 8 == 0 and cin1 % 64 == 0:   # one conv per source on that source's columns of W^T
+                tape.setg(x0, dgrad(dy, wn, k, cin0 + cin1, residual=tape.g(x0), col0=0, ncols=cin0))
+                tape.setg(x1, dgrad(dy, wn, k, cin0 + cin1, residual=tape.g(x1), col0=cin0, ncols=cin1))
+            else:   # narrow second source: one conv over the concatenation, split by channel block
+                da = dgrad(dy, wn, k, cin0 + cin1)
+                tape.addg(x0, da[:, :cin0 // 8].contiguous())
+                tape.addg(x1, da[:, cin0 // 8:].contiguous())
+        elif kind == "attn":
+            do = tape.g(rec["o"])
+            qkv = rec["qkv"]
+            n, c3, hh, ww = qkv.shape
+            dqkv = ops.attention_bwd(qkv.view(n, c3, hh * ww), rec["o"].view(n, c3 // 3, hh * ww),
+                                     do.view(n, c3 // 3, hh * ww), rec["lse"], rec["heads"])
+            tape.setg(qkv, dqkv.view(n, c3, hh, ww))
+        elif kind == "qkv":
+            dqkv = tape.g(rec["qkv"])
+            x, pre = rec["x"], rec["pre"]
+            c = chans(x)
+            sums = ops.channel_sums(dqkv)
+            x32 = ops.from_blocked(x)
+            for i, t in enumerate(("to_q", "to_k", "to_v")):
+                ops.reduce_rows_add(sums[:, i * c:], st.grad(f"{pre}.{t}.bias"), stride=sums.stride(0))
+                ops.conv_wgrad(x32, dqkv, st.grad(f"{pre}.{t}.weight"), ksize=1, gn_scale_shift=rec["ss"], silu=False,
+                               cout=c, dy_coff=i * c)
+                done(f"{pre}.{t}.weight", f"{pre}.{t}.bias")
+            _, wd, _ = st.qkv_w(pre)
+            if c % 64 == 0:
+                da = ops.conv2d_fused(dqkv, wd, ksize=1, cout=c, src_blocked=False, dst_blocked=True, compute_dtype=dt,
+                                      weight_h2=packs.qkv(pre, ops.PACK_DGRAD), weight_h2_stride=_pad64(c))
+            else:
+                da = ops.to_blocked(ops.conv2d_fused(dqkv, wd, ksize=1, cout=c), dt)
+            gnn = rec["gn"]
+            dx, _ = ops.gn_bwd_blocked(x, da, rec["ss"], rec["mr"], P[gnn + ".weight"].detach(), groups, False,
+                                       st.grad(gnn + ".weight"), st.grad(gnn + ".bias"), add0=tape.g(x))
+            done(gnn + ".weight", gnn + ".bias")
+            tape.setg(x, dx)
+    _backward_temb(st, tb, done)

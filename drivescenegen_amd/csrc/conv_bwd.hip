@@ -17,7 +17,7 @@
 // images (grid.y = K split); partial sums are added to dW (OIHW, the checkpoint layout) with fp32 atomics.
 // LDS: dY tile [64 co][64 px (+1 pad)], patch [ci][rows*cols (odd stride)] -- both conflict-free for the
 // lane patterns of v_mfma_f32_32x32x2_f32 (A/B: 32 consecutive rows at a fixed k).
-#include "dsg_common.h"
+#include "dsg_h16.h"
 #include <algorithm>
 #include <type_traits>
 
@@ -667,6 +667,270 @@ static int launch_wgrad_h2(WgradP p, size_t ws_bytes, hipStream_t st) {
   return DSG_OK;
 }
 
+// ---------------------------------------------------------------------------------------------------
+// Weight gradient of the mixed-precision tape: x and dY are channel-blocked 16-bit tensors [N][C/8][H][W][8] (bf16 or
+// fp16), one MFMA per product, fp32 accumulate.
+//
+// K is the pixel index, but in memory a pixel's 8 channels are adjacent -- the operands arrive transposed.  The LDS
+// keeps the global layout ([pixel][32 channels], 64 bytes per pixel: written with the 16-byte pieces as they were
+// loaded) and the fragments are fetched with ds_read_b64_tr_b16, gfx950's transposing read: within a 16-lane group
+// source lane s supplies the address of 4 contiguous 16-bit values and lane L receives, in slot k, element (L & 3) of
+// source lane 4 k + (L >> 2) (measured: tools/probes/probe_tr.hip).  With source lane s pointing at
+// [pixel p0 + (s >> 2)][channel quad (s & 3)] of a 16-channel group, lane L ends up with channel L of pixels
+// p0 .. p0 + 3: two reads give the 8 k-values of one 32x32x16 operand row, for A (activations, rows = ci) and B (dY,
+// columns = co) alike, so the pixel order inside a k-step is the same on both sides.  A tap's (dy, dx) shift is just
+// another pixel address: no pre-shifted copies.  64-byte pixel rows put the 4 pixels of a read on 4 x 16 distinct banks.
+//
+// Workgroup = 64 ci x 64 co x 9 taps (wave w: ci tile w >> 1, co tile w & 1, 9 accumulator tiles), walking consecutive
+// row pairs of one 32-column strip of one image through a 6-row LDS ring (every input row is activated and converted
+// once); GroupNorm affine + SiLU are recomputed in fp32 from the saved pre-norm tensor; split-K partials go to the same
+// workspace / fixed-order reduce as the fp32 kernels.
+// ---------------------------------------------------------------------------------------------------
+struct Wgrad16P {
+  const void* src0;
+  const void* src1;
+  int c0, c1, cin;
+  int n, h, w;          // stride 1, padding 1: source and dY maps have the same size
+  int cout;
+  const void* dy;       // blocked [N][dy_ctotal/8][h][w][8]; this conv's channels start at dy_coff
+  int dy_ctotal, dy_coff;
+  const float* ss;      // optional [N][cin][2]
+  int silu;
+  float* ws;            // [slab][9][cin][cout]
+  int tiles_x, stages;  // 32-column strips per row, row pairs per image
+  int ci_blocks, nrs;   // 64-channel ci blocks; row splits per strip
+};
+
+typedef short wg_s4 __attribute__((ext_vector_type(4)));
+constexpr int W16_SLOTS = 6, W16_PW = 34;
+constexpr int W16_A_HALFS = 2 * W16_SLOTS * W16_PW * 32;  // [ci tile 2][slot][col 34][32 ch]
+constexpr int W16_D_HALFS = 2 * 64 * 32;                  // [co tile 2][px 64][32 co], double-buffered
+constexpr int W16_LDS_BYTES = (W16_A_HALFS + 2 * W16_D_HALFS) * 2;
+
+template <int PREC>
+__global__ __launch_bounds__(256, 2) void conv_wgrad16_kernel(Wgrad16P p) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char wsm16[];
+  unsigned short* Ab = reinterpret_cast<unsigned short*>(wsm16);
+  unsigned short* Db = Ab + W16_A_HALFS;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int half = lane >> 5, l31 = lane & 31;
+  const int cit = wave >> 1, cot = wave & 1;
+
+  const int cib = blockIdx.x % p.ci_blocks, cob = blockIdx.x / p.ci_blocks;
+  const int ci0 = cib * 64, co0 = cob * 64;
+  const int plane = p.h * p.w;
+  const bool has_ss = p.ss != nullptr;
+  const bool do_silu = has_ss && p.silu;
+
+  // this workgroup's run: strip (image n, column tile tx), stages [s0, s1)
+  const int strip = blockIdx.y / p.nrs, rs = blockIdx.y - strip * p.nrs;
+  const int n = strip / p.tiles_x, tx = strip - n * p.tiles_x;
+  const int ox0 = tx * 32;
+  const int per = (p.stages + p.nrs - 1) / p.nrs;
+  const int s0 = rs * per, s1 = min(p.stages, s0 + per);
+
+  // the 64-channel ci block sits entirely in one of the two concatenated sources (c0 % 64 == 0)
+  const bool in0 = ci0 < p.c0;
+  const unsigned short* xsrc = in0 ? static_cast<const unsigned short*>(p.src0) + ((size_t)n * p.c0 + ci0) * plane
+                                   : static_cast<const unsigned short*>(p.src1) + ((size_t)n * p.c1 + (ci0 - p.c0)) * plane;
+  const unsigned short* dsrc = static_cast<const unsigned short*>(p.dy) + ((size_t)n * p.dy_ctotal + p.dy_coff + co0) * plane;
+
+  // staging items.  A: (row of the pair, column 0..33, channel block 0..7) = 544, three rounds; dY: (pixel 0..63, co block) = 512
+  const int a_cb = tid & 7;  // the same channel block in every round: its scale / shift live in registers
+  float sc[8], sh[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    sc[j] = 1.f;
+    sh[j] = 0.f;
+    if (has_ss) {
+      const float2 t2 = *reinterpret_cast<const float2*>(p.ss + ((size_t)n * p.cin + ci0 + a_cb * 8 + j) * 2);
+      sc[j] = t2.x;
+      sh[j] = t2.y;
+    }
+  }
+  int a_row[3], a_col[3];
+  bool a_use[3];
+#pragma unroll
+  for (int u = 0; u < 3; ++u) {
+    const int pc = (tid + 256 * u) >> 3;  // 0..95; valid below 68
+    a_use[u] = pc < 2 * W16_PW;
+    a_row[u] = pc / W16_PW;
+    a_col[u] = pc - a_row[u] * W16_PW;
+  }
+  uint4 xa[3], xd[2];
+  bool va[3];
+  auto load_rows = [&](int k) {  // input rows 2k-1, 2k of the strip (columns ox0-1 .. ox0+32)
+#pragma unroll
+    for (int u = 0; u < 3; ++u) {
+      const int y = 2 * k - 1 + a_row[u], x = ox0 - 1 + a_col[u];
+      va[u] = a_use[u] && (unsigned)y < (unsigned)p.h && (unsigned)x < (unsigned)p.w;
+      const size_t off = (size_t)a_cb * 8 * plane + ((size_t)(va[u] ? y : 0) * p.w + (va[u] ? x : 0)) * 8;
+      xa[u] = *reinterpret_cast<const uint4*>(xsrc + off);
+    }
+  };
+  auto load_dy = [&](int s) {  // output rows 2s, 2s+1 (clamped past the image: never used)
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int id = tid + 256 * u, cb = id & 7, px = id >> 3;
+      const int y = min(2 * s + (px >> 5), p.h - 1), x = ox0 + (px & 31);
+      xd[u] = *reinterpret_cast<const uint4*>(dsrc + (size_t)cb * 8 * plane + ((size_t)y * p.w + x) * 8);
+    }
+  };
+  auto commit_rows = [&](int k) {  // -> ring slots (2k) % 6, (2k) % 6 + 1
+#pragma unroll
+    for (int u = 0; u < 3; ++u) {
+      if (!a_use[u]) continue;
+      const unsigned w4[4] = {xa[u].x, xa[u].y, xa[u].z, xa[u].w};
+      unsigned o4[4];
+#pragma unroll
+      for (int jp = 0; jp < 4; ++jp) {
+        float a = lo16<PREC>(w4[jp]), b = hi16<PREC>(w4[jp]);
+        if (has_ss) {
+          a = a * sc[2 * jp] + sh[2 * jp];
+          b = b * sc[2 * jp + 1] + sh[2 * jp + 1];
+        }
+        if (do_silu) {
+          a = silu_fast_b(a);
+          b = silu_fast_b(b);
+        }
+        o4[jp] = va[u] ? pack2<PREC>(a, b) : 0u;  // zero padding applies to the ACTIVATED map
+      }
+      const int slot = (2 * k) % W16_SLOTS + a_row[u];
+      unsigned short* dst = Ab + (a_cb >> 2) * (W16_SLOTS * W16_PW * 32) + (slot * W16_PW + a_col[u]) * 32 + (a_cb & 3) * 8;
+      *reinterpret_cast<uint4*>(dst) = make_uint4(o4[0], o4[1], o4[2], o4[3]);
+    }
+  };
+  auto commit_dy = [&](int par) {
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int id = tid + 256 * u, cb = id & 7, px = id >> 3;
+      unsigned short* dst = Db + par * W16_D_HALFS + (cb >> 2) * (64 * 32) + px * 32 + (cb & 3) * 8;
+      *reinterpret_cast<uint4*>(dst) = xd[u];
+    }
+  };
+
+  wf32x16 acc[9];
+#pragma unroll
+  for (int t = 0; t < 9; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+
+  // prologue: row pairs s0, s0+1 and dY(s0) in LDS; pair s0+2 and dY(s0+1) in registers
+  if (s0 < s1) {
+    load_rows(s0);
+    load_dy(s0);
+    commit_rows(s0);
+    commit_dy(0);
+    load_rows(s0 + 1);
+    commit_rows(s0 + 1);
+    load_rows(s0 + 2);
+    load_dy(s0 + 1);
+  }
+  __syncthreads();
+
+  // transposing-read addressing of this lane: source lane s = lane & 15 -> pixel + (s >> 2), channel quad (s & 3) of the
+  // 16-channel group (lane >> 4) & 1 of the wave's 32-channel tile
+  const int s16 = lane & 15, g16 = (lane >> 4) & 1;
+  const int t_px = s16 >> 2, t_ch = g16 * 16 + (s16 & 3) * 4;
+  const unsigned short* a_lane = Ab + cit * (W16_SLOTS * W16_PW * 32) + t_ch;
+  const unsigned short* d_lane = Db + cot * (64 * 32) + t_ch;
+  auto tr4 = [](const unsigned short* q) -> wg_s4 {
+    return __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+        (__attribute__((address_space(3))) wg_s4*)(const_cast<unsigned short*>(q)));
+  };
+  typedef short wg_s8 __attribute__((ext_vector_type(8)));
+  for (int s = s0; s < s1; ++s) {
+    const int par = (s - s0) & 1;
+    // stage the next pair / dY tile (other ring slots, other dY buffer), then fetch the ones after them
+    commit_rows(s + 2);
+    commit_dy(par ^ 1);
+    load_rows(s + 3);
+    load_dy(s + 2);
+    const unsigned short* dl = d_lane + par * W16_D_HALFS;
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+      const int orow = kk >> 1, colb = (kk & 1) * 16 + half * 8 + t_px;  // this lane's first pixel of the k-step
+      const wg_s4 b0 = tr4(dl + (orow * 32 + colb) * 32), b1 = tr4(dl + (orow * 32 + colb + 4) * 32);
+      const half8 fb = __builtin_bit_cast(half8, wg_s8{b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w});
+#pragma unroll
+      for (int tp = 0; tp < 9; ++tp) {
+        const int dy = tp / 3, dx = tp % 3;
+        const int slot = (2 * s + orow + dy) % W16_SLOTS;  // input row 2s - 1 + orow + dy
+        const unsigned short* ap = a_lane + (slot * W16_PW + colb + dx) * 32;
+        const wg_s4 a0 = tr4(ap), a1 = tr4(ap + 4 * 32);
+        const half8 fa = __builtin_bit_cast(half8, wg_s8{a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w});
+        acc[tp] = mma16<PREC>(fa, fb, acc[tp]);
+      }
+    }
+    __syncthreads();
+  }
+
+  // epilogue: D[ci rows][co = l31]; partials to this run's slab [tap][ci][co]
+  const int co = co0 + cot * 32 + l31;
+  float* wsb = p.ws + (size_t)blockIdx.y * 9 * p.cin * p.cout;
+#pragma unroll
+  for (int tp = 0; tp < 9; ++tp)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int ci = ci0 + cit * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+      wsb[((size_t)tp * p.cin + ci) * p.cout + co] = acc[tp][r];
+    }
+}
+
+static void wgrad16_runs(int cin, int cout, int n, int hout, int wout, int* strips, int* rsplit) {
+  const int pairs = (cin / 64) * (cout / 64);
+  *strips = n * (wout / 32);
+  const int stages = hout / 2;
+  const int want = std::max(1, cdiv(512, pairs));  // workgroups wanted per (ci, co) block pair (2 per CU in all)
+  *rsplit = std::max(1, std::min(stages, cdiv(want, *strips)));
+}
+
+static bool wgrad16_ok(const dsg_conv_wgrad_args* a, int hout, int wout) {
+  const int cin = a->c0 + a->c1, ctot = a->dy_ctotal ? a->dy_ctotal : a->cout;
+  return a->ksize == 3 && a->stride == 1 && !a->upsample && cin % 64 == 0 && (a->c1 == 0 || a->c0 % 64 == 0) &&
+         a->cout % 64 == 0 && ctot % 8 == 0 && a->dy_coff % 64 == 0 && wout % 32 == 0 && hout % 2 == 0;
+}
+
+static size_t wgrad16_ws_bytes(int cin, int cout, int n, int hout, int wout) {
+  int strips, rsplit;
+  wgrad16_runs(cin, cout, n, hout, wout, &strips, &rsplit);
+  return (size_t)strips * rsplit * 9 * cin * cout * sizeof(float);
+}
+
+static int launch_wgrad16(const dsg_conv_wgrad_args* a, int hout, int wout, hipStream_t st) {
+  Wgrad16P p;
+  p.src0 = a->src0; p.src1 = a->src1; p.c0 = a->c0; p.c1 = a->c1; p.cin = a->c0 + a->c1;
+  p.n = a->n; p.h = a->hin; p.w = a->win; p.cout = a->cout;
+  p.dy = a->dy; p.dy_ctotal = a->dy_ctotal ? a->dy_ctotal : a->cout; p.dy_coff = a->dy_coff;
+  p.ss = a->gn_scale_shift; p.silu = a->silu; p.ws = static_cast<float*>(a->workspace);
+  p.tiles_x = wout / 32; p.stages = hout / 2; p.ci_blocks = p.cin / 64;
+  int strips, rsplit;
+  wgrad16_runs(p.cin, p.cout, p.n, hout, wout, &strips, &rsplit);
+  p.nrs = rsplit;
+  const int nslab = strips * rsplit;
+  const size_t need = (size_t)nslab * 9 * p.cin * p.cout * sizeof(float);
+  if (p.ws == nullptr || a->workspace_bytes < need)
+    return fail(DSG_ERR_WORKSPACE_TOO_SMALL, "dsg_conv2d_wgrad: workspace %zu bytes < required %zu", a->workspace_bytes, need);
+  int pi = -1;
+  if (prof_on())
+    pi = prof_begin(29, 2.0 * p.n * hout * wout * (double)p.cout * p.cin * 9,
+                    2.0 * ((double)p.n * p.cin * p.h * p.w + (double)p.n * p.cout * hout * wout), st);
+  const dim3 grid(p.ci_blocks * (p.cout / 64), nslab);
+  if (a->compute_dtype == DSG_BF16)
+    hipLaunchKernelGGL(conv_wgrad16_kernel<1>, grid, dim3(256), (size_t)W16_LDS_BYTES, st, p);
+  else
+    hipLaunchKernelGGL(conv_wgrad16_kernel<2>, grid, dim3(256), (size_t)W16_LDS_BYTES, st, p);
+  DSG_LAUNCH_CHECK();
+  const int64_t slab = (int64_t)9 * p.cin * p.cout;
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)cdiv64(slab / 4, 64)), dim3(256), 0, st, p.ws, nslab, 9, p.cin,
+                     p.cout, p.cin, p.cout, a->dw);
+  prof_end(pi, st);
+  DSG_LAUNCH_CHECK();
+  return DSG_OK;
+}
+
 // bytes of split-K workspace the MFMA path needs for these dims (0 for the VALU fallback)
 static size_t wgrad_ws_bytes(int cin, int cout, int ks, int stride, int hout, int wout, int n) {
   if ((wout % 32) || (hout % WG_SR)) return 0;
@@ -700,6 +964,14 @@ DSG_API int dsg_conv2d_wgrad(const dsg_conv_wgrad_args* a, void* stream) {
   DSG_CHECK_ARG(a->dy_coff >= 0 && (a->dy_ctotal == 0 || a->dy_coff + a->cout <= a->dy_ctotal),
                 "dsg_conv2d_wgrad: dy channel window out of range");
   hipStream_t st = static_cast<hipStream_t>(stream);
+  DSG_CHECK_ARG(a->compute_dtype >= DSG_F32 && a->compute_dtype <= DSG_F16, "dsg_conv2d_wgrad: bad compute_dtype %d", a->compute_dtype);
+  if (a->compute_dtype != DSG_F32) {  // mixed-precision tape: channel-blocked 16-bit x and dY
+    DSG_CHECK_SHAPE(wgrad16_ok(a, a->hin, a->win) && !a->force_direct,
+                    "dsg_conv2d_wgrad: the 16-bit kernel takes 3x3 stride-1 convs with cin %% 64 == 0, cout %% 64 == 0, "
+                    "wout %% 32 == 0, hout %% 2 == 0 (got k %d, stride %d, cin %d + %d, cout %d, %dx%d); convert to fp32 "
+                    "[N,C,H,W] for the rest", a->ksize, a->stride, a->c0, a->c1, a->cout, a->hin, a->win);
+    return launch_wgrad16(a, a->hin, a->win, st);
+  }
   WgradP p;
   p.src0 = a->src0; p.src1 = a->src1; p.c0 = a->c0; p.c1 = a->c1; p.cin = a->c0 + a->c1;
   p.n = a->n; p.hin = a->hin; p.win = a->win;
@@ -734,6 +1006,11 @@ DSG_API int dsg_conv2d_wgrad_workspace_bytes(const dsg_conv_wgrad_args* a, size_
   const int hc = a->upsample ? 2 * a->hin : a->hin, wc = a->upsample ? 2 * a->win : a->win;
   const int pad = a->ksize / 2;
   const int hout = (hc + 2 * pad - a->ksize) / a->stride + 1, wout = (wc + 2 * pad - a->ksize) / a->stride + 1;
+  if (a->compute_dtype != DSG_F32) {
+    DSG_CHECK_SHAPE(dsg::wgrad16_ok(a, hout, wout), "dsg_conv2d_wgrad_workspace_bytes: shape not served by the 16-bit kernel");
+    *bytes = dsg::wgrad16_ws_bytes(a->c0 + a->c1, a->cout, a->n, hout, wout);
+    return DSG_OK;
+  }
   *bytes = a->force_direct ? 0 : dsg::wgrad_ws_bytes(a->c0 + a->c1, a->cout, a->ksize, a->stride, hout, wout, a->n);
   return DSG_OK;
 }

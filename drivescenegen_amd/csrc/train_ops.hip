@@ -11,7 +11,7 @@
 //  - small linear-layer backward (time MLP, time_emb_proj), SiLU backward;
 //  - MSE loss forward+backward, global grad-norm (sum of squares), fused AdamW with the clip factor
 //    applied on the fly.
-#include "dsg_common.h"
+#include "dsg_h16.h"
 #include <cmath>
 
 namespace dsg {
@@ -440,7 +440,274 @@ __global__ __launch_bounds__(256) void sumpool2x2_kernel(const float* __restrict
   }
   *reinterpret_cast<float2*>(dst + r * w + 2 * x2) = o;
 }
+
+// ---------------------------------------------------------------------------------------------------------------
+// The same passes for the mixed-precision training tape: channel-blocked 16-bit tensors [N][C/8][hw][8] (dt: 1 bf16,
+// 2 fp16; include/dsg.h dsg_dtype).  A thread owns one pixel's 8 channels = one 16-byte access per tensor; all
+// arithmetic in fp32, sums in fp64 across threads, results rounded once.
+// ---------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void unpack8(const uint4& q, int dt, float (&v)[8]) {
+  v[0] = word_lo(q.x, dt); v[1] = word_hi(q.x, dt); v[2] = word_lo(q.y, dt); v[3] = word_hi(q.y, dt);
+  v[4] = word_lo(q.z, dt); v[5] = word_hi(q.z, dt); v[6] = word_lo(q.w, dt); v[7] = word_hi(q.w, dt);
+}
+__device__ __forceinline__ uint4 pack8(const float (&v)[8], int dt) {
+  return make_uint4(word_pack(v[0], v[1], dt), word_pack(v[2], v[3], dt), word_pack(v[4], v[5], dt), word_pack(v[6], v[7], dt));
+}
+
+// block-wide sums of 16 floats (8 channels x 2 quantities) -> doubles, fixed order; valid in threads 0..15
+__device__ __forceinline__ double block_sum16(const float (&a)[8], const float (&b)[8]) {
+  __shared__ double red16[16][4];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const double x = wave_sum_d((double)a[j]), y = wave_sum_d((double)b[j]);
+    if (lane == 0) {
+      red16[2 * j][wave] = x;
+      red16[2 * j + 1][wave] = y;
+    }
+  }
+  __syncthreads();
+  double r = 0.0;
+  if (threadIdx.x < 16) r = (red16[threadIdx.x][0] + red16[threadIdx.x][1]) + (red16[threadIdx.x][2] + red16[threadIdx.x][3]);
+  return r;
+}
+
+// grid = ((c0 + c1) / 8, n, splits): partial[n][c][split] = (sum du, sum du * xhat) over the split's run of pixels
+__global__ __launch_bounds__(256) void gn_bwd_stats_blk_kernel(const void* __restrict__ src0, int c0,
+                                                               const void* __restrict__ src1, int c1,
+                                                               const void* __restrict__ dy, const float* __restrict__ ss,
+                                                               const float* __restrict__ mr, int silu, int hw_total, int dt,
+                                                               double* __restrict__ part) {
+  const int cb = blockIdx.x, n = blockIdx.y, sp = blockIdx.z, splits = gridDim.z, ct = c0 + c1;
+  const int hw = hw_total / splits;
+  const bool first = cb * 8 < c0;
+  const unsigned short* xb = first ? static_cast<const unsigned short*>(src0) + ((size_t)n * c0 + cb * 8) * hw_total
+                                   : static_cast<const unsigned short*>(src1) + ((size_t)n * c1 + (cb * 8 - c0)) * hw_total;
+  const uint4* xp = reinterpret_cast<const uint4*>(xb) + (size_t)sp * hw;
+  const uint4* dp = reinterpret_cast<const uint4*>(static_cast<const unsigned short*>(dy) + ((size_t)n * ct + cb * 8) * hw_total) +
+                    (size_t)sp * hw;
+  const size_t k0 = ((size_t)n * ct + cb * 8) * 2;
+  float sc[8], sh[8], mean[8], rstd[8], a[8], b[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    sc[j] = ss[k0 + 2 * j]; sh[j] = ss[k0 + 2 * j + 1]; mean[j] = mr[k0 + 2 * j]; rstd[j] = mr[k0 + 2 * j + 1];
+    a[j] = b[j] = 0.f;
+  }
+  for (int i = threadIdx.x; i < hw; i += 256) {
+    float x[8], du[8];
+    unpack8(xp[i], dt, x);
+    unpack8(dp[i], dt, du);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      if (silu) du[j] *= dsilu(x[j] * sc[j] + sh[j]);
+      a[j] += du[j];
+      b[j] += du[j] * ((x[j] - mean[j]) * rstd[j]);
+    }
+  }
+  const double r = block_sum16(a, b);
+  if (threadIdx.x < 16)
+    part[(((size_t)n * ct + cb * 8 + (threadIdx.x >> 1)) * splits + sp) * 2 + (threadIdx.x & 1)] = r;
+}
+
+// s12[i] = sum over splits of part[i][split] (fixed order)
+__global__ void sum_splits_kernel(const double* __restrict__ part, int64_t count, int splits, double* __restrict__ out) {
+  const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;  // over (n, c, which)
+  if (i >= count) return;
+  const int64_t nc = i >> 1;
+  const int which = (int)(i & 1);
+  double s = 0.0;
+  for (int k = 0; k < splits; ++k) s += part[(nc * splits + k) * 2 + which];
+  out[i] = s;
+}
+
+// grid = (ceil(hw / 256), (c0 + c1) / 8, n): dx = k0 * du - k1 - xhat * k2 (+ addend), one pixel x 8 channels per thread
+__global__ __launch_bounds__(256) void gn_bwd_apply_blk_kernel(const void* __restrict__ src0, int c0,
+                                                               const void* __restrict__ src1, int c1,
+                                                               const void* __restrict__ dy, const float* __restrict__ ss,
+                                                               const float* __restrict__ mr, const float* __restrict__ coef,
+                                                               int silu, int hw, int dt, const void* __restrict__ add0,
+                                                               const void* __restrict__ add1, void* __restrict__ dx0,
+                                                               void* __restrict__ dx1) {
+  const int cb = blockIdx.y, n = blockIdx.z, ct = c0 + c1;
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= hw) return;
+  const bool first = cb * 8 < c0;
+  const size_t xo = (first ? ((size_t)n * c0 + cb * 8) : ((size_t)n * c1 + (cb * 8 - c0))) * hw + (size_t)i * 8;  // elements
+  const unsigned short* xs = static_cast<const unsigned short*>(first ? src0 : src1);
+  const unsigned short* as = static_cast<const unsigned short*>(first ? add0 : add1);
+  unsigned short* ds = static_cast<unsigned short*>(first ? dx0 : dx1);
+  const size_t k = (size_t)n * ct + cb * 8;
+  float x[8], du[8], ad[8], v[8];
+  unpack8(*reinterpret_cast<const uint4*>(xs + xo), dt, x);
+  unpack8(*reinterpret_cast<const uint4*>(static_cast<const unsigned short*>(dy) + k * hw + (size_t)i * 8), dt, du);
+  if (as) unpack8(*reinterpret_cast<const uint4*>(as + xo), dt, ad);
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const size_t kj = k + j;
+    float d = du[j];
+    if (silu) d *= dsilu(x[j] * ss[2 * kj] + ss[2 * kj + 1]);
+    v[j] = coef[3 * kj] * d - coef[3 * kj + 1] - ((x[j] - mr[2 * kj]) * mr[2 * kj + 1]) * coef[3 * kj + 2];
+    if (as) v[j] += ad[j];
+  }
+  *reinterpret_cast<uint4*>(ds + xo) = pack8(v, dt);
+}
+
+// grid = (c / 8, n): out[n][c] = sum over hw of a channel-blocked 16-bit tensor
+__global__ __launch_bounds__(256) void channel_sums_blk_kernel(const void* __restrict__ x, int c, int hw, int dt,
+                                                               float* __restrict__ out, int out_stride) {
+  const int cb = blockIdx.x, n = blockIdx.y;
+  const uint4* xp = reinterpret_cast<const uint4*>(static_cast<const unsigned short*>(x) + ((size_t)n * c + cb * 8) * hw);
+  float a[8], b[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) a[j] = b[j] = 0.f;
+  // two interleaved fp32 partial sums per channel, combined in fp64 (b carries the odd iterations)
+  int it = 0;
+  for (int i = threadIdx.x; i < hw; i += 256, ++it) {
+    float v[8];
+    unpack8(xp[i], dt, v);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      if (it & 1) b[j] += v[j];
+      else a[j] += v[j];
+    }
+  }
+  const double r = block_sum16(a, b);
+  __shared__ double pair[16];
+  if (threadIdx.x < 16) pair[threadIdx.x] = r;
+  __syncthreads();
+  if (threadIdx.x < 8) out[(size_t)n * out_stride + cb * 8 + threadIdx.x] = (float)(pair[2 * threadIdx.x] + pair[2 * threadIdx.x + 1]);
+}
+
+// out = a + b over 16-bit values (8 per thread-step)
+__global__ __launch_bounds__(256) void add2_16_kernel(const uint4* __restrict__ a, const uint4* __restrict__ b, int64_t n8,
+                                                      int dt, uint4* __restrict__ out) {
+  for (int64_t i = blockIdx.x * (int64_t)256 + threadIdx.x; i < n8; i += (int64_t)gridDim.x * 256) {
+    float x[8], y[8];
+    unpack8(a[i], dt, x);
+    unpack8(b[i], dt, y);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) x[j] += y[j];
+    out[i] = pack8(x, dt);
+  }
+}
+
+// channel-blocked [planes = N * C/8][h][w][8] -> [planes][2h][2w][8]: a pixel (16 bytes) is copied to its 2x2 block
+__global__ __launch_bounds__(256) void upsample2x_blk_kernel(const uint4* __restrict__ src, uint4* __restrict__ dst, int h,
+                                                             int w, int64_t total) {
+  const int64_t i = blockIdx.x * (int64_t)256 + threadIdx.x;  // over (plane, y, x) of the source
+  if (i >= total) return;
+  const int x = (int)(i % w);
+  const int64_t r = i / w;  // plane * h + y
+  const uint4 v = src[i];
+  uint4* d = dst + (r * 2) * (2 * (int64_t)w) + 2 * x;
+  d[0] = v; d[1] = v; d[2 * w] = v; d[2 * w + 1] = v;
+}
+
+// the adjoint: [planes][2h][2w][8] -> [planes][h][w][8] sums of 2x2 blocks (+ add), fp32 arithmetic
+__global__ __launch_bounds__(256) void sumpool2x2_blk_kernel(const uint4* __restrict__ src, const uint4* __restrict__ add,
+                                                             uint4* __restrict__ dst, int h, int w, int dt, int64_t total) {
+  const int64_t i = blockIdx.x * (int64_t)256 + threadIdx.x;  // over (plane, y, x) of the result
+  if (i >= total) return;
+  const int x = (int)(i % w);
+  const int64_t r = i / w;
+  const uint4* s = src + (r * 2) * (2 * (int64_t)w) + 2 * x;
+  float a[8], b[8], c[8], d[8];
+  unpack8(s[0], dt, a); unpack8(s[1], dt, b); unpack8(s[2 * w], dt, c); unpack8(s[2 * w + 1], dt, d);
+#pragma unroll
+  for (int j = 0; j < 8; ++j) a[j] = (a[j] + b[j]) + (c[j] + d[j]);
+  if (add) {
+    unpack8(add[i], dt, b);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) a[j] += b[j];
+  }
+  dst[i] = pack8(a, dt);
+}
 }  // namespace dsg
+
+#define DSG_CHECK_DT16(dt, who) DSG_CHECK_ARG((dt) == DSG_BF16 || (dt) == DSG_F16, who ": dtype must be DSG_BF16 or DSG_F16")
+
+DSG_API int dsg_gn_bwd_blocked(const void* src0, int32_t c0, const void* src1, int32_t c1, const void* dy,
+                               const float* scale_shift, const float* mean_rstd, const float* gamma, int32_t silu,
+                               int32_t n, int32_t hw, int32_t groups, const void* add0, const void* add1, void* dx0,
+                               void* dx1, float* dgamma, float* dbeta, double* ws_s12, float* ws_coef, int32_t dtype,
+                               void* stream) {
+  using namespace dsg;
+  DSG_CHECK_ARG(src0 && dy && scale_shift && mean_rstd && gamma && dx0 && dgamma && dbeta && ws_s12 && ws_coef,
+                "dsg_gn_bwd_blocked: NULL pointer");
+  DSG_CHECK_DT16(dtype, "dsg_gn_bwd_blocked");
+  DSG_CHECK_ARG(c0 > 0 && c1 >= 0 && c0 % 8 == 0 && c1 % 8 == 0 && n > 0 && hw > 0 && groups > 0, "dsg_gn_bwd_blocked: bad dims");
+  DSG_CHECK_ARG((c1 == 0) == (src1 == nullptr) && (c1 == 0 || dx1 != nullptr), "dsg_gn_bwd_blocked: src1/dx1/c1 mismatch");
+  const int c = c0 + c1;
+  DSG_CHECK_ARG(c % groups == 0 && n <= 65535, "dsg_gn_bwd_blocked: channels not divisible by groups / batch too large");
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const int splits = dsg_gn_bwd_blocked_splits(hw);
+  // ws_s12: [N][C][2] sums followed by the [N][C][splits][2] partials
+  double* part = ws_s12 + (size_t)n * c * 2;
+  hipLaunchKernelGGL(gn_bwd_stats_blk_kernel, dim3(c / 8, n, splits), dim3(256), 0, st, src0, c0, src1, c1, dy, scale_shift,
+                     mean_rstd, silu, hw, dtype, part);
+  DSG_LAUNCH_CHECK();
+  hipLaunchKernelGGL(sum_splits_kernel, dim3((unsigned)cdiv64((int64_t)n * c * 2, 256)), dim3(256), 0, st, part,
+                     (int64_t)n * c * 2, splits, ws_s12);
+  DSG_LAUNCH_CHECK();
+  hipLaunchKernelGGL(gn_bwd_finalize_kernel, dim3(cdiv(n * c, 256)), dim3(256), 0, st, ws_s12, gamma, mean_rstd, n, c, groups,
+                     hw, ws_coef, dgamma, dbeta);
+  DSG_LAUNCH_CHECK();
+  hipLaunchKernelGGL(gn_bwd_apply_blk_kernel, dim3(cdiv(hw, 256), c / 8, n), dim3(256), 0, st, src0, c0, src1, c1, dy,
+                     scale_shift, mean_rstd, ws_coef, silu, hw, dtype, add0, add1, dx0, dx1);
+  DSG_LAUNCH_CHECK();
+  return DSG_OK;
+}
+
+DSG_API int dsg_gn_bwd_blocked_splits(int32_t hw) {
+  int splits = 1;
+  while (splits < 16 && hw % (2 * splits) == 0 && hw / (2 * splits) >= 2048) splits *= 2;
+  return splits;
+}
+
+DSG_API int dsg_channel_sums_blocked(const void* x, int32_t n, int32_t c, int32_t hw, float* out_nc, int32_t out_stride,
+                                     int32_t dtype, void* stream) {
+  DSG_CHECK_ARG(x && out_nc, "dsg_channel_sums_blocked: NULL pointer");
+  DSG_CHECK_DT16(dtype, "dsg_channel_sums_blocked");
+  DSG_CHECK_ARG(n > 0 && c > 0 && c % 8 == 0 && hw > 0 && n <= 65535 && out_stride >= c, "dsg_channel_sums_blocked: bad dims");
+  hipLaunchKernelGGL(dsg::channel_sums_blk_kernel, dim3(c / 8, n), dim3(256), 0, static_cast<hipStream_t>(stream), x, c, hw,
+                     dtype, out_nc, out_stride);
+  DSG_LAUNCH_CHECK();
+  return DSG_OK;
+}
+
+DSG_API int dsg_add_dt(const void* a, const void* b, int64_t numel, void* out, int32_t dtype, void* stream) {
+  if (dtype == DSG_F32)
+    return dsg_add(static_cast<const float*>(a), static_cast<const float*>(b), numel, static_cast<float*>(out), stream);
+  DSG_CHECK_DT16(dtype, "dsg_add_dt");
+  DSG_CHECK_ARG(a && b && out && numel > 0 && numel % 8 == 0, "dsg_add_dt: bad argument (16-bit tensors: numel %% 8 == 0)");
+  hipLaunchKernelGGL(dsg::add2_16_kernel, dim3(dsg::stream_blocks2(numel / 8)), dim3(256), 0, static_cast<hipStream_t>(stream),
+                     static_cast<const uint4*>(a), static_cast<const uint4*>(b), numel / 8, dtype, static_cast<uint4*>(out));
+  DSG_LAUNCH_CHECK();
+  return DSG_OK;
+}
+
+DSG_API int dsg_upsample_nearest2x_blocked(const void* src, void* dst, int64_t planes, int32_t h, int32_t w, int32_t dtype,
+                                           void* stream) {
+  DSG_CHECK_ARG(src && dst && planes > 0 && h > 0 && w > 0, "dsg_upsample_nearest2x_blocked: bad argument");
+  DSG_CHECK_DT16(dtype, "dsg_upsample_nearest2x_blocked");
+  const int64_t total = planes * h * w;
+  hipLaunchKernelGGL(dsg::upsample2x_blk_kernel, dim3((unsigned)dsg::cdiv64(total, 256)), dim3(256), 0,
+                     static_cast<hipStream_t>(stream), static_cast<const uint4*>(src), static_cast<uint4*>(dst), h, w, total);
+  DSG_LAUNCH_CHECK();
+  return DSG_OK;
+}
+
+DSG_API int dsg_sumpool2x2_blocked(const void* src, const void* add, void* dst, int64_t planes, int32_t h, int32_t w,
+                                   int32_t dtype, void* stream) {
+  DSG_CHECK_ARG(src && dst && planes > 0 && h > 0 && w > 0, "dsg_sumpool2x2_blocked: bad argument");
+  DSG_CHECK_DT16(dtype, "dsg_sumpool2x2_blocked");
+  const int64_t total = planes * h * w;
+  hipLaunchKernelGGL(dsg::sumpool2x2_blk_kernel, dim3((unsigned)dsg::cdiv64(total, 256)), dim3(256), 0,
+                     static_cast<hipStream_t>(stream), static_cast<const uint4*>(src), static_cast<const uint4*>(add),
+                     static_cast<uint4*>(dst), h, w, dtype, total);
+  DSG_LAUNCH_CHECK();
+  return DSG_OK;
+}
 
 DSG_API int dsg_upsample_nearest2x(const float* src, float* dst, int64_t planes, int32_t h, int32_t w, void* stream) {
   DSG_CHECK_ARG(src && dst && planes > 0 && h > 0 && w > 0 && (w & 1) == 0, "dsg_upsample_nearest2x: bad argument (w even)");

@@ -343,17 +343,35 @@ def postprocess(x, mode=0):
 # ---------------------------------------------------------------------------------------------------
 # Training-step ops (backward / loss / optimizer); see include/dsg.h "Training step"
 # ---------------------------------------------------------------------------------------------------
+def wgrad16_supported(c0, c1, cout, h, w, ksize=3, stride=1, upsample=False, dy_coff=0) -> bool:
+    """Shapes dsg_conv2d_wgrad serves on channel-blocked 16-bit tensors (include/dsg.h); the rest goes through
+    from_blocked() and the fp32 form."""
+    return (ksize == 3 and stride == 1 and not upsample and (c0 + c1) % 64 == 0 and (c1 == 0 or c0 % 64 == 0)
+            and cout % 64 == 0 and dy_coff % 64 == 0 and w % 32 == 0 and h % 2 == 0)
+
+
 def conv_wgrad(src0, dy, dw, src1=None, ksize=3, stride=1, upsample=False, gn_scale_shift=None, silu=False,
                direct=False, cout=None, dy_coff=0):
-    """dw[cout][cin][k][k] += wgrad; the activation is recomputed from (src, gn_scale_shift)."""
-    n, c0, hin, win = src0.shape
+    """dw[cout][cin][k][k] += wgrad; the activation is recomputed from (src, gn_scale_shift).  Channel-blocked 16-bit
+    src / dy tensors ([N, C/8, H, W, 8] bf16 / fp16, the mixed-precision tape) select the 16-bit kernel."""
     a = _lib.ConvWgradArgs()
+    if src0.dim() == 5:
+        n, cb0, hin, win, _ = src0.shape
+        c0, c1 = 8 * cb0, (8 * src1.shape[1] if src1 is not None else 0)
+        dy_c = 8 * dy.shape[1]
+        a.compute_dtype = _DT_OF[src0.dtype]
+        if dy.dtype != src0.dtype or dy.dim() != 5:
+            raise RuntimeError("conv_wgrad: src and dy must both be channel-blocked tensors of one 16-bit dtype")
+    else:
+        n, c0, hin, win = src0.shape
+        c1 = src1.shape[1] if src1 is not None else 0
+        dy_c = dy.shape[1]
     a.src0, a.src1 = _lib.ptr(src0), _lib.ptr(src1)
-    a.c0, a.c1 = c0, (src1.shape[1] if src1 is not None else 0)
+    a.c0, a.c1 = c0, c1
     a.n, a.hin, a.win = n, hin, win
-    a.upsample, a.ksize, a.stride, a.cout = int(upsample), ksize, stride, cout or dy.shape[1]
+    a.upsample, a.ksize, a.stride, a.cout = int(upsample), ksize, stride, cout or dy_c
     a.dy, a.gn_scale_shift, a.silu = _lib.ptr(dy), _lib.ptr(gn_scale_shift), int(silu)
-    a.dy_ctotal, a.dy_coff = dy.shape[1], dy_coff
+    a.dy_ctotal, a.dy_coff = dy_c, dy_coff
     a.dw, a.force_direct = _lib.ptr(dw), int(direct)
     lib = _lib.load()
     need = C.c_size_t()
@@ -416,8 +434,36 @@ def gn_bwd(src0, dy, ss, mr, gamma, groups, silu, dgamma, dbeta, src1=None, add0
     return dx0, dx1
 
 
+def gn_bwd_blocked(src0, dy, ss, mr, gamma, groups, silu, dgamma, dbeta, src1=None, add0=None, add1=None):
+    """gn_bwd on channel-blocked 16-bit tensors [N, C/8, H, W, 8] (dy covers cat(src0, src1)); returns (dx0, dx1)."""
+    n, cb0, h, w, _ = src0.shape
+    c0, c1 = 8 * cb0, (8 * src1.shape[1] if src1 is not None else 0)
+    c, hw = c0 + c1, h * w
+    lib = _lib.load()
+    splits = lib.dsg_gn_bwd_blocked_splits(hw)
+    dx0 = torch.empty_like(src0)
+    dx1 = torch.empty_like(src1) if src1 is not None else None
+    s12 = torch.empty(n * c * 2 * (1 + splits), dtype=torch.float64, device=src0.device)
+    coef = torch.empty((n, c, 3), dtype=torch.float32, device=src0.device)
+    with torch.cuda.device(src0.device):
+        _lib.check(lib.dsg_gn_bwd_blocked(_lib.ptr(src0), c0, _lib.ptr(src1), c1, _lib.ptr(dy), _lib.ptr(ss), _lib.ptr(mr),
+                                          _lib.ptr(gamma), int(silu), n, hw, groups, _lib.ptr(add0), _lib.ptr(add1),
+                                          _lib.ptr(dx0), _lib.ptr(dx1), _lib.ptr(dgamma), _lib.ptr(dbeta), _lib.ptr(s12),
+                                          _lib.ptr(coef), _DT_OF[src0.dtype], _st(src0)))
+    return dx0, dx1
+
+
 def channel_sums(x, out=None, out_stride=None):
-    """[N, C, ...] -> [N, C] sums over the trailing dims (optionally into rows of a wider matrix)."""
+    """[N, C, ...] -> [N, C] sums over the trailing dims (optionally into rows of a wider matrix); channel-blocked
+    16-bit tensors [N, C/8, H, W, 8] are summed per channel likewise."""
+    if x.dim() == 5:
+        n, cb, h, w, _ = x.shape
+        if out is None:
+            out = torch.empty((n, cb * 8), dtype=torch.float32, device=x.device)
+        with torch.cuda.device(x.device):
+            _lib.check(_lib.load().dsg_channel_sums_blocked(_lib.ptr(x), n, cb * 8, h * w, out.data_ptr(),
+                                                            out_stride or out.stride(0), _DT_OF[x.dtype], _st(x)))
+        return out
     n, c = x.shape[0], x.shape[1]
     if out is None:
         out = torch.empty((n, c), dtype=torch.float32, device=x.device)
@@ -428,7 +474,13 @@ def channel_sums(x, out=None, out_stride=None):
 
 
 def upsample_nearest2x(x):
-    """[N, C, h, w] -> [N, C, 2h, 2w] (dsg_upsample_nearest2x)."""
+    """[N, C, h, w] -> [N, C, 2h, 2w] (dsg_upsample_nearest2x); channel-blocked 16-bit [N, C/8, h, w, 8] likewise."""
+    if x.dim() == 5:
+        n, cb, h, w, _ = x.shape
+        out = torch.empty((n, cb, 2 * h, 2 * w, 8), dtype=x.dtype, device=x.device)
+        with torch.cuda.device(x.device):
+            _lib.check(_lib.load().dsg_upsample_nearest2x_blocked(_lib.ptr(x), _lib.ptr(out), n * cb, h, w, _DT_OF[x.dtype], _st(x)))
+        return out
     n, c, h, w = x.shape
     out = torch.empty((n, c, 2 * h, 2 * w), dtype=torch.float32, device=x.device)
     with torch.cuda.device(x.device):
@@ -438,6 +490,13 @@ def upsample_nearest2x(x):
 
 def sumpool2x2(x, add=None):
     """[N, C, 2h, 2w] -> [N, C, h, w] sums of 2x2 blocks (+ add): the adjoint of upsample_nearest2x."""
+    if x.dim() == 5:
+        n, cb, h2, w2, _ = x.shape
+        out = torch.empty((n, cb, h2 // 2, w2 // 2, 8), dtype=x.dtype, device=x.device)
+        with torch.cuda.device(x.device):
+            _lib.check(_lib.load().dsg_sumpool2x2_blocked(_lib.ptr(x), _lib.ptr(add), _lib.ptr(out), n * cb, h2 // 2, w2 // 2,
+                                                          _DT_OF[x.dtype], _st(x)))
+        return out
     n, c, h2, w2 = x.shape
     out = torch.empty((n, c, h2 // 2, w2 // 2), dtype=torch.float32, device=x.device)
     with torch.cuda.device(x.device):
@@ -448,7 +507,7 @@ def sumpool2x2(x, add=None):
 def add(a, b):
     out = torch.empty_like(a)
     with torch.cuda.device(a.device):
-        _lib.check(_lib.load().dsg_add(_lib.ptr(a), _lib.ptr(b), a.numel(), _lib.ptr(out), _st(a)))
+        _lib.check(_lib.load().dsg_add_dt(_lib.ptr(a), _lib.ptr(b), a.numel(), _lib.ptr(out), _DT_OF[a.dtype], _st(a)))
     return out
 
 

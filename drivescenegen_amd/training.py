@@ -551,22 +551,25 @@ class Accelerator:
         if self._buckets is None or self._buckets.flat.data_ptr() != st.grad_flat.data_ptr():
             self._buckets = GradBuckets(st.grad_flat, st.offsets)
             st.grad_ready_hooks[:] = [self._on_ready]
+            st.post_backward[:] = [self._finish_buckets]  # (runs when the backward walk is done, before its loss scale is removed)
         return self._buckets
+
+    def _finish_buckets(self):
+        if self.sync_gradients and self._buckets is not None:
+            self._buckets.finish()
 
     def _on_ready(self, name):
         if self.sync_gradients and self._buckets is not None:
             self._buckets.ready(name)
 
     def backward(self, loss):
-        b = self._ensure_buckets()
+        self._ensure_buckets()
         mult = 1.0 / self.gradient_accumulation_steps
         if self.scaler is not None:
             mult *= self.scaler.get_scale()
         if mult != 1.0:
             loss = _ScaleLoss.apply(loss, mult)
-        loss.backward()
-        if b is not None and self.sync_gradients:
-            b.finish()
+        loss.backward()  # (the tape's end-of-backward callback finishes the bucketed all-reduce: _finish_buckets)
 
     def clip_grad_norm_(self, parameters, max_norm, norm_type=2):
         if not self.sync_gradients:

@@ -298,6 +298,12 @@ typedef struct {
   int32_t force_direct;         /* test hook: VALU reference kernel */
   void* workspace;              /* split-K partial sums, summed in a fixed order (deterministic) */
   size_t workspace_bytes;       /* >= dsg_conv2d_wgrad_workspace_bytes(args) */
+  int32_t compute_dtype;        /* dsg_dtype.  DSG_F32: fp32 [N, C, H, W] tensors as above.  DSG_BF16 / DSG_F16 (the mixed-
+                                   precision training tape): src0 / src1 / dy are channel-blocked [N, C/8, H, W, 8] tensors of
+                                   that type, products run once on the 16-bit matrix cores, dw stays fp32.  Served: 3x3
+                                   stride-1 convs with (c0 + c1) % 64 == 0, c0 % 64 == 0 when c1 > 0, cout % 64 == 0,
+                                   dy_ctotal % 8 == 0 and dy_coff % 64 == 0, wout % 32 == 0, hout % 2 == 0; anything else is
+                                   DSG_ERR_UNSUPPORTED_SHAPE (convert with dsg_layout_convert_dt and use the fp32 form). */
 } dsg_conv_wgrad_args;
 int dsg_conv2d_wgrad(const dsg_conv_wgrad_args* a, void* stream);
 int dsg_conv2d_wgrad_workspace_bytes(const dsg_conv_wgrad_args* a, size_t* bytes);
@@ -311,6 +317,21 @@ int dsg_gn_bwd(const float* src0, int32_t c0, const float* src1, int32_t c1, con
                const float* scale_shift, const float* mean_rstd, const float* gamma, int32_t silu, int32_t n,
                int32_t hw, int32_t groups, const float* add0, const float* add1, float* dx0, float* dx1,
                float* dgamma, float* dbeta, double* ws_s12, float* ws_coef, void* stream);
+/* The streaming passes of the backward walk on the mixed-precision tape: channel-blocked [N, C/8, hw, 8] tensors of
+ * `dtype` (DSG_BF16 / DSG_F16); fp32 arithmetic, fp64 sums, results rounded once.  ws_s12 of dsg_gn_bwd_blocked holds
+ * [N][C][2] + [N][C][dsg_gn_bwd_blocked_splits(hw)][2] doubles. */
+int dsg_gn_bwd_blocked(const void* src0, int32_t c0, const void* src1, int32_t c1, const void* dy,
+                       const float* scale_shift, const float* mean_rstd, const float* gamma, int32_t silu, int32_t n,
+                       int32_t hw, int32_t groups, const void* add0, const void* add1, void* dx0, void* dx1,
+                       float* dgamma, float* dbeta, double* ws_s12, float* ws_coef, int32_t dtype, void* stream);
+int dsg_gn_bwd_blocked_splits(int32_t hw);
+int dsg_channel_sums_blocked(const void* x, int32_t n, int32_t c, int32_t hw, float* out_nc, int32_t out_stride,
+                             int32_t dtype, void* stream);
+int dsg_add_dt(const void* a, const void* b, int64_t numel, void* out, int32_t dtype, void* stream);
+int dsg_upsample_nearest2x_blocked(const void* src, void* dst, int64_t planes /* N * C/8 */, int32_t h, int32_t w,
+                                   int32_t dtype, void* stream);
+int dsg_sumpool2x2_blocked(const void* src, const void* add, void* dst, int64_t planes, int32_t h /* of dst */,
+                           int32_t w, int32_t dtype, void* stream);
 /* out_nc[n*out_stride + c] = sum over hw of x[n][c][:] (bias / time-embedding gradients) */
 int dsg_channel_sums(const float* x, int32_t n, int32_t c, int32_t hw, float* out_nc, int32_t out_stride, void* stream);
 int dsg_add(const float* a, const float* b, int64_t numel, float* out, void* stream);

@@ -120,9 +120,11 @@ def test_conv_blocked16(case, mode):
     out = ops.from_blocked(got).cpu()
     assert torch.isfinite(out).all()
     assert rel_l2(out, ref) <= OUT_TOL[mode], rel_l2(out, ref)
-    # element-wise: one rounding of the result (+ accumulation-order noise)
-    ulp = 2.0 ** -8 if mode == "bf16" else 2.0 ** -10
-    assert float(((out.double() - ref).abs() / (ref.abs() + 1e-2)).max()) <= 1.5 * ulp
+    # element-wise: half an ulp of the stored result, plus noise that scales with the terms, not with the (possibly
+    # cancelling) sum: operands whose fp32 activation sits on a rounding boundary may round the other way
+    ulp = 2.0 ** -8 if mode == "bf16" else 2.0 ** -11
+    rms = float(ref.pow(2).mean().sqrt())
+    assert float(((out.double() - ref).abs() - 0.51 * ulp * ref.abs()).max()) <= 0.25 * ulp * rms
     if stats is not None:   # epilogue statistics describe the fp32 values before the rounding: within 2^-8 of the stored tensor's
         s_ref = ref.sum((2, 3))
         s_got = stats.cpu()[..., 0].sum(-1)
