@@ -746,6 +746,11 @@ int conv2d_fwd_impl(const dsg_conv_args* a, hipStream_t st, int force_direct) {
     const bool mt2 = (p.wstride % 64 == 0) && p.cout > 32;
     return mt2 ? launch_mfma<3, 2, 0, 2, 4, 3>(p, st) : launch_mfma<3, 2, 0, 1, 4, 3>(p, st);
   }
+  if (io16 == 3 && !force_direct && tile_ok && k == 3 && s == 1 && u == 1 && !p.pool && (p.c1 == 0 || p.c0 % 8 == 0)) {
+    // up-sampler convs of maps the folded split kernel does not tile (source narrower than 32 columns)
+    const bool mt2 = (p.wstride % 64 == 0) && p.cout > 32;
+    return mt2 ? launch_mfma<3, 1, 1, 2, 8, 3>(p, st) : launch_mfma<3, 1, 1, 1, 8, 3>(p, st);
+  }
   DSG_CHECK_SHAPE(io16 == 0,
                   "dsg_conv2d_fwd: no %s kernel serves this call with channel-blocked tensors (k %d, stride %d, "
                   "upsample %d, cin %d, cout %d, %dx%d); the 16-bit modes take the shapes of dsg_conv2d_fwd's "

@@ -44,7 +44,7 @@ bool conv_h2_eligible(const dsg_conv_args* a, int hout, int wout) {
   if (conv_h2_fold(a)) return true;
   if (a->weight_h2_cout_stride && (a->weight_h2_cout_stride % 64 || a->weight_h2_cout_stride < (a->cout + 63) / 64 * 64))
     return false;
-  if (cin > 1024) return false;  // the GroupNorm scale/shift table shares LDS with the K-chunk buffers
+  if (cin > 1024 && a->gn_scale_shift) return false;  // the GroupNorm scale/shift table shares LDS with the K-chunk buffers
   if (a->ksize == 1)  // pointwise: the map is re-tiled as (h*w/32) rows of 32 pixels, so only h*w matters
     return g_h2.enabled && a->weight_h2 != nullptr && a->stride == 1 && !a->upsample && !a->pool2 && !a->temb &&
            cin % 16 == 0 && (a->c1 == 0 || a->c0 % 16 == 0) && (hout * wout) % (8 * H2_TW) == 0 && a->cout % 8 == 0;

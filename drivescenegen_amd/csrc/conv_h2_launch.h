@@ -75,6 +75,9 @@ int conv_h2_launch_t(const dsg_conv_args* a, int hout, int wout, hipStream_t st)
   p.wh = fold ? a->weight_h2_fold : (s2 ? a->weight_h2_s2 : a->weight_h2);
   p.bias = a->bias; p.ss = a->gn_scale_shift; p.silu = a->silu; p.temb = a->temb; p.temb_stride = a->temb_stride;
   p.res = a->residual; p.dst = a->dst;
+  p.bound0 = (PREC == 0 && !a->gn_scale_shift) ? a->src_bound : nullptr;
+  p.bound1 = (p.bound0 && a->src1) ? a->src_bound1 : nullptr;
+  p.bound_out = (PREC == 0 && a->stats_out) ? a->dst_bound : nullptr;
   // 16-row tiles (NT = 4) when they still give every CU a workgroup; 8-row tiles otherwise
   const int th = nt4 ? 16 : 8;
   p.tiles_x = (wout + H2_TW - 1) / H2_TW; p.tiles_y = hout / th;

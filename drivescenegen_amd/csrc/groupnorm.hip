@@ -214,7 +214,48 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const float* __restrict__
   }
 }
 
+// one block per image: max over (channel, tile) of the sum of squares -> bits of its square root, atomically maxed
+__global__ __launch_bounds__(256) void range_bound_kernel(const double* __restrict__ stats, int per_image,
+                                                          unsigned* __restrict__ bound) {
+  const int n = blockIdx.x;
+  const double* p = stats + (size_t)n * per_image * 2;
+  float m = 0.f;
+  for (int i = threadIdx.x; i < per_image; i += 256) m = fmaxf(m, (float)p[2 * i + 1]);
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+  if ((threadIdx.x & 63) == 0) atomicMax(bound + n, __float_as_uint(sqrtf(m)));
+}
+
+// out[0] = max |x| (one block; weights only)
+__global__ __launch_bounds__(1024) void abs_max_kernel(const float* __restrict__ x, int64_t numel, float* __restrict__ out) {
+  __shared__ float red[16];
+  float m = 0.f;
+  for (int64_t i = threadIdx.x; i < numel; i += 1024) m = fmaxf(m, fabsf(x[i]));
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (int k = 1; k < 16; ++k) m = fmaxf(m, red[k]);
+    out[0] = m;
+  }
+}
+
 }  // namespace dsg
+
+DSG_API int dsg_range_bound_from_stats(const double* stats, int32_t n, int32_t c, int32_t tiles, uint32_t* bound, void* stream) {
+  DSG_CHECK_ARG(stats && bound && n > 0 && c > 0 && tiles > 0, "dsg_range_bound_from_stats: bad argument");
+  hipLaunchKernelGGL(dsg::range_bound_kernel, dim3(n), dim3(256), 0, static_cast<hipStream_t>(stream), stats, c * tiles, bound);
+  DSG_LAUNCH_CHECK();
+  return DSG_OK;
+}
+
+DSG_API int dsg_abs_max(const float* x, int64_t numel, float* out, void* stream) {
+  DSG_CHECK_ARG(x && out && numel > 0, "dsg_abs_max: bad argument");
+  hipLaunchKernelGGL(dsg::abs_max_kernel, dim3(1), dim3(1024), 0, static_cast<hipStream_t>(stream), x, numel, out);
+  DSG_LAUNCH_CHECK();
+  return DSG_OK;
+}
 
 DSG_API int dsg_gn_channel_stats(const float* src0, int32_t c0, const float* src1, int32_t c1, int32_t n, int32_t hw,
                                  double* chan_stats, void* stream) {

@@ -111,6 +111,17 @@ typedef struct {
                                    weight_h2* must then come from dsg_conv_weight_pack(..., the same dtype).  Served:
                                    the matrix-core shapes with at least one channel-blocked side, conv_in (fp32 image ->
                                    blocked) and conv_out (blocked -> fp32 image); anything else is DSG_ERR_UNSUPPORTED_SHAPE. */
+  /* Range guard of the fp32-equivalent split path (compute_dtype == DSG_F32), all optional:
+     src_bound / src_bound1  [N] per-image upper bounds of max|src0| / max|src1| as IEEE-754 bits of a non-negative
+                             float.  Used by calls WITHOUT gn_scale_shift (their source is not normalised): when the bound
+                             leaves [2^-6, 2^12] the patch is scaled by the power of two that brings it to ~1 before the
+                             fp16 split and the result scaled back -- exact, so large or tiny activations neither
+                             overflow the fp16 pieces nor lose precision.  NULL: no guard (|x| < 65504 is then required).
+     dst_bound               [N], zero-initialised by the caller: receives (atomic max) such a bound for dst wherever the
+                             call also writes stats_out. */
+  const uint32_t* src_bound;
+  const uint32_t* src_bound1;
+  uint32_t* dst_bound;
 } dsg_conv_args;
 
 int dsg_conv2d_fwd(const dsg_conv_args* a, void* stream);
@@ -171,6 +182,11 @@ int dsg_gn_channel_stats(const float* src0, int32_t c0, const float* src1, int32
  * partial sums over equal runs of pixels (splits divides hw): feed dsg_gn_finalize_parts with tiles = splits */
 int dsg_gn_channel_stats_blocked(const float* src, int32_t c, int32_t n, int32_t hw, int32_t splits,
                                  double* chan_stats /* [N][C][splits][2] */, void* stream);
+/* bound[n] = max(bound[n], bits(sqrt(max over (c, tile) of the sum of squares))) from statistics [N][C][tiles][2]: the
+ * dsg_conv_args.src_bound of a tensor whose statistics came from a pass of their own (bound zero-initialised) */
+int dsg_range_bound_from_stats(const double* stats, int32_t n, int32_t c, int32_t tiles, uint32_t* bound, void* stream);
+/* max |w| of a weight tensor (device scalar): the plan keeps a conv off the fp16x2 split when it leaves [2^-8, 3e4] */
+int dsg_abs_max(const float* x, int64_t numel, float* out, void* stream);
 /* the same for a channel-blocked tensor stored as `dtype` (dsg_dtype) */
 int dsg_gn_channel_stats_blocked_dt(const void* src, int32_t c, int32_t n, int32_t hw, int32_t splits,
                                     double* chan_stats, int32_t dtype, void* stream);
