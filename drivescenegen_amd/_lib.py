@@ -45,6 +45,7 @@ class ConvArgs(C.Structure):
         ("src_layout", C.c_int32), ("dst_layout", C.c_int32),
         ("weight_h2_s2", C.c_void_p),
         ("compute_dtype", C.c_int32),
+        ("src_bound", C.c_void_p), ("src_bound1", C.c_void_p),
     ]
 
 
@@ -92,6 +93,9 @@ SIGNATURES = {
     "dsg_layout_convert_dt": [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp],
     "dsg_gn_channel_stats_blocked_dt": [_vp, _i32, _i32, _i32, _i32, _vp, _i32, _vp],
     "dsg_unscale_check": [_vp, _i64, _f32, _vp, _vp],
+    "dsg_range_bound_from_stats": [_vp, _i32, _i32, _i32, _vp, _vp],
+    "dsg_gn_finalize_parts_bound": [_vp, _i32, _i32, _vp, _i32, _i32, _vp, _vp, _i32, _i32, _i32, _f32, _vp, _vp, _vp],
+    "dsg_abs_max": [_vp, _i64, _vp, _vp],
     "dsg_gn_bwd_blocked": [_vp, _i32, _vp, _i32, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp,
                            _vp, _vp, _i32, _vp],
     "dsg_gn_bwd_blocked_splits": [_i32],

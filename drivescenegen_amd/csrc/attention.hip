@@ -147,7 +147,10 @@ constexpr int ATM_KT = 512;                  // keys per LDS tile (35 KB of LDS:
 constexpr int ATM_VSTR = ATM_KT + 4;         // V row stride in halfs (+8 bytes: rows fall into different banks)
 
 constexpr int ATM_NW = 8;                    // waves per workgroup: 256 queries share one conversion of K and V
-__global__ __launch_bounds__(64 * ATM_NW, 4) void attention_mfma8_kernel(const float* __restrict__ qkv, float* __restrict__ out,
+#ifndef DSG_ATM_MINW
+#define DSG_ATM_MINW 4
+#endif
+__global__ __launch_bounds__(64 * ATM_NW, DSG_ATM_MINW) void attention_mfma8_kernel(const float* __restrict__ qkv, float* __restrict__ out,
                                                                  float* __restrict__ lse, int c, int heads, int l,
                                                                  float qscale) {
   __shared__ __attribute__((aligned(16))) _Float16 Kh[ATM_KT * 8], Kl[ATM_KT * 8];          // [key][d]
@@ -279,11 +282,13 @@ __global__ __launch_bounds__(64 * ATM_NW, 4) void attention_mfma8_kernel(const f
 static int g_att_mfma = 1;  // head_dim 8 on the matrix cores (tuning key 14: A/B against the VALU kernel)
 void attention_set_mfma(int v) { g_att_mfma = v; }
 
+// exact: keep off the fp16x2-split matrix-core kernel (q, k, v beyond fp16's range: the plan's range guard)
 template <int D>
-static int launch_attention(const float* qkv, float* out, float* lse, int n, int c, int heads, int l, hipStream_t st) {
+static int launch_attention(const float* qkv, float* out, float* lse, int n, int c, int heads, int l, hipStream_t st,
+                            bool exact) {
   // scores are kept in the log2 domain: q is pre-scaled by log2(e)/sqrt(D)
   const float qscale = 1.4426950408889634f / sqrtf((float)D);
-  if (D == 8 && g_att_mfma && l % 32 == 0) {
+  if (D == 8 && g_att_mfma && !exact && l % 32 == 0) {
     hipLaunchKernelGGL(attention_mfma8_kernel, dim3(cdiv(l, 32 * ATM_NW), heads, n), dim3(64 * ATM_NW), 0, st, qkv, out, lse, c, heads, l,
                        qscale);
     DSG_LAUNCH_CHECK();
@@ -315,7 +320,7 @@ static int launch_attention(const float* qkv, float* out, float* lse, int n, int
 }  // namespace dsg
 
 static int attention_fwd_impl(const float* qkv, float* out, float* lse, int32_t n, int32_t c, int32_t heads, int32_t l,
-                              void* stream) {
+                              void* stream, bool exact = false) {
   DSG_CHECK_ARG(qkv && out, "dsg_attention_fwd: NULL pointer");
   DSG_CHECK_ARG(n > 0 && c > 0 && heads > 0 && l > 0, "dsg_attention_fwd: bad dims");
   DSG_CHECK_ARG(c % heads == 0, "dsg_attention_fwd: channels (%d) not divisible by heads (%d)", c, heads);
@@ -323,14 +328,21 @@ static int attention_fwd_impl(const float* qkv, float* out, float* lse, int32_t 
   const int d = c / heads;
   hipStream_t st = static_cast<hipStream_t>(stream);
   switch (d) {
-    case 8: return dsg::launch_attention<8>(qkv, out, lse, n, c, heads, l, st);
-    case 16: return dsg::launch_attention<16>(qkv, out, lse, n, c, heads, l, st);
-    case 32: return dsg::launch_attention<32>(qkv, out, lse, n, c, heads, l, st);
-    case 64: return dsg::launch_attention<64>(qkv, out, lse, n, c, heads, l, st);
+    case 8: return dsg::launch_attention<8>(qkv, out, lse, n, c, heads, l, st, exact);
+    case 16: return dsg::launch_attention<16>(qkv, out, lse, n, c, heads, l, st, exact);
+    case 32: return dsg::launch_attention<32>(qkv, out, lse, n, c, heads, l, st, exact);
+    case 64: return dsg::launch_attention<64>(qkv, out, lse, n, c, heads, l, st, exact);
     default:
       return dsg::fail(DSG_ERR_UNSUPPORTED_SHAPE, "dsg_attention_fwd: head_dim %d not in {8,16,32,64}", d);
   }
 }
+
+namespace dsg {
+// the plan's range guard: q / k / v projections whose weights left the split's range run the fp32 VALU kernel
+int attention_fwd_exact(const float* qkv, float* out, int n, int c, int heads, int l, hipStream_t st) {
+  return attention_fwd_impl(qkv, out, nullptr, n, c, heads, l, st, true);
+}
+}  // namespace dsg
 
 DSG_API int dsg_attention_fwd(const float* qkv, float* out, int32_t n, int32_t c, int32_t heads, int32_t l,
                               void* stream) {

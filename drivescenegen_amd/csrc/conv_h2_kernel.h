@@ -55,11 +55,10 @@ struct ConvH2P {
   // like their bits).  bound0 / bound1 describe the two sources of a call WITHOUT a norm in front (shortcuts, up- /
   // down-sampler convs): when the bound leaves [2^-6, 2^12] the patch is multiplied by the power of two that brings it
   // to ~1 before the split and the accumulators by its inverse -- exact, so |x| = 1e5 neither overflows the fp16 pieces
-  // nor changes the result.  bound_out receives (atomic max) the bound of the tensor this call writes, from the
-  // statistics epilogue: sqrt of a tile's sum of squares >= every |value| in the tile.
+  // nor changes the result.  (The bounds come from the GroupNorm statistics: dsg_gn_finalize_parts_bound,
+  // dsg_range_bound_from_stats.)
   const unsigned* bound0;
   const unsigned* bound1;
-  unsigned* bound_out;
 };
 
 constexpr int H2_TW = 32, H2_KC = 16, H2_BM = 64;
@@ -215,9 +214,9 @@ __global__ __launch_bounds__(64 * NW, OCC * NW / 4) void conv_h2_kernel(ConvH2P 
   const bool has_ss = ACT == 3 ? p.ss != nullptr : ACT != 0;
   const bool do_silu = ACT == 3 ? (has_ss && p.silu) : ACT == 2;
   const float* ssg = has_ss ? p.ss + (size_t)n * p.cin * 2 : nullptr;
-  // range guard (see ConvH2P): xs = 2^-e pre-scale of an un-normalised patch, oscale = 2^e on the way out; both 1
+  // range guard (see ConvH2P): xs = 2^-e pre-scale of an un-normalised patch, rg_out = 2^e on the way out; both 1
   // (and the products bit-identical to the unguarded kernel) while the bound is inside the safe range
-  float xs = 1.f, oscale = 1.f;
+  float xs = 1.f, rg_out = 1.f;
   if constexpr (PREC == 0 && ACT != 2) {
     if (p.bound0 != nullptr && !has_ss) {
       unsigned b = p.bound0[n];
@@ -226,7 +225,7 @@ __global__ __launch_bounds__(64 * NW, OCC * NW / 4) void conv_h2_kernel(ConvH2P 
       const int e = min(100, max(-100, (int)(b >> 23) - 127));  // floor(log2(bound))
       if (b != 0u && (e > 12 || e < -6)) {
         xs = __uint_as_float((unsigned)(127 - e) << 23);
-        oscale = __uint_as_float((unsigned)(127 + e) << 23);
+        rg_out = __uint_as_float((unsigned)(127 + e) << 23);
       }
     }
   }
@@ -729,7 +728,7 @@ __global__ __launch_bounds__(64 * NW, OCC * NW / 4) void conv_h2_kernel(ConvH2P 
           for (int nt = 0; nt < NT; ++nt) {
             const int r = 4 * rg + j;
             if constexpr (NP == 2 && ACT != 2)
-              vv[j][nt] = ((acc_hi[mt][nt][r] + acc_lo[mt][nt][r] * (1.0f / 2048.0f)) * oscale + addv[r]) + rv[r][nt];
+              vv[j][nt] = ((acc_hi[mt][nt][r] + acc_lo[mt][nt][r] * (1.0f / 2048.0f)) * rg_out + addv[r]) + rv[r][nt];
             else if constexpr (NP == 2)
               vv[j][nt] = ((acc_hi[mt][nt][r] + acc_lo[mt][nt][r] * (1.0f / 2048.0f)) + addv[r]) + rv[r][nt];
             else
@@ -801,7 +800,6 @@ __global__ __launch_bounds__(64 * NW, OCC * NW / 4) void conv_h2_kernel(ConvH2P 
         constexpr int NE = NW * NT / 8;  // 8-row statistics tiles per workgroup tile
         const int ntile1 = p.tiles_x * p.tiles_y * NE;           // entries per phase
         const int ntile = ntile1 * (GM == 2 ? 4 : 1);
-        float sq_max = 0.f;
 #pragma unroll
         for (int e = 0; e < NE; ++e) {
           double t = 0.0;
@@ -811,11 +809,7 @@ __global__ __launch_bounds__(64 * NW, OCC * NW / 4) void conv_h2_kernel(ConvH2P 
 #ifndef DSG_H2_TIMING
           p.stats[(((size_t)n * p.cout + m0 + cl) * ntile + tile8) * 2 + which] = t;
 #endif
-          if (which == 1) sq_max = fmaxf(sq_max, (float)t);
         }
-        // range bound of the tensor just written: sqrt(sum of squares of a tile) >= every |value| in it
-        if (PREC == 0 && p.bound_out != nullptr && which == 1)
-          atomicMax(p.bound_out + n, __float_as_uint(sqrtf(sq_max)));
       }
     }
   }

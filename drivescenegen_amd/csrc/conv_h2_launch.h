@@ -77,7 +77,6 @@ int conv_h2_launch_t(const dsg_conv_args* a, int hout, int wout, hipStream_t st)
   p.res = a->residual; p.dst = a->dst;
   p.bound0 = (PREC == 0 && !a->gn_scale_shift) ? a->src_bound : nullptr;
   p.bound1 = (p.bound0 && a->src1) ? a->src_bound1 : nullptr;
-  p.bound_out = (PREC == 0 && a->stats_out) ? a->dst_bound : nullptr;
   // 16-row tiles (NT = 4) when they still give every CU a workgroup; 8-row tiles otherwise
   const int th = nt4 ? 16 : 8;
   p.tiles_x = (wout + H2_TW - 1) / H2_TW; p.tiles_y = hout / th;

@@ -142,7 +142,7 @@ __global__ __launch_bounds__(64) void gn_finalize_parts_kernel(const double* __r
                                                               const float* __restrict__ gamma,
                                                               const float* __restrict__ beta, int groups, int hw,
                                                               float eps, float* __restrict__ out,
-                                                              float* __restrict__ mr) {
+                                                              float* __restrict__ mr, unsigned* __restrict__ bound) {
   const int c = c0 + c1, cpg = c / groups;
   const int ni = blockIdx.x / groups, g = blockIdx.x - ni * groups;
   const int lane = threadIdx.x;
@@ -150,6 +150,7 @@ __global__ __launch_bounds__(64) void gn_finalize_parts_kernel(const double* __r
   // source: the 64 lanes stride over that run (the deep levels have 16-32 channels x 4 tiles per group -- a loop
   // over channels with 4 active lanes would be 32 dependent round trips).  Fixed order for a given shape.
   double s = 0.0, ss = 0.0;
+  float sq_max = 0.f;  // largest per-tile sum of squares: its square root bounds every |value| of the group
   const int ch0 = g * cpg, ch1 = ch0 + cpg;
   {
     const int a = min(ch0, c0), b = min(ch1, c0);  // the group's channels that live in source 0
@@ -158,6 +159,7 @@ __global__ __launch_bounds__(64) void gn_finalize_parts_kernel(const double* __r
       const double2 v = p[i];
       s += v.x;
       ss += v.y;
+      sq_max = fmaxf(sq_max, (float)v.y);
     }
   }
   if (c1 > 0) {
@@ -167,7 +169,13 @@ __global__ __launch_bounds__(64) void gn_finalize_parts_kernel(const double* __r
       const double2 v = p[i];
       s += v.x;
       ss += v.y;
+      sq_max = fmaxf(sq_max, (float)v.y);
     }
+  }
+  if (bound != nullptr) {  // range guard of the split convs that read these tensors un-normalised (dsg_conv_args.src_bound)
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) sq_max = fmaxf(sq_max, __shfl_xor(sq_max, m));
+    if (lane == 0) atomicMax(bound + ni, __float_as_uint(sqrtf(sq_max)));
   }
 #pragma unroll
   for (int m = 32; m >= 1; m >>= 1) {
@@ -314,7 +322,8 @@ DSG_API int dsg_gn_finalize_train(const double* chan_stats, const float* gamma, 
 
 static int gn_finalize_parts_impl(const double* stats0, int32_t c0, int32_t tiles0, const double* stats1, int32_t c1,
                                   int32_t tiles1, const float* gamma, const float* beta, int32_t n, int32_t groups,
-                                  int32_t hw, float eps, float* scale_shift, float* mean_rstd, void* stream) {
+                                  int32_t hw, float eps, float* scale_shift, float* mean_rstd, void* stream,
+                                  uint32_t* bound = nullptr) {
   DSG_CHECK_ARG(stats0 && gamma && beta && scale_shift, "dsg_gn_finalize_parts: NULL pointer");
   DSG_CHECK_ARG((c1 == 0) == (stats1 == nullptr), "dsg_gn_finalize_parts: stats1/c1 mismatch");
   DSG_CHECK_ARG(n > 0 && c0 > 0 && c1 >= 0 && groups > 0 && hw > 0 && tiles0 > 0 && (c1 == 0 || tiles1 > 0),
@@ -322,7 +331,7 @@ static int gn_finalize_parts_impl(const double* stats0, int32_t c0, int32_t tile
   DSG_CHECK_ARG((c0 + c1) % groups == 0, "dsg_gn_finalize_parts: channels (%d) not divisible by groups (%d)",
                 c0 + c1, groups);
   hipLaunchKernelGGL(dsg::gn_finalize_parts_kernel, dim3(n * groups), dim3(64), 0, static_cast<hipStream_t>(stream),
-                     stats0, c0, tiles0, stats1, c1, tiles1, gamma, beta, groups, hw, eps, scale_shift, mean_rstd);
+                     stats0, c0, tiles0, stats1, c1, tiles1, gamma, beta, groups, hw, eps, scale_shift, mean_rstd, bound);
   DSG_LAUNCH_CHECK();
   return DSG_OK;
 }
@@ -332,6 +341,13 @@ DSG_API int dsg_gn_finalize_parts(const double* stats0, int32_t c0, int32_t tile
                                   int32_t hw, float eps, float* scale_shift, void* stream) {
   return gn_finalize_parts_impl(stats0, c0, tiles0, stats1, c1, tiles1, gamma, beta, n, groups, hw, eps, scale_shift,
                                 nullptr, stream);
+}
+
+DSG_API int dsg_gn_finalize_parts_bound(const double* stats0, int32_t c0, int32_t tiles0, const double* stats1, int32_t c1,
+                                        int32_t tiles1, const float* gamma, const float* beta, int32_t n, int32_t groups,
+                                        int32_t hw, float eps, float* scale_shift, uint32_t* bound, void* stream) {
+  return gn_finalize_parts_impl(stats0, c0, tiles0, stats1, c1, tiles1, gamma, beta, n, groups, hw, eps, scale_shift,
+                                nullptr, stream, bound);
 }
 
 DSG_API int dsg_gn_finalize_parts_train(const double* stats0, int32_t c0, int32_t tiles0, const double* stats1,

@@ -25,6 +25,7 @@
 namespace dsg {
 int conv2d_fwd_impl(const dsg_conv_args* a, hipStream_t st, int force_direct);
 int conv_h2_tuning_epoch();
+int attention_fwd_exact(const float* qkv, float* out, int n, int c, int heads, int l, hipStream_t st);
 }
 
 namespace {
@@ -82,9 +83,17 @@ struct T {  // activation [N, c, h, w] (or any scratch when c/h/w are unused)
   std::shared_ptr<Buf> sb;
   double* stats = nullptr;
   int stiles = 0;
+  // range guard of the split path: [N] upper bounds of max|x| (float bits), written with the statistics
+  unsigned* bound = nullptr;
 };
 
-struct Conv { float* w = nullptr; float* b = nullptr; int cin = 0, cout = 0, k = 0, wstride = 0; void* wh = nullptr; void* whf = nullptr; void* whs = nullptr; };
+struct Conv {
+  float* w = nullptr; float* b = nullptr; int cin = 0, cout = 0, k = 0, wstride = 0;
+  void* wh = nullptr; void* whf = nullptr; void* whs = nullptr;
+  // range guard: bit i set = the i-th weight tensor packed into this conv has max|w| outside [2^-8, 3e4], where the
+  // fp16 pairs of the split stop carrying fp32's precision (or overflow): the conv then runs on the exact f32 MFMA
+  unsigned off_split = 0;
+};
 struct GN { float* g = nullptr; float* b = nullptr; int c = 0; };
 struct Res { GN n1; Conv c1; int toff = 0; GN n2; Conv c2; bool sc = false; Conv csc; int cin = 0, cout = 0; };
 struct Att { GN gn; Conv qkv; Conv out; int c = 0, heads = 0; };
@@ -101,6 +110,8 @@ struct Param {
   void* wh;   // fp16x2-split copy of a 3x3 weight (conv_h2.hip), or nullptr
   void* whf;  // up-sampler convs: the same weight folded into four 2x2 phase kernels, or nullptr
   void* whs;  // down-sampler convs: the same weight over the space-to-depth image (stride 2 on the split path), or nullptr
+  Conv* conv = nullptr;  // the conv this weight belongs to (range guard), and its bit in Conv::off_split
+  int conv_bit = 0;
 };
 
 }  // namespace
@@ -129,6 +140,11 @@ struct dsg_unet {
   std::map<std::tuple<int, int, int>, size_t> ws_cache;  // (batch, blocked layout, tuning epoch) -> workspace bytes
   std::string err;
   int dt() const { return cfg.compute_dtype; }  // dsg_dtype of the channel-blocked intermediates / matrix-core products
+  float* scratch_ = nullptr;
+  float* scratch4() {
+    if (!scratch_) scratch_ = dalloc(4);
+    return scratch_;
+  }
 
   ~dsg_unet() {
     for (void* p : allocs)
@@ -154,6 +170,7 @@ struct dsg_unet {
     if (c.w && c.wstride != cout) (void)hipMemset(c.w, 0, (size_t)cin * k * k * c.wstride * sizeof(float));
     c.b = dalloc(cout);
     add_param(pre + ".weight", P_CONV, c.w, (int64_t)cin * k * k * cout, cout, cin, k, c.wstride, 0);
+    params.back().conv = &c;
     // second copy, packed for the matrix-core kernel: pre-split fp16 pairs (the same bytes as the fp32 copy), or the
     // weights rounded to the 16-bit compute type (conv_out's 4 / 8 columns are zero-padded to a 64-column tile there)
     if (cin % 16 == 0 && (cout % 64 == 0 || (dt() != DSG_F32 && cout % 8 == 0))) {
@@ -210,6 +227,8 @@ struct dsg_unet {
     for (int i = 0; i < 3; ++i) {
       add_param(pre + "." + names[i] + ".weight", P_CONV, a.qkv.w, (int64_t)c * c, c, c, 1, 3 * c, i * c);
       params.back().wh = a.qkv.wh;
+      params.back().conv = &a.qkv;
+      params.back().conv_bit = i;
       add_param(pre + "." + names[i] + ".bias", P_COPY, a.qkv.b + i * c, c);
     }
     reg_conv(pre + ".to_out.0", a.out, c, c, 1);
@@ -234,6 +253,14 @@ struct Runner {
   Arena arena;
   int rc = DSG_OK;
   bool blocked = false;  // intermediates channel-blocked (every channel count a multiple of 8; tuning key 13)
+  // range-guard bounds: one zeroed region at the start of the workspace, a slot of B words per tensor
+  static constexpr int kBoundSlots = 512;
+  unsigned* bound_base = nullptr;
+  int bound_used = 0;
+  unsigned* bound_slot() {
+    if (dt() != DSG_F32 || bound_used >= kBoundSlots) return nullptr;
+    return bound_base + (size_t)(bound_used++) * B;
+  }
 
   int dt() const { return h->cfg.compute_dtype; }
   // bytes per element of an activation: channel-blocked intermediates are 16-bit in the mixed-precision modes
@@ -272,23 +299,35 @@ struct Runner {
                  : dsg_gn_channel_stats(t.p, t.c, nullptr, 0, B, hw, t.stats, st);
   }
 
+  // range bound of a tensor that a conv reads WITHOUT a norm in front (up- / down-sampler inputs), from its statistics
+  void ensure_bound(T& t) {
+    ensure_stats(t);
+    if (t.bound) return;
+    t.bound = bound_slot();
+    if (t.bound && !dry && ok()) rc = dsg_range_bound_from_stats(t.stats, B, t.c, t.stiles, t.bound, st);
+  }
+
   // scale/shift of GroupNorm(gn) over cat(x, skip) from the per-tile statistics both tensors carry
-  T gn_ss(T& x, T* skip, const GN& gn) {
+  // want_bound: also leave the range bound of cat(x, skip) in a fresh slot (the resnet's shortcut conv reads them raw)
+  T gn_ss(T& x, T* skip, const GN& gn, unsigned** want_bound = nullptr) {
     const int c = x.c + (skip ? skip->c : 0);
     ensure_stats(x);
     if (skip) ensure_stats(*skip);
     T ss = alloc(0, 0, 0, (size_t)B * c * 2);
+    unsigned* bnd = want_bound ? bound_slot() : nullptr;
+    if (want_bound) *want_bound = bnd;
     if (!dry && ok())
-      rc = dsg_gn_finalize_parts(x.stats, x.c, x.stiles, skip ? skip->stats : nullptr, skip ? skip->c : 0,
-                                 skip ? skip->stiles : 0, gn.g, gn.b, B, h->cfg.norm_num_groups, x.h * x.w,
-                                 h->cfg.norm_eps, ss.p, st);
+      rc = dsg_gn_finalize_parts_bound(x.stats, x.c, x.stiles, skip ? skip->stats : nullptr, skip ? skip->c : 0,
+                                       skip ? skip->stiles : 0, gn.g, gn.b, B, h->cfg.norm_num_groups, x.h * x.w,
+                                       h->cfg.norm_eps, ss.p, bnd, st);
     return ss;
   }
 
   // want_stats: the result feeds a GroupNorm -- have the conv write its per-tile statistics when it can
   // dst_blk: layout of the result (-1: the net's default for intermediates)
   T conv(const T& x, const T* skip, const Conv& cv, int stride, int ups, const T* ss, int silu, const float* temb,
-         const T* res, float* dst_override = nullptr, bool want_stats = false, int dst_blk = -1) {
+         const T* res, float* dst_override = nullptr, bool want_stats = false, int dst_blk = -1,
+         const unsigned* raw_bound = nullptr) {
     if (dst_blk < 0) dst_blk = blocked ? 1 : 0;
     if (ok() && ((skip && skip->blk != x.blk) || (res && res->blk != dst_blk)))
       rc = dsg::fail(DSG_ERR_INVALID_ARG, "dsg_unet_forward: mixed activation layouts in one conv (internal)");
@@ -306,7 +345,16 @@ struct Runner {
     a.src0 = x.p; a.c0 = x.c;
     a.src1 = skip ? skip->p : nullptr; a.c1 = skip ? skip->c : 0;
     a.n = B; a.hin = x.h; a.win = x.w; a.upsample = ups; a.ksize = cv.k; a.stride = stride; a.cout = cv.cout;
-    a.weight = cv.w; a.weight_cout_stride = cv.wstride; a.bias = cv.b; a.weight_h2 = cv.wh; a.weight_h2_fold = cv.whf; a.weight_h2_s2 = cv.whs;
+    a.weight = cv.w; a.weight_cout_stride = cv.wstride; a.bias = cv.b;
+    if (!cv.off_split || dt() != DSG_F32) {  // (weights out of the split's range: the exact f32 MFMA kernel serves the conv)
+      a.weight_h2 = cv.wh; a.weight_h2_fold = cv.whf; a.weight_h2_s2 = cv.whs;
+    }
+    if (!ss && raw_bound) {  // un-normalised source(s): hand the kernel their range bound (one for the concatenation)
+      a.src_bound = raw_bound;
+    } else if (!ss && x.bound && (!skip || skip->bound)) {
+      a.src_bound = x.bound;
+      a.src_bound1 = skip ? skip->bound : nullptr;
+    }
     a.gn_scale_shift = ss ? ss->p : nullptr; a.silu = silu;
     a.temb = temb; a.temb_stride = h->proj_total;
     a.residual = res ? res->p : nullptr;
@@ -331,13 +379,14 @@ struct Runner {
   }
 
   T resnet(T& x, T* skip, const Res& r, const float* tproj) {
-    T ss1 = gn_ss(x, skip, r.n1);
+    unsigned* raw = nullptr;
+    T ss1 = gn_ss(x, skip, r.n1, r.sc ? &raw : nullptr);
     T hmid = conv(x, skip, r.c1, 1, 0, &ss1, 1, tproj + r.toff, nullptr, nullptr, true);
     ss1 = T();
     T ss2 = gn_ss(hmid, nullptr, r.n2);
     T y;
     if (r.sc) {
-      T sc = conv(x, skip, r.csc, 1, 0, nullptr, 0, nullptr, nullptr);
+      T sc = conv(x, skip, r.csc, 1, 0, nullptr, 0, nullptr, nullptr, nullptr, false, -1, raw);
       y = conv(hmid, nullptr, r.c2, 1, 0, &ss2, 1, nullptr, &sc, nullptr, true);
     } else {
       y = conv(hmid, nullptr, r.c2, 1, 0, &ss2, 1, nullptr, &x, nullptr, true);
@@ -350,13 +399,23 @@ struct Runner {
     T qkv = conv(x, nullptr, at.qkv, 1, 0, &ss, 0, nullptr, nullptr, nullptr, false, 0);  // (the attention kernel reads [N,3C,L])
     ss = T();
     T o = alloc(x.c, x.h, x.w);  // ([N,C,L] fp32 in every mode, like q/k/v: softmax(QK^T)V runs in fp32-equivalent arithmetic)
-    if (!dry && ok()) rc = dsg_attention_fwd(qkv.p, o.p, B, x.c, at.heads, x.h * x.w, st);
+    if (!dry && ok())
+      rc = at.qkv.off_split ? dsg::attention_fwd_exact(qkv.p, o.p, B, x.c, at.heads, x.h * x.w, st)
+                            : dsg_attention_fwd(qkv.p, o.p, B, x.c, at.heads, x.h * x.w, st);
     qkv = T();
     return conv(o, nullptr, at.out, 1, 0, nullptr, 0, nullptr, &x, nullptr, true);
   }
 
   int run(const float* xin, const int64_t* t, float* out) {
     const dsg_unet_config& cfg = h->cfg;
+    {  // range-guard slots first (their place does not depend on anything else); zeroed once per forward
+      const size_t bytes = (size_t)kBoundSlots * B * sizeof(unsigned);
+      const size_t off = arena.alloc(bytes);
+      bound_base = reinterpret_cast<unsigned*>(ws + off);
+      bound_used = 0;
+      if (!dry && dt() == DSG_F32 && hipMemsetAsync(bound_base, 0, bytes, st) != hipSuccess)
+        return rc = dsg::fail(DSG_ERR_HIP, "dsg_unet_forward: hipMemsetAsync failed");
+    }
     blocked = dsg::unet_blocked() != 0 || dt() != DSG_F32;  // (the 16-bit modes exist for channel-blocked tensors only)
     for (int i = 0; i < cfg.num_blocks; ++i) blocked = blocked && cfg.block_out_channels[i] % 8 == 0;
     if (dt() != DSG_F32 && !blocked)
@@ -382,6 +441,7 @@ struct Runner {
         skips.push_back(x);
       }
       if (d.resample) {
+        ensure_bound(x);
         x = conv(x, nullptr, d.rconv, 2, 0, nullptr, 0, nullptr, nullptr, nullptr, true);
         ensure_stats(x);
         skips.push_back(x);
@@ -397,7 +457,10 @@ struct Runner {
         x = resnet(x, &s, u.res[j], tproj.p);
         if (!u.att.empty()) x = attention(x, u.att[j]);
       }
-      if (u.resample) x = conv(x, nullptr, u.rconv, 1, 1, nullptr, 0, nullptr, nullptr, nullptr, true);
+      if (u.resample) {
+        ensure_bound(x);
+        x = conv(x, nullptr, u.rconv, 1, 1, nullptr, 0, nullptr, nullptr, nullptr, true);
+      }
     }
     T ssf = gn_ss(x, nullptr, h->norm_out);
     conv(x, nullptr, h->conv_out, 1, 0, &ssf, 1, nullptr, nullptr, out, false, 0);
@@ -568,6 +631,19 @@ DSG_API int dsg_unet_set_param(dsg_unet_t* h, const char* name, const float* dat
     int rc = dsg_conv_weight_relayout(data, p.dst, p.cout, p.cin, p.k, p.cout_total, p.cout_off, stream);
     if (rc != DSG_OK) return rc;
     const int dt = h->dt();
+    if (p.conv && dt == DSG_F32 && (p.wh || p.whf || p.whs)) {
+      // range guard: max|w| decides whether the fp16 pairs of the split can carry this tensor (one D2H word per upload)
+      float* dmax = h->scratch4();
+      float wmax = 0.f;
+      DSG_CHECK_ARG(dmax != nullptr, "dsg_unet_set_param: hipMalloc failed");
+      rc = dsg_abs_max(data, numel, dmax, stream);
+      if (rc != DSG_OK) return rc;
+      DSG_HIP(hipMemcpyAsync(&wmax, dmax, sizeof(float), hipMemcpyDeviceToHost, st));
+      DSG_HIP(hipStreamSynchronize(st));
+      const bool bad = !(wmax <= 3.0e4f) || (wmax != 0.f && wmax < 0.00390625f);
+      if (bad) p.conv->off_split |= 1u << p.conv_bit;
+      else p.conv->off_split &= ~(1u << p.conv_bit);
+    }
     if (p.wh) {  // (a column window only where the packed matrix is wider than this weight: the fused q/k/v projection)
       const bool window = p.cout_off != 0 || p.cout_total > (p.cout + 63) / 64 * 64;
       rc = dsg_conv_weight_pack(data, p.wh, p.cout, p.cin, p.k, 0, dt, window ? p.cout_total : 0, p.cout_off, stream);

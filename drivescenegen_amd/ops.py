@@ -135,7 +135,8 @@ def relayout_conv_weight_dgrad(w_oihw: torch.Tensor, out: torch.Tensor = None) -
 def conv2d_fused(src0, weight_r, bias=None, src1=None, ksize=3, stride=1, upsample=False, gn_scale_shift=None,
                  silu=False, temb=None, temb_stride=0, residual=None, out=None, direct=False, cout=None,
                  pool2=False, wstride=None, weight_h2=None, want_stats=False, stats_buf=None, weight_h2_col=0, weight_h2_fold=None,
-                 src_blocked=False, dst_blocked=False, weight_h2_s2=None, compute_dtype=0, weight_h2_stride=0):
+                 src_blocked=False, dst_blocked=False, weight_h2_s2=None, compute_dtype=0, weight_h2_stride=0,
+                 src_bound=None, src_bound1=None):
     """dsg_conv2d_fwd: see include/dsg.h.  `weight_r` is in engine layout; `temb` is a [N, temb_stride] view
     whose first `cout` columns (from its data pointer) are added per (n, cout).
     want_stats: also return the per-tile GroupNorm statistics [N][cout][tiles][2] (fp64) of the result, or None
@@ -191,6 +192,8 @@ def conv2d_fused(src0, weight_r, bias=None, src1=None, ksize=3, stride=1, upsamp
             raise RuntimeError("temb must be a GPU tensor")
         a.temb, a.temb_stride = temb.data_ptr(), int(temb_stride or temb.stride(0))
     a.residual, a.dst = _lib.ptr(residual), _lib.ptr(out)
+    # range guard of the split path (include/dsg.h): int32 [N] tensors holding float bits
+    a.src_bound, a.src_bound1 = _lib.ptr(src_bound), _lib.ptr(src_bound1)
     stats = None
     if want_stats and not direct:
         tiles = C.c_int32(0)
@@ -234,6 +237,17 @@ def gn_channel_stats_blocked(x, splits=1):
         _lib.check(_lib.load().dsg_gn_channel_stats_blocked_dt(_lib.ptr(x), cb * 8, n, h * w, splits, _lib.ptr(st),
                                                                _DT_OF[x.dtype], _st(x)))
     return st
+
+
+def range_bound_from_stats(stats, bound=None):
+    """dsg_range_bound_from_stats: per-image upper bound of max|x| (float bits in an int32 [N] tensor) from statistics
+    [N][C][tiles][2] -- what dsg_conv_args.src_bound wants for a source without a norm in front."""
+    n, c, tiles = stats.shape[0], stats.shape[1], stats.shape[2]
+    if bound is None:
+        bound = torch.zeros(n, dtype=torch.int32, device=stats.device)
+    with torch.cuda.device(stats.device):
+        _lib.check(_lib.load().dsg_range_bound_from_stats(_lib.ptr(stats), n, c, tiles, _lib.ptr(bound), _st(stats)))
+    return bound
 
 
 def gn_scale_shift_from_parts_train(stats0, gamma, beta, groups, eps, hw, stats1=None):

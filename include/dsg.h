@@ -117,11 +117,10 @@ typedef struct {
                              leaves [2^-6, 2^12] the patch is scaled by the power of two that brings it to ~1 before the
                              fp16 split and the result scaled back -- exact, so large or tiny activations neither
                              overflow the fp16 pieces nor lose precision.  NULL: no guard (|x| < 65504 is then required).
-     dst_bound               [N], zero-initialised by the caller: receives (atomic max) such a bound for dst wherever the
-                             call also writes stats_out. */
+                             Bounds come from the statistics a GroupNorm needs anyway: dsg_gn_finalize_parts_bound,
+                             dsg_range_bound_from_stats. */
   const uint32_t* src_bound;
   const uint32_t* src_bound1;
-  uint32_t* dst_bound;
 } dsg_conv_args;
 
 int dsg_conv2d_fwd(const dsg_conv_args* a, void* stream);
@@ -198,6 +197,11 @@ int dsg_gn_finalize(const double* chan_stats, const float* gamma, const float* b
 int dsg_gn_finalize_parts(const double* stats0, int32_t c0, int32_t tiles0, const double* stats1, int32_t c1,
                           int32_t tiles1, const float* gamma, const float* beta, int32_t n, int32_t groups,
                           int32_t hw, float eps, float* scale_shift /* [N][c0+c1][2] */, void* stream);
+/* the same, also leaving in bound[n] (zero-initialised by the caller; atomic max) the range bound of cat(src0, src1) for
+ * dsg_conv_args.src_bound: the resnet's shortcut conv reads the tensors this norm normalises, un-normalised */
+int dsg_gn_finalize_parts_bound(const double* stats0, int32_t c0, int32_t tiles0, const double* stats1, int32_t c1,
+                                int32_t tiles1, const float* gamma, const float* beta, int32_t n, int32_t groups,
+                                int32_t hw, float eps, float* scale_shift, uint32_t* bound, void* stream);
 /* the same, also returning (mean, rstd) per (n, c) for the backward pass (training forward) */
 int dsg_gn_finalize_parts_train(const double* stats0, int32_t c0, int32_t tiles0, const double* stats1, int32_t c1,
                                 int32_t tiles1, const float* gamma, const float* beta, int32_t n, int32_t groups,

@@ -1,19 +1,23 @@
-"""Training-step throughput on one GPU (BASELINE configs[2] shape: 256x256x4 default U-Net, DDPM step):
-add_noise -> fwd -> mse -> bwd -> clip -> AdamW.  images/s and ms/step.  Usage: train_bench.py [batch] [steps]"""
+"""Training-step throughput on one GPU: add_noise -> fwd -> mse -> bwd -> clip -> AdamW; images/s and ms/step.
+Usage: train_bench.py [batch] [steps] [fp32|bf16|fp16]   (fp32: BASELINE configs[2] network, 256x256x4;
+bf16 / fp16: configs[4] network, 256x256x8, mixed-precision tape)"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 import drivescenegen_amd as d
 from drivescenegen_amd import synth
-from tests.common import CFG2, synth_weights
+from drivescenegen_amd.configs import CFG3, CFG5, synth_weights
 
 b = int(sys.argv[1]) if len(sys.argv) > 1 else 16
 steps = int(sys.argv[2]) if len(sys.argv) > 2 else 5
-net = synth_weights(d.UNet2DModel(**CFG2)).to("cuda").train()
+dtype = sys.argv[3] if len(sys.argv) > 3 else "fp32"
+cfg = CFG3 if dtype == "fp32" else CFG5
+c = cfg["in_channels"]
+net = synth_weights(d.UNet2DModel(**cfg)).to("cuda").train().set_compute_dtype(dtype)
 opt = d.AdamW(net.parameters(), lr=1e-5)
 sch = d.DDPMScheduler()
-x0 = torch.from_numpy(synth.synth_scene_rasters(b, 4, 256, 256, 1)).cuda()
-noise = torch.from_numpy(synth.normal(2, (b, 4, 256, 256))).cuda()
+x0 = torch.from_numpy(synth.synth_scene_rasters(b, c, 256, 256, 1)).cuda()
+noise = torch.from_numpy(synth.normal(2, (b, c, 256, 256))).cuda()
 t = torch.randint(0, 1000, (b,), device="cuda")
 
 
@@ -35,6 +39,6 @@ for _ in range(steps):
     loss = step()
 torch.cuda.synchronize()
 dt = (time.perf_counter() - t0) / steps
-print(f"batch {b}: {dt*1e3:.1f} ms/step, {b/dt:.1f} images/s, loss {float(loss.detach()):.4f}, "
+print(f"{dtype} batch {b}: {dt*1e3:.1f} ms/step, {b/dt:.1f} images/s, loss {float(loss.detach()):.4f}, "
       f"peak mem {torch.cuda.max_memory_allocated()/2**30:.1f} GiB, "
       f"~{3*352.98e9*b/dt/1e12:.1f} TF/s (3x fwd FLOPs)")
