@@ -68,16 +68,19 @@ class TrainState:
                 p.grad = g
 
     # engine-layout weights, refreshed when the parameter changed (every optimizer step)
-    def _fresh(self, name):
-        p = self.params[name]
+    def _fresh(self, key):
+        """key: a parameter name, or (name, variant) when several cached forms of one parameter are tracked apart"""
+        p = self.params[key[0] if isinstance(key, tuple) else key]
         sig = (p.data_ptr(), p._version)
-        if self.versions.get(name) == sig:
+        if self.versions.get(key) == sig:
             return False
-        self.versions[name] = sig
+        self.versions[key] = sig
         return True
 
-    def conv_w(self, name):
-        if self._fresh(name) or name not in self.wf:
+    def conv_w(self, name, split=True):
+        """(forward, data-gradient) fp32 engine layouts of a conv weight; split: also its fp16x2-split packs (the fp32
+        tape's matrix-core operands -- the mixed-precision tape keeps its own 16-bit packs and skips them)."""
+        if self._fresh((name, split)) or name not in self.wf:
             p = self.params[name].detach()
             self.wf[name] = ops.relayout_conv_weight(p, out=self.wf.get(name))
             cin = p.shape[1]
@@ -87,6 +90,8 @@ class TrainState:
                                             device=p.device)
             ops.relayout_conv_weight_dgrad(p, out=self.wd[name])
             cout = p.shape[0]
+            if not split:
+                return self.wf[name], self.wd[name]
             if cin % 16 == 0 and cout % 64 == 0:   # forward conv on the fp16x2-split matrix-core path
                 self.wh[name] = ops.relayout_conv_weight_h2(p, out=self.wh.get(name))
             if cout % 16 == 0 and cin % 64 == 0:   # its data gradient (K = cout, N = cin)
@@ -550,7 +555,7 @@ def _forward16(model, st: TrainState, tape: _Tape, sample, timesteps, dt):
 
     def conv(x0, wname, x1=None, gn=None, silu=False, k=3, stride=1, ups=False, toff=None, res=None, need_dx=True,
              feeds_norm=False, dst_blocked=True):
-        wf, _ = st.conv_w(wname + ".weight")
+        wf, _ = st.conv_w(wname + ".weight", split=False)
         bias = P[wname + ".bias"].detach()
         cout = bias.numel()
         src_blocked = x0.dim() == 5
@@ -670,7 +675,7 @@ def _backward16(model, st: TrainState, tape: _Tape, dout):
 
     def dgrad(dy, wname, k, cout, stride=1, residual=None, col0=0, ncols=None, dst_blocked=True):
         """dX = conv(dY, W^T flipped) for columns [col0, col0 + ncols) of the conv's input channels; + residual."""
-        _, wd = st.conv_w(wname)
+        _, wd = st.conv_w(wname, split=False)
         ncols = ncols or cout
         full = col0 == 0 and ncols == cout
         src_blocked = blocked(dy)

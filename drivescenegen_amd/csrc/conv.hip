@@ -462,6 +462,7 @@ void conv_h2_set_pw_occ2(int v);
 void conv_h2_set_s2(int v);
 void conv_h2_set_bm32(int v);
 void conv_h2_set_bm32_small(int v);
+void conv_h2_set_bm128(int v);
 void unet_set_blocked(int v);
 void attention_set_mfma(int v);
 void wgrad_h2_set_enabled(int on);
@@ -824,6 +825,10 @@ DSG_API int dsg_set_tuning(int32_t key, int32_t value) {
   }
   if (key == 17 && (value == 0 || value == 1)) {
     dsg::conv_h2_set_bm32_small(value);
+    return DSG_OK;
+  }
+  if (key == 18 && (value == 0 || value == 1)) {
+    dsg::conv_h2_set_bm128(value);
     return DSG_OK;
   }
   if (key == 16 && value >= 0) {

@@ -702,13 +702,20 @@ struct Wgrad16P {
 };
 
 typedef short wg_s4 __attribute__((ext_vector_type(4)));
-constexpr int W16_SLOTS = 6, W16_PW = 34;
-constexpr int W16_A_HALFS = 2 * W16_SLOTS * W16_PW * 32;  // [ci tile 2][slot][col 34][32 ch]
+constexpr int W16_SLOTS = 6;
 constexpr int W16_D_HALFS = 2 * 64 * 32;                  // [co tile 2][px 64][32 co], double-buffered
-constexpr int W16_LDS_BYTES = (W16_A_HALFS + 2 * W16_D_HALFS) * 2;
+template <int KS>
+struct W16Geom {
+  static constexpr int PW = 32 + 2 * (KS / 2);                  // patch columns (halo of KS / 2)
+  static constexpr int A_HALFS = 2 * W16_SLOTS * PW * 32;       // [ci tile 2][slot][col][32 ch]
+  static constexpr int LDS_BYTES = (A_HALFS + 2 * W16_D_HALFS) * 2;
+};
 
-template <int PREC>
+// KS = 3: 3x3, padding 1.  KS = 1: pointwise (shortcuts, attention projections): the map is re-tiled by the host as
+// h * w / 32 rows of 32 pixels (a channel-blocked tensor is linear in the pixel index), no halo, one tap.
+template <int PREC, int KS>
 __global__ __launch_bounds__(256, 2) void conv_wgrad16_kernel(Wgrad16P p) {
+  constexpr int W16_PW = W16Geom<KS>::PW, W16_A_HALFS = W16Geom<KS>::A_HALFS, PADK = KS / 2, TAPS = KS * KS;
   extern __shared__ __attribute__((aligned(16))) unsigned char wsm16[];
   unsigned short* Ab = reinterpret_cast<unsigned short*>(wsm16);
   unsigned short* Db = Ab + W16_A_HALFS;
@@ -761,10 +768,10 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad16_kernel(Wgrad16P p) {
   }
   uint4 xa[3], xd[2];
   bool va[3];
-  auto load_rows = [&](int k) {  // input rows 2k-1, 2k of the strip (columns ox0-1 .. ox0+32)
+  auto load_rows = [&](int k) {  // input rows 2k - PADK, 2k + 1 - PADK of the strip (columns ox0 - PADK ...)
 #pragma unroll
     for (int u = 0; u < 3; ++u) {
-      const int y = 2 * k - 1 + a_row[u], x = ox0 - 1 + a_col[u];
+      const int y = 2 * k - PADK + a_row[u], x = ox0 - PADK + a_col[u];
       va[u] = a_use[u] && (unsigned)y < (unsigned)p.h && (unsigned)x < (unsigned)p.w;
       const size_t off = (size_t)a_cb * 8 * plane + ((size_t)(va[u] ? y : 0) * p.w + (va[u] ? x : 0)) * 8;
       xa[u] = *reinterpret_cast<const uint4*>(xsrc + off);
@@ -811,9 +818,9 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad16_kernel(Wgrad16P p) {
     }
   };
 
-  wf32x16 acc[9];
+  wf32x16 acc[TAPS];
 #pragma unroll
-  for (int t = 0; t < 9; ++t)
+  for (int t = 0; t < TAPS; ++t)
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
 
@@ -855,9 +862,9 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad16_kernel(Wgrad16P p) {
       const wg_s4 b0 = tr4(dl + (orow * 32 + colb) * 32), b1 = tr4(dl + (orow * 32 + colb + 4) * 32);
       const half8 fb = __builtin_bit_cast(half8, wg_s8{b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w});
 #pragma unroll
-      for (int tp = 0; tp < 9; ++tp) {
-        const int dy = tp / 3, dx = tp % 3;
-        const int slot = (2 * s + orow + dy) % W16_SLOTS;  // input row 2s - 1 + orow + dy
+      for (int tp = 0; tp < TAPS; ++tp) {
+        const int dy = tp / KS, dx = tp % KS;
+        const int slot = (2 * s + orow + dy) % W16_SLOTS;  // input row 2s - PADK + orow + dy
         const unsigned short* ap = a_lane + (slot * W16_PW + colb + dx) * 32;
         const wg_s4 a0 = tr4(ap), a1 = tr4(ap + 4 * 32);
         const half8 fa = __builtin_bit_cast(half8, wg_s8{a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w});
@@ -869,9 +876,9 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad16_kernel(Wgrad16P p) {
 
   // epilogue: D[ci rows][co = l31]; partials to this run's slab [tap][ci][co]
   const int co = co0 + cot * 32 + l31;
-  float* wsb = p.ws + (size_t)blockIdx.y * 9 * p.cin * p.cout;
+  float* wsb = p.ws + (size_t)blockIdx.y * TAPS * p.cin * p.cout;
 #pragma unroll
-  for (int tp = 0; tp < 9; ++tp)
+  for (int tp = 0; tp < TAPS; ++tp)
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int ci = ci0 + cit * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
@@ -889,20 +896,31 @@ static void wgrad16_runs(int cin, int cout, int n, int hout, int wout, int* stri
 
 static bool wgrad16_ok(const dsg_conv_wgrad_args* a, int hout, int wout) {
   const int cin = a->c0 + a->c1, ctot = a->dy_ctotal ? a->dy_ctotal : a->cout;
-  return a->ksize == 3 && a->stride == 1 && !a->upsample && cin % 64 == 0 && (a->c1 == 0 || a->c0 % 64 == 0) &&
-         a->cout % 64 == 0 && ctot % 8 == 0 && a->dy_coff % 64 == 0 && wout % 32 == 0 && hout % 2 == 0;
+  const bool chans = a->stride == 1 && !a->upsample && cin % 64 == 0 && (a->c1 == 0 || a->c0 % 64 == 0) &&
+                     a->cout % 64 == 0 && ctot % 8 == 0 && a->dy_coff % 64 == 0;
+  if (a->ksize == 1) return chans && (hout * wout) % 64 == 0;  // (re-tiled as rows of 32 pixels)
+  return chans && a->ksize == 3 && wout % 32 == 0 && hout % 2 == 0;
 }
 
-static size_t wgrad16_ws_bytes(int cin, int cout, int n, int hout, int wout) {
+static size_t wgrad16_ws_bytes(int cin, int cout, int ksize, int n, int hout, int wout) {
+  if (ksize == 1) {
+    hout = hout * wout / 32;
+    wout = 32;
+  }
   int strips, rsplit;
   wgrad16_runs(cin, cout, n, hout, wout, &strips, &rsplit);
-  return (size_t)strips * rsplit * 9 * cin * cout * sizeof(float);
+  return (size_t)strips * rsplit * ksize * ksize * cin * cout * sizeof(float);
 }
 
 static int launch_wgrad16(const dsg_conv_wgrad_args* a, int hout, int wout, hipStream_t st) {
   Wgrad16P p;
+  const int taps = a->ksize * a->ksize;
+  if (a->ksize == 1) {  // pointwise: rows of 32 pixels
+    hout = hout * wout / 32;
+    wout = 32;
+  }
   p.src0 = a->src0; p.src1 = a->src1; p.c0 = a->c0; p.c1 = a->c1; p.cin = a->c0 + a->c1;
-  p.n = a->n; p.h = a->hin; p.w = a->win; p.cout = a->cout;
+  p.n = a->n; p.h = hout; p.w = wout; p.cout = a->cout;
   p.dy = a->dy; p.dy_ctotal = a->dy_ctotal ? a->dy_ctotal : a->cout; p.dy_coff = a->dy_coff;
   p.ss = a->gn_scale_shift; p.silu = a->silu; p.ws = static_cast<float*>(a->workspace);
   p.tiles_x = wout / 32; p.stages = hout / 2; p.ci_blocks = p.cin / 64;
@@ -910,21 +928,25 @@ static int launch_wgrad16(const dsg_conv_wgrad_args* a, int hout, int wout, hipS
   wgrad16_runs(p.cin, p.cout, p.n, hout, wout, &strips, &rsplit);
   p.nrs = rsplit;
   const int nslab = strips * rsplit;
-  const size_t need = (size_t)nslab * 9 * p.cin * p.cout * sizeof(float);
+  const size_t need = (size_t)nslab * taps * p.cin * p.cout * sizeof(float);
   if (p.ws == nullptr || a->workspace_bytes < need)
     return fail(DSG_ERR_WORKSPACE_TOO_SMALL, "dsg_conv2d_wgrad: workspace %zu bytes < required %zu", a->workspace_bytes, need);
   int pi = -1;
   if (prof_on())
-    pi = prof_begin(29, 2.0 * p.n * hout * wout * (double)p.cout * p.cin * 9,
+    pi = prof_begin(29, 2.0 * p.n * hout * wout * (double)p.cout * p.cin * taps,
                     2.0 * ((double)p.n * p.cin * p.h * p.w + (double)p.n * p.cout * hout * wout), st);
   const dim3 grid(p.ci_blocks * (p.cout / 64), nslab);
-  if (a->compute_dtype == DSG_BF16)
-    hipLaunchKernelGGL(conv_wgrad16_kernel<1>, grid, dim3(256), (size_t)W16_LDS_BYTES, st, p);
-  else
-    hipLaunchKernelGGL(conv_wgrad16_kernel<2>, grid, dim3(256), (size_t)W16_LDS_BYTES, st, p);
+  const bool bf = a->compute_dtype == DSG_BF16;
+  if (a->ksize == 3) {
+    if (bf) hipLaunchKernelGGL((conv_wgrad16_kernel<1, 3>), grid, dim3(256), (size_t)W16Geom<3>::LDS_BYTES, st, p);
+    else hipLaunchKernelGGL((conv_wgrad16_kernel<2, 3>), grid, dim3(256), (size_t)W16Geom<3>::LDS_BYTES, st, p);
+  } else {
+    if (bf) hipLaunchKernelGGL((conv_wgrad16_kernel<1, 1>), grid, dim3(256), (size_t)W16Geom<1>::LDS_BYTES, st, p);
+    else hipLaunchKernelGGL((conv_wgrad16_kernel<2, 1>), grid, dim3(256), (size_t)W16Geom<1>::LDS_BYTES, st, p);
+  }
   DSG_LAUNCH_CHECK();
-  const int64_t slab = (int64_t)9 * p.cin * p.cout;
-  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)cdiv64(slab / 4, 64)), dim3(256), 0, st, p.ws, nslab, 9, p.cin,
+  const int64_t slab = (int64_t)taps * p.cin * p.cout;
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)cdiv64(slab / 4, 64)), dim3(256), 0, st, p.ws, nslab, taps, p.cin,
                      p.cout, p.cin, p.cout, a->dw);
   prof_end(pi, st);
   DSG_LAUNCH_CHECK();
@@ -967,9 +989,10 @@ DSG_API int dsg_conv2d_wgrad(const dsg_conv_wgrad_args* a, void* stream) {
   DSG_CHECK_ARG(a->compute_dtype >= DSG_F32 && a->compute_dtype <= DSG_F16, "dsg_conv2d_wgrad: bad compute_dtype %d", a->compute_dtype);
   if (a->compute_dtype != DSG_F32) {  // mixed-precision tape: channel-blocked 16-bit x and dY
     DSG_CHECK_SHAPE(wgrad16_ok(a, a->hin, a->win) && !a->force_direct,
-                    "dsg_conv2d_wgrad: the 16-bit kernel takes 3x3 stride-1 convs with cin %% 64 == 0, cout %% 64 == 0, "
-                    "wout %% 32 == 0, hout %% 2 == 0 (got k %d, stride %d, cin %d + %d, cout %d, %dx%d); convert to fp32 "
-                    "[N,C,H,W] for the rest", a->ksize, a->stride, a->c0, a->c1, a->cout, a->hin, a->win);
+                    "dsg_conv2d_wgrad: the 16-bit kernel takes stride-1 3x3 / 1x1 convs with cin %% 64 == 0, cout %% 64 == 0 "
+                    "and (3x3) wout %% 32 == 0, hout %% 2 == 0 or (1x1) h * w %% 64 == 0 (got k %d, stride %d, cin %d + %d, "
+                    "cout %d, %dx%d); convert to fp32 [N,C,H,W] for the rest", a->ksize, a->stride, a->c0, a->c1, a->cout,
+                    a->hin, a->win);
     return launch_wgrad16(a, a->hin, a->win, st);
   }
   WgradP p;
@@ -1008,7 +1031,7 @@ DSG_API int dsg_conv2d_wgrad_workspace_bytes(const dsg_conv_wgrad_args* a, size_
   const int hout = (hc + 2 * pad - a->ksize) / a->stride + 1, wout = (wc + 2 * pad - a->ksize) / a->stride + 1;
   if (a->compute_dtype != DSG_F32) {
     DSG_CHECK_SHAPE(dsg::wgrad16_ok(a, hout, wout), "dsg_conv2d_wgrad_workspace_bytes: shape not served by the 16-bit kernel");
-    *bytes = dsg::wgrad16_ws_bytes(a->c0 + a->c1, a->cout, a->n, hout, wout);
+    *bytes = dsg::wgrad16_ws_bytes(a->c0 + a->c1, a->cout, a->ksize, a->n, hout, wout);
     return DSG_OK;
   }
   *bytes = a->force_direct ? 0 : dsg::wgrad_ws_bytes(a->c0 + a->c1, a->cout, a->ksize, a->stride, hout, wout, a->n);

@@ -100,6 +100,7 @@ void conv_h2_set_pw_occ2(int v) { g_h2.pw_occ2 = v; ++g_h2.epoch; }
 void conv_h2_set_s2(int v) { g_h2.s2 = v; ++g_h2.epoch; }
 void conv_h2_set_bm32_small(int v) { g_h2.bm32_small = v; ++g_h2.epoch; }
 void conv_h2_set_bm32(int v) { g_h2.bm32 = v != 0; if (v > 1) g_h2.bm32_min = v; ++g_h2.epoch; }
+void conv_h2_set_bm128(int v) { g_h2.bm128 = v; ++g_h2.epoch; }
 int conv_h2_tuning_epoch() { return g_h2.epoch; }
 
 // ---------------------------------------------------------------------------------------------------------------

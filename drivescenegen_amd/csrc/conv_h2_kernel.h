@@ -131,7 +131,10 @@ __device__ __forceinline__ float silu_fast_h(float x) { return x * __builtin_amd
 // LAY: bit 0: the sources are channel-blocked [N][C/8][H][W][8] (a halo position's k-group is 32 contiguous bytes:
 //      two 16-byte loads instead of eight dword gathers from eight channel planes); bit 1: dst / residual are
 //      (a lane's four consecutive output channels are one 16-byte store; a wave instruction writes 1 KB contiguous)
-// BM: output channels per workgroup.  32 (with NT = 2, OCC = 2) is the small-workgroup geometry for the shallow levels:
+// BM: output channels per workgroup.  128 (16-bit modes): four 32-channel MFMA tiles share one staged patch -- a third of
+//     the MFMAs per K-chunk but the same GroupNorm / SiLU / rounding work per patch makes the 64-cout geometry
+//     staging-bound there; with 128 couts the accumulators fill the register file as the split's two sets do.
+//     32 (with NT = 2, OCC = 2) is the small-workgroup geometry for the shallow levels:
 //     80 KB of LDS and half the register file, so two workgroups share a CU and one's patch loads and output stores
 //     run under the other's MFMAs (a workgroup that owns the CU runs those phases back to back).
 // PREC: 0 fp32 tensors, fp16x2-split products; 1 bf16 / 2 fp16: channel-blocked tensors are 16-bit in HBM, one MFMA per
@@ -390,11 +393,15 @@ __global__ __launch_bounds__(64 * NW, OCC * NW / 4) void conv_h2_kernel(ConvH2P 
   const char* wtile = static_cast<const char*>(p.wh) + ((size_t)phase * nq * G::NSEG * p.wh_stride + m0) * 16;
   // a DMA moves 1 KB = 64 / BM segments of BM couts x 16 B: LDS [segment][cout][8 halfs] is contiguous, in global
   // memory the segments are `segb` apart
+  // (BM = 32: a unit is two segments of 32 couts; BM = 128: a segment is two units of 64 couts)
+  constexpr int SPU = BM >= 64 ? 1 : 64 / BM, UPS = BM >= 64 ? BM / 64 : 1;
   int segoff[G::NDMA];
 #pragma unroll
-  for (int k = 0; k < G::NDMA; ++k)
-    segoff[k] = __builtin_amdgcn_readfirstlane(min(wave + NW * k, G::NUNIT - 1) * (64 / BM) * (int)segb);
-  const int lane16 = (lane % BM) * 16 + (lane / BM) * (int)segb;
+  for (int k = 0; k < G::NDMA; ++k) {
+    const int u = min(wave + NW * k, G::NUNIT - 1);
+    segoff[k] = __builtin_amdgcn_readfirstlane((u / UPS) * SPU * (int)segb + (u % UPS) * 1024);
+  }
+  const int lane16 = (lane % (BM < 64 ? BM : 64)) * 16 + (BM < 64 ? (lane / BM) * (int)segb : 0);
   auto dma_weights = [&](int k, const char* wq, unsigned char* buf) {  // wq: wtile + chunk * chunkb (uniform)
     // (uniform; a wave whose last share falls past the end repeats the final unit: same bytes, no branch)
     const int unit = min(wave + NW * k, G::NUNIT - 1);

@@ -3,6 +3,12 @@
 #pragma once
 #include "conv_h2_kernel.h"
 
+// 16-bit modes, 16-row tiles: workgroups the kernel is compiled to fit per CU (2: half the register file each -- one's
+// patch loads and output stores run under the other's MFMAs; A/B with tools/build_variant.sh)
+#ifndef DSG_H16_NT4_OCC
+#define DSG_H16_NT4_OCC 2   // measured on the configs[4] forward at batch 64: 31.9 -> 28.3 ms per step
+#endif
+
 namespace dsg {
 
 // kernel-selection switches (dsg_set_tuning); defined in conv_h2.hip
@@ -18,6 +24,7 @@ struct H2Tuning {
   int s2 = 1;           // stride-2 convs on the split path (key 15: A/B against the f32 MFMA kernel)
   int pw_occ2 = 1;      // pointwise convs: 8-row tiles compiled for two workgroups per CU (key 11)
   int rows = 0;         // rows per wave: 0 = by grid size, 2 | 4 forced (key 3)
+  int bm128 = 1;        // 16-bit modes: 128-cout workgroups where the grid still fills the chip (key 18)
   int epoch = 0;        // bumped by every change: plans key their cached workspace sizes on it
 };
 extern H2Tuning g_h2;
@@ -106,7 +113,7 @@ int conv_h2_launch_t(const dsg_conv_args* a, int hout, int wout, hipStream_t st)
   } while (0)
 #define DSG_H2_LAUNCH_BLK(GM, KS, ACT, LAY) /* channel-blocked: four-wave kernels only */ \
   do {                                                                              \
-    if (nt4) rc = h2_launch<GM, 4, KS, ACT, 4, 1, LAY, 64, PREC>(grid, lds, st, p);  \
+    if (nt4) rc = h2_launch<GM, 4, KS, ACT, 4, (PREC ? DSG_H16_NT4_OCC : 1), LAY, 64, PREC>(grid, lds, st, p);  \
     else rc = h2_launch<GM, 2, KS, ACT, 4, 1, LAY, 64, PREC>(grid, lds, st, p);      \
   } while (0)
 #define DSG_H2_LAUNCH_PW(ACT) /* pointwise, two workgroups per CU: any layout pair */ \
@@ -149,8 +156,35 @@ int conv_h2_launch_t(const dsg_conv_args* a, int hout, int wout, hipStream_t st)
     if (act == 0) rc = h2_launch<0, 2, 3, 0, 4, 2, 3, 32, PREC>(g32, lds32, st, q);
     else rc = h2_launch<0, 2, 3, 2, 4, 2, 3, 32, PREC>(g32, lds32, st, q);
   } else if (lay == 3) {
-    if (act == 0) DSG_H2_LAUNCH_BLK(0, 3, 0, 3);
-    else DSG_H2_LAUNCH_BLK(0, 3, 2, 3);
+    bool done128 = false;
+    if constexpr (PREC != 0) {
+      // 128-cout workgroups (four MFMA tiles per staged patch) while they still give every CU a workgroup
+      if (g_h2.bm128 && p.cout_pad % 128 == 0 && wout % H2_TW == 0) {
+        const int per_row = p.tiles_x * p.n * (p.cout_pad / 128);
+        const bool r16 = hout % 16 == 0 && per_row * (hout / 16) >= H2_CUS;
+        const int th128 = r16 ? 16 : 8;
+        const dim3 g128(per_row * (hout / th128));
+        if ((int)g128.x >= H2_CUS) {
+          ConvH2P q = p;
+          q.tiles_y = hout / th128;
+          const size_t ssb = a->gn_scale_shift ? (size_t)p.cin * 2 * sizeof(float) : 0;
+          done128 = true;
+          if (r16) {
+            const size_t l128 = 2 * (size_t)H2Geom<4, 3, 4, 9, 128, NP>::BUF_BYTES + ssb;
+            if (act == 0) rc = h2_launch<0, 4, 3, 0, 4, 1, 3, 128, PREC>(g128, l128, st, q);
+            else rc = h2_launch<0, 4, 3, 2, 4, 1, 3, 128, PREC>(g128, l128, st, q);
+          } else {
+            const size_t l128 = 2 * (size_t)H2Geom<2, 3, 4, 9, 128, NP>::BUF_BYTES + ssb;
+            if (act == 0) rc = h2_launch<0, 2, 3, 0, 4, 1, 3, 128, PREC>(g128, l128, st, q);
+            else rc = h2_launch<0, 2, 3, 2, 4, 1, 3, 128, PREC>(g128, l128, st, q);
+          }
+        }
+      }
+    }
+    if (!done128) {
+      if (act == 0) DSG_H2_LAUNCH_BLK(0, 3, 0, 3);
+      else DSG_H2_LAUNCH_BLK(0, 3, 2, 3);
+    }
   } else if (lay == 1) {  // 16-bit modes only (conv_out: blocked 16-bit sources -> fp32 [N,C,H,W])
     if constexpr (PREC != 0) DSG_H2_LAUNCH_BLK(0, 3, 2, 1);
   } else {

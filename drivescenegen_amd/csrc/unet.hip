@@ -403,7 +403,11 @@ struct Runner {
       rc = at.qkv.off_split ? dsg::attention_fwd_exact(qkv.p, o.p, B, x.c, at.heads, x.h * x.w, st)
                             : dsg_attention_fwd(qkv.p, o.p, B, x.c, at.heads, x.h * x.w, st);
     qkv = T();
-    return conv(o, nullptr, at.out, 1, 0, nullptr, 0, nullptr, &x, nullptr, true);
+    // (q / k / v weights beyond the split's range make the attention output's range suspect too: its projection then
+    //  takes the exact kernel as well -- o has no norm and no statistics to bound it)
+    Conv outc = at.out;
+    outc.off_split |= at.qkv.off_split;
+    return conv(o, nullptr, outc, 1, 0, nullptr, 0, nullptr, &x, nullptr, true);
   }
 
   int run(const float* xin, const int64_t* t, float* out) {

@@ -360,8 +360,11 @@ def postprocess(x, mode=0):
 def wgrad16_supported(c0, c1, cout, h, w, ksize=3, stride=1, upsample=False, dy_coff=0) -> bool:
     """Shapes dsg_conv2d_wgrad serves on channel-blocked 16-bit tensors (include/dsg.h); the rest goes through
     from_blocked() and the fp32 form."""
-    return (ksize == 3 and stride == 1 and not upsample and (c0 + c1) % 64 == 0 and (c1 == 0 or c0 % 64 == 0)
-            and cout % 64 == 0 and dy_coff % 64 == 0 and w % 32 == 0 and h % 2 == 0)
+    chans = (stride == 1 and not upsample and (c0 + c1) % 64 == 0 and (c1 == 0 or c0 % 64 == 0) and cout % 64 == 0
+             and dy_coff % 64 == 0)
+    if ksize == 1:
+        return chans and (h * w) % 64 == 0
+    return chans and ksize == 3 and w % 32 == 0 and h % 2 == 0
 
 
 def conv_wgrad(src0, dy, dw, src1=None, ksize=3, stride=1, upsample=False, gn_scale_shift=None, silu=False,

@@ -30,12 +30,14 @@ def _rnd(x, mode):
 
 
 @pytest.mark.parametrize("mode", ["bf16", "fp16"])
-@pytest.mark.parametrize("case", [("gn_silu", 64, 0, 64, 32, 64, 2, True), ("concat", 128, 64, 128, 16, 32, 3, True),
-                                  ("plain_wide", 64, 0, 192, 8, 96, 2, False)], ids=lambda c: c[0])
+@pytest.mark.parametrize("case", [("gn_silu", 64, 0, 64, 32, 64, 2, True, 3), ("concat", 128, 64, 128, 16, 32, 3, True, 3),
+                                  ("plain_wide", 64, 0, 192, 8, 96, 2, False, 3),
+                                  ("pointwise_shortcut", 128, 64, 64, 16, 32, 3, False, 1),
+                                  ("pointwise_odd_rows", 64, 0, 128, 6, 32, 2, True, 1)], ids=lambda c: c[0])
 def test_wgrad16(case, mode):
     """dsg_conv2d_wgrad on blocked 16-bit x / dY (transposing LDS reads) vs an fp64 evaluation of the same rounded
-    operands."""
-    _, c0, c1, cout, h, w, n, gn = case
+    operands; 3x3 and pointwise."""
+    _, c0, c1, cout, h, w, n, gn, k = case
     cin = c0 + c1
     x0, x1 = _rnd(_t(1, (n, c0, h, w)), mode), (_rnd(_t(2, (n, c1, h, w)), mode) if c1 else None)
     dy = _rnd(_t(3, (n, cout, h, w), 0.3), mode)
@@ -48,9 +50,9 @@ def test_wgrad16(case, mode):
                                            stats1=ops.gn_channel_stats_blocked(b1) if c1 else None)
         act = F.silu(xin.double() * ss.cpu()[:, :, 0, None, None].double() + ss.cpu()[:, :, 1, None, None].double())
     act = _rnd(act.float(), mode).double()
-    ref = torch.nn.grad.conv2d_weight(act, (cout, cin, 3, 3), dy.double(), padding=1)
-    dw = torch.full((cout, cin, 3, 3), 0.25, dtype=torch.float32, device=DEV)   # accumulated into
-    ops.conv_wgrad(b0, ops.to_blocked(dy.to(DEV), mode), dw, src1=b1, gn_scale_shift=ss, silu=gn)
+    ref = torch.nn.grad.conv2d_weight(act, (cout, cin, k, k), dy.double(), padding=k // 2)
+    dw = torch.full((cout, cin, k, k), 0.25, dtype=torch.float32, device=DEV)   # accumulated into
+    ops.conv_wgrad(b0, ops.to_blocked(dy.to(DEV), mode), dw, src1=b1, ksize=k, gn_scale_shift=ss, silu=gn)
     got = dw.cpu().double() - 0.25
     assert rel_l2(got, ref) <= (2e-4 if gn else 2e-5), rel_l2(got, ref)
 

@@ -95,6 +95,8 @@ def test_weights_outside_the_split_range_take_the_exact_kernel(factor):
     names = ["down_blocks.0.resnets.1.conv2.weight", "down_blocks.1.resnets.0.conv_shortcut.weight",
              "down_blocks.0.downsamplers.0.conv.weight", "up_blocks.0.upsamplers.0.conv.weight",
              "mid_block.attentions.0.to_k.weight"]
+    if factor > 1:   # (1e6 per layer compounds: four such layers in a row overflow torch-CPU's own fp32 GroupNorm variance, and
+        names = [names[0], names[1], "mid_block.attentions.0.to_v.weight"]   # 1e12 scores its softmax -- the oracle must stay finite)
     net, ora = _with_scaled(CFG1, {n: factor for n in names})
     x = noisy_inputs(CFG1, 2)
     t = torch.tensor([500, 3])

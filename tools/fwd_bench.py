@@ -21,6 +21,10 @@ ts = [int(t) for t in sch.timesteps]
 for i in range(5):
     x = sch.step(net(x, ts[i]).sample, ts[i], x).prev_sample
 torch.cuda.synchronize()
+dump = os.environ.get("PROF_DUMP")   # per-launch HIP-event records of the conv kernels (csv)
+if dump:
+    from drivescenegen_amd import _lib
+    _lib.load().dsg_prof_enable(1)
 t0 = time.perf_counter()
 for i in range(steps):
     t = ts[(5 + i) % 50]
@@ -28,3 +32,5 @@ for i in range(steps):
 torch.cuda.synchronize()
 dt = (time.perf_counter() - t0) / steps
 print(f"{name} {dtype} batch {b}: {dt*1e3:.2f} ms/step, {b/dt:.1f} image-steps/s")
+if dump:
+    _lib.check(_lib.load().dsg_prof_dump(dump.encode()))
