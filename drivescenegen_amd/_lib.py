@@ -46,6 +46,7 @@ class ConvArgs(C.Structure):
         ("weight_h2_s2", C.c_void_p),
         ("compute_dtype", C.c_int32),
         ("src_bound", C.c_void_p), ("src_bound1", C.c_void_p),
+        ("splitk_ws", C.c_void_p), ("splitk_ws_bytes", C.c_size_t),
     ]
 
 
@@ -88,6 +89,7 @@ TORCH_DTYPES = {DSG_F32: torch.float32, DSG_BF16: torch.bfloat16, DSG_F16: torch
 # Python-side statement of the ABI; tests/test_abi.py checks it against include/dsg.h.
 SIGNATURES = {
     "dsg_conv2d_stats_tiles": [_vp, _vp],
+    "dsg_conv2d_splitk_bytes": [_vp, C.POINTER(_sz)],
     "dsg_conv_weight_pack": [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp],
     "dsg_conv_weight_pack_bytes": [_i32, _i32, _i32, _i32, _i32, _i32, C.POINTER(_sz)],
     "dsg_layout_convert_dt": [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp],

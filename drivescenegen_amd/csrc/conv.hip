@@ -463,6 +463,8 @@ void conv_h2_set_s2(int v);
 void conv_h2_set_bm32(int v);
 void conv_h2_set_bm32_small(int v);
 void conv_h2_set_bm128(int v);
+void conv_h2_set_splitk(int v);
+int conv_h2_splitk_slices(const dsg_conv_args* a, int hout, int wout, int* stat_splits);
 void unet_set_blocked(int v);
 void attention_set_mfma(int v);
 void wgrad_h2_set_enabled(int on);
@@ -827,6 +829,10 @@ DSG_API int dsg_set_tuning(int32_t key, int32_t value) {
     dsg::conv_h2_set_bm32_small(value);
     return DSG_OK;
   }
+  if (key == 19 && (value == 0 || value == 1)) {
+    dsg::conv_h2_set_splitk(value);
+    return DSG_OK;
+  }
   if (key == 18 && (value == 0 || value == 1)) {
     dsg::conv_h2_set_bm128(value);
     return DSG_OK;
@@ -866,6 +872,17 @@ DSG_API int dsg_conv2d_stats_tiles(const dsg_conv_args* a, int32_t* tiles) {
   const int pad = a->ksize / 2;
   const int hout = (hc + 2 * pad - a->ksize) / a->stride + 1, wout = (wc + 2 * pad - a->ksize) / a->stride + 1;
   *tiles = dsg::conv_h2_stats_tiles(a, hout, wout);
+  return DSG_OK;
+}
+
+DSG_API int dsg_conv2d_splitk_bytes(const dsg_conv_args* a, size_t* bytes) {
+  DSG_CHECK_ARG(a != nullptr && bytes != nullptr, "dsg_conv2d_splitk_bytes: NULL pointer");
+  DSG_CHECK_ARG((a->ksize == 3 || a->ksize == 1) && (a->stride == 1 || a->stride == 2), "dsg_conv2d_splitk_bytes: bad ksize / stride");
+  const int hc = a->upsample ? 2 * a->hin : a->hin, wc = a->upsample ? 2 * a->win : a->win;
+  const int pad = a->ksize / 2;
+  const int hout = (hc + 2 * pad - a->ksize) / a->stride + 1, wout = (wc + 2 * pad - a->ksize) / a->stride + 1;
+  const int slices = dsg::conv_h2_splitk_slices(a, hout, wout, nullptr);
+  *bytes = slices > 1 ? (size_t)slices * a->n * a->cout * hout * wout * sizeof(float) : 0;
   return DSG_OK;
 }
 

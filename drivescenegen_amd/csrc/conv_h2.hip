@@ -79,8 +79,118 @@ bool conv_h2_rows16(const dsg_conv_args* a, int hout, int wout) {
   return rows16_pays((hout % 16 == 0) ? (wout / H2_TW) * (hout / 16) * a->n * (cout_pad / H2_BM) : 0);
 }
 
+// Split-K plan of a call (see dsg_conv_args.splitk_ws): fp32 path, every tensor channel-blocked, plain or stride-2 3x3
+// or pointwise; only when the tile grid the launcher would use covers at most half the CUs and K is long enough to cut.
+int conv_h2_splitk_slices(const dsg_conv_args* a, int hout, int wout, int* stat_splits) {
+  if (stat_splits) *stat_splits = 1;
+  if (!g_h2.splitk || a->compute_dtype != DSG_F32 || a->src_layout != 1 || a->dst_layout != 1 || a->upsample) return 1;
+  if (!conv_h2_eligible(a, hout, wout)) return 1;
+  const bool s2 = conv_h2_s2(a, hout, wout);
+  int th = hout, tw = wout;
+  if (a->ksize == 1) {
+    th = hout * wout / H2_TW;
+    tw = H2_TW;
+  }
+  if (tw % H2_TW != 0 || th % 8 != 0) return 1;  // (narrow maps keep the one-slice kernels)
+  const int cout_pad = (a->cout + 63) / 64 * 64;
+  int grid = (tw / H2_TW) * (th / 8) * a->n * (cout_pad / H2_BM);
+  if (a->ksize == 3 && !s2 && g_h2.bm32_small && grid <= H2_CUS / 2) grid *= 2;  // (the launcher's 32-cout workgroups)
+  const int nq = (s2 ? 4 * a->c0 : a->c0 + a->c1) / H2_KC;
+  if (grid > H2_CUS / 2 || nq < 8) return 1;
+  int slices = std::min(4, std::min(H2_CUS / grid, nq / 4));
+  while (slices > 1 && ((nq + slices - 1) / slices) * (slices - 1) >= nq) --slices;  // (no empty slice)
+  if (slices < 2) return 1;
+  if (stat_splits) {
+    const int hw = hout * wout;
+    int sp = 1;
+    while (sp < 16 && hw % (2 * sp) == 0 && hw / (2 * sp) >= 2048) sp *= 2;
+    *stat_splits = sp;
+  }
+  return slices;
+}
+
+// out = sum over the K slices (in slice order) + bias + temb + residual, channel-blocked fp32; grid = (C/8, n, stat
+// splits): a thread owns a pixel's 8 channels; per-(n, c, split) (sum, sum of squares) for the GroupNorm that follows
+__global__ __launch_bounds__(256) void splitk_reduce_blk_kernel(const float* __restrict__ part, int slices, size_t slab,
+                                                                const float* __restrict__ bias,
+                                                                const float* __restrict__ temb, int temb_stride,
+                                                                const float* __restrict__ res, float* __restrict__ dst,
+                                                                int c, int hw_total, double* __restrict__ stats) {
+  const int cb = blockIdx.x, n = blockIdx.y, sp = blockIdx.z, splits = gridDim.z;
+  const int hw = hw_total / splits;
+  const size_t base = ((size_t)n * c + cb * 8) * hw_total + (size_t)sp * hw * 8;
+  float add[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j)
+    add[j] = (bias ? bias[cb * 8 + j] : 0.f) + (temb ? temb[(size_t)n * temb_stride + cb * 8 + j] : 0.f);
+  double s[8], ss[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) s[j] = ss[j] = 0.0;
+  for (int i = threadIdx.x; i < hw; i += 256) {
+    const size_t at = base + (size_t)i * 8;
+    float v[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = 0.f;
+    for (int k = 0; k < slices; ++k) {
+      const float4 a0 = *reinterpret_cast<const float4*>(part + k * slab + at);
+      const float4 a1 = *reinterpret_cast<const float4*>(part + k * slab + at + 4);
+      v[0] += a0.x; v[1] += a0.y; v[2] += a0.z; v[3] += a0.w;
+      v[4] += a1.x; v[5] += a1.y; v[6] += a1.z; v[7] += a1.w;
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] += add[j];   // (the epilogue's order: accumulators + (bias + temb), then + residual)
+    if (res) {
+      const float4 r0 = *reinterpret_cast<const float4*>(res + at), r1 = *reinterpret_cast<const float4*>(res + at + 4);
+      v[0] += r0.x; v[1] += r0.y; v[2] += r0.z; v[3] += r0.w;
+      v[4] += r1.x; v[5] += r1.y; v[6] += r1.z; v[7] += r1.w;
+    }
+    *reinterpret_cast<float4*>(dst + at) = make_float4(v[0], v[1], v[2], v[3]);
+    *reinterpret_cast<float4*>(dst + at + 4) = make_float4(v[4], v[5], v[6], v[7]);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      s[j] += (double)v[j];
+      ss[j] += (double)v[j] * v[j];
+    }
+  }
+  if (stats == nullptr) return;
+  __shared__ double red[16][4];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    double x = s[j], y = ss[j];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      x += __shfl_down(x, o, 64);
+      y += __shfl_down(y, o, 64);
+    }
+    if (lane == 0) {
+      red[2 * j][wave] = x;
+      red[2 * j + 1][wave] = y;
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x < 16) {
+    const int j = threadIdx.x >> 1, which = threadIdx.x & 1;
+    stats[(((size_t)n * c + cb * 8 + j) * splits + sp) * 2 + which] =
+        (red[threadIdx.x][0] + red[threadIdx.x][1]) + (red[threadIdx.x][2] + red[threadIdx.x][3]);
+  }
+}
+
+int splitk_reduce_launch(const float* part, int slices, const dsg_conv_args* a, int hout, int wout, int stat_splits,
+                         hipStream_t st) {
+  const int hw = hout * wout;
+  const size_t slab = (size_t)a->n * a->cout * hw;
+  hipLaunchKernelGGL(splitk_reduce_blk_kernel, dim3(a->cout / 8, a->n, a->stats_out ? stat_splits : 1), dim3(256), 0, st, part,
+                     slices, slab, a->bias, a->temb, a->temb_stride, a->residual, a->dst, a->cout, hw, a->stats_out);
+  return DSG_OK;
+}
+
 int conv_h2_stats_tiles(const dsg_conv_args* a, int hout, int wout) {
   if (!g_h2.stats || !conv_h2_eligible(a, hout, wout)) return 0;
+  if (a->splitk_ws) {  // the split-K path's reduce pass writes its own (coarser) partials
+    int sp = 1;
+    if (conv_h2_splitk_slices(a, hout, wout, &sp) > 1) return sp;
+  }
   if (a->ksize == 1) return hout * wout / (8 * H2_TW);  // (pointwise: the map is re-tiled as rows of 32 pixels)
   return (hout / 8) * ((wout + H2_TW - 1) / H2_TW);  // 8-row x 32-column statistics tiles for either block height
 }
@@ -101,6 +211,7 @@ void conv_h2_set_s2(int v) { g_h2.s2 = v; ++g_h2.epoch; }
 void conv_h2_set_bm32_small(int v) { g_h2.bm32_small = v; ++g_h2.epoch; }
 void conv_h2_set_bm32(int v) { g_h2.bm32 = v != 0; if (v > 1) g_h2.bm32_min = v; ++g_h2.epoch; }
 void conv_h2_set_bm128(int v) { g_h2.bm128 = v; ++g_h2.epoch; }
+void conv_h2_set_splitk(int v) { g_h2.splitk = v; ++g_h2.epoch; }
 int conv_h2_tuning_epoch() { return g_h2.epoch; }
 
 // ---------------------------------------------------------------------------------------------------------------

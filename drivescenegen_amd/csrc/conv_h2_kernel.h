@@ -59,6 +59,10 @@ struct ConvH2P {
   // dsg_range_bound_from_stats.)
   const unsigned* bound0;
   const unsigned* bound1;
+  // Split-K (small batches: grids smaller than the chip): gridDim.y workgroups share a tile, each contracts a
+  // contiguous run of K-chunks and writes its fp32 partial sums to slab blockIdx.y of `dst` (split_stride bytes
+  // apart; bias / temb / residual / statistics are then the reduce pass's: splitk_reduce_blk_kernel)
+  size_t split_stride;
 };
 
 constexpr int H2_TW = 32, H2_KC = 16, H2_BM = 64;
@@ -186,7 +190,12 @@ __global__ __launch_bounds__(64 * NW, OCC * NW / 4) void conv_h2_kernel(ConvH2P 
   const int m0 = ct * BM;
   const int oy0 = ty * H2_TH, ox0 = tx * H2_TW;
   const int plane = p.hin * p.win;
-  const int nq = p.cin / H2_KC;
+  int nq = p.cin / H2_KC, qb = 0;  // this workgroup's K-chunks: [qb, qb + nq)
+  if (gridDim.y > 1) {
+    const int per = (nq + (int)gridDim.y - 1) / (int)gridDim.y;
+    qb = (int)blockIdx.y * per;
+    nq = min(per, nq - qb);
+  }
   const int g2 = wave / (NW / 2);  // k-group of the remainder unit (uniform per wave)
 
   // Per staging unit: global halo offset, and the LDS slots of its pieces.  Positions outside the image (zero
@@ -246,7 +255,7 @@ __global__ __launch_bounds__(64 * NW, OCC * NW / 4) void conv_h2_kernel(ConvH2P 
   const char* src0b = static_cast<const char*>(p.src0);
   const char* src1b = static_cast<const char*>(p.src1);
   auto src_of = [&](int q) -> const char* {  // uniform
-    const int cb = q * H2_KC;
+    const int cb = (q + qb) * H2_KC;
     return (cb < p.c0) ? src0b + ((size_t)n * p.c0 + cb) * plane * ESS
                        : src1b + ((size_t)n * p.c1 + (cb - p.c0)) * plane * ESS;
   };
@@ -259,7 +268,7 @@ __global__ __launch_bounds__(64 * NW, OCC * NW / 4) void conv_h2_kernel(ConvH2P 
   // descriptor of k-group g of chunk q: its 8 channel planes / its channel block (uniform)
   auto grp_rs = [&](const char* sp, int q, int g) -> __amdgpu_buffer_rsrc_t {
     if constexpr (GM == 3) {  // group (cb, py, px) of the space-to-depth image: block cb, first pixel (py, px)
-      const int gi = 2 * q + g, cb = gi >> 2, pp = gi & 3;
+      const int gi = 2 * (q + qb) + g, cb = gi >> 2, pp = gi & 3;
       const int first = ((pp >> 1) * p.win + (pp & 1)) * 8;
       return __builtin_amdgcn_make_buffer_rsrc(
           const_cast<char*>(src0b + (((size_t)n * p.c0 + cb * 8) * plane + first) * ESS), 0, (8 * plane - first) * ESS,
@@ -326,7 +335,7 @@ __global__ __launch_bounds__(64 * NW, OCC * NW / 4) void conv_h2_kernel(ConvH2P 
     unsigned w1[4], w2[4];
     float4 sr[4];
     if (has_ss) {
-      const float4* ssq = reinterpret_cast<const float4*>(ssl + 2 * (q * H2_KC + unit_g(i) * 8));
+      const float4* ssq = reinterpret_cast<const float4*>(ssl + 2 * ((q + qb) * H2_KC + unit_g(i) * 8));
 #pragma unroll
       for (int j = 0; j < 4; ++j) sr[j] = ssq[j];
     }
@@ -349,7 +358,7 @@ __global__ __launch_bounds__(64 * NW, OCC * NW / 4) void conv_h2_kernel(ConvH2P 
     const int i = P / 4, jp = P % 4;
     if (stage) {
       float4 s4 = make_float4(1.f, 1.f, 0.f, 0.f);
-      if (has_ss) s4 = *reinterpret_cast<const float4*>(ssl + 2 * (qs * H2_KC + unit_g(i) * 8 + 2 * jp));
+      if (has_ss) s4 = *reinterpret_cast<const float4*>(ssl + 2 * ((qs + qb) * H2_KC + unit_g(i) * 8 + 2 * jp));
       float a, b;
       pair_of(xr, i, jp, a, b);
       to_operand(a, b, s4, w1s[i][jp], w2s[i][jp]);
@@ -390,7 +399,8 @@ __global__ __launch_bounds__(64 * NW, OCC * NW / 4) void conv_h2_kernel(ConvH2P 
   // the only vector operand is the constant lane * 16.
   const unsigned segb = (unsigned)p.wh_stride * 16u;  // bytes of one (piece, tap, g) segment row in global memory
   const unsigned chunkb = G::NSEG * segb;             // bytes of one K-chunk's weights
-  const char* wtile = static_cast<const char*>(p.wh) + ((size_t)phase * nq * G::NSEG * p.wh_stride + m0) * 16;
+  const char* wtile = static_cast<const char*>(p.wh) +
+                      (((size_t)phase * (p.cin / H2_KC) + qb) * G::NSEG * p.wh_stride + m0) * 16;
   // a DMA moves 1 KB = 64 / BM segments of BM couts x 16 B: LDS [segment][cout][8 halfs] is contiguous, in global
   // memory the segments are `segb` apart
   // (BM = 32: a unit is two segments of 32 couts; BM = 128: a segment is two units of 64 couts)
@@ -644,7 +654,7 @@ __global__ __launch_bounds__(64 * NW, OCC * NW / 4) void conv_h2_kernel(ConvH2P 
   const int nvalid = min(BM, p.cout - m0);        // output channels of this tile that exist
   const size_t tile_off = ((size_t)n * p.cout + m0) * oplane * ESD;  // bytes
   const int range = nvalid * oplane * ESD;
-  char* dstb = static_cast<char*>(p.dst);
+  char* dstb = static_cast<char*>(p.dst) + (size_t)blockIdx.y * p.split_stride;
   const __amdgpu_buffer_rsrc_t dst_rs = __builtin_amdgcn_make_buffer_rsrc(dstb + tile_off, 0, range, 0x00020000);
   const __amdgpu_buffer_rsrc_t res_rs = __builtin_amdgcn_make_buffer_rsrc(
       has_r ? const_cast<char*>(static_cast<const char*>(p.res)) + tile_off : dstb, 0, has_r ? range : 0, 0x00020000);

@@ -25,6 +25,7 @@ struct H2Tuning {
   int pw_occ2 = 1;      // pointwise convs: 8-row tiles compiled for two workgroups per CU (key 11)
   int rows = 0;         // rows per wave: 0 = by grid size, 2 | 4 forced (key 3)
   int bm128 = 1;        // 16-bit modes: 128-cout workgroups where the grid still fills the chip (key 18)
+  int splitk = 1;       // split-K for grids of at most half the CUs, when the caller gives scratch (key 19)
   int epoch = 0;        // bumped by every change: plans key their cached workspace sizes on it
 };
 extern H2Tuning g_h2;
@@ -33,6 +34,10 @@ constexpr int H2_CUS = 256;
 bool conv_h2_fold(const dsg_conv_args* a);
 bool conv_h2_s2(const dsg_conv_args* a, int hout, int wout);
 bool conv_h2_rows16(const dsg_conv_args* a, int hout, int wout);
+// K slices (1 = no split) and statistics splits of the reduce pass for a call that may split (see dsg_conv_args.splitk_ws)
+int conv_h2_splitk_slices(const dsg_conv_args* a, int hout, int wout, int* stat_splits);
+int splitk_reduce_launch(const float* part, int slices, const dsg_conv_args* a, int hout, int wout, int stat_splits,
+                         hipStream_t st);
 
 template <int GM, int NT, int KS, int ACT, int NW = 4, int OCC = 1, int LAY = 0, int BM = 64, int PREC = 0>
 static int h2_launch(dim3 grid, size_t lds, hipStream_t st, const ConvH2P& p) {
@@ -53,6 +58,7 @@ static int h2_launch(dim3 grid, size_t lds, hipStream_t st, const ConvH2P& p) {
 template <int PREC>
 int conv_h2_launch_t(const dsg_conv_args* a, int hout, int wout, hipStream_t st) {
   constexpr int NP = PREC ? 1 : 2;
+  const int hout0 = hout, wout0 = wout;  // the conv's own output map (the kernel may re-tile it)
   // pointwise: 8-row tiles, two workgroups per CU (the only pointwise kernels that take channel-blocked tensors)
   const bool occ2 = a->ksize == 1 && (g_h2.pw_occ2 || a->src_layout || a->dst_layout);
   const bool nt4 = !occ2 && conv_h2_rows16(a, hout, wout);
@@ -105,6 +111,21 @@ int conv_h2_launch_t(const dsg_conv_args* a, int hout, int wout, hipStream_t st)
   }
   const int act = a->gn_scale_shift ? (a->silu ? 2 : 3) : 0;
   int rc = DSG_OK;
+  // split-K (PREC 0, every tensor channel-blocked, plain / stride-2 3x3 and pointwise): the slices write fp32 partials
+  // to the caller's scratch, the reduce pass does what the epilogue would have
+  int stat_splits = 1;
+  const int slices = (PREC == 0 && a->splitk_ws) ? conv_h2_splitk_slices(a, hout0, wout0, &stat_splits) : 1;
+  if (slices > 1) {
+    const size_t slab = (size_t)p.n * p.cout * p.hout * p.wout * sizeof(float);
+    if (a->splitk_ws_bytes < slab * slices)
+      return fail(DSG_ERR_WORKSPACE_TOO_SMALL, "dsg_conv2d_fwd: splitk_ws %zu bytes < required %zu", a->splitk_ws_bytes, slab * slices);
+    p.dst = a->splitk_ws;
+    p.split_stride = slab;
+    p.bias = nullptr; p.temb = nullptr; p.res = nullptr; p.stats = nullptr;
+    grid.y = slices;
+  } else {
+    p.split_stride = 0;
+  }
 #define DSG_H2_LAUNCH(GM, KS, ACT)                                                  \
   do {                                                                              \
     if (nt4 && g_h2.waves == 8) rc = h2_launch<GM, 2, KS, ACT, 8>(grid, lds, st, p); \
@@ -149,7 +170,7 @@ int conv_h2_launch_t(const dsg_conv_args* a, int hout, int wout, hipStream_t st)
     if constexpr (PREC == 0) DSG_H2_LAUNCH(1, 3, 0);
   } else if (bm32) {
     // shallow levels: 32 couts x 8 rows x 32 columns per workgroup, two workgroups per CU
-    const dim3 g32(((wout + H2_TW - 1) / H2_TW) * (hout / 8) * p.n * (p.cout_pad / 32));
+    const dim3 g32(((wout + H2_TW - 1) / H2_TW) * (hout / 8) * p.n * (p.cout_pad / 32), grid.y);
     const size_t lds32 = 2 * (size_t)H2Geom<2, 3, 4, 9, 32, NP>::BUF_BYTES + (a->gn_scale_shift ? (size_t)p.cin * 2 * sizeof(float) : 0);
     ConvH2P q = p;
     q.tiles_y = hout / 8;
@@ -197,6 +218,11 @@ int conv_h2_launch_t(const dsg_conv_args* a, int hout, int wout, hipStream_t st)
 #undef DSG_H2_LAUNCH_BLK
 #undef DSG_H2_LAUNCH_PW
   if (rc != DSG_OK) return rc;
+  if (slices > 1) {
+    DSG_LAUNCH_CHECK();
+    rc = splitk_reduce_launch(static_cast<const float*>(a->splitk_ws), slices, a, hout0, wout0, stat_splits, st);
+    if (rc != DSG_OK) return rc;
+  }
   prof_end(pi, st);
   DSG_LAUNCH_CHECK();
   return DSG_OK;

@@ -362,6 +362,16 @@ struct Runner {
     a.src_layout = x.blk; a.dst_layout = dst_blk;
     a.compute_dtype = dt();
     y.blk = dst_blk;
+    T splitk;  // scratch of the small-batch split-K path (lives until the call has been enqueued: stream order)
+    if (ok() && dt() == DSG_F32) {
+      size_t sk = 0;
+      rc = dsg_conv2d_splitk_bytes(&a, &sk);
+      if (ok() && sk > 0) {
+        splitk = alloc(0, 0, 0, sk / sizeof(float));
+        a.splitk_ws = splitk.p;
+        a.splitk_ws_bytes = sk;
+      }
+    }
     if (want_stats && ok()) {
       int32_t tiles = 0;
       rc = dsg_conv2d_stats_tiles(&a, &tiles);

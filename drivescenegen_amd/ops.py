@@ -136,7 +136,7 @@ def conv2d_fused(src0, weight_r, bias=None, src1=None, ksize=3, stride=1, upsamp
                  silu=False, temb=None, temb_stride=0, residual=None, out=None, direct=False, cout=None,
                  pool2=False, wstride=None, weight_h2=None, want_stats=False, stats_buf=None, weight_h2_col=0, weight_h2_fold=None,
                  src_blocked=False, dst_blocked=False, weight_h2_s2=None, compute_dtype=0, weight_h2_stride=0,
-                 src_bound=None, src_bound1=None):
+                 src_bound=None, src_bound1=None, splitk=False):
     """dsg_conv2d_fwd: see include/dsg.h.  `weight_r` is in engine layout; `temb` is a [N, temb_stride] view
     whose first `cout` columns (from its data pointer) are added per (n, cout).
     want_stats: also return the per-tile GroupNorm statistics [N][cout][tiles][2] (fp64) of the result, or None
@@ -194,6 +194,13 @@ def conv2d_fused(src0, weight_r, bias=None, src1=None, ksize=3, stride=1, upsamp
     a.residual, a.dst = _lib.ptr(residual), _lib.ptr(out)
     # range guard of the split path (include/dsg.h): int32 [N] tensors holding float bits
     a.src_bound, a.src_bound1 = _lib.ptr(src_bound), _lib.ptr(src_bound1)
+    scratch = None
+    if splitk:   # small-grid calls may contract K in parallel slices (dsg_conv_args.splitk_ws)
+        need = C.c_size_t()
+        _lib.check(lib.dsg_conv2d_splitk_bytes(C.byref(a), C.byref(need)))
+        if need.value:
+            scratch = torch.empty(need.value, dtype=torch.uint8, device=src0.device)
+            a.splitk_ws, a.splitk_ws_bytes = scratch.data_ptr(), need.value
     stats = None
     if want_stats and not direct:
         tiles = C.c_int32(0)

@@ -121,6 +121,14 @@ typedef struct {
                              dsg_range_bound_from_stats. */
   const uint32_t* src_bound;
   const uint32_t* src_bound1;
+  /* Split-K for grids smaller than the chip (the reference's own sampling calls run at batch 1 and 5): optional scratch
+     of dsg_conv2d_splitk_bytes(args) bytes.  With it, a call on channel-blocked fp32 tensors whose tile grid covers at
+     most half the CUs contracts its K-chunks in 2-4 parallel slices (fp32 partial sums in the scratch) and a reduce
+     pass adds them in slice order together with bias / temb / residual and writes stats_out.  The accumulation order
+     then differs from the one-slice kernel's (round-off class, <= 1e-6 relative); results still do not depend on
+     anything but the call's own shape.  NULL: never split. */
+  void* splitk_ws;
+  size_t splitk_ws_bytes;
 } dsg_conv_args;
 
 int dsg_conv2d_fwd(const dsg_conv_args* a, void* stream);
@@ -130,8 +138,11 @@ int dsg_layout_convert(const float* src, float* dst, int32_t n, int32_t c, int32
 int dsg_layout_convert_dt(const void* src, void* dst, int32_t n, int32_t c, int32_t hw, int32_t to_blocked,
                           int32_t blocked_dtype, void* stream);
 /* Number of spatial tiles per (n, cout) this call would write into stats_out; 0 when the kernel that serves the
- * call cannot produce the statistics (then run dsg_gn_channel_stats on dst instead). Host-only. */
+ * call cannot produce the statistics (then run dsg_gn_channel_stats on dst instead). Host-only.  (Set splitk_ws
+ * before asking: the split-K path has its own tile count.) */
 int dsg_conv2d_stats_tiles(const dsg_conv_args* a, int32_t* tiles);
+/* Scratch bytes the call would use for split-K (0: it would not split). Host-only; independent of splitk_ws. */
+int dsg_conv2d_splitk_bytes(const dsg_conv_args* a, size_t* bytes);
 
 /* OIHW (checkpoint layout) -> engine layout [Cin][k*k][cout_total], written at
  * column offset cout_off (used to fuse to_q/to_k/to_v into one projection). nn.Linear weights
@@ -447,6 +458,7 @@ int dsg_prof_dump(const char* csv_path);
  *  16  blocked 3x3 convs with cin <= 128 as 32-cout x 8-row workgroups, two per CU: [0] | 1 | n > 1 = when the
  *      64-cout x 16-row grid has at least n workgroups (1 = 512); bit-identical results, measured slower
  *  18  16-bit modes: 3x3 convs with cout % 128 == 0 as 128-cout workgroups while the grid fills the chip: [1] | 0
+ *  19  split-K for grids of at most half the CUs (needs dsg_conv_args.splitk_ws): [1] | 0
  *  15  stride-2 convs of channel-blocked tensors on the split path: [1] | 0 = the f32 MFMA kernel
  *  14  attention with head_dim 8 on the matrix cores (fp16x2 split): [1] | 0 = the VALU kernel */
 int dsg_set_tuning(int32_t key, int32_t value);

@@ -99,8 +99,11 @@ def test_cfg4_six_level_512_forward_vs_oracle_and_row_independence():
     with torch.no_grad():
         want = ora(x[:1], t[:1]).sample
     assert rel_l2(got[:1].cpu(), want) <= 1e-4 and max_abs(got[:1].cpu(), want) <= 2e-4 * max(1.0, float(want.abs().max()))
+    from tests.common import same_kernels_at_any_batch
     for i in (3, 7):
-        assert torch.equal(net(x[i:i + 1].to(DEV), t[i:i + 1].to(DEV)).sample, got[i:i + 1])
+        with same_kernels_at_any_batch():
+            assert torch.equal(net(x[i:i + 1].to(DEV), t[i:i + 1].to(DEV)).sample, got[i:i + 1])
+        assert rel_l2(net(x[i:i + 1].to(DEV), t[i:i + 1].to(DEV)).sample.cpu(), got[i:i + 1].cpu()) <= 2e-6
 
 
 def test_cfg5_bf16_training_step_256_vs_oracle_autograd():

@@ -113,8 +113,45 @@ def test_default_net_results_unchanged_by_the_guard_in_the_normal_range():
     x = noisy_inputs(DEFAULT3, 3)
     t = torch.tensor([900, 450, 10])
     got = net(x.to(DEV), t.to(DEV)).sample
-    assert torch.equal(net(x[2:3].to(DEV), t[2:3].to(DEV)).sample, got[2:3])
+    from tests.common import same_kernels_at_any_batch
+    with same_kernels_at_any_batch():
+        assert torch.equal(net(x[2:3].to(DEV), t[2:3].to(DEV)).sample, got[2:3])
     ora = synth_weights(OracleUNet2DModel(**DEFAULT3)).eval()
     with torch.no_grad():
         want = ora(x[:1], t[:1]).sample
     assert rel_l2(got[:1].cpu(), want) <= 1e-4
+
+
+@pytest.mark.parametrize("kind", ["deep3x3_gn", "pointwise", "stride2"])
+def test_small_grid_split_k_matches_the_one_slice_kernel(kind):
+    """Small batches (the reference samples at batch 1 and 5): a deep-level conv covers a fraction of the chip, so its K
+    is contracted in parallel slices plus a reduce pass (dsg_conv_args.splitk_ws).  Same values as the one-slice kernel
+    to fp32 round-off, identical statistics up to the summation order, fp64-reference accuracy unchanged."""
+    n, h, w = 1, 32, 32
+    c, cout, k, stride = {"deep3x3_gn": (512, 512, 3, 1), "pointwise": (1024, 512, 1, 1), "stride2": (256, 256, 3, 2)}[kind]
+    x = _t(1, (n, c, h, w))
+    wt = _t(2, (cout, c, k, k), 1.0 / np.sqrt(c * k * k))
+    bias, r = _t(3, (cout,), 0.1), _t(4, (n, cout, h // stride, w // stride))
+    tproj = _t(5, (n, cout), 0.3)
+    xb = ops.to_blocked(x.to(DEV))
+    ss, act = None, x.double()
+    if kind == "deep3x3_gn":
+        gamma, beta = (1 + _t(6, (c,), 0.1)), _t(7, (c,), 0.1)
+        ss = ops.gn_scale_shift_from_parts(ops.gn_channel_stats_blocked(xb), gamma.to(DEV), beta.to(DEV), 32, 1e-5, h * w)
+        act = F.silu(F.group_norm(x.double(), 32, gamma.double(), beta.double(), 1e-5))
+    ref = F.conv2d(act, wt.double(), bias.double(), stride=stride, padding=k // 2) + r.double()
+    if kind == "deep3x3_gn":
+        ref = ref + tproj.double()[:, :, None, None]
+    kw = dict(weight_h2_s2=ops.relayout_conv_weight_h2_s2(wt.to(DEV))) if stride == 2 else dict(
+        weight_h2=ops.relayout_conv_weight_h2(wt.to(DEV)))
+    call = lambda split: ops.conv2d_fused(xb, ops.relayout_conv_weight(wt.to(DEV)), bias.to(DEV), ksize=k, stride=stride,
+                                          gn_scale_shift=ss, silu=ss is not None, cout=cout,
+                                          temb=tproj.to(DEV) if kind == "deep3x3_gn" else None, temb_stride=cout,
+                                          residual=ops.to_blocked(r.to(DEV)), src_blocked=True, dst_blocked=True,
+                                          want_stats=True, splitk=split, **kw)
+    one, st_one = call(False)
+    many, st_many = call(True)
+    assert st_many is not None and st_many.shape[2] != st_one.shape[2]   # the split path really ran (its own tile count)
+    a, b = ops.from_blocked(one).cpu(), ops.from_blocked(many).cpu()
+    assert rel_l2(b, a) <= 1e-6 and rel_l2(b, ref) <= 2e-6 and rel_l2(a, ref) <= 2e-6
+    assert torch.allclose(st_many.cpu().sum(2), st_one.cpu().sum(2), rtol=1e-5, atol=1e-3)
