@@ -112,9 +112,9 @@ def test_default_net_results_unchanged_by_the_guard_in_the_normal_range():
     net = synth_weights(d.UNet2DModel(**DEFAULT3)).to(DEV).eval().requires_grad_(False)
     x = noisy_inputs(DEFAULT3, 3)
     t = torch.tensor([900, 450, 10])
-    got = net(x.to(DEV), t.to(DEV)).sample
     from tests.common import same_kernels_at_any_batch
-    with same_kernels_at_any_batch():
+    with same_kernels_at_any_batch():   # (batch 3 and batch 1 would cut K differently on the deep levels)
+        got = net(x.to(DEV), t.to(DEV)).sample
         assert torch.equal(net(x[2:3].to(DEV), t[2:3].to(DEV)).sample, got[2:3])
     ora = synth_weights(OracleUNet2DModel(**DEFAULT3)).eval()
     with torch.no_grad():
@@ -127,7 +127,7 @@ def test_small_grid_split_k_matches_the_one_slice_kernel(kind):
     """Small batches (the reference samples at batch 1 and 5): a deep-level conv covers a fraction of the chip, so its K
     is contracted in parallel slices plus a reduce pass (dsg_conv_args.splitk_ws).  Same values as the one-slice kernel
     to fp32 round-off, identical statistics up to the summation order, fp64-reference accuracy unchanged."""
-    n, h, w = 1, 32, 32
+    n, h, w = 1, 32, 64 if kind == "stride2" else 32   # (stride 2: the result must still be a tile wide)
     c, cout, k, stride = {"deep3x3_gn": (512, 512, 3, 1), "pointwise": (1024, 512, 1, 1), "stride2": (256, 256, 3, 2)}[kind]
     x = _t(1, (n, c, h, w))
     wt = _t(2, (cout, c, k, k), 1.0 / np.sqrt(c * k * k))
