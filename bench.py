@@ -208,8 +208,9 @@ def mixed_leg(args, dtype="bf16"):
             peak=PEAK_HBM_GBS if bound == "hbm" else PEAK_F16_TFLOPS, unit="GB/s" if bound == "hbm" else "TFLOP/s",
             frac=max(t_mfma, t_hbm) / (dom["avg_ms"] * 1e-3), mfma_tflops=dom["tflops"], mfma_frac=dom["tflops"] / PEAK_F16_TFLOPS,
             alg_gbs=dom["alg_gbs"], hbm_frac=dom["alg_gbs"] / PEAK_HBM_GBS, avg_launch_ms=dom["avg_ms"],
-            launches=dom["launches"], traffic=None,
-            note="mean over the 44 resnet convs of a step: frac = max(alg FLOPs / 2.5 PF, alg bytes / 8 TB/s) / measured time")
+            launches=dom["launches"], **pmc_class_traffic(r"conv_h2_kernel<0, [24], 3, [02], 4, [12], 3, (64|128), 1>", "_bf16"),
+            note="mean over the 44 resnet convs of a step (three instantiations: 128-cout / 64-cout workgroups, 16- / 8-row "
+                 "tiles): frac = max(alg FLOPs / 2.5 PF, alg bytes / 8 TB/s) / measured time")
     return rec
 
 
@@ -288,13 +289,13 @@ def small_batch_leg(args):
     return out
 
 
-def pmc_traffic(kernel):
+def pmc_traffic(kernel, suffix=""):
     """HBM bytes per launch of `kernel` from the committed PMC pass (tools/pmc_bench.sh -> profiles/*_pmc_traffic.json:
     rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes over this same bench command line, FETCH_SIZE doubled as
     the gfx950 guide prescribes).  bench.py cannot collect counters on itself; the newest committed file is quoted,
     with its name, next to the live HIP-event numbers.  None when no such file travels with the repo."""
     import glob
-    files = sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "*_pmc_traffic.json")))
+    files = sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", f"*_pmc_traffic{suffix}.json")))
     if not files:
         return dict(traffic=None)
     try:
@@ -308,12 +309,32 @@ def pmc_traffic(kernel):
         return dict(traffic=None)
 
 
-def pmc_mfma(kernel):
+def pmc_class_traffic(pattern, suffix):
+    """Launch-weighted mean HBM bytes per launch over every kernel of the newest profiles/*_pmc_traffic<suffix>.json
+    whose name matches `pattern` (a kernel class served by several instantiations)."""
+    import glob
+    import re
+    files = sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", f"*_pmc_traffic{suffix}.json")))
+    if not files:
+        return dict(traffic=None)
+    try:
+        ks = [v for name, v in json.load(open(files[-1]))["kernels"].items() if re.search(pattern, name)]
+        n = sum(k["launches"] for k in ks)
+        if not n:
+            return dict(traffic=None)
+        return dict(traffic=sum(k["hbm_bytes_per_launch"] * k["launches"] for k in ks) / n,
+                    traffic_unit="bytes/launch (HBM read + write, launch-weighted mean over the class's instantiations)",
+                    traffic_source="profiles/" + os.path.basename(files[-1]))
+    except (KeyError, ValueError, OSError):
+        return dict(traffic=None)
+
+
+def pmc_mfma(kernel, suffix=""):
     """Matrix-pipe utilisation of `kernel` from the committed SQ-counter pass (tools/pmc_mfma.sh ->
     profiles/*_pmc_mfma.json): MFMA instructions issued x 32 cycles / (GPU cycles x 1024 SIMDs), independent of the
     clock the chip throttles to.  Quoted next to the live figures like the HBM traffic; {} when no file travels."""
     import glob
-    files = sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "*_pmc_mfma.json")))
+    files = sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", f"*_pmc_mfma{suffix}.json")))
     if not files:
         return {}
     try:

@@ -10,17 +10,21 @@
 # with cycles = GRBM_GUI_ACTIVE / 8: the counter is reported summed over the 8 XCDs (checked: GUI_ACTIVE / 8 / kernel
 # duration = 1.99 GHz, the clock the chip runs at under this load; SQ_INSTS_MFMA equals 3 x algorithmic FLOPs / 32768
 # to the last digit, and SQ_VALU_MFMA_BUSY_CYCLES = 32 x SQ_INSTS_MFMA).
-# Usage (on the GPU box): bash tools/pmc_mfma.sh <tag>
+# Usage (on the GPU box): bash tools/pmc_mfma.sh <tag> [suffix]     (PMC_CMD / suffix as in pmc_bench.sh)
 cd "$GRAFT_REPO_ROOT" || exit 1
 export TMPDIR=/tmp
 tag=$1
+export PMC_SUFFIX=${2:-}
+cmd=${PMC_CMD:-"python bench.py --steps 3 --warmup 1 --no-cpu --no-prof --no-extras"}
+export PMC_CMD_TEXT="$cmd"
 mkdir -p gpurun_out
-rocprofv3 --pmc SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE --kernel-trace -d /tmp/pmcm_$tag -o p \
-  --output-format csv -- python bench.py --steps 3 --warmup 1 --no-cpu --no-prof > /dev/null 2> gpurun_out/${tag}_pmc_mfma.err
+rocprofv3 --pmc SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE --kernel-trace -d /tmp/pmcm_$tag$PMC_SUFFIX -o p \
+  --output-format csv -- $cmd > /dev/null 2> gpurun_out/${tag}_pmc_mfma$PMC_SUFFIX.err
 python - "$tag" <<'PY'
-import csv, glob, json, re, sys, collections
+import csv, glob, json, os, re, sys, collections
 tag = sys.argv[1]
-f = glob.glob(f"/tmp/pmcm_{tag}/**/*counter_collection.csv", recursive=True)[0]
+sfx = os.environ.get("PMC_SUFFIX", "")
+f = glob.glob(f"/tmp/pmcm_{tag}{sfx}/**/*counter_collection.csv", recursive=True)[0]
 acc = collections.defaultdict(lambda: collections.defaultdict(float))
 cnt = collections.Counter()
 seen = set()
@@ -42,8 +46,8 @@ for k, v in acc.items():
     res[k] = {"launches": n, "SQ_INSTS_MFMA": m, "SQ_VALU_MFMA_BUSY_CYCLES": b, "SQ_BUSY_CYCLES": v.get("SQ_BUSY_CYCLES", 0.0) / n,
               "cycles (GRBM_GUI_ACTIVE / 8 XCDs)": g, "mfma_util_issued": (m * 32.0 / (g * 1024.0)) if g else None,
               "mfma_util_counter": (b / (g * 1024.0)) if g else None}
-json.dump({"source": "rocprofv3 --pmc SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE over bench.py --steps 3 --warmup 1",
-           "kernels": res}, open(f"gpurun_out/{tag}_pmc_mfma.json", "w"), indent=1)
+json.dump({"source": "rocprofv3 --pmc SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE over: " + os.environ.get("PMC_CMD_TEXT", ""),
+           "kernels": res}, open(f"gpurun_out/{tag}_pmc_mfma{sfx}.json", "w"), indent=1)
 for k, v in sorted(res.items(), key=lambda kv: -kv[1]["cycles (GRBM_GUI_ACTIVE / 8 XCDs)"] * kv[1]["launches"])[:8]:
     print(f'{k[:58]:58s} n={v["launches"]:4d} insts {v["SQ_INSTS_MFMA"]:12.0f} busy {v["SQ_VALU_MFMA_BUSY_CYCLES"]:12.0f} cycles {v["cycles (GRBM_GUI_ACTIVE / 8 XCDs)"]:10.0f} '
           f'util issued {v["mfma_util_issued"] or 0:.3f} counter {v["mfma_util_counter"] or 0:.3f}')
