@@ -9,7 +9,7 @@
 //
 // Layout: qkv [N][3C][L] is the output of the fused q/k/v projection (a 1x1 conv over [N,C,L]);
 // channel = head*D + i, so a head's q/k/v are D rows of L contiguous floats.  out is [N][C][L].
-#include "dsg_common.h"
+#include "dsg_h16.h"
 
 namespace dsg {
 
@@ -143,6 +143,7 @@ __global__ __launch_bounds__(256) void attention_kernel(const float* __restrict_
 // ---------------------------------------------------------------------------------------------------
 typedef _Float16 att_half4 __attribute__((ext_vector_type(4)));
 typedef _Float16 att_half8 __attribute__((ext_vector_type(8)));
+typedef short att_short4 __attribute__((ext_vector_type(4)));
 constexpr int ATM_KT = 512;                  // keys per LDS tile (35 KB of LDS: four workgroups per CU)
 constexpr int ATM_VSTR = ATM_KT + 4;         // V row stride in halfs (+8 bytes: rows fall into different banks)
 
@@ -150,11 +151,33 @@ constexpr int ATM_NW = 8;                    // waves per workgroup: 256 queries
 #ifndef DSG_ATM_MINW
 #define DSG_ATM_MINW 4
 #endif
+
+// fp32 -> the 16-bit operand type of PREC, carried in a _Float16-typed container (bits only)
+template <int PREC>
+__device__ __forceinline__ _Float16 att_cvt(float v) {
+  if constexpr (PREC == 1) return __builtin_bit_cast(_Float16, (__bf16)v);
+  else return (_Float16)v;
+}
+// 8-deep S^T = K^T Q step on the matrix cores
+template <int PREC>
+__device__ __forceinline__ f32x16 att_mma8(att_half4 a, att_half4 b, f32x16 c) {
+  if constexpr (PREC == 1)
+    return __builtin_amdgcn_mfma_f32_32x32x8bf16_1k(__builtin_bit_cast(att_short4, a), __builtin_bit_cast(att_short4, b), c, 0, 0, 0);
+  else
+    return __builtin_amdgcn_mfma_f32_32x32x8f16(a, b, c, 0, 0, 0);
+}
+
+// PREC 0: fp32-class accuracy (fp16 pairs, three MFMAs per product).  PREC 1 / 2 (the mixed-precision modes,
+// BASELINE.json configs[4] "MFMA bf16 attn"): q, k, v and the probabilities are rounded once to bf16 / fp16, ONE MFMA per
+// product, fp32 scores / running maximum / accumulators; the row of ones in V still accumulates the denominator of
+// exactly the (rounded) probabilities that were multiplied, so each output row is a convex combination of V rows.
+template <int PREC>
 __global__ __launch_bounds__(64 * ATM_NW, DSG_ATM_MINW) void attention_mfma8_kernel(const float* __restrict__ qkv, float* __restrict__ out,
                                                                  float* __restrict__ lse, int c, int heads, int l,
                                                                  float qscale) {
-  __shared__ __attribute__((aligned(16))) _Float16 Kh[ATM_KT * 8], Kl[ATM_KT * 8];          // [key][d]
-  __shared__ __attribute__((aligned(16))) _Float16 Vh[9 * ATM_VSTR], Vl[9 * ATM_VSTR];      // [d | ones][key]
+  constexpr bool SPLIT = PREC == 0;
+  __shared__ __attribute__((aligned(16))) _Float16 Kh[ATM_KT * 8], Kl[SPLIT ? ATM_KT * 8 : 8];          // [key][d]
+  __shared__ __attribute__((aligned(16))) _Float16 Vh[9 * ATM_VSTR], Vl[SPLIT ? 9 * ATM_VSTR : 8];      // [d | ones][key]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, l31 = lane & 31;
   const int h = blockIdx.y, n = blockIdx.z;
   const float* qp = qkv + ((size_t)n * 3 * c + h * 8) * l;
@@ -169,15 +192,20 @@ __global__ __launch_bounds__(64 * ATM_NW, DSG_ATM_MINW) void attention_mfma8_ker
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     const float v = qp[(size_t)(4 * half + i) * l + qi] * qscale;
-    const _Float16 a = (_Float16)v;
-    qh[i] = a;
-    ql[i] = (_Float16)((v - (float)a) * 2048.0f);
+    if constexpr (SPLIT) {
+      const _Float16 a = (_Float16)v;
+      qh[i] = a;
+      ql[i] = (_Float16)((v - (float)a) * 2048.0f);
+    } else {
+      qh[i] = att_cvt<PREC>(v);
+    }
   }
   f32x16 o_hi, o_lo;
 #pragma unroll
   for (int r = 0; r < 16; ++r) o_hi[r] = o_lo[r] = 0.f;
   float m = -1e30f;
   const int vrow = min(l31, 8);  // A operand of O = V P: row = head dim (8 = the ones row, beyond: its copy, ignored)
+  const _Float16 one16 = SPLIT ? (_Float16)1.0f : att_cvt<PREC>(1.0f), zero16 = __builtin_bit_cast(_Float16, (unsigned short)0);
 
   for (int j0 = 0; j0 < l; j0 += ATM_KT) {
     const int kt = min(ATM_KT, l - j0);
@@ -189,27 +217,36 @@ __global__ __launch_bounds__(64 * ATM_NW, DSG_ATM_MINW) void attention_mfma8_ker
         kv = kp[(size_t)i * l + j0 + j];
         vv = vp[(size_t)i * l + j0 + j];
       }
-      const _Float16 ka = (_Float16)kv, va = (_Float16)vv;
-      Kh[j * 8 + i] = ka;
-      Kl[j * 8 + i] = (_Float16)((kv - (float)ka) * 2048.0f);
-      Vh[i * ATM_VSTR + j] = va;
-      Vl[i * ATM_VSTR + j] = (_Float16)((vv - (float)va) * 2048.0f);
+      if constexpr (SPLIT) {
+        const _Float16 ka = (_Float16)kv, va = (_Float16)vv;
+        Kh[j * 8 + i] = ka;
+        Kl[j * 8 + i] = (_Float16)((kv - (float)ka) * 2048.0f);
+        Vh[i * ATM_VSTR + j] = va;
+        Vl[i * ATM_VSTR + j] = (_Float16)((vv - (float)va) * 2048.0f);
+      } else {
+        Kh[j * 8 + i] = att_cvt<PREC>(kv);
+        Vh[i * ATM_VSTR + j] = att_cvt<PREC>(vv);
+      }
     }
     for (int j = tid; j < ATM_KT; j += 64 * ATM_NW) {
-      Vh[8 * ATM_VSTR + j] = (_Float16)(j < kt ? 1.0f : 0.0f);
-      Vl[8 * ATM_VSTR + j] = (_Float16)0.0f;
+      Vh[8 * ATM_VSTR + j] = j < kt ? one16 : zero16;
+      if constexpr (SPLIT) Vl[8 * ATM_VSTR + j] = (_Float16)0.0f;
     }
     __syncthreads();
     if (!active) continue;
-    // S^T tile = 32 keys x 32 queries; the NEXT tile's three MFMAs are issued before this tile's softmax arithmetic
+    // S^T tile = 32 keys x 32 queries; the NEXT tile's MFMAs are issued before this tile's softmax arithmetic
     // so that the matrix pipe works under it
     auto s_tile = [&](int t, f32x16& s_hi, f32x16& s_lo) {
       const att_half4 kh = *reinterpret_cast<const att_half4*>(&Kh[(t + l31) * 8 + 4 * half]);
-      const att_half4 kl = *reinterpret_cast<const att_half4*>(&Kl[(t + l31) * 8 + 4 * half]);
       const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-      s_hi = __builtin_amdgcn_mfma_f32_32x32x8f16(kh, qh, zero, 0, 0, 0);  // (C = the inline constant 0)
-      s_lo = __builtin_amdgcn_mfma_f32_32x32x8f16(kh, ql, zero, 0, 0, 0);
-      s_lo = __builtin_amdgcn_mfma_f32_32x32x8f16(kl, qh, s_lo, 0, 0, 0);
+      if constexpr (SPLIT) {
+        const att_half4 kl = *reinterpret_cast<const att_half4*>(&Kl[(t + l31) * 8 + 4 * half]);
+        s_hi = __builtin_amdgcn_mfma_f32_32x32x8f16(kh, qh, zero, 0, 0, 0);  // (C = the inline constant 0)
+        s_lo = __builtin_amdgcn_mfma_f32_32x32x8f16(kh, ql, zero, 0, 0, 0);
+        s_lo = __builtin_amdgcn_mfma_f32_32x32x8f16(kl, qh, s_lo, 0, 0, 0);
+      } else {
+        s_hi = att_mma8<PREC>(kh, qh, zero);
+      }
     };
     // one tile's softmax and O += V P from the scores in (s_hi, s_lo)
     auto pv_tile = [&](int t, const f32x16& s_hi, const f32x16& s_lo) {
@@ -217,7 +254,8 @@ __global__ __launch_bounds__(64 * ATM_NW, DSG_ATM_MINW) void attention_mfma8_ker
       float mx = -1e30f;
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        sv[r] = s_hi[r] + s_lo[r] * (1.0f / 2048.0f);
+        if constexpr (SPLIT) sv[r] = s_hi[r] + s_lo[r] * (1.0f / 2048.0f);
+        else sv[r] = s_hi[r];
         mx = fmaxf(mx, sv[r]);
       }
       mx = fmaxf(mx, __shfl_xor(mx, 32, 64));  // the query's other 16 keys live in lane ^ 32
@@ -227,7 +265,7 @@ __global__ __launch_bounds__(64 * ATM_NW, DSG_ATM_MINW) void attention_mfma8_ker
 #pragma unroll
       for (int r = 0; r < 5; ++r) {  // rows 0..3 (+4 half) = the head dims, row 8 (r = 4, half 0) = the denominator
         o_hi[r] *= sc;
-        o_lo[r] *= sc;
+        if constexpr (SPLIT) o_lo[r] *= sc;
       }
 #pragma unroll
       for (int b = 0; b < 2; ++b) {
@@ -237,19 +275,27 @@ __global__ __launch_bounds__(64 * ATM_NW, DSG_ATM_MINW) void attention_mfma8_ker
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
           const float pv = __builtin_amdgcn_exp2f(sv[8 * b + i] - mn);
-          const _Float16 a = (_Float16)pv;
-          ph[i] = a;
-          pl[i] = (_Float16)((pv - (float)a) * 2048.0f);
+          if constexpr (SPLIT) {
+            const _Float16 a = (_Float16)pv;
+            ph[i] = a;
+            pl[i] = (_Float16)((pv - (float)a) * 2048.0f);
+          } else {
+            ph[i] = att_cvt<PREC>(pv);
+          }
         }
         const _Float16* vhp = &Vh[vrow * ATM_VSTR + t + 16 * b + 4 * half];
-        const _Float16* vlp = &Vl[vrow * ATM_VSTR + t + 16 * b + 4 * half];
         const att_half4 vh0 = *reinterpret_cast<const att_half4*>(vhp), vh1 = *reinterpret_cast<const att_half4*>(vhp + 8);
-        const att_half4 vl0 = *reinterpret_cast<const att_half4*>(vlp), vl1 = *reinterpret_cast<const att_half4*>(vlp + 8);
         const att_half8 vh = {vh0[0], vh0[1], vh0[2], vh0[3], vh1[0], vh1[1], vh1[2], vh1[3]};
-        const att_half8 vl = {vl0[0], vl0[1], vl0[2], vl0[3], vl1[0], vl1[1], vl1[2], vl1[3]};
-        o_hi = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh, ph, o_hi, 0, 0, 0);
-        o_lo = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh, pl, o_lo, 0, 0, 0);
-        o_lo = __builtin_amdgcn_mfma_f32_32x32x16_f16(vl, ph, o_lo, 0, 0, 0);
+        if constexpr (SPLIT) {
+          const _Float16* vlp = &Vl[vrow * ATM_VSTR + t + 16 * b + 4 * half];
+          const att_half4 vl0 = *reinterpret_cast<const att_half4*>(vlp), vl1 = *reinterpret_cast<const att_half4*>(vlp + 8);
+          const att_half8 vl = {vl0[0], vl0[1], vl0[2], vl0[3], vl1[0], vl1[1], vl1[2], vl1[3]};
+          o_hi = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh, ph, o_hi, 0, 0, 0);
+          o_lo = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh, pl, o_lo, 0, 0, 0);
+          o_lo = __builtin_amdgcn_mfma_f32_32x32x16_f16(vl, ph, o_lo, 0, 0, 0);
+        } else {
+          o_hi = mma16<(PREC == 0 ? 2 : PREC)>(vh, ph, o_hi);
+        }
       }
     };
     // two score sets alternate (no register copies): while one tile's arithmetic runs, the other's MFMAs are in flight
@@ -266,7 +312,7 @@ __global__ __launch_bounds__(64 * ATM_NW, DSG_ATM_MINW) void attention_mfma8_ker
   }
   if (!active) return;
   // row 8 of the tile (register 4 of the lower half-wave) is the denominator; the upper half-wave fetches it
-  const float den_lo = o_hi[4] + o_lo[4] * (1.0f / 2048.0f);  // (meaningful in the lower half-wave only)
+  const float den_lo = SPLIT ? o_hi[4] + o_lo[4] * (1.0f / 2048.0f) : o_hi[4];  // (meaningful in the lower half-wave only)
   const float den_x = __shfl_xor(den_lo, 32, 64);
   const float den = half ? den_x : den_lo;
   const float inv = 1.0f / den;
@@ -274,7 +320,7 @@ __global__ __launch_bounds__(64 * ATM_NW, DSG_ATM_MINW) void attention_mfma8_ker
   if (q0 + l31 < l) {
 #pragma unroll
     for (int r = 0; r < 4; ++r)
-      op[(size_t)(r + 4 * half) * l + q0 + l31] = (o_hi[r] + o_lo[r] * (1.0f / 2048.0f)) * inv;
+      op[(size_t)(r + 4 * half) * l + q0 + l31] = (SPLIT ? o_hi[r] + o_lo[r] * (1.0f / 2048.0f) : o_hi[r]) * inv;
     if (lse && half == 0) lse[((size_t)n * heads + h) * l + q0 + l31] = m + log2f(den);
   }
 }
@@ -283,14 +329,17 @@ static int g_att_mfma = 1;  // head_dim 8 on the matrix cores (tuning key 14: A/
 void attention_set_mfma(int v) { g_att_mfma = v; }
 
 // exact: keep off the fp16x2-split matrix-core kernel (q, k, v beyond fp16's range: the plan's range guard)
+// dt: dsg_dtype of the products (DSG_F32 = the fp32-class split)
 template <int D>
 static int launch_attention(const float* qkv, float* out, float* lse, int n, int c, int heads, int l, hipStream_t st,
-                            bool exact) {
+                            bool exact, int dt = DSG_F32) {
   // scores are kept in the log2 domain: q is pre-scaled by log2(e)/sqrt(D)
   const float qscale = 1.4426950408889634f / sqrtf((float)D);
   if (D == 8 && g_att_mfma && !exact && l % 32 == 0) {
-    hipLaunchKernelGGL(attention_mfma8_kernel, dim3(cdiv(l, 32 * ATM_NW), heads, n), dim3(64 * ATM_NW), 0, st, qkv, out, lse, c, heads, l,
-                       qscale);
+    const dim3 grid(cdiv(l, 32 * ATM_NW), heads, n), block(64 * ATM_NW);
+    if (dt == DSG_BF16) hipLaunchKernelGGL(attention_mfma8_kernel<1>, grid, block, 0, st, qkv, out, lse, c, heads, l, qscale);
+    else if (dt == DSG_F16) hipLaunchKernelGGL(attention_mfma8_kernel<2>, grid, block, 0, st, qkv, out, lse, c, heads, l, qscale);
+    else hipLaunchKernelGGL(attention_mfma8_kernel<0>, grid, block, 0, st, qkv, out, lse, c, heads, l, qscale);
     DSG_LAUNCH_CHECK();
     return DSG_OK;
   }
@@ -320,7 +369,7 @@ static int launch_attention(const float* qkv, float* out, float* lse, int n, int
 }  // namespace dsg
 
 static int attention_fwd_impl(const float* qkv, float* out, float* lse, int32_t n, int32_t c, int32_t heads, int32_t l,
-                              void* stream, bool exact = false) {
+                              void* stream, bool exact = false, int dt = DSG_F32) {
   DSG_CHECK_ARG(qkv && out, "dsg_attention_fwd: NULL pointer");
   DSG_CHECK_ARG(n > 0 && c > 0 && heads > 0 && l > 0, "dsg_attention_fwd: bad dims");
   DSG_CHECK_ARG(c % heads == 0, "dsg_attention_fwd: channels (%d) not divisible by heads (%d)", c, heads);
@@ -328,7 +377,7 @@ static int attention_fwd_impl(const float* qkv, float* out, float* lse, int32_t 
   const int d = c / heads;
   hipStream_t st = static_cast<hipStream_t>(stream);
   switch (d) {
-    case 8: return dsg::launch_attention<8>(qkv, out, lse, n, c, heads, l, st, exact);
+    case 8: return dsg::launch_attention<8>(qkv, out, lse, n, c, heads, l, st, exact, dt);
     case 16: return dsg::launch_attention<16>(qkv, out, lse, n, c, heads, l, st, exact);
     case 32: return dsg::launch_attention<32>(qkv, out, lse, n, c, heads, l, st, exact);
     case 64: return dsg::launch_attention<64>(qkv, out, lse, n, c, heads, l, st, exact);
@@ -347,6 +396,12 @@ int attention_fwd_exact(const float* qkv, float* out, int n, int c, int heads, i
 DSG_API int dsg_attention_fwd(const float* qkv, float* out, int32_t n, int32_t c, int32_t heads, int32_t l,
                               void* stream) {
   return attention_fwd_impl(qkv, out, nullptr, n, c, heads, l, stream);
+}
+
+DSG_API int dsg_attention_fwd_dt(const float* qkv, float* out, int32_t n, int32_t c, int32_t heads, int32_t l,
+                                 int32_t dtype, void* stream) {
+  DSG_CHECK_ARG(dtype >= DSG_F32 && dtype <= DSG_F16, "dsg_attention_fwd_dt: bad dtype %d", dtype);
+  return attention_fwd_impl(qkv, out, nullptr, n, c, heads, l, stream, false, dtype);
 }
 
 DSG_API int dsg_attention_fwd_train(const float* qkv, float* out, float* lse, int32_t n, int32_t c, int32_t heads,

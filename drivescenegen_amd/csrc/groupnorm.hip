@@ -9,6 +9,7 @@
 // Statistics are kept per CHANNEL (sum, sum of squares, fp64) so that a group straddling the
 // [x || skip] concat of the up path (6 of the 12 up-resnet norm1's) needs no concat tensor.
 #include "dsg_h16.h"
+#include <algorithm>
 
 namespace dsg {
 
@@ -234,19 +235,13 @@ __global__ __launch_bounds__(256) void range_bound_kernel(const double* __restri
   if ((threadIdx.x & 63) == 0) atomicMax(bound + n, __float_as_uint(sqrtf(m)));
 }
 
-// out[0] = max |x| (one block; weights only)
-__global__ __launch_bounds__(1024) void abs_max_kernel(const float* __restrict__ x, int64_t numel, float* __restrict__ out) {
-  __shared__ float red[16];
+// out[0] = max(out[0], max |x|) (out zeroed by the caller; non-negative floats order like their bits)
+__global__ __launch_bounds__(256) void abs_max_kernel(const float* __restrict__ x, int64_t numel, float* __restrict__ out) {
   float m = 0.f;
-  for (int64_t i = threadIdx.x; i < numel; i += 1024) m = fmaxf(m, fabsf(x[i]));
+  for (int64_t i = blockIdx.x * (int64_t)256 + threadIdx.x; i < numel; i += (int64_t)gridDim.x * 256) m = fmaxf(m, fabsf(x[i]));
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
-  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    for (int k = 1; k < 16; ++k) m = fmaxf(m, red[k]);
-    out[0] = m;
-  }
+  if ((threadIdx.x & 63) == 0) atomicMax(reinterpret_cast<unsigned*>(out), __float_as_uint(m));
 }
 
 }  // namespace dsg
@@ -260,7 +255,9 @@ DSG_API int dsg_range_bound_from_stats(const double* stats, int32_t n, int32_t c
 
 DSG_API int dsg_abs_max(const float* x, int64_t numel, float* out, void* stream) {
   DSG_CHECK_ARG(x && out && numel > 0, "dsg_abs_max: bad argument");
-  hipLaunchKernelGGL(dsg::abs_max_kernel, dim3(1), dim3(1024), 0, static_cast<hipStream_t>(stream), x, numel, out);
+  DSG_HIP(hipMemsetAsync(out, 0, sizeof(float), static_cast<hipStream_t>(stream)));
+  const int blocks = (int)std::min<int64_t>(dsg::cdiv64(numel, 256 * 16), 512);
+  hipLaunchKernelGGL(dsg::abs_max_kernel, dim3(std::max(blocks, 1)), dim3(256), 0, static_cast<hipStream_t>(stream), x, numel, out);
   DSG_LAUNCH_CHECK();
   return DSG_OK;
 }

@@ -411,7 +411,7 @@ struct Runner {
     T o = alloc(x.c, x.h, x.w);  // ([N,C,L] fp32 in every mode, like q/k/v: softmax(QK^T)V runs in fp32-equivalent arithmetic)
     if (!dry && ok())
       rc = at.qkv.off_split ? dsg::attention_fwd_exact(qkv.p, o.p, B, x.c, at.heads, x.h * x.w, st)
-                            : dsg_attention_fwd(qkv.p, o.p, B, x.c, at.heads, x.h * x.w, st);
+                            : dsg_attention_fwd_dt(qkv.p, o.p, B, x.c, at.heads, x.h * x.w, dt(), st);
     qkv = T();
     // (q / k / v weights beyond the split's range make the attention output's range suspect too: its projection then
     //  takes the exact kernel as well -- o has no norm and no statistics to bound it)

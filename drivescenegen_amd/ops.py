@@ -310,13 +310,13 @@ def gn_apply(src, scale_shift, silu=False):
     return out
 
 
-def attention(qkv, heads):
-    """qkv [N, 3C, L] -> [N, C, L]."""
+def attention(qkv, heads, dtype=0):
+    """qkv [N, 3C, L] -> [N, C, L]; dtype: dsg_dtype of the matrix-core products (fp32 tensors in every mode)."""
     n, c3, l = qkv.shape
     c = c3 // 3
     out = torch.empty((n, c, l), dtype=torch.float32, device=qkv.device)
     with torch.cuda.device(qkv.device):
-        _lib.check(_lib.load().dsg_attention_fwd(_lib.ptr(qkv), _lib.ptr(out), n, c, heads, l, _st(qkv)))
+        _lib.check(_lib.load().dsg_attention_fwd_dt(_lib.ptr(qkv), _lib.ptr(out), n, c, heads, l, dtype_code(dtype), _st(qkv)))
     return out
 
 

@@ -227,6 +227,11 @@ int dsg_gn_apply(const float* src, const float* scale_shift, int32_t silu, float
  * ---------------------------------------------------------------------------------------- */
 int dsg_attention_fwd(const float* qkv, float* out, int32_t n, int32_t c, int32_t heads, int32_t l,
                       void* stream);
+/* the same with the products in `dtype` (dsg_dtype): DSG_BF16 / DSG_F16 round q, k, v and the probabilities once and
+ * issue ONE matrix-core product each (head_dim 8, L % 32 == 0; other shapes run the fp32 kernel); q/k/v/out stay fp32
+ * [N, C, L], the scores, running maximum, denominators and accumulators fp32 (BASELINE configs[4]: "MFMA bf16 attn") */
+int dsg_attention_fwd_dt(const float* qkv, float* out, int32_t n, int32_t c, int32_t heads, int32_t l,
+                         int32_t dtype, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Timestep path (UNet2DModel.time_proj + time_embedding + every ResnetBlock2D.time_emb_proj):

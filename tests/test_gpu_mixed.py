@@ -263,3 +263,23 @@ def test_cfg5_default_net_bf16_256_vs_oracle():
     assert e <= 2e-2, e
     solo = net(x[1:2].to(DEV), t[1:2].to(DEV)).sample
     assert torch.equal(solo, got[1:2])
+
+
+@pytest.mark.parametrize("mode", ["bf16", "fp16"])
+@pytest.mark.parametrize("n,c,heads,l", [(2, 64, 8, 1024), (1, 512, 64, 256), (3, 32, 4, 96)])
+def test_attention_single_product(mode, n, c, heads, l):
+    """Self-attention core with ONE bf16 / fp16 matrix-core product per MAC (q, k, v and the probabilities rounded once,
+    fp32 scores / max / denominators / accumulators) against fp64 softmax attention of the fp32 inputs: rounding-class
+    error of the 16-bit type; every output row is still a convex combination of V rows (|out| <= max |v| over the rounded v)."""
+    qkv = _t(61, (n, 3 * c, l), 1.3)
+    d_head = c // heads
+    q, k, v = (qkv[:, i * c:(i + 1) * c].double().view(n, heads, d_head, l) for i in range(3))
+    att = torch.softmax(torch.einsum("nhdi,nhdj->nhij", q, k) / np.sqrt(d_head), -1)
+    ref = torch.einsum("nhij,nhdj->nhdi", att, v).reshape(n, c, l)
+    got = ops.attention(qkv.to(DEV), heads, dtype=mode).cpu()
+    assert torch.isfinite(got).all()
+    assert rel_l2(got, ref) <= (1.5e-2 if mode == "bf16" else 2e-3), rel_l2(got, ref)
+    vmax = _rnd(qkv[:, 2 * c:], mode).abs().view(n, heads, d_head, l).amax(-1)      # per (n, head, dim)
+    assert (got.view(n, heads, d_head, l).abs().amax(-1) <= vmax * (1 + 2e-2)).all()
+    exact = ops.attention(qkv.to(DEV), heads).cpu()
+    assert rel_l2(exact, ref) <= 1e-5
