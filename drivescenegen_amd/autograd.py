@@ -664,14 +664,18 @@ def _backward16(model, st: TrainState, tape: _Tape, dout):
     def f32(t):   # [N, C, H, W] fp32 view of a tape tensor (conversion pass for the shapes the 16-bit kernels skip)
         return ops.from_blocked(t) if blocked(t) else t
 
-    def wgrad(x0, x1, dy, wname, k, stride, ups, ss, silu, cout=None, dy_coff=0):
+    def wgrad(x0, x1, dy, wname, k, stride, ups, ss, silu, cout=None, dy_coff=0, sums=None, sums_stride=0):
+        """weight gradient; returns True when `sums` (per-(n, cout) sums of dy) was filled as a by-product"""
         c0, c1 = chans(x0), (chans(x1) if x1 is not None else 0)
         co = cout or chans(dy)
         if blocked(x0) and blocked(dy) and ops.wgrad16_supported(c0, c1, co, x0.shape[2], x0.shape[3], k, stride, ups, dy_coff):
-            ops.conv_wgrad(x0, dy, st.grad(wname), src1=x1, ksize=k, gn_scale_shift=ss, silu=silu, cout=co, dy_coff=dy_coff)
+            ops.conv_wgrad(x0, dy, st.grad(wname), src1=x1, ksize=k, gn_scale_shift=ss, silu=silu, cout=co, dy_coff=dy_coff,
+                           dy_sums=sums, dy_sums_stride=sums_stride)
+            return sums is not None
         else:
             ops.conv_wgrad(f32(x0), f32(dy), st.grad(wname), src1=None if x1 is None else f32(x1), ksize=k, stride=stride,
                            upsample=ups, gn_scale_shift=ss, silu=silu, cout=co, dy_coff=dy_coff)
+            return False
 
     def dgrad(dy, wname, k, cout, stride=1, residual=None, col0=0, ncols=None, dst_blocked=True):
         """dX = conv(dY, W^T flipped) for columns [col0, col0 + ncols) of the conv's input channels; + residual."""
@@ -708,17 +712,24 @@ def _backward16(model, st: TrainState, tape: _Tape, dout):
                 continue
             wname, cout, k = rec["wname"], rec["cout"], rec["k"]
             x0, x1 = rec["x0"], rec["x1"]
+            # per-(n, c) sums of dy (bias and time-embedding gradients): a by-product of the 16-bit weight-gradient
+            # kernel where that serves the conv, a pass of their own otherwise
             if rec["toff"] is not None:
-                sums = ops.channel_sums(dy, out=tb["dtproj"][:, rec["toff"]:], out_stride=tb["dtproj"].stride(0))
-                ops.reduce_rows_add(sums, st.grad(wname + ".bias"), stride=tb["dtproj"].stride(0))
+                sums, sstride = tb["dtproj"][:, rec["toff"]:], tb["dtproj"].stride(0)
             else:
-                ops.reduce_rows_add(ops.channel_sums(dy), st.grad(wname + ".bias"))
+                sums = torch.empty((dy.shape[0], cout), dtype=torch.float32, device=dy.device)
+                sstride = cout
             if rec["res"] is not None:
                 tape.addg(rec["res"], dy)
             if rec["ups"]:   # weight gradient from the materialised nearest-x2 input, data gradient at full resolution
-                wgrad(ops.upsample_nearest2x(x0), None, dy, wname + ".weight", k, 1, False, None, False)
+                have = wgrad(ops.upsample_nearest2x(x0), None, dy, wname + ".weight", k, 1, False, None, False,
+                             sums=sums, sums_stride=sstride)
             else:
-                wgrad(x0, x1, dy, wname + ".weight", k, rec["stride"], False, rec["ss"], rec["silu"])
+                have = wgrad(x0, x1, dy, wname + ".weight", k, rec["stride"], False, rec["ss"], rec["silu"],
+                             sums=sums, sums_stride=sstride)
+            if not have:
+                ops.channel_sums(dy, out=sums, out_stride=sstride)
+            ops.reduce_rows_add(sums, st.grad(wname + ".bias"), stride=sstride)
             done(wname + ".weight", wname + ".bias")
             if not rec["need_dx"]:
                 continue

@@ -699,6 +699,8 @@ struct Wgrad16P {
   float* ws;            // [slab][9][cin][cout]
   int tiles_x, stages;  // 32-column strips per row, row pairs per image
   int ci_blocks, nrs;   // 64-channel ci blocks; row splits per strip
+  float* dysum_ws;      // optional [slab][cout]: per-run sums of dY over its pixels (bias / time-embedding gradients):
+                        // the dY tiles pass through this kernel anyway -- saves a pass of its own over dY
 };
 
 typedef short wg_s4 __attribute__((ext_vector_type(4)));
@@ -809,12 +811,24 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad16_kernel(Wgrad16P p) {
       *reinterpret_cast<uint4*>(dst) = make_uint4(o4[0], o4[1], o4[2], o4[3]);
     }
   };
-  auto commit_dy = [&](int par) {
+  const bool want_dysum = p.dysum_ws != nullptr && cib == 0;  // (one ci block per co block owns the by-product)
+  float dsum[8];  // this thread's channel block (tid & 7) of dY, summed over its pixels of the run
+#pragma unroll
+  for (int j = 0; j < 8; ++j) dsum[j] = 0.f;
+  auto commit_dy = [&](int par, bool count) {
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
       const int id = tid + 256 * u, cb = id & 7, px = id >> 3;
       unsigned short* dst = Db + par * W16_D_HALFS + (cb >> 2) * (64 * 32) + px * 32 + (cb & 3) * 8;
       *reinterpret_cast<uint4*>(dst) = xd[u];
+      if (want_dysum && count) {
+        const unsigned w4[4] = {xd[u].x, xd[u].y, xd[u].z, xd[u].w};
+#pragma unroll
+        for (int jp = 0; jp < 4; ++jp) {
+          dsum[2 * jp] += lo16<PREC>(w4[jp]);
+          dsum[2 * jp + 1] += hi16<PREC>(w4[jp]);
+        }
+      }
     }
   };
 
@@ -829,7 +843,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad16_kernel(Wgrad16P p) {
     load_rows(s0);
     load_dy(s0);
     commit_rows(s0);
-    commit_dy(0);
+    commit_dy(0, true);
     load_rows(s0 + 1);
     commit_rows(s0 + 1);
     load_rows(s0 + 2);
@@ -852,7 +866,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad16_kernel(Wgrad16P p) {
     const int par = (s - s0) & 1;
     // stage the next pair / dY tile (other ring slots, other dY buffer), then fetch the ones after them
     commit_rows(s + 2);
-    commit_dy(par ^ 1);
+    commit_dy(par ^ 1, s + 1 < s1);  // (the tile after the run's last one is loaded clamped and never used)
     load_rows(s + 3);
     load_dy(s + 2);
     const unsigned short* dl = d_lane + par * W16_D_HALFS;
@@ -874,6 +888,18 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad16_kernel(Wgrad16P p) {
     __syncthreads();
   }
 
+  if (want_dysum) {  // 32 threads share a channel block: fixed-order sum through LDS (the K loop is done with it)
+    float* red = reinterpret_cast<float*>(wsm16);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) red[tid * 8 + j] = dsum[j];
+    __syncthreads();
+    if (tid < 64) {
+      const int cb = tid >> 3, j = tid & 7;
+      float t = 0.f;
+      for (int k = 0; k < 32; ++k) t += red[(cb + 8 * k) * 8 + j];
+      p.dysum_ws[(size_t)blockIdx.y * p.cout + co0 + tid] = t;
+    }
+  }
   // epilogue: D[ci rows][co = l31]; partials to this run's slab [tap][ci][co]
   const int co = co0 + cot * 32 + l31;
   float* wsb = p.ws + (size_t)blockIdx.y * TAPS * p.cin * p.cout;
@@ -884,6 +910,16 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad16_kernel(Wgrad16P p) {
       const int ci = ci0 + cit * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
       wsb[((size_t)tp * p.cin + ci) * p.cout + co] = acc[tp][r];
     }
+}
+
+// out[n][co] = sum over the image's runs of the per-run dY sums
+__global__ void wgrad16_dysum_reduce_kernel(const float* __restrict__ part, int slabs_per_image, int cout,
+                                            float* __restrict__ out, int out_stride) {
+  const int co = blockIdx.x * blockDim.x + threadIdx.x, n = blockIdx.y;
+  if (co >= cout) return;
+  float t = 0.f;
+  for (int k = 0; k < slabs_per_image; ++k) t += part[((size_t)n * slabs_per_image + k) * cout + co];
+  out[(size_t)n * out_stride + co] = t;
 }
 
 static void wgrad16_runs(int cin, int cout, int n, int hout, int wout, int* strips, int* rsplit) {
@@ -909,7 +945,7 @@ static size_t wgrad16_ws_bytes(int cin, int cout, int ksize, int n, int hout, in
   }
   int strips, rsplit;
   wgrad16_runs(cin, cout, n, hout, wout, &strips, &rsplit);
-  return (size_t)strips * rsplit * ksize * ksize * cin * cout * sizeof(float);
+  return (size_t)strips * rsplit * ((size_t)ksize * ksize * cin * cout + cout) * sizeof(float);  // + the dY-sum rows
 }
 
 static int launch_wgrad16(const dsg_conv_wgrad_args* a, int hout, int wout, hipStream_t st) {
@@ -928,9 +964,10 @@ static int launch_wgrad16(const dsg_conv_wgrad_args* a, int hout, int wout, hipS
   wgrad16_runs(p.cin, p.cout, p.n, hout, wout, &strips, &rsplit);
   p.nrs = rsplit;
   const int nslab = strips * rsplit;
-  const size_t need = (size_t)nslab * taps * p.cin * p.cout * sizeof(float);
+  const size_t need = (size_t)nslab * ((size_t)taps * p.cin * p.cout + p.cout) * sizeof(float);
   if (p.ws == nullptr || a->workspace_bytes < need)
     return fail(DSG_ERR_WORKSPACE_TOO_SMALL, "dsg_conv2d_wgrad: workspace %zu bytes < required %zu", a->workspace_bytes, need);
+  p.dysum_ws = a->dy_sums ? p.ws + (size_t)nslab * taps * p.cin * p.cout : nullptr;
   int pi = -1;
   if (prof_on())
     pi = prof_begin(29, 2.0 * p.n * hout * wout * (double)p.cout * p.cin * taps,
@@ -948,6 +985,11 @@ static int launch_wgrad16(const dsg_conv_wgrad_args* a, int hout, int wout, hipS
   const int64_t slab = (int64_t)taps * p.cin * p.cout;
   hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)cdiv64(slab / 4, 64)), dim3(256), 0, st, p.ws, nslab, taps, p.cin,
                      p.cout, p.cin, p.cout, a->dw);
+  if (a->dy_sums) {
+    DSG_LAUNCH_CHECK();
+    hipLaunchKernelGGL(wgrad16_dysum_reduce_kernel, dim3(cdiv(p.cout, 256), p.n), dim3(256), 0, st, p.dysum_ws,
+                       p.tiles_x * rsplit, p.cout, a->dy_sums, a->dy_sums_stride ? a->dy_sums_stride : p.cout);
+  }
   prof_end(pi, st);
   DSG_LAUNCH_CHECK();
   return DSG_OK;
@@ -987,6 +1029,7 @@ DSG_API int dsg_conv2d_wgrad(const dsg_conv_wgrad_args* a, void* stream) {
                 "dsg_conv2d_wgrad: dy channel window out of range");
   hipStream_t st = static_cast<hipStream_t>(stream);
   DSG_CHECK_ARG(a->compute_dtype >= DSG_F32 && a->compute_dtype <= DSG_F16, "dsg_conv2d_wgrad: bad compute_dtype %d", a->compute_dtype);
+  DSG_CHECK_ARG(a->dy_sums == nullptr || a->compute_dtype != DSG_F32, "dsg_conv2d_wgrad: dy_sums is a by-product of the 16-bit kernel only");
   if (a->compute_dtype != DSG_F32) {  // mixed-precision tape: channel-blocked 16-bit x and dY
     DSG_CHECK_SHAPE(wgrad16_ok(a, a->hin, a->win) && !a->force_direct,
                     "dsg_conv2d_wgrad: the 16-bit kernel takes stride-1 3x3 / 1x1 convs with cin %% 64 == 0, cout %% 64 == 0 "

@@ -136,9 +136,12 @@ __global__ void gn_finalize_kernel(const double* __restrict__ stats, const float
   }
 }
 
-// One wave per (n, group): per-tile partial statistics of the group's channels (which may sit in either of two
-// concatenated sources) summed in a fixed order -- lane-strided over tiles, then a fixed butterfly.
-__global__ __launch_bounds__(64) void gn_finalize_parts_kernel(const double* __restrict__ st0, int c0, int t0,
+// One workgroup of FP_T threads per (n, group): per-tile partial statistics of the group's channels (which may sit in
+// either of two concatenated sources) summed in a fixed order -- thread-strided over tiles, a fixed butterfly per wave,
+// the waves in order.  (256 threads: the shallow levels have 2 channels x 256 tiles per group -- with one wave that was
+// 8 dependent round trips of a launch whose whole cost is latency.)
+constexpr int FP_T = 256;
+__global__ __launch_bounds__(FP_T) void gn_finalize_parts_kernel(const double* __restrict__ st0, int c0, int t0,
                                                               const double* __restrict__ st1, int c1, int t1,
                                                               const float* __restrict__ gamma,
                                                               const float* __restrict__ beta, int groups, int hw,
@@ -146,7 +149,7 @@ __global__ __launch_bounds__(64) void gn_finalize_parts_kernel(const double* __r
                                                               float* __restrict__ mr, unsigned* __restrict__ bound) {
   const int c = c0 + c1, cpg = c / groups;
   const int ni = blockIdx.x / groups, g = blockIdx.x - ni * groups;
-  const int lane = threadIdx.x;
+  const int lane = threadIdx.x;  // (index within the workgroup)
   // A group's channels are consecutive, hence its partials are one contiguous run of (sum, sum of squares) pairs per
   // source: the 64 lanes stride over that run (the deep levels have 16-32 channels x 4 tiles per group -- a loop
   // over channels with 4 active lanes would be 32 dependent round trips).  Fixed order for a given shape.
@@ -156,7 +159,7 @@ __global__ __launch_bounds__(64) void gn_finalize_parts_kernel(const double* __r
   {
     const int a = min(ch0, c0), b = min(ch1, c0);  // the group's channels that live in source 0
     const double2* p = reinterpret_cast<const double2*>(st0 + ((size_t)ni * c0 + a) * t0 * 2);
-    for (int i = lane; i < (b - a) * t0; i += 64) {
+    for (int i = lane; i < (b - a) * t0; i += FP_T) {
       const double2 v = p[i];
       s += v.x;
       ss += v.y;
@@ -166,7 +169,7 @@ __global__ __launch_bounds__(64) void gn_finalize_parts_kernel(const double* __r
   if (c1 > 0) {
     const int a = max(ch0, c0) - c0, b = max(ch1, c0) - c0;  // ... and in source 1
     const double2* p = reinterpret_cast<const double2*>(st1 + ((size_t)ni * c1 + a) * t1 * 2);
-    for (int i = lane; i < (b - a) * t1; i += 64) {
+    for (int i = lane; i < (b - a) * t1; i += FP_T) {
       const double2 v = p[i];
       s += v.x;
       ss += v.y;
@@ -176,20 +179,28 @@ __global__ __launch_bounds__(64) void gn_finalize_parts_kernel(const double* __r
   if (bound != nullptr) {  // range guard of the split convs that read these tensors un-normalised (dsg_conv_args.src_bound)
 #pragma unroll
     for (int m = 32; m >= 1; m >>= 1) sq_max = fmaxf(sq_max, __shfl_xor(sq_max, m));
-    if (lane == 0) atomicMax(bound + ni, __float_as_uint(sqrtf(sq_max)));
+    if ((lane & 63) == 0) atomicMax(bound + ni, __float_as_uint(sqrtf(sq_max)));
   }
 #pragma unroll
   for (int m = 32; m >= 1; m >>= 1) {
     s += __shfl_xor(s, m);
     ss += __shfl_xor(ss, m);
   }
+  __shared__ double wsum[2][FP_T / 64];
+  if ((lane & 63) == 0) {
+    wsum[0][lane >> 6] = s;
+    wsum[1][lane >> 6] = ss;
+  }
+  __syncthreads();
+  s = (wsum[0][0] + wsum[0][1]) + (wsum[0][2] + wsum[0][3]);
+  ss = (wsum[1][0] + wsum[1][1]) + (wsum[1][2] + wsum[1][3]);
   const double cnt = (double)cpg * (double)hw;
   const double mean = s / cnt;
   double var = ss / cnt - mean * mean;
   if (var < 0.0) var = 0.0;
   const float rstd = (float)(1.0 / sqrt(var + (double)eps));
   const float meanf = (float)mean;
-  for (int k = lane; k < cpg; k += 64) {
+  for (int k = lane; k < cpg; k += FP_T) {
     const int ch = g * cpg + k;
     const float sc = rstd * gamma[ch];
     out[2 * ((size_t)ni * c + ch)] = sc;
@@ -327,7 +338,7 @@ static int gn_finalize_parts_impl(const double* stats0, int32_t c0, int32_t tile
                 "dsg_gn_finalize_parts: bad dims");
   DSG_CHECK_ARG((c0 + c1) % groups == 0, "dsg_gn_finalize_parts: channels (%d) not divisible by groups (%d)",
                 c0 + c1, groups);
-  hipLaunchKernelGGL(dsg::gn_finalize_parts_kernel, dim3(n * groups), dim3(64), 0, static_cast<hipStream_t>(stream),
+  hipLaunchKernelGGL(dsg::gn_finalize_parts_kernel, dim3(n * groups), dim3(dsg::FP_T), 0, static_cast<hipStream_t>(stream),
                      stats0, c0, tiles0, stats1, c1, tiles1, gamma, beta, groups, hw, eps, scale_shift, mean_rstd, bound);
   DSG_LAUNCH_CHECK();
   return DSG_OK;

@@ -52,7 +52,11 @@ def test_wgrad16(case, mode):
     act = _rnd(act.float(), mode).double()
     ref = torch.nn.grad.conv2d_weight(act, (cout, cin, k, k), dy.double(), padding=k // 2)
     dw = torch.full((cout, cin, k, k), 0.25, dtype=torch.float32, device=DEV)   # accumulated into
-    ops.conv_wgrad(b0, ops.to_blocked(dy.to(DEV), mode), dw, src1=b1, ksize=k, gn_scale_shift=ss, silu=gn)
+    sums = torch.full((n, cout + 3), -7.0, dtype=torch.float32, device=DEV)   # by-product: per-(n, cout) sums of dY
+    ops.conv_wgrad(b0, ops.to_blocked(dy.to(DEV), mode), dw, src1=b1, ksize=k, gn_scale_shift=ss, silu=gn,
+                   dy_sums=sums[:, 1:], dy_sums_stride=sums.stride(0))
+    assert torch.allclose(sums[:, 1:cout + 1].cpu().double(), dy.double().sum((2, 3)), rtol=1e-5, atol=1e-4)
+    assert float(sums[:, 0].min()) == -7.0 and float(sums[:, cout + 1:].max()) == -7.0   # nothing outside the window
     got = dw.cpu().double() - 0.25
     assert rel_l2(got, ref) <= (2e-4 if gn else 2e-5), rel_l2(got, ref)
 
