@@ -354,11 +354,32 @@ __global__ __launch_bounds__(64 * NW, OCC * NW / 4) void conv_h2_kernel(ConvH2P 
   // turns two channels (2jp, 2jp+1) of unit P/4 into operand words -- the unit's LDS write rides on its last step --
   // and refills the registers just freed with chunk q+2's values.
   unsigned w1s[H2_NU][4], w2s[H2_NU][4];
-  auto stage_step = [&](int P, int qs, unsigned char* buf, bool stage, bool load, const char* spn) {  // (loads: chunk qs + 1)
+  // s4: the step's scale/shift entry.  The caller reads it from the LDS table ONE TAP AHEAD: a table read consumed at
+  // once queues behind the twelve fragment reads of the tap and stalls the wave -- MFMAs included -- for their whole
+  // drain (20 such waits per K-chunk were a quarter of the loop's time).  The read is volatile so that it stays where
+  // it is written: a plain load is sunk to its use, across the tap boundary, before the scheduler ever sees it.
+  typedef float ss_f4 __attribute__((ext_vector_type(4)));
+  auto ss_entry = [&](int P, int qs) -> float4 {
+    // (the explicit LDS address space matters: a volatile access through a generic pointer is a flat load)
+    const ss_f4 v = *(const volatile __attribute__((address_space(3))) ss_f4*)(
+        ssl + 2 * ((qs + qb) * H2_KC + unit_g(P / 4) * 8 + 2 * (P % 4)));
+    return make_float4(v.x, v.y, v.z, v.w);
+  };
+  constexpr int SS_NSTEP = 4 * H2_NU, SS_ST = TAPS > 1 ? TAPS - 1 : 1, SS_SPT = (SS_NSTEP + SS_ST - 1) / SS_ST;
+  float4 s4b[2][KS == 3 ? SS_SPT : 1];  // [tap parity][step of the tap]
+  // entries of the steps that ride on tap `tap` of the chunk that stages chunk qs
+  auto load_ss = [&](int tap, int qs) {
+    if constexpr (KS == 3) {
+      if (has_ss) {
+#pragma unroll
+        for (int P = tap * SS_NSTEP / SS_ST; P < (tap + 1) * SS_NSTEP / SS_ST; ++P)
+          s4b[tap & 1][P - tap * SS_NSTEP / SS_ST] = ss_entry(P, qs);
+      }
+    }
+  };
+  auto stage_step = [&](int P, int qs, unsigned char* buf, bool stage, bool load, const char* spn, const float4& s4) {  // (loads: chunk qs + 1)
     const int i = P / 4, jp = P % 4;
     if (stage) {
-      float4 s4 = make_float4(1.f, 1.f, 0.f, 0.f);
-      if (has_ss) s4 = *reinterpret_cast<const float4*>(ssl + 2 * ((qs + qb) * H2_KC + unit_g(i) * 8 + 2 * jp));
       float a, b;
       pair_of(xr, i, jp, a, b);
       to_operand(a, b, s4, w1s[i][jp], w2s[i][jp]);
@@ -555,6 +576,10 @@ __global__ __launch_bounds__(64 * NW, OCC * NW / 4) void conv_h2_kernel(ConvH2P 
       const unsigned long long tt0 = __builtin_readcyclecounter();
       __builtin_amdgcn_sched_barrier(0);
 #endif
+      // next tap's scale/shift entries (BEFORE the fragments in program order: LDS returns in order, so a counted wait
+      // covers the entries alone); the clear last tap fetches tap 0's entries of the next chunk
+      if (STAGE && tap + 1 < TAPS - 1) load_ss(tap + 1, q + 1);
+      if (LOAD && tap == TAPS - 1) load_ss(0, q + 2);
       if (tap + 1 < TAPS) load_frags(tap + 1, (tap + 1) & 1);
       if (KS == 1) {  // one tap: all units and the four weight segments ride on it
 #pragma unroll
@@ -569,11 +594,15 @@ __global__ __launch_bounds__(64 * NW, OCC * NW / 4) void conv_h2_kernel(ConvH2P 
       if (KS == 3 && tap < TAPS - 1) {
         constexpr int NSTEP = 4 * H2_NU, ST = TAPS - 1;
 #pragma unroll
-        for (int P = tap * NSTEP / ST; P < (tap + 1) * NSTEP / ST; ++P) stage_step(P, q + 1, nxt, STAGE, LOAD, spn);
+        for (int P = tap * NSTEP / ST; P < (tap + 1) * NSTEP / ST; ++P)
+          stage_step(P, q + 1, nxt, STAGE, LOAD, spn,
+                     has_ss ? s4b[tap & 1][P - tap * NSTEP / ST] : make_float4(1.f, 1.f, 0.f, 0.f));
+#ifndef DSG_H2_ABL_NODMA
         if (STAGE) {
 #pragma unroll
           for (int k = tap * G::NDMA / ST; k < (tap + 1) * G::NDMA / ST; ++k) dma_weights(k, wqn, nxt);
         }
+#endif
       }
       const int par = tap & 1;
 #pragma unroll
@@ -620,12 +649,21 @@ __global__ __launch_bounds__(64 * NW, OCC * NW / 4) void conv_h2_kernel(ConvH2P 
   };
   using T = std::true_type;
   using F = std::false_type;
+  if (nq > 1) load_ss(0, 1);  // tap 0 of the first chunk stages chunk 1
 #ifdef DSG_H2_TIMING
   const unsigned long long t_begin = __builtin_readcyclecounter();
   const unsigned long long rt_loop = __builtin_amdgcn_s_memrealtime();
 #endif
   int q = 0;
+#if defined(DSG_H2_ABL_NOSTAGE)  // (tools/ timing experiments only: wrong results, loop time without a component)
+  for (; q + 2 < nq; ++q) chunk(q, F{}, T{});
+#elif defined(DSG_H2_ABL_NOLOAD)
+  for (; q + 2 < nq; ++q) chunk(q, T{}, F{});
+#elif defined(DSG_H2_ABL_MFMAONLY)
+  for (; q + 2 < nq; ++q) chunk(q, F{}, F{});
+#else
   for (; q + 2 < nq; ++q) chunk(q, T{}, T{});
+#endif
   if (q + 1 < nq) chunk(q++, T{}, F{});  // last staged chunk: nothing left to load
   chunk(q, F{}, F{});                    // last chunk: MFMAs only
 #ifdef DSG_H2_TIMING

@@ -42,6 +42,10 @@ if os.environ.get('ONLY'):
     SHAPES = [s for s in SHAPES if os.environ['ONLY'] in s[0]]
 for name, c0, c1, cout, h, k, s, ups, gn, res in SHAPES:
     cin = c0 + c1
+    if os.environ.get("NOGN") == "1":   # ablation: the same conv without the GroupNorm-apply + SiLU staging work
+        gn = False
+    if os.environ.get("NORES") == "1":
+        res = False
     x0 = torch.randn(B, c0, h, h, device=dev)
     x1 = torch.randn(B, c1, h, h, device=dev) if c1 else None
     w = torch.randn(cin, k * k, cout, device=dev) * 0.05
