@@ -464,6 +464,7 @@ void conv_h2_set_bm32(int v);
 void conv_h2_set_bm32_small(int v);
 void conv_h2_set_bm128(int v);
 void conv_h2_set_splitk(int v);
+void conv_h2_set_ws2(int v);
 int conv_h2_splitk_slices(const dsg_conv_args* a, int hout, int wout, int* stat_splits);
 void unet_set_blocked(int v);
 void attention_set_mfma(int v);
@@ -831,6 +832,10 @@ DSG_API int dsg_set_tuning(int32_t key, int32_t value) {
   }
   if (key == 19 && (value == 0 || value == 1)) {
     dsg::conv_h2_set_splitk(value);
+    return DSG_OK;
+  }
+  if (key == 20 && (value == 0 || value == 1)) {
+    dsg::conv_h2_set_ws2(value);
     return DSG_OK;
   }
   if (key == 18 && (value == 0 || value == 1)) {

@@ -212,6 +212,7 @@ void conv_h2_set_bm32_small(int v) { g_h2.bm32_small = v; ++g_h2.epoch; }
 void conv_h2_set_bm32(int v) { g_h2.bm32 = v != 0; if (v > 1) g_h2.bm32_min = v; ++g_h2.epoch; }
 void conv_h2_set_bm128(int v) { g_h2.bm128 = v; ++g_h2.epoch; }
 void conv_h2_set_splitk(int v) { g_h2.splitk = v; ++g_h2.epoch; }
+void conv_h2_set_ws2(int v) { g_h2.ws2 = v; ++g_h2.epoch; }
 int conv_h2_tuning_epoch() { return g_h2.epoch; }
 
 // ---------------------------------------------------------------------------------------------------------------

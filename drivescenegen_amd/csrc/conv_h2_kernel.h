@@ -143,8 +143,14 @@ __device__ __forceinline__ float silu_fast_h(float x) { return x * __builtin_amd
 //     run under the other's MFMAs (a workgroup that owns the CU runs those phases back to back).
 // PREC: 0 fp32 tensors, fp16x2-split products; 1 bf16 / 2 fp16: channel-blocked tensors are 16-bit in HBM, one MFMA per
 //       product, fp32 accumulate, GroupNorm affine + SiLU in fp32 before the operand is rounded ([N,C,H,W] tensors stay fp32)
-template <int GM, int NT, int KS, int ACT = 3, int NW = 4, int OCC = 1, int LAY = 0, int BM = 64, int PREC = 0>
+// WS: ONE weight slab in LDS instead of two (the patch stays double-buffered): 80 KB per workgroup at 64 couts x 8 rows
+//     with the split's two-piece operands, i.e. two workgroups per CU for the 64- / 128-channel levels, whose tiles are
+//     short (4-8 K-chunks) and spend a third of their life in the prologue and epilogue.  The slab of chunk q+1 can only
+//     be fetched once every wave is done with chunk q -- that DMA latency is exposed per chunk and, like the prologue and
+//     the epilogue, covered by the CU's other workgroup.
+template <int GM, int NT, int KS, int ACT = 3, int NW = 4, int OCC = 1, int LAY = 0, int BM = 64, int PREC = 0, int WS = 0>
 __global__ __launch_bounds__(64 * NW, OCC * NW / 4) void conv_h2_kernel(ConvH2P p) {
+  static_assert(!WS || KS == 3, "the one-slab layout is for the 3x3 kernels");
   constexpr bool SB = (LAY & 1) != 0, DB = (LAY & 2) != 0;
   constexpr int NP = PREC ? 1 : 2;              // operand pieces
   constexpr bool S16 = PREC != 0 && SB;         // 16-bit sources (8 channels of a pixel = one 16-byte load)
@@ -250,7 +256,11 @@ __global__ __launch_bounds__(64 * NW, OCC * NW / 4) void conv_h2_kernel(ConvH2P 
   Patch xr;
   // GroupNorm (scale, shift) of this image's channels: copied once into LDS behind the two K-chunk buffers; a commit
   // reads its 8 channels from there (uniform address: a broadcast read) instead of carrying them in registers
-  float* ssl = reinterpret_cast<float*>(smem_raw + 2 * H2_BUF_BYTES);
+  // LDS: [W | X | dump] x 2, or with WS [W | X | dump | X | dump]: buffer 1 starts one X region further, so that the
+  // same (buffer base + offset) addressing reaches its patch; weights are always read from / fetched into buffer 0's
+  constexpr int H2_BUF1_OFF = WS ? H2_XHALFS * 2 + 64 : H2_BUF_BYTES;
+  constexpr int H2_LDS_BUFS = WS ? H2_BUF_BYTES + H2_BUF1_OFF : 2 * H2_BUF_BYTES;
+  float* ssl = reinterpret_cast<float*>(smem_raw + H2_LDS_BUFS);
 
   const char* src0b = static_cast<const char*>(p.src0);
   const char* src1b = static_cast<const char*>(p.src1);
@@ -460,7 +470,7 @@ __global__ __launch_bounds__(64 * NW, OCC * NW / 4) void conv_h2_kernel(ConvH2P 
       }
 
   unsigned char* buf0 = smem_raw;
-  unsigned char* buf1 = smem_raw + H2_BUF_BYTES;
+  unsigned char* buf1 = smem_raw + H2_BUF1_OFF;
 
   // zero padding: halo positions outside the image are zeroed once in both buffers and never written again
 #pragma unroll
@@ -545,8 +555,8 @@ __global__ __launch_bounds__(64 * NW, OCC * NW / 4) void conv_h2_kernel(ConvH2P 
     unsigned char* nxt = (q & 1) ? buf0 : buf1;
     const char* spn = LOAD ? src_of(q + 2) : nullptr;
     const char* wqn = wtile + (size_t)(q + 1) * chunkb;  // the staged chunk's weights
-    const _Float16* wl = reinterpret_cast<const _Float16*>(cur);
-    const _Float16* xl = wl + H2_WHALFS;
+    const _Float16* wl = reinterpret_cast<const _Float16*>(WS ? buf0 : cur);
+    const _Float16* xl = reinterpret_cast<const _Float16*>(cur) + H2_WHALFS;
     // Operand fragments are fetched one tap ahead into the other half of fa/fb: the reads of tap t+1 are issued
     // BEFORE tap t's staging writes in program order, so tap t's MFMAs depend on registers only and the scheduler
     // is free to interleave them with the staging work (LDS reads after a possibly-aliasing LDS write are not).
@@ -598,7 +608,7 @@ __global__ __launch_bounds__(64 * NW, OCC * NW / 4) void conv_h2_kernel(ConvH2P 
           stage_step(P, q + 1, nxt, STAGE, LOAD, spn,
                      has_ss ? s4b[tap & 1][P - tap * NSTEP / ST] : make_float4(1.f, 1.f, 0.f, 0.f));
 #ifndef DSG_H2_ABL_NODMA
-        if (STAGE) {
+        if (STAGE && !WS) {
 #pragma unroll
           for (int k = tap * G::NDMA / ST; k < (tap + 1) * G::NDMA / ST; ++k) dma_weights(k, wqn, nxt);
         }
@@ -641,10 +651,29 @@ __global__ __launch_bounds__(64 * NW, OCC * NW / 4) void conv_h2_kernel(ConvH2P 
     const unsigned long long tc = __builtin_readcyclecounter();
     t_vm += tb - ta;
     t_bar += tc - tb;
+    if constexpr (WS) {  // (timing build: the exposed slab fetch counts as memory wait)
+      if (STAGE) {
+#pragma unroll
+        for (int k = 0; k < G::NDMA; ++k) dma_weights(k, wqn, buf0);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        t_vm += __builtin_readcyclecounter() - tc;
+      }
+    }
     __builtin_amdgcn_sched_barrier(0);
 #else
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the weight DMAs (not tracked by the compiler) have landed
-    __syncthreads();  // nxt is complete; everyone is done reading cur
+    if constexpr (WS) {
+      __syncthreads();  // everyone is done with the weight slab (and with cur); nxt's patch is complete
+      if (STAGE) {
+#pragma unroll
+        for (int k = 0; k < G::NDMA; ++k) dma_weights(k, wqn, buf0);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();  // the next chunk's weights are in
+      }
+    } else {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the weight DMAs (not tracked by the compiler) have landed
+      __syncthreads();  // nxt is complete; everyone is done reading cur
+    }
 #endif
   };
   using T = std::true_type;
@@ -869,28 +898,17 @@ __global__ __launch_bounds__(64 * NW, OCC * NW / 4) void conv_h2_kernel(ConvH2P 
     }
   }
 #ifdef DSG_H2_TIMING
-  if (p.stats && tid == 0) p.stats[8 + 4 * (size_t)gridDim.x + blockIdx.x] =
-      (double)__builtin_amdgcn_s_memrealtime();
-#endif
-#ifdef DSG_H2_TIMING
-  if (p.stats && lane == 0) {
-    atomicAdd(&p.stats[0], (double)t_loop_cycles);
-    atomicAdd(&p.stats[1], (double)t_vm);
-    atomicAdd(&p.stats[2], (double)t_bar);
-    atomicAdd(&p.stats[3], 1.0);
-    for (int t = 0; t < TAPS; ++t) atomicAdd(&p.stats[8 + 5 * (size_t)gridDim.x + t], (double)t_tap[t]);
-    if (wave == 0) {  // per-block record: start / loop begin / loop end (10-ns ticks), loop cycles
-      double* rec = p.stats + 8 + 4 * (size_t)blockIdx.x;
-      rec[0] = (double)rt_entry;
-      rec[1] = (double)rt_loop;
-      rec[2] = (double)rt_loop_end;
-      rec[3] = (double)t_loop_cycles;
-      double* pr = p.stats + 8 + 5 * (size_t)gridDim.x + 16 + 4 * (size_t)blockIdx.x;
-      for (int k = 0; k < 4; ++k) pr[k] = (double)rt_p[k];
-      double* er = p.stats + 8 + 9 * (size_t)gridDim.x + 16 + 6 * (size_t)blockIdx.x;
-      rt_e[5] = __builtin_amdgcn_s_memrealtime();
-      for (int k = 0; k < 6; ++k) er[k] = (double)rt_e[k];
-    }
+  // one 32-double record per workgroup, written by its first lane only (no atomics: 30k waves adding into one word
+  // were most of the instrumented kernel's time); tools/h2_timing.py reads them
+  if (p.stats && tid == 0) {
+    double* rec = p.stats + 32 * (size_t)blockIdx.x;
+    rec[0] = (double)rt_entry; rec[1] = (double)rt_loop; rec[2] = (double)rt_loop_end; rec[3] = (double)t_loop_cycles;
+    rec[4] = (double)t_vm; rec[5] = (double)t_bar;
+    for (int k = 0; k < 4; ++k) rec[6 + k] = (double)rt_p[k];
+    rt_e[5] = __builtin_amdgcn_s_memrealtime();
+    for (int k = 0; k < 6; ++k) rec[10 + k] = (double)rt_e[k];
+    for (int t = 0; t < 10; ++t) rec[17 + t] = (double)t_tap[t];
+    rec[16] = (double)__builtin_amdgcn_s_memrealtime();
   }
 #endif
 }

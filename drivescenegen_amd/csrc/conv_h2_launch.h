@@ -26,6 +26,7 @@ struct H2Tuning {
   int rows = 0;         // rows per wave: 0 = by grid size, 2 | 4 forced (key 3)
   int bm128 = 1;        // 16-bit modes: 128-cout workgroups where the grid still fills the chip (key 18)
   int splitk = 1;       // split-K for grids of at most half the CUs, when the caller gives scratch (key 19)
+  int ws2 = 1;          // fp32-equivalent 3x3 convs with cin <= 128: 8-row tiles, one weight slab, two workgroups per CU (key 20)
   int epoch = 0;        // bumped by every change: plans key their cached workspace sizes on it
 };
 extern H2Tuning g_h2;
@@ -39,9 +40,9 @@ int conv_h2_splitk_slices(const dsg_conv_args* a, int hout, int wout, int* stat_
 int splitk_reduce_launch(const float* part, int slices, const dsg_conv_args* a, int hout, int wout, int stat_splits,
                          hipStream_t st);
 
-template <int GM, int NT, int KS, int ACT, int NW = 4, int OCC = 1, int LAY = 0, int BM = 64, int PREC = 0>
+template <int GM, int NT, int KS, int ACT, int NW = 4, int OCC = 1, int LAY = 0, int BM = 64, int PREC = 0, int WS = 0>
 static int h2_launch(dim3 grid, size_t lds, hipStream_t st, const ConvH2P& p) {
-  auto kern = conv_h2_kernel<GM, NT, KS, ACT, NW, OCC, LAY, BM, PREC>;
+  auto kern = conv_h2_kernel<GM, NT, KS, ACT, NW, OCC, LAY, BM, PREC, WS>;
   static bool raised = false;
   if (!raised) {
     DSG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -176,6 +177,18 @@ int conv_h2_launch_t(const dsg_conv_args* a, int hout, int wout, hipStream_t st)
     q.tiles_y = hout / 8;
     if (act == 0) rc = h2_launch<0, 2, 3, 0, 4, 2, 3, 32, PREC>(g32, lds32, st, q);
     else rc = h2_launch<0, 2, 3, 2, 4, 2, 3, 32, PREC>(g32, lds32, st, q);
+  } else if (PREC == 0 && lay == 3 && g_h2.ws2 && p.cin <= 128 && wout % H2_TW == 0 && slices == 1 &&
+             (wout / H2_TW) * (hout / 8) * p.n * (p.cout_pad / H2_BM) >= 2 * H2_CUS) {
+    // shallow levels: 64 couts x 8 rows, ONE weight slab (80 KB of LDS, half the register file): two workgroups per CU
+    if constexpr (PREC == 0) {
+      using GW = H2Geom<2, 3, 4, 9, 64, 2>;
+      const dim3 gws(p.tiles_x * (hout / 8) * p.n * (p.cout_pad / H2_BM));
+      const size_t ldsw = (size_t)GW::BUF_BYTES + GW::XHALFS * 2 + 64 + (a->gn_scale_shift ? (size_t)p.cin * 2 * sizeof(float) : 0);
+      ConvH2P q = p;
+      q.tiles_y = hout / 8;
+      if (act == 0) rc = h2_launch<0, 2, 3, 0, 4, 2, 3, 64, 0, 1>(gws, ldsw, st, q);
+      else rc = h2_launch<0, 2, 3, 2, 4, 2, 3, 64, 0, 1>(gws, ldsw, st, q);
+    }
   } else if (lay == 3) {
     bool done128 = false;
     if constexpr (PREC != 0) {
