@@ -699,6 +699,9 @@ struct Wgrad16P {
   float* ws;            // [slab][9][cin][cout]
   int tiles_x, stages;  // 32-column strips per row, row pairs per image
   int ci_blocks, nrs;   // 64-channel ci blocks; row splits per strip
+  int spw;              // strips per workgroup (> 1 only with nrs == 1): consecutive strips accumulate into ONE partial slab
+                        // -- at 512 channels the (ci, co) block pairs alone fill the chip, and a slab per image meant 300 MB
+                        // of partials for the reduce pass to read back
   float* dysum_ws;      // optional [slab][cout]: per-run sums of dY over its pixels (bias / time-embedding gradients):
                         // the dY tiles pass through this kernel anyway -- saves a pass of its own over dY
 };
@@ -733,32 +736,35 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad16_kernel(Wgrad16P p) {
   const bool has_ss = p.ss != nullptr;
   const bool do_silu = has_ss && p.silu;
 
-  // this workgroup's run: strip (image n, column tile tx), stages [s0, s1)
-  const int strip = blockIdx.y / p.nrs, rs = blockIdx.y - strip * p.nrs;
-  const int n = strip / p.tiles_x, tx = strip - n * p.tiles_x;
-  const int ox0 = tx * 32;
+  // this workgroup's runs: strips [run * spw, (run + 1) * spw) (image n, column tile tx), stages [s0, s1) of each
+  const int run = blockIdx.y / p.nrs, rs = blockIdx.y - run * p.nrs;
   const int per = (p.stages + p.nrs - 1) / p.nrs;
   const int s0 = rs * per, s1 = min(p.stages, s0 + per);
-
-  // the 64-channel ci block sits entirely in one of the two concatenated sources (c0 % 64 == 0)
-  const bool in0 = ci0 < p.c0;
-  const unsigned short* xsrc = in0 ? static_cast<const unsigned short*>(p.src0) + ((size_t)n * p.c0 + ci0) * plane
-                                   : static_cast<const unsigned short*>(p.src1) + ((size_t)n * p.c1 + (ci0 - p.c0)) * plane;
-  const unsigned short* dsrc = static_cast<const unsigned short*>(p.dy) + ((size_t)n * p.dy_ctotal + p.dy_coff + co0) * plane;
+  int n = 0, ox0 = 0;
+  const unsigned short* xsrc = nullptr;
+  const unsigned short* dsrc = nullptr;
+  const bool in0 = ci0 < p.c0;  // the 64-channel ci block sits entirely in one of the two concatenated sources (c0 % 64 == 0)
 
   // staging items.  A: (row of the pair, column 0..33, channel block 0..7) = 544, three rounds; dY: (pixel 0..63, co block) = 512
   const int a_cb = tid & 7;  // the same channel block in every round: its scale / shift live in registers
   float sc[8], sh[8];
+  auto begin_strip = [&](int strip) {  // per-strip state: image, column tile, source bases, the image's scale / shift
+    n = strip / p.tiles_x;
+    ox0 = (strip - n * p.tiles_x) * 32;
+    xsrc = in0 ? static_cast<const unsigned short*>(p.src0) + ((size_t)n * p.c0 + ci0) * plane
+               : static_cast<const unsigned short*>(p.src1) + ((size_t)n * p.c1 + (ci0 - p.c0)) * plane;
+    dsrc = static_cast<const unsigned short*>(p.dy) + ((size_t)n * p.dy_ctotal + p.dy_coff + co0) * plane;
 #pragma unroll
-  for (int j = 0; j < 8; ++j) {
-    sc[j] = 1.f;
-    sh[j] = 0.f;
-    if (has_ss) {
-      const float2 t2 = *reinterpret_cast<const float2*>(p.ss + ((size_t)n * p.cin + ci0 + a_cb * 8 + j) * 2);
-      sc[j] = t2.x;
-      sh[j] = t2.y;
+    for (int j = 0; j < 8; ++j) {
+      sc[j] = 1.f;
+      sh[j] = 0.f;
+      if (has_ss) {
+        const float2 t2 = *reinterpret_cast<const float2*>(p.ss + ((size_t)n * p.cin + ci0 + a_cb * 8 + j) * 2);
+        sc[j] = t2.x;
+        sh[j] = t2.y;
+      }
     }
-  }
+  };
   int a_row[3], a_col[3];
   bool a_use[3];
 #pragma unroll
@@ -838,6 +844,21 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad16_kernel(Wgrad16P p) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
 
+  // transposing-read addressing of this lane: source lane s = lane & 15 -> pixel + (s >> 2), channel quad (s & 3) of the
+  // 16-channel group (lane >> 4) & 1 of the wave's 32-channel tile
+  const int s16 = lane & 15, g16 = (lane >> 4) & 1;
+  const int t_px = s16 >> 2, t_ch = g16 * 16 + (s16 & 3) * 4;
+  const unsigned short* a_lane = Ab + cit * (W16_SLOTS * W16_PW * 32) + t_ch;
+  const unsigned short* d_lane = Db + cot * (64 * 32) + t_ch;
+  auto tr4 = [](const unsigned short* q) -> wg_s4 {
+    return __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+        (__attribute__((address_space(3))) wg_s4*)(const_cast<unsigned short*>(q)));
+  };
+  typedef short wg_s8 __attribute__((ext_vector_type(8)));
+
+  for (int it = 0; it < p.spw; ++it) {  // (body not re-indented)
+  const int strip = run * p.spw + it;
+  begin_strip(strip);
   // prologue: row pairs s0, s0+1 and dY(s0) in LDS; pair s0+2 and dY(s0+1) in registers
   if (s0 < s1) {
     load_rows(s0);
@@ -851,17 +872,6 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad16_kernel(Wgrad16P p) {
   }
   __syncthreads();
 
-  // transposing-read addressing of this lane: source lane s = lane & 15 -> pixel + (s >> 2), channel quad (s & 3) of the
-  // 16-channel group (lane >> 4) & 1 of the wave's 32-channel tile
-  const int s16 = lane & 15, g16 = (lane >> 4) & 1;
-  const int t_px = s16 >> 2, t_ch = g16 * 16 + (s16 & 3) * 4;
-  const unsigned short* a_lane = Ab + cit * (W16_SLOTS * W16_PW * 32) + t_ch;
-  const unsigned short* d_lane = Db + cot * (64 * 32) + t_ch;
-  auto tr4 = [](const unsigned short* q) -> wg_s4 {
-    return __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-        (__attribute__((address_space(3))) wg_s4*)(const_cast<unsigned short*>(q)));
-  };
-  typedef short wg_s8 __attribute__((ext_vector_type(8)));
   for (int s = s0; s < s1; ++s) {
     const int par = (s - s0) & 1;
     // stage the next pair / dY tile (other ring slots, other dY buffer), then fetch the ones after them
@@ -888,18 +898,23 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad16_kernel(Wgrad16P p) {
     __syncthreads();
   }
 
-  if (want_dysum) {  // 32 threads share a channel block: fixed-order sum through LDS (the K loop is done with it)
+  if (want_dysum) {  // 32 threads share a channel block: fixed-order sum through LDS (the strip's K loop is done with it)
     float* red = reinterpret_cast<float*>(wsm16);
 #pragma unroll
-    for (int j = 0; j < 8; ++j) red[tid * 8 + j] = dsum[j];
+    for (int j = 0; j < 8; ++j) {
+      red[tid * 8 + j] = dsum[j];
+      dsum[j] = 0.f;
+    }
     __syncthreads();
     if (tid < 64) {
       const int cb = tid >> 3, j = tid & 7;
       float t = 0.f;
       for (int k = 0; k < 32; ++k) t += red[(cb + 8 * k) * 8 + j];
-      p.dysum_ws[(size_t)blockIdx.y * p.cout + co0 + tid] = t;
+      p.dysum_ws[((size_t)strip * p.nrs + rs) * p.cout + co0 + tid] = t;  // (per strip: the sums are per image)
     }
+    __syncthreads();  // the next strip's prologue writes the same LDS
   }
+  }  // strips of this workgroup
   // epilogue: D[ci rows][co = l31]; partials to this run's slab [tap][ci][co]
   const int co = co0 + cot * 32 + l31;
   float* wsb = p.ws + (size_t)blockIdx.y * TAPS * p.cin * p.cout;
@@ -922,12 +937,17 @@ __global__ void wgrad16_dysum_reduce_kernel(const float* __restrict__ part, int 
   out[(size_t)n * out_stride + co] = t;
 }
 
-static void wgrad16_runs(int cin, int cout, int n, int hout, int wout, int* strips, int* rsplit) {
+static void wgrad16_runs(int cin, int cout, int n, int hout, int wout, int* strips, int* rsplit, int* spw = nullptr) {
   const int pairs = (cin / 64) * (cout / 64);
   *strips = n * (wout / 32);
   const int stages = hout / 2;
   const int want = std::max(1, cdiv(512, pairs));  // workgroups wanted per (ci, co) block pair (2 per CU in all)
   *rsplit = std::max(1, std::min(stages, cdiv(want, *strips)));
+  int per = 1;  // strips per workgroup: the largest divisor of `strips` that still leaves `want` workgroups per pair
+  if (*rsplit == 1)
+    for (int d = 1; d <= *strips / want; ++d)
+      if (*strips % d == 0) per = d;
+  if (spw) *spw = per;
 }
 
 static bool wgrad16_ok(const dsg_conv_wgrad_args* a, int hout, int wout) {
@@ -943,9 +963,9 @@ static size_t wgrad16_ws_bytes(int cin, int cout, int ksize, int n, int hout, in
     hout = hout * wout / 32;
     wout = 32;
   }
-  int strips, rsplit;
-  wgrad16_runs(cin, cout, n, hout, wout, &strips, &rsplit);
-  return (size_t)strips * rsplit * ((size_t)ksize * ksize * cin * cout + cout) * sizeof(float);  // + the dY-sum rows
+  int strips, rsplit, spw;
+  wgrad16_runs(cin, cout, n, hout, wout, &strips, &rsplit, &spw);
+  return ((size_t)(strips / spw) * rsplit * ksize * ksize * cin * cout + (size_t)strips * rsplit * cout) * sizeof(float);  // + the dY-sum rows
 }
 
 static int launch_wgrad16(const dsg_conv_wgrad_args* a, int hout, int wout, hipStream_t st) {
@@ -960,11 +980,12 @@ static int launch_wgrad16(const dsg_conv_wgrad_args* a, int hout, int wout, hipS
   p.dy = a->dy; p.dy_ctotal = a->dy_ctotal ? a->dy_ctotal : a->cout; p.dy_coff = a->dy_coff;
   p.ss = a->gn_scale_shift; p.silu = a->silu; p.ws = static_cast<float*>(a->workspace);
   p.tiles_x = wout / 32; p.stages = hout / 2; p.ci_blocks = p.cin / 64;
-  int strips, rsplit;
-  wgrad16_runs(p.cin, p.cout, p.n, hout, wout, &strips, &rsplit);
+  int strips, rsplit, spw;
+  wgrad16_runs(p.cin, p.cout, p.n, hout, wout, &strips, &rsplit, &spw);
   p.nrs = rsplit;
-  const int nslab = strips * rsplit;
-  const size_t need = (size_t)nslab * ((size_t)taps * p.cin * p.cout + p.cout) * sizeof(float);
+  p.spw = spw;
+  const int nslab = (strips / spw) * rsplit;
+  const size_t need = ((size_t)nslab * taps * p.cin * p.cout + (size_t)strips * rsplit * p.cout) * sizeof(float);
   if (p.ws == nullptr || a->workspace_bytes < need)
     return fail(DSG_ERR_WORKSPACE_TOO_SMALL, "dsg_conv2d_wgrad: workspace %zu bytes < required %zu", a->workspace_bytes, need);
   p.dysum_ws = a->dy_sums ? p.ws + (size_t)nslab * taps * p.cin * p.cout : nullptr;
