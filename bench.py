@@ -208,7 +208,7 @@ def mixed_leg(args, dtype="bf16"):
             peak=PEAK_HBM_GBS if bound == "hbm" else PEAK_F16_TFLOPS, unit="GB/s" if bound == "hbm" else "TFLOP/s",
             frac=max(t_mfma, t_hbm) / (dom["avg_ms"] * 1e-3), mfma_tflops=dom["tflops"], mfma_frac=dom["tflops"] / PEAK_F16_TFLOPS,
             alg_gbs=dom["alg_gbs"], hbm_frac=dom["alg_gbs"] / PEAK_HBM_GBS, avg_launch_ms=dom["avg_ms"],
-            launches=dom["launches"], **pmc_class_traffic(r"conv_h2_kernel<0, [24], 3, [02], 4, [12], 3, (64|128), 1>", "_bf16"),
+            launches=dom["launches"], **pmc_class_traffic(r"conv_h2_kernel<0, [24], 3, [02], 4, [12], 3, (64|128), 1[,>]", "_bf16"),
             note="mean over the 44 resnet convs of a step (three instantiations: 128-cout / 64-cout workgroups, 16- / 8-row "
                  "tiles): frac = max(alg FLOPs / 2.5 PF, alg bytes / 8 TB/s) / measured time")
     return rec
