@@ -97,7 +97,8 @@ def gpu_leg(args, rank, world):
     if not args.no_prof:
         names = {0: "conv3x3_s1_mfma_f32", 1: "conv3x3_upsample_mfma_f32", 2: "conv3x3_s2_mfma_f32",
                  3: "conv1x1_mfma_f32", 4: "conv_direct_valu", 6: "conv3x3_s1_mfma_f16x2split",
-                 7: "conv3x3_upsample_mfma_f16x2split", 8: "conv1x1_mfma_f16x2split"}
+                 7: "conv3x3_upsample_mfma_f16x2split", 8: "conv1x1_mfma_f16x2split",
+                 10: "conv3x3_s1_mfma_f16x2split_two_wg_per_cu"}
         for kid, nm in names.items():
             ms, fl, by, n = C.c_double(), C.c_double(), C.c_double(), C.c_int64()
             _lib.check(lib.dsg_prof_summary(kid, C.byref(ms), C.byref(fl), C.byref(by), C.byref(n)))
@@ -415,6 +416,14 @@ def main():
                             alg_flops_per_launch=dom["flops_per_launch"],
                             alg_gbs=dom["alg_gbs"], sampled_every_nth_step=PROF_EVERY,
                             time_share=dom["total_ms"] * 1e-3 * args.steps / len(range(0, args.steps, PROF_EVERY)) / dt)
+            ws = prof.get("conv3x3_s1_mfma_f16x2split_two_wg_per_cu")
+            if ws:  # the same convs at the 64- / 128-channel levels (cin <= 128): 8-row tiles, two workgroups per CU
+                roofline["second_kernel"] = dict(
+                    kernel="dsg::conv_h2_kernel<0, 2, 3, 2, 4, 2, 3, 64, 0, 1>", achieved=ws["tflops"], frac=ws["tflops"] / peak,
+                    avg_launch_ms=ws["avg_ms"], launches=ws["launches"], alg_flops_per_launch=ws["flops_per_launch"],
+                    alg_gbs=ws["alg_gbs"],
+                    time_share=ws["total_ms"] * 1e-3 * args.steps / len(range(0, args.steps, PROF_EVERY)) / dt,
+                    **pmc_traffic("dsg::conv_h2_kernel<0, 2, 3, 2, 4, 2, 3, 64, 0, 1>"))
         elif "conv3x3_s1_mfma_f32" in prof:
             dom = prof["conv3x3_s1_mfma_f32"]
             roofline = dict(bound="mfma", kernel="dsg::conv_mfma_kernel<3,1,0,2,*>", achieved=dom["tflops"],

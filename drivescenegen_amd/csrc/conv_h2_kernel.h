@@ -351,9 +351,14 @@ __global__ __launch_bounds__(64 * NW, OCC * NW / 4) void conv_h2_kernel(ConvH2P 
     }
 #pragma unroll
     for (int jp = 0; jp < 4; ++jp) {
-      float a, b;
-      pair_of(src, i, jp, a, b);
-      to_operand(a, b, sr[jp], w1[jp], w2[jp]);
+      if constexpr (S16 && ACT == 0) {  // 16-bit source used as it is (data-gradient convs): the word IS the operand
+        w1[jp] = src.q[i][jp];
+        w2[jp] = 0;
+      } else {
+        float a, b;
+        pair_of(src, i, jp, a, b);
+        to_operand(a, b, sr[jp], w1[jp], w2[jp]);
+      }
     }
     // (branch-free: a branch here would fence the instruction scheduler between staging and MFMAs)
     _Float16* xb = reinterpret_cast<_Float16*>(buf);
@@ -390,9 +395,14 @@ __global__ __launch_bounds__(64 * NW, OCC * NW / 4) void conv_h2_kernel(ConvH2P 
   auto stage_step = [&](int P, int qs, unsigned char* buf, bool stage, bool load, const char* spn, const float4& s4) {  // (loads: chunk qs + 1)
     const int i = P / 4, jp = P % 4;
     if (stage) {
-      float a, b;
-      pair_of(xr, i, jp, a, b);
-      to_operand(a, b, s4, w1s[i][jp], w2s[i][jp]);
+      if constexpr (S16 && ACT == 0) {
+        w1s[i][jp] = xr.q[i][jp];
+        w2s[i][jp] = 0;
+      } else {
+        float a, b;
+        pair_of(xr, i, jp, a, b);
+        to_operand(a, b, s4, w1s[i][jp], w2s[i][jp]);
+      }
       if (jp == 3) {
         _Float16* xb = reinterpret_cast<_Float16*>(buf);
         *reinterpret_cast<st_u32x4*>(xb + xoff[i]) = st_u32x4{w1s[i][0], w1s[i][1], w1s[i][2], w1s[i][3]};
@@ -632,9 +642,15 @@ __global__ __launch_bounds__(64 * NW, OCC * NW / 4) void conv_h2_kernel(ConvH2P 
       // instead of leaving it in one block as the scheduler would.
       if (KS == 3 && tap < TAPS - 1 && (STAGE || LOAD)) {
 #pragma unroll
+#ifndef DSG_H2_SGB
+#define DSG_H2_SGB 0
+#endif
         for (int m = 0; m < (NP == 2 ? 3 : 1) * MTN * NT; ++m) {
           __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);               // 1 MFMA
+          if (DSG_H2_SGB == 1 || DSG_H2_SGB == 3) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);  // (experiment) 1 DS read
           __builtin_amdgcn_sched_group_barrier(0x002, NP == 2 ? 2 : 5, 0);  // 2 VALU (a third of the MFMAs: 5)
+          if (DSG_H2_SGB == 2 || DSG_H2_SGB == 3) __builtin_amdgcn_sched_group_barrier(0x004, 1, 0);  // (experiment) 1 SALU
+          if (DSG_H2_SGB == 4) __builtin_amdgcn_sched_group_barrier(0x002, 1, 0);                      // (experiment) a third VALU
         }
       }
 #ifdef DSG_H2_TIMING
@@ -717,7 +733,14 @@ __global__ __launch_bounds__(64 * NW, OCC * NW / 4) void conv_h2_kernel(ConvH2P 
 #endif
   float* red = reinterpret_cast<float*>(smem_raw);  // [wave][sum | sumsq][cout 64] (the K loop is done with LDS)
   constexpr int RED_FLOATS = NW * (NT / 2) * 2 * BM;
-  float* red_lane = (l31 == 16) ? red + 4 * half : red + RED_FLOATS + 64 + lane;  // (+ crel etc. per value)
+  // Cross-lane sums of the statistics go through LDS, not DPP chains: a lane leaves its row-pair values in a
+  // wave-private [value][lane] table, then lane L adds up the 32 entries of table row L (and L + 64) in a fixed order.
+  // (The DPP version -- five dependent adds per value, 128 values per lane and slab -- was 3.3 of the epilogue's 8.2 us.)
+  constexpr int SV = 16 * (NT / 2) * 2;  // values per lane and slab: 16 channels x row pairs x (sum, sum of squares)
+  // (table row r = (value, half-wave) = 32 floats; its 16-byte chunks are stored at chunk ^ (r & 7), so that both the
+  // 4-byte writes of a half-wave and the 16-byte reads of eight neighbouring rows spread over all banks)
+  float* stab = red + RED_FLOATS + wave * (SV * 64);
+  const int stab_w = half * 32 + (l31 & 3);  // this lane's fixed part of a write address
   const int nvalid = min(BM, p.cout - m0);        // output channels of this tile that exist
   const size_t tile_off = ((size_t)n * p.cout + m0) * oplane * ESD;  // bytes
   const int range = nvalid * oplane * ESD;
@@ -851,18 +874,38 @@ __global__ __launch_bounds__(64 * NW, OCC * NW / 4) void conv_h2_kernel(ConvH2P 
         if (STATS) {  // GroupNorm statistics of the tensor just produced (the next layer's norm reads them)
 #pragma unroll
           for (int j = 0; j < 4; ++j) {
-            const int crel = mt * 32 + j + 8 * rg;
 #pragma unroll
             for (int pr = 0; pr < NT / 2; ++pr) {  // one partial per pair of rows: the same summation tree for any NT
               const float a = (NARROW && !lane_ok) ? 0.f : vv[j][2 * pr], b = (NARROW && !lane_ok) ? 0.f : vv[j][2 * pr + 1];
-              const float t1 = half_wave_sum(a + b), t2 = half_wave_sum(a * a + b * b);
-              // every lane stores -- lanes 16 / 48 to the real slot, the others to a per-lane dump area behind it:
-              // a predicated store here is a branch, and 128 branches fence the scheduler between the DPP chains
-              red_lane[((wave * (NT / 2) + pr) * 2 + 0) * BM + crel] = t1;
-              red_lane[((wave * (NT / 2) + pr) * 2 + 1) * BM + crel] = t2;
+              const int v = ((rg * 4 + j) * (NT / 2) + pr) * 2;
+              stab[stab_w + v * 64 + (((l31 >> 2) ^ ((2 * v + half) & 7)) << 2)] = a + b;
+              stab[stab_w + (v + 1) * 64 + (((l31 >> 2) ^ ((2 * v + 2 + half) & 7)) << 2)] = __builtin_fmaf(a, a, b * b);  // (explicit: every instantiation must round alike)
             }
           }
         }
+      }
+      if (STATS) {
+        // table row = (value, half-wave): 32 consecutive floats; same-wave LDS operations complete in order, so the
+        // rows are there when they are read
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int rr = 0; rr < (2 * SV + 63) / 64; ++rr) {
+          const int row = lane + 64 * rr;
+          if (2 * SV >= 64 * (rr + 1) || row < 2 * SV) {
+            const int v = row >> 1, hh = row & 1;
+            const float4* rp = reinterpret_cast<const float4*>(stab + row * 32);
+            float t = 0.f;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+              const float4 q4 = rp[k ^ (row & 7)];
+              t = (((t + q4.x) + q4.y) + q4.z) + q4.w;
+            }
+            const int which = v & 1, pr = (v >> 1) % (NT / 2), cj = (v >> 1) / (NT / 2);  // cj = rg * 4 + j
+            const int crel = mt * 32 + (cj & 3) + 8 * (cj >> 2);
+            red[((wave * (NT / 2) + pr) * 2 + which) * BM + crel + 4 * hh] = t;
+          }
+        }
+        __builtin_amdgcn_wave_barrier();
       }
       DSG_ET(2 + 2 * mt);
     }

@@ -49,6 +49,10 @@ static int h2_launch(dim3 grid, size_t lds, hipStream_t st, const ConvH2P& p) {
                                 160 * 1024));
     raised = true;
   }
+  // the epilogue's statistics tables live in the (by then free) K-loop buffers: [NW][row pairs][2][BM] partials + a
+  // [values][64 lanes] table per wave; the pointwise kernels' buffers are smaller than that
+  constexpr size_t STATS_LDS = ((size_t)NW * (NT / 2) * 2 * BM + (size_t)NW * (16 * (NT / 2) * 2) * 64) * sizeof(float);
+  if (p.stats != nullptr && lds < STATS_LDS) lds = STATS_LDS;
   hipLaunchKernelGGL(kern, grid, dim3(64 * NW), lds, st, p);
   return DSG_OK;
 }
@@ -100,16 +104,6 @@ int conv_h2_launch_t(const dsg_conv_args* a, int hout, int wout, hipStream_t st)
                      (a->gn_scale_shift ? (size_t)p.cin * 2 * sizeof(float) : 0);  // + the scale/shift table
   dim3 grid(p.tiles_x * p.tiles_y * p.n * (p.cout_pad / H2_BM) * (fold ? 4 : 1));
   const int lay = (a->src_layout ? 1 : 0) | (a->dst_layout ? 2 : 0);
-  int pi = -1;
-  if (prof_on()) {
-    const double px = (double)p.n * hout * wout * (fold ? 4 : 1);  // output pixels; FLOPs are the reference op's
-    const int taps = a->ksize * a->ksize;
-    const double cin_ref = a->c0 + a->c1;  // (stride 2: the kernel's 4 C x 4 taps are the reference op's C x 9)
-    const double es = (PREC && (lay & 1)) ? 2.0 : 4.0, ed = (PREC && (lay & 2)) ? 2.0 : 4.0, ew = PREC ? 2.0 : 4.0;
-    pi = prof_begin((PREC ? 20 : 0) + (s2 ? 2 : (a->ksize == 1 ? 8 : (a->upsample ? 7 : 6))), 2.0 * px * p.cout * cin_ref * taps,
-                    es * (double)p.n * cin_ref * p.hin * p.win + ew * cin_ref * taps * p.cout +
-                        ed * px * p.cout * (p.res ? 2.0 : 1.0), st);
-  }
   const int act = a->gn_scale_shift ? (a->silu ? 2 : 3) : 0;
   int rc = DSG_OK;
   // split-K (PREC 0, every tensor channel-blocked, plain / stride-2 3x3 and pointwise): the slices write fp32 partials
@@ -126,6 +120,20 @@ int conv_h2_launch_t(const dsg_conv_args* a, int hout, int wout, hipStream_t st)
     grid.y = slices;
   } else {
     p.split_stride = 0;
+  }
+  // shallow levels of the fp32-equivalent path: 64 couts x 8 rows, ONE weight slab, two workgroups per CU (see WS)
+  const bool ws2 = PREC == 0 && lay == 3 && g_h2.ws2 && !s2 && !fold && a->ksize == 3 && !a->upsample && p.cin <= 128 &&
+                   wout % H2_TW == 0 && slices == 1 &&
+                   (wout / H2_TW) * (hout / 8) * p.n * (p.cout_pad / H2_BM) >= 2 * H2_CUS;
+  int pi = -1;
+  if (prof_on()) {
+    const double px = (double)p.n * hout * wout * (fold ? 4 : 1);  // output pixels; FLOPs are the reference op's
+    const int taps = a->ksize * a->ksize;
+    const double cin_ref = a->c0 + a->c1;  // (stride 2: the kernel's 4 C x 4 taps are the reference op's C x 9)
+    const double es = (PREC && (lay & 1)) ? 2.0 : 4.0, ed = (PREC && (lay & 2)) ? 2.0 : 4.0, ew = PREC ? 2.0 : 4.0;
+    pi = prof_begin((PREC ? 20 : 0) + (s2 ? 2 : (a->ksize == 1 ? 8 : (a->upsample ? 7 : (ws2 ? 10 : 6)))), 2.0 * px * p.cout * cin_ref * taps,
+                    es * (double)p.n * cin_ref * p.hin * p.win + ew * cin_ref * taps * p.cout +
+                        ed * px * p.cout * (p.res ? 2.0 : 1.0), st);
   }
 #define DSG_H2_LAUNCH(GM, KS, ACT)                                                  \
   do {                                                                              \
@@ -177,8 +185,7 @@ int conv_h2_launch_t(const dsg_conv_args* a, int hout, int wout, hipStream_t st)
     q.tiles_y = hout / 8;
     if (act == 0) rc = h2_launch<0, 2, 3, 0, 4, 2, 3, 32, PREC>(g32, lds32, st, q);
     else rc = h2_launch<0, 2, 3, 2, 4, 2, 3, 32, PREC>(g32, lds32, st, q);
-  } else if (PREC == 0 && lay == 3 && g_h2.ws2 && p.cin <= 128 && wout % H2_TW == 0 && slices == 1 &&
-             (wout / H2_TW) * (hout / 8) * p.n * (p.cout_pad / H2_BM) >= 2 * H2_CUS) {
+  } else if (ws2 && !bm32) {
     // shallow levels: 64 couts x 8 rows, ONE weight slab (80 KB of LDS, half the register file): two workgroups per CU
     if constexpr (PREC == 0) {
       using GW = H2Geom<2, 3, 4, 9, 64, 2>;

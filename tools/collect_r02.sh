@@ -4,7 +4,7 @@
 cd "$GRAFT_REPO_ROOT" || exit 1
 export TMPDIR=/tmp
 tag=$1
-mkdir -p gpurun_out
+mkdir -p gpurun_out "$(dirname gpurun_out/${tag}_x)" "$(dirname /tmp/prof_${tag}_x)"
 # 1. the bench line as the driver runs it (extras and CPU baseline on)
 python bench.py > gpurun_out/${tag}_bench.json 2> gpurun_out/${tag}_bench.err
 # 2. rocprofv3 kernel-trace summary of the headline leg; per-launch HIP-event records
