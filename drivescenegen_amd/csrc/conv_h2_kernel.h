@@ -741,6 +741,11 @@ __global__ __launch_bounds__(64 * NW, OCC * NW / 4) void conv_h2_kernel(ConvH2P 
   // 4-byte writes of a half-wave and the 16-byte reads of eight neighbouring rows spread over all banks)
   float* stab = red + RED_FLOATS + wave * (SV * 64);
   const int stab_w = half * 32 + (l31 & 3);  // this lane's fixed part of a write address
+  // row r = 2 v + half, so (r & 7) = 2 (v & 3) | half: the swizzled chunk is ((l31 >> 2) ^ half) ^ 2 (v & 3) -- four
+  // per-lane values, not one per table value
+  int stab_sw[4];
+#pragma unroll
+  for (int c = 0; c < 4; ++c) stab_sw[c] = stab_w + (((((l31 >> 2) ^ half) ^ (2 * c)) & 7) << 2);
   const int nvalid = min(BM, p.cout - m0);        // output channels of this tile that exist
   const size_t tile_off = ((size_t)n * p.cout + m0) * oplane * ESD;  // bytes
   const int range = nvalid * oplane * ESD;
@@ -828,6 +833,11 @@ __global__ __launch_bounds__(64 * NW, OCC * NW / 4) void conv_h2_kernel(ConvH2P 
       DSG_ET(1 + 2 * mt);
 #pragma unroll
       for (int rg = 0; rg < 4; ++rg) {  // a register group = four consecutive output channels
+        // One group at a time: left alone, the scheduler reads all 256 accumulators out early, spills what no longer
+        // fits -- and a spill reload issued after this tile's stores waits for every one of them (vmcnt retires in order:
+        // a full write drain per reload).  +2.2% on the whole denoising step.  (The 16-bit kernels spill MORE with the
+        // fence -- 12 -> 140 bytes at two workgroups per CU -- and lose 0.5%: fp32-equivalent kernels only.)
+        if constexpr (PREC == 0) __builtin_amdgcn_sched_barrier(0);
         float vv[4][NT];
 #pragma unroll
         for (int j = 0; j < 4; ++j)
@@ -878,8 +888,8 @@ __global__ __launch_bounds__(64 * NW, OCC * NW / 4) void conv_h2_kernel(ConvH2P 
             for (int pr = 0; pr < NT / 2; ++pr) {  // one partial per pair of rows: the same summation tree for any NT
               const float a = (NARROW && !lane_ok) ? 0.f : vv[j][2 * pr], b = (NARROW && !lane_ok) ? 0.f : vv[j][2 * pr + 1];
               const int v = ((rg * 4 + j) * (NT / 2) + pr) * 2;
-              stab[stab_w + v * 64 + (((l31 >> 2) ^ ((2 * v + half) & 7)) << 2)] = a + b;
-              stab[stab_w + (v + 1) * 64 + (((l31 >> 2) ^ ((2 * v + 2 + half) & 7)) << 2)] = __builtin_fmaf(a, a, b * b);  // (explicit: every instantiation must round alike)
+              stab[stab_sw[v & 3] + v * 64] = a + b;
+              stab[stab_sw[(v + 1) & 3] + (v + 1) * 64] = __builtin_fmaf(a, a, b * b);  // (explicit: every instantiation must round alike)
             }
           }
         }

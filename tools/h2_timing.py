@@ -47,3 +47,8 @@ for name, c, h, B in (("res512@32", 512, 32, 16), ("res256@64", 256, 64, 16), ("
     d = lambda a, b: (er[:, b] - er[:, a]).mean() / 100
     print("   epilogue us: slab0 loads land %.2f  slab0 math+stores %.2f  slab1 loads land %.2f  slab1 math+stores %.2f  stats tail %.2f" % (
         d(0, 1), d(1, 2), d(2, 3), d(3, 4), d(4, 5)))
+    if os.environ.get("PERS") == "1":   # persistent variant: the tap slots carry (loop end, tile end) of the first four tiles
+        pt = (recs[:, 17:25] - recs[:, 0:1]) / 100.0
+        print("   persistent: entry->loop %.2f us; tile k (K loop done, tile done) since entry: " % ((recs[:, 1] - recs[:, 0]).mean() / 100)
+              + "  ".join(f"({pt[:, 2 * i].mean():.1f}, {pt[:, 2 * i + 1].mean():.1f})" for i in range(4))
+              + f"   workgroup total {((recs[:, 16] - recs[:, 0]) / 100).mean():.1f} us")
