@@ -468,6 +468,8 @@ int dsg_prof_dump(const char* csv_path);
  *      64-cout x 16-row grid has at least n workgroups (1 = 512); bit-identical results, measured slower
  *  18  16-bit modes: 3x3 convs with cout % 128 == 0 as 128-cout workgroups while the grid fills the chip: [1] | 0
  *  19  split-K for grids of at most half the CUs (needs dsg_conv_args.splitk_ws): [1] | 0
+ *  20  fp32-equivalent 3x3 convs with cin <= 128 on channel-blocked tensors: 8-row tiles with ONE weight slab in LDS,
+ *      two workgroups per CU (grids of at least 512 workgroups): [1] | 0
  *  15  stride-2 convs of channel-blocked tensors on the split path: [1] | 0 = the f32 MFMA kernel
  *  14  attention with head_dim 8 on the matrix cores (fp16x2 split): [1] | 0 = the VALU kernel */
 int dsg_set_tuning(int32_t key, int32_t value);
