@@ -541,3 +541,38 @@ def test_conv_split_path_random_shapes(case):
     if st is not None:  # whenever the kernel offers statistics they must be those of the tensor it wrote
         ref = torch.stack([got.double().sum(dim=(2, 3)), (got.double() ** 2).sum(dim=(2, 3))], dim=-1).cpu()
         assert torch.allclose(st.sum(dim=2).cpu(), ref, rtol=3e-6, atol=1e-4)
+
+
+@pytest.mark.parametrize("cin,cout,res,gn", [(64, 64, True, True), (128, 64, False, True), (128, 128, True, True), (64, 128, False, False)])
+def test_conv_two_workgroups_per_cu_is_bit_identical(cin, cout, res, gn):
+    """The one-weight-slab kernel (8-row tiles, two workgroups per CU: dsg_set_tuning key 20) serves the cin <= 128 convs of
+    grids with >= 512 workgroups.  Same K order, same summation tree of the statistics: its results and its per-tile
+    GroupNorm partials are BITWISE those of the 16-row kernel."""
+    from drivescenegen_amd import _lib
+    lib = _lib.load()
+    n, h, w = 4, 128, 128   # 4 x 16 x 4 x (cout / 64) 8-row tiles >= 512 for cout 128; cout 64: n = 8
+    if cout == 64:
+        n = 8
+    d = lambda t: t.to(DEV)
+    x = ops.to_blocked(d(_t(21, (n, cin, h, w))))
+    wt = d(_t(22, (cout, cin, 3, 3), 0.05))
+    bias = d(_t(23, (cout,)))
+    r = ops.to_blocked(d(_t(24, (n, cout, h, w)))) if res else None
+    ss = d(_t(25, (n, cin, 2))) if gn else None
+    wr, wh = ops.relayout_conv_weight(wt), ops.relayout_conv_weight_h2(wt)
+    outs = []
+    try:
+        for on in (0, 1):
+            _lib.check(lib.dsg_set_tuning(20, on))
+            y, st = ops.conv2d_fused(x, wr, bias, residual=r, gn_scale_shift=ss, silu=gn, weight_h2=wh, want_stats=True,
+                                     src_blocked=True, dst_blocked=True)
+            outs.append((y.clone(), st.clone()))
+    finally:
+        lib.dsg_set_tuning(20, 1)
+    assert torch.equal(outs[0][0], outs[1][0])
+    assert torch.equal(outs[0][1], outs[1][1])
+    ref = F.conv2d(F.silu(ops.from_blocked(x).cpu().double() * ss.cpu().double()[:, :, 0, None, None] + ss.cpu().double()[:, :, 1, None, None])
+                   if gn else ops.from_blocked(x).cpu().double(), wt.cpu().double(), bias.cpu().double(), padding=1)
+    if res:
+        ref = ref + ops.from_blocked(r).cpu().double()
+    assert rel_l2(ops.from_blocked(outs[1][0]).cpu(), ref) < 2e-6
