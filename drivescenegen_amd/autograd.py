@@ -15,10 +15,13 @@ gather, exactly as they are folded into the forward gather.
 from __future__ import annotations
 
 import math
+import os
 
 import torch
 
 from . import _lib, ops
+
+_EAGER_RELAYOUT = os.environ.get("DSG_EAGER_RELAYOUT") == "1"  # A/B switch of TrainState.lazy_w (tools/train_bench.py)
 
 
 SLABS = {}  # storage data_ptr -> (flat gradient slab, number of parameter slices): lets the optimizer / clipper
@@ -44,6 +47,7 @@ class TrainState:
         self.params = dict(self.items)
         self.wf, self.wd, self.versions = {}, {}, {}
         self.wh, self.whd = {}, {}  # fp16x2-split copies (forward / data-gradient) of the eligible 3x3 weights
+        self.needs_w = {}           # (name, "wf" | "wd") -> does the mixed-precision tape's call read the fp32 engine layout?
         self.freqs = ops.sinusoid_freqs(model.config.block_out_channels[0]).to(dev)
         self.grad_ready_hooks = []  # callables(name) fired when a parameter's gradient is final (DDP buckets)
         self.post_backward = []     # callables() run when the backward walk is complete, before the internal loss scale
@@ -97,6 +101,41 @@ class TrainState:
             if cout % 16 == 0 and cin % 64 == 0:   # its data gradient (K = cout, N = cin)
                 self.whd[name] = ops.relayout_conv_weight_h2_dgrad(p, out=self.whd.get(name))
         return self.wf[name], self.wd[name]
+
+    def wf_of(self, name):
+        """fp32 engine layout of a conv weight for the forward kernels that read it (conv_in, conv_out, narrow maps)."""
+        if self._fresh((name, "wf")) or name not in self.wf:
+            self.wf[name] = ops.relayout_conv_weight(self.params[name].detach(), out=self.wf.get(name))
+        return self.wf[name]
+
+    def wd_of(self, name):
+        """... and its data-gradient form."""
+        if self._fresh((name, "wd")) or name not in self.wd:
+            p = self.params[name].detach()
+            if name not in self.wd:
+                k = p.shape[2] if p.dim() == 4 else 1
+                self.wd[name] = torch.zeros((p.shape[0], k * k, ops._pad32(p.shape[1]) + 64), dtype=torch.float32, device=p.device)
+            ops.relayout_conv_weight_dgrad(p, out=self.wd[name])
+        return self.wd[name]
+
+    def lazy_w(self, name, which, call):
+        """call(w): w = the fp32 engine layout (`which`: "wf" | "wd") only if the library's kernels for this call read it.
+        Most convs of the mixed-precision tape run on their 16-bit operand images alone; re-laying out all 70 weights twice
+        per step was 1.5 ms of launches.  The first call passes None; the library refuses it BEFORE launching anything when
+        the call does need the layout, and the answer is remembered."""
+        getter = self.wf_of if which == "wf" else self.wd_of
+        need = self.needs_w.get((name, which))
+        if need or _EAGER_RELAYOUT:
+            return call(getter(name))
+        try:
+            out = call(None)
+        except _lib.DsgError as e:
+            if "weight is NULL" not in str(e):
+                raise
+            self.needs_w[(name, which)] = True
+            return call(getter(name))
+        self.needs_w[(name, which)] = False
+        return out
 
     def qkv_w(self, prefix):
         """Fused q/k/v projection: forward [C][1][3C], data-gradient [3C][1][C(+pad)], bias [3C]."""
@@ -555,7 +594,6 @@ def _forward16(model, st: TrainState, tape: _Tape, sample, timesteps, dt):
 
     def conv(x0, wname, x1=None, gn=None, silu=False, k=3, stride=1, ups=False, toff=None, res=None, need_dx=True,
              feeds_norm=False, dst_blocked=True):
-        wf, _ = st.conv_w(wname + ".weight", split=False)
         bias = P[wname + ".bias"].detach()
         cout = bias.numel()
         src_blocked = x0.dim() == 5
@@ -572,10 +610,10 @@ def _forward16(model, st: TrainState, tape: _Tape, sample, timesteps, dt):
             else:
                 kw["weight_h2"] = packs.get(wname + ".weight", ops.PACK_FWD)
                 kw["weight_h2_stride"] = _pad64(cout)
-        y = ops.conv2d_fused(x0, wf, bias, src1=x1, ksize=k, stride=stride, upsample=ups, gn_scale_shift=ss, silu=silu,
-                             temb=None if toff is None else tproj[:, toff:], temb_stride=tproj.stride(0), residual=res,
-                             cout=cout, want_stats=feeds_norm, src_blocked=src_blocked, dst_blocked=dst_blocked,
-                             compute_dtype=dt, **kw)
+        y = st.lazy_w(wname + ".weight", "wf", lambda wf: ops.conv2d_fused(
+            x0, wf, bias, src1=x1, ksize=k, stride=stride, upsample=ups, gn_scale_shift=ss, silu=silu,
+            temb=None if toff is None else tproj[:, toff:], temb_stride=tproj.stride(0), residual=res,
+            cout=cout, want_stats=feeds_norm, src_blocked=src_blocked, dst_blocked=dst_blocked, compute_dtype=dt, **kw))
         if feeds_norm:
             y, ystats = y
             if ystats is not None:
@@ -679,7 +717,7 @@ def _backward16(model, st: TrainState, tape: _Tape, dout):
 
     def dgrad(dy, wname, k, cout, stride=1, residual=None, col0=0, ncols=None, dst_blocked=True):
         """dX = conv(dY, W^T flipped) for columns [col0, col0 + ncols) of the conv's input channels; + residual."""
-        _, wd = st.conv_w(wname, split=False)
+        wd_stride = ops._pad32(cout) + 64   # row length of the fp32 data-gradient layout (st.wd_of)
         ncols = ncols or cout
         full = col0 == 0 and ncols == cout
         src_blocked = blocked(dy)
@@ -688,20 +726,23 @@ def _backward16(model, st: TrainState, tape: _Tape, dout):
         if stride == 2:   # the adjoint of the space-to-depth conv: four 2x2 phase convs of the low-resolution dY
             ok = use16 and full and src_blocked and dst_blocked and dy.shape[3] % 32 == 0 and dy.shape[2] % 8 == 0
             if ok:
-                return ops.conv2d_fused(dy, wd, ksize=3, upsample=True, cout=cout, residual=residual, src_blocked=True,
-                                        dst_blocked=True, compute_dtype=dt, weight_h2_fold=packs.get(wname, ops.PACK_DGRAD_S2))
-            g = ops.conv2d_fused(f32(dy), wd, ksize=3, upsample=2, cout=cout, residual=None if residual is None else f32(residual))
+                return st.lazy_w(wname, "wd", lambda wd: ops.conv2d_fused(
+                    dy, wd, ksize=3, upsample=True, cout=cout, residual=residual, src_blocked=True, dst_blocked=True,
+                    compute_dtype=dt, weight_h2_fold=packs.get(wname, ops.PACK_DGRAD_S2)))
+            g = ops.conv2d_fused(f32(dy), st.wd_of(wname), ksize=3, upsample=2, cout=cout,
+                                 residual=None if residual is None else f32(residual))
             return ops.to_blocked(g, dt)
         if use16:
-            return ops.conv2d_fused(dy, wd if full else wd[:, :, col0:], ksize=k, cout=ncols, residual=residual,
-                                    wstride=None if full else wd.shape[-1], src_blocked=src_blocked, dst_blocked=dst_blocked,
-                                    compute_dtype=dt, weight_h2=packs.get(wname, ops.PACK_DGRAD), weight_h2_col=col0,
-                                    weight_h2_stride=_pad64(cout))
+            return st.lazy_w(wname, "wd", lambda wd: ops.conv2d_fused(
+                dy, wd if (full or wd is None) else wd[:, :, col0:], ksize=k, cout=ncols, residual=residual,
+                wstride=None if full else wd_stride, src_blocked=src_blocked, dst_blocked=dst_blocked, compute_dtype=dt,
+                weight_h2=packs.get(wname, ops.PACK_DGRAD), weight_h2_col=col0, weight_h2_stride=_pad64(cout)))
         # no 16-bit kernel for this shape (conv_out's 8-channel dY, narrow channel windows): the fp32 kernels
+        wd = st.wd_of(wname)
         if not src_blocked and dst_blocked and full and k == 3:   # fp32 [N,C,H,W] dY -> 16-bit blocked dX directly
             return ops.conv2d_fused(dy, wd, ksize=k, cout=cout, residual=residual, dst_blocked=True, compute_dtype=dt)
         g = ops.conv2d_fused(f32(dy), wd if full else wd[:, :, col0:], ksize=k, cout=ncols,
-                             residual=None if residual is None else f32(residual), wstride=None if full else wd.shape[-1])
+                             residual=None if residual is None else f32(residual), wstride=None if full else wd_stride)
         return ops.to_blocked(g, dt) if dst_blocked else g
 
     for rec in reversed(tape.recs):

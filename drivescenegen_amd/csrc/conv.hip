@@ -684,7 +684,7 @@ static int launch_direct(const ConvP& p, int ks, int stride, int gm, hipStream_t
 
 int conv2d_fwd_impl(const dsg_conv_args* a, hipStream_t st, int force_direct) {
   DSG_CHECK_ARG(a != nullptr, "dsg_conv2d_fwd: args is NULL");
-  DSG_CHECK_ARG(a->src0 && a->weight && a->dst, "dsg_conv2d_fwd: src0/weight/dst must be non-NULL");
+  DSG_CHECK_ARG(a->src0 && a->dst, "dsg_conv2d_fwd: src0/dst must be non-NULL");
   DSG_CHECK_ARG(a->c0 > 0 && a->c1 >= 0 && a->n > 0 && a->hin > 0 && a->win > 0 && a->cout > 0,
                 "dsg_conv2d_fwd: non-positive dimension");
   DSG_CHECK_ARG((a->c1 == 0) == (a->src1 == nullptr), "dsg_conv2d_fwd: src1/c1 mismatch");
@@ -725,6 +725,10 @@ int conv2d_fwd_impl(const dsg_conv_args* a, hipStream_t st, int force_direct) {
   DSG_CHECK_ARG(!(p.pool && ((p.hout | p.wout) & 1)), "dsg_conv2d_fwd: pool2 needs even output dims");
 
   if (!force_direct && conv_h2_eligible(a, p.hout, p.wout)) return conv_h2_launch(a, p.hout, p.wout, st);
+  // (`weight`, the fp32 engine layout, may be NULL for a call the operand-image kernels serve: a training step re-lays
+  // out every weight it passes here, and most calls never read it)
+  DSG_CHECK_ARG(a->weight != nullptr,
+                "dsg_conv2d_fwd: weight is NULL and this call is not served by the weight_h2* kernels (needs the fp32 engine layout)");
   DSG_CHECK_ARG(a->stats_out == nullptr,
                 "dsg_conv2d_fwd: stats_out given but this call is not served by the kernel that produces them "
                 "(dsg_conv2d_stats_tiles reports 0)");

@@ -158,8 +158,13 @@ def conv2d_fused(src0, weight_r, bias=None, src1=None, ksize=3, stride=1, upsamp
     else:
         n, c0, hin, win = src0.shape
         c1 = src1.shape[1] if src1 is not None else 0
-    wptr = weight_r.data_ptr() if wstride else _lib.ptr(weight_r)  # a column window of a wider matrix is allowed
-    wstride = wstride or weight_r.shape[-1]
+    if weight_r is None:  # allowed when the weight_h2* kernels serve the call (the library says so if they do not)
+        if not cout:
+            raise RuntimeError("conv2d_fused: cout is required when weight_r is None")
+        wptr, wstride = None, wstride or cout
+    else:
+        wptr = weight_r.data_ptr() if wstride else _lib.ptr(weight_r)  # a column window of a wider matrix is allowed
+        wstride = wstride or weight_r.shape[-1]
     cout = cout or wstride
     hc, wc = (2 * hin, 2 * win) if upsample else (hin, win)
     pad = ksize // 2
