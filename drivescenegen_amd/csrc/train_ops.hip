@@ -22,8 +22,10 @@ __device__ __forceinline__ double wave_sum_d(double v) {
   return v;
 }
 
+// d/du (u * sigmoid(u)); hardware exp / reciprocal (1 ulp each: the gradients' tolerances are 1e-4 and up) -- the IEEE
+// division and the full-range expf were a third of the GroupNorm backward's instructions
 __device__ __forceinline__ float dsilu(float u) {
-  const float s = 1.0f / (1.0f + expf(-u));
+  const float s = __builtin_amdgcn_rcpf(1.0f + __expf(-u));
   return s * (1.0f + u * (1.0f - s));
 }
 
@@ -446,6 +448,15 @@ __global__ __launch_bounds__(256) void sumpool2x2_kernel(const float* __restrict
 // 2 fp16; include/dsg.h dsg_dtype).  A thread owns one pixel's 8 channels = one 16-byte access per tensor; all
 // arithmetic in fp32, sums in fp64 across threads, results rounded once.
 // ---------------------------------------------------------------------------------------------------------------
+template <int DT>
+__device__ __forceinline__ void unpack8t(const uint4& q, float (&v)[8]) {
+  v[0] = lo16<DT>(q.x); v[1] = hi16<DT>(q.x); v[2] = lo16<DT>(q.y); v[3] = hi16<DT>(q.y);
+  v[4] = lo16<DT>(q.z); v[5] = hi16<DT>(q.z); v[6] = lo16<DT>(q.w); v[7] = hi16<DT>(q.w);
+}
+template <int DT>
+__device__ __forceinline__ uint4 pack8t(const float (&v)[8]) {
+  return make_uint4(pack2<DT>(v[0], v[1]), pack2<DT>(v[2], v[3]), pack2<DT>(v[4], v[5]), pack2<DT>(v[6], v[7]));
+}
 __device__ __forceinline__ void unpack8(const uint4& q, int dt, float (&v)[8]) {
   v[0] = word_lo(q.x, dt); v[1] = word_hi(q.x, dt); v[2] = word_lo(q.y, dt); v[3] = word_hi(q.y, dt);
   v[4] = word_lo(q.z, dt); v[5] = word_hi(q.z, dt); v[6] = word_lo(q.w, dt); v[7] = word_hi(q.w, dt);
@@ -473,10 +484,12 @@ __device__ __forceinline__ double block_sum16(const float (&a)[8], const float (
 }
 
 // grid = ((c0 + c1) / 8, n, splits): partial[n][c][split] = (sum du, sum du * xhat) over the split's run of pixels
+// (two pixels per thread and iteration, all four loads issued first: one 16-byte load pair per round trip ran at 2.8 TB/s)
+template <int DT>
 __global__ __launch_bounds__(256) void gn_bwd_stats_blk_kernel(const void* __restrict__ src0, int c0,
                                                                const void* __restrict__ src1, int c1,
                                                                const void* __restrict__ dy, const float* __restrict__ ss,
-                                                               const float* __restrict__ mr, int silu, int hw_total, int dt,
+                                                               const float* __restrict__ mr, int silu, int hw_total,
                                                                double* __restrict__ part) {
   const int cb = blockIdx.x, n = blockIdx.y, sp = blockIdx.z, splits = gridDim.z, ct = c0 + c1;
   const int hw = hw_total / splits;
@@ -493,17 +506,24 @@ __global__ __launch_bounds__(256) void gn_bwd_stats_blk_kernel(const void* __res
     sc[j] = ss[k0 + 2 * j]; sh[j] = ss[k0 + 2 * j + 1]; mean[j] = mr[k0 + 2 * j]; rstd[j] = mr[k0 + 2 * j + 1];
     a[j] = b[j] = 0.f;
   }
-  for (int i = threadIdx.x; i < hw; i += 256) {
+  auto accum = [&](const uint4& xq, const uint4& dq) {
     float x[8], du[8];
-    unpack8(xp[i], dt, x);
-    unpack8(dp[i], dt, du);
+    unpack8t<DT>(xq, x);
+    unpack8t<DT>(dq, du);
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
       if (silu) du[j] *= dsilu(x[j] * sc[j] + sh[j]);
       a[j] += du[j];
       b[j] += du[j] * ((x[j] - mean[j]) * rstd[j]);
     }
+  };
+  int i = threadIdx.x;
+  for (; i + 256 < hw; i += 512) {  // (same per-thread order of additions as one pixel per iteration)
+    const uint4 x0 = xp[i], d0 = dp[i], x1 = xp[i + 256], d1 = dp[i + 256];
+    accum(x0, d0);
+    accum(x1, d1);
   }
+  if (i < hw) accum(xp[i], dp[i]);
   const double r = block_sum16(a, b);
   if (threadIdx.x < 16)
     part[(((size_t)n * ct + cb * 8 + (threadIdx.x >> 1)) * splits + sp) * 2 + (threadIdx.x & 1)] = r;
@@ -520,36 +540,57 @@ __global__ void sum_splits_kernel(const double* __restrict__ part, int64_t count
   out[i] = s;
 }
 
-// grid = (ceil(hw / 256), (c0 + c1) / 8, n): dx = k0 * du - k1 - xhat * k2 (+ addend), one pixel x 8 channels per thread
+// grid = (ceil(hw / 1024), (c0 + c1) / 8, n): dx = k0 * du - k1 - xhat * k2 (+ addend); a thread owns four pixels x 8
+// channels (256 apart: coalesced), every load issued before the first use; the per-channel constants are block-uniform
+template <int DT>
 __global__ __launch_bounds__(256) void gn_bwd_apply_blk_kernel(const void* __restrict__ src0, int c0,
                                                                const void* __restrict__ src1, int c1,
                                                                const void* __restrict__ dy, const float* __restrict__ ss,
                                                                const float* __restrict__ mr, const float* __restrict__ coef,
-                                                               int silu, int hw, int dt, const void* __restrict__ add0,
+                                                               int silu, int hw, const void* __restrict__ add0,
                                                                const void* __restrict__ add1, void* __restrict__ dx0,
                                                                void* __restrict__ dx1) {
+  constexpr int PX = 4;
   const int cb = blockIdx.y, n = blockIdx.z, ct = c0 + c1;
-  const int i = blockIdx.x * 256 + threadIdx.x;
-  if (i >= hw) return;
+  const int i0 = blockIdx.x * (256 * PX) + threadIdx.x;
   const bool first = cb * 8 < c0;
-  const size_t xo = (first ? ((size_t)n * c0 + cb * 8) : ((size_t)n * c1 + (cb * 8 - c0))) * hw + (size_t)i * 8;  // elements
-  const unsigned short* xs = static_cast<const unsigned short*>(first ? src0 : src1);
+  const size_t xbase = (first ? ((size_t)n * c0 + cb * 8) : ((size_t)n * c1 + (cb * 8 - c0))) * hw;  // elements
+  const unsigned short* xs = static_cast<const unsigned short*>(first ? src0 : src1) + xbase;
   const unsigned short* as = static_cast<const unsigned short*>(first ? add0 : add1);
-  unsigned short* ds = static_cast<unsigned short*>(first ? dx0 : dx1);
+  unsigned short* ds = static_cast<unsigned short*>(first ? dx0 : dx1) + xbase;
   const size_t k = (size_t)n * ct + cb * 8;
-  float x[8], du[8], ad[8], v[8];
-  unpack8(*reinterpret_cast<const uint4*>(xs + xo), dt, x);
-  unpack8(*reinterpret_cast<const uint4*>(static_cast<const unsigned short*>(dy) + k * hw + (size_t)i * 8), dt, du);
-  if (as) unpack8(*reinterpret_cast<const uint4*>(as + xo), dt, ad);
+  const unsigned short* dys = static_cast<const unsigned short*>(dy) + k * hw;
+  float sc[8], sh[8], mean[8], rstd[8], q0[8], q1[8], q2[8];
 #pragma unroll
   for (int j = 0; j < 8; ++j) {
     const size_t kj = k + j;
-    float d = du[j];
-    if (silu) d *= dsilu(x[j] * ss[2 * kj] + ss[2 * kj + 1]);
-    v[j] = coef[3 * kj] * d - coef[3 * kj + 1] - ((x[j] - mr[2 * kj]) * mr[2 * kj + 1]) * coef[3 * kj + 2];
-    if (as) v[j] += ad[j];
+    sc[j] = ss[2 * kj]; sh[j] = ss[2 * kj + 1]; mean[j] = mr[2 * kj]; rstd[j] = mr[2 * kj + 1];
+    q0[j] = coef[3 * kj]; q1[j] = coef[3 * kj + 1]; q2[j] = coef[3 * kj + 2];
   }
-  *reinterpret_cast<uint4*>(ds + xo) = pack8(v, dt);
+  uint4 xq[PX], dq[PX], aq[PX];
+#pragma unroll
+  for (int u = 0; u < PX; ++u) {
+    const int i = min(i0 + 256 * u, hw - 1);  // (clamped: the tail's extra loads are not stored)
+    xq[u] = *reinterpret_cast<const uint4*>(xs + (size_t)i * 8);
+    dq[u] = *reinterpret_cast<const uint4*>(dys + (size_t)i * 8);
+    if (as) aq[u] = *reinterpret_cast<const uint4*>(as + xbase + (size_t)i * 8);
+  }
+#pragma unroll
+  for (int u = 0; u < PX; ++u) {
+    float x[8], du[8], ad[8], v[8];
+    unpack8t<DT>(xq[u], x);
+    unpack8t<DT>(dq[u], du);
+    if (as) unpack8t<DT>(aq[u], ad);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      float d = du[j];
+      if (silu) d *= dsilu(x[j] * sc[j] + sh[j]);
+      v[j] = q0[j] * d - q1[j] - ((x[j] - mean[j]) * rstd[j]) * q2[j];
+      if (as) v[j] += ad[j];
+    }
+    const int i = i0 + 256 * u;
+    if (i < hw) *reinterpret_cast<uint4*>(ds + (size_t)i * 8) = pack8t<DT>(v);
+  }
 }
 
 // grid = (c / 8, n): out[n][c] = sum over hw of a channel-blocked 16-bit tensor
@@ -643,8 +684,12 @@ DSG_API int dsg_gn_bwd_blocked(const void* src0, int32_t c0, const void* src1, i
   const int splits = dsg_gn_bwd_blocked_splits(hw);
   // ws_s12: [N][C][2] sums followed by the [N][C][splits][2] partials
   double* part = ws_s12 + (size_t)n * c * 2;
-  hipLaunchKernelGGL(gn_bwd_stats_blk_kernel, dim3(c / 8, n, splits), dim3(256), 0, st, src0, c0, src1, c1, dy, scale_shift,
-                     mean_rstd, silu, hw, dtype, part);
+  if (dtype == DSG_BF16)
+    hipLaunchKernelGGL(gn_bwd_stats_blk_kernel<1>, dim3(c / 8, n, splits), dim3(256), 0, st, src0, c0, src1, c1, dy, scale_shift,
+                       mean_rstd, silu, hw, part);
+  else
+    hipLaunchKernelGGL(gn_bwd_stats_blk_kernel<2>, dim3(c / 8, n, splits), dim3(256), 0, st, src0, c0, src1, c1, dy, scale_shift,
+                       mean_rstd, silu, hw, part);
   DSG_LAUNCH_CHECK();
   hipLaunchKernelGGL(sum_splits_kernel, dim3((unsigned)cdiv64((int64_t)n * c * 2, 256)), dim3(256), 0, st, part,
                      (int64_t)n * c * 2, splits, ws_s12);
@@ -652,8 +697,12 @@ DSG_API int dsg_gn_bwd_blocked(const void* src0, int32_t c0, const void* src1, i
   hipLaunchKernelGGL(gn_bwd_finalize_kernel, dim3(cdiv(n * c, 256)), dim3(256), 0, st, ws_s12, gamma, mean_rstd, n, c, groups,
                      hw, ws_coef, dgamma, dbeta);
   DSG_LAUNCH_CHECK();
-  hipLaunchKernelGGL(gn_bwd_apply_blk_kernel, dim3(cdiv(hw, 256), c / 8, n), dim3(256), 0, st, src0, c0, src1, c1, dy,
-                     scale_shift, mean_rstd, ws_coef, silu, hw, dtype, add0, add1, dx0, dx1);
+  if (dtype == DSG_BF16)
+    hipLaunchKernelGGL(gn_bwd_apply_blk_kernel<1>, dim3(cdiv(hw, 1024), c / 8, n), dim3(256), 0, st, src0, c0, src1, c1, dy,
+                       scale_shift, mean_rstd, ws_coef, silu, hw, add0, add1, dx0, dx1);
+  else
+    hipLaunchKernelGGL(gn_bwd_apply_blk_kernel<2>, dim3(cdiv(hw, 1024), c / 8, n), dim3(256), 0, st, src0, c0, src1, c1, dy,
+                       scale_shift, mean_rstd, ws_coef, silu, hw, add0, add1, dx0, dx1);
   DSG_LAUNCH_CHECK();
   return DSG_OK;
 }
