@@ -783,8 +783,12 @@ __global__ __launch_bounds__(64 * NW, OCC * NW / 4) void conv_h2_kernel(ConvH2P 
 #define DSG_ET(i)
 #endif
   DSG_ET(0);
-  auto epilogue = [&](auto stats_tag, auto narrow_tag) {
-    constexpr bool STATS = decltype(stats_tag)::value, NARROW = decltype(narrow_tag)::value;
+  // ONE copy of the epilogue, the statistics under a (uniform) run-time branch and the narrow-map mask always applied:
+  // with four compile-time variants behind a four-way branch the compiler hoisted their common head -- the read-out of
+  // half the accumulators -- above the branch, spilled 32 of them there and reloaded them in every variant behind the
+  // first slab's stores.
+  auto epilogue = [&](const bool STATS) {
+    constexpr bool NARROW = true;
 #pragma unroll
     for (int mt = 0; mt < MTN; ++mt) {
       float rv[16][NT], addv[16];
@@ -920,13 +924,7 @@ __global__ __launch_bounds__(64 * NW, OCC * NW / 4) void conv_h2_kernel(ConvH2P 
       DSG_ET(2 + 2 * mt);
     }
   };
-  if (p.wout < H2_TW) {
-    if (want_stats) epilogue(T{}, T{});
-    else epilogue(F{}, T{});
-  } else {
-    if (want_stats) epilogue(T{}, F{});
-    else epilogue(F{}, F{});
-  }
+  epilogue(want_stats);
   if (want_stats) {
     // statistics tiles are 8 rows x 32 columns (4 row pairs, summed in row order in fp64) whatever NT is, so the
     // values -- and everything downstream of the norm -- do not depend on the launch geometry
