@@ -837,11 +837,6 @@ __global__ __launch_bounds__(64 * NW, OCC * NW / 4) void conv_h2_kernel(ConvH2P 
       DSG_ET(1 + 2 * mt);
 #pragma unroll
       for (int rg = 0; rg < 4; ++rg) {  // a register group = four consecutive output channels
-        // One group at a time: left alone, the scheduler reads all 256 accumulators out early, spills what no longer
-        // fits -- and a spill reload issued after this tile's stores waits for every one of them (vmcnt retires in order:
-        // a full write drain per reload).  +2.2% on the whole denoising step.  (The 16-bit kernels spill MORE with the
-        // fence -- 12 -> 140 bytes at two workgroups per CU -- and lose 0.5%: fp32-equivalent kernels only.)
-        if constexpr (PREC == 0) __builtin_amdgcn_sched_barrier(0);
         float vv[4][NT];
 #pragma unroll
         for (int j = 0; j < 4; ++j)
