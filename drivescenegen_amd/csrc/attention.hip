@@ -427,6 +427,8 @@ DSG_API int dsg_attention_fwd_train(const float* qkv, float* out, float* lse, in
 // ---------------------------------------------------------------------------------------------------
 namespace dsg {
 
+typedef float att_f2 __attribute__((ext_vector_type(2)));
+
 template <int D>
 __global__ __launch_bounds__(256) void attention_bwd_dq_kernel(const float* __restrict__ qkv,
                                                                const float* __restrict__ o,
@@ -447,6 +449,9 @@ __global__ __launch_bounds__(256) void attention_bwd_dq_kernel(const float* __re
   const int qi = blockIdx.x * 256 + tid;
   const int qc = min(qi, l - 1);
   float q[D], dO[D], dq[D];
+  att_f2 dq2[D];  // (even keys, odd keys)
+#pragma unroll
+  for (int i = 0; i < D; ++i) dq2[i] = att_f2{0.f, 0.f};
   float dd = 0.f;
 #pragma unroll
   for (int i = 0; i < D; ++i) {
@@ -466,23 +471,50 @@ __global__ __launch_bounds__(256) void attention_bwd_dq_kernel(const float* __re
         kv = kp[(size_t)i * l + j0 + j];
         vv = vp[(size_t)i * l + j0 + j];
       }
-      Kl[j * D + i] = kv;
-      Vl[j * D + i] = vv;
+      // key PAIRS side by side: [pair][dim][2] -- the loop below works on two keys per packed fp32 instruction
+      Kl[((j >> 1) * D + i) * 2 + (j & 1)] = kv;
+      Vl[((j >> 1) * D + i) * 2 + (j & 1)] = vv;
     }
     __syncthreads();
-    for (int j = 0; j < kt; ++j) {
-      float s = 0.f, dp = 0.f;
+    // (a padded key has K = V = 0: its probability is not zero, but everything it is multiplied into dq by is)
+    // (the pair's K and V rows are fetched one iteration ahead into a second register set -- consumed as they are read,
+    // the broadcast LDS reads' latency was most of an iteration; two sets taking turns, no copies)
+    const int npair = (kt + 1) / 2;
+    const att_f2* K2 = reinterpret_cast<const att_f2*>(Kl);
+    const att_f2* V2 = reinterpret_cast<const att_f2*>(Vl);
+    auto fetch = [&](int jp, att_f2 (&kr)[D], att_f2 (&vr)[D]) {
+      const int jc = min(jp, npair - 1);
 #pragma unroll
       for (int i = 0; i < D; ++i) {
-        s = fmaf(q[i], Kl[j * D + i], s);
-        dp = fmaf(dO[i], Vl[j * D + i], dp);
+        kr[i] = K2[jc * D + i];
+        vr[i] = V2[jc * D + i];
       }
-      const float pr = exp2f(s - ls);
-      const float ds = pr * (dp - dd);
+    };
+    auto pair = [&](const att_f2 (&kr)[D], const att_f2 (&vr)[D]) {
+      att_f2 s = {0.f, 0.f}, dp = {0.f, 0.f};
 #pragma unroll
-      for (int i = 0; i < D; ++i) dq[i] = fmaf(ds, Kl[j * D + i], dq[i]);
+      for (int i = 0; i < D; ++i) {
+        s = __builtin_elementwise_fma(att_f2{q[i], q[i]}, kr[i], s);
+        dp = __builtin_elementwise_fma(att_f2{dO[i], dO[i]}, vr[i], dp);
+      }
+      const att_f2 pr = {__builtin_amdgcn_exp2f(s.x - ls), __builtin_amdgcn_exp2f(s.y - ls)};  // (arguments <= ~0)
+      const att_f2 ds = pr * (dp - att_f2{dd, dd});
+#pragma unroll
+      for (int i = 0; i < D; ++i) dq2[i] = __builtin_elementwise_fma(ds, kr[i], dq2[i]);
+    };
+    att_f2 ka[D], va[D], kb[D], vb[D];
+    fetch(0, ka, va);
+    int jp = 0;
+    for (; jp + 1 < npair; jp += 2) {
+      fetch(jp + 1, kb, vb);
+      pair(ka, va);
+      fetch(jp + 2, ka, va);
+      pair(kb, vb);
     }
+    if (jp < npair) pair(ka, va);
   }
+#pragma unroll
+  for (int i = 0; i < D; ++i) dq[i] = dq2[i].x + dq2[i].y;
   if (qi < l) {
     // qscale = log2(e)/sqrt(D); the softmax scale alone is 1/sqrt(D)
     const float sm = qscale * 0.6931471805599453f;
@@ -500,7 +532,7 @@ __global__ __launch_bounds__(256) void attention_bwd_dkv_kernel(const float* __r
                                                                 const float* __restrict__ dsum,
                                                                 float* __restrict__ dqkv, int c, int heads, int l,
                                                                 float qscale) {
-  constexpr int QT = ATT_LDS_FLOATS / (D + 1);  // queries per LDS tile: q[D], dO[D], lse, D-sum
+  constexpr int QT = (ATT_LDS_FLOATS / (D + 1)) & ~1;  // queries per LDS tile (even: they sit in pairs): q[D], dO[D], lse, D-sum
   __shared__ __attribute__((aligned(16))) float Sm[2 * QT * (D + 1)];
   float* Ql = Sm;                  // [QT][D+1]: q (prescaled) then lse
   float* Gl = Sm + QT * (D + 1);   // [QT][D+1]: dO then dsum
@@ -514,6 +546,9 @@ __global__ __launch_bounds__(256) void attention_bwd_dkv_kernel(const float* __r
   const int ki = blockIdx.x * 256 + tid;
   const int kc = min(ki, l - 1);
   float k[D], v[D], dk[D], dv[D];
+  att_f2 dk2[D], dv2[D];  // (even queries, odd queries)
+#pragma unroll
+  for (int i = 0; i < D; ++i) dk2[i] = dv2[i] = att_f2{0.f, 0.f};
 #pragma unroll
   for (int i = 0; i < D; ++i) {
     k[i] = kp[(size_t)i * l + kc];
@@ -536,27 +571,54 @@ __global__ __launch_bounds__(256) void attention_bwd_dkv_kernel(const float* __r
           b = dsum[lbase + j0 + j];
         }
       }
-      Ql[j * (D + 1) + i] = a;
-      Gl[j * (D + 1) + i] = b;
+      // query PAIRS side by side: [pair][dim + 1][2]
+      Ql[((j >> 1) * (D + 1) + i) * 2 + (j & 1)] = a;
+      Gl[((j >> 1) * (D + 1) + i) * 2 + (j & 1)] = b;
     }
     __syncthreads();
-    for (int j = 0; j < qt; ++j) {
-      const float* qr = Ql + j * (D + 1);
-      const float* gr = Gl + j * (D + 1);
-      float s = 0.f, dp = 0.f;
+    // (a padded query has q = dO = lse = D-sum = 0: whatever its probability, it adds 0 to dk and dv)
+    const int npair = (qt + 1) / 2;
+    const att_f2* Q2 = reinterpret_cast<const att_f2*>(Ql);
+    const att_f2* G2 = reinterpret_cast<const att_f2*>(Gl);
+    auto fetch = [&](int jp, att_f2 (&qr)[D + 1], att_f2 (&gr)[D + 1]) {
+      const int jc = min(jp, npair - 1);
+#pragma unroll
+      for (int i = 0; i <= D; ++i) {
+        qr[i] = Q2[jc * (D + 1) + i];
+        gr[i] = G2[jc * (D + 1) + i];
+      }
+    };
+    auto pair = [&](const att_f2 (&qr)[D + 1], const att_f2 (&gr)[D + 1]) {
+      att_f2 s = {0.f, 0.f}, dp = {0.f, 0.f};
 #pragma unroll
       for (int i = 0; i < D; ++i) {
-        s = fmaf(qr[i], k[i], s);
-        dp = fmaf(gr[i], v[i], dp);
+        s = __builtin_elementwise_fma(qr[i], att_f2{k[i], k[i]}, s);
+        dp = __builtin_elementwise_fma(gr[i], att_f2{v[i], v[i]}, dp);
       }
-      const float pr = exp2f(s - qr[D]);
-      const float ds = pr * (dp - gr[D]);
+      const att_f2 e = s - qr[D];
+      const att_f2 pr = {__builtin_amdgcn_exp2f(e.x), __builtin_amdgcn_exp2f(e.y)};
+      const att_f2 ds = pr * (dp - gr[D]);
 #pragma unroll
       for (int i = 0; i < D; ++i) {
-        dv[i] = fmaf(pr, gr[i], dv[i]);
-        dk[i] = fmaf(ds, qr[i], dk[i]);  // qr is prescaled by log2(e)/sqrt(D): undone below
+        dv2[i] = __builtin_elementwise_fma(pr, gr[i], dv2[i]);
+        dk2[i] = __builtin_elementwise_fma(ds, qr[i], dk2[i]);  // qr is prescaled by log2(e)/sqrt(D): undone below
       }
+    };
+    att_f2 qa[D + 1], ga[D + 1], qb[D + 1], gb[D + 1];
+    fetch(0, qa, ga);
+    int jp = 0;
+    for (; jp + 1 < npair; jp += 2) {
+      fetch(jp + 1, qb, gb);
+      pair(qa, ga);
+      fetch(jp + 2, qa, ga);
+      pair(qb, gb);
     }
+    if (jp < npair) pair(qa, ga);
+  }
+#pragma unroll
+  for (int i = 0; i < D; ++i) {
+    dk[i] = dk2[i].x + dk2[i].y;
+    dv[i] = dv2[i].x + dv2[i].y;
   }
   if (ki < l) {
     float* dkp = dqkv + ((size_t)n * 3 * c + c + h * D) * l;
