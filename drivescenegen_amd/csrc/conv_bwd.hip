@@ -261,6 +261,53 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
     if (co + q < cout) dw[((size_t)(co + q) * cin + ci) * taps + tp] += sv[q];
 }
 
+// The same reduction for the layers with FEW slabs and a big gradient (256 / 512 channels: 2.4 M elements, 8-32 slabs),
+// where the kernel above is dominated by its output: each lane's four results go to [co][ci][tp] addresses a whole
+// cin x taps row apart -- scattered 4-byte read-modify-writes.  Here a workgroup owns a 32 co x 2 ci x all-taps tile: its
+// four waves each sum every fourth slab (thread = (co, ci), one value per tap: 128-byte runs along co), the partial tiles
+// meet in LDS in a fixed order, and dw is updated in runs of 2 ci x taps contiguous floats per co.
+constexpr int WRT_CO = 32, WRT_CI = 2;
+__global__ __launch_bounds__(256) void wgrad_reduce_t_kernel(const float* __restrict__ ws, int nslab, int taps, int cin,
+                                                             int cout, int cin_pad, int cout_pad,
+                                                             float* __restrict__ dw) {
+  __shared__ float tile[4][WRT_CO][WRT_CI * 9 + 1];  // [slab wave][co][ci * taps + tp]
+  const int co0 = blockIdx.x * WRT_CO, ci0 = blockIdx.y * WRT_CI;
+  const int t = threadIdx.x, sl = t >> 6, co = t & 31, ci = (t >> 5) & 1;
+  const int64_t tstride = (int64_t)cin_pad * cout_pad, slab = (int64_t)taps * tstride;
+  float acc[9];
+#pragma unroll
+  for (int tp = 0; tp < 9; ++tp) acc[tp] = 0.f;
+  if (ci0 + ci < cin_pad && co0 + co < cout_pad) {
+    const float* p = ws + (int64_t)sl * slab + (int64_t)(ci0 + ci) * cout_pad + co0 + co;
+    for (int k = sl; k < nslab; k += 4, p += 4 * slab) {
+#pragma unroll
+      for (int tp = 0; tp < 9; ++tp)
+        if (tp < taps) acc[tp] += p[tp * tstride];
+    }
+  }
+#pragma unroll
+  for (int tp = 0; tp < 9; ++tp)
+    if (tp < taps) tile[sl][co][ci * taps + tp] = acc[tp];
+  __syncthreads();
+  const int run = WRT_CI * taps;  // contiguous floats per co in dw
+  for (int o = t; o < WRT_CO * run; o += 256) {
+    const int c = o / run, r = o - c * run;
+    if (co0 + c < cout && ci0 + r / taps < cin)
+      dw[((size_t)(co0 + c) * cin + ci0) * taps + r] += (tile[0][c][r] + tile[1][c][r]) + (tile[2][c][r] + tile[3][c][r]);
+  }
+}
+
+static void launch_wgrad_reduce(const float* ws, int nslab, int taps, int cin, int cout, int cin_pad, int cout_pad, float* dw,
+                                hipStream_t st) {
+  const int64_t slab = (int64_t)taps * cin_pad * cout_pad;
+  if (nslab <= 32 && slab >= (int64_t)256 * 256 && cin_pad % WRT_CI == 0)
+    hipLaunchKernelGGL(wgrad_reduce_t_kernel, dim3(cdiv(cout_pad, WRT_CO), cdiv(cin_pad, WRT_CI)), dim3(256), 0, st, ws, nslab, taps,
+                       cin, cout, cin_pad, cout_pad, dw);
+  else
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)cdiv64(slab / 4, 64)), dim3(256), 0, st, ws, nslab, taps, cin, cout,
+                       cin_pad, cout_pad, dw);
+}
+
 // Generic VALU fallback (odd spatial sizes): one thread per (co, ci, tap), loops over all pixels.
 __global__ __launch_bounds__(256) void conv_wgrad_direct_kernel(WgradP p, int ks, int stride, int ups) {
   const int taps = ks * ks;
@@ -618,8 +665,8 @@ static int launch_wgrad(WgradP p, size_t ws_bytes, hipStream_t st) {
   hipLaunchKernelGGL(kern, dim3(pairs, nsplit), dim3(256), lds, st, p);
   DSG_LAUNCH_CHECK();
   const int64_t slab = (int64_t)G::TAPS * p.cin_pad * p.cout_pad;
-  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)cdiv64(slab / 4, 64)), dim3(256), 0, st, p.ws, nslab, G::TAPS, p.cin,
-                     p.cout, p.cin_pad, p.cout_pad, p.dw);
+  (void)slab;
+  launch_wgrad_reduce(p.ws, nslab, G::TAPS, p.cin, p.cout, p.cin_pad, p.cout_pad, p.dw, st);
   prof_end(pi, st);
   DSG_LAUNCH_CHECK();
   return DSG_OK;
@@ -660,8 +707,8 @@ static int launch_wgrad_h2(WgradP p, size_t ws_bytes, hipStream_t st) {
   hipLaunchKernelGGL(conv_wgrad_h2_kernel, dim3(pairs, nslab), dim3(256), (size_t)WH_LDS_BYTES, st, p);
   DSG_LAUNCH_CHECK();
   const int64_t slab = (int64_t)9 * p.cin_pad * p.cout_pad;
-  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)cdiv64(slab / 4, 64)), dim3(256), 0, st, p.ws, nslab, 9, p.cin,
-                     p.cout, p.cin_pad, p.cout_pad, p.dw);
+  (void)slab;
+  launch_wgrad_reduce(p.ws, nslab, 9, p.cin, p.cout, p.cin_pad, p.cout_pad, p.dw, st);
   prof_end(pi, st);
   DSG_LAUNCH_CHECK();
   return DSG_OK;
@@ -1004,8 +1051,8 @@ static int launch_wgrad16(const dsg_conv_wgrad_args* a, int hout, int wout, hipS
   }
   DSG_LAUNCH_CHECK();
   const int64_t slab = (int64_t)taps * p.cin * p.cout;
-  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)cdiv64(slab / 4, 64)), dim3(256), 0, st, p.ws, nslab, taps, p.cin,
-                     p.cout, p.cin, p.cout, a->dw);
+  (void)slab;
+  launch_wgrad_reduce(p.ws, nslab, taps, p.cin, p.cout, p.cin, p.cout, a->dw, st);
   if (a->dy_sums) {
     DSG_LAUNCH_CHECK();
     hipLaunchKernelGGL(wgrad16_dysum_reduce_kernel, dim3(cdiv(p.cout, 256), p.n), dim3(256), 0, st, p.dysum_ws,
