@@ -765,7 +765,10 @@ struct W16Geom {
 
 // KS = 3: 3x3, padding 1.  KS = 1: pointwise (shortcuts, attention projections): the map is re-tiled by the host as
 // h * w / 32 rows of 32 pixels (a channel-blocked tensor is linear in the pixel index), no halo, one tap.
-template <int PREC, int KS>
+// ACT: 1 = the sources go through GroupNorm affine + SiLU (every resnet conv), 0 = used as they are (shortcuts, samplers),
+// 2 = decided at run time (affine without SiLU: the attention projections) -- compile-time in the two common cases: the
+// run-time flags cost branches in the staging code and registers the kernel does not have
+template <int PREC, int KS, int ACT = 2>
 __global__ __launch_bounds__(256, 2) void conv_wgrad16_kernel(Wgrad16P p) {
   constexpr int W16_PW = W16Geom<KS>::PW, W16_A_HALFS = W16Geom<KS>::A_HALFS, PADK = KS / 2, TAPS = KS * KS;
   extern __shared__ __attribute__((aligned(16))) unsigned char wsm16[];
@@ -780,8 +783,8 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad16_kernel(Wgrad16P p) {
   const int cib = blockIdx.x % p.ci_blocks, cob = blockIdx.x / p.ci_blocks;
   const int ci0 = cib * 64, co0 = cob * 64;
   const int plane = p.h * p.w;
-  const bool has_ss = p.ss != nullptr;
-  const bool do_silu = has_ss && p.silu;
+  const bool has_ss = ACT == 2 ? p.ss != nullptr : ACT == 1;
+  const bool do_silu = ACT == 2 ? (has_ss && p.silu) : ACT == 1;
 
   // this workgroup's runs: strips [run * spw, (run + 1) * spw) (image n, column tile tx), stages [s0, s1) of each
   const int run = blockIdx.y / p.nrs, rs = blockIdx.y - run * p.nrs;
@@ -1042,13 +1045,21 @@ static int launch_wgrad16(const dsg_conv_wgrad_args* a, int hout, int wout, hipS
                     2.0 * ((double)p.n * p.cin * p.h * p.w + (double)p.n * p.cout * hout * wout), st);
   const dim3 grid(p.ci_blocks * (p.cout / 64), nslab);
   const bool bf = a->compute_dtype == DSG_BF16;
+  const int act = p.ss == nullptr ? 0 : (p.silu ? 1 : 2);
+#define DSG_W16_LAUNCH(PRC, KSZ)                                                                                            \
+  do {                                                                                                                      \
+    if (act == 0) hipLaunchKernelGGL((conv_wgrad16_kernel<PRC, KSZ, 0>), grid, dim3(256), (size_t)W16Geom<KSZ>::LDS_BYTES, st, p); \
+    else if (act == 1) hipLaunchKernelGGL((conv_wgrad16_kernel<PRC, KSZ, 1>), grid, dim3(256), (size_t)W16Geom<KSZ>::LDS_BYTES, st, p); \
+    else hipLaunchKernelGGL((conv_wgrad16_kernel<PRC, KSZ, 2>), grid, dim3(256), (size_t)W16Geom<KSZ>::LDS_BYTES, st, p);    \
+  } while (0)
   if (a->ksize == 3) {
-    if (bf) hipLaunchKernelGGL((conv_wgrad16_kernel<1, 3>), grid, dim3(256), (size_t)W16Geom<3>::LDS_BYTES, st, p);
-    else hipLaunchKernelGGL((conv_wgrad16_kernel<2, 3>), grid, dim3(256), (size_t)W16Geom<3>::LDS_BYTES, st, p);
+    if (bf) DSG_W16_LAUNCH(1, 3);
+    else DSG_W16_LAUNCH(2, 3);
   } else {
-    if (bf) hipLaunchKernelGGL((conv_wgrad16_kernel<1, 1>), grid, dim3(256), (size_t)W16Geom<1>::LDS_BYTES, st, p);
-    else hipLaunchKernelGGL((conv_wgrad16_kernel<2, 1>), grid, dim3(256), (size_t)W16Geom<1>::LDS_BYTES, st, p);
+    if (bf) DSG_W16_LAUNCH(1, 1);
+    else DSG_W16_LAUNCH(2, 1);
   }
+#undef DSG_W16_LAUNCH
   DSG_LAUNCH_CHECK();
   const int64_t slab = (int64_t)taps * p.cin * p.cout;
   (void)slab;
