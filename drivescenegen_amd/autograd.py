@@ -47,6 +47,7 @@ class TrainState:
         self.params = dict(self.items)
         self.wf, self.wd, self.versions = {}, {}, {}
         self.wh, self.whd = {}, {}  # fp16x2-split copies (forward / data-gradient) of the eligible 3x3 weights
+        self.scratch16 = {}         # padded 16-bit buffers of the mixed-precision tape's conv_in / conv_out weight gradients
         self.needs_w = {}           # (name, "wf" | "wd") -> does the mixed-precision tape's call read the fp32 engine layout?
         self.freqs = ops.sinusoid_freqs(model.config.block_out_channels[0]).to(dev)
         self.grad_ready_hooks = []  # callables(name) fired when a parameter's gradient is final (DDP buckets)
@@ -702,6 +703,39 @@ def _backward16(model, st: TrainState, tape: _Tape, dout):
     def f32(t):   # [N, C, H, W] fp32 view of a tape tensor (conversion pass for the shapes the 16-bit kernels skip)
         return ops.from_blocked(t) if blocked(t) else t
 
+    def pad64(t, key):
+        """a tape tensor (fp32 [N, C, H, W] or blocked 16-bit, C <= 64) as a blocked 16-bit tensor of 64 channels, the
+        missing ones zero; the padded buffer is kept between steps (its zero channels are written once)"""
+        if blocked(t) and t.shape[1] == 8:
+            return t
+        n = t.shape[0]
+        h, w = (t.shape[2], t.shape[3])
+        buf = st.scratch16.get((key, n, h, w, dt))
+        if buf is None:
+            buf = st.scratch16[(key, n, h, w, dt)] = torch.zeros((n, 8, h, w, 8), dtype=_lib.TORCH_DTYPES[ops.dtype_code(dt)],
+                                                                 device=t.device)
+        if blocked(t):
+            buf[:, :t.shape[1]].copy_(t)
+        else:
+            c = t.shape[1]
+            if c % 8:
+                x8 = st.scratch16.get((key, "nchw", n, h, w))
+                if x8 is None:
+                    x8 = st.scratch16[(key, "nchw", n, h, w)] = torch.zeros((n, (c + 7) // 8 * 8, h, w), dtype=torch.float32,
+                                                                            device=t.device)
+                x8[:, :c].copy_(t)
+                t = x8
+            buf[:, :t.shape[1] // 8].copy_(ops.to_blocked(t.contiguous(), dt))
+        return buf
+
+    def pad_ss(ss, c):
+        """[N, c, 2] scale / shift -> [N, 64, 2] (the padded channels are zero anyway)"""
+        if ss is None or c == 64:
+            return ss
+        out = torch.zeros((ss.shape[0], 64, 2), dtype=ss.dtype, device=ss.device)
+        out[:, :c].copy_(ss)
+        return out
+
     def wgrad(x0, x1, dy, wname, k, stride, ups, ss, silu, cout=None, dy_coff=0, sums=None, sums_stride=0):
         """weight gradient; returns True when `sums` (per-(n, cout) sums of dy) was filled as a by-product"""
         c0, c1 = chans(x0), (chans(x1) if x1 is not None else 0)
@@ -710,6 +744,34 @@ def _backward16(model, st: TrainState, tape: _Tape, dout):
             ops.conv_wgrad(x0, dy, st.grad(wname), src1=x1, ksize=k, gn_scale_shift=ss, silu=silu, cout=co, dy_coff=dy_coff,
                            dy_sums=sums, dy_sums_stride=sums_stride)
             return sums is not None
+        elif (k == 3 and stride == 2 and not ups and x1 is None and dy_coff == 0 and blocked(x0) and blocked(dy) and ss is None
+              and ops.wgrad16_supported(c0, 0, co, x0.shape[2], x0.shape[3], 3)):
+            # down-sampler conv: its weight gradient is the stride-1 one against dY with zeros between its pixels
+            # (dY_up[2y, 2x] = dY[y, x]): the 16-bit kernel at full resolution instead of two conversions to fp32 and the
+            # exact f32 kernel.  The zero positions of the buffer are written once and kept between steps.
+            key = ("dyup", wname, tuple(dy.shape))
+            up = st.scratch16.get(key)
+            if up is None:
+                up = st.scratch16[key] = torch.zeros((dy.shape[0], dy.shape[1], x0.shape[2], x0.shape[3], 8), dtype=dy.dtype,
+                                                     device=dy.device)
+            up[:, :, ::2, ::2].copy_(dy)
+            ops.conv_wgrad(x0, up, st.grad(wname), ksize=3, cout=co, dy_sums=sums, dy_sums_stride=sums_stride)
+            return sums is not None
+        elif (k == 3 and stride == 1 and not ups and x1 is None and dy_coff == 0 and c0 <= 64 and co <= 64
+              and ops.wgrad16_supported(64, 0, 64, x0.shape[2], x0.shape[3], 3)):
+            # conv_in (few input channels) / conv_out (few output channels): the 16-bit kernel wants 64-channel blocks, so
+            # the narrow side is padded with zero channels -- a 64 x 64 weight gradient of which one corner is kept.  (The
+            # fp32 detour -- dY or x converted back to [N,C,H,W], the exact f32 kernel on a 2 M-pixel contraction with 8
+            # rows -- was 2.3 ms of the bf16 step; this is 0.6.)
+            xb, dyb = pad64(x0, "x:" + wname), pad64(dy, "dy:" + wname)
+            tmp = st.scratch16.get(("dw", wname))
+            if tmp is None:
+                tmp = st.scratch16[("dw", wname)] = torch.empty((64, 64, 3, 3), dtype=torch.float32, device=dy.device)
+            tmp.zero_()
+            ops.conv_wgrad(xb, dyb, tmp, ksize=3, gn_scale_shift=pad_ss(ss, c0), silu=silu, cout=64)
+            g = st.grad(wname)
+            g.copy_(ops.add(g, tmp[:co, :c0].contiguous()))
+            return False
         else:
             ops.conv_wgrad(f32(x0), f32(dy), st.grad(wname), src1=None if x1 is None else f32(x1), ksize=k, stride=stride,
                            upsample=ups, gn_scale_shift=ss, silu=silu, cout=co, dy_coff=dy_coff)
