@@ -740,8 +740,11 @@ def _backward16(model, st: TrainState, tape: _Tape, dout):
         """weight gradient; returns True when `sums` (per-(n, cout) sums of dy) was filled as a by-product"""
         c0, c1 = chans(x0), (chans(x1) if x1 is not None else 0)
         co = cout or chans(dy)
-        if blocked(x0) and blocked(dy) and ops.wgrad16_supported(c0, c1, co, x0.shape[2], x0.shape[3], k, stride, ups, dy_coff):
-            ops.conv_wgrad(x0, dy, st.grad(wname), src1=x1, ksize=k, gn_scale_shift=ss, silu=silu, cout=co, dy_coff=dy_coff,
+        if (blocked(dy) and (blocked(x0) or x1 is None)
+                and ops.wgrad16_supported(c0, c1, co, x0.shape[2], x0.shape[3], k, stride, ups, dy_coff)):
+            # (an fp32 [N, C, H, W] source -- the attention output in front of to_out -- is rounded to the tape's type first)
+            xb = x0 if blocked(x0) else ops.to_blocked(x0.contiguous(), dt)
+            ops.conv_wgrad(xb, dy, st.grad(wname), src1=x1, ksize=k, gn_scale_shift=ss, silu=silu, cout=co, dy_coff=dy_coff,
                            dy_sums=sums, dy_sums_stride=sums_stride)
             return sums is not None
         elif (k == 3 and stride == 2 and not ups and x1 is None and dy_coff == 0 and blocked(x0) and blocked(dy) and ss is None
@@ -873,10 +876,15 @@ def _backward16(model, st: TrainState, tape: _Tape, dout):
             x, pre = rec["x"], rec["pre"]
             c = chans(x)
             sums = ops.channel_sums(dqkv)
-            x32 = ops.from_blocked(x)
+            # the three projections' weight gradients on the 16-bit kernel: dqkv (fp32 [N, 3C, L], the attention
+            # backward's result) is rounded to the tape's type once; shapes the kernel does not take keep the fp32 form
+            # (bf16 only: dqkv's entries for K are small enough to lose bits in fp16's range even under the loss scale --
+            # the worst tensor of the fp16 parity test sat at its tolerance)
+            w16 = dt == _lib.DSG_BF16 and ops.wgrad16_supported(c, 0, c, x.shape[2], x.shape[3], 1, 1, False, 0)
+            xw, dyw = (x, ops.to_blocked(dqkv.contiguous(), dt)) if w16 else (ops.from_blocked(x), dqkv)
             for i, t in enumerate(("to_q", "to_k", "to_v")):
                 ops.reduce_rows_add(sums[:, i * c:], st.grad(f"{pre}.{t}.bias"), stride=sums.stride(0))
-                ops.conv_wgrad(x32, dqkv, st.grad(f"{pre}.{t}.weight"), ksize=1, gn_scale_shift=rec["ss"], silu=False,
+                ops.conv_wgrad(xw, dyw, st.grad(f"{pre}.{t}.weight"), ksize=1, gn_scale_shift=rec["ss"], silu=False,
                                cout=c, dy_coff=i * c)
                 done(f"{pre}.{t}.weight", f"{pre}.{t}.bias")
             _, wd, _ = st.qkv_w(pre)
