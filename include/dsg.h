@@ -72,7 +72,9 @@ typedef struct {
   int32_t ksize;                /* 3 or 1; padding = ksize/2 */
   int32_t stride;               /* 1 or 2 (Downsample2D) */
   int32_t cout;
-  const float* weight;          /* [c0+c1][ksize*ksize][weight_cout_stride] */
+  const float* weight;          /* [c0+c1][ksize*ksize][weight_cout_stride]; may be NULL when one of the weight_h2* operand
+                                   images below serves the call (otherwise DSG_ERR_INVALID_ARG, before anything is
+                                   launched): a training step need not re-lay-out weights no kernel reads */
   int32_t weight_cout_stride;   /* 0 = cout; >= cout when the matrix is zero-padded (conv_out: 4 -> 32) */
   const float* bias;            /* [cout] or NULL */
   const float* gn_scale_shift;  /* optional [N][c0+c1][2] */
