@@ -642,16 +642,10 @@ __global__ __launch_bounds__(64 * NW, OCC * NW / 4) void conv_h2_kernel(ConvH2P 
       // instead of leaving it in one block as the scheduler would.
       if (KS == 3 && tap < TAPS - 1 && (STAGE || LOAD)) {
 #pragma unroll
-#ifndef DSG_H2_SGB
-#define DSG_H2_SGB 0
-#endif
         for (int m = 0; m < (NP == 2 ? 3 : 1) * MTN * NT; ++m) {
-          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);               // 1 MFMA
-          if (DSG_H2_SGB == 1 || DSG_H2_SGB == 3) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);  // (experiment) 1 DS read
-                    // 2 VALU per MFMA (a third of the MFMAs: 5; 128 couts, twice the MFMAs per tap again: 3)
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);  // 1 MFMA
+          // 2 VALU per MFMA (a third of the MFMAs: 5; 128 couts, twice the MFMAs per tap again: 3)
           __builtin_amdgcn_sched_group_barrier(0x002, NP == 2 ? 2 : (BM == 128 ? 3 : 5), 0);
-          if (DSG_H2_SGB == 2 || DSG_H2_SGB == 3) __builtin_amdgcn_sched_group_barrier(0x004, 1, 0);  // (experiment) 1 SALU
-          if (DSG_H2_SGB == 4) __builtin_amdgcn_sched_group_barrier(0x002, 1, 0);                      // (experiment) a third VALU
         }
       }
 #ifdef DSG_H2_TIMING
