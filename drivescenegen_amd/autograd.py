@@ -119,6 +119,13 @@ class TrainState:
             ops.relayout_conv_weight_dgrad(p, out=self.wd[name])
         return self.wd[name]
 
+    def pack32(self, name, kind):
+        """fp16x2-split operand image of `kind` (ops.PACK_*) of a conv weight for the fp32 tape, refreshed when it changes"""
+        key = (name, "p32", kind)
+        if self._fresh(key) or key not in self.wh:
+            self.wh[key] = ops.pack_conv_weight(self.params[name].detach(), kind, 0, out=self.wh.get(key))
+        return self.wh[key]
+
     def lazy_w(self, name, which, call):
         """call(w): w = the fp32 engine layout (`which`: "wf" | "wd") only if the library's kernels for this call read it.
         Most convs of the mixed-precision tape run on their 16-bit operand images alone; re-laying out all 70 weights twice
@@ -251,10 +258,13 @@ def _forward(model, st: TrainState, tape: _Tape, sample, timesteps):
         ss = mr = None
         if gn is not None:
             ss, mr = norm_ss(x0, x1, gn)
+        # (up-sampler convs: the folded 2x2 phase kernels of the inference plan instead of the nearest-x2 gather)
+        fold = st.pack32(wname + ".weight", ops.PACK_FOLD) if (ups and k == 3 and x1 is None and gn is None
+                                                                 and x0.shape[1] % 16 == 0 and cout % 64 == 0) else None
         y = ops.conv2d_fused(x0, wf, bias, src1=x1, ksize=k, stride=stride, upsample=ups, gn_scale_shift=ss,
                              silu=silu, temb=None if toff is None else tproj[:, toff:],
                              temb_stride=tproj.stride(0), residual=res, cout=cout,
-                             weight_h2=st.wh.get(wname + ".weight"), want_stats=feeds_norm)
+                             weight_h2=st.wh.get(wname + ".weight"), weight_h2_fold=fold, want_stats=feeds_norm)
         if feeds_norm:
             y, ystats = y
             if ystats is not None:
@@ -375,8 +385,14 @@ def _backward(model, st: TrainState, tape: _Tape, dout):
             else:
                 # no norm in front: the data gradient lands on the source(s) directly (one conv per source,
                 # selecting that source's columns of the transposed weight; the fan-in add rides the epilogue)
-                tape.setg(x0, ops.conv2d_fused(dy, wd, ksize=k, upsample=up_mode, cout=cin0, pool2=rec["ups"],
-                                               residual=tape.g(x0), weight_h2=whd))
+                s2fold = (rec["stride"] == 2 and k == 3 and x1 is None and dy.shape[1] % 16 == 0 and cin0 % 64 == 0
+                          and dy.shape[3] % 32 == 0 and dy.shape[2] % 8 == 0)
+                if s2fold:  # the adjoint of the stride-2 conv = four 2x2 phase convs of dY: the folded up-sampler's kernel
+                    tape.setg(x0, ops.conv2d_fused(dy, wd, ksize=3, upsample=True, cout=cin0, residual=tape.g(x0),
+                                                   weight_h2_fold=st.pack32(wname + ".weight", ops.PACK_DGRAD_S2)))
+                else:
+                    tape.setg(x0, ops.conv2d_fused(dy, wd, ksize=k, upsample=up_mode, cout=cin0, pool2=rec["ups"],
+                                                   residual=tape.g(x0), weight_h2=whd))
                 if x1 is not None:
                     tape.setg(x1, ops.conv2d_fused(dy, wd[:, :, cin0:], ksize=k, upsample=up_mode, cout=cin1,
                                                    pool2=rec["ups"], residual=tape.g(x1), wstride=wd.shape[-1],
