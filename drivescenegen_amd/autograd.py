@@ -119,6 +119,18 @@ class TrainState:
             ops.relayout_conv_weight_dgrad(p, out=self.wd[name])
         return self.wd[name]
 
+    def h2_of(self, name):
+        """(forward, data-gradient) fp16x2-split operand images of a conv weight for the fp32 tape, or None where the split
+        kernels do not take the shape; refreshed when the parameter changes"""
+        if self._fresh((name, "h2")) or (name not in self.wh and name not in self.whd):
+            p = self.params[name].detach()
+            cout, cin = p.shape[0], p.shape[1]
+            if cin % 16 == 0 and cout % 64 == 0:
+                self.wh[name] = ops.relayout_conv_weight_h2(p, out=self.wh.get(name))
+            if cout % 16 == 0 and cin % 64 == 0:
+                self.whd[name] = ops.relayout_conv_weight_h2_dgrad(p, out=self.whd.get(name))
+        return self.wh.get(name), self.whd.get(name)
+
     def pack32(self, name, kind):
         """fp16x2-split operand image of `kind` (ops.PACK_*) of a conv weight for the fp32 tape, refreshed when it changes"""
         key = (name, "p32", kind)
@@ -252,7 +264,7 @@ def _forward(model, st: TrainState, tape: _Tape, sample, timesteps):
 
     def conv(x0, wname, x1=None, gn=None, silu=False, k=3, stride=1, ups=False, toff=None, res=None,
              need_dx=True, feeds_norm=False):
-        wf, wd = st.conv_w(wname + ".weight")
+        wh, whd = st.h2_of(wname + ".weight")
         bias = P[wname + ".bias"].detach()
         cout = bias.numel()
         ss = mr = None
@@ -261,17 +273,17 @@ def _forward(model, st: TrainState, tape: _Tape, sample, timesteps):
         # (up-sampler convs: the folded 2x2 phase kernels of the inference plan instead of the nearest-x2 gather)
         fold = st.pack32(wname + ".weight", ops.PACK_FOLD) if (ups and k == 3 and x1 is None and gn is None
                                                                  and x0.shape[1] % 16 == 0 and cout % 64 == 0) else None
-        y = ops.conv2d_fused(x0, wf, bias, src1=x1, ksize=k, stride=stride, upsample=ups, gn_scale_shift=ss,
-                             silu=silu, temb=None if toff is None else tproj[:, toff:],
-                             temb_stride=tproj.stride(0), residual=res, cout=cout,
-                             weight_h2=st.wh.get(wname + ".weight"), weight_h2_fold=fold, want_stats=feeds_norm)
+        # (wf, the fp32 engine layout, only for the calls whose kernels read it: TrainState.lazy_w)
+        y = st.lazy_w(wname + ".weight", "wf", lambda wf: ops.conv2d_fused(
+            x0, wf, bias, src1=x1, ksize=k, stride=stride, upsample=ups, gn_scale_shift=ss, silu=silu,
+            temb=None if toff is None else tproj[:, toff:], temb_stride=tproj.stride(0), residual=res, cout=cout,
+            weight_h2=wh, weight_h2_fold=fold, want_stats=feeds_norm))
         if feeds_norm:
             y, ystats = y
             if ystats is not None:
                 pstats[id(y)] = ystats
         tape.recs.append(dict(kind="conv", x0=x0, x1=x1, ss=ss, mr=mr, gn=gn, silu=silu, k=k, stride=stride, ups=ups,
-                              toff=toff, res=res, y=y, wname=wname, wd=wd, cout=cout, need_dx=need_dx,
-                              whd=st.whd.get(wname + ".weight")))
+                              toff=toff, res=res, y=y, wname=wname, cout=cout, need_dx=need_dx, whd=whd))
         return y
 
     def resnet(x, skip, pre):
@@ -364,16 +376,16 @@ def _backward(model, st: TrainState, tape: _Tape, dout):
             if not rec["need_dx"]:
                 continue
             cin0, cin1 = x0.shape[1], (x1.shape[1] if x1 is not None else 0)
-            wd = rec["wd"]
+            wdn, wd_stride = wname + ".weight", ops._pad32(cin0 + cin1) + 64  # (row length of TrainState.wd_of's layout)
             if ups_h2:
-                dfull = ops.conv2d_fused(dy, wd, ksize=k, cout=cin0, weight_h2=rec["whd"])
+                dfull = st.lazy_w(wdn, "wd", lambda wd: ops.conv2d_fused(dy, wd, ksize=k, cout=cin0, weight_h2=rec["whd"]))
                 tape.setg(x0, ops.sumpool2x2(dfull, add=tape.g(x0)))
                 continue
             up_mode = 2 if rec["stride"] == 2 else 0
             whd = rec["whd"] if (rec["stride"] == 1 and not rec["ups"]) else None  # the split kernel has no pool / zero-stuff mode
             if rec["gn"] is not None:
-                da = ops.conv2d_fused(dy, wd, ksize=k, upsample=up_mode, cout=cin0 + cin1, pool2=rec["ups"],
-                                      weight_h2=whd)
+                da = st.lazy_w(wdn, "wd", lambda wd: ops.conv2d_fused(dy, wd, ksize=k, upsample=up_mode, cout=cin0 + cin1,
+                                                                       pool2=rec["ups"], weight_h2=whd))
                 gnn = rec["gn"]
                 dx0, dx1 = ops.gn_bwd(x0, da, rec["ss"], rec["mr"], P[gnn + ".weight"].detach(), groups, rec["silu"],
                                       st.grad(gnn + ".weight"), st.grad(gnn + ".bias"), src1=x1, add0=tape.g(x0),
@@ -388,16 +400,19 @@ def _backward(model, st: TrainState, tape: _Tape, dout):
                 s2fold = (rec["stride"] == 2 and k == 3 and x1 is None and dy.shape[1] % 16 == 0 and cin0 % 64 == 0
                           and dy.shape[3] % 32 == 0 and dy.shape[2] % 8 == 0)
                 if s2fold:  # the adjoint of the stride-2 conv = four 2x2 phase convs of dY: the folded up-sampler's kernel
-                    tape.setg(x0, ops.conv2d_fused(dy, wd, ksize=3, upsample=True, cout=cin0, residual=tape.g(x0),
-                                                   weight_h2_fold=st.pack32(wname + ".weight", ops.PACK_DGRAD_S2)))
+                    tape.setg(x0, st.lazy_w(wdn, "wd", lambda wd: ops.conv2d_fused(
+                        dy, wd, ksize=3, upsample=True, cout=cin0, residual=tape.g(x0),
+                        weight_h2_fold=st.pack32(wname + ".weight", ops.PACK_DGRAD_S2))))
                 else:
-                    tape.setg(x0, ops.conv2d_fused(dy, wd, ksize=k, upsample=up_mode, cout=cin0, pool2=rec["ups"],
-                                                   residual=tape.g(x0), weight_h2=whd))
+                    tape.setg(x0, st.lazy_w(wdn, "wd", lambda wd: ops.conv2d_fused(
+                        dy, wd, ksize=k, upsample=up_mode, cout=cin0, pool2=rec["ups"], residual=tape.g(x0), weight_h2=whd,
+                        wstride=wd_stride if x1 is not None else None)))
                 if x1 is not None:
-                    tape.setg(x1, ops.conv2d_fused(dy, wd[:, :, cin0:], ksize=k, upsample=up_mode, cout=cin1,
-                                                   pool2=rec["ups"], residual=tape.g(x1), wstride=wd.shape[-1],
-                                                   weight_h2=whd if (cin0 % 8 == 0 and cin1 % 64 == 0) else None,
-                                                   weight_h2_col=cin0))  # (a window must end inside its row)
+                    tape.setg(x1, st.lazy_w(wdn, "wd", lambda wd: ops.conv2d_fused(
+                        dy, None if wd is None else wd[:, :, cin0:], ksize=k, upsample=up_mode, cout=cin1, pool2=rec["ups"],
+                        residual=tape.g(x1), wstride=wd_stride,
+                        weight_h2=whd if (cin0 % 8 == 0 and cin1 % 64 == 0) else None,
+                        weight_h2_col=cin0)))  # (a window must end inside its row)
         elif kind == "attn":
             do = tape.g(rec["o"])
             qkv = rec["qkv"]
