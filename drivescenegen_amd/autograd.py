@@ -355,23 +355,30 @@ def _backward(model, st: TrainState, tape: _Tape, dout):
                 continue
             wname, cout, k = rec["wname"], rec["cout"], rec["k"]
             x0, x1 = rec["x0"], rec["x1"]
-            # bias (+ time-embedding) gradient: per-(n, c) sums of dy
-            if rec["toff"] is not None:
-                sums = ops.channel_sums(dy, out=tb["dtproj"][:, rec["toff"]:], out_stride=tb["dtproj"].stride(0))
-                ops.reduce_rows_add(sums, st.grad(wname + ".bias"), stride=tb["dtproj"].stride(0))
-            else:
-                ops.reduce_rows_add(ops.channel_sums(dy), st.grad(wname + ".bias"))
             if rec["res"] is not None:
                 tape.addg(rec["res"], dy)
             # up-sampler conv (no norm, one source): both gradients run at full resolution on the split matrix-core
             # kernels -- the weight gradient from the materialised nearest-x2 input, the data gradient as a plain
             # transposed conv followed by the upsample's adjoint (2x2 sum-pool)
             ups_h2 = bool(rec["ups"]) and rec["whd"] is not None and x1 is None and rec["gn"] is None and k == 3
+            # bias (+ time-embedding) gradient: per-(n, c) sums of dy -- a by-product of the split weight-gradient kernel
+            # where it serves the conv (the dY tiles pass through it anyway), a pass of their own over dy otherwise
+            if rec["toff"] is not None:
+                sums, sstride = tb["dtproj"][:, rec["toff"]:], tb["dtproj"].stride(0)
+            else:
+                sums = torch.empty((dy.shape[0], cout), dtype=torch.float32, device=dy.device)
+                sstride = cout
+            byp = ops.wgrad_h2_supported(x0.shape[1], 0 if (x1 is None or ups_h2) else x1.shape[1], cout, dy.shape[2], dy.shape[3],
+                                         k, 1 if ups_h2 else rec["stride"], False if ups_h2 else bool(rec["ups"]))
+            kw = dict(dy_sums=sums, dy_sums_stride=sstride) if byp else {}
             if ups_h2:
-                ops.conv_wgrad(ops.upsample_nearest2x(x0), dy, st.grad(wname + ".weight"), ksize=k)
+                ops.conv_wgrad(ops.upsample_nearest2x(x0), dy, st.grad(wname + ".weight"), ksize=k, **kw)
             else:
                 ops.conv_wgrad(x0, dy, st.grad(wname + ".weight"), src1=x1, ksize=k, stride=rec["stride"],
-                               upsample=rec["ups"], gn_scale_shift=rec["ss"], silu=rec["silu"])
+                               upsample=rec["ups"], gn_scale_shift=rec["ss"], silu=rec["silu"], **kw)
+            if not byp:
+                ops.channel_sums(dy, out=sums, out_stride=sstride)
+            ops.reduce_rows_add(sums, st.grad(wname + ".bias"), stride=sstride)
             done(wname + ".weight", wname + ".bias")
             if not rec["need_dx"]:
                 continue

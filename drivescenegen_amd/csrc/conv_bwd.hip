@@ -44,6 +44,8 @@ struct WgradP {
   int cin_pad, cout_pad;
   int tiles_x, tiles_y, ntiles;
   int ci_blocks;
+  float* dysum_ws;  // optional (split kernel): [run][cout_pad] sums of dY over the run's pixels -- the bias / time-embedding
+                    // gradients as a by-product of the tiles that pass through the kernel anyway
 };
 
 __device__ __forceinline__ float silu_fast_b(float x) { return x * __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
@@ -503,10 +505,13 @@ __global__ __launch_bounds__(256, 1) void conv_wgrad_h2_kernel(WgradP p) {
       *reinterpret_cast<uint4*>(dst + (s * 2 + 1) * 32 * WH_ASTR) = wl;
     }
   };
-  auto commit_dy = [&](int par, int u0, int u1) {
+  float dsum[2] = {0.f, 0.f};  // this thread's two (co, pixel octet) items of dY, summed over the run (cnt: 1 inside it, 0 past it)
+  auto commit_dy = [&](int par, int u0, int u1, float cnt) {
     _Float16* db = dbase + par * WH_D_HALFS;
 #pragma unroll
     for (int u = u0; u < u1; ++u) {
+      dsum[u] += cnt * (((xd[u][0].x + xd[u][0].y) + (xd[u][0].z + xd[u][0].w)) +
+                        ((xd[u][1].x + xd[u][1].y) + (xd[u][1].z + xd[u][1].w)));
       uint4 dh, dl;
       split2(xd[u][0].x, xd[u][0].y, dh.x, dl.x);
       split2(xd[u][0].z, xd[u][0].w, dh.y, dl.y);
@@ -532,7 +537,7 @@ __global__ __launch_bounds__(256, 1) void conv_wgrad_h2_kernel(WgradP p) {
     load_dy(s0);
     commit_rows(s0, 2);
     load_rows(s0 + 1);
-    commit_dy(0, 0, 2);
+    commit_dy(0, 0, 2, 1.f);
     commit_rows(s0 + 1, 2);
     load_rows(s0 + 2);               // (past the image: masked to zero)
     if (s0 + 1 < s1) load_dy(s0 + 1);
@@ -585,9 +590,9 @@ __global__ __launch_bounds__(256, 1) void conv_wgrad_h2_kernel(WgradP p) {
         }
         // (unconditional: past the run's last stage the values are never read and the loads are range-checked to
         // zero -- a branch here would fence the scheduler)
-        if (kk == 2) commit_dy(par ^ 1, 0, 1);
+        if (kk == 2) commit_dy(par ^ 1, 0, 1, more ? 1.f : 0.f);
         if (kk == 3) {
-          commit_dy(par ^ 1, 1, 2);
+          commit_dy(par ^ 1, 1, 2, more ? 1.f : 0.f);
           load_dy(s + 2);
         }
         const int fp = kk & 1;
@@ -611,6 +616,16 @@ __global__ __launch_bounds__(256, 1) void conv_wgrad_h2_kernel(WgradP p) {
   if (first) run(std::true_type{});
   else run(std::false_type{});
 
+  if (p.dysum_ws != nullptr && cib == 0) {  // one ci block per co block owns the by-product; 8 neighbouring lanes share a co
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      float t = dsum[u];
+      t += __shfl_xor(t, 1, 64);
+      t += __shfl_xor(t, 2, 64);
+      t += __shfl_xor(t, 4, 64);
+      if ((tid & 7) == 0) p.dysum_ws[(size_t)blockIdx.y * p.cout_pad + co0 + ((tid + 256 * u) >> 3)] = t;
+    }
+  }
   // epilogue: D[ci][co = l31]; partials to this run's slab [tap][ci][co]
   const int co = co0 + cot * 32 + l31;
   float* wsb = p.ws + (size_t)blockIdx.y * 9 * p.cin_pad * p.cout_pad;
@@ -681,7 +696,10 @@ static void wgrad_h2_runs(int cin, int cout, int n, int hout, int wout, int* str
   *rsplit = std::max(1, std::min(stages, cdiv(want, *strips)));
 }
 
-static int launch_wgrad_h2(WgradP p, size_t ws_bytes, hipStream_t st) {
+__global__ void wgrad16_dysum_reduce_kernel(const float* __restrict__ part, int slabs_per_image, int cout,
+                                            float* __restrict__ out, int out_stride);
+
+static int launch_wgrad_h2(WgradP p, size_t ws_bytes, hipStream_t st, float* dy_sums = nullptr, int dy_sums_stride = 0) {
   p.ci_blocks = p.cin / 32;
   const int co_blocks = p.cout / WG_CO;
   const int pairs = p.ci_blocks * co_blocks;
@@ -691,9 +709,10 @@ static int launch_wgrad_h2(WgradP p, size_t ws_bytes, hipStream_t st) {
   p.cin_pad = p.cin;
   p.cout_pad = p.cout;
   p.ntiles = rsplit;  // (field reused: row splits per strip)
-  const size_t need = (size_t)nslab * 9 * p.cin_pad * p.cout_pad * sizeof(float);
+  const size_t need = (size_t)nslab * (9 * (size_t)p.cin_pad * p.cout_pad + p.cout_pad) * sizeof(float);
   if (p.ws == nullptr || ws_bytes < need)
     return fail(DSG_ERR_WORKSPACE_TOO_SMALL, "dsg_conv2d_wgrad: workspace %zu bytes < required %zu", ws_bytes, need);
+  p.dysum_ws = dy_sums ? p.ws + (size_t)nslab * 9 * p.cin_pad * p.cout_pad : nullptr;
   static bool raised = false;
   if (!raised) {
     DSG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wgrad_h2_kernel),
@@ -709,6 +728,11 @@ static int launch_wgrad_h2(WgradP p, size_t ws_bytes, hipStream_t st) {
   const int64_t slab = (int64_t)9 * p.cin_pad * p.cout_pad;
   (void)slab;
   launch_wgrad_reduce(p.ws, nslab, 9, p.cin, p.cout, p.cin_pad, p.cout_pad, p.dw, st);
+  if (dy_sums) {  // run index = (image, column tile, row split): an image's runs are consecutive
+    DSG_LAUNCH_CHECK();
+    hipLaunchKernelGGL(wgrad16_dysum_reduce_kernel, dim3(cdiv(p.cout, 256), p.n), dim3(256), 0, st, p.dysum_ws, p.tiles_x * rsplit,
+                       p.cout, dy_sums, dy_sums_stride ? dy_sums_stride : p.cout);
+  }
   prof_end(pi, st);
   DSG_LAUNCH_CHECK();
   return DSG_OK;
@@ -1086,7 +1110,7 @@ static size_t wgrad_ws_bytes(int cin, int cout, int ks, int stride, int hout, in
   if (ks == 3 && stride == 1 && cin % 32 == 0 && cout % 64 == 0) {  // the fp16x2-split kernel: one slab per run
     int strips, rsplit;
     wgrad_h2_runs(cin, cout, n, hout, wout, &strips, &rsplit);
-    need = std::max(need, (size_t)strips * rsplit * 9 * cin * cout * sizeof(float));
+    need = std::max(need, (size_t)strips * rsplit * (9 * (size_t)cin * cout + cout) * sizeof(float));  // + the dY-sum rows
   }
   return need;
 }
@@ -1108,7 +1132,7 @@ DSG_API int dsg_conv2d_wgrad(const dsg_conv_wgrad_args* a, void* stream) {
                 "dsg_conv2d_wgrad: dy channel window out of range");
   hipStream_t st = static_cast<hipStream_t>(stream);
   DSG_CHECK_ARG(a->compute_dtype >= DSG_F32 && a->compute_dtype <= DSG_F16, "dsg_conv2d_wgrad: bad compute_dtype %d", a->compute_dtype);
-  DSG_CHECK_ARG(a->dy_sums == nullptr || a->compute_dtype != DSG_F32, "dsg_conv2d_wgrad: dy_sums is a by-product of the 16-bit kernel only");
+
   if (a->compute_dtype != DSG_F32) {  // mixed-precision tape: channel-blocked 16-bit x and dY
     DSG_CHECK_SHAPE(wgrad16_ok(a, a->hin, a->win) && !a->force_direct,
                     "dsg_conv2d_wgrad: the 16-bit kernel takes stride-1 3x3 / 1x1 convs with cin %% 64 == 0, cout %% 64 == 0 "
@@ -1129,16 +1153,21 @@ DSG_API int dsg_conv2d_wgrad(const dsg_conv_wgrad_args* a, void* stream) {
   p.cout = a->cout; p.dy = a->dy; p.dy_ctotal = a->dy_ctotal ? a->dy_ctotal : a->cout; p.dy_coff = a->dy_coff;
   p.ss = a->gn_scale_shift; p.silu = a->silu; p.dw = a->dw;
   p.tiles_x = p.wout / 32; p.tiles_y = p.hout / WG_SR; p.ntiles = p.tiles_x * p.tiles_y * p.n; p.ci_blocks = 1;
+  p.dysum_ws = nullptr;
   const bool tile_ok = (p.wout % 32 == 0) && (p.hout % WG_SR == 0) && !a->force_direct;
   if (tile_ok) {
     const int k = a->ksize, s = a->stride, u = a->upsample;
     const bool small_ci = p.cin <= 32;
-    if (wgrad_h2_eligible(p, k, s, u)) return launch_wgrad_h2(p, a->workspace_bytes, st);
+    if (wgrad_h2_eligible(p, k, s, u)) return launch_wgrad_h2(p, a->workspace_bytes, st, a->dy_sums, a->dy_sums_stride);
+    DSG_CHECK_ARG(a->dy_sums == nullptr,
+                  "dsg_conv2d_wgrad: dy_sums is a by-product of the 16-bit kernel and of the fp32 split 3x3 kernel (stride 1, "
+                  "cin %% 32 == 0, cout %% 64 == 0, wout %% 32 == 0, hout %% 2 == 0) only");
     if (k == 3 && s == 1 && u == 0) return small_ci ? launch_wgrad<3, 1, 0, 1>(p, a->workspace_bytes, st) : launch_wgrad<3, 1, 0, 2>(p, a->workspace_bytes, st);
     if (k == 3 && s == 1 && u == 1) return small_ci ? launch_wgrad<3, 1, 1, 1>(p, a->workspace_bytes, st) : launch_wgrad<3, 1, 1, 2>(p, a->workspace_bytes, st);
     if (k == 3 && s == 2) return launch_wgrad<3, 2, 0, 1>(p, a->workspace_bytes, st);
     if (k == 1 && s == 1 && u == 0) return small_ci ? launch_wgrad<1, 1, 0, 1>(p, a->workspace_bytes, st) : launch_wgrad<1, 1, 0, 2>(p, a->workspace_bytes, st);
   }
+  DSG_CHECK_ARG(a->dy_sums == nullptr, "dsg_conv2d_wgrad: dy_sums given but the split kernels do not serve this call");
   const int64_t total = (int64_t)p.cout * p.cin * a->ksize * a->ksize;
   hipLaunchKernelGGL(conv_wgrad_direct_kernel, dim3((unsigned)cdiv64(total, 256)), dim3(256), 0, st, p, a->ksize,
                      a->stride, a->upsample);

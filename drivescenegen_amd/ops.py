@@ -379,6 +379,13 @@ def wgrad16_supported(c0, c1, cout, h, w, ksize=3, stride=1, upsample=False, dy_
     return chans and ksize == 3 and w % 32 == 0 and h % 2 == 0
 
 
+def wgrad_h2_supported(c0, c1, cout, h, w, ksize=3, stride=1, upsample=False) -> bool:
+    """fp32 [N, C, H, W] calls of dsg_conv2d_wgrad that the fp16x2-split 3x3 kernel serves (the ones that can return
+    dy_sums as a by-product); h, w: the conv's output map."""
+    return (ksize == 3 and stride == 1 and not upsample and (c0 + c1) % 32 == 0 and cout % 64 == 0 and w % 32 == 0 and h % 2 == 0
+            and (c1 == 0 or c0 % 32 == 0))
+
+
 def conv_wgrad(src0, dy, dw, src1=None, ksize=3, stride=1, upsample=False, gn_scale_shift=None, silu=False,
                direct=False, cout=None, dy_coff=0, dy_sums=None, dy_sums_stride=0):
     """dw[cout][cin][k][k] += wgrad; the activation is recomputed from (src, gn_scale_shift).  Channel-blocked 16-bit
@@ -402,7 +409,7 @@ def conv_wgrad(src0, dy, dw, src1=None, ksize=3, stride=1, upsample=False, gn_sc
     a.dy, a.gn_scale_shift, a.silu = _lib.ptr(dy), _lib.ptr(gn_scale_shift), int(silu)
     a.dy_ctotal, a.dy_coff = dy_c, dy_coff
     a.dw, a.force_direct = _lib.ptr(dw), int(direct)
-    if dy_sums is not None:   # 16-bit kernel only: per-(n, cout) sums of dy as a by-product (bias / temb gradients)
+    if dy_sums is not None:   # per-(n, cout) sums of dy as a by-product (bias / temb gradients): see wgrad*_supported
         a.dy_sums, a.dy_sums_stride = dy_sums.data_ptr(), int(dy_sums_stride or dy_sums.stride(0))
     lib = _lib.load()
     need = C.c_size_t()

@@ -342,7 +342,9 @@ typedef struct {
                                    stride-1 convs with (c0 + c1) % 64 == 0, c0 % 64 == 0 when c1 > 0, cout % 64 == 0,
                                    dy_ctotal % 8 == 0 and dy_coff % 64 == 0, wout % 32 == 0, hout % 2 == 0; anything else is
                                    DSG_ERR_UNSUPPORTED_SHAPE (convert with dsg_layout_convert_dt and use the fp32 form). */
-  float* dy_sums;               /* optional, 16-bit form only: out[n * dy_sums_stride + co] = sum over pixels of dY[n][co] (this
+  float* dy_sums;               /* optional; the 16-bit form, and the fp32 form where the split 3x3 kernel serves it (stride 1,
+                                   cin % 32 == 0, cout % 64 == 0, wout % 32 == 0, hout % 2 == 0; DSG_ERR_INVALID_ARG
+                                   otherwise): out[n * dy_sums_stride + co] = sum over pixels of dY[n][co] (this
                                    conv's cout channels), the bias / time-embedding gradient -- a by-product of the dY tiles
                                    the kernel stages anyway (no pass of its own over dY: dsg_channel_sums_blocked) */
   int32_t dy_sums_stride;       /* 0 = cout */
