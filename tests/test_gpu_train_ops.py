@@ -206,5 +206,33 @@ def test_wgrad_split_path_random_shapes(case):
     d = lambda t: None if t is None else t.detach().to(DEV)
     ss = ops.gn_scale_shift(d(x0), d(gamma), d(beta), 8, 1e-5, src1=d(x1)) if gn else None
     dw = torch.zeros_like(wt.detach()).to(DEV)
-    ops.conv_wgrad(d(x0), d(dy), dw, src1=d(x1), ksize=3, gn_scale_shift=ss, silu=gn)
+    # the split kernel also returns sum over pixels of dY per (n, cout) -- the bias / time-embedding gradients -- into a
+    # strided table (column 0 is left alone); a shape it does not serve must refuse the request, not ignore it
+    byp = ops.wgrad_h2_supported(c0, c1, cout, h, w)
+    sums = torch.full((batch, cout + 1), 7.0, device=DEV)
+    kw = dict(dy_sums=sums[:, 1:], dy_sums_stride=sums.stride(0))
+    if byp:
+        ops.conv_wgrad(d(x0), d(dy), dw, src1=d(x1), ksize=3, gn_scale_shift=ss, silu=gn, **kw)
+        want = dy.double().sum((2, 3))
+        assert torch.allclose(sums[:, 1:].cpu().double(), want, rtol=0, atol=2e-5 * float(want.abs().max()))
+        assert bool((sums[:, 0] == 7.0).all())
+    else:
+        with pytest.raises(RuntimeError):
+            ops.conv_wgrad(d(x0), d(dy), dw.clone(), src1=d(x1), ksize=3, gn_scale_shift=ss, silu=gn, **kw)
+        ops.conv_wgrad(d(x0), d(dy), dw, src1=d(x1), ksize=3, gn_scale_shift=ss, silu=gn)
     _close(dw, wt.grad, rel=3e-5, ab=3e-5)
+
+
+def test_wgrad_dy_sums_refused_where_not_a_by_product():
+    """dy_sums is a by-product of the split 3x3 kernel (and of the 16-bit one); a call another kernel serves reports
+    the request as unsupported instead of leaving the table unwritten."""
+    x = _t(61, (2, 64, 8, 32)).to(DEV)
+    dy = _t(62, (2, 64, 8, 32)).to(DEV)
+    dw = torch.zeros(64, 64, 1, 1, device=DEV)
+    sums = torch.zeros(2, 64, device=DEV)
+    assert not ops.wgrad_h2_supported(64, 0, 64, 8, 32, ksize=1)
+    with pytest.raises(RuntimeError):
+        ops.conv_wgrad(x, dy, dw, ksize=1, dy_sums=sums, dy_sums_stride=sums.stride(0))
+    ops.conv_wgrad(x, dy, dw, ksize=1)
+    want = torch.einsum("nohw,nchw->oc", dy.double().cpu(), x.double().cpu())[:, :, None, None]
+    _close(dw, want.float(), rel=3e-5, ab=3e-5)
