@@ -739,6 +739,293 @@ static int launch_wgrad_h2(WgradP p, size_t ws_bytes, hipStream_t st, float* dy_
 }
 
 // ---------------------------------------------------------------------------------------------------
+// Pointwise (1x1) weight gradient on the same fp16x2 split: dW[co][ci] = sum over (n, pixel) of dY[co][px] * A[ci][px].
+// Both operands are pixel-contiguous in [N, C, H, W], so a k-group of 8 is 8 consecutive pixels on either side and no
+// shifted copies exist: a stage is 64 pixels of one image, TM ci x TN co per workgroup (128 x 128: wave w owns the
+// 64 x 64 quarter (w >> 1, w & 1), four accumulator tile pairs; 64 x 64 for the channel counts 128 does not divide).
+// With one tap the staging (affine, split, LDS write: ~7 VALU per element) weighs as much as the MFMAs, so the tile is
+// as large as the register file allows -- every A row is staged cout / TN times, every dY row cin / TM times.  The
+// (n, pixel) sequence is cut into gridDim.y runs; partial slabs [ci][co] and the fixed-order reduce as above.
+// No 1x1 conv of the network has SiLU on its input (shortcuts and to_out read raw tensors, qkv the normalised one);
+// the flag is honoured all the same.
+// ---------------------------------------------------------------------------------------------------
+constexpr int WP_STR = 64 + 8;  // halfs per (piece, channel): 64 pixels + 16 bytes of padding
+
+__device__ __forceinline__ void wsplit2(float v0, float v1, unsigned& hi, unsigned& lo) {
+  const _Float16 a0 = (_Float16)v0, a1 = (_Float16)v1;
+  const _Float16 b0 = (_Float16)((v0 - (float)a0) * 2048.0f), b1 = (_Float16)((v1 - (float)a1) * 2048.0f);
+  hi = (unsigned)__builtin_bit_cast(unsigned short, a0) | ((unsigned)__builtin_bit_cast(unsigned short, a1) << 16);
+  lo = (unsigned)__builtin_bit_cast(unsigned short, b0) | ((unsigned)__builtin_bit_cast(unsigned short, b1) << 16);
+}
+
+// grid = (runs, ci blocks x co blocks); p.ci_blocks = cin / TM.  The run index is the fast one: consecutive workgroups
+// go to different XCDs, so each XCD's L2 holds ITS pixel runs of A and dY once and serves every (ci, co) tile pair of
+// them (with the pair index fast, every XCD pulled all of dY through its own L2)
+template <int MI, int NJ>
+__global__ __launch_bounds__(256, 1) void conv_wgrad_h2_pw_kernel(WgradP p) {
+  constexpr int TM = 64 * MI, TN = 64 * NJ;
+  constexpr int A_HALFS = 2 * TM * WP_STR, D_HALFS = 2 * TN * WP_STR, BUF_HALFS = A_HALFS + D_HALFS;  // [piece][channel][72]
+  // staging items per thread: (channel row + 32 j; pixels 4 q .. 4 q + 3 and 32 + 4 q .. of the stage, q = tid & 7): a
+  // 16-byte load instruction then covers whole 128-byte lines (eight consecutive pixels per lane made every instruction
+  // touch twice the lines it used: the L1 was the bound, 419 -> 2xx us on the 1024 -> 512 layer at B=64)
+  constexpr int NA = TM / 32, ND = TN / 32, NI = NA + ND;
+  static_assert(NI % 4 == 0, "items are dealt over the four k-steps of a stage");
+  extern __shared__ __attribute__((aligned(16))) unsigned char wsm[];
+  _Float16* lds = reinterpret_cast<_Float16*>(wsm);
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int half = lane >> 5, l31 = lane & 31;
+  const int wci = wave >> 1, wco = wave & 1;
+  const int cib = blockIdx.y % p.ci_blocks, cob = blockIdx.y / p.ci_blocks;
+  const int ci0 = cib * TM, co0 = cob * TN;
+  const int plane = p.hin * p.win;
+  const int spi = plane >> 6;  // stages per image
+  const int total = p.n * spi;
+  const int per = (total + (int)gridDim.x - 1) / (int)gridDim.x;
+  const int s0 = blockIdx.x * per, s1 = min(total, s0 + per);
+  const bool has_ss = p.ss != nullptr;
+  const bool do_silu = has_ss && p.silu;
+  const int row = tid >> 3, oct = tid & 7;
+
+  const float* abase[NA];
+  size_t astride[NA];
+#pragma unroll
+  for (int j = 0; j < NA; ++j) {
+    const int ci = ci0 + row + 32 * j;
+    const bool in0 = ci < p.c0;
+    abase[j] = (in0 ? p.src0 + (size_t)ci * plane : p.src1 + (size_t)(ci - p.c0) * plane) + oct * 4;
+    astride[j] = (size_t)(in0 ? p.c0 : p.c1) * plane;
+  }
+  const float* dbase = p.dy + ((size_t)p.dy_coff + co0 + row) * plane + oct * 4;
+  const size_t dstride = (size_t)p.dy_ctotal * plane;
+
+  float4 xa[NA][2], xd[ND][2];
+  float sca[NA], sha[NA];
+  int ln = 0, lq = 0, lst = 0;  // (image, stage within it, stage index) of the loads issued next; never past the run
+  auto load_a = [&](int j) {
+    const float* q = abase[j] + (size_t)ln * astride[j] + (lq << 6);
+    xa[j][0] = *reinterpret_cast<const float4*>(q);
+    xa[j][1] = *reinterpret_cast<const float4*>(q + 32);
+    if (has_ss) {
+      const float2 s2 = *reinterpret_cast<const float2*>(p.ss + ((size_t)ln * p.cin + ci0 + row + 32 * j) * 2);
+      sca[j] = s2.x;
+      sha[j] = s2.y;
+    }
+  };
+  auto load_d = [&](int j) {
+    const float* q = dbase + (size_t)ln * dstride + (size_t)(32 * j) * plane + (lq << 6);
+    xd[j][0] = *reinterpret_cast<const float4*>(q);
+    xd[j][1] = *reinterpret_cast<const float4*>(q + 32);
+  };
+  auto advance = [&]() {
+    if (lst + 1 < s1) {
+      ++lst;
+      if (++lq == spi) {
+        lq = 0;
+        ++ln;
+      }
+    }
+  };
+  auto act = [&](float x, int j) {
+    if (has_ss) {
+      x = x * sca[j] + sha[j];
+      if (do_silu) x = silu_fast_b(x);
+    }
+    return x;
+  };
+  auto commit_a = [&](int j, int par) {
+    uint2 h0, l0, h1, l1;
+    wsplit2(act(xa[j][0].x, j), act(xa[j][0].y, j), h0.x, l0.x);
+    wsplit2(act(xa[j][0].z, j), act(xa[j][0].w, j), h0.y, l0.y);
+    wsplit2(act(xa[j][1].x, j), act(xa[j][1].y, j), h1.x, l1.x);
+    wsplit2(act(xa[j][1].z, j), act(xa[j][1].w, j), h1.y, l1.y);
+    _Float16* d = lds + par * BUF_HALFS + (row + 32 * j) * WP_STR + oct * 4;
+    *reinterpret_cast<uint2*>(d) = h0;
+    *reinterpret_cast<uint2*>(d + 32) = h1;
+    *reinterpret_cast<uint2*>(d + TM * WP_STR) = l0;
+    *reinterpret_cast<uint2*>(d + TM * WP_STR + 32) = l1;
+  };
+  auto commit_d = [&](int j, int par) {
+    uint2 h0, l0, h1, l1;
+    wsplit2(xd[j][0].x, xd[j][0].y, h0.x, l0.x);
+    wsplit2(xd[j][0].z, xd[j][0].w, h0.y, l0.y);
+    wsplit2(xd[j][1].x, xd[j][1].y, h1.x, l1.x);
+    wsplit2(xd[j][1].z, xd[j][1].w, h1.y, l1.y);
+    _Float16* d = lds + par * BUF_HALFS + A_HALFS + (row + 32 * j) * WP_STR + oct * 4;
+    *reinterpret_cast<uint2*>(d) = h0;
+    *reinterpret_cast<uint2*>(d + 32) = h1;
+    *reinterpret_cast<uint2*>(d + TN * WP_STR) = l0;
+    *reinterpret_cast<uint2*>(d + TN * WP_STR + 32) = l1;
+  };
+
+  wf32x16 acc_hi[MI][NJ], acc_lo[MI][NJ];
+#pragma unroll
+  for (int i = 0; i < MI; ++i)
+#pragma unroll
+    for (int j = 0; j < NJ; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        acc_hi[i][j][r] = 0.f;
+        acc_lo[i][j][r] = 0.f;
+      }
+
+  if (s0 < s1) {  // stage s0 into LDS buffer 0, stage s0 + 1 into registers
+    ln = s0 / spi;
+    lq = s0 - ln * spi;
+    lst = s0;
+#pragma unroll
+    for (int j = 0; j < NA; ++j) load_a(j);
+#pragma unroll
+    for (int j = 0; j < ND; ++j) load_d(j);
+#pragma unroll
+    for (int j = 0; j < NA; ++j) commit_a(j, 0);
+#pragma unroll
+    for (int j = 0; j < ND; ++j) commit_d(j, 0);
+    advance();
+#pragma unroll
+    for (int j = 0; j < NA; ++j) load_a(j);
+#pragma unroll
+    for (int j = 0; j < ND; ++j) load_d(j);
+    advance();
+  }
+  __syncthreads();
+
+  const _Float16* a_lane = lds + (wci * 32 * MI + l31) * WP_STR + half * 8;
+  const _Float16* d_lane = lds + A_HALFS + (wco * 32 * NJ + l31) * WP_STR + half * 8;
+  for (int s = s0; s < s1; ++s) {
+    const int par = (s - s0) & 1;
+    const _Float16* al = a_lane + par * BUF_HALFS;
+    const _Float16* dl = d_lane + par * BUF_HALFS;
+    // operands one k-step ahead in a register double buffer (as in the 3x3 kernel: the reads of k-step kk + 1 precede
+    // kk's staging writes in program order, so kk's MFMAs wait for registers only)
+    whalf8 fa[2][MI][2], fb[2][NJ][2];
+    auto frags = [&](int kk, int fp) {
+#pragma unroll
+      for (int i = 0; i < MI; ++i) {
+        fa[fp][i][0] = *reinterpret_cast<const whalf8*>(al + i * 32 * WP_STR + kk * 16);
+        fa[fp][i][1] = *reinterpret_cast<const whalf8*>(al + (TM + i * 32) * WP_STR + kk * 16);
+      }
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) {
+        fb[fp][j][0] = *reinterpret_cast<const whalf8*>(dl + j * 32 * WP_STR + kk * 16);
+        fb[fp][j][1] = *reinterpret_cast<const whalf8*>(dl + (TN + j * 32) * WP_STR + kk * 16);
+      }
+    };
+    frags(0, 0);
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+      __builtin_amdgcn_sched_barrier(0);
+      if (kk < 3) frags(kk + 1, (kk + 1) & 1);
+      // the next stage's items (held in registers) -> the other buffer, NI / 4 per k-step; each item's registers are
+      // refilled for the stage after it at once
+#pragma unroll
+      for (int it = kk * (NI / 4); it < (kk + 1) * (NI / 4); ++it) {
+#ifndef PW_ABL_NOSTAGE
+        if (it < NA) {
+#ifndef PW_ABL_NOCOMMIT
+          commit_a(it, par ^ 1);
+#endif
+#ifndef PW_ABL_NOLOAD
+          load_a(it);
+#endif
+        } else {
+#ifndef PW_ABL_NOCOMMIT
+          commit_d(it - NA, par ^ 1);
+#endif
+#ifndef PW_ABL_NOLOAD
+          load_d(it - NA);
+#endif
+        }
+#endif
+      }
+      const int fp = kk & 1;
+#pragma unroll
+      for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+          acc_hi[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[fp][i][0], fb[fp][j][0], acc_hi[i][j], 0, 0, 0);
+          acc_lo[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[fp][i][0], fb[fp][j][1], acc_lo[i][j], 0, 0, 0);
+          acc_lo[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[fp][i][1], fb[fp][j][0], acc_lo[i][j], 0, 0, 0);
+        }
+#pragma unroll
+      for (int m = 0; m < 3 * MI * NJ; ++m) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x002, 8, 0);
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    advance();
+    __syncthreads();
+  }
+
+  // epilogue: D[ci][co = l31] of every tile pair -> this run's slab [ci][co]
+  float* wsb = p.ws + (size_t)blockIdx.x * p.cin_pad * p.cout_pad;
+#pragma unroll
+  for (int i = 0; i < MI; ++i)
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+      const int co = co0 + (wco * NJ + j) * 32 + l31;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int ci = ci0 + (wci * MI + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+        wsb[(size_t)ci * p.cout_pad + co] = acc_hi[i][j][r] + acc_lo[i][j][r] * (1.0f / 2048.0f);
+      }
+    }
+}
+
+static bool wgrad_h2_pw_eligible(int cin, int c0, int c1, int cout, int ks, int stride, int ups, int plane) {
+  (void)c0; (void)c1;
+  return g_wgrad_h2 && ks == 1 && stride == 1 && ups == 0 && cin % 64 == 0 && cout % 64 == 0 && plane % 64 == 0;
+}
+
+// (tile, runs) of the pointwise split kernel: 128 x 128 tiles where both channel counts allow, about one workgroup per
+// CU in all, at least four stages per run
+static void wgrad_h2_pw_plan(int cin, int cout, int n, int plane, int* big, int* runs) {
+  *big = (cin % 128 == 0 && cout % 128 == 0) ? 1 : 0;
+  const int t = *big ? 128 : 64;
+  const int pairs = (cin / t) * (cout / t);
+  const int total = n * (plane / 64);
+  int r = std::max(1, std::min(std::max(1, (*big ? 256 : 512) / pairs), std::max(1, total / 4)));  // (64 x 64 tiles: two per CU)
+  if (r > 8) r = r / 8 * 8;  // (a multiple of the 8 XCDs, never more workgroups than CUs)
+  *runs = std::min(r, std::max(1, total));
+}
+
+static int launch_wgrad_h2_pw(WgradP p, size_t ws_bytes, hipStream_t st) {
+  int big, runs;
+  const int plane = p.hin * p.win;
+  wgrad_h2_pw_plan(p.cin, p.cout, p.n, plane, &big, &runs);
+  const int t = big ? 128 : 64;
+  p.ci_blocks = p.cin / t;
+  const int pairs = p.ci_blocks * (p.cout / t);
+  p.cin_pad = p.cin;
+  p.cout_pad = p.cout;
+  const size_t need = (size_t)runs * p.cin_pad * p.cout_pad * sizeof(float);
+  if (p.ws == nullptr || ws_bytes < need)
+    return fail(DSG_ERR_WORKSPACE_TOO_SMALL, "dsg_conv2d_wgrad: workspace %zu bytes < required %zu", ws_bytes, need);
+  static bool raised = false;
+  if (!raised) {
+    DSG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wgrad_h2_pw_kernel<2, 2>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    DSG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wgrad_h2_pw_kernel<1, 1>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    raised = true;
+  }
+  int pi = -1;
+  if (prof_on())
+    pi = prof_begin(5, 2.0 * p.n * plane * (double)p.cout * p.cin,
+                    4.0 * ((double)p.n * p.cin * plane + (double)p.n * p.cout * plane), st);
+  const size_t lds = (size_t)2 * 2 * 2 * t * WP_STR * 2;  // 2 buffers x (A + dY) x 2 pieces x t rows x 72 halfs x 2 bytes
+  if (big) hipLaunchKernelGGL((conv_wgrad_h2_pw_kernel<2, 2>), dim3(runs, pairs), dim3(256), lds, st, p);
+  else hipLaunchKernelGGL((conv_wgrad_h2_pw_kernel<1, 1>), dim3(runs, pairs), dim3(256), lds, st, p);
+  DSG_LAUNCH_CHECK();
+  launch_wgrad_reduce(p.ws, runs, 1, p.cin, p.cout, p.cin_pad, p.cout_pad, p.dw, st);
+  prof_end(pi, st);
+  DSG_LAUNCH_CHECK();
+  return DSG_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------
 // Weight gradient of the mixed-precision tape: x and dY are channel-blocked 16-bit tensors [N][C/8][H][W][8] (bf16 or
 // fp16), one MFMA per product, fp32 accumulate.
 //
@@ -1112,6 +1399,11 @@ static size_t wgrad_ws_bytes(int cin, int cout, int ks, int stride, int hout, in
     wgrad_h2_runs(cin, cout, n, hout, wout, &strips, &rsplit);
     need = std::max(need, (size_t)strips * rsplit * (9 * (size_t)cin * cout + cout) * sizeof(float));  // + the dY-sum rows
   }
+  if (wgrad_h2_pw_eligible(cin, cin, 0, cout, ks, stride, 0, hout * wout)) {
+    int big, runs;
+    wgrad_h2_pw_plan(cin, cout, n, hout * wout, &big, &runs);
+    need = std::max(need, (size_t)runs * cin * cout * sizeof(float));
+  }
   return need;
 }
 
@@ -1165,6 +1457,7 @@ DSG_API int dsg_conv2d_wgrad(const dsg_conv_wgrad_args* a, void* stream) {
     if (k == 3 && s == 1 && u == 0) return small_ci ? launch_wgrad<3, 1, 0, 1>(p, a->workspace_bytes, st) : launch_wgrad<3, 1, 0, 2>(p, a->workspace_bytes, st);
     if (k == 3 && s == 1 && u == 1) return small_ci ? launch_wgrad<3, 1, 1, 1>(p, a->workspace_bytes, st) : launch_wgrad<3, 1, 1, 2>(p, a->workspace_bytes, st);
     if (k == 3 && s == 2) return launch_wgrad<3, 2, 0, 1>(p, a->workspace_bytes, st);
+    if (wgrad_h2_pw_eligible(p.cin, p.c0, p.c1, p.cout, k, s, u, p.hin * p.win)) return launch_wgrad_h2_pw(p, a->workspace_bytes, st);
     if (k == 1 && s == 1 && u == 0) return small_ci ? launch_wgrad<1, 1, 0, 1>(p, a->workspace_bytes, st) : launch_wgrad<1, 1, 0, 2>(p, a->workspace_bytes, st);
   }
   DSG_CHECK_ARG(a->dy_sums == nullptr, "dsg_conv2d_wgrad: dy_sums given but the split kernels do not serve this call");

@@ -236,3 +236,34 @@ def test_wgrad_dy_sums_refused_where_not_a_by_product():
     ops.conv_wgrad(x, dy, dw, ksize=1)
     want = torch.einsum("nohw,nchw->oc", dy.double().cpu(), x.double().cpu())[:, :, None, None]
     _close(dw, want.float(), rel=3e-5, ab=3e-5)
+
+
+PW_CASES = [
+    # c0, c1, cout, h, w, batch, norm (GroupNorm affine on the input, no SiLU: the qkv projections), dY channel window
+    (128, 0, 128, 8, 16, 3, False, None),      # 128 x 128 tiles, one run per stage pair
+    (256, 128, 128, 16, 16, 2, False, None),   # concatenated sources, three ci blocks
+    (96, 32, 64, 8, 32, 3, False, None),       # 64 x 64 tiles, sources meet inside a tile
+    (128, 0, 128, 4, 32, 5, True, (384, 128)),  # normalised input, dY = channels [128, 256) of a fused [N, 384, L] tensor
+    (192, 0, 64, 32, 32, 2, True, None),
+]
+
+
+@pytest.mark.parametrize("case", PW_CASES, ids=lambda c: "c%d+%d_o%d_%dx%d_b%d" % c[:6])
+def test_wgrad_pointwise_split_path(case):
+    """1x1 weight gradient on the fp16x2 split (pixel runs, 128- / 64-channel tiles) vs fp64 einsum."""
+    c0, c1, cout, h, w, batch, norm, window = case
+    cin = c0 + c1
+    x0, x1 = _t(71, (batch, c0, h, w)), (_t(72, (batch, c1, h, w)) if c1 else None)
+    ctot, coff = window if window else (cout, 0)
+    dy = _t(73, (batch, ctot, h, w))
+    xin = torch.cat([x0, x1], 1) if c1 else x0
+    gamma, beta = 1 + _t(75, (cin,), 0.1), _t(76, (cin,), 0.1)
+    a = F.group_norm(xin, 8, gamma, beta, 1e-5) if norm else xin
+    want = torch.einsum("nohw,nchw->oc", dy[:, coff:coff + cout].double(), a.double())[:, :, None, None].float()
+    d = lambda t: None if t is None else t.to(DEV)
+    ss = ops.gn_scale_shift(d(x0), d(gamma), d(beta), 8, 1e-5, src1=d(x1)) if norm else None
+    dw = torch.zeros(cout, cin, 1, 1, device=DEV)
+    ops.conv_wgrad(d(x0), d(dy), dw, src1=d(x1), ksize=1, gn_scale_shift=ss, silu=False, cout=cout, dy_coff=coff)
+    _close(dw, want, rel=3e-5, ab=3e-5)
+    ops.conv_wgrad(d(x0), d(dy), dw, src1=d(x1), ksize=1, gn_scale_shift=ss, silu=False, cout=cout, dy_coff=coff)
+    _close(dw, 2 * want, rel=3e-5, ab=6e-5)  # dw accumulates
