@@ -766,8 +766,7 @@ __global__ __launch_bounds__(256, 1) void conv_wgrad_h2_pw_kernel(WgradP p) {
   constexpr int TM = 64 * MI, TN = 64 * NJ;
   constexpr int A_HALFS = 2 * TM * WP_STR, D_HALFS = 2 * TN * WP_STR, BUF_HALFS = A_HALFS + D_HALFS;  // [piece][channel][72]
   // staging items per thread: (channel row + 32 j; pixels 4 q .. 4 q + 3 and 32 + 4 q .. of the stage, q = tid & 7): a
-  // 16-byte load instruction then covers whole 128-byte lines (eight consecutive pixels per lane made every instruction
-  // touch twice the lines it used: the L1 was the bound, 419 -> 2xx us on the 1024 -> 512 layer at B=64)
+  // 16-byte load instruction covers whole 128-byte lines
   constexpr int NA = TM / 32, ND = TN / 32, NI = NA + ND;
   static_assert(NI % 4 == 0, "items are dealt over the four k-steps of a stage");
   extern __shared__ __attribute__((aligned(16))) unsigned char wsm[];
@@ -921,23 +920,13 @@ __global__ __launch_bounds__(256, 1) void conv_wgrad_h2_pw_kernel(WgradP p) {
       // refilled for the stage after it at once
 #pragma unroll
       for (int it = kk * (NI / 4); it < (kk + 1) * (NI / 4); ++it) {
-#ifndef PW_ABL_NOSTAGE
         if (it < NA) {
-#ifndef PW_ABL_NOCOMMIT
           commit_a(it, par ^ 1);
-#endif
-#ifndef PW_ABL_NOLOAD
           load_a(it);
-#endif
         } else {
-#ifndef PW_ABL_NOCOMMIT
           commit_d(it - NA, par ^ 1);
-#endif
-#ifndef PW_ABL_NOLOAD
           load_d(it - NA);
-#endif
         }
-#endif
       }
       const int fp = kk & 1;
 #pragma unroll
