@@ -336,7 +336,11 @@ typedef struct {
   int32_t force_direct;         /* test hook: VALU reference kernel */
   void* workspace;              /* split-K partial sums, summed in a fixed order (deterministic) */
   size_t workspace_bytes;       /* >= dsg_conv2d_wgrad_workspace_bytes(args) */
-  int32_t compute_dtype;        /* dsg_dtype.  DSG_F32: fp32 [N, C, H, W] tensors as above.  DSG_BF16 / DSG_F16 (the mixed-
+  int32_t compute_dtype;        /* dsg_dtype.  DSG_F32: fp32 [N, C, H, W] tensors as above; stride-1 3x3 calls with cin % 32 == 0,
+                                   cout % 64 == 0, wout % 32 == 0, hout % 2 == 0 and 1x1 calls with cin % 64 == 0, cout % 64 == 0,
+                                   wout % 32 == 0, hout % 2 == 0 run on the fp16x2 split (both operands split into two fp16
+                                   pieces, three matrix-core products, fp32 accumulate: fp32-class accuracy), every other shape
+                                   on the exact f32 matrix-core / VALU kernels.  DSG_BF16 / DSG_F16 (the mixed-
                                    precision training tape): src0 / src1 / dy are channel-blocked [N, C/8, H, W, 8] tensors of
                                    that type, products run once on the 16-bit matrix cores, dw stays fp32.  Served: 3x3
                                    stride-1 convs with (c0 + c1) % 64 == 0, c0 % 64 == 0 when c1 > 0, cout % 64 == 0,
