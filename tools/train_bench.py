@@ -34,6 +34,10 @@ def step():
 for _ in range(2):
     step()
 torch.cuda.synchronize()
+dump = os.environ.get("PROF_DUMP")   # per-launch HIP-event records of the conv / weight-gradient kernels (csv)
+if dump:
+    from drivescenegen_amd import _lib
+    _lib.load().dsg_prof_enable(1)
 t0 = time.perf_counter()
 for _ in range(steps):
     loss = step()
@@ -42,3 +46,5 @@ dt = (time.perf_counter() - t0) / steps
 print(f"{dtype} batch {b}: {dt*1e3:.1f} ms/step, {b/dt:.1f} images/s, loss {float(loss.detach()):.4f}, "
       f"peak mem {torch.cuda.max_memory_allocated()/2**30:.1f} GiB, "
       f"~{3*352.98e9*b/dt/1e12:.1f} TF/s (3x fwd FLOPs)")
+if dump:
+    _lib.check(_lib.load().dsg_prof_dump(dump.encode()))
