@@ -772,7 +772,7 @@ __global__ __launch_bounds__(64 * NW, OCC * NW / 4) void conv_h2_kernel(ConvH2P 
   // of the descriptor's range) and count as zeros in the statistics
   const bool lane_ok = ox0 + l31 < p.wout;
 #ifdef DSG_H2_TIMING
-  unsigned long long rt_e[6] = {0, 0, 0, 0, 0, 0};
+  unsigned long long rt_e[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};  // (128-cout tiles mark four slabs; the record keeps the first two: its "stats tail" then holds slabs 2, 3)
 #define DSG_ET(i) do { __builtin_amdgcn_sched_barrier(0); rt_e[i] = __builtin_amdgcn_s_memrealtime(); __builtin_amdgcn_sched_barrier(0); } while (0)
 #else
 #define DSG_ET(i)
