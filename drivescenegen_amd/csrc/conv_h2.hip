@@ -290,6 +290,44 @@ __global__ void weight_pack_kernel(const float* __restrict__ w, unsigned short* 
   }
 }
 
+// Kinds 0 and 3 of a 3x3 weight, one thread per (k, n) pair: it reads the pair's nine taps -- 36 contiguous bytes; the
+// eight k (kind 0) or eight n (kind 3) neighbours of a wave make 288-byte runs, every fetched line is used whole -- and
+// writes nine (x pieces) 16-bit values, each of them one of 64 consecutive ones of the wave (128-byte stores).  The
+// one-thread-per-output-value kernel above fetched every line nine times, 4 bytes of 36 at a time (weights are re-packed
+// after every optimizer step: 138 launches per training step).
+__global__ void weight_pack3x3_kernel(const float* __restrict__ w, unsigned short* __restrict__ dst, int cout_w, int cin_w,
+                                      int kind, int dt, int n_pad, int n_off) {
+  const int kdim = kind == 3 ? cout_w : cin_w, ndim = kind == 3 ? cin_w : cout_w;
+  const int nq = kdim / 16, np = dt == 0 ? 2 : 1;
+  const int64_t total = (int64_t)nq * 2 * ndim * 8;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int j = (int)(i % 8);
+    int64_t r = i / 8;
+    const int nn = (int)(r % ndim);
+    r /= ndim;
+    const int g = (int)(r % 2);
+    const int q = (int)(r / 2);
+    const int kk = q * 16 + g * 8 + j;
+    const float* wp = w + (kind == 0 ? ((int64_t)nn * cin_w + kk) : ((int64_t)kk * cin_w + nn)) * 9;
+    float v[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t) v[t] = wp[t];
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) {
+      const float x = v[kind == 0 ? tap : 8 - tap];
+      const int64_t at = (((((int64_t)q * np + 0) * 9 + tap) * 2 + g) * n_pad + n_off + nn) * 8 + j;
+      if (dt == 0) {
+        const _Float16 h1 = (_Float16)x;
+        const _Float16 h2 = (_Float16)((x - (float)h1) * 2048.0f);
+        dst[at] = __builtin_bit_cast(unsigned short, h1);
+        dst[at + (int64_t)9 * 2 * n_pad * 8] = __builtin_bit_cast(unsigned short, h2);
+      } else {
+        dst[at] = cvt16(x, dt);
+      }
+    }
+  }
+}
+
 }  // namespace dsg
 
 static int pack_dims(int32_t cout, int32_t cin, int32_t ksize, int32_t kind, int32_t dtype, int32_t n_total,
@@ -327,6 +365,14 @@ DSG_API int dsg_conv_weight_pack(const float* w_oihw, void* dst, int32_t cout, i
   if (rc != DSG_OK) return rc;
   DSG_CHECK_ARG(n_off >= 0 && n_off + ndim <= (n_total ? n_total : ndim), "dsg_conv_weight_pack: column window out of range");
   DSG_CHECK_ARG((kind == 0 || kind == 3) || (n_total == 0 && n_off == 0), "dsg_conv_weight_pack: column windows are for kinds 0 and 3");
+  if (ksize == 3 && (kind == 0 || kind == 3)) {
+    const int64_t pairs = (int64_t)kdim * ndim;
+    hipLaunchKernelGGL(dsg::weight_pack3x3_kernel, dim3((unsigned)std::min<int64_t>(dsg::cdiv64(pairs, 256), 4096)), dim3(256), 0,
+                       static_cast<hipStream_t>(stream), w_oihw, static_cast<unsigned short*>(dst), cout, cin, kind, dtype, n_pad,
+                       n_off);
+    DSG_LAUNCH_CHECK();
+    return DSG_OK;
+  }
   const int64_t total = (int64_t)phases * (kdim / 16) * taps * 2 * ndim * 8;
   const int blocks = (int)std::min<int64_t>(dsg::cdiv64(total, 256), 4096);
   hipLaunchKernelGGL(dsg::weight_pack_kernel, dim3(blocks), dim3(256), 0, static_cast<hipStream_t>(stream), w_oihw,
