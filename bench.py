@@ -66,7 +66,7 @@ def gpu_leg(args, rank, world):
 
     def barrier():
         torch.cuda.synchronize(dev)
-        if world > 1:
+        if torch.distributed.is_initialized():
             torch.distributed.barrier()
         torch.cuda.synchronize(dev)
 
@@ -87,7 +87,7 @@ def gpu_leg(args, rank, world):
         x = step(args.warmup + i, x)
     barrier()
     dt = time.perf_counter() - t0
-    if world > 1:
+    if torch.distributed.is_initialized():
         tt = torch.tensor([dt], dtype=torch.float64, device=dev)
         torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
         dt = float(tt.item())
@@ -387,7 +387,8 @@ def main():
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
-    if world > 1:
+    # (DSG_FORCE_COLLECTIVES=1 under a launcher: the RCCL group, barrier and max-over-ranks also run at WORLD_SIZE 1)
+    if world > 1 or (os.environ.get("DSG_FORCE_COLLECTIVES") == "1" and "RANK" in os.environ):
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", 0)))
@@ -462,7 +463,7 @@ def main():
         if not args.no_cpu and world == 1:  # (rank 0 at N = 1 only: the other ranks of a multi-GPU run would wait for it)
             out["cpu_baseline"] = cpu_leg(args)
         print(json.dumps(out))
-    if world > 1:
+    if torch.distributed.is_initialized():
         torch.distributed.barrier()
         torch.distributed.destroy_process_group()
 

@@ -174,6 +174,12 @@ class AdamW(torch.optim.Optimizer):
 # ------------------------------------------------------------------------------------------------
 # data-parallel gradient averaging: reverse-order flat buckets, launched as they fill
 # ------------------------------------------------------------------------------------------------
+def _force_collectives() -> bool:
+    """DSG_FORCE_COLLECTIVES=1 under a launcher (RANK set): create the RCCL process group and issue every broadcast /
+    all-reduce / barrier of the data-parallel path even when WORLD_SIZE is 1, so that one GPU exercises the calls."""
+    return os.environ.get("DSG_FORCE_COLLECTIVES") == "1" and "RANK" in os.environ
+
+
 class GradBuckets:
     """All-reduce(mean) of a flat gradient slab in ~bucket_mb buckets.  ``ready(name)`` is called by the
     backward pass when a parameter's gradient is final; a bucket is launched asynchronously on the
@@ -183,6 +189,8 @@ class GradBuckets:
     def __init__(self, flat, offsets: dict, group=None, bucket_mb: float = 25.0):
         self.flat, self.group = flat, group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        # a one-rank RCCL communicator still runs every call below (DSG_FORCE_COLLECTIVES=1: the one-GPU hardware test)
+        self.active = self.world > 1 or (dist.is_initialized() and _force_collectives())
         names = sorted(offsets, key=lambda k: offsets[k][0])
         cap = int(bucket_mb * (1 << 20) / 4)
         self.buckets, self.of = [], {}
@@ -212,7 +220,7 @@ class GradBuckets:
         self.launch_order = []
 
     def ready(self, name):
-        if self.world == 1 or name in self.seen or name not in self.of:
+        if not self.active or name in self.seen or name not in self.of:
             return
         self.seen.add(name)
         i = self.of[name]
@@ -228,7 +236,7 @@ class GradBuckets:
         self.launch_order.append(i)
 
     def finish(self):
-        if self.world == 1:
+        if not self.active:
             return
         for i, left in enumerate(self.pending):  # parameters that got no gradient this step
             if left > 0:
@@ -287,7 +295,7 @@ class _ShardedLoader:
         seed = torch.zeros(1, dtype=torch.int64)
         if self.rank == 0:
             seed = torch.randint(0, 2 ** 62, (1,), dtype=torch.int64)  # global CPU generator, like RandomSampler
-        if self.world > 1 and dist.is_initialized():
+        if (self.world > 1 or _force_collectives()) and dist.is_initialized():
             if dist.get_backend() == "nccl":
                 dev_seed = seed.to(self.device)
                 dist.broadcast(dev_seed, src=0)
@@ -459,7 +467,8 @@ class Accelerator:
         self.world = int(os.environ.get("WORLD_SIZE", "1"))
         self.rank = int(os.environ.get("RANK", "0"))
         self.local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-        if self.world > 1 and not dist.is_initialized():
+        self.collectives = self.world > 1 or _force_collectives()
+        if self.collectives and not dist.is_initialized():
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
             os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
             torch.cuda.set_device(self.local_rank)
@@ -510,7 +519,7 @@ class Accelerator:
             self._log_file = None
 
     def wait_for_everyone(self):
-        if self.world > 1:
+        if self.collectives:
             dist.barrier()
 
     def unwrap_model(self, model):
@@ -524,7 +533,7 @@ class Accelerator:
                 self._model = o
                 if hasattr(o, "set_compute_dtype"):
                     o.set_compute_dtype(_MIXED[self.mixed_precision])
-                if self.world > 1:
+                if self.collectives:
                     for p in o.parameters():  # identical replicas: rank 0's initial weights
                         dist.broadcast(p.data, src=0)
                 out.append(o)
@@ -545,7 +554,7 @@ class Accelerator:
         yield
 
     def _ensure_buckets(self):
-        if self.world == 1 or self._model is None:
+        if not self.collectives or self._model is None:
             return None
         st = get_train_state(self._model)
         if self._buckets is None or self._buckets.flat.data_ptr() != st.grad_flat.data_ptr():
