@@ -454,6 +454,11 @@ __global__ void weight_relayout_kernel(const float* __restrict__ w, float* __res
 bool conv_h2_eligible(const dsg_conv_args* a, int hout, int wout);
 int conv_h2_launch(const dsg_conv_args* a, int hout, int wout, hipStream_t st);
 int conv_h2_stats_tiles(const dsg_conv_args* a, int hout, int wout);
+// conv_in.hip: fp32 [N,C<=8,H,W] image -> channel-blocked activations, every compute_dtype
+bool conv_in_eligible(const dsg_conv_args* a, int hout, int wout);
+int conv_in_stats_tiles(const dsg_conv_args* a, int hout, int wout);
+int conv_in_launch(const dsg_conv_args* a, int hout, int wout, hipStream_t st);
+void conv_in_set_enabled(int v);
 void conv_h2_set_enabled(int on);
 void conv_h2_set_rows(int r);
 void conv_h2_set_stats(int on);
@@ -724,6 +729,7 @@ int conv2d_fwd_impl(const dsg_conv_args* a, hipStream_t st, int force_direct) {
   p.tiles_x = (p.wout + TW - 1) / TW; p.tiles_y = p.hout / TH;
   DSG_CHECK_ARG(!(p.pool && ((p.hout | p.wout) & 1)), "dsg_conv2d_fwd: pool2 needs even output dims");
 
+  if (!force_direct && conv_in_eligible(a, p.hout, p.wout)) return conv_in_launch(a, p.hout, p.wout, st);
   if (!force_direct && conv_h2_eligible(a, p.hout, p.wout)) return conv_h2_launch(a, p.hout, p.wout, st);
   // (`weight`, the fp32 engine layout, may be NULL for a call the operand-image kernels serve: a training step re-lays
   // out every weight it passes here, and most calls never read it)
@@ -866,6 +872,10 @@ DSG_API int dsg_set_tuning(int32_t key, int32_t value) {
     dsg::conv_h2_set_pw_occ2(value);
     return DSG_OK;
   }
+  if (key == 21 && (value == 0 || value == 1)) {
+    dsg::conv_in_set_enabled(value);
+    return DSG_OK;
+  }
   if (key == 5 && (value == 0 || value == 1)) {
     dsg::conv_h2_set_stats(value);
     return DSG_OK;
@@ -880,7 +890,7 @@ DSG_API int dsg_conv2d_stats_tiles(const dsg_conv_args* a, int32_t* tiles) {
   const int hc = a->upsample ? 2 * a->hin : a->hin, wc = a->upsample ? 2 * a->win : a->win;
   const int pad = a->ksize / 2;
   const int hout = (hc + 2 * pad - a->ksize) / a->stride + 1, wout = (wc + 2 * pad - a->ksize) / a->stride + 1;
-  *tiles = dsg::conv_h2_stats_tiles(a, hout, wout);
+  *tiles = dsg::conv_in_eligible(a, hout, wout) ? dsg::conv_in_stats_tiles(a, hout, wout) : dsg::conv_h2_stats_tiles(a, hout, wout);
   return DSG_OK;
 }
 

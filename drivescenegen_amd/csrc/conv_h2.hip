@@ -213,7 +213,8 @@ void conv_h2_set_bm32(int v) { g_h2.bm32 = v != 0; if (v > 1) g_h2.bm32_min = v;
 void conv_h2_set_bm128(int v) { g_h2.bm128 = v; ++g_h2.epoch; }
 void conv_h2_set_splitk(int v) { g_h2.splitk = v; ++g_h2.epoch; }
 void conv_h2_set_ws2(int v) { g_h2.ws2 = v; ++g_h2.epoch; }
-int conv_h2_tuning_epoch() { return g_h2.epoch; }
+int conv_in_tuning_epoch();  // conv_in.hip: its on/off switch moves the plan's statistics buffers too
+int conv_h2_tuning_epoch() { return g_h2.epoch + conv_in_tuning_epoch(); }
 
 // ---------------------------------------------------------------------------------------------------------------
 // Weight packing: OIHW fp32 (the checkpoint layout) -> the kernel's operand image

@@ -443,7 +443,7 @@ struct Runner {
     act = T();
     T x0;
     x0.p = const_cast<float*>(xin); x0.c = cfg.in_channels; x0.h = cfg.sample_h; x0.w = cfg.sample_w;
-    T x = conv(x0, nullptr, h->conv_in, 1, 0, nullptr, 0, nullptr, nullptr);
+    T x = conv(x0, nullptr, h->conv_in, 1, 0, nullptr, 0, nullptr, nullptr, nullptr, true);  // (conv_in.hip leaves norm1's statistics)
     std::vector<T> skips;
     ensure_stats(x);  // (before the copy: the skip connection then carries them)
     skips.push_back(x);

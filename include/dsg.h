@@ -478,6 +478,8 @@ int dsg_prof_dump(const char* csv_path);
  *  19  split-K for grids of at most half the CUs (needs dsg_conv_args.splitk_ws): [1] | 0
  *  20  fp32-equivalent 3x3 convs with cin <= 128 on channel-blocked tensors: 8-row tiles with ONE weight slab in LDS,
  *      two workgroups per CU (grids of at least 512 workgroups): [1] | 0
+ *  21  conv_in (fp32 [N,C<=8,H,W] image -> channel-blocked result, 16 x 32 pixel tiles, cout % 32 == 0) on its own kernel
+ *      with built-in operand scaling and GroupNorm statistics (csrc/conv_in.hip): [1] | 0 = the exact f32-MFMA kernel
  *  15  stride-2 convs of channel-blocked tensors on the split path: [1] | 0 = the f32 MFMA kernel
  *  14  attention with head_dim 8 on the matrix cores (fp16x2 split): [1] | 0 = the VALU kernel */
 int dsg_set_tuning(int32_t key, int32_t value);
