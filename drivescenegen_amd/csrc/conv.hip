@@ -459,6 +459,10 @@ bool conv_in_eligible(const dsg_conv_args* a, int hout, int wout);
 int conv_in_stats_tiles(const dsg_conv_args* a, int hout, int wout);
 int conv_in_launch(const dsg_conv_args* a, int hout, int wout, hipStream_t st);
 void conv_in_set_enabled(int v);
+// conv_out.hip: normalised + activated channel-blocked activations -> fp32 [N,C<=8,H,W] image, every compute_dtype
+bool conv_out_eligible(const dsg_conv_args* a, int hout, int wout);
+int conv_out_launch(const dsg_conv_args* a, int hout, int wout, hipStream_t st);
+void conv_out_set_enabled(int v);
 void conv_h2_set_enabled(int on);
 void conv_h2_set_rows(int r);
 void conv_h2_set_stats(int on);
@@ -730,6 +734,7 @@ int conv2d_fwd_impl(const dsg_conv_args* a, hipStream_t st, int force_direct) {
   DSG_CHECK_ARG(!(p.pool && ((p.hout | p.wout) & 1)), "dsg_conv2d_fwd: pool2 needs even output dims");
 
   if (!force_direct && conv_in_eligible(a, p.hout, p.wout)) return conv_in_launch(a, p.hout, p.wout, st);
+  if (!force_direct && conv_out_eligible(a, p.hout, p.wout)) return conv_out_launch(a, p.hout, p.wout, st);
   if (!force_direct && conv_h2_eligible(a, p.hout, p.wout)) return conv_h2_launch(a, p.hout, p.wout, st);
   // (`weight`, the fp32 engine layout, may be NULL for a call the operand-image kernels serve: a training step re-lays
   // out every weight it passes here, and most calls never read it)
@@ -870,6 +875,10 @@ DSG_API int dsg_set_tuning(int32_t key, int32_t value) {
   }
   if (key == 11 && (value == 0 || value == 1)) {
     dsg::conv_h2_set_pw_occ2(value);
+    return DSG_OK;
+  }
+  if (key == 22 && (value == 0 || value == 1)) {
+    dsg::conv_out_set_enabled(value);
     return DSG_OK;
   }
   if (key == 21 && (value == 0 || value == 1)) {

@@ -480,6 +480,8 @@ int dsg_prof_dump(const char* csv_path);
  *      two workgroups per CU (grids of at least 512 workgroups): [1] | 0
  *  21  conv_in (fp32 [N,C<=8,H,W] image -> channel-blocked result, 16 x 32 pixel tiles, cout % 32 == 0) on its own kernel
  *      with built-in operand scaling and GroupNorm statistics (csrc/conv_in.hip): [1] | 0 = the exact f32-MFMA kernel
+ *  22  conv_out (normalised channel-blocked source of <= 64 channels -> fp32 [N,C<=8,H,W] image, 16 x 32 pixel tiles) on its
+ *      own matrix-core kernel with per-output-channel weight scaling (csrc/conv_out.hip): [1] | 0 = the VALU / padded kernels
  *  15  stride-2 convs of channel-blocked tensors on the split path: [1] | 0 = the f32 MFMA kernel
  *  14  attention with head_dim 8 on the matrix cores (fp16x2 split): [1] | 0 = the VALU kernel */
 int dsg_set_tuning(int32_t key, int32_t value);

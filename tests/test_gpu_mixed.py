@@ -182,8 +182,10 @@ def test_conv_in_fp32_image_to_blocked16(mode, cin):
 @pytest.mark.parametrize("mode", ["bf16", "fp16"])
 @pytest.mark.parametrize("cout", [3, 4, 8])
 def test_conv_out_blocked16_to_fp32_image(mode, cout):
-    """conv_out: GroupNorm + SiLU folded in front, 16-bit blocked sources -> fp32 [N,C,H,W] (cout 8: matrix-core kernel
-    with a zero-padded cout tile; cout <= 4: the VALU kernel)."""
+    """conv_out: GroupNorm + SiLU folded in front, 16-bit blocked sources -> fp32 [N,C,H,W] on csrc/conv_out.hip: the
+    activated input and the weights are rounded once to the 16-bit type, as torch.autocast does for this conv
+    (tests/test_gpu_conv_out.py has the kernel's own cases; with tuning key 22 off: cout 8 on the zero-padded matrix-core
+    kernel, cout <= 4 on the VALU kernel, which keeps the activated values in fp32)."""
     n, c, h, w = 2, 64, 32, 64
     xq = _rnd(_t(31, (n, c, h, w)), mode)
     wt = _t(32, (cout, c, 3, 3), 1.0 / np.sqrt(c * 9))
@@ -192,10 +194,10 @@ def test_conv_out_blocked16_to_fp32_image(mode, cout):
     b0 = _blk(xq, mode)
     ss = ops.gn_scale_shift_from_parts(ops.gn_channel_stats_blocked(b0, splits=4), gamma.to(DEV), beta.to(DEV), 32, 1e-5, h * w)
     act = F.silu(xq.double() * ss.cpu()[:, :, 0, None, None].double() + ss.cpu()[:, :, 1, None, None].double())
-    h2 = cout % 8 == 0
+    h2 = True
     ref = F.conv2d(_rnd(act.float(), mode).double() if h2 else act, _rnd(wt, mode).double() if h2 else wt.double(),
                    bias.double(), padding=1)
-    kw = dict(weight_h2=ops.pack_conv_weight(wt.to(DEV), ops.PACK_FWD, mode), weight_h2_stride=64) if h2 else {}
+    kw = dict(weight_h2=ops.pack_conv_weight(wt.to(DEV), ops.PACK_FWD, mode), weight_h2_stride=64) if cout % 8 == 0 else {}
     got = ops.conv2d_fused(b0, ops.relayout_conv_weight(wt.to(DEV)), bias.to(DEV), gn_scale_shift=ss, silu=True, cout=cout,
                            src_blocked=True, dst_blocked=False, compute_dtype=mode, **kw)
     assert got.dtype == torch.float32 and got.shape == (n, cout, h, w)
