@@ -98,7 +98,8 @@ def gpu_leg(args, rank, world):
         names = {0: "conv3x3_s1_mfma_f32", 1: "conv3x3_upsample_mfma_f32", 2: "conv3x3_s2_mfma_f32",
                  3: "conv1x1_mfma_f32", 4: "conv_direct_valu", 6: "conv3x3_s1_mfma_f16x2split",
                  7: "conv3x3_upsample_mfma_f16x2split", 8: "conv1x1_mfma_f16x2split",
-                 10: "conv3x3_s1_mfma_f16x2split_two_wg_per_cu"}
+                 10: "conv3x3_s1_mfma_f16x2split_two_wg_per_cu", 11: "conv_in_image_to_blocked",
+                 12: "conv_out_blocked_to_image"}
         for kid, nm in names.items():
             ms, fl, by, n = C.c_double(), C.c_double(), C.c_double(), C.c_int64()
             _lib.check(lib.dsg_prof_summary(kid, C.byref(ms), C.byref(fl), C.byref(by), C.byref(n)))
@@ -189,7 +190,8 @@ def mixed_leg(args, dtype="bf16"):
     dt = time.perf_counter() - t0
     assert torch.isfinite(x).all()
     rows = _prof_rows(lib, _lib, {26: "conv3x3_s1_mfma_16bit", 27: "conv3x3_upsample_mfma_16bit", 22: "conv3x3_s2_mfma_16bit",
-                                   28: "conv1x1_mfma_16bit", 0: "conv3x3_s1_mfma_f32", 4: "conv_direct_valu"})
+                                   28: "conv1x1_mfma_16bit", 0: "conv3x3_s1_mfma_f32", 4: "conv_direct_valu",
+                                   11: "conv_in_image_to_blocked", 12: "conv_out_blocked_to_image"})
     lib.dsg_prof_enable(0)
     del net
     flops_img = 353.58e9  # SURVEY 8d, cfg5 forward

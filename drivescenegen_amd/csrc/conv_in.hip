@@ -304,7 +304,7 @@ int conv_in_launch(const dsg_conv_args* a, int hout, int wout, hipStream_t st) {
   int pi = -1;
   if (prof_on()) {
     const double px = (double)a->n * hout * wout;
-    pi = prof_begin(a->compute_dtype ? 20 : 0, 2.0 * px * a->cout * a->c0 * 9,
+    pi = prof_begin(11, 2.0 * px * a->cout * a->c0 * 9,
                     4.0 * (px * a->c0 + 9.0 * a->c0 * a->cout) + (a->compute_dtype ? 2.0 : 4.0) * px * a->cout, st);
   }
   const bool ws2 = a->cout % 64 == 0;

@@ -258,7 +258,7 @@ int conv_out_launch(const dsg_conv_args* a, int hout, int wout, hipStream_t st) 
   int pi = -1;
   if (prof_on()) {
     const double px = (double)a->n * hout * wout;
-    pi = prof_begin(a->compute_dtype ? 24 : 4, 2.0 * px * a->cout * a->c0 * 9,
+    pi = prof_begin(12, 2.0 * px * a->cout * a->c0 * 9,
                     (a->compute_dtype ? 2.0 : 4.0) * px * a->c0 + 4.0 * (9.0 * a->c0 * a->cout + px * a->cout), st);
   }
   const int total = p.tiles_x * p.tiles_y * p.n;

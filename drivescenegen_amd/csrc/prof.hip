@@ -52,7 +52,7 @@ void prof_end(int idx, hipStream_t st) {
 }  // namespace dsg
 
 // Kernel classes: 0 conv3x3 stride-1 (plain or [x||skip] gather), 1 conv3x3 on nearest-x2 upsampled
-// input, 2 conv3x3 stride-2, 3 conv1x1, 4 direct (VALU) conv.
+// input, 2 conv3x3 stride-2, 3 conv1x1, 4 direct (VALU) conv, 11 conv_in.hip, 12 conv_out.hip (either mode).
 // on: 1 start (drops earlier records), 0 stop (drops records); 2 pause, 3 resume -- keep the records (bench.py
 // brackets only every n-th step of its timed region, so that the event records cost it next to nothing)
 DSG_API int dsg_prof_enable(int32_t on) {
