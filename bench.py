@@ -10,9 +10,10 @@ One "step" = one denoising step of the whole batch: dsg_unet_forward + dsg_ddim_
 inputs already resident in HBM.  Samples are independent, so ranks shard them with NO data-path
 collective (weak scaling: 16 samples per GPU); the only communication is the timing barrier / max.
 Rank 0 prints ONE JSON line, with
-  roofline     -- the dominant kernel (3x3 stride-1 implicit-GEMM conv on the f32 matrix cores):
-                  algorithmic FLOPs of its launches / their summed duration, from HIP events recorded on
-                  the launch stream inside the timed region (dsg_prof_*), against the 157.3 TF/s f32 peak;
+  roofline     -- the dominant kernel (3x3 stride-1 implicit-GEMM conv, fp32-equivalent as an fp16x2 split on the f16
+                  matrix cores): algorithmic FLOPs of its launches / their summed duration, from HIP events
+                  recorded on the launch stream inside the timed region (dsg_prof_*), against 2500 / 3 = 833 TF/s
+                  (the guide's dense f16 MFMA peak over the split's three products per MAC);
   cpu_baseline -- the torch-CPU oracle (oracle/, kind "port") timed on the host cores on a bounded
                   sample (a few steps at batch 2) of the same workload.
 """

@@ -8,6 +8,7 @@ from .unet import UNet2DModel  # noqa: F401
 from .schedulers import DDPMScheduler, DDIMScheduler  # noqa: F401
 from .pipelines import DDPMPipeline, DDIMPipeline, ImagePipelineOutput  # noqa: F401
 from .optimization import get_cosine_schedule_with_warmup  # noqa: F401
+from .train_loop import fit, notebook_launcher, sample_to_pil  # noqa: F401
 from .training import AdamW, Accelerator, GradBuckets, clip_grad_norm_, mse_loss  # noqa: F401
 
 __version__ = "0.1.0"

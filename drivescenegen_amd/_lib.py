@@ -158,6 +158,7 @@ SIGNATURES = {
     "dsg_clip_scale": [_vp, _i64, _vp, _f32, _vp],
     "dsg_adamw_step": [_vp, _vp, _vp, _vp, _i64, _f64, _f64, _f64, _f64, _f64, _i64, _vp, _f32, _vp],
     "dsg_resize_normalize_u8": [_vp, _i32, _i32, _i32, _i32, _vp, _i32, _i32, _f32, _f32, _vp],
+    "dsg_resize_normalize_f32": [_vp, _i32, _i32, _i32, _i32, _vp, _i32, _i32, _f32, _f32, _vp],
     "dsg_hist_u8": [_vp, _i32, _i32, _i32, _vp, _vp],
     "dsg_mask_lut_u8": [_vp, _i32, _i32, _i32, _i32, _i32, _vp, C.c_uint8, C.c_uint8, _vp, _vp],
     "dsg_prof_enable": [_i32],

@@ -13,8 +13,9 @@
 // cycles.  fp16 x fp16 products are exact in the fp32 accumulator; the scaled low-order products go to a
 // second accumulator so that nothing is lost to fp16's narrow exponent (the 2^11 pre-scale keeps the low
 // parts normal).  Measured error vs fp64 is at or below that of a sequential fp32 fmaf chain
-// (tests/test_gpu_ops.py::test_conv_h2_*).  Inputs must satisfy |x| < 65504 (GroupNorm/SiLU outputs and
-// residual-stream activations do).
+// (tests/test_gpu_ops.py::test_conv_h2_*).  Operands outside fp16's range are handled by the range guard: sources
+// without a norm in front are pre-scaled by the power of two of their per-image bound (ConvH2P::bound0 / bound1),
+// weights outside [2^-8, 3e4] send the conv to the exact f32-MFMA kernel (unet.hip: Conv::off_split).
 //
 // LDS images (per K-chunk of 16 channels, double-buffered; same bytes as the fp32 kernel's):
 //   X[piece 2][g 2][pos 10x34][8 halfs]   -- lane = pixel reads one 16-B fragment (k-group g = lane>>5)

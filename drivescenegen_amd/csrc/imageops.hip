@@ -13,11 +13,14 @@
 
 namespace dsg {
 
-// grid = (ceil(wo*ho/256), c, n)
-__global__ __launch_bounds__(256) void resize_normalize_u8_kernel(const uint8_t* __restrict__ src, int hs, int ws, int c,
-                                                                  float* __restrict__ dst, int ho, int wo,
-                                                                  float scale_h, float scale_w, float mean,
-                                                                  float inv_std) {
+// grid = (ceil(wo*ho/256), c, n).  SrcT = uint8_t: a decoded image, ToTensor's / 255 applied; float: the .pkl branch's
+// `fig_tensor` [H][W][C] (dataset.py:37-41), used as it is.
+template <typename SrcT>
+__global__ __launch_bounds__(256) void resize_normalize_kernel(const SrcT* __restrict__ src, int hs, int ws, int c,
+                                                               float* __restrict__ dst, int ho, int wo,
+                                                               float scale_h, float scale_w, float mean,
+                                                               float inv_std) {
+  constexpr bool U8 = sizeof(SrcT) == 1;
   const int pix = blockIdx.x * 256 + threadIdx.x;
   if (pix >= ho * wo) return;
   const int ci = blockIdx.y, n = blockIdx.z;
@@ -29,11 +32,12 @@ __global__ __launch_bounds__(256) void resize_normalize_u8_kernel(const uint8_t*
   const int y1 = min(y0 + 1, hs - 1), x1 = min(x0 + 1, ws - 1);
   const float ly1 = sy - (float)y0, lx1 = sx - (float)x0;
   const float ly0 = 1.f - ly1, lx0 = 1.f - lx1;
-  const uint8_t* sp = src + (size_t)n * hs * ws * c + ci;
-  const float v00 = (float)sp[((size_t)y0 * ws + x0) * c] / 255.0f;
-  const float v01 = (float)sp[((size_t)y0 * ws + x1) * c] / 255.0f;
-  const float v10 = (float)sp[((size_t)y1 * ws + x0) * c] / 255.0f;
-  const float v11 = (float)sp[((size_t)y1 * ws + x1) * c] / 255.0f;
+  const SrcT* sp = src + (size_t)n * hs * ws * c + ci;
+  auto at = [&](int y, int x) -> float {
+    const float v = (float)sp[((size_t)y * ws + x) * c];
+    return U8 ? v / 255.0f : v;
+  };
+  const float v00 = at(y0, x0), v01 = at(y0, x1), v10 = at(y1, x0), v11 = at(y1, x1);
   const float v = ly0 * (lx0 * v00 + lx1 * v01) + ly1 * (lx0 * v10 + lx1 * v11);
   dst[(((size_t)n * c + ci) * ho + oy) * wo + ox] = (v - mean) * inv_std;
 }
@@ -112,7 +116,19 @@ DSG_API int dsg_resize_normalize_u8(const uint8_t* src, int32_t n, int32_t hs, i
   DSG_CHECK_ARG(src && dst, "dsg_resize_normalize_u8: NULL pointer");
   DSG_CHECK_ARG(n > 0 && hs > 0 && ws > 0 && c > 0 && ho > 0 && wo > 0 && std != 0.f && n <= 65535 && c <= 65535,
                 "dsg_resize_normalize_u8: bad dims");
-  hipLaunchKernelGGL(dsg::resize_normalize_u8_kernel, dim3(dsg::cdiv(ho * wo, 256), c, n), dim3(256), 0,
+  hipLaunchKernelGGL(dsg::resize_normalize_kernel<uint8_t>, dim3(dsg::cdiv(ho * wo, 256), c, n), dim3(256), 0,
+                     static_cast<hipStream_t>(stream), src, hs, ws, c, dst, ho, wo, (float)hs / (float)ho,
+                     (float)ws / (float)wo, mean, 1.0f / std);
+  DSG_LAUNCH_CHECK();
+  return DSG_OK;
+}
+
+DSG_API int dsg_resize_normalize_f32(const float* src, int32_t n, int32_t hs, int32_t ws, int32_t c, float* dst,
+                                     int32_t ho, int32_t wo, float mean, float std, void* stream) {
+  DSG_CHECK_ARG(src && dst, "dsg_resize_normalize_f32: NULL pointer");
+  DSG_CHECK_ARG(n > 0 && hs > 0 && ws > 0 && c > 0 && ho > 0 && wo > 0 && std != 0.f && n <= 65535 && c <= 65535,
+                "dsg_resize_normalize_f32: bad dims");
+  hipLaunchKernelGGL(dsg::resize_normalize_kernel<float>, dim3(dsg::cdiv(ho * wo, 256), c, n), dim3(256), 0,
                      static_cast<hipStream_t>(stream), src, hs, ws, c, dst, ho, wo, (float)hs / (float)ho,
                      (float)ws / (float)wo, mean, 1.0f / std);
   DSG_LAUNCH_CHECK();

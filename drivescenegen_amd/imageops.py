@@ -18,25 +18,38 @@ import threading
 import numpy as np
 import torch
 
-from . import _lib
+from . import _lib, sharding
 
 
-def resize_normalize(images_u8: torch.Tensor, size, mean=0.5, std=0.5) -> torch.Tensor:
-    """uint8 [N, Hs, Ws, C] (GPU) -> fp32 [N, C, H, W] = Normalize(Resize(ToTensor(img)))."""
-    if not images_u8.is_cuda or images_u8.dtype != torch.uint8:
-        raise RuntimeError("resize_normalize: expects a uint8 GPU tensor [N, H, W, C] (no CPU fallback)")
-    n, hs, ws, c = images_u8.shape
-    out = torch.empty((n, c, size[0], size[1]), dtype=torch.float32, device=images_u8.device)
-    x = images_u8.contiguous()
+def resize_normalize(images: torch.Tensor, size, mean=0.5, std=0.5) -> torch.Tensor:
+    """[N, Hs, Ws, C] (GPU) -> fp32 [N, C, H, W] = Normalize(Resize(.)) of
+    uint8: a decoded image through ToTensor (/ 255)                         (dataset.py:43-45)
+    float32: the .pkl branch's `fig_tensor`, permuted HWC -> CHW and used as is  (dataset.py:37-41)"""
+    if not images.is_cuda or images.dtype not in (torch.uint8, torch.float32):
+        raise RuntimeError("resize_normalize: expects a uint8 or float32 GPU tensor [N, H, W, C] (no CPU fallback)")
+    n, hs, ws, c = images.shape
+    out = torch.empty((n, c, size[0], size[1]), dtype=torch.float32, device=images.device)
+    x = images.contiguous()
+    lib = _lib.load()
+    fn = lib.dsg_resize_normalize_u8 if x.dtype == torch.uint8 else lib.dsg_resize_normalize_f32
     with torch.cuda.device(x.device):
-        _lib.check(_lib.load().dsg_resize_normalize_u8(x.data_ptr(), n, hs, ws, c, _lib.ptr(out), size[0], size[1],
-                                                      float(mean), float(std), _lib.stream_ptr(x.device)))
+        _lib.check(fn(x.data_ptr(), n, hs, ws, c, _lib.ptr(out), size[0], size[1], float(mean), float(std),
+                      _lib.stream_ptr(x.device)))
     return out
 
 
 class GpuImageLoader:
-    """Iterates batches of normalised fp32 [B, C, H, W] GPU tensors from image files.  Host threads decode and
-    pin; the H2D copy runs on a side stream two batches ahead; resize + normalise is one HIP kernel."""
+    """Iterates batches of normalised fp32 [B, C, H, W] GPU tensors from the files ``Image_Dataset`` reads
+    (utils/datasets/dataset.py:15-50): PNG / any PIL image, or ``.pkl`` with a ``fig_tensor`` [H, W, C] float entry
+    (a pickle that is not a dict falls through to the next file, dataset.py:39-40).  Host threads decode into pinned
+    buffers; the H2D copy runs on a side stream `prefetch` batches ahead; permute + resize + normalise is one HIP kernel
+    (uint8 or float source).
+
+    Under data parallelism (`rank`, `world`) it follows accelerate's prepared loader exactly like
+    ``training._ShardedLoader`` (sharding.py): ONE shuffled order per epoch on every rank -- rank 0 draws the epoch's
+    seed, broadcasts it when a process group exists (`seed=None`), or all ranks derive it from `seed + epoch` -- rank r
+    takes batches r, r + W, ..., and a ragged tail is completed from the start of the order so that every rank runs
+    ``len(loader)`` full-size steps (a rank short of one batch would never join the last gradient all-reduce)."""
 
     def __init__(self, pattern_or_files, size, batch_size, shuffle=True, seed=0, device="cuda", prefetch=2,
                  rank=0, world=1, drop_last=False):
@@ -46,31 +59,41 @@ class GpuImageLoader:
         self.device = torch.device(device)
         self.prefetch, self.rank, self.world, self.drop_last = prefetch, rank, world, drop_last
         self.epoch = 0
+        self.epoch_seed = None
         self._copy_stream = None
 
     def __len__(self):
-        nb = len(self.files) // self.bs if self.drop_last else -(-len(self.files) // self.bs)
-        return -(-nb // self.world)
+        return sharding.steps_per_epoch(len(self.files), self.bs, self.world, self.drop_last)
 
     def _batches(self):
         idx = np.arange(len(self.files))
         if self.shuffle:
-            np.random.default_rng(self.seed + self.epoch).shuffle(idx)
-        bl = [idx[i:i + self.bs] for i in range(0, len(idx), self.bs)]
-        if self.drop_last and bl and len(bl[-1]) < self.bs:
-            bl.pop()
-        return [b for i, b in enumerate(bl) if i % self.world == self.rank]
+            self.epoch_seed = (sharding.broadcast_epoch_seed(self.rank, self.world, self.device) if self.seed is None
+                               else self.seed + self.epoch)
+            np.random.default_rng(self.epoch_seed).shuffle(idx)
+        return sharding.shard_batches(idx.tolist(), self.bs, self.rank, self.world, self.drop_last)
+
+    def _load_one(self, i):
+        """One file as an HWC array: uint8 for images, float32 for the .pkl branch."""
+        f = self.files[i % len(self.files)]
+        if f.lower().endswith(".pkl"):
+            with open(f, "rb") as fh:
+                dd = torch.load(fh, weights_only=False)
+            if not isinstance(dd, dict):
+                return self._load_one(i + 1)
+            return np.ascontiguousarray(dd["fig_tensor"][:, :, :].float().numpy())
+        from PIL import Image
+        a = np.asarray(Image.open(f))
+        return a[:, :, None] if a.ndim == 2 else a
 
     def _decode(self, ids):
-        from PIL import Image
-        arrs = []
-        for i in ids:
-            a = np.asarray(Image.open(self.files[i]))
-            arrs.append(a[:, :, None] if a.ndim == 2 else a)
+        arrs = [self._load_one(i) for i in ids]
         if any(a.shape != arrs[0].shape for a in arrs):
             raise ValueError("GpuImageLoader: images of one batch must share a shape")
-        host = torch.from_numpy(np.stack(arrs)).pin_memory()
-        return host
+        if any(a.dtype != np.uint8 for a in arrs):  # a batch with .pkl members travels as float32 (ToTensor's / 255 on the host)
+            arrs = [a.astype(np.float32) / np.float32(255) if a.dtype == np.uint8 else a.astype(np.float32, copy=False)
+                    for a in arrs]
+        return torch.from_numpy(np.stack(arrs)).pin_memory()
 
     def __iter__(self):
         q: "queue.Queue" = queue.Queue(maxsize=self.prefetch)

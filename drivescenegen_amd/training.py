@@ -23,7 +23,7 @@ from contextlib import contextmanager
 import torch
 import torch.distributed as dist
 
-from . import ops
+from . import ops, sharding
 from .autograd import SLABS, get_train_state
 
 
@@ -174,10 +174,7 @@ class AdamW(torch.optim.Optimizer):
 # ------------------------------------------------------------------------------------------------
 # data-parallel gradient averaging: reverse-order flat buckets, launched as they fill
 # ------------------------------------------------------------------------------------------------
-def _force_collectives() -> bool:
-    """DSG_FORCE_COLLECTIVES=1 under a launcher (RANK set): create the RCCL process group and issue every broadcast /
-    all-reduce / barrier of the data-parallel path even when WORLD_SIZE is 1, so that one GPU exercises the calls."""
-    return os.environ.get("DSG_FORCE_COLLECTIVES") == "1" and "RANK" in os.environ
+_force_collectives = sharding.force_collectives
 
 
 class GradBuckets:
@@ -218,6 +215,12 @@ class GradBuckets:
         self.seen = set()
         self.works = []
         self.launch_order = []
+        self._in_finish = False
+
+    # DSG_DDP_TRACE=1 (tests / tools): keep, per step, which buckets were launched from inside the backward walk and a
+    # GPU event at each launch and at the end of the walk -- "communication overlaps backward" as a measured statement
+    trace_enabled = os.environ.get("DSG_DDP_TRACE") == "1"
+    last_trace = None
 
     def ready(self, name):
         if not self.active or name in self.seen or name not in self.of:
@@ -232,12 +235,24 @@ class GradBuckets:
         b = self.buckets[i]
         view = self.flat[b["lo"]:b["hi"]]
         op = dist.ReduceOp.AVG if self.avg_native else dist.ReduceOp.SUM
+        ev = None
+        if self.trace_enabled and view.is_cuda:
+            ev = torch.cuda.Event(enable_timing=True)
+            ev.record()   # on the backward walk's stream: everything enqueued so far precedes the bucket's all-reduce
         self.works.append((dist.all_reduce(view, op=op, group=self.group, async_op=True), view))
         self.launch_order.append(i)
+        if self.trace_enabled:
+            self._trace = getattr(self, "_trace", [])
+            self._trace.append((i, not self._in_finish, ev))
 
     def finish(self):
         if not self.active:
             return
+        self._in_finish = True
+        end_ev = None
+        if self.trace_enabled and self.flat.is_cuda:
+            end_ev = torch.cuda.Event(enable_timing=True)
+            end_ev.record()   # the end of the backward walk on its stream
         for i, left in enumerate(self.pending):  # parameters that got no gradient this step
             if left > 0:
                 self.pending[i] = 0
@@ -249,6 +264,15 @@ class GradBuckets:
                     ops.scale(view, None, 1.0 / self.world, out=view)
                 else:  # gloo on CPU tensors: only reachable from the host-logic tests
                     view.div_(self.world)
+        if self.trace_enabled:
+            tr = getattr(self, "_trace", [])
+            if end_ev is not None:
+                torch.cuda.synchronize()
+            GradBuckets.last_trace = dict(
+                order=[i for i, _, _ in tr], in_walk=[w for _, w, _ in tr],
+                ms_before_walk_end=[(ev.elapsed_time(end_ev) if ev is not None and end_ev is not None else None)
+                                    for _, _, ev in tr])
+            self._trace = []
         self.reset()
 
 
@@ -261,6 +285,8 @@ class _ShardedLoader:
     order that is identical on all ranks -- and every rank runs the SAME number of steps per epoch: when the batch
     count is not a multiple of the world size (or the last batch is short) the tail is completed with samples from
     the start of the epoch's order, so no rank waits in a collective that the others never join.
+    With ONE process accelerate shards nothing: the loader runs as it is -- its own sampler (generator, replacement,
+    num_samples) and a SHORT last batch, exactly the reference's single-GPU epoch (train.py:35: batch 14, shuffle=True).
 
     The global order comes from the loader's own sampler when it is sequential; for a shuffling loader
     (train.py:35 ``shuffle=True``) rank 0 draws a seed from the global CPU generator and broadcasts it, and every
@@ -282,6 +308,8 @@ class _ShardedLoader:
         return n // b if self.drop_last else math.ceil(n / b)
 
     def __len__(self):
+        if self.world == 1:
+            return len(self.loader)
         nb = self._num_batches() if self.index_mode else len(self.loader)
         return math.ceil(nb / self.world)
 
@@ -292,22 +320,16 @@ class _ShardedLoader:
         n = len(self.dataset)
         if not self.shuffle:
             return list(range(n))
-        seed = torch.zeros(1, dtype=torch.int64)
-        if self.rank == 0:
-            seed = torch.randint(0, 2 ** 62, (1,), dtype=torch.int64)  # global CPU generator, like RandomSampler
-        if (self.world > 1 or _force_collectives()) and dist.is_initialized():
-            if dist.get_backend() == "nccl":
-                dev_seed = seed.to(self.device)
-                dist.broadcast(dev_seed, src=0)
-                seed = dev_seed.cpu()
-            else:
-                dist.broadcast(seed, src=0)
-        self.epoch_seed = int(seed.item())
+        self.epoch_seed = sharding.broadcast_epoch_seed(self.rank, self.world, self.device)
         g = torch.Generator()
         g.manual_seed(self.epoch_seed)
         return torch.randperm(n, generator=g).tolist()
 
     def __iter__(self):
+        if self.world == 1:  # nothing to shard, nothing to even out: the loader's own batches, short tail included
+            for batch in self.loader:
+                yield self._to_device(batch)
+            return
         if not self.index_mode:  # opaque loader: rank r keeps every W-th batch, the tail wraps to the first batches
             head, count = [], 0
             for i, batch in enumerate(self.loader):
@@ -320,16 +342,8 @@ class _ShardedLoader:
                 if j % self.world == self.rank:
                     yield self._to_device(head[(j - count) % len(head)])
             return
-        order, b = self._global_order(), self.batch_size
-        if self.drop_last:
-            order = order[:len(order) // b * b]
-        per_round = b * self.world
-        if order and len(order) % per_round:  # even_batches: complete the last round from the start of the order
-            need = per_round - len(order) % per_round
-            order = order + [order[i % len(order)] for i in range(need)]
         collate = self.loader.collate_fn
-        for k in range(self.rank, len(order) // b, self.world):
-            idx = order[k * b:(k + 1) * b]
+        for idx in sharding.shard_batches(self._global_order(), self.batch_size, self.rank, self.world, self.drop_last):
             yield self._to_device(collate([self.dataset[i] for i in idx]))
 
 

@@ -425,6 +425,8 @@ int dsg_adamw_step(float* param, const float* grad, float* exp_avg, float* exp_a
  *   dsg_resize_normalize_u8  Image_Dataset.__getitem__ (utils/datasets/dataset.py:21-24,43-45): decoded uint8
  *                            [N][Hs][Ws][C] -> ToTensor -> bilinear (align_corners=False, no antialias) ->
  *                            (x - mean) / std -> fp32 [N][C][Ho][Wo]
+ *   dsg_resize_normalize_f32 the same for the dataset's .pkl branch (utils/datasets/dataset.py:37-41): `fig_tensor`
+ *                            float [N][Hs][Ws][C] -> permute -> bilinear -> (x - mean) / std (no / 255)
  *   dsg_hist_u8              get_gray_image's per-channel histograms (vectorization/utils/image_utils.py:26-28):
  *                            hist[n][c][256] of uint8 [N][H*W][C]
  *   dsg_mask_lut_u8          its +-0.1 background mask (:40) and extract_agents' threshold
@@ -433,6 +435,8 @@ int dsg_adamw_step(float* param, const float* grad, float* exp_avg, float* exp_a
  * ---------------------------------------------------------------------------------------- */
 int dsg_resize_normalize_u8(const uint8_t* src, int32_t n, int32_t hs, int32_t ws, int32_t c, float* dst, int32_t ho,
                             int32_t wo, float mean, float std, void* stream);
+int dsg_resize_normalize_f32(const float* src, int32_t n, int32_t hs, int32_t ws, int32_t c, float* dst, int32_t ho,
+                             int32_t wo, float mean, float std, void* stream);
 int dsg_hist_u8(const uint8_t* img, int32_t n, int32_t hw, int32_t c, uint32_t* hist, void* stream);
 int dsg_mask_lut_u8(const uint8_t* img, int32_t n, int32_t hw, int32_t c, int32_t ch0, int32_t ch1, const uint8_t* lut,
                     uint8_t on_value, uint8_t off_value, uint8_t* out, void* stream);

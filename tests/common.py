@@ -24,3 +24,107 @@ def rel_l2(a, b):
 
 def max_abs(a, b):
     return float((a.double() - b.double()).abs().max())
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# Full-size oracle outputs kept as golden vectors (tests/golden/fullsize_golden.npz, made by
+# tests/golden/make_fullsize_golden.py): the inputs are rebuilt here from the deterministic synthetic streams.
+# key -> (order, config name, config, batch the inputs are drawn at, input seed, timestep, spatial stride of the stored output)
+# ---------------------------------------------------------------------------------------------------------------
+FULLSIZE_FWD = {
+    "default3_b1_t749": (0, "DEFAULT3", DEFAULT3, 1, 14555, 749, 1),
+    "default3_b3_row0_t900": (1, "DEFAULT3", DEFAULT3, 3, 14555, 900, 1),
+    "cfg2_b16_row0_t500": (20, "CFG2", CFG2, 16, 14555, 500, 1),
+    "cfg4_b8_row0_t990": (30, "CFG4", CFG4, 8, 14555, 990, 2),
+    "cfg5_b3_row0_t980": (40, "CFG5", CFG5, 3, 14555, 980, 2),
+}
+# the reference's sampling call walks t = 749 ... 0 (training_pipeline.py:26-32): one forward every 50 steps of that table
+DEFAULT3_STEP_TS = tuple(range(749, 0, -50)) + (0,)
+for _t in DEFAULT3_STEP_TS:
+    FULLSIZE_FWD[f"default3_step_t{_t}"] = (2, "DEFAULT3", DEFAULT3, 1, 2000 + _t, _t, 4)
+# key -> (config, batch, seed) of one DDPM training step (loss + gradients)
+# (default3_train_b2: the reference's own 3-channel network, train.py:39-57 -- checked under its own fp16 AMP mode)
+FULLSIZE_TRAIN = {"cfg3_train_b2": (CFG3, 2, 5), "cfg5_train_b2": (CFG5, 2, 21), "default3_train_b2": (DEFAULT3, 2, 33)}
+
+
+def fullsize_case(key):
+    """(config name, config, x [1,C,H,W], timestep, stride) of a stored forward case (row 0 of the batch it names)."""
+    import torch
+    _, name, cfg, batch, seed, t, stride = FULLSIZE_FWD[key]
+    return name, cfg, noisy_inputs(cfg, batch, seed)[:1].contiguous(), int(t), stride
+
+
+def fullsize_train_case(key):
+    """(config, x0, noise, timesteps) of a stored training-step case."""
+    import numpy as np
+    import torch
+    from drivescenegen_amd import synth
+    cfg, b, seed = FULLSIZE_TRAIN[key]
+    ss = cfg["sample_size"]
+    h, w = (ss, ss) if isinstance(ss, int) else ss
+    x0 = torch.from_numpy(synth.synth_scene_rasters(b, cfg["in_channels"], h, w, seed))
+    noise = torch.from_numpy(synth.normal(seed + 1, tuple(x0.shape)))
+    t = torch.from_numpy((synth.uniform01(seed + 2, b) * 1000).astype(np.int64))
+    return cfg, x0, noise, t
+
+
+def grad_sample_stride(numel):
+    return max(1, numel // 512)
+
+
+_FULLSIZE = None
+
+
+def fullsize_golden():
+    global _FULLSIZE
+    if _FULLSIZE is None:
+        import os
+        import numpy as np
+        _FULLSIZE = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "fullsize_golden.npz"))
+    return _FULLSIZE
+
+
+def assert_matches_fullsize_golden(got, key, rel=1e-4, ab=2e-4):
+    """`got` [1,C,H,W] (any device) against the stored oracle output of `key`: rel-L2 and max-abs on the stored pixels
+    (all of them, or every stride-th in both directions), and per-channel mean / mean square of the WHOLE output."""
+    import torch
+    gold = fullsize_golden()
+    stride = FULLSIZE_FWD[key][6]
+    got = got.detach().float().cpu()
+    assert torch.isfinite(got).all(), key
+    want = torch.from_numpy(gold[key])
+    sub = got[:, :, ::stride, ::stride]
+    assert sub.shape == want.shape, (key, sub.shape, want.shape)
+    e = rel_l2(sub, want)
+    assert e <= rel, (key, e)
+    if ab is not None:
+        assert max_abs(sub, want) <= ab * max(1.0, float(want.abs().max())), (key, max_abs(sub, want))
+    mom = torch.from_numpy(gold[key + "/moments"])
+    m, ms = got.double().mean((0, 2, 3)), got.double().pow(2).mean((0, 2, 3))
+    assert ((m - mom[0]).abs() <= 2 * rel * mom[1].sqrt() + 1e-7).all(), (key, "mean")
+    assert ((ms - mom[1]).abs() <= 4 * rel * mom[1] + 1e-9).all(), (key, "mean square")
+    return e
+
+
+def compare_grads_with_golden(named_grads, key):
+    """Engine gradients (iterable of (name, grad tensor) in named_parameters order) against the stored oracle gradients of
+    `key`: returns (rel-L2 over all stored samples, worst per-tensor relative error of the L2 norm, per-tensor outliers)."""
+    import torch
+    gold = fullsize_golden()
+    norms, samples = gold[key + "/grad_norms"], torch.from_numpy(gold[key + "/grad_samples"])
+    at, num, den, worst_norm, bad = 0, 0.0, 0.0, 0.0, []
+    gmax = float(norms.max())
+    for i, (name, g) in enumerate(named_grads):
+        g = g.detach().float().cpu().flatten()
+        s = g[::grad_sample_stride(g.numel())].double()
+        w = samples[at:at + s.numel()].double()
+        at += s.numel()
+        num += float((s - w).pow(2).sum())
+        den += float(w.pow(2).sum())
+        if norms[i] > 1e-7:
+            worst_norm = max(worst_norm, abs(float(g.double().norm()) - norms[i]) / norms[i])
+            scale = float(w.abs().max()) + 1e-12
+            if float((s - w).abs().max()) > 1e-3 * scale + 1e-8 * max(1.0, gmax):
+                bad.append((name, float((s - w).abs().max()), scale))
+    assert at == samples.numel(), (at, samples.numel())
+    return (num / max(den, 1e-300)) ** 0.5, worst_norm, bad

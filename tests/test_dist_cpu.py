@@ -71,6 +71,24 @@ def _worker(rank, world, port, q):
         # drop_last: 22 samples, batch 4 -> 5 full batches, the 2 left-over samples are never seen
         dl = torch.utils.data.DataLoader(torch.arange(22, dtype=torch.float32).view(22, 1), batch_size=4, drop_last=True)
         assert sum(x.shape[0] for x in _ShardedLoader(dl, "cpu", rank, world)) == 12
+        # --- the GPU input pipeline's loader shards the same way (host logic only here: file indices, no decode):
+        #     7 batches of 3 from 21 files -> odd for world 2, plus seed=None -> rank 0's broadcast seed ---
+        from drivescenegen_amd.imageops import GpuImageLoader
+        for seed in (None, 11):
+            gl = GpuImageLoader([f"f{i}.png" for i in range(20)], (8, 8), batch_size=3, shuffle=True, seed=seed, device="cpu",
+                                rank=rank, world=world)
+            for _epoch in range(2):
+                mine = gl._batches()
+                gl.epoch += 1
+                assert len(mine) == len(gl) == 4 and all(len(b) == 3 for b in mine)
+                allv = [torch.zeros(12, dtype=torch.int64) for _ in range(world)]
+                dist.all_gather(allv, torch.tensor(mine).reshape(-1))
+                order = torch.stack([v.view(4, 3) for v in allv], 1).reshape(-1)   # global batch k*W + r
+                assert torch.equal(order[:20].sort().values, torch.arange(20))      # the shards partition the files
+                assert torch.equal(order[20:], order[:4])                           # the tail wraps to the epoch's start
+                seeds = [torch.zeros(1, dtype=torch.int64) for _ in range(world)]
+                dist.all_gather(seeds, torch.tensor([gl.epoch_seed]))
+                assert seeds[0].item() == seeds[1].item()
         # --- gradient accumulation: the prepared optimizer steps / zeroes only on the synchronising micro-batch ---
         from drivescenegen_amd.training import Accelerator, _PreparedOptimizer
 
@@ -183,3 +201,24 @@ def test_grad_scaler_state_machine():
     other = GradScaler()
     other.load_state_dict(sd)
     assert other.get_scale() == sc.get_scale() and other._growth_tracker == sc._growth_tracker
+
+
+def test_one_process_loader_is_the_loader_itself():
+    """accelerate shards nothing when num_processes == 1: the prepared loader yields the wrapped loader's own batches --
+    short last batch included, the sampler's own generator honoured -- as the reference's single-GPU run does
+    (train.py:35: DataLoader(dataset, batch_size=14, shuffle=True))."""
+    from drivescenegen_amd.training import _ShardedLoader
+    ds = torch.arange(23, dtype=torch.float32).view(23, 1)
+
+    def make():
+        return torch.utils.data.DataLoader(ds, batch_size=5, shuffle=True, generator=torch.Generator().manual_seed(7))
+    want = [b.clone() for b in make()]
+    sl = _ShardedLoader(make(), "cpu", 0, 1)
+    got = list(sl)
+    assert len(sl) == len(got) == 5 and [tuple(b.shape) for b in got] == [(5, 1)] * 4 + [(3, 1)]
+    assert all(torch.equal(a, b) for a, b in zip(got, want))          # the sampler's generator decides the order
+    assert torch.equal(torch.cat(got).flatten().sort().values, ds.flatten())   # every sample exactly once: no padded tail
+    # sampling with replacement / num_samples passes through untouched too
+    smp = torch.utils.data.RandomSampler(ds, replacement=True, num_samples=12, generator=torch.Generator().manual_seed(3))
+    sl = _ShardedLoader(torch.utils.data.DataLoader(ds, batch_size=5, sampler=smp), "cpu", 0, 1)
+    assert [b.shape[0] for b in sl] == [5, 5, 2]

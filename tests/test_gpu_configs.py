@@ -1,8 +1,15 @@
 """Every BASELINE.json config at its own size (configs_untested): configs[2] -- a training step of the
 256x256x4 default network against torch-CPU autograd of the oracle plus a batch-64 size-independent property --,
 configs[3] -- the 6-level 512x512 attention network (SURVEY 8d reading, 66,294,660 parameters) --, configs[4] -- a bf16
-training step of the 8-channel network --, and the reference's own sampling call (750-step seeded DDPM at batch 1,
-training_pipeline.py:26-32) teacher-forced against the oracle every 50 steps."""
+training step of the 8-channel network plus its batch-128 property --, the reference's own training operating point
+(fp16 AMP, batch 14, train.py:16,24) and its own sampling call (750-step seeded DDPM at batch 1,
+training_pipeline.py:26-32) teacher-forced against the oracle.
+
+The full-size oracle results these tests compare with are committed golden vectors (tests/golden/fullsize_golden.npz,
+made by tests/golden/make_fullsize_golden.py from the same torch-CPU oracle; the CPU suite re-runs the oracle against
+them): the GPU box's host cores are shared and a 56-66 M-parameter oracle pass costs them seconds to a minute each
+(848 s of the driver's 1200 s).  The oracle still runs LIVE here where the input only exists at run time
+(the teacher-forced checkpoints of the free-running 750-step trajectory)."""
 import numpy as np
 import pytest
 import torch
@@ -14,7 +21,9 @@ import drivescenegen_amd as d  # noqa: E402
 from drivescenegen_amd import synth  # noqa: E402
 from oracle.scheduler_oracle import OracleDDPMScheduler  # noqa: E402
 from oracle.unet_oracle import OracleUNet2DModel  # noqa: E402
-from tests.common import CFG3, CFG4, CFG5, DEFAULT3, PARAM_COUNTS, max_abs, noisy_inputs, rel_l2, synth_weights  # noqa: E402
+from tests.common import (CFG3, CFG4, CFG5, DEFAULT3, DEFAULT3_STEP_TS, PARAM_COUNTS, assert_matches_fullsize_golden,  # noqa: E402
+                          compare_grads_with_golden, fullsize_case, fullsize_golden, fullsize_train_case, max_abs,
+                          noisy_inputs, rel_l2, synth_weights)
 
 DEV = "cuda"
 
@@ -28,34 +37,21 @@ def _train_inputs(cfg, b, seed=5):
     return x0, noise, t
 
 
-def _oracle_grads(cfg, x0, noise, t):
-    ora = synth_weights(OracleUNet2DModel(**cfg)).train()
-    noisy = OracleDDPMScheduler().add_noise(x0, noise, t)
-    loss = F.mse_loss(ora(noisy, t, return_dict=False)[0], noise)
-    loss.backward()
-    return ora, noisy, float(loss.detach())
-
-
 def test_cfg3_training_step_256_vs_oracle_autograd():
     """configs[2] network (256x256x4, 56,575,748 parameters): loss and all 282 gradients of one DDPM training step at
-    batch 2 against torch-CPU autograd of the fp32 oracle."""
-    x0, noise, t = _train_inputs(CFG3, 2)
-    ora, noisy, loss_o = _oracle_grads(CFG3, x0, noise, t)
-    net = synth_weights(d.UNet2DModel(**CFG3)).to(DEV).train()
+    batch 2 against torch-CPU autograd of the fp32 oracle (stored: the loss, every gradient's L2 norm and <= 512 evenly
+    spaced entries of each)."""
+    cfg, x0, noise, t = fullsize_train_case("cfg3_train_b2")
+    loss_o = float(fullsize_golden()["cfg3_train_b2/loss"][0])
+    net = synth_weights(d.UNet2DModel(**cfg)).to(DEV).train()
     assert sum(p.numel() for p in net.parameters()) == PARAM_COUNTS["CFG2"] and len(list(net.parameters())) == 282
-    loss = d.mse_loss(net(noisy.to(DEV), t.to(DEV), return_dict=False)[0], noise.to(DEV))
+    noisy = d.DDPMScheduler().add_noise(x0.to(DEV), noise.to(DEV), t.to(DEV))   # (bit-exact vs the oracle's: test_gpu_ops)
+    loss = d.mse_loss(net(noisy, t.to(DEV), return_dict=False)[0], noise.to(DEV))
     loss.backward()
     assert abs(float(loss.detach().cpu()) - loss_o) <= 2e-5 * loss_o
-    og = dict(ora.named_parameters())
-    bad, num, den = [], 0.0, 0.0
-    for name, p in net.named_parameters():
-        g, w = p.grad.detach().cpu(), og[name].grad
-        num += float((g.double() - w.double()).pow(2).sum())
-        den += float(w.double().pow(2).sum())
-        scale = float(w.abs().max()) + 1e-12
-        if max_abs(g, w) > 1e-3 * scale + 1e-8 or (float(w.norm()) > 1e-7 and rel_l2(g, w) > 5e-4):
-            bad.append((name, rel_l2(g, w), max_abs(g, w), scale))
-    assert (num / den) ** 0.5 <= 1e-4, (num / den) ** 0.5
+    err, norm_err, bad = compare_grads_with_golden(((n, p.grad) for n, p in net.named_parameters()), "cfg3_train_b2")
+    assert err <= 1e-4, err
+    assert norm_err <= 5e-4, norm_err
     assert not bad, bad[:8]
 
 
@@ -99,10 +95,8 @@ def test_cfg4_six_level_512_forward_vs_oracle_and_row_independence():
     fast = net(x.to(DEV), t.to(DEV)).sample
     assert rel_l2(fast.cpu(), got.cpu()) <= 2e-6
     assert torch.isfinite(got).all()
-    ora = synth_weights(OracleUNet2DModel(**CFG4)).eval()
-    with torch.no_grad():
-        want = ora(x[:1], t[:1]).sample
-    assert rel_l2(got[:1].cpu(), want) <= 1e-4 and max_abs(got[:1].cpu(), want) <= 2e-4 * max(1.0, float(want.abs().max()))
+    assert torch.equal(fullsize_case("cfg4_b8_row0_t990")[2], x[:1])
+    assert_matches_fullsize_golden(got[:1], "cfg4_b8_row0_t990")   # (the oracle's stored output: every 2nd pixel + whole-map moments)
     for i in (3, 7):
         with same_kernels_at_any_batch():
             assert torch.equal(net(x[i:i + 1].to(DEV), t[i:i + 1].to(DEV)).sample, got[i:i + 1])
@@ -111,24 +105,82 @@ def test_cfg4_six_level_512_forward_vs_oracle_and_row_independence():
 
 def test_cfg5_bf16_training_step_256_vs_oracle_autograd():
     """configs[4] network (256x256x8, 56,580,360 parameters), one mixed-bf16 training step at batch 2 against fp32
-    autograd of the oracle: loss within 1e-2, the whole gradient vector within 3e-2 (rel-L2)."""
-    x0, noise, t = _train_inputs(CFG5, 2, seed=21)
-    ora, noisy, loss_o = _oracle_grads(CFG5, x0, noise, t)
-    net = synth_weights(d.UNet2DModel(**CFG5)).to(DEV).train().set_compute_dtype("bf16")
-    loss = d.mse_loss(net(noisy.to(DEV), t.to(DEV), return_dict=False)[0], noise.to(DEV))
+    autograd of the oracle (stored): loss within 1e-2, the gradient vector within 3e-2 (rel-L2 over the stored entries),
+    every gradient tensor's norm within 6e-2."""
+    cfg, x0, noise, t = fullsize_train_case("cfg5_train_b2")
+    loss_o = float(fullsize_golden()["cfg5_train_b2/loss"][0])
+    net = synth_weights(d.UNet2DModel(**cfg)).to(DEV).train().set_compute_dtype("bf16")
+    noisy = d.DDPMScheduler().add_noise(x0.to(DEV), noise.to(DEV), t.to(DEV))
+    loss = d.mse_loss(net(noisy, t.to(DEV), return_dict=False)[0], noise.to(DEV))
     loss.backward()
     assert abs(float(loss.detach().cpu()) - loss_o) <= 1e-2 * loss_o
-    og = dict(ora.named_parameters())
-    num = sum(float((p.grad.detach().cpu().double() - og[n].grad.double()).pow(2).sum()) for n, p in net.named_parameters())
-    den = sum(float(w.grad.double().pow(2).sum()) for w in og.values())
-    assert (num / den) ** 0.5 <= 3e-2, (num / den) ** 0.5
+    err, norm_err, _ = compare_grads_with_golden(((n, p.grad) for n, p in net.named_parameters()), "cfg5_train_b2")
+    assert err <= 3e-2, err
+    assert norm_err <= 6e-2, norm_err
+
+
+def test_cfg5_bf16_batch128_rows_are_independent():
+    """configs[4] at its own batch (128 per GPU, mixed bf16): three rows of the batch-128 forward equal their own batch-1
+    runs bit for bit, everything is finite, and the call stays far inside one MI355X's memory."""
+    net = synth_weights(d.UNet2DModel(**CFG5)).to(DEV).eval().requires_grad_(False).set_compute_dtype("bf16")
+    x8 = noisy_inputs(CFG5, 8)
+    x = x8.repeat(16, 1, 1, 1)
+    x[5], x[77], x[127] = x8[1] * 0.5, -x8[2], x8[3].flip(-1)        # rows that are nobody's copy
+    t = (torch.arange(128) * 7) % 1000
+    torch.cuda.reset_peak_memory_stats()
+    out = net(x.to(DEV), t.to(DEV)).sample
+    assert out.shape == (128, 8, 256, 256) and torch.isfinite(out).all()
+    assert torch.cuda.max_memory_allocated() / 2 ** 30 < 100
+    for i in (5, 77, 127):
+        assert torch.equal(net(x[i:i + 1].to(DEV), t[i:i + 1].to(DEV)).sample, out[i:i + 1]), i
+    assert torch.equal(out[0], out[8]) is False and rel_l2(out[8].cpu(), out[0].cpu()) > 1e-3   # (different timesteps)
+
+
+def _train_step_fp16(net, noisy, t, noise, scale=65536.0):
+    """One fp16-AMP backward as accelerate drives it (training_pipeline.py:48-49,84-88): scaled loss, then unscale."""
+    from drivescenegen_amd.training import GradScaler, _ScaleLoss
+    sc = GradScaler(init_scale=scale)
+    loss = d.mse_loss(net(noisy, t, return_dict=False)[0], noise)
+    _ScaleLoss.apply(loss, sc.get_scale()).backward()
+    params = list(net.parameters())
+    sc.unscale_(params)
+    assert not bool(sc._found.item())
+    return float(loss.detach().cpu())
+
+
+def test_reference_operating_point_fp16_amp_default_net():
+    """The reference's own training configuration (train.py:16,24,39-57): the 3-channel default network under fp16 AMP with
+    the GradScaler.  Batch 2: loss and gradients against fp32 autograd of the oracle (stored: default3_train_b2);
+    batch 14 = the reference's: seven copies of the pair give the pair's gradients (mean-reduced loss), finite throughout."""
+    cfg, x0, noise, t = fullsize_train_case("default3_train_b2")
+    loss_o = float(fullsize_golden()["default3_train_b2/loss"][0])
+    net = synth_weights(d.UNet2DModel(**cfg)).to(DEV).train().set_compute_dtype("fp16")
+    noisy = d.DDPMScheduler().add_noise(x0.to(DEV), noise.to(DEV), t.to(DEV))
+    loss = _train_step_fp16(net, noisy, t.to(DEV), noise.to(DEV))
+    assert abs(loss - loss_o) <= 1e-2 * loss_o
+    err, norm_err, _ = compare_grads_with_golden(((n, p.grad) for n, p in net.named_parameters()), "default3_train_b2")
+    assert err <= 1e-2, err            # (fp16 carries 3 more mantissa bits than bf16: measured ~1e-3)
+    assert norm_err <= 2e-2, norm_err
+    small = {n: p.grad.detach().clone() for n, p in net.named_parameters()}
+    for p in net.parameters():
+        p.grad.zero_()
+    rep = lambda a: a.repeat(7, *([1] * (a.dim() - 1)))
+    _train_step_fp16(net, rep(noisy), rep(t.to(DEV)), rep(noise.to(DEV)))
+    worst = 0.0
+    for n, p in net.named_parameters():
+        assert torch.isfinite(p.grad).all(), n
+        if float(small[n].norm()) > 1e-7:
+            worst = max(worst, rel_l2(p.grad.cpu(), small[n].cpu()))
+    assert worst <= 5e-3, worst
 
 
 def test_reference_evaluate_call_750_steps_teacher_forced():
     """training_pipeline.py:26-32: 750-step DDPM, batch 1, CPU generator seeded 14555, on the train.py:39-57 network.
-    The engine free-runs the whole trajectory; every 50th step its x_t is handed to the CPU oracle, whose eps and
-    x_{t-1} for that step must agree (eps rel-L2 <= 1e-4, x_{t-1} <= 1e-4): 15 teacher-forced checkpoints over the
-    749 ... 0 timestep table.  The pipeline object, seeded the same way, reproduces the free-running result bit for bit."""
+    The engine free-runs the whole trajectory; at t = 749, 499, 249 and 0 its x_t is handed to the LIVE CPU oracle, whose
+    eps and x_{t-1} for that step must agree (rel-L2 <= 1e-4): teacher-forced checkpoints on inputs that only exist at run
+    time.  Every 50th timestep of the 749 ... 0 table is additionally checked on a synthetic x_t against the oracle's
+    stored eps (16 cases, tests/golden).  The pipeline object, seeded the same way, reproduces the free-running result
+    bit for bit."""
     net = synth_weights(d.UNet2DModel(**DEFAULT3)).to(DEV).eval().requires_grad_(False)
     ora = synth_weights(OracleUNet2DModel(**DEFAULT3)).eval()
     sch, osch = d.DDPMScheduler(), OracleDDPMScheduler()
@@ -143,7 +195,7 @@ def test_reference_evaluate_call_750_steps_teacher_forced():
         eps = net(x, t).sample
         noise = torch.randn((1, 3, 256, 256), generator=gen) if t > 0 else None
         nxt = sch.step(eps, t, x, variance_noise=None if noise is None else noise.to(DEV)).prev_sample
-        if i % 50 == 0 or t == 0:
+        if i % 250 == 0 or t == 0:
             with torch.no_grad():
                 oeps = ora(x.cpu(), t).sample
             onxt = osch.step(oeps, t, x.cpu(), noise=noise).prev_sample
@@ -151,7 +203,10 @@ def test_reference_evaluate_call_750_steps_teacher_forced():
             assert rel_l2(nxt.cpu(), onxt) <= 1e-4, (t, rel_l2(nxt.cpu(), onxt))
             checked += 1
         x = nxt
-    assert checked == 16 and torch.isfinite(x).all()
+    assert checked == 4 and torch.isfinite(x).all()
+    for ts in DEFAULT3_STEP_TS:   # 749, 699, ..., 49, 0: the timestep embedding path at every stretch of the table
+        _, _, xs, tt, _ = fullsize_case(f"default3_step_t{ts}")
+        assert_matches_fullsize_golden(net(xs.to(DEV), tt).sample, f"default3_step_t{ts}")
     pipe = d.DDPMPipeline(unet=net, scheduler=d.DDPMScheduler())
     img = pipe(num_inference_steps=750, batch_size=1, generator=torch.manual_seed(14555), output_type="np.array",
                return_dict=False)[0]

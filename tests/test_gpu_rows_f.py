@@ -45,6 +45,33 @@ def test_f1_resize_normalize_matches_dataset(tmp_path, hs, ws, ho, wo):
     assert float((torch.cat(batches) - torch.stack([ds[ds.data_list.index(f)] for f in ld.files])).abs().max()) <= 2e-6
 
 
+def test_f1_pkl_branch_matches_dataset(tmp_path):
+    """The dataset's .pkl branch (dataset.py:37-41: `fig_tensor` [H,W,C] float -> permute -> Resize -> Normalize) through the
+    GPU loader: float source variant of the resize kernel, pickles that are not dicts fall through to the next file, and
+    a batch that mixes PNG and .pkl files travels as float32."""
+    from types import SimpleNamespace
+    from PIL import Image
+    from drivescenegen_amd.dataset import Image_Dataset
+    imgs = _scene_u8(4, 96, 80, 9)
+    figs = [torch.from_numpy(imgs[i]).float() / 255 * (0.9 + 0.05 * i) for i in range(3)]   # not on the /255 grid
+    for i in range(3):
+        torch.save({"fig_tensor": figs[i], "other": i}, tmp_path / f"{i}.pkl")
+    Image.fromarray(imgs[3]).save(tmp_path / "3.png")
+    torch.save([1, 2, 3], tmp_path / "2b.pkl")   # not a dict: dataset.py:39-40 moves on to the next file
+    ds = Image_Dataset(SimpleNamespace(dataset_name=str(tmp_path / "*"), patterns_size_height=64, patterns_size_width=48))
+    ds.data_list.sort()   # (glob order is the directory's; the loader sorts: "the next file" must mean the same on both sides)
+    got = imageops.resize_normalize(torch.stack(figs).to(DEV), (64, 48)).cpu()
+    want = torch.stack([ds[ds.data_list.index(str(tmp_path / f"{i}.pkl"))] for i in range(3)])
+    assert float((got - want).abs().max()) <= 2e-6
+    ld = imageops.GpuImageLoader(str(tmp_path / "*"), (64, 48), batch_size=2, shuffle=False)
+    assert [f.split("/")[-1] for f in ld.files] == ["0.pkl", "1.pkl", "2.pkl", "2b.pkl", "3.png"] and len(ld) == 3
+    batches = [b.cpu() for b in ld]
+    assert [b.shape[0] for b in batches] == [2, 2, 1]
+    ref = torch.stack([ds[ds.data_list.index(f)] for f in ld.files])    # (2b.pkl -> the file after it, as in the dataset)
+    assert float((torch.cat(batches) - ref).abs().max()) <= 2e-6
+    assert torch.equal(torch.cat(batches)[3], torch.cat(batches)[4])
+
+
 def test_f2_masks_bit_exact():
     imgs = _scene_u8(4, 128, 128, 7)
     dev = torch.from_numpy(imgs).to(DEV)

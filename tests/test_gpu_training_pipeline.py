@@ -103,7 +103,7 @@ def test_dataset_loader_and_logging(tmp_path):
     loader = acc.prepare(torch.utils.data.DataLoader(ds, batch_size=4, shuffle=True))
     batches = list(loader)
     assert len(batches) == len(loader) == 2 and batches[0].is_cuda and batches[0].shape == (4, 3, 64, 64)
-    assert batches[1].shape == (4, 3, 64, 64)  # even batches: the short tail is completed from the start of the order
+    assert batches[1].shape == (2, 3, 64, 64)  # one process: accelerate shards nothing, the last batch stays short (train.py:35)
     if acc.is_main_process:
         acc.init_trackers("train_example")
     acc.log({"loss": 0.25, "lr": 1e-5, "step": 0}, step=0)
@@ -137,6 +137,45 @@ def test_seeded_sampling_then_checkpoint_folder_then_reload(tmp_path, tiny_net):
     assert len(imgs) == 2 and imgs[0].size == (64, 64) and imgs[0].mode == "RGB"
     reread = d.UNet2DModel.from_pretrained(out, subfolder="unet")  # train.py:59
     assert all(torch.equal(p.cpu(), q.cpu()) for p, q in zip(tiny_net.parameters(), reread.parameters()))
+
+
+def test_fit_runs_epochs_samples_and_checkpoints(tmp_path, tiny_net):
+    """drivescenegen_amd.train_loop.fit: the whole driver (what training_pipeline.py:46-107 + :16-43 do) on a 6-image folder
+    -- two epochs of batches [4, 2], a truncated-uint8 sample PNG per epoch from the seeded 750-step call (shortened here),
+    a diffusers-layout checkpoint at the end, one JSONL log record per step -- started through the notebook_launcher shim
+    the way train.py:121-122 does."""
+    from PIL import Image
+    from drivescenegen_amd import train_loop
+    out = tmp_path / "run"
+    cfg = SimpleNamespace(dataset_name=_png_folder(tmp_path / "pngs", 6), patterns_size_height=64, patterns_size_width=64,
+                          mixed_precision="no", gradient_accumulation_steps=1, output_dir=str(out), num_epochs=2,
+                          save_image_epochs=1, save_model_epochs=5, eval_batch_size=1, seed=14555, learning_rate=1e-4)
+    loader = torch.utils.data.DataLoader(Image_Dataset(cfg), batch_size=4, shuffle=True)
+    opt = d.AdamW(tiny_net.parameters(), lr=cfg.learning_rate)
+    lrs = d.get_cosine_schedule_with_warmup(optimizer=opt, num_warmup_steps=2, num_training_steps=len(loader) * cfg.num_epochs)
+    seen = []
+    steps = train_loop.notebook_launcher(
+        lambda *a: train_loop.fit(*a, sample_steps=6, on_step=lambda e, r: seen.append((e, r))),
+        (cfg, tiny_net, d.DDPMScheduler(), opt, loader, lrs), num_processes=1)
+    assert steps == 4 and [e for e, _ in seen] == [0, 0, 1, 1]
+    assert all(np.isfinite(r["loss"]) and r["loss"] > 0 for _, r in seen) and seen[1][1]["lr"] > seen[0][1]["lr"]
+    pngs = sorted(os.listdir(out / "samples"))
+    assert pngs == ["000.png", "001.png"]
+    im = np.asarray(Image.open(out / "samples" / "001.png"))
+    assert im.shape == (64, 64, 3) and im.dtype == np.uint8
+    # the PNG is the seeded sample of the FINAL weights, truncated (not rounded) to bytes
+    pipe = d.DDPMPipeline(unet=tiny_net, scheduler=d.DDPMScheduler())
+    again = pipe(num_inference_steps=6, batch_size=1, generator=torch.manual_seed(14555), output_type="np.array", return_dict=False)[0]
+    assert np.array_equal(im, (again[0] * 255.0).astype(np.uint8))
+    for rel in ("model_index.json", "unet/config.json", "unet/diffusion_pytorch_model.bin", "scheduler/scheduler_config.json"):
+        assert os.path.exists(out / rel), rel
+    reread = d.UNet2DModel.from_pretrained(str(out), subfolder="unet")
+    assert all(torch.equal(p.detach().cpu(), q.detach().cpu()) for p, q in zip(tiny_net.parameters(), reread.parameters()))
+    log = [json.loads(ln) for ln in open(out / "logs" / "train_example.jsonl").read().splitlines()]
+    assert [r["step"] for r in log] == [0, 1, 2, 3]
+    assert train_loop.notebook_launcher(lambda a, b: a + b, (1, 2), num_processes=1) == 3
+    with pytest.raises(RuntimeError):
+        train_loop.notebook_launcher(lambda: 0, (), num_processes=8)
 
 
 def test_loss_goes_down_on_fixed_batch():

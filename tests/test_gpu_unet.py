@@ -11,7 +11,8 @@ import drivescenegen_amd as d  # noqa: E402
 from drivescenegen_amd import synth  # noqa: E402
 from oracle.scheduler_oracle import OracleDDIMScheduler, OracleDDPMScheduler, oracle_pipeline  # noqa: E402
 from oracle.unet_oracle import OracleUNet2DModel  # noqa: E402
-from tests.common import CFG1, CFG2, CFG4_SMALL, DEFAULT3, max_abs, noisy_inputs, rel_l2, synth_weights  # noqa: E402
+from tests.common import (CFG1, CFG2, CFG4_SMALL, DEFAULT3, assert_matches_fullsize_golden, fullsize_case, max_abs,  # noqa: E402
+                          noisy_inputs, rel_l2, synth_weights)
 
 DEV = "cuda"
 GOLD = np.load(os.path.join(os.path.dirname(__file__), "golden", "cfg1_golden.npz"))
@@ -150,21 +151,20 @@ def test_blocked_and_plain_intermediates_agree(cfg):
 
 
 def test_default_unet_256_forward_vs_oracle():
-    """The train.py:39-57 network itself (56,574,595 params), B=1, 256x256x3."""
-    net, ora = _pair(DEFAULT3)
+    """The train.py:39-57 network itself (56,574,595 params), B=1, 256x256x3, against the oracle's stored output
+    (tests/golden/fullsize_golden.npz; tests/test_oracle_kat.py re-runs the oracle against the same entry on the CPU)."""
+    net = synth_weights(d.UNet2DModel(**DEFAULT3)).to(DEV).eval().requires_grad_(False)
     assert sum(p.numel() for p in net.parameters()) == 56_574_595
-    x = noisy_inputs(DEFAULT3, 1)
-    with torch.no_grad():
-        want = ora(x, 749).sample
-    got = net(x.to(DEV), 749).sample
-    _assert_close(got, want)
+    _, _, x, t, _ = fullsize_case("default3_b1_t749")
+    assert torch.equal(x, noisy_inputs(DEFAULT3, 1)) and t == 749
+    assert_matches_fullsize_golden(net(x.to(DEV), t).sample, "default3_b1_t749", TOL_REL, TOL_ABS)
 
 
 def test_cfg2_full_size_batch_properties():
     """BASELINE configs[1] shape (256x256x4, B=16): size-independent properties instead of a CPU oracle run --
     batch rows are independent (row i of a B=16 call == the B=1 call on row i, bitwise: the kernels'
-    reduction order does not depend on batch) and one oracle spot-check on row 0."""
-    net, ora = _pair(CFG2)
+    reduction order does not depend on batch) and row 0 against the oracle's stored output."""
+    net = synth_weights(d.UNet2DModel(**CFG2)).to(DEV).eval().requires_grad_(False)
     x = noisy_inputs(CFG2, 16)
     t = torch.full((16,), 500, dtype=torch.long)
     t[1] = 20
@@ -178,9 +178,8 @@ def test_cfg2_full_size_batch_properties():
         # the default batch-1 path (split-K on the deep, small-grid layers): the same values to fp32 round-off
         fast = net(x[i:i + 1].to(DEV), t[i:i + 1].to(DEV)).sample
         assert rel_l2(fast[0].cpu(), out[i].cpu()) <= 2e-6, rel_l2(fast[0].cpu(), out[i].cpu())
-    with torch.no_grad():
-        want = ora(x[:1], t[:1]).sample
-    _assert_close(out[:1], want)
+    assert torch.equal(fullsize_case("cfg2_b16_row0_t500")[2], x[:1]) and int(t[0]) == 500
+    assert_matches_fullsize_golden(out[:1], "cfg2_b16_row0_t500", TOL_REL, TOL_ABS)
 
 
 def test_checkpoint_roundtrip(tmp_path, tiny):

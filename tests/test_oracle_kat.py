@@ -124,3 +124,24 @@ def test_postproc_oracle_known_answers():
     u = np.arange(256, dtype=np.float32)
     rt = ((u / np.float32(255)) * 255).astype(np.uint8)
     assert (rt <= np.arange(256)).all() and (np.arange(256) - rt).max() <= 1
+
+
+def test_fullsize_golden_vectors_are_what_the_oracle_computes():
+    """tests/golden/fullsize_golden.npz (the full-size oracle outputs the `-m gpu` suite compares the engine with) against a
+    live run of the oracle on this host: one forward of the train.py:39-57 network on the stored case's rebuilt inputs --
+    the stored pixels to 1e-6 (torch-CPU thread counts may reorder sums), the whole-map moments likewise."""
+    import torch
+    from oracle.unet_oracle import OracleUNet2DModel
+    from tests.common import FULLSIZE_FWD, FULLSIZE_TRAIN, fullsize_case, fullsize_golden, rel_l2, synth_weights
+    gold = fullsize_golden()
+    for key in FULLSIZE_FWD:
+        assert key in gold and key + "/moments" in gold, key
+    for key in FULLSIZE_TRAIN:
+        assert gold[key + "/grad_norms"].shape == (282,) and gold[key + "/loss"].shape == (1,), key
+    key = "default3_step_t0"
+    _, cfg, x, t, stride = fullsize_case(key)
+    with torch.no_grad():
+        y = synth_weights(OracleUNet2DModel(**cfg)).eval()(x, t).sample
+    assert rel_l2(y[:, :, ::stride, ::stride], torch.from_numpy(gold[key])) <= 1e-6
+    mom = torch.from_numpy(gold[key + "/moments"])
+    assert torch.allclose(y.double().pow(2).mean((0, 2, 3)), mom[1], rtol=1e-6)
