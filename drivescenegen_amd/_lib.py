@@ -47,6 +47,8 @@ class ConvArgs(C.Structure):
         ("compute_dtype", C.c_int32),
         ("src_bound", C.c_void_p), ("src_bound1", C.c_void_p),
         ("splitk_ws", C.c_void_p), ("splitk_ws_bytes", C.c_size_t),
+        ("sc_src0", C.c_void_p), ("sc_src1", C.c_void_p), ("sc_c0", C.c_int32), ("sc_c1", C.c_int32),
+        ("sc_weight_h2", C.c_void_p), ("sc_bias", C.c_void_p), ("sc_src_bound", C.c_void_p), ("sc_src_bound1", C.c_void_p),
     ]
 
 
@@ -114,6 +116,7 @@ SIGNATURES = {
     "dsg_gn_finalize_parts": [_vp, _i32, _i32, _vp, _i32, _i32, _vp, _vp, _i32, _i32, _i32, _f32, _vp, _vp],
     "dsg_gn_finalize_parts_train": [_vp, _i32, _i32, _vp, _i32, _i32, _vp, _vp, _i32, _i32, _i32, _f32, _vp, _vp, _vp],
     "dsg_conv2d_fwd": [C.POINTER(ConvArgs), _vp],
+    "dsg_conv2d_fuses_shortcut": [C.POINTER(ConvArgs), C.POINTER(_i32)],
     "dsg_layout_convert": [_vp, _vp, _i32, _i32, _i32, _i32, _vp],
     "dsg_conv2d_fwd_direct": [C.POINTER(ConvArgs), _vp],
     "dsg_conv_weight_relayout": [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp],

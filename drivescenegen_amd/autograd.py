@@ -380,6 +380,8 @@ def _backward(model, st: TrainState, tape: _Tape, dout):
                 ops.channel_sums(dy, out=sums, out_stride=sstride)
             ops.reduce_rows_add(sums, st.grad(wname + ".bias"), stride=sstride)
             done(wname + ".weight", wname + ".bias")
+            if rec["toff"] is not None:
+                _temb_proj_grads(st, tb, wname[:-len(".conv1")], done)
             if not rec["need_dx"]:
                 continue
             cin0, cin1 = x0.shape[1], (x1.shape[1] if x1 is not None else 0)
@@ -447,16 +449,28 @@ def _backward(model, st: TrainState, tape: _Tape, dout):
     _backward_temb(st, tb, done)
 
 
+def _temb_proj_grads(st, tb, pre, done):
+    """time_emb_proj gradients of ONE resnet, taken the moment its conv1's per-(n, cout) sums of dY -- this resnet's columns
+    of d(time projection) -- are final.  Inside the walk on purpose: every resnet owns a time_emb_proj, so with these
+    gradients left to the end of backward no gradient bucket of the data-parallel all-reduce (training.GradBuckets) was
+    complete before the walk had finished, and nothing overlapped (found by tests/test_gpu_rccl_one_rank.py on the
+    56.6 M-parameter network: launch order 0, 1, 2, ... from finish() instead of N-1, N-2, ... from inside the walk)."""
+    if pre in tb.setdefault("proj_done", set()):
+        return
+    tb["proj_done"].add(pre)
+    dtproj, o = tb["dtproj"], tb["toffs"][pre]
+    w = st.params[pre + ".time_emb_proj.weight"]
+    ops.linear_bwd(tb["act"], w.detach(), dtproj[:, o:], st.grad(pre + ".time_emb_proj.weight"),
+                   st.grad(pre + ".time_emb_proj.bias"), need_dx=False, dy_stride=dtproj.stride(0))
+    done(pre + ".time_emb_proj.weight", pre + ".time_emb_proj.bias")
+
+
 def _backward_temb(st, tb, done):
     """Backward of the timestep path (sinusoid -> MLP -> all time_emb_proj), shared by both tapes (fp32 throughout)."""
     P = st.params
     dtproj, act = tb["dtproj"], tb["act"]
-    for pre in tb["resnets"]:
-        o = tb["toffs"][pre]
-        w = P[pre + ".time_emb_proj.weight"]
-        ops.linear_bwd(act, w.detach(), dtproj[:, o:], st.grad(pre + ".time_emb_proj.weight"),
-                       st.grad(pre + ".time_emb_proj.bias"), need_dx=False, dy_stride=dtproj.stride(0))
-        done(pre + ".time_emb_proj.weight", pre + ".time_emb_proj.bias")
+    for pre in tb["resnets"]:   # (resnets whose conv1 got no gradient this step)
+        _temb_proj_grads(st, tb, pre, done)
     dact = ops.linear_bwd(act, tb["wp"], dtproj, None, None, need_dx=True)
     dz2 = ops.silu_bwd(tb["z2"], dact)
     # h1 = silu(z1) is recomputed by its definition through the kernels' own activation
@@ -875,6 +889,8 @@ def _backward16(model, st: TrainState, tape: _Tape, dout):
                 ops.channel_sums(dy, out=sums, out_stride=sstride)
             ops.reduce_rows_add(sums, st.grad(wname + ".bias"), stride=sstride)
             done(wname + ".weight", wname + ".bias")
+            if rec["toff"] is not None:
+                _temb_proj_grads(st, tb, wname[:-len(".conv1")], done)
             if not rec["need_dx"]:
                 continue
             cin0, cin1 = chans(x0), (chans(x1) if x1 is not None else 0)

@@ -474,6 +474,8 @@ void conv_h2_set_bm32_small(int v);
 void conv_h2_set_bm128(int v);
 void conv_h2_set_splitk(int v);
 void conv_h2_set_ws2(int v);
+void conv_h2_set_fuse_sc(int v);
+bool conv_h2_sc_fusable(const dsg_conv_args* a, int hout, int wout);
 int conv_h2_splitk_slices(const dsg_conv_args* a, int hout, int wout, int* stat_splits);
 void unet_set_blocked(int v);
 void attention_set_mfma(int v);
@@ -733,6 +735,15 @@ int conv2d_fwd_impl(const dsg_conv_args* a, hipStream_t st, int force_direct) {
   p.tiles_x = (p.wout + TW - 1) / TW; p.tiles_y = p.hout / TH;
   DSG_CHECK_ARG(!(p.pool && ((p.hout | p.wout) & 1)), "dsg_conv2d_fwd: pool2 needs even output dims");
 
+  if (a->sc_weight_h2 != nullptr) {  // fused shortcut: only the split-path kernel that contracts it serves the call
+    DSG_CHECK_ARG(a->sc_src0 != nullptr && a->sc_c0 > 0 && a->sc_c1 >= 0 && (a->sc_c1 == 0) == (a->sc_src1 == nullptr) &&
+                      a->residual == nullptr,
+                  "dsg_conv2d_fwd: sc_weight_h2 needs sc_src0 / sc_c0 (sc_src1 / sc_c1 together) and no residual");
+    DSG_CHECK_SHAPE(!force_direct && conv_h2_sc_fusable(a, p.hout, p.wout),
+                    "dsg_conv2d_fwd: this call cannot fuse a shortcut (dsg_conv2d_fuses_shortcut reports 0): run the 1x1 "
+                    "conv on its own and pass its result as residual");
+    return conv_h2_launch(a, p.hout, p.wout, st);
+  }
   if (!force_direct && conv_in_eligible(a, p.hout, p.wout)) return conv_in_launch(a, p.hout, p.wout, st);
   if (!force_direct && conv_out_eligible(a, p.hout, p.wout)) return conv_out_launch(a, p.hout, p.wout, st);
   if (!force_direct && conv_h2_eligible(a, p.hout, p.wout)) return conv_h2_launch(a, p.hout, p.wout, st);
@@ -853,6 +864,10 @@ DSG_API int dsg_set_tuning(int32_t key, int32_t value) {
     dsg::conv_h2_set_ws2(value);
     return DSG_OK;
   }
+  if (key == 23 && (value == 0 || value == 1)) {
+    dsg::conv_h2_set_fuse_sc(value);
+    return DSG_OK;
+  }
   if (key == 18 && (value == 0 || value == 1)) {
     dsg::conv_h2_set_bm128(value);
     return DSG_OK;
@@ -911,6 +926,15 @@ DSG_API int dsg_conv2d_splitk_bytes(const dsg_conv_args* a, size_t* bytes) {
   const int hout = (hc + 2 * pad - a->ksize) / a->stride + 1, wout = (wc + 2 * pad - a->ksize) / a->stride + 1;
   const int slices = dsg::conv_h2_splitk_slices(a, hout, wout, nullptr);
   *bytes = slices > 1 ? (size_t)slices * a->n * a->cout * hout * wout * sizeof(float) : 0;
+  return DSG_OK;
+}
+
+DSG_API int dsg_conv2d_fuses_shortcut(const dsg_conv_args* a, int32_t* yes) {
+  DSG_CHECK_ARG(a != nullptr && yes != nullptr, "dsg_conv2d_fuses_shortcut: NULL pointer");
+  *yes = 0;
+  if (a->sc_weight_h2 == nullptr || a->sc_src0 == nullptr || a->sc_c0 <= 0 || a->ksize != 3 || a->stride != 1 || a->upsample)
+    return DSG_OK;
+  *yes = dsg::conv_h2_sc_fusable(a, a->hin, a->win) ? 1 : 0;
   return DSG_OK;
 }
 

@@ -54,6 +54,20 @@ bool conv_h2_eligible(const dsg_conv_args* a, int hout, int wout) {
          a->cout % 8 == 0;
 }
 
+// Fused shortcut (dsg_conv_args.sc_*): a resnet's conv2 -- 3x3, stride 1, GroupNorm + SiLU in front, every tensor
+// channel-blocked, no residual -- takes the 1x1 conv_shortcut over the resnet's raw input into its own K loop.
+// fp32-equivalent mode only so far; a call that would split K (small batches) keeps the separate shortcut kernel.
+bool conv_h2_sc_fusable(const dsg_conv_args* a, int hout, int wout) {
+  if (!g_h2.enabled || !g_h2.fuse_sc || a->compute_dtype != DSG_F32) return false;
+  if (a->ksize != 3 || a->stride != 1 || a->upsample || a->pool2 || !a->gn_scale_shift || !a->silu || a->residual) return false;
+  if (a->src_layout != 1 || a->dst_layout != 1 || a->weight_h2 == nullptr || a->weight_h2_cout_stride) return false;
+  if (!conv_h2_eligible(a, hout, wout) || wout % H2_TW != 0) return false;
+  const int cin = a->c0 + a->c1, sc_cin = a->sc_c0 + (a->sc_src1 ? a->sc_c1 : 0);
+  if (cin < 2 * H2_KC || sc_cin < 2 * H2_KC || sc_cin % H2_KC || (a->sc_src1 && a->sc_c0 % H2_KC)) return false;
+  if (a->splitk_ws && conv_h2_splitk_slices(a, hout, wout, nullptr) > 1) return false;
+  return true;
+}
+
 // tile geometry shared by the launcher and dsg_conv2d_stats_tiles
 // 16-row tiles (4 rows per wave) are the efficient shape; 8-row tiles double the workgroup count.  The chip runs
 // 256 workgroups at a time, so what counts is the number of ROUNDS: an 8-row workgroup costs ~0.55 of a 16-row one
@@ -213,6 +227,7 @@ void conv_h2_set_bm32(int v) { g_h2.bm32 = v != 0; if (v > 1) g_h2.bm32_min = v;
 void conv_h2_set_bm128(int v) { g_h2.bm128 = v; ++g_h2.epoch; }
 void conv_h2_set_splitk(int v) { g_h2.splitk = v; ++g_h2.epoch; }
 void conv_h2_set_ws2(int v) { g_h2.ws2 = v; ++g_h2.epoch; }
+void conv_h2_set_fuse_sc(int v) { g_h2.fuse_sc = v; ++g_h2.epoch; }
 int conv_in_tuning_epoch();  // conv_in.hip: its on/off switch moves the plan's statistics buffers too
 int conv_h2_tuning_epoch() { return g_h2.epoch + conv_in_tuning_epoch(); }
 

@@ -64,6 +64,17 @@ struct ConvH2P {
   // contiguous run of K-chunks and writes its fp32 partial sums to slab blockIdx.y of `dst` (split_stride bytes
   // apart; bias / temb / residual / statistics are then the reduce pass's: splitk_reduce_blk_kernel)
   size_t split_stride;
+  // Fused shortcut (SC kernels): the resnet's 1x1 conv_shortcut over its UN-normalised input (diffusers ResnetBlock2D:
+  // output = conv_shortcut(x) + conv2(...), the blocks train.py:39-57 builds wherever in != out channels) rides on this
+  // conv2's accumulators as sc_cin / 16 extra K-chunks of ONE tap each, read through the same halo-patch addressing:
+  // the shortcut's result is never written to HBM and never read back as a residual.  bound0 / bound1 are then the
+  // range-guard bounds of sc_src0 / sc_src1 (the main source is normalised); sc_bias is added with bias / temb.
+  const void* sc_src0;
+  const void* sc_src1;
+  int sc_c0, sc_c1, sc_cin;
+  const void* sc_wh;   // [sc_cin/16][pieces][1][2][sc_wh_stride][8]
+  int sc_wh_stride;
+  const float* sc_bias;
 };
 
 constexpr int H2_TW = 32, H2_KC = 16, H2_BM = 64;
@@ -149,9 +160,15 @@ __device__ __forceinline__ float silu_fast_h(float x) { return x * __builtin_amd
 //     short (4-8 K-chunks) and spend a third of their life in the prologue and epilogue.  The slab of chunk q+1 can only
 //     be fetched once every wave is done with chunk q -- that DMA latency is exposed per chunk and, like the prologue and
 //     the epilogue, covered by the CU's other workgroup.
-template <int GM, int NT, int KS, int ACT = 3, int NW = 4, int OCC = 1, int LAY = 0, int BM = 64, int PREC = 0, int WS = 0>
+// SC: 1 = the fused-shortcut form (see ConvH2P::sc_*): after the nq 3x3 chunks of the normalised source come
+//     sc_cin / 16 one-tap chunks of the raw shortcut source(s), staged through the same patch slots (centre tap only)
+template <int GM, int NT, int KS, int ACT = 3, int NW = 4, int OCC = 1, int LAY = 0, int BM = 64, int PREC = 0, int WS = 0, int SC = 0>
 __global__ __launch_bounds__(64 * NW, OCC * NW / 4) void conv_h2_kernel(ConvH2P p) {
   static_assert(!WS || KS == 3, "the one-slab layout is for the 3x3 kernels");
+  static_assert(!SC || (KS == 3 && GM == 0 && ACT == 2 && BM >= 64 && (LAY & 1)), "fused shortcut: plain 3x3 conv2 of a resnet, blocked sources");
+  using K0 = std::integral_constant<int, 0>;   // chunk kinds: 0 = a 3x3 chunk of the main (normalised) source,
+  using K1 = std::integral_constant<int, 1>;   //              1 = a one-tap chunk of the shortcut source,
+  using KN = std::integral_constant<int, -1>;  //             -1 = none
   constexpr bool SB = (LAY & 1) != 0, DB = (LAY & 2) != 0;
   constexpr int NP = PREC ? 1 : 2;              // operand pieces
   constexpr bool S16 = PREC != 0 && SB;         // 16-bit sources (8 channels of a pixel = one 16-byte load)
@@ -236,8 +253,8 @@ __global__ __launch_bounds__(64 * NW, OCC * NW / 4) void conv_h2_kernel(ConvH2P 
   // range guard (see ConvH2P): xs = 2^-e pre-scale of an un-normalised patch, rg_out = 2^e on the way out; both 1
   // (and the products bit-identical to the unguarded kernel) while the bound is inside the safe range
   float xs = 1.f, rg_out = 1.f;
-  if constexpr (PREC == 0 && ACT != 2) {
-    if (p.bound0 != nullptr && !has_ss) {
+  if constexpr (PREC == 0 && (ACT != 2 || SC)) {
+    if (p.bound0 != nullptr && (SC || !has_ss)) {
       unsigned b = p.bound0[n];
       if (p.bound1 != nullptr) b = max(b, p.bound1[n]);
       b = __builtin_amdgcn_readfirstlane(b);
@@ -269,6 +286,13 @@ __global__ __launch_bounds__(64 * NW, OCC * NW / 4) void conv_h2_kernel(ConvH2P 
     const int cb = (q + qb) * H2_KC;
     return (cb < p.c0) ? src0b + ((size_t)n * p.c0 + cb) * plane * ESS
                        : src1b + ((size_t)n * p.c1 + (cb - p.c0)) * plane * ESS;
+  };
+  const char* sc0b = static_cast<const char*>(p.sc_src0);
+  const char* sc1b = static_cast<const char*>(p.sc_src1);
+  auto sc_src_of = [&](int j) -> const char* {  // chunk j of the shortcut's source(s) (uniform)
+    const int cb = j * H2_KC;
+    return (cb < p.sc_c0) ? sc0b + ((size_t)n * p.sc_c0 + cb) * plane * ESS
+                          : sc1b + ((size_t)n * p.sc_c1 + (cb - p.sc_c0)) * plane * ESS;
   };
   auto unit_g = [&](int i) -> int { return i < FULL ? 0 : (i < 2 * FULL ? 1 : g2); };
   // patch loads are buffer loads: descriptor = the chunk's 16 channel planes (uniform), soffset = the channel
@@ -319,17 +343,24 @@ __global__ __launch_bounds__(64 * NW, OCC * NW / 4) void conv_h2_kernel(ConvH2P 
   };
   // the pair after GroupNorm affine (sc0, sc1, sh0, sh1) + SiLU -> operand words: (hi, scaled lo) fp16 pairs of the
   // split, or one rounded pair in the 16-bit type
-  auto to_operand = [&](float a, float b, const float4& s4, unsigned& w1, unsigned& w2) {
-    if (has_ss) {
-      a = a * s4.x + s4.z;
-      b = b * s4.y + s4.w;
-    } else if constexpr (PREC == 0 && ACT != 2) {
-      a *= xs;
-      b *= xs;
+  auto to_operand = [&](auto kt, float a, float b, const float4& s4, unsigned& w1, unsigned& w2) {
+    if constexpr (decltype(kt)::value == 1) {  // shortcut chunk: the raw source, pre-scaled by the range guard
+      if constexpr (PREC == 0) {
+        a *= xs;
+        b *= xs;
+      }
+    } else {
+      if (has_ss) {
+        a = a * s4.x + s4.z;
+        b = b * s4.y + s4.w;
+      } else if constexpr (PREC == 0 && ACT != 2) {
+        a *= xs;
+        b *= xs;
+      }
+      const float sa = silu_fast_h(a), sb = silu_fast_h(b);
+      a = do_silu ? sa : a;
+      b = do_silu ? sb : b;
     }
-    const float sa = silu_fast_h(a), sb = silu_fast_h(b);
-    a = do_silu ? sa : a;
-    b = do_silu ? sb : b;
     if constexpr (PREC == 0) {
       const _Float16 a1 = (_Float16)a, b1 = (_Float16)b;
       const half2v h = {a1, b1};
@@ -358,7 +389,7 @@ __global__ __launch_bounds__(64 * NW, OCC * NW / 4) void conv_h2_kernel(ConvH2P 
       } else {
         float a, b;
         pair_of(src, i, jp, a, b);
-        to_operand(a, b, sr[jp], w1[jp], w2[jp]);
+        to_operand(K0{}, a, b, sr[jp], w1[jp], w2[jp]);
       }
     }
     // (branch-free: a branch here would fence the instruction scheduler between staging and MFMAs)
@@ -393,16 +424,16 @@ __global__ __launch_bounds__(64 * NW, OCC * NW / 4) void conv_h2_kernel(ConvH2P 
       }
     }
   };
-  auto stage_step = [&](int P, int qs, unsigned char* buf, bool stage, bool load, const char* spn, const float4& s4) {  // (loads: chunk qs + 1)
+  auto stage_step = [&](auto kt, int P, int qs, unsigned char* buf, bool stage, bool load, const char* spn, const float4& s4) {  // (loads: chunk qs + 1)
     const int i = P / 4, jp = P % 4;
     if (stage) {
-      if constexpr (S16 && ACT == 0) {
+      if constexpr (S16 && (ACT == 0 || decltype(kt)::value == 1)) {
         w1s[i][jp] = xr.q[i][jp];
         w2s[i][jp] = 0;
       } else {
         float a, b;
         pair_of(xr, i, jp, a, b);
-        to_operand(a, b, s4, w1s[i][jp], w2s[i][jp]);
+        to_operand(kt, a, b, s4, w1s[i][jp], w2s[i][jp]);
       }
       if (jp == 3) {
         _Float16* xb = reinterpret_cast<_Float16*>(buf);
@@ -466,6 +497,26 @@ __global__ __launch_bounds__(64 * NW, OCC * NW / 4) void conv_h2_kernel(ConvH2P 
         (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)(buf + unit * 1024);
     asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1\n" ::"v"(lane16), "s"(wq + segoff[k]),
                  "s"(__builtin_amdgcn_readfirstlane(lds_addr))  // (uniform by construction)
+                 : "memory");
+  };
+
+  // the shortcut's weight slab of a chunk: (piece, g) segments of BM couts x 16 B = NUNIT_SC 1-KB units at the start of the
+  // W region, [piece][tap 1][g][cout][8]
+  constexpr int NUNIT_SC = 2 * NP * BM / 64, NDMA_SC = (NUNIT_SC + NW - 1) / NW;
+  const unsigned sc_segb = (unsigned)p.sc_wh_stride * 16u, sc_chunkb = 2 * NP * sc_segb;
+  const char* sc_wtile = SC ? static_cast<const char*>(p.sc_wh) + (size_t)m0 * 16 : nullptr;
+  int segoff_sc[NDMA_SC];
+#pragma unroll
+  for (int k = 0; k < NDMA_SC; ++k) {
+    const int u = min(wave + NW * k, NUNIT_SC - 1);
+    segoff_sc[k] = __builtin_amdgcn_readfirstlane((u / UPS) * SPU * (int)sc_segb + (u % UPS) * 1024);
+  }
+  auto dma_weights_sc = [&](int k, const char* wq, unsigned char* buf) {  // wq: sc_wtile + chunk * sc_chunkb (uniform)
+    const int unit = min(wave + NW * k, NUNIT_SC - 1);
+    const unsigned lds_addr =
+        (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)(buf + unit * 1024);
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1\n" ::"v"(lane16), "s"(wq + segoff_sc[k]),
+                 "s"(__builtin_amdgcn_readfirstlane(lds_addr))
                  : "memory");
   };
 
@@ -560,12 +611,17 @@ __global__ __launch_bounds__(64 * NW, OCC * NW / 4) void conv_h2_kernel(ConvH2P 
   unsigned long long t_vm = 0, t_bar = 0;
   const unsigned long long rt_start = __builtin_amdgcn_s_memrealtime();  // 100 MHz, same base on every CU
 #endif
-  auto chunk = [&](int q, auto stage_tag, auto load_tag) {
-    constexpr bool STAGE = decltype(stage_tag)::value, LOAD = decltype(load_tag)::value;
+  // q: index in the unified chunk sequence (main chunks 0 .. nq-1, then -- SC -- shortcut chunks nq .. nq+ns-1);
+  // ck / sk / lk: kind of the chunk computed / staged (q+1) / loaded (q+2), see K0 / K1 / KN
+  auto chunk = [&](int q, auto ck, auto sk, auto lk) {
+    constexpr int CK = decltype(ck)::value, SK = decltype(sk)::value, LK = decltype(lk)::value;
+    constexpr bool STAGE = SK >= 0, LOAD = LK >= 0;
+    constexpr int CTAPS = CK == 1 ? 1 : TAPS;  // taps of the chunk computed
     unsigned char* cur = (q & 1) ? buf1 : buf0;
     unsigned char* nxt = (q & 1) ? buf0 : buf1;
-    const char* spn = LOAD ? src_of(q + 2) : nullptr;
-    const char* wqn = wtile + (size_t)(q + 1) * chunkb;  // the staged chunk's weights
+    const char* spn = !LOAD ? nullptr : (LK == 1 ? sc_src_of(q + 2 - nq) : src_of(q + 2));
+    // the staged chunk's weights
+    const char* wqn = SK == 1 ? sc_wtile + (size_t)(q + 1 - nq) * sc_chunkb : wtile + (size_t)(q + 1) * chunkb;
     const _Float16* wl = reinterpret_cast<const _Float16*>(WS ? buf0 : cur);
     const _Float16* xl = reinterpret_cast<const _Float16*>(cur) + H2_WHALFS;
     // Operand fragments are fetched one tap ahead into the other half of fa/fb: the reads of tap t+1 are issued
@@ -573,15 +629,16 @@ __global__ __launch_bounds__(64 * NW, OCC * NW / 4) void conv_h2_kernel(ConvH2P 
     // is free to interleave them with the staging work (LDS reads after a possibly-aliasing LDS write are not).
     half8 fa[2][MTN][NP], fb[2][NT][NP];  // [parity][tile][piece]
     auto load_frags = [&](int tap, int par) {
-      // folded up-sampler: the phase's 2x2 corner of the patch; stride 2: the {y-1, y} x {x-1, x} corner
-      const int dy = GM == 2 ? (phase >> 1) + (tap >> 1) : (GM == 3 ? (tap >> 1) : tap / KS);
-      const int dx = GM == 2 ? (phase & 1) + (tap & 1) : (GM == 3 ? (tap & 1) : tap % KS);
+      // folded up-sampler: the phase's 2x2 corner of the patch; stride 2: the {y-1, y} x {x-1, x} corner;
+      // shortcut chunk: the centre of the 3x3 patch
+      const int dy = CK == 1 ? 1 : (GM == 2 ? (phase >> 1) + (tap >> 1) : (GM == 3 ? (tap >> 1) : tap / KS));
+      const int dx = CK == 1 ? 1 : (GM == 2 ? (phase & 1) + (tap & 1) : (GM == 3 ? (tap & 1) : tap % KS));
 #pragma unroll
       for (int mt = 0; mt < MTN; ++mt)
 #pragma unroll
         for (int pc = 0; pc < NP; ++pc)
           fa[par][mt][pc] =
-              *reinterpret_cast<const half8*>(wl + (((pc * TAPS + tap) * 2 + half) * BM + mt * 32 + l31) * 8);
+              *reinterpret_cast<const half8*>(wl + (((pc * CTAPS + tap) * 2 + half) * BM + mt * 32 + l31) * 8);
 #pragma unroll
       for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
@@ -591,7 +648,7 @@ __global__ __launch_bounds__(64 * NW, OCC * NW / 4) void conv_h2_kernel(ConvH2P 
     };
     load_frags(0, 0);
 #pragma unroll
-    for (int tap = 0; tap < TAPS; ++tap) {
+    for (int tap = 0; tap < CTAPS; ++tap) {
       __builtin_amdgcn_sched_barrier(0);
 #ifdef DSG_H2_TIMING
       const unsigned long long tt0 = __builtin_readcyclecounter();
@@ -599,9 +656,9 @@ __global__ __launch_bounds__(64 * NW, OCC * NW / 4) void conv_h2_kernel(ConvH2P 
 #endif
       // next tap's scale/shift entries (BEFORE the fragments in program order: LDS returns in order, so a counted wait
       // covers the entries alone); the clear last tap fetches tap 0's entries of the next chunk
-      if (STAGE && tap + 1 < TAPS - 1) load_ss(tap + 1, q + 1);
-      if (LOAD && tap == TAPS - 1) load_ss(0, q + 2);
-      if (tap + 1 < TAPS) load_frags(tap + 1, (tap + 1) & 1);
+      if (CK == 0 && SK == 0 && tap + 1 < TAPS - 1) load_ss(tap + 1, q + 1);
+      if (CK == 0 && LK == 0 && tap == TAPS - 1) load_ss(0, q + 2);
+      if (tap + 1 < CTAPS) load_frags(tap + 1, (tap + 1) & 1);
       if (KS == 1) {  // one tap: all units and the four weight segments ride on it
 #pragma unroll
         for (int u = 0; u < H2_NU; ++u) {
@@ -612,18 +669,34 @@ __global__ __launch_bounds__(64 * NW, OCC * NW / 4) void conv_h2_kernel(ConvH2P 
       }
       // KS = 3: the chunk's staging steps and weight DMAs are dealt out evenly over taps 0..TAPS-2 (the last tap
       // stays clear so that the newest loads have a tap's worth of MFMAs to land before the closing vmcnt(0))
-      if (KS == 3 && tap < TAPS - 1) {
+      if (KS == 3 && CK == 0 && tap < TAPS - 1) {
         constexpr int NSTEP = 4 * H2_NU, ST = TAPS - 1;
 #pragma unroll
         for (int P = tap * NSTEP / ST; P < (tap + 1) * NSTEP / ST; ++P)
-          stage_step(P, q + 1, nxt, STAGE, LOAD, spn,
-                     has_ss ? s4b[tap & 1][P - tap * NSTEP / ST] : make_float4(1.f, 1.f, 0.f, 0.f));
+          stage_step(sk, P, q + 1, nxt, STAGE, LOAD, spn,
+                     (SK == 0 && has_ss) ? s4b[tap & 1][P - tap * NSTEP / ST] : make_float4(1.f, 1.f, 0.f, 0.f));
 #ifndef DSG_H2_ABL_NODMA
         if (STAGE && !WS) {
+          if constexpr (SK == 1) {  // the shortcut's slab is NDMA_SC units per wave: all on the first tap
+            if (tap == 0) {
 #pragma unroll
-          for (int k = tap * G::NDMA / ST; k < (tap + 1) * G::NDMA / ST; ++k) dma_weights(k, wqn, nxt);
+              for (int k = 0; k < NDMA_SC; ++k) dma_weights_sc(k, wqn, nxt);
+            }
+          } else {
+#pragma unroll
+            for (int k = tap * G::NDMA / ST; k < (tap + 1) * G::NDMA / ST; ++k) dma_weights(k, wqn, nxt);
+          }
         }
 #endif
+      }
+      if (KS == 3 && CK == 1 && (STAGE || LOAD)) {  // a one-tap chunk: every staging step rides on it
+        if (STAGE && !WS) {
+#pragma unroll
+          for (int k = 0; k < NDMA_SC; ++k) dma_weights_sc(k, wqn, nxt);
+        }
+#pragma unroll
+        for (int P = 0; P < 4 * H2_NU; ++P)
+          stage_step(sk, P, q + 1, nxt, STAGE, LOAD, spn, make_float4(1.f, 1.f, 0.f, 0.f));
       }
       const int par = tap & 1;
 #pragma unroll
@@ -641,12 +714,19 @@ __global__ __launch_bounds__(64 * NW, OCC * NW / 4) void conv_h2_kernel(ConvH2P 
       // Issue order within the tap: with one wave per SIMD nothing else fills the matrix pipe while this wave
       // issues staging work, so spread that work between the MFMAs (at most ~5 issues hide behind one MFMA)
       // instead of leaving it in one block as the scheduler would.
-      if (KS == 3 && tap < TAPS - 1 && (STAGE || LOAD)) {
+      if (KS == 3 && CK == 0 && tap < TAPS - 1 && (STAGE || LOAD)) {
 #pragma unroll
         for (int m = 0; m < (NP == 2 ? 3 : 1) * MTN * NT; ++m) {
           __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);  // 1 MFMA
           // 2 VALU per MFMA (a third of the MFMAs: 5; 128 couts, twice the MFMAs per tap again: 3)
           __builtin_amdgcn_sched_group_barrier(0x002, NP == 2 ? 2 : (BM == 128 ? 3 : 5), 0);
+        }
+      }
+      if (KS == 3 && CK == 1 && (STAGE || LOAD)) {  // (a whole chunk's staging behind a tap's MFMAs: as many as hide)
+#pragma unroll
+        for (int m = 0; m < (NP == 2 ? 3 : 1) * MTN * NT; ++m) {
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+          __builtin_amdgcn_sched_group_barrier(0x002, 5, 0);
         }
       }
 #ifdef DSG_H2_TIMING
@@ -655,6 +735,15 @@ __global__ __launch_bounds__(64 * NW, OCC * NW / 4) void conv_h2_kernel(ConvH2P 
 #endif
     }
     __builtin_amdgcn_sched_barrier(0);
+    auto dma_next_slab = [&]() {  // WS: the staged chunk's whole weight slab, after everyone is done with this one's
+      if constexpr (SK == 1) {
+#pragma unroll
+        for (int k = 0; k < NDMA_SC; ++k) dma_weights_sc(k, wqn, buf0);
+      } else {
+#pragma unroll
+        for (int k = 0; k < G::NDMA; ++k) dma_weights(k, wqn, buf0);
+      }
+    };
 #ifdef DSG_H2_TIMING  // tools/ only: where does a wave wait at the end of a chunk?  (p.stats = 4 counters)
     const unsigned long long ta = __builtin_readcyclecounter();
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
@@ -665,8 +754,7 @@ __global__ __launch_bounds__(64 * NW, OCC * NW / 4) void conv_h2_kernel(ConvH2P 
     t_bar += tc - tb;
     if constexpr (WS) {  // (timing build: the exposed slab fetch counts as memory wait)
       if (STAGE) {
-#pragma unroll
-        for (int k = 0; k < G::NDMA; ++k) dma_weights(k, wqn, buf0);
+        dma_next_slab();
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         t_vm += __builtin_readcyclecounter() - tc;
@@ -677,8 +765,7 @@ __global__ __launch_bounds__(64 * NW, OCC * NW / 4) void conv_h2_kernel(ConvH2P 
     if constexpr (WS) {
       __syncthreads();  // everyone is done with the weight slab (and with cur); nxt's patch is complete
       if (STAGE) {
-#pragma unroll
-        for (int k = 0; k < G::NDMA; ++k) dma_weights(k, wqn, buf0);
+        dma_next_slab();
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();  // the next chunk's weights are in
       }
@@ -688,25 +775,50 @@ __global__ __launch_bounds__(64 * NW, OCC * NW / 4) void conv_h2_kernel(ConvH2P 
     }
 #endif
   };
-  using T = std::true_type;
-  using F = std::false_type;
   if (nq > 1) load_ss(0, 1);  // tap 0 of the first chunk stages chunk 1
 #ifdef DSG_H2_TIMING
   const unsigned long long t_begin = __builtin_readcyclecounter();
   const unsigned long long rt_loop = __builtin_amdgcn_s_memrealtime();
 #endif
   int q = 0;
+  if constexpr (SC) {
+    // (the host dispatches here with nq >= 2 main chunks and ns >= 2 shortcut chunks)
+    const int ns = p.sc_cin / H2_KC;
+    for (; q + 2 < nq; ++q) chunk(q, K0{}, K0{}, K0{});
+    chunk(q++, K0{}, K0{}, K1{});  // q = nq - 2: stages the last main chunk, loads the shortcut's first
+    chunk(q++, K0{}, K1{}, K1{});  // q = nq - 1: stages the shortcut's first chunk, loads its second
+    if constexpr (PREC == 0) {
+      // Range guard: the shortcut's products arrive scaled by xs = 2^-e (their source was), and the epilogue multiplies
+      // the accumulators by 2^e.  The main chunks' sums, already in the same accumulators, take the factor here --
+      // powers of two, exact; a uniform branch that only an out-of-range source ever takes.
+      if (xs != 1.f) {
+#pragma unroll
+        for (int mt = 0; mt < MTN; ++mt)
+#pragma unroll
+          for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+              acc_hi[mt][nt][r] *= xs;
+              acc_lo[mt][nt][r] *= xs;
+            }
+      }
+    }
+    for (; q + 2 < nq + ns; ++q) chunk(q, K1{}, K1{}, K1{});
+    chunk(q++, K1{}, K1{}, KN{});
+    chunk(q, K1{}, KN{}, KN{});
+  } else {
 #if defined(DSG_H2_ABL_NOSTAGE)  // (tools/ timing experiments only: wrong results, loop time without a component)
-  for (; q + 2 < nq; ++q) chunk(q, F{}, T{});
+    for (; q + 2 < nq; ++q) chunk(q, K0{}, KN{}, K0{});
 #elif defined(DSG_H2_ABL_NOLOAD)
-  for (; q + 2 < nq; ++q) chunk(q, T{}, F{});
+    for (; q + 2 < nq; ++q) chunk(q, K0{}, K0{}, KN{});
 #elif defined(DSG_H2_ABL_MFMAONLY)
-  for (; q + 2 < nq; ++q) chunk(q, F{}, F{});
+    for (; q + 2 < nq; ++q) chunk(q, K0{}, KN{}, KN{});
 #else
-  for (; q + 2 < nq; ++q) chunk(q, T{}, T{});
+    for (; q + 2 < nq; ++q) chunk(q, K0{}, K0{}, K0{});
 #endif
-  if (q + 1 < nq) chunk(q++, T{}, F{});  // last staged chunk: nothing left to load
-  chunk(q, F{}, F{});                    // last chunk: MFMAs only
+    if (q + 1 < nq) chunk(q++, K0{}, K0{}, KN{});  // last staged chunk: nothing left to load
+    chunk(q, K0{}, KN{}, KN{});                    // last chunk: MFMAs only
+  }
 #ifdef DSG_H2_TIMING
   const unsigned long long rt_loop_end = __builtin_amdgcn_s_memrealtime();
   const unsigned long long t_loop_cycles = __builtin_readcyclecounter() - t_begin;
@@ -754,6 +866,9 @@ __global__ __launch_bounds__(64 * NW, OCC * NW / 4) void conv_h2_kernel(ConvH2P 
   const __amdgpu_buffer_rsrc_t temb_rs = __builtin_amdgcn_make_buffer_rsrc(
       p.temb ? const_cast<float*>(p.temb + (size_t)n * p.temb_stride + m0) : reinterpret_cast<float*>(dstb), 0,
       p.temb ? nvalid * 4 : 0, 0x00020000);
+  const __amdgpu_buffer_rsrc_t scb_rs = __builtin_amdgcn_make_buffer_rsrc(
+      (SC && p.sc_bias) ? const_cast<float*>(p.sc_bias + m0) : reinterpret_cast<float*>(dstb), 0,
+      (SC && p.sc_bias) ? nvalid * 4 : 0, 0x00020000);
   int voff[NT];  // bytes, per lane and row; the channel part of an address is the scalar offset
 #pragma unroll
   for (int nt = 0; nt < NT; ++nt) {
@@ -793,6 +908,8 @@ __global__ __launch_bounds__(64 * NW, OCC * NW / 4) void conv_h2_kernel(ConvH2P 
         const int crel = mt * 32 + (r & 3) + 8 * (r >> 2);  // this lane's channel is crel + 4*half
         addv[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(bias_rs, 16 * half, crel * 4, 0)) +
                   __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(temb_rs, 16 * half, crel * 4, 0));
+        if constexpr (SC)
+          addv[r] += __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(scb_rs, 16 * half, crel * 4, 0));
       }
       if (has_r) {
         if constexpr (DB) {
@@ -839,7 +956,7 @@ __global__ __launch_bounds__(64 * NW, OCC * NW / 4) void conv_h2_kernel(ConvH2P 
 #pragma unroll
           for (int nt = 0; nt < NT; ++nt) {
             const int r = 4 * rg + j;
-            if constexpr (NP == 2 && ACT != 2)
+            if constexpr (NP == 2 && (ACT != 2 || SC))
               vv[j][nt] = ((acc_hi[mt][nt][r] + acc_lo[mt][nt][r] * (1.0f / 2048.0f)) * rg_out + addv[r]) + rv[r][nt];
             else if constexpr (NP == 2)
               vv[j][nt] = ((acc_hi[mt][nt][r] + acc_lo[mt][nt][r] * (1.0f / 2048.0f)) + addv[r]) + rv[r][nt];

@@ -27,6 +27,7 @@ struct H2Tuning {
   int bm128 = 1;        // 16-bit modes: 128-cout workgroups where the grid still fills the chip (key 18)
   int splitk = 1;       // split-K for grids of at most half the CUs, when the caller gives scratch (key 19)
   int ws2 = 1;          // fp32-equivalent 3x3 convs with cin <= 128: 8-row tiles, one weight slab, two workgroups per CU (key 20)
+  int fuse_sc = 1;      // resnet shortcuts fused into conv2's K loop (key 23: A/B against the separate 1x1 kernel)
   int epoch = 0;        // bumped by every change: plans key their cached workspace sizes on it
 };
 extern H2Tuning g_h2;
@@ -35,14 +36,17 @@ constexpr int H2_CUS = 256;
 bool conv_h2_fold(const dsg_conv_args* a);
 bool conv_h2_s2(const dsg_conv_args* a, int hout, int wout);
 bool conv_h2_rows16(const dsg_conv_args* a, int hout, int wout);
+// does the call take the fused-shortcut kernel (dsg_conv_args.sc_*)?  Shape and dtype only, never the grid size: whether a
+// resnet's shortcut is fused must not depend on the batch it runs in (row i of a batch == the batch-1 call on row i, bitwise)
+bool conv_h2_sc_fusable(const dsg_conv_args* a, int hout, int wout);
 // K slices (1 = no split) and statistics splits of the reduce pass for a call that may split (see dsg_conv_args.splitk_ws)
 int conv_h2_splitk_slices(const dsg_conv_args* a, int hout, int wout, int* stat_splits);
 int splitk_reduce_launch(const float* part, int slices, const dsg_conv_args* a, int hout, int wout, int stat_splits,
                          hipStream_t st);
 
-template <int GM, int NT, int KS, int ACT, int NW = 4, int OCC = 1, int LAY = 0, int BM = 64, int PREC = 0, int WS = 0>
+template <int GM, int NT, int KS, int ACT, int NW = 4, int OCC = 1, int LAY = 0, int BM = 64, int PREC = 0, int WS = 0, int SC = 0>
 static int h2_launch(dim3 grid, size_t lds, hipStream_t st, const ConvH2P& p) {
-  auto kern = conv_h2_kernel<GM, NT, KS, ACT, NW, OCC, LAY, BM, PREC, WS>;
+  auto kern = conv_h2_kernel<GM, NT, KS, ACT, NW, OCC, LAY, BM, PREC, WS, SC>;
   static bool raised = false;
   if (!raised) {
     DSG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -95,6 +99,17 @@ int conv_h2_launch_t(const dsg_conv_args* a, int hout, int wout, hipStream_t st)
   p.res = a->residual; p.dst = a->dst;
   p.bound0 = (PREC == 0 && !a->gn_scale_shift) ? a->src_bound : nullptr;
   p.bound1 = (p.bound0 && a->src1) ? a->src_bound1 : nullptr;
+  // fused shortcut: the 1x1 over the resnet's raw input rides on this conv2 (conv_h2_kernel's SC form)
+  const bool sc = a->sc_weight_h2 != nullptr;
+  p.sc_src0 = p.sc_src1 = p.sc_wh = nullptr; p.sc_bias = nullptr; p.sc_c0 = p.sc_c1 = p.sc_cin = p.sc_wh_stride = 0;
+  if (sc) {
+    if (!conv_h2_sc_fusable(a, hout, wout))
+      return fail(DSG_ERR_UNSUPPORTED_SHAPE, "dsg_conv2d_fwd: sc_* given for a call that cannot fuse a shortcut (ask dsg_conv2d_fuses_shortcut first)");
+    p.sc_src0 = a->sc_src0; p.sc_src1 = a->sc_src1; p.sc_c0 = a->sc_c0; p.sc_c1 = a->sc_src1 ? a->sc_c1 : 0;
+    p.sc_cin = p.sc_c0 + p.sc_c1; p.sc_wh = a->sc_weight_h2; p.sc_wh_stride = (a->cout + 63) / 64 * 64; p.sc_bias = a->sc_bias;
+    p.bound0 = PREC == 0 ? a->sc_src_bound : nullptr;
+    p.bound1 = (p.bound0 && a->sc_src1) ? a->sc_src_bound1 : nullptr;
+  }
   // 16-row tiles (NT = 4) when they still give every CU a workgroup; 8-row tiles otherwise
   const int th = nt4 ? 16 : 8;
   p.tiles_x = (wout + H2_TW - 1) / H2_TW; p.tiles_y = hout / th;
@@ -109,7 +124,7 @@ int conv_h2_launch_t(const dsg_conv_args* a, int hout, int wout, hipStream_t st)
   // split-K (PREC 0, every tensor channel-blocked, plain / stride-2 3x3 and pointwise): the slices write fp32 partials
   // to the caller's scratch, the reduce pass does what the epilogue would have
   int stat_splits = 1;
-  const int slices = (PREC == 0 && a->splitk_ws) ? conv_h2_splitk_slices(a, hout0, wout0, &stat_splits) : 1;
+  const int slices = (PREC == 0 && a->splitk_ws && !sc) ? conv_h2_splitk_slices(a, hout0, wout0, &stat_splits) : 1;
   if (slices > 1) {
     const size_t slab = (size_t)p.n * p.cout * p.hout * p.wout * sizeof(float);
     if (a->splitk_ws_bytes < slab * slices)
@@ -130,9 +145,10 @@ int conv_h2_launch_t(const dsg_conv_args* a, int hout, int wout, hipStream_t st)
     const double px = (double)p.n * hout * wout * (fold ? 4 : 1);  // output pixels; FLOPs are the reference op's
     const int taps = a->ksize * a->ksize;
     const double cin_ref = a->c0 + a->c1;  // (stride 2: the kernel's 4 C x 4 taps are the reference op's C x 9)
+    const double sc_cin = sc ? p.sc_cin : 0;  // fused shortcut: its 1x1 FLOPs, source and weight bytes count too
     const double es = (PREC && (lay & 1)) ? 2.0 : 4.0, ed = (PREC && (lay & 2)) ? 2.0 : 4.0, ew = PREC ? 2.0 : 4.0;
-    pi = prof_begin((PREC ? 20 : 0) + (s2 ? 2 : (a->ksize == 1 ? 8 : (a->upsample ? 7 : (ws2 ? 10 : 6)))), 2.0 * px * p.cout * cin_ref * taps,
-                    es * (double)p.n * cin_ref * p.hin * p.win + ew * cin_ref * taps * p.cout +
+    pi = prof_begin((PREC ? 20 : 0) + (s2 ? 2 : (a->ksize == 1 ? 8 : (a->upsample ? 7 : (ws2 ? 10 : 6)))), 2.0 * px * p.cout * (cin_ref * taps + sc_cin),
+                    es * (double)p.n * (cin_ref + sc_cin) * p.hin * p.win + ew * (cin_ref * taps + sc_cin) * p.cout +
                         ed * px * p.cout * (p.res ? 2.0 : 1.0), st);
   }
 #define DSG_H2_LAUNCH(GM, KS, ACT)                                                  \
@@ -156,7 +172,7 @@ int conv_h2_launch_t(const dsg_conv_args* a, int hout, int wout, hipStream_t st)
   } while (0)
   // 32-cout workgroups: (a) optional, two per CU on the shallow levels (cin <= 128: LDS); (b) small batches: when
   // even the 8-row x 64-cout grid leaves more than half of the CUs idle, halve the cout tile to double the grid
-  const bool bm32_ok = lay == 3 && !fold && !s2 && !k1 && !a->upsample && wout % H2_TW == 0;
+  const bool bm32_ok = lay == 3 && !fold && !s2 && !k1 && !a->upsample && wout % H2_TW == 0 && !sc;
   const bool bm32 = bm32_ok && ((g_h2.bm32 && p.cin <= 128 && (int)grid.x >= g_h2.bm32_min) ||
                                 (g_h2.bm32_small && !nt4 && (int)grid.x <= H2_CUS / 2));
   if (s2) {
@@ -193,14 +209,15 @@ int conv_h2_launch_t(const dsg_conv_args* a, int hout, int wout, hipStream_t st)
       const size_t ldsw = (size_t)GW::BUF_BYTES + GW::XHALFS * 2 + 64 + (a->gn_scale_shift ? (size_t)p.cin * 2 * sizeof(float) : 0);
       ConvH2P q = p;
       q.tiles_y = hout / 8;
-      if (act == 0) rc = h2_launch<0, 2, 3, 0, 4, 2, 3, 64, 0, 1>(gws, ldsw, st, q);
+      if (sc) rc = h2_launch<0, 2, 3, 2, 4, 2, 3, 64, 0, 1, 1>(gws, ldsw, st, q);
+      else if (act == 0) rc = h2_launch<0, 2, 3, 0, 4, 2, 3, 64, 0, 1>(gws, ldsw, st, q);
       else rc = h2_launch<0, 2, 3, 2, 4, 2, 3, 64, 0, 1>(gws, ldsw, st, q);
     }
   } else if (lay == 3) {
     bool done128 = false;
     if constexpr (PREC != 0) {
       // 128-cout workgroups (four MFMA tiles per staged patch) while they still give every CU a workgroup
-      if (g_h2.bm128 && p.cout_pad % 128 == 0 && wout % H2_TW == 0) {
+      if (g_h2.bm128 && p.cout_pad % 128 == 0 && wout % H2_TW == 0 && !sc) {
         const int per_row = p.tiles_x * p.n * (p.cout_pad / 128);
         const bool r16 = hout % 16 == 0 && per_row * (hout / 16) >= H2_CUS;
         const int th128 = r16 ? 16 : 8;
@@ -223,7 +240,12 @@ int conv_h2_launch_t(const dsg_conv_args* a, int hout, int wout, hipStream_t st)
       }
     }
     if (!done128) {
-      if (act == 0) DSG_H2_LAUNCH_BLK(0, 3, 0, 3);
+      if (sc) {
+        if constexpr (PREC == 0) {
+          if (nt4) rc = h2_launch<0, 4, 3, 2, 4, 1, 3, 64, 0, 0, 1>(grid, lds, st, p);
+          else rc = h2_launch<0, 2, 3, 2, 4, 1, 3, 64, 0, 0, 1>(grid, lds, st, p);
+        }
+      } else if (act == 0) DSG_H2_LAUNCH_BLK(0, 3, 0, 3);
       else DSG_H2_LAUNCH_BLK(0, 3, 2, 3);
     }
   } else if (lay == 1) {  // 16-bit modes only (conv_out: blocked 16-bit sources -> fp32 [N,C,H,W])

@@ -131,6 +131,21 @@ typedef struct {
      anything but the call's own shape.  NULL: never split. */
   void* splitk_ws;
   size_t splitk_ws_bytes;
+  /* Fused resnet shortcut (optional; diffusers ResnetBlock2D with in != out channels, i.e. the first resnet of a wider
+     down block and every up-block resnet of train.py:39-57's network: output = conv_shortcut(input) + conv2(act(norm2(h)))):
+       dst = conv3x3(act(affine(src))) + bias (+ temb) + conv1x1(cat(sc_src0, sc_src1), sc_weight_h2) + sc_bias
+     The 1x1 over the resnet's UN-normalised input is contracted in the same kernel, on the same accumulators: the
+     shortcut's result is never written to HBM nor read back as `residual` (which must be NULL).  Served for the calls
+     dsg_conv2d_fuses_shortcut accepts (a resnet's conv2 on channel-blocked tensors); anything else with sc_weight_h2
+     set is DSG_ERR_UNSUPPORTED_SHAPE.  sc_weight_h2 = dsg_conv_weight_pack(kind 0, ksize 1, compute_dtype) of the
+     [cout][sc_c0 + sc_c1] weight; sc_src* are [N, sc_c*, hout, wout] in src_layout; sc_src_bound* as src_bound* above. */
+  const void* sc_src0;
+  const void* sc_src1;
+  int32_t sc_c0, sc_c1;
+  const void* sc_weight_h2;
+  const float* sc_bias;
+  const uint32_t* sc_src_bound;
+  const uint32_t* sc_src_bound1;
 } dsg_conv_args;
 
 int dsg_conv2d_fwd(const dsg_conv_args* a, void* stream);
@@ -145,6 +160,10 @@ int dsg_layout_convert_dt(const void* src, void* dst, int32_t n, int32_t c, int3
 int dsg_conv2d_stats_tiles(const dsg_conv_args* a, int32_t* tiles);
 /* Scratch bytes the call would use for split-K (0: it would not split). Host-only; independent of splitk_ws. */
 int dsg_conv2d_splitk_bytes(const dsg_conv_args* a, size_t* bytes);
+/* *yes = 1 when a call with these arguments (sc_src0 / sc_c0 / sc_c1 / sc_weight_h2 filled in) takes the fused-shortcut
+ * kernel, 0 when the shortcut has to run as a 1x1 call of its own with its result passed as `residual`.  Host-only; the
+ * answer depends on shapes, layouts, dtype and the split-K decision of the call -- not on the batch size as such. */
+int dsg_conv2d_fuses_shortcut(const dsg_conv_args* a, int32_t* yes);
 
 /* OIHW (checkpoint layout) -> engine layout [Cin][k*k][cout_total], written at
  * column offset cout_off (used to fuse to_q/to_k/to_v into one projection). nn.Linear weights
@@ -481,6 +500,7 @@ int dsg_prof_dump(const char* csv_path);
  *      64-cout x 16-row grid has at least n workgroups (1 = 512); bit-identical results, measured slower
  *  18  16-bit modes: 3x3 convs with cout % 128 == 0 as 128-cout workgroups while the grid fills the chip: [1] | 0
  *  19  split-K for grids of at most half the CUs (needs dsg_conv_args.splitk_ws): [1] | 0
+ *  23  resnet shortcuts fused into conv2's K loop (dsg_conv_args.sc_*): [1] | 0 (0: dsg_conv2d_fuses_shortcut answers no)
  *  20  fp32-equivalent 3x3 convs with cin <= 128 on channel-blocked tensors: 8-row tiles with ONE weight slab in LDS,
  *      two workgroups per CU (grids of at least 512 workgroups): [1] | 0
  *  21  conv_in (fp32 [N,C<=8,H,W] image -> channel-blocked result, 16 x 32 pixel tiles, cout % 32 == 0) on its own kernel

@@ -52,7 +52,7 @@ def test_training_steps_over_one_rank_rccl_are_bitwise_the_plain_run():
 
 
 def test_default_net_buckets_launch_back_to_front_inside_the_backward_walk():
-    """The train.py:39-57 network (56.6 M parameters, 226 MB gradient slab = 9 buckets of ~25 MB) through the same path
+    """The train.py:39-57 network (56.6 M parameters, 226 MB gradient slab = 8 buckets of >= 25 MB) through the same path
     (VERDICT r02 item 4): the buckets reach RCCL in strictly descending order (the backward walk finalises the last layers'
     gradients first), all but the last-filled ones are launched from INSIDE the walk -- a GPU event recorded at the first
     launch precedes the end-of-walk event by a measurable stretch of backward work -- and two training steps are bitwise
@@ -64,7 +64,7 @@ def test_default_net_buckets_launch_back_to_front_inside_the_backward_walk():
     assert plain.returncode == 0, plain.stderr[-4000:]
     forced = _launcher(args, force=True, extra_env={"DSG_DDP_TRACE": "1"})
     f = _lines(forced, "collectives")[0].split()
-    assert f[1] == "on" and f[3] == "nccl" and int(f[5]) >= 9, f
+    assert f[1] == "on" and f[3] == "nccl" and int(f[5]) >= 8, f
     tr = json.loads(_lines(forced, "trace")[0][len("trace "):])
     order = tr["order"]
     assert len(order) == int(f[5]) and order == sorted(order, reverse=True) and len(set(order)) == len(order), order

@@ -2,7 +2,7 @@
 Under a launcher:  python -m torch.distributed.run --nproc-per-node N --master-addr 127.0.0.1 tools/ddp_smoke.py [cfg] [batch] [steps]
 With DSG_FORCE_COLLECTIVES=1 and N = 1 every collective of the path still runs on a one-rank RCCL communicator (what
 tests/test_gpu_rccl_one_rank.py does on the one-GPU box).  cfg: CFG1 (default, 919 k parameters = one bucket) or any name
-of drivescenegen_amd.configs (DEFAULT3: the train.py:39-57 network, 56.6 M parameters = 9 buckets of ~25 MB).
+of drivescenegen_amd.configs (DEFAULT3: the train.py:39-57 network, 56.6 M parameters = 8 buckets of >= 25 MB).
 Prints one line per step, the bucket trace of the last step (DSG_DDP_TRACE=1) and a checksum of the parameters."""
 import json, os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
