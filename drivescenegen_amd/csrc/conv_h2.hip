@@ -63,7 +63,7 @@ bool conv_h2_sc_fusable(const dsg_conv_args* a, int hout, int wout) {
   if (a->src_layout != 1 || a->dst_layout != 1 || a->weight_h2 == nullptr || a->weight_h2_cout_stride) return false;
   if (!conv_h2_eligible(a, hout, wout) || wout % H2_TW != 0) return false;
   const int cin = a->c0 + a->c1, sc_cin = a->sc_c0 + (a->sc_src1 ? a->sc_c1 : 0);
-  if (cin < 2 * H2_KC || sc_cin < 2 * H2_KC || sc_cin % H2_KC || (a->sc_src1 && a->sc_c0 % H2_KC)) return false;
+  if (cin < 2 * H2_KC || sc_cin < 4 * H2_KC || sc_cin % H2_KC || (a->sc_src1 && a->sc_c0 % H2_KC)) return false;  // (ring depth 4)
   if (a->splitk_ws && conv_h2_splitk_slices(a, hout, wout, nullptr) > 1) return false;
   return true;
 }

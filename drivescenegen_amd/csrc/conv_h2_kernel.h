@@ -165,10 +165,10 @@ __device__ __forceinline__ float silu_fast_h(float x) { return x * __builtin_amd
 template <int GM, int NT, int KS, int ACT = 3, int NW = 4, int OCC = 1, int LAY = 0, int BM = 64, int PREC = 0, int WS = 0, int SC = 0>
 __global__ __launch_bounds__(64 * NW, OCC * NW / 4) void conv_h2_kernel(ConvH2P p) {
   static_assert(!WS || KS == 3, "the one-slab layout is for the 3x3 kernels");
-  static_assert(!SC || (KS == 3 && GM == 0 && ACT == 2 && BM >= 64 && (LAY & 1)), "fused shortcut: plain 3x3 conv2 of a resnet, blocked sources");
-  using K0 = std::integral_constant<int, 0>;   // chunk kinds: 0 = a 3x3 chunk of the main (normalised) source,
-  using K1 = std::integral_constant<int, 1>;   //              1 = a one-tap chunk of the shortcut source,
-  using KN = std::integral_constant<int, -1>;  //             -1 = none
+  static_assert(!SC || (KS == 3 && GM == 0 && ACT == 2 && BM >= 64 && (LAY & 1) && PREC == 0),
+                "fused shortcut: plain 3x3 conv2 of a resnet, channel-blocked fp32 sources");
+  using K0 = std::integral_constant<int, 0>;   // operand kinds: 0 = the main source (GroupNorm affine + SiLU as configured),
+  using K1 = std::integral_constant<int, 1>;   //                1 = the fused shortcut's raw source
   constexpr bool SB = (LAY & 1) != 0, DB = (LAY & 2) != 0;
   constexpr int NP = PREC ? 1 : 2;              // operand pieces
   constexpr bool S16 = PREC != 0 && SB;         // 16-bit sources (8 channels of a pixel = one 16-byte load)
@@ -424,16 +424,16 @@ __global__ __launch_bounds__(64 * NW, OCC * NW / 4) void conv_h2_kernel(ConvH2P 
       }
     }
   };
-  auto stage_step = [&](auto kt, int P, int qs, unsigned char* buf, bool stage, bool load, const char* spn, const float4& s4) {  // (loads: chunk qs + 1)
+  auto stage_step = [&](int P, int qs, unsigned char* buf, bool stage, bool load, const char* spn, const float4& s4) {  // (loads: chunk qs + 1)
     const int i = P / 4, jp = P % 4;
     if (stage) {
-      if constexpr (S16 && (ACT == 0 || decltype(kt)::value == 1)) {
+      if constexpr (S16 && ACT == 0) {
         w1s[i][jp] = xr.q[i][jp];
         w2s[i][jp] = 0;
       } else {
         float a, b;
         pair_of(xr, i, jp, a, b);
-        to_operand(kt, a, b, s4, w1s[i][jp], w2s[i][jp]);
+        to_operand(K0{}, a, b, s4, w1s[i][jp], w2s[i][jp]);
       }
       if (jp == 3) {
         _Float16* xb = reinterpret_cast<_Float16*>(buf);
@@ -534,6 +534,137 @@ __global__ __launch_bounds__(64 * NW, OCC * NW / 4) void conv_h2_kernel(ConvH2P 
   unsigned char* buf0 = smem_raw;
   unsigned char* buf1 = smem_raw + H2_BUF1_OFF;
 
+  auto scale_acc = [&](float f) {
+#pragma unroll
+    for (int mt = 0; mt < MTN; ++mt)
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          acc_hi[mt][nt][r] *= f;
+          if constexpr (NP == 2) acc_lo[mt][nt][r] *= f;
+        }
+  };
+  // ---- Fused shortcut: sc_cin / 16 one-tap chunks of the resnet's raw input on the same accumulators -----------------
+  // No staging pass here.  A 1x1 conv's B fragment -- the 8 channels of k-group `half` at this lane's pixel -- is used by
+  // exactly one wave, so the fp32 -> (hi, scaled lo) split is done by the consumer, on fragments read straight from the RAW
+  // fp32 rows: in the channel-blocked layout a tile row of one channel block is 1 KB of contiguous HBM, i.e. ONE
+  // global_load_lds_dwordx4 per (k-group, row), issued by the wave that will read it.  The K loop's buffers are free, so
+  // the rows go into a ring of SCD chunk slots [g][row][32 px][8 ch] fp32 (+ the shortcut's weight slabs beside it):
+  // SCD - 1 chunks of loads are in flight per workgroup with no register holding them -- the phase streams at what HBM
+  // gives (a register-staged one-tap chunk has one chunk's time, ~0.4 us, to cover ~1 us of latency: measured 2.3-3.0 k
+  // cycles per chunk).  One barrier per chunk publishes the weight slab; raw rows need none (own DMAs, own vmcnt).
+  // Which phase comes first alternates with the tile's position (16-row band + column tile: the same for every tile
+  // geometry and batch size, so a pixel's summation order never depends on the launch): while one workgroup streams its
+  // shortcut rows -- HBM-bound, matrix pipe idle -- its neighbours are in their 3x3 chunks -- matrix pipe busy, HBM idle.
+  // With every workgroup in the same phase at the same time the two phases' times simply add up (measured: 252 us of
+  // 3x3 chunks + 149 us of shortcut rows at 5.4 TB/s on the 192 -> 64 @ 256^2 resnets).
+  const bool sc_first = SC && (((oy0 >> 4) + tx) & 1) != 0;
+  auto sc_phase = [&](const bool first) {
+    constexpr int SCD = 4;                               // ring depth
+    constexpr int RAW_BYTES = 2 * H2_TH * 1024;          // a chunk's raw rows
+    constexpr int SCW_BYTES = NUNIT_SC * 1024;           // a chunk's weight slab
+    constexpr int SCW_OFF = SCD * RAW_BYTES;
+    constexpr int PER = NDMA_SC + 2 * NT;                // DMA instructions per wave and chunk
+    static_assert(SCD == 4, "the tail below is written out for three chunks in flight");
+    static_assert(!SC || SCW_OFF + SCD * SCW_BYTES <= 160 * 1024 / OCC, "the shortcut ring must fit the workgroup's share of LDS");
+    static_assert(!SC || (SCD - 2) * PER <= 63, "vmcnt range");
+    const int ns = p.sc_cin / H2_KC;                     // (the host dispatches here with ns >= SCD)
+    int rowoff[2 * NT], ldsoff[2 * NT];                  // this wave's (k-group, row) pieces: global / LDS byte offsets
+#pragma unroll
+    for (int k = 0; k < 2 * NT; ++k) {
+      const int g = k / NT, row = wave * NT + k % NT;
+      rowoff[k] = __builtin_amdgcn_readfirstlane(g * 8 * plane * 4 + ((oy0 + row) * p.win + ox0) * 32);
+      ldsoff[k] = __builtin_amdgcn_readfirstlane((g * H2_TH + row) * 1024);
+    }
+    auto sc_issue = [&](int j) {  // every DMA of chunk j (uniform)
+      unsigned char* slab = smem_raw + SCW_OFF + (j & (SCD - 1)) * SCW_BYTES;
+#pragma unroll
+      for (int k = 0; k < NDMA_SC; ++k) dma_weights_sc(k, sc_wtile + (size_t)j * sc_chunkb, slab);
+      const char* sp = sc_src_of(j);
+      unsigned char* ring = smem_raw + (j & (SCD - 1)) * RAW_BYTES;
+#pragma unroll
+      for (int k = 0; k < 2 * NT; ++k) {
+        const unsigned lds_addr = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)(ring + ldsoff[k]);
+        asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1\n" ::"v"(lane16), "s"(sp + rowoff[k]),
+                     "s"(__builtin_amdgcn_readfirstlane(lds_addr))
+                     : "memory");
+      }
+    };
+    auto sc_compute = [&](int j) {
+      const _Float16* wl = reinterpret_cast<const _Float16*>(smem_raw + SCW_OFF + (j & (SCD - 1)) * SCW_BYTES);
+      const float* raw = reinterpret_cast<const float*>(smem_raw + (j & (SCD - 1)) * RAW_BYTES);
+      half8 fa[MTN][NP];
+      float4 rv[NT][2];
+#pragma unroll
+      for (int mt = 0; mt < MTN; ++mt)
+#pragma unroll
+        for (int pc = 0; pc < NP; ++pc)
+          fa[mt][pc] = *reinterpret_cast<const half8*>(wl + ((pc * 2 + half) * BM + mt * 32 + l31) * 8);
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) {
+        const float4* rp = reinterpret_cast<const float4*>(raw + ((half * H2_TH + wave * NT + nt) * 32 + l31) * 8);
+        rv[nt][0] = rp[0];
+        rv[nt][1] = rp[1];
+      }
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) {
+        unsigned w1[4], w2[4];
+        const float4 dummy = make_float4(1.f, 1.f, 0.f, 0.f);
+        to_operand(K1{}, rv[nt][0].x, rv[nt][0].y, dummy, w1[0], w2[0]);
+        to_operand(K1{}, rv[nt][0].z, rv[nt][0].w, dummy, w1[1], w2[1]);
+        to_operand(K1{}, rv[nt][1].x, rv[nt][1].y, dummy, w1[2], w2[2]);
+        to_operand(K1{}, rv[nt][1].z, rv[nt][1].w, dummy, w1[3], w2[3]);
+        const half8 b_hi = __builtin_bit_cast(half8, st_u32x4{w1[0], w1[1], w1[2], w1[3]});
+        const half8 b_lo = __builtin_bit_cast(half8, st_u32x4{w2[0], w2[1], w2[2], w2[3]});
+#pragma unroll
+        for (int mt = 0; mt < MTN; ++mt) {
+          if constexpr (NP == 2) {
+            acc_hi[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[mt][0], b_hi, acc_hi[mt][nt], 0, 0, 0);
+            acc_lo[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[mt][0], b_lo, acc_lo[mt][nt], 0, 0, 0);
+            acc_lo[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[mt][1], b_hi, acc_lo[mt][nt], 0, 0, 0);
+          } else {
+            acc_hi[mt][nt] = mma16<PREC>(fa[mt][0], b_hi, acc_hi[mt][nt]);
+          }
+        }
+      }
+    };
+    // (first phase: nothing has touched LDS yet; second: the K loop's closing barrier is behind us)
+#pragma unroll
+    for (int j = 0; j < SCD - 1; ++j) sc_issue(j);
+    if constexpr (PREC == 0) {
+      // Range guard: the shortcut's products arrive scaled by xs = 2^-e (their source was).  Second phase: the 3x3
+      // chunks' sums, already in the accumulators, take the same factor here and the epilogue multiplies everything by
+      // 2^e.  First phase: the factor is taken back out after the last shortcut chunk (below), before the 3x3 chunks add
+      // theirs.  Powers of two, exact; uniform branches that only an out-of-range source ever takes.
+      if (!first && xs != 1.f) scale_acc(xs);
+    }
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"((SCD - 2) * PER) : "memory");  // chunk 0 has landed
+    __syncthreads();
+    int j = 0;
+    for (; j + SCD - 1 < ns; ++j) {
+      sc_issue(j + SCD - 1);   // into the slot chunk j - 1 was read from (own rows: program order; slab: the barrier)
+      sc_compute(j);
+      asm volatile("s_waitcnt vmcnt(%0)" ::"n"((SCD - 2) * PER) : "memory");  // chunk j + 1 has landed
+      __syncthreads();
+    }
+    // the last SCD - 1 chunks: nothing left to issue
+    sc_compute(j++);
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PER) : "memory");
+    __syncthreads();
+    sc_compute(j++);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    sc_compute(j);
+    if constexpr (PREC == 0) {
+      if (first && xs != 1.f) scale_acc(rg_out);
+    }
+    __syncthreads();  // (the K loop's prologue / the epilogue re-use LDS)
+  };
+  if constexpr (SC) {
+    if (sc_first) sc_phase(true);
+  }
+
   // zero padding: halo positions outside the image are zeroed once in both buffers and never written again
 #pragma unroll
   for (int i = 0; i < H2_NU; ++i) {
@@ -611,17 +742,12 @@ __global__ __launch_bounds__(64 * NW, OCC * NW / 4) void conv_h2_kernel(ConvH2P 
   unsigned long long t_vm = 0, t_bar = 0;
   const unsigned long long rt_start = __builtin_amdgcn_s_memrealtime();  // 100 MHz, same base on every CU
 #endif
-  // q: index in the unified chunk sequence (main chunks 0 .. nq-1, then -- SC -- shortcut chunks nq .. nq+ns-1);
-  // ck / sk / lk: kind of the chunk computed / staged (q+1) / loaded (q+2), see K0 / K1 / KN
-  auto chunk = [&](int q, auto ck, auto sk, auto lk) {
-    constexpr int CK = decltype(ck)::value, SK = decltype(sk)::value, LK = decltype(lk)::value;
-    constexpr bool STAGE = SK >= 0, LOAD = LK >= 0;
-    constexpr int CTAPS = CK == 1 ? 1 : TAPS;  // taps of the chunk computed
+  auto chunk = [&](int q, auto stage_tag, auto load_tag) {
+    constexpr bool STAGE = decltype(stage_tag)::value, LOAD = decltype(load_tag)::value;
     unsigned char* cur = (q & 1) ? buf1 : buf0;
     unsigned char* nxt = (q & 1) ? buf0 : buf1;
-    const char* spn = !LOAD ? nullptr : (LK == 1 ? sc_src_of(q + 2 - nq) : src_of(q + 2));
-    // the staged chunk's weights
-    const char* wqn = SK == 1 ? sc_wtile + (size_t)(q + 1 - nq) * sc_chunkb : wtile + (size_t)(q + 1) * chunkb;
+    const char* spn = LOAD ? src_of(q + 2) : nullptr;
+    const char* wqn = wtile + (size_t)(q + 1) * chunkb;  // the staged chunk's weights
     const _Float16* wl = reinterpret_cast<const _Float16*>(WS ? buf0 : cur);
     const _Float16* xl = reinterpret_cast<const _Float16*>(cur) + H2_WHALFS;
     // Operand fragments are fetched one tap ahead into the other half of fa/fb: the reads of tap t+1 are issued
@@ -629,16 +755,15 @@ __global__ __launch_bounds__(64 * NW, OCC * NW / 4) void conv_h2_kernel(ConvH2P 
     // is free to interleave them with the staging work (LDS reads after a possibly-aliasing LDS write are not).
     half8 fa[2][MTN][NP], fb[2][NT][NP];  // [parity][tile][piece]
     auto load_frags = [&](int tap, int par) {
-      // folded up-sampler: the phase's 2x2 corner of the patch; stride 2: the {y-1, y} x {x-1, x} corner;
-      // shortcut chunk: the centre of the 3x3 patch
-      const int dy = CK == 1 ? 1 : (GM == 2 ? (phase >> 1) + (tap >> 1) : (GM == 3 ? (tap >> 1) : tap / KS));
-      const int dx = CK == 1 ? 1 : (GM == 2 ? (phase & 1) + (tap & 1) : (GM == 3 ? (tap & 1) : tap % KS));
+      // folded up-sampler: the phase's 2x2 corner of the patch; stride 2: the {y-1, y} x {x-1, x} corner
+      const int dy = GM == 2 ? (phase >> 1) + (tap >> 1) : (GM == 3 ? (tap >> 1) : tap / KS);
+      const int dx = GM == 2 ? (phase & 1) + (tap & 1) : (GM == 3 ? (tap & 1) : tap % KS);
 #pragma unroll
       for (int mt = 0; mt < MTN; ++mt)
 #pragma unroll
         for (int pc = 0; pc < NP; ++pc)
           fa[par][mt][pc] =
-              *reinterpret_cast<const half8*>(wl + (((pc * CTAPS + tap) * 2 + half) * BM + mt * 32 + l31) * 8);
+              *reinterpret_cast<const half8*>(wl + (((pc * TAPS + tap) * 2 + half) * BM + mt * 32 + l31) * 8);
 #pragma unroll
       for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
@@ -648,7 +773,7 @@ __global__ __launch_bounds__(64 * NW, OCC * NW / 4) void conv_h2_kernel(ConvH2P 
     };
     load_frags(0, 0);
 #pragma unroll
-    for (int tap = 0; tap < CTAPS; ++tap) {
+    for (int tap = 0; tap < TAPS; ++tap) {
       __builtin_amdgcn_sched_barrier(0);
 #ifdef DSG_H2_TIMING
       const unsigned long long tt0 = __builtin_readcyclecounter();
@@ -656,9 +781,9 @@ __global__ __launch_bounds__(64 * NW, OCC * NW / 4) void conv_h2_kernel(ConvH2P 
 #endif
       // next tap's scale/shift entries (BEFORE the fragments in program order: LDS returns in order, so a counted wait
       // covers the entries alone); the clear last tap fetches tap 0's entries of the next chunk
-      if (CK == 0 && SK == 0 && tap + 1 < TAPS - 1) load_ss(tap + 1, q + 1);
-      if (CK == 0 && LK == 0 && tap == TAPS - 1) load_ss(0, q + 2);
-      if (tap + 1 < CTAPS) load_frags(tap + 1, (tap + 1) & 1);
+      if (STAGE && tap + 1 < TAPS - 1) load_ss(tap + 1, q + 1);
+      if (LOAD && tap == TAPS - 1) load_ss(0, q + 2);
+      if (tap + 1 < TAPS) load_frags(tap + 1, (tap + 1) & 1);
       if (KS == 1) {  // one tap: all units and the four weight segments ride on it
 #pragma unroll
         for (int u = 0; u < H2_NU; ++u) {
@@ -669,34 +794,18 @@ __global__ __launch_bounds__(64 * NW, OCC * NW / 4) void conv_h2_kernel(ConvH2P 
       }
       // KS = 3: the chunk's staging steps and weight DMAs are dealt out evenly over taps 0..TAPS-2 (the last tap
       // stays clear so that the newest loads have a tap's worth of MFMAs to land before the closing vmcnt(0))
-      if (KS == 3 && CK == 0 && tap < TAPS - 1) {
-        constexpr int NSTEP = 4 * H2_NU, ST = TAPS - 1;
+      if (KS == 3 && tap < TAPS - 1) {
+        constexpr int NSTEP = 4 * H2_NU, ST = TAPS > 1 ? TAPS - 1 : 1;
 #pragma unroll
         for (int P = tap * NSTEP / ST; P < (tap + 1) * NSTEP / ST; ++P)
-          stage_step(sk, P, q + 1, nxt, STAGE, LOAD, spn,
-                     (SK == 0 && has_ss) ? s4b[tap & 1][P - tap * NSTEP / ST] : make_float4(1.f, 1.f, 0.f, 0.f));
+          stage_step(P, q + 1, nxt, STAGE, LOAD, spn,
+                     has_ss ? s4b[tap & 1][P - tap * NSTEP / ST] : make_float4(1.f, 1.f, 0.f, 0.f));
 #ifndef DSG_H2_ABL_NODMA
         if (STAGE && !WS) {
-          if constexpr (SK == 1) {  // the shortcut's slab is NDMA_SC units per wave: all on the first tap
-            if (tap == 0) {
 #pragma unroll
-              for (int k = 0; k < NDMA_SC; ++k) dma_weights_sc(k, wqn, nxt);
-            }
-          } else {
-#pragma unroll
-            for (int k = tap * G::NDMA / ST; k < (tap + 1) * G::NDMA / ST; ++k) dma_weights(k, wqn, nxt);
-          }
+          for (int k = tap * G::NDMA / ST; k < (tap + 1) * G::NDMA / ST; ++k) dma_weights(k, wqn, nxt);
         }
 #endif
-      }
-      if (KS == 3 && CK == 1 && (STAGE || LOAD)) {  // a one-tap chunk: every staging step rides on it
-        if (STAGE && !WS) {
-#pragma unroll
-          for (int k = 0; k < NDMA_SC; ++k) dma_weights_sc(k, wqn, nxt);
-        }
-#pragma unroll
-        for (int P = 0; P < 4 * H2_NU; ++P)
-          stage_step(sk, P, q + 1, nxt, STAGE, LOAD, spn, make_float4(1.f, 1.f, 0.f, 0.f));
       }
       const int par = tap & 1;
 #pragma unroll
@@ -714,19 +823,12 @@ __global__ __launch_bounds__(64 * NW, OCC * NW / 4) void conv_h2_kernel(ConvH2P 
       // Issue order within the tap: with one wave per SIMD nothing else fills the matrix pipe while this wave
       // issues staging work, so spread that work between the MFMAs (at most ~5 issues hide behind one MFMA)
       // instead of leaving it in one block as the scheduler would.
-      if (KS == 3 && CK == 0 && tap < TAPS - 1 && (STAGE || LOAD)) {
+      if (KS == 3 && tap < TAPS - 1 && (STAGE || LOAD)) {
 #pragma unroll
         for (int m = 0; m < (NP == 2 ? 3 : 1) * MTN * NT; ++m) {
           __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);  // 1 MFMA
           // 2 VALU per MFMA (a third of the MFMAs: 5; 128 couts, twice the MFMAs per tap again: 3)
           __builtin_amdgcn_sched_group_barrier(0x002, NP == 2 ? 2 : (BM == 128 ? 3 : 5), 0);
-        }
-      }
-      if (KS == 3 && CK == 1 && (STAGE || LOAD)) {  // (a whole chunk's staging behind a tap's MFMAs: as many as hide)
-#pragma unroll
-        for (int m = 0; m < (NP == 2 ? 3 : 1) * MTN * NT; ++m) {
-          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-          __builtin_amdgcn_sched_group_barrier(0x002, 5, 0);
         }
       }
 #ifdef DSG_H2_TIMING
@@ -736,13 +838,8 @@ __global__ __launch_bounds__(64 * NW, OCC * NW / 4) void conv_h2_kernel(ConvH2P 
     }
     __builtin_amdgcn_sched_barrier(0);
     auto dma_next_slab = [&]() {  // WS: the staged chunk's whole weight slab, after everyone is done with this one's
-      if constexpr (SK == 1) {
 #pragma unroll
-        for (int k = 0; k < NDMA_SC; ++k) dma_weights_sc(k, wqn, buf0);
-      } else {
-#pragma unroll
-        for (int k = 0; k < G::NDMA; ++k) dma_weights(k, wqn, buf0);
-      }
+      for (int k = 0; k < G::NDMA; ++k) dma_weights(k, wqn, buf0);
     };
 #ifdef DSG_H2_TIMING  // tools/ only: where does a wave wait at the end of a chunk?  (p.stats = 4 counters)
     const unsigned long long ta = __builtin_readcyclecounter();
@@ -780,44 +877,23 @@ __global__ __launch_bounds__(64 * NW, OCC * NW / 4) void conv_h2_kernel(ConvH2P 
   const unsigned long long t_begin = __builtin_readcyclecounter();
   const unsigned long long rt_loop = __builtin_amdgcn_s_memrealtime();
 #endif
+  using T = std::true_type;
+  using F = std::false_type;
   int q = 0;
-  if constexpr (SC) {
-    // (the host dispatches here with nq >= 2 main chunks and ns >= 2 shortcut chunks)
-    const int ns = p.sc_cin / H2_KC;
-    for (; q + 2 < nq; ++q) chunk(q, K0{}, K0{}, K0{});
-    chunk(q++, K0{}, K0{}, K1{});  // q = nq - 2: stages the last main chunk, loads the shortcut's first
-    chunk(q++, K0{}, K1{}, K1{});  // q = nq - 1: stages the shortcut's first chunk, loads its second
-    if constexpr (PREC == 0) {
-      // Range guard: the shortcut's products arrive scaled by xs = 2^-e (their source was), and the epilogue multiplies
-      // the accumulators by 2^e.  The main chunks' sums, already in the same accumulators, take the factor here --
-      // powers of two, exact; a uniform branch that only an out-of-range source ever takes.
-      if (xs != 1.f) {
-#pragma unroll
-        for (int mt = 0; mt < MTN; ++mt)
-#pragma unroll
-          for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-              acc_hi[mt][nt][r] *= xs;
-              acc_lo[mt][nt][r] *= xs;
-            }
-      }
-    }
-    for (; q + 2 < nq + ns; ++q) chunk(q, K1{}, K1{}, K1{});
-    chunk(q++, K1{}, K1{}, KN{});
-    chunk(q, K1{}, KN{}, KN{});
-  } else {
 #if defined(DSG_H2_ABL_NOSTAGE)  // (tools/ timing experiments only: wrong results, loop time without a component)
-    for (; q + 2 < nq; ++q) chunk(q, K0{}, KN{}, K0{});
+  for (; q + 2 < nq; ++q) chunk(q, F{}, T{});
 #elif defined(DSG_H2_ABL_NOLOAD)
-    for (; q + 2 < nq; ++q) chunk(q, K0{}, K0{}, KN{});
+  for (; q + 2 < nq; ++q) chunk(q, T{}, F{});
 #elif defined(DSG_H2_ABL_MFMAONLY)
-    for (; q + 2 < nq; ++q) chunk(q, K0{}, KN{}, KN{});
+  for (; q + 2 < nq; ++q) chunk(q, F{}, F{});
 #else
-    for (; q + 2 < nq; ++q) chunk(q, K0{}, K0{}, K0{});
+  for (; q + 2 < nq; ++q) chunk(q, T{}, T{});
 #endif
-    if (q + 1 < nq) chunk(q++, K0{}, K0{}, KN{});  // last staged chunk: nothing left to load
-    chunk(q, K0{}, KN{}, KN{});                    // last chunk: MFMAs only
+  if (q + 1 < nq) chunk(q++, T{}, F{});  // last staged chunk: nothing left to load
+  chunk(q, F{}, F{});                    // last chunk: MFMAs only
+
+  if constexpr (SC) {
+    if (!sc_first) sc_phase(false);
   }
 #ifdef DSG_H2_TIMING
   const unsigned long long rt_loop_end = __builtin_amdgcn_s_memrealtime();
@@ -898,6 +974,7 @@ __global__ __launch_bounds__(64 * NW, OCC * NW / 4) void conv_h2_kernel(ConvH2P 
   // with four compile-time variants behind a four-way branch the compiler hoisted their common head -- the read-out of
   // half the accumulators -- above the branch, spilled 32 of them there and reloaded them in every variant behind the
   // first slab's stores.
+  const float ep_scale = (SC && sc_first) ? 1.f : rg_out;  // (shortcut-first tiles took the guard's factor back out already)
   auto epilogue = [&](const bool STATS) {
     constexpr bool NARROW = true;
 #pragma unroll
@@ -957,7 +1034,7 @@ __global__ __launch_bounds__(64 * NW, OCC * NW / 4) void conv_h2_kernel(ConvH2P 
           for (int nt = 0; nt < NT; ++nt) {
             const int r = 4 * rg + j;
             if constexpr (NP == 2 && (ACT != 2 || SC))
-              vv[j][nt] = ((acc_hi[mt][nt][r] + acc_lo[mt][nt][r] * (1.0f / 2048.0f)) * rg_out + addv[r]) + rv[r][nt];
+              vv[j][nt] = ((acc_hi[mt][nt][r] + acc_lo[mt][nt][r] * (1.0f / 2048.0f)) * ep_scale + addv[r]) + rv[r][nt];
             else if constexpr (NP == 2)
               vv[j][nt] = ((acc_hi[mt][nt][r] + acc_lo[mt][nt][r] * (1.0f / 2048.0f)) + addv[r]) + rv[r][nt];
             else

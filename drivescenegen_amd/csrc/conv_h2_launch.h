@@ -53,6 +53,10 @@ static int h2_launch(dim3 grid, size_t lds, hipStream_t st, const ConvH2P& p) {
                                 160 * 1024));
     raised = true;
   }
+  if constexpr (SC) {  // the shortcut phase's ring: 4 chunks of raw rows + 4 weight slabs (conv_h2_kernel.h)
+    constexpr size_t SC_LDS = 4 * (size_t)(2 * NW * NT * 1024) + 4 * (size_t)(2 * (PREC ? 1 : 2) * BM / 64) * 1024;
+    if (lds < SC_LDS) lds = SC_LDS;
+  }
   // the epilogue's statistics tables live in the (by then free) K-loop buffers: [NW][row pairs][2][BM] partials + a
   // [values][64 lanes] table per wave; the pointwise kernels' buffers are smaller than that
   constexpr size_t STATS_LDS = ((size_t)NW * (NT / 2) * 2 * BM + (size_t)NW * (16 * (NT / 2) * 2) * 64) * sizeof(float);

@@ -325,9 +325,15 @@ struct Runner {
 
   // want_stats: the result feeds a GroupNorm -- have the conv write its per-tile statistics when it can
   // dst_blk: layout of the result (-1: the net's default for intermediates)
+  // A resnet's shortcut offered to its conv2 for fusion (dsg_conv_args.sc_*): the 1x1 conv, its source(s) -- the resnet's
+  // raw input -- and their range bound.  `taken` tells the caller whether conv2 contracted it.
+  struct Shortcut {
+    const T* x; const T* skip; const Conv* cv; const unsigned* bound; bool taken;
+  };
+
   T conv(const T& x, const T* skip, const Conv& cv, int stride, int ups, const T* ss, int silu, const float* temb,
          const T* res, float* dst_override = nullptr, bool want_stats = false, int dst_blk = -1,
-         const unsigned* raw_bound = nullptr) {
+         const unsigned* raw_bound = nullptr, Shortcut* sc = nullptr) {
     if (dst_blk < 0) dst_blk = blocked ? 1 : 0;
     if (ok() && ((skip && skip->blk != x.blk) || (res && res->blk != dst_blk)))
       rc = dsg::fail(DSG_ERR_INVALID_ARG, "dsg_unet_forward: mixed activation layouts in one conv (internal)");
@@ -372,6 +378,24 @@ struct Runner {
         a.splitk_ws_bytes = sk;
       }
     }
+    if (sc && ok()) {  // offer the shortcut; keep it only if this call's kernel contracts it
+      sc->taken = false;
+      if (!res && sc->cv->wh && !sc->cv->off_split && !cv.off_split && sc->x->blk == x.blk &&
+          (!sc->skip || sc->skip->blk == x.blk)) {
+        a.sc_src0 = sc->x->p; a.sc_c0 = sc->x->c;
+        a.sc_src1 = sc->skip ? sc->skip->p : nullptr; a.sc_c1 = sc->skip ? sc->skip->c : 0;
+        a.sc_weight_h2 = sc->cv->wh; a.sc_bias = sc->cv->b;
+        a.sc_src_bound = sc->bound;   // (one bound for the concatenation: gn_ss leaves it)
+        int32_t yes = 0;
+        rc = dsg_conv2d_fuses_shortcut(&a, &yes);
+        sc->taken = ok() && yes != 0;
+        if (!sc->taken) {
+          a.sc_src0 = a.sc_src1 = a.sc_weight_h2 = nullptr; a.sc_bias = nullptr; a.sc_src_bound = nullptr;
+          a.sc_c0 = a.sc_c1 = 0;
+        }
+      }
+      if (!sc->taken) return y;  // (the caller runs the 1x1 on its own and calls again with its result as the residual)
+    }
     if (want_stats && ok()) {
       int32_t tiles = 0;
       rc = dsg_conv2d_stats_tiles(&a, &tiles);
@@ -396,8 +420,15 @@ struct Runner {
     T ss2 = gn_ss(hmid, nullptr, r.n2);
     T y;
     if (r.sc) {
-      T sc = conv(x, skip, r.csc, 1, 0, nullptr, 0, nullptr, nullptr, nullptr, false, -1, raw);
-      y = conv(hmid, nullptr, r.c2, 1, 0, &ss2, 1, nullptr, &sc, nullptr, true);
+      // conv_shortcut rides on conv2's K loop where the kernel takes it (ResnetBlock2D: conv_shortcut(input) + conv2(...));
+      // otherwise it is a 1x1 call of its own whose result conv2 adds as its residual
+      Shortcut fuse{&x, skip, &r.csc, raw, false};
+      y = conv(hmid, nullptr, r.c2, 1, 0, &ss2, 1, nullptr, nullptr, nullptr, true, -1, nullptr, &fuse);
+      if (!fuse.taken) {
+        y = T();
+        T sc = conv(x, skip, r.csc, 1, 0, nullptr, 0, nullptr, nullptr, nullptr, false, -1, raw);
+        y = conv(hmid, nullptr, r.c2, 1, 0, &ss2, 1, nullptr, &sc, nullptr, true);
+      }
     } else {
       y = conv(hmid, nullptr, r.c2, 1, 0, &ss2, 1, nullptr, &x, nullptr, true);
     }

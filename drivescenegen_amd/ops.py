@@ -136,14 +136,17 @@ def conv2d_fused(src0, weight_r, bias=None, src1=None, ksize=3, stride=1, upsamp
                  silu=False, temb=None, temb_stride=0, residual=None, out=None, direct=False, cout=None,
                  pool2=False, wstride=None, weight_h2=None, want_stats=False, stats_buf=None, weight_h2_col=0, weight_h2_fold=None,
                  src_blocked=False, dst_blocked=False, weight_h2_s2=None, compute_dtype=0, weight_h2_stride=0,
-                 src_bound=None, src_bound1=None, splitk=False):
+                 src_bound=None, src_bound1=None, splitk=False, shortcut=None):
     """dsg_conv2d_fwd: see include/dsg.h.  `weight_r` is in engine layout; `temb` is a [N, temb_stride] view
     whose first `cout` columns (from its data pointer) are added per (n, cout).
     want_stats: also return the per-tile GroupNorm statistics [N][cout][tiles][2] (fp64) of the result, or None
     when the kernel serving the call does not produce them.
     src_blocked / dst_blocked: the sources / (result, residual) are channel-blocked [N, C/8, H, W, 8] tensors.
     compute_dtype: dsg_dtype ("bf16" / "fp16" / code): the channel-blocked tensors are then torch.bfloat16 / float16 and
-    weight_h2* must come from pack_conv_weight(..., dtype=the same); [N, C, H, W] tensors stay fp32."""
+    weight_h2* must come from pack_conv_weight(..., dtype=the same); [N, C, H, W] tensors stay fp32.
+    shortcut: dict(src0=, src1=None, weight_h2=, bias=None, bound=None, bound1=None) -- the resnet's 1x1 conv_shortcut over
+    its raw input, contracted in the same kernel (dsg_conv_args.sc_*); raises when the call cannot fuse it
+    (ask `conv2d_fuses_shortcut` first)."""
     lib = _lib.load()
     cdt = dtype_code(compute_dtype)
     blk_dtype = _lib.TORCH_DTYPES[cdt]
@@ -199,6 +202,14 @@ def conv2d_fused(src0, weight_r, bias=None, src1=None, ksize=3, stride=1, upsamp
     a.residual, a.dst = _lib.ptr(residual), _lib.ptr(out)
     # range guard of the split path (include/dsg.h): int32 [N] tensors holding float bits
     a.src_bound, a.src_bound1 = _lib.ptr(src_bound), _lib.ptr(src_bound1)
+    if shortcut is not None:
+        s0, s1 = shortcut["src0"], shortcut.get("src1")
+        a.sc_src0, a.sc_src1 = _lib.ptr(s0), _lib.ptr(s1)
+        a.sc_c0 = 8 * s0.shape[1] if src_blocked else s0.shape[1]
+        a.sc_c1 = 0 if s1 is None else (8 * s1.shape[1] if src_blocked else s1.shape[1])
+        a.sc_weight_h2 = shortcut["weight_h2"].data_ptr()
+        a.sc_bias = _lib.ptr(shortcut.get("bias"))
+        a.sc_src_bound, a.sc_src_bound1 = _lib.ptr(shortcut.get("bound")), _lib.ptr(shortcut.get("bound1"))
     scratch = None
     if splitk:   # small-grid calls may contract K in parallel slices (dsg_conv_args.splitk_ws)
         need = C.c_size_t()
@@ -214,6 +225,10 @@ def conv2d_fused(src0, weight_r, bias=None, src1=None, ksize=3, stride=1, upsamp
             stats = stats_buf if stats_buf is not None else torch.empty(
                 (n, cout, tiles.value, 2), dtype=torch.float64, device=src0.device)
             a.stats_out = stats.data_ptr()
+    if shortcut is not None and shortcut.get("query_only"):
+        yes = C.c_int32(0)
+        _lib.check(lib.dsg_conv2d_fuses_shortcut(C.byref(a), C.byref(yes)))
+        return bool(yes.value)
     fn = lib.dsg_conv2d_fwd_direct if direct else lib.dsg_conv2d_fwd
     with torch.cuda.device(src0.device):
         _lib.check(fn(C.byref(a), _st(src0)))
