@@ -56,11 +56,12 @@ bool conv_h2_eligible(const dsg_conv_args* a, int hout, int wout) {
 
 // Fused shortcut (dsg_conv_args.sc_*): a resnet's conv2 -- 3x3, stride 1, GroupNorm + SiLU in front, every tensor
 // channel-blocked, no residual -- takes the 1x1 conv_shortcut over the resnet's raw input into its own K loop.
-// fp32-equivalent mode only so far; a call that would split K (small batches) keeps the separate shortcut kernel.
+// Every dsg_dtype; a call that would split K (small batches, fp32-equivalent mode) keeps the separate shortcut kernel.
 bool conv_h2_sc_fusable(const dsg_conv_args* a, int hout, int wout) {
-  if (!g_h2.enabled || !g_h2.fuse_sc || a->compute_dtype != DSG_F32) return false;
+  if (!g_h2.enabled || !g_h2.fuse_sc) return false;
   if (a->ksize != 3 || a->stride != 1 || a->upsample || a->pool2 || !a->gn_scale_shift || !a->silu || a->residual) return false;
-  if (a->src_layout != 1 || a->dst_layout != 1 || a->weight_h2 == nullptr || a->weight_h2_cout_stride) return false;
+  if (a->src_layout != 1 || a->dst_layout != 1 || a->weight_h2 == nullptr) return false;
+  if (a->weight_h2_cout_stride && a->weight_h2_cout_stride != (a->cout + 63) / 64 * 64) return false;  // (no column windows)
   if (!conv_h2_eligible(a, hout, wout) || wout % H2_TW != 0) return false;
   const int cin = a->c0 + a->c1, sc_cin = a->sc_c0 + (a->sc_src1 ? a->sc_c1 : 0);
   if (cin < 2 * H2_KC || sc_cin < 4 * H2_KC || sc_cin % H2_KC || (a->sc_src1 && a->sc_c0 % H2_KC)) return false;  // (ring depth 4)

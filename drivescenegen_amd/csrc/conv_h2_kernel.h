@@ -165,8 +165,8 @@ __device__ __forceinline__ float silu_fast_h(float x) { return x * __builtin_amd
 template <int GM, int NT, int KS, int ACT = 3, int NW = 4, int OCC = 1, int LAY = 0, int BM = 64, int PREC = 0, int WS = 0, int SC = 0>
 __global__ __launch_bounds__(64 * NW, OCC * NW / 4) void conv_h2_kernel(ConvH2P p) {
   static_assert(!WS || KS == 3, "the one-slab layout is for the 3x3 kernels");
-  static_assert(!SC || (KS == 3 && GM == 0 && ACT == 2 && BM >= 64 && (LAY & 1) && PREC == 0),
-                "fused shortcut: plain 3x3 conv2 of a resnet, channel-blocked fp32 sources");
+  static_assert(!SC || (KS == 3 && GM == 0 && ACT == 2 && BM >= 64 && LAY == 3),
+                "fused shortcut: plain 3x3 conv2 of a resnet, channel-blocked tensors");
   using K0 = std::integral_constant<int, 0>;   // operand kinds: 0 = the main source (GroupNorm affine + SiLU as configured),
   using K1 = std::integral_constant<int, 1>;   //                1 = the fused shortcut's raw source
   constexpr bool SB = (LAY & 1) != 0, DB = (LAY & 2) != 0;
@@ -562,21 +562,26 @@ __global__ __launch_bounds__(64 * NW, OCC * NW / 4) void conv_h2_kernel(ConvH2P 
   const bool sc_first = SC && (((oy0 >> 4) + tx) & 1) != 0;
   auto sc_phase = [&](const bool first) {
     constexpr int SCD = 4;                               // ring depth
-    constexpr int RAW_BYTES = 2 * H2_TH * 1024;          // a chunk's raw rows
+    // 16-bit tensors: a row of a channel block is 512 B, so ONE DMA brings both k-groups of a row (lanes 32-63 address
+    // the second block: slot layout [row][g][32 px][8 ch]) and the words it lands ARE the B operands -- no arithmetic at all
+    constexpr int NRAW = S16 ? NT : 2 * NT;              // raw-row DMAs per wave and chunk
+    constexpr int RAW_BYTES = NW * NRAW * 1024;          // a chunk's raw rows
     constexpr int SCW_BYTES = NUNIT_SC * 1024;           // a chunk's weight slab
     constexpr int SCW_OFF = SCD * RAW_BYTES;
-    constexpr int PER = NDMA_SC + 2 * NT;                // DMA instructions per wave and chunk
+    constexpr int PER = NDMA_SC + NRAW;                  // DMA instructions per wave and chunk
     static_assert(SCD == 4, "the tail below is written out for three chunks in flight");
     static_assert(!SC || SCW_OFF + SCD * SCW_BYTES <= 160 * 1024 / OCC, "the shortcut ring must fit the workgroup's share of LDS");
     static_assert(!SC || (SCD - 2) * PER <= 63, "vmcnt range");
     const int ns = p.sc_cin / H2_KC;                     // (the host dispatches here with ns >= SCD)
-    int rowoff[2 * NT], ldsoff[2 * NT];                  // this wave's (k-group, row) pieces: global / LDS byte offsets
+    int rowoff[NRAW], ldsoff[NRAW];                      // this wave's pieces: global / LDS byte offsets (uniform)
 #pragma unroll
-    for (int k = 0; k < 2 * NT; ++k) {
-      const int g = k / NT, row = wave * NT + k % NT;
-      rowoff[k] = __builtin_amdgcn_readfirstlane(g * 8 * plane * 4 + ((oy0 + row) * p.win + ox0) * 32);
-      ldsoff[k] = __builtin_amdgcn_readfirstlane((g * H2_TH + row) * 1024);
+    for (int k = 0; k < NRAW; ++k) {
+      const int g = S16 ? 0 : k / NT, row = wave * NT + k % NT;
+      rowoff[k] = __builtin_amdgcn_readfirstlane(g * 8 * plane * ESS + ((oy0 + row) * p.win + ox0) * 8 * ESS);
+      ldsoff[k] = __builtin_amdgcn_readfirstlane(S16 ? row * 1024 : (g * H2_TH + row) * 1024);
     }
+    // per-lane part of a raw-row address: 16 bytes per lane; 16-bit rows: lanes 32-63 read the chunk's second channel block
+    const int lane_raw = S16 ? (lane >> 5) * (8 * plane * ESS) + (lane & 31) * 16 : lane * 16;
     auto sc_issue = [&](int j) {  // every DMA of chunk j (uniform)
       unsigned char* slab = smem_raw + SCW_OFF + (j & (SCD - 1)) * SCW_BYTES;
 #pragma unroll
@@ -584,18 +589,20 @@ __global__ __launch_bounds__(64 * NW, OCC * NW / 4) void conv_h2_kernel(ConvH2P 
       const char* sp = sc_src_of(j);
       unsigned char* ring = smem_raw + (j & (SCD - 1)) * RAW_BYTES;
 #pragma unroll
-      for (int k = 0; k < 2 * NT; ++k) {
+      for (int k = 0; k < NRAW; ++k) {
         const unsigned lds_addr = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)(ring + ldsoff[k]);
-        asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1\n" ::"v"(lane16), "s"(sp + rowoff[k]),
+        asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1\n" ::"v"(lane_raw), "s"(sp + rowoff[k]),
                      "s"(__builtin_amdgcn_readfirstlane(lds_addr))
                      : "memory");
       }
     };
     auto sc_compute = [&](int j) {
       const _Float16* wl = reinterpret_cast<const _Float16*>(smem_raw + SCW_OFF + (j & (SCD - 1)) * SCW_BYTES);
-      const float* raw = reinterpret_cast<const float*>(smem_raw + (j & (SCD - 1)) * RAW_BYTES);
+      const unsigned char* rawb = smem_raw + (j & (SCD - 1)) * RAW_BYTES;
+      const float* raw = reinterpret_cast<const float*>(rawb);
       half8 fa[MTN][NP];
-      float4 rv[NT][2];
+      float4 rv[S16 ? 1 : NT][2];
+      half8 rh[S16 ? NT : 1];
 #pragma unroll
       for (int mt = 0; mt < MTN; ++mt)
 #pragma unroll
@@ -603,20 +610,30 @@ __global__ __launch_bounds__(64 * NW, OCC * NW / 4) void conv_h2_kernel(ConvH2P 
           fa[mt][pc] = *reinterpret_cast<const half8*>(wl + ((pc * 2 + half) * BM + mt * 32 + l31) * 8);
 #pragma unroll
       for (int nt = 0; nt < NT; ++nt) {
-        const float4* rp = reinterpret_cast<const float4*>(raw + ((half * H2_TH + wave * NT + nt) * 32 + l31) * 8);
-        rv[nt][0] = rp[0];
-        rv[nt][1] = rp[1];
+        if constexpr (S16) {
+          rh[nt] = *reinterpret_cast<const half8*>(rawb + ((wave * NT + nt) * 2 + half) * 512 + l31 * 16);
+        } else {
+          const float4* rp = reinterpret_cast<const float4*>(raw + ((half * H2_TH + wave * NT + nt) * 32 + l31) * 8);
+          rv[nt][0] = rp[0];
+          rv[nt][1] = rp[1];
+        }
       }
 #pragma unroll
       for (int nt = 0; nt < NT; ++nt) {
-        unsigned w1[4], w2[4];
-        const float4 dummy = make_float4(1.f, 1.f, 0.f, 0.f);
-        to_operand(K1{}, rv[nt][0].x, rv[nt][0].y, dummy, w1[0], w2[0]);
-        to_operand(K1{}, rv[nt][0].z, rv[nt][0].w, dummy, w1[1], w2[1]);
-        to_operand(K1{}, rv[nt][1].x, rv[nt][1].y, dummy, w1[2], w2[2]);
-        to_operand(K1{}, rv[nt][1].z, rv[nt][1].w, dummy, w1[3], w2[3]);
-        const half8 b_hi = __builtin_bit_cast(half8, st_u32x4{w1[0], w1[1], w1[2], w1[3]});
-        const half8 b_lo = __builtin_bit_cast(half8, st_u32x4{w2[0], w2[1], w2[2], w2[3]});
+        half8 b_hi, b_lo;
+        if constexpr (S16) {
+          b_hi = rh[nt];
+          b_lo = rh[nt];
+        } else {
+          unsigned w1[4], w2[4];
+          const float4 dummy = make_float4(1.f, 1.f, 0.f, 0.f);
+          to_operand(K1{}, rv[nt][0].x, rv[nt][0].y, dummy, w1[0], w2[0]);
+          to_operand(K1{}, rv[nt][0].z, rv[nt][0].w, dummy, w1[1], w2[1]);
+          to_operand(K1{}, rv[nt][1].x, rv[nt][1].y, dummy, w1[2], w2[2]);
+          to_operand(K1{}, rv[nt][1].z, rv[nt][1].w, dummy, w1[3], w2[3]);
+          b_hi = __builtin_bit_cast(half8, st_u32x4{w1[0], w1[1], w1[2], w1[3]});
+          b_lo = __builtin_bit_cast(half8, st_u32x4{w2[0], w2[1], w2[2], w2[3]});
+        }
 #pragma unroll
         for (int mt = 0; mt < MTN; ++mt) {
           if constexpr (NP == 2) {

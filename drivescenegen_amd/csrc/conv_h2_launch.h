@@ -54,7 +54,7 @@ static int h2_launch(dim3 grid, size_t lds, hipStream_t st, const ConvH2P& p) {
     raised = true;
   }
   if constexpr (SC) {  // the shortcut phase's ring: 4 chunks of raw rows + 4 weight slabs (conv_h2_kernel.h)
-    constexpr size_t SC_LDS = 4 * (size_t)(2 * NW * NT * 1024) + 4 * (size_t)(2 * (PREC ? 1 : 2) * BM / 64) * 1024;
+    constexpr size_t SC_LDS = 4 * (size_t)((PREC ? 1 : 2) * NW * NT * 1024) + 4 * (size_t)(2 * (PREC ? 1 : 2) * BM / 64) * 1024;
     if (lds < SC_LDS) lds = SC_LDS;
   }
   // the epilogue's statistics tables live in the (by then free) K-loop buffers: [NW][row pairs][2][BM] partials + a
@@ -221,7 +221,7 @@ int conv_h2_launch_t(const dsg_conv_args* a, int hout, int wout, hipStream_t st)
     bool done128 = false;
     if constexpr (PREC != 0) {
       // 128-cout workgroups (four MFMA tiles per staged patch) while they still give every CU a workgroup
-      if (g_h2.bm128 && p.cout_pad % 128 == 0 && wout % H2_TW == 0 && !sc) {
+      if (g_h2.bm128 && p.cout_pad % 128 == 0 && wout % H2_TW == 0) {
         const int per_row = p.tiles_x * p.n * (p.cout_pad / 128);
         const bool r16 = hout % 16 == 0 && per_row * (hout / 16) >= H2_CUS;
         const int th128 = r16 ? 16 : 8;
@@ -233,11 +233,13 @@ int conv_h2_launch_t(const dsg_conv_args* a, int hout, int wout, hipStream_t st)
           done128 = true;
           if (r16) {
             const size_t l128 = 2 * (size_t)H2Geom<4, 3, 4, 9, 128, NP>::BUF_BYTES + ssb;
-            if (act == 0) rc = h2_launch<0, 4, 3, 0, 4, 1, 3, 128, PREC>(g128, l128, st, q);
+            if (sc) rc = h2_launch<0, 4, 3, 2, 4, 1, 3, 128, PREC, 0, 1>(g128, l128, st, q);
+            else if (act == 0) rc = h2_launch<0, 4, 3, 0, 4, 1, 3, 128, PREC>(g128, l128, st, q);
             else rc = h2_launch<0, 4, 3, 2, 4, 1, 3, 128, PREC>(g128, l128, st, q);
           } else {
             const size_t l128 = 2 * (size_t)H2Geom<2, 3, 4, 9, 128, NP>::BUF_BYTES + ssb;
-            if (act == 0) rc = h2_launch<0, 2, 3, 0, 4, 1, 3, 128, PREC>(g128, l128, st, q);
+            if (sc) rc = h2_launch<0, 2, 3, 2, 4, 1, 3, 128, PREC, 0, 1>(g128, l128, st, q);
+            else if (act == 0) rc = h2_launch<0, 2, 3, 0, 4, 1, 3, 128, PREC>(g128, l128, st, q);
             else rc = h2_launch<0, 2, 3, 2, 4, 1, 3, 128, PREC>(g128, l128, st, q);
           }
         }
@@ -245,10 +247,8 @@ int conv_h2_launch_t(const dsg_conv_args* a, int hout, int wout, hipStream_t st)
     }
     if (!done128) {
       if (sc) {
-        if constexpr (PREC == 0) {
-          if (nt4) rc = h2_launch<0, 4, 3, 2, 4, 1, 3, 64, 0, 0, 1>(grid, lds, st, p);
-          else rc = h2_launch<0, 2, 3, 2, 4, 1, 3, 64, 0, 0, 1>(grid, lds, st, p);
-        }
+        if (nt4) rc = h2_launch<0, 4, 3, 2, 4, (PREC ? DSG_H16_NT4_OCC : 1), 3, 64, PREC, 0, 1>(grid, lds, st, p);
+        else rc = h2_launch<0, 2, 3, 2, 4, 1, 3, 64, PREC, 0, 1>(grid, lds, st, p);
       } else if (act == 0) DSG_H2_LAUNCH_BLK(0, 3, 0, 3);
       else DSG_H2_LAUNCH_BLK(0, 3, 2, 3);
     }

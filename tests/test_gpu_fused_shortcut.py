@@ -189,3 +189,69 @@ def test_whole_net_with_and_without_the_fusion(cfg_name, cfg, batch):
     assert rel_l2(fused.cpu(), plain.cpu()) <= 5e-6, rel_l2(fused.cpu(), plain.cpu())
     if cfg_name == "cfg2":
         assert not torch.equal(fused, plain)   # (the fused kernels really ran: one rounding fewer per shortcut)
+
+
+# 16-bit modes: (n, c, cout, sc0, sc1, h, w) -- 64-cout two-per-CU tiles, 128-cout tiles (16 and 8 rows), 8-row 64-cout tiles
+SHAPES16 = {
+    "bm64_16rows": (32, 64, 64, 128, 64, 64, 64),
+    "bm128_16rows": (64, 128, 128, 128, 128, 32, 32),
+    "bm128_8rows": (32, 64, 256, 64, 64, 8, 64),
+    "bm64_8rows": (1, 128, 64, 128, 0, 32, 32),
+}
+
+
+@pytest.mark.parametrize("mode", ["bf16", "fp16"])
+@pytest.mark.parametrize("name", list(SHAPES16))
+def test_fused_shortcut_16bit_modes(name, mode):
+    """bf16 / fp16 (train.py:24's mixed_precision; BASELINE configs[4]): the raw shortcut rows are 16-bit words that ARE the
+    matrix-core operands -- one LDS-DMA per pixel row brings both channel blocks, no arithmetic.  Against fp64 on the
+    rounded operands: the 16-bit rounding class, and closer than the two-call path, which rounds the shortcut's result to
+    16 bits on its way through HBM."""
+    tdt = {"bf16": torch.bfloat16, "fp16": torch.float16}[mode]
+    rnd = lambda t: t.to(tdt).float()
+    n, c, cout, sc0, sc1, h, w = SHAPES16[name]
+    hm, x0, x1, w2, wsc, b2, bsc, ss, tproj = _case(n, c, cout, sc0, sc1, h, w, seed=zlib.crc32(name.encode()) % 1000)
+    hm, x0 = rnd(hm), rnd(x0)
+    x1 = rnd(x1) if x1 is not None else None
+    # reference: operands rounded once (activation after the fp32 affine + SiLU; weights), fp64 accumulate
+    act = rnd(F.silu(hm * ss[:, :, 0, None, None] + ss[:, :, 1, None, None])).double()
+    xin = (x0 if x1 is None else torch.cat([x0, x1], 1)).double()
+    ref = F.conv2d(act, rnd(w2).double(), b2.double(), padding=1) + tproj.double()[:, :, None, None] + \
+        F.conv2d(xin, rnd(wsc).double(), bsc.double())
+    g = lambda t: None if t is None else t.to(DEV)
+    hb, x0b = ops.to_blocked(g(hm), mode), ops.to_blocked(g(x0), mode)
+    x1b = ops.to_blocked(g(x1), mode) if x1 is not None else None
+    cp = (cout + 63) // 64 * 64
+    wh2, whsc = ops.pack_conv_weight(g(w2), ops.PACK_FWD, mode), ops.pack_conv_weight(g(wsc), ops.PACK_FWD, mode)
+    common = dict(ksize=3, cout=cout, gn_scale_shift=g(ss), silu=True, temb=g(tproj), temb_stride=cout, src_blocked=True,
+                  dst_blocked=True, weight_h2=wh2, weight_h2_stride=cp, compute_dtype=mode)
+    sc = dict(src0=x0b, src1=x1b, weight_h2=whsc, bias=g(bsc))
+    assert ops.conv2d_fused(hb, None, g(b2), shortcut=dict(sc, query_only=True), **common)
+    fused = ops.from_blocked(ops.conv2d_fused(hb, None, g(b2), shortcut=sc, **common)).cpu()
+    r = ops.conv2d_fused(x0b, None, g(bsc), src1=x1b, ksize=1, cout=cout, src_blocked=True, dst_blocked=True,
+                         weight_h2=whsc, weight_h2_stride=cp, compute_dtype=mode)
+    unfused = ops.from_blocked(ops.conv2d_fused(hb, None, g(b2), residual=r, **common)).cpu()
+    assert torch.isfinite(fused).all()
+    tol = {"bf16": 3e-3, "fp16": 8e-4}[mode]      # (tests/test_gpu_mixed.py: OUT_TOL)
+    e_f, e_u = rel_l2(fused, ref), rel_l2(unfused, ref)
+    assert e_f <= tol, e_f
+    assert e_f <= e_u * 1.02 + 1e-6, (e_f, e_u)
+    ulp = 2.0 ** -7 if mode == "bf16" else 2.0 ** -10
+    rms = float(ref.pow(2).mean().sqrt())
+    assert float(((fused.double() - ref).abs() - 0.51 * ulp * ref.abs()).max()) <= 0.5 * ulp * rms
+
+
+def test_whole_net_bf16_with_and_without_the_fusion():
+    from tests.common import CFG5
+    lib = _lib.load()
+    net = synth_weights(d.UNet2DModel(**CFG5)).to(DEV).eval().requires_grad_(False).set_compute_dtype("bf16")
+    x = noisy_inputs(CFG5, 2).to(DEV)
+    t = torch.tensor([980, 20], device=DEV)
+    fused = net(x, t).sample.clone()
+    try:
+        _lib.check(lib.dsg_set_tuning(23, 0))
+        plain = net(x, t).sample.clone()
+    finally:
+        lib.dsg_set_tuning(23, 1)
+    assert torch.isfinite(fused).all() and not torch.equal(fused, plain)
+    assert rel_l2(fused.cpu(), plain.cpu()) <= 1e-2   # two bf16 evaluations of the same net (each <= 2e-2 of the fp32 oracle)
