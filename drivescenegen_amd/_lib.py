@@ -129,6 +129,7 @@ SIGNATURES = {
     "dsg_gn_apply": [_vp, _vp, _i32, _vp, _i32, _i32, _i32, _vp],
     "dsg_attention_fwd": [_vp, _vp, _i32, _i32, _i32, _i32, _vp],
     "dsg_attention_fwd_dt": [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp],
+    "dsg_attention_fwd_blocked": [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp],
     "dsg_time_embed_fwd": [_vp, _vp, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp],
     "dsg_linear_fwd": [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _vp],
     "dsg_add_noise": [_vp, _vp, _vp, _vp, _vp, _i32, _i64, _vp],

@@ -171,11 +171,30 @@ __device__ __forceinline__ f32x16 att_mma8(att_half4 a, att_half4 b, f32x16 c) {
 // BASELINE.json configs[4] "MFMA bf16 attn"): q, k, v and the probabilities are rounded once to bf16 / fp16, ONE MFMA per
 // product, fp32 scores / running maximum / accumulators; the row of ones in V still accumulates the denominator of
 // exactly the (rounded) probabilities that were multiplied, so each output row is a convex combination of V rows.
-template <int PREC>
+// BLK: q, k, v and the output are CHANNEL-BLOCKED, [N][3C/8][L][8] / [N][C/8][L][8] in the plan's element type (fp32, or
+// the 16-bit type of PREC): head_dim 8 is exactly one channel block, so a token's q / k / v vector is one 32- / 16-byte
+// piece -- the projection in front writes 16-byte pieces instead of scattering 4-byte words over 3C planes (its kernel
+// ran at 0.8-1.2 TB/s), the K / V tiles load as whole vectors, and the out-projection behind reads blocked sources.
+template <int PREC, bool BLK = false>
 __global__ __launch_bounds__(64 * ATM_NW, DSG_ATM_MINW) void attention_mfma8_kernel(const float* __restrict__ qkv, float* __restrict__ out,
                                                                  float* __restrict__ lse, int c, int heads, int l,
                                                                  float qscale) {
   constexpr bool SPLIT = PREC == 0;
+  constexpr bool E16 = BLK && PREC != 0;        // 16-bit elements
+  constexpr int ESZ = E16 ? 2 : 4;
+  typedef unsigned att_u2 __attribute__((ext_vector_type(2)));
+  typedef unsigned att_u4 __attribute__((ext_vector_type(4)));
+  // 8 consecutive elements of a blocked tensor as fp32
+  auto load8 = [&](const char* ptr, float (&v)[8]) {
+    if constexpr (E16) {
+      const att_u4 w = *reinterpret_cast<const att_u4*>(ptr);
+      v[0] = lo16<PREC>(w.x); v[1] = hi16<PREC>(w.x); v[2] = lo16<PREC>(w.y); v[3] = hi16<PREC>(w.y);
+      v[4] = lo16<PREC>(w.z); v[5] = hi16<PREC>(w.z); v[6] = lo16<PREC>(w.w); v[7] = hi16<PREC>(w.w);
+    } else {
+      const float4 a = *reinterpret_cast<const float4*>(ptr), b = *reinterpret_cast<const float4*>(ptr + 16);
+      v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+    }
+  };
   __shared__ __attribute__((aligned(16))) _Float16 Kh[ATM_KT * 8], Kl[SPLIT ? ATM_KT * 8 : 8];          // [key][d]
   __shared__ __attribute__((aligned(16))) _Float16 Vh[9 * ATM_VSTR], Vl[SPLIT ? 9 * ATM_VSTR : 8];      // [d | ones][key]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, l31 = lane & 31;
@@ -191,15 +210,21 @@ __global__ __launch_bounds__(64 * ATM_NW, DSG_ATM_MINW) void attention_mfma8_ker
   const float* qp = qkv + ((size_t)n * 3 * c + h * 8) * l;
   const float* kp = qp + (size_t)c * l;
   const float* vp = kp + (size_t)c * l;
+  // blocked: channel block h of the q / k / v thirds of image n, [L][8] elements each
+  const char* qb = reinterpret_cast<const char*>(qkv) + ((size_t)n * 3 * c + h * 8) * l * ESZ;
+  const char* kb = qb + (size_t)c * l * ESZ;
+  const char* vb = kb + (size_t)c * l * ESZ;
   const int q0 = (qt * ATM_NW + wave) * 32;  // this wave's 32 queries (l % 32 == 0; a wave past the end idles)
   const bool active = q0 < l;
   const int qi = min(q0 + l31, l - 1);
 
   // B operand of S^T = K^T Q: lane (query l31, half) holds d = 4 half .. 4 half + 3, pre-scaled into the log2 domain
   att_half4 qh, ql;
+  float qv8[8];
+  if constexpr (BLK) load8(qb + (size_t)qi * 8 * ESZ, qv8);
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
-    const float v = qp[(size_t)(4 * half + i) * l + qi] * qscale;
+    const float v = (BLK ? (half ? qv8[4 + i] : qv8[i]) : qp[(size_t)(4 * half + i) * l + qi]) * qscale;
     if constexpr (SPLIT) {
       const _Float16 a = (_Float16)v;
       qh[i] = a;
@@ -218,7 +243,34 @@ __global__ __launch_bounds__(64 * ATM_NW, DSG_ATM_MINW) void attention_mfma8_ker
   for (int j0 = 0; j0 < l; j0 += ATM_KT) {
     const int kt = min(ATM_KT, l - j0);
     __syncthreads();
-    for (int e = tid; e < 8 * ATM_KT; e += 64 * ATM_NW) {
+    if constexpr (BLK) {  // one key per thread: its k and v vectors are one piece each
+      for (int j = tid; j < ATM_KT; j += 64 * ATM_NW) {
+        float kv[8], vv[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) kv[i] = vv[i] = 0.f;
+        if (j < kt) {
+          load8(kb + (size_t)(j0 + j) * 8 * ESZ, kv);
+          load8(vb + (size_t)(j0 + j) * 8 * ESZ, vv);
+        }
+        att_half8 k8, k8l;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          if constexpr (SPLIT) {
+            const _Float16 ka = (_Float16)kv[i], va = (_Float16)vv[i];
+            k8[i] = ka;
+            k8l[i] = (_Float16)((kv[i] - (float)ka) * 2048.0f);
+            Vh[i * ATM_VSTR + j] = va;
+            Vl[i * ATM_VSTR + j] = (_Float16)((vv[i] - (float)va) * 2048.0f);
+          } else {
+            k8[i] = att_cvt<PREC>(kv[i]);
+            Vh[i * ATM_VSTR + j] = att_cvt<PREC>(vv[i]);
+          }
+        }
+        *reinterpret_cast<att_half8*>(&Kh[j * 8]) = k8;
+        if constexpr (SPLIT) *reinterpret_cast<att_half8*>(&Kl[j * 8]) = k8l;
+      }
+    }
+    for (int e = tid; e < (BLK ? 0 : 8 * ATM_KT); e += 64 * ATM_NW) {
       const int i = e / ATM_KT, j = e - i * ATM_KT;  // coalesced along the keys
       float kv = 0.f, vv = 0.f;
       if (j < kt) {
@@ -326,8 +378,16 @@ __global__ __launch_bounds__(64 * ATM_NW, DSG_ATM_MINW) void attention_mfma8_ker
   const float inv = 1.0f / den;
   float* op = out + ((size_t)n * c + h * 8) * l;
   if (q0 + l31 < l) {
+    if constexpr (BLK) {  // this lane's four head dims of its query: one 16- / 8-byte piece of the token's channel block
+      float o4[4];
 #pragma unroll
-    for (int r = 0; r < 4; ++r)
+      for (int r = 0; r < 4; ++r) o4[r] = (SPLIT ? o_hi[r] + o_lo[r] * (1.0f / 2048.0f) : o_hi[r]) * inv;
+      char* ob = reinterpret_cast<char*>(out) + ((((size_t)n * c + h * 8) * l + (size_t)(q0 + l31) * 8) + 4 * half) * ESZ;
+      if constexpr (E16) *reinterpret_cast<att_u2*>(ob) = att_u2{pack2<PREC>(o4[0], o4[1]), pack2<PREC>(o4[2], o4[3])};
+      else *reinterpret_cast<float4*>(ob) = make_float4(o4[0], o4[1], o4[2], o4[3]);
+    }
+#pragma unroll
+    for (int r = 0; r < (BLK ? 0 : 4); ++r)
       op[(size_t)(r + 4 * half) * l + q0 + l31] = (SPLIT ? o_hi[r] + o_lo[r] * (1.0f / 2048.0f) : o_hi[r]) * inv;
     if (lse && half == 0) lse[((size_t)n * heads + h) * l + q0 + l31] = m + log2f(den);
   }
@@ -335,6 +395,11 @@ __global__ __launch_bounds__(64 * ATM_NW, DSG_ATM_MINW) void attention_mfma8_ker
 
 static int g_att_mfma = 1;  // head_dim 8 on the matrix cores (tuning key 14: A/B against the VALU kernel)
 void attention_set_mfma(int v) { g_att_mfma = v; }
+static int g_att_blocked = 1;  // the plan keeps q, k, v and the attention output channel-blocked (tuning key 25)
+void attention_set_blocked(int v) { g_att_blocked = v; }
+bool attention_blocked_ok(int c, int heads, int l) {
+  return g_att_mfma && g_att_blocked && heads > 0 && c % heads == 0 && c / heads == 8 && l % 32 == 0;
+}
 
 // exact: keep off the fp16x2-split matrix-core kernel (q, k, v beyond fp16's range: the plan's range guard)
 // dt: dsg_dtype of the products (DSG_F32 = the fp32-class split)
@@ -410,6 +475,27 @@ DSG_API int dsg_attention_fwd_dt(const float* qkv, float* out, int32_t n, int32_
                                  int32_t dtype, void* stream) {
   DSG_CHECK_ARG(dtype >= DSG_F32 && dtype <= DSG_F16, "dsg_attention_fwd_dt: bad dtype %d", dtype);
   return attention_fwd_impl(qkv, out, nullptr, n, c, heads, l, stream, false, dtype);
+}
+
+// the same on channel-blocked tensors (see attention_mfma8_kernel<PREC, BLK>): head_dim 8, l % 32 == 0 only
+DSG_API int dsg_attention_fwd_blocked(const void* qkv, void* out, int32_t n, int32_t c, int32_t heads, int32_t l,
+                                      int32_t dtype, void* stream) {
+  DSG_CHECK_ARG(qkv && out, "dsg_attention_fwd_blocked: NULL pointer");
+  DSG_CHECK_ARG(dtype >= DSG_F32 && dtype <= DSG_F16, "dsg_attention_fwd_blocked: bad dtype %d", dtype);
+  DSG_CHECK_ARG(n > 0 && c > 0 && heads > 0 && l > 0 && c % heads == 0, "dsg_attention_fwd_blocked: bad dims");
+  DSG_CHECK_SHAPE(c / heads == 8 && l % 32 == 0,
+                  "dsg_attention_fwd_blocked: head_dim %d / %d tokens (needs head_dim 8 = one channel block, tokens %% 32 == 0)",
+                  c / heads, l);
+  const float qscale = 1.4426950408889634f / sqrtf(8.0f);
+  const dim3 grid(dsg::cdiv(l, 32 * dsg::ATM_NW) * heads * n), block(64 * dsg::ATM_NW);
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const float* q = static_cast<const float*>(qkv);
+  float* o = static_cast<float*>(out);
+  if (dtype == DSG_BF16) hipLaunchKernelGGL((dsg::attention_mfma8_kernel<1, true>), grid, block, 0, st, q, o, nullptr, c, heads, l, qscale);
+  else if (dtype == DSG_F16) hipLaunchKernelGGL((dsg::attention_mfma8_kernel<2, true>), grid, block, 0, st, q, o, nullptr, c, heads, l, qscale);
+  else hipLaunchKernelGGL((dsg::attention_mfma8_kernel<0, true>), grid, block, 0, st, q, o, nullptr, c, heads, l, qscale);
+  DSG_LAUNCH_CHECK();
+  return DSG_OK;
 }
 
 DSG_API int dsg_attention_fwd_train(const float* qkv, float* out, float* lse, int32_t n, int32_t c, int32_t heads,

@@ -475,6 +475,8 @@ void conv_h2_set_bm128(int v);
 void conv_h2_set_splitk(int v);
 void conv_h2_set_ws2(int v);
 void conv_h2_set_fuse_sc(int v);
+int conv_h2_get_fuse_sc();
+void attention_set_blocked(int v);
 bool conv_h2_sc_fusable(const dsg_conv_args* a, int hout, int wout);
 int conv_h2_splitk_slices(const dsg_conv_args* a, int hout, int wout, int* stat_splits);
 void unet_set_blocked(int v);
@@ -862,6 +864,11 @@ DSG_API int dsg_set_tuning(int32_t key, int32_t value) {
   }
   if (key == 20 && (value == 0 || value == 1)) {
     dsg::conv_h2_set_ws2(value);
+    return DSG_OK;
+  }
+  if (key == 25 && (value == 0 || value == 1)) {
+    dsg::attention_set_blocked(value);
+    dsg::conv_h2_set_fuse_sc(dsg::conv_h2_get_fuse_sc());  // (bumps the tuning epoch: the plan's arena changes)
     return DSG_OK;
   }
   if (key == 23 && (value == 0 || value == 1)) {

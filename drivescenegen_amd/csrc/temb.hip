@@ -51,20 +51,36 @@ __global__ __launch_bounds__(256) void time_embed_kernel(const int64_t* __restri
 
 // y[n][j] = x[n][:] . w[j][:] + b[j].  One wave per output row j, lanes stride the K axis
 // (coalesced weight reads); grid = ceil(out_f / 4), block = 256.
+// Eight images per pass: their dot products and shuffle trees are independent chains (the one-image-at-a-time loop was a
+// single dependent chain of ~n x 100 cycles: 90 us at batch 64 for 0.2 GFLOP); per image the arithmetic -- lane-strided
+// fmaf partials, then the shfl_down tree -- is unchanged, so results are bit-identical to the old kernel's.
 __global__ __launch_bounds__(256) void linear_rows_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                           const float* __restrict__ b, float* __restrict__ y, int n,
                                                           int in_f, int out_f) {
+  constexpr int NB = 8;
   const int lane = threadIdx.x & 63;
   const int j = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (j >= out_f) return;
   const float* wr = w + (size_t)j * in_f;
-  for (int ni = 0; ni < n; ++ni) {
-    const float* xr = x + (size_t)ni * in_f;
-    float s = 0.f;
-    for (int k = lane; k < in_f; k += 64) s = fmaf(wr[k], xr[k], s);
+  const float bj = b ? b[j] : 0.f;
+  for (int n0 = 0; n0 < n; n0 += NB) {
+    float s[NB];
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) s += __shfl_down(s, o, 64);
-    if (lane == 0) y[(size_t)ni * out_f + j] = s + (b ? b[j] : 0.f);
+    for (int i = 0; i < NB; ++i) s[i] = 0.f;
+    for (int k = lane; k < in_f; k += 64) {
+      const float wk = wr[k];
+#pragma unroll
+      for (int i = 0; i < NB; ++i) s[i] = fmaf(wk, x[(size_t)min(n0 + i, n - 1) * in_f + k], s[i]);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1)
+#pragma unroll
+      for (int i = 0; i < NB; ++i) s[i] += __shfl_down(s[i], o, 64);
+    if (lane == 0) {
+#pragma unroll
+      for (int i = 0; i < NB; ++i)
+        if (n0 + i < n) y[(size_t)(n0 + i) * out_f + j] = s[i] + bj;
+    }
   }
 }
 

@@ -26,6 +26,7 @@ namespace dsg {
 int conv2d_fwd_impl(const dsg_conv_args* a, hipStream_t st, int force_direct);
 int conv_h2_tuning_epoch();
 int attention_fwd_exact(const float* qkv, float* out, int n, int c, int heads, int l, hipStream_t st);
+bool attention_blocked_ok(int c, int heads, int l);
 }
 
 namespace {
@@ -437,12 +438,17 @@ struct Runner {
 
   T attention(T& x, const Att& at) {
     T ss = gn_ss(x, nullptr, at.gn);
-    T qkv = conv(x, nullptr, at.qkv, 1, 0, &ss, 0, nullptr, nullptr, nullptr, false, 0);  // (the attention kernel reads [N,3C,L])
+    // head_dim 8 is one channel block: with blocked intermediates q, k, v and the attention output stay blocked (in the
+    // plan's element type) between the three kernels; otherwise they are [N,3C,L] / [N,C,L] fp32
+    const bool blk = x.blk && dsg::attention_blocked_ok(x.c, at.heads, x.h * x.w) && !at.qkv.off_split;
+    T qkv = conv(x, nullptr, at.qkv, 1, 0, &ss, 0, nullptr, nullptr, nullptr, false, blk ? 1 : 0);
     ss = T();
-    T o = alloc(x.c, x.h, x.w);  // ([N,C,L] fp32 in every mode, like q/k/v: softmax(QK^T)V runs in fp32-equivalent arithmetic)
+    T o = blk ? alloc(x.c, x.h, x.w, 0, esz_of(1)) : alloc(x.c, x.h, x.w);
+    o.blk = blk ? 1 : 0;
     if (!dry && ok())
-      rc = at.qkv.off_split ? dsg::attention_fwd_exact(qkv.p, o.p, B, x.c, at.heads, x.h * x.w, st)
-                            : dsg_attention_fwd_dt(qkv.p, o.p, B, x.c, at.heads, x.h * x.w, dt(), st);
+      rc = blk ? dsg_attention_fwd_blocked(qkv.p, o.p, B, x.c, at.heads, x.h * x.w, dt(), st)
+               : (at.qkv.off_split ? dsg::attention_fwd_exact(qkv.p, o.p, B, x.c, at.heads, x.h * x.w, st)
+                                   : dsg_attention_fwd_dt(qkv.p, o.p, B, x.c, at.heads, x.h * x.w, dt(), st));
     qkv = T();
     // (q / k / v weights beyond the split's range make the attention output's range suspect too: its projection then
     //  takes the exact kernel as well -- o has no norm and no statistics to bound it)

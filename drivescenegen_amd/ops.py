@@ -340,6 +340,18 @@ def attention(qkv, heads, dtype=0):
     return out
 
 
+def attention_blocked(qkv_blk, heads, dtype=0):
+    """dsg_attention_fwd_blocked: channel-blocked qkv [N, 3C/8, H, W, 8] (fp32, or the 16-bit type of `dtype`) -> blocked
+    [N, C/8, H, W, 8] of the same element type.  head_dim 8 (one channel block per head), H * W % 32 == 0."""
+    n, cb3, h, w, _ = qkv_blk.shape
+    c, l = cb3 * 8 // 3, h * w
+    out = torch.empty((n, c // 8, h, w, 8), dtype=qkv_blk.dtype, device=qkv_blk.device)
+    with torch.cuda.device(qkv_blk.device):
+        _lib.check(_lib.load().dsg_attention_fwd_blocked(_lib.ptr(qkv_blk), _lib.ptr(out), n, c, heads, l,
+                                                        dtype_code(dtype), _st(qkv_blk)))
+    return out
+
+
 def sinusoid_freqs(ch: int) -> torch.Tensor:
     """exp(-ln(10000) * arange(ch/2) / (ch/2)) with the reference's fp32 op order (get_timestep_embedding,
     flip_sin_to_cos=True, freq_shift=0).  Host-side, [ch/2] fp32 CPU tensor."""

@@ -40,7 +40,7 @@ def write_sample(config, pipeline, steps: int = 750):
     """One seeded sample -> ``<output_dir>/samples/NNN.png`` (NNN = files already there); returns the path."""
     out = pipeline(num_inference_steps=steps, batch_size=config.eval_batch_size, generator=torch.manual_seed(config.seed),
                    output_type="np.array", return_dict=False)
-    first = torch.tensor(out)[0, 0]          # the 1-tuple of [B, H, W, C] -> image 0 of the batch
+    first = torch.from_numpy(np.asarray(out))[0, 0]   # the 1-tuple of [B, H, W, C] -> image 0 of the batch
     folder = os.path.join(config.output_dir, "samples")
     os.makedirs(folder, exist_ok=True)
     index = sum(os.path.isfile(os.path.join(folder, f)) for f in os.listdir(folder))

@@ -253,6 +253,12 @@ int dsg_attention_fwd(const float* qkv, float* out, int32_t n, int32_t c, int32_
  * [N, C, L], the scores, running maximum, denominators and accumulators fp32 (BASELINE configs[4]: "MFMA bf16 attn") */
 int dsg_attention_fwd_dt(const float* qkv, float* out, int32_t n, int32_t c, int32_t heads, int32_t l,
                          int32_t dtype, void* stream);
+/* The same with q, k, v and the output channel-blocked -- qkv [N][3C/8][L][8], out [N][C/8][L][8], elements fp32
+ * (DSG_F32) or the 16-bit type of `dtype` -- for head_dim 8 (one channel block per head) and L % 32 == 0: the layout
+ * dsg_unet_forward keeps its intermediates in, so the q/k/v projection in front and the out-projection behind move
+ * whole channel blocks (anything else: DSG_ERR_UNSUPPORTED_SHAPE, use dsg_attention_fwd_dt on [N,3C,L] fp32). */
+int dsg_attention_fwd_blocked(const void* qkv, void* out, int32_t n, int32_t c, int32_t heads, int32_t l, int32_t dtype,
+                              void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Timestep path (UNet2DModel.time_proj + time_embedding + every ResnetBlock2D.time_emb_proj):
@@ -500,6 +506,7 @@ int dsg_prof_dump(const char* csv_path);
  *      64-cout x 16-row grid has at least n workgroups (1 = 512); bit-identical results, measured slower
  *  18  16-bit modes: 3x3 convs with cout % 128 == 0 as 128-cout workgroups while the grid fills the chip: [1] | 0
  *  19  split-K for grids of at most half the CUs (needs dsg_conv_args.splitk_ws): [1] | 0
+ *  25  dsg_unet_forward keeps q, k, v and the attention output channel-blocked (head_dim 8): [1] | 0
  *  23  resnet shortcuts fused into conv2's K loop (dsg_conv_args.sc_*): [1] | 0 (0: dsg_conv2d_fuses_shortcut answers no)
  *  20  fp32-equivalent 3x3 convs with cin <= 128 on channel-blocked tensors: 8-row tiles with ONE weight slab in LDS,
  *      two workgroups per CU (grids of at least 512 workgroups): [1] | 0

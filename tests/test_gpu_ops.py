@@ -131,6 +131,34 @@ def test_attention(n, c, heads, l):
     _check(got, ref, tol_rel=1e-5, tol_abs=1e-5)
 
 
+@pytest.mark.parametrize("mode", ["fp32", "bf16", "fp16"])
+@pytest.mark.parametrize("n,c,heads,l", [(2, 512, 64, 1024), (1, 16, 2, 2048), (2, 24, 3, 96)])
+def test_attention_blocked_layout(n, c, heads, l, mode):
+    """dsg_attention_fwd_blocked: q, k, v and the output channel-blocked (head_dim 8 = one channel block), the layout the
+    plan keeps between the q/k/v projection, the attention core and the out-projection.  fp32: the SAME arithmetic as the
+    [N,3C,L] kernel, bit for bit; bf16 / fp16: q, k, v arrive rounded (the projection's store) instead of being rounded
+    at the load -- compared with fp64 softmax attention of the rounded operands at the 16-bit rounding class."""
+    qkv = _t(33, (n, 3 * c, l), 1.3)
+    if mode == "fp32":
+        want = ops.attention(qkv.to(DEV), heads)
+        got = ops.from_blocked(ops.attention_blocked(ops.to_blocked(qkv.to(DEV)[:, :, :, None]), heads))
+        assert torch.equal(got[:, :, :, 0], want)
+        return
+    tdt = {"bf16": torch.bfloat16, "fp16": torch.float16}[mode]
+    qr = qkv.to(tdt).float()
+    d_head = c // heads
+    q, k, v = (qr[:, i * c:(i + 1) * c].double().view(n, heads, d_head, l) for i in range(3))
+    att = torch.softmax(torch.einsum("nhdi,nhdj->nhij", q, k) / np.sqrt(d_head), -1)
+    ref = torch.einsum("nhij,nhdj->nhdi", att, v).reshape(n, c, l)
+    blk = ops.to_blocked(qkv.to(DEV)[:, :, :, None], mode)
+    out = ops.attention_blocked(blk, heads, mode)
+    assert out.dtype == tdt
+    got = ops.from_blocked(out).cpu()[:, :, :, 0]
+    assert torch.isfinite(got).all()
+    from tests.common import rel_l2
+    assert rel_l2(got, ref) <= (1.5e-2 if mode == "bf16" else 2e-3), rel_l2(got, ref)
+
+
 def test_attention_spiked_scores():
     """Large score range: exercises the online-softmax rescale (one key dominates late in the sweep)."""
     n, c, heads, l = 1, 16, 2, 1024
