@@ -27,6 +27,8 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
+os.environ.setdefault("DSG_TESTING", "1")   # --pure-f32 / --separate-gn-stats flip kernel-selection switches (a test hook)
+
 import torch  # noqa: E402
 
 PEAK_F32_TFLOPS = 157.3  # /opt/skills/guides/MI355X_MICROARCH.md: f32 vector = f32 MFMA peak

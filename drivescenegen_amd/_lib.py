@@ -78,8 +78,11 @@ class UNetConfig(C.Structure):
         ("norm_num_groups", C.c_int32), ("norm_eps", C.c_float),
         ("attention_head_dim", C.c_int32), ("add_attention", C.c_int32),
         ("compute_dtype", C.c_int32),
+        ("flags", C.c_uint32),
     ]
 
+
+UNET_BATCH_INVARIANT = 1  # dsg_unet_config.flags
 
 _vp, _i32, _i64, _f32, _sz, _f64 = C.c_void_p, C.c_int32, C.c_int64, C.c_float, C.c_size_t, C.c_double
 
@@ -188,6 +191,8 @@ def load():
             raise RuntimeError(
                 f"libdsg.so not found at {LIB_PATH}: build it with `python drivescenegen_amd/csrc/build.py` "
                 "(or __graft_entry__.build()). The engine has no CPU fallback.")
+        if os.environ.get("DSG_TUNING"):   # (the switches are a test hook the library only honours under DSG_TESTING=1)
+            os.environ["DSG_TESTING"] = "1"
         lib = C.CDLL(LIB_PATH)
         for name, argtypes in SIGNATURES.items():
             fn = getattr(lib, name)

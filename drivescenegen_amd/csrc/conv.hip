@@ -24,6 +24,7 @@
 // Epilogue: + bias (+ time-embedding column) (+ residual), 128-B row stores; optional 2x2 sum-pool
 // (the adjoint of the nearest-x2 upsample).
 #include "dsg_h16.h"
+#include <cstdlib>
 #include <algorithm>
 
 namespace dsg {
@@ -826,6 +827,12 @@ int conv2d_fwd_impl(const dsg_conv_args* a, hipStream_t st, int force_direct) {
 // Tuning / A-B switches (key 1: K-chunk of the fp32 3x3 kernel, 0 = auto | 4 | 8; key 2: fp16x2-split 3x3 kernel
 // on/off).  Not part of the reference surface.
 DSG_API int dsg_set_tuning(int32_t key, int32_t value) {
+  {  // a test / measurement hook: production processes keep the library's global state immutable
+    const char* t = getenv("DSG_TESTING");
+    if (t == nullptr || t[0] != '1')
+      return dsg::fail(DSG_ERR_INVALID_ARG, "dsg_set_tuning: kernel-selection switches are a test hook (set DSG_TESTING=1 in the "
+                                            "environment); per-plan choices are in dsg_unet_config.flags");
+  }
   if (key == 1 && (value == 0 || value == 4 || value == 8)) {
     dsg::g_conv_kc = value;
     return DSG_OK;

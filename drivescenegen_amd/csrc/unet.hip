@@ -370,7 +370,7 @@ struct Runner {
     a.compute_dtype = dt();
     y.blk = dst_blk;
     T splitk;  // scratch of the small-batch split-K path (lives until the call has been enqueued: stream order)
-    if (ok() && dt() == DSG_F32) {
+    if (ok() && dt() == DSG_F32 && !(h->cfg.flags & DSG_UNET_BATCH_INVARIANT)) {
       size_t sk = 0;
       rc = dsg_conv2d_splitk_bytes(&a, &sk);
       if (ok() && sk > 0) {
@@ -533,6 +533,7 @@ int check_cfg(const dsg_unet_config* c) {
                   "dsg_unet_create: block_out_channels[%d]=%d not a positive multiple of norm_num_groups=%d", i, ch,
                   c->norm_num_groups);
   }
+  DSG_CHECK_ARG((c->flags & ~(uint32_t)DSG_UNET_BATCH_INVARIANT) == 0, "dsg_unet_create: unknown flags 0x%x", c->flags);
   DSG_CHECK_ARG(c->compute_dtype >= DSG_F32 && c->compute_dtype <= DSG_F16,
                 "dsg_unet_create: compute_dtype must be DSG_F32, DSG_BF16 or DSG_F16 (got %d)", c->compute_dtype);
   const int f = 1 << (c->num_blocks - 1);

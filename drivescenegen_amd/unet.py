@@ -170,6 +170,9 @@ class UNet2DModel(nn.Module):
         self.conv_out = nn.Conv2d(boc[0], c.out_channels, 3, padding=1)
 
         self.compute_dtype = "fp32"  # "fp32" | "bf16" | "fp16": see set_compute_dtype
+        # dsg_unet_config.flags / DSG_UNET_BATCH_INVARIANT: row i of a batch == the batch-1 call on row i, bitwise (the
+        # small-batch split-K kernels, ~20 % faster at batch 1 / 5 and equal to fp32 round-off, are then not selected)
+        self.batch_invariant = False
         self._plan = None          # dsg_unet_t* (c_void_p)
         self._plan_state = {}      # name -> (data_ptr, version) last pushed
         self._plan_device = None
@@ -219,7 +222,7 @@ class UNet2DModel(nn.Module):
 
     def _ensure_plan(self, h, w, device):
         lib = _lib.load()
-        key = (h, w, str(device), self.compute_dtype)
+        key = (h, w, str(device), self.compute_dtype, bool(self.batch_invariant))
         if self._plan is None or self._plan_device != key:
             self._destroy_plan()
             c = self.config
@@ -237,6 +240,7 @@ class UNet2DModel(nn.Module):
             cfg.attention_head_dim = c.attention_head_dim
             cfg.add_attention = int(bool(c.add_attention))
             cfg.compute_dtype = _lib.DTYPE_CODES[self.compute_dtype]
+            cfg.flags = _lib.UNET_BATCH_INVARIANT if self.batch_invariant else 0
             hnd = C.c_void_p()
             with torch.cuda.device(device):
                 _lib.check(lib.dsg_unet_create(C.byref(cfg), C.byref(hnd)))

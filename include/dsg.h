@@ -317,7 +317,15 @@ typedef struct {
   int32_t compute_dtype;            /* dsg_dtype: DSG_F32 = the fp32-equivalent engine; DSG_BF16 / DSG_F16 = the intermediate
                                        activations are 16-bit channel-blocked tensors and every conv / projection runs
                                        once on the bf16 / f16 matrix cores (x, eps, parameters, statistics stay fp32) */
+  uint32_t flags;                   /* DSG_UNET_* bits below; 0 = defaults */
 } dsg_unet_config;
+/* dsg_unet_config.flags -- per-plan behaviour (nothing process-global):
+ *   DSG_UNET_BATCH_INVARIANT  kernel selection never depends on the batch size: the small-batch split-K path (K contracted
+ *                             in parallel slices when a layer's grid covers at most half the chip) is not taken, so row i
+ *                             of a batch-B call is BITWISE the batch-1 call on row i.  Default off: batch-1 / batch-5
+ *                             sampling (training_pipeline.py:26-32, generation.py:14-20) is ~20 % faster with the split,
+ *                             and equal to the one-slice result to fp32 round-off (<= 2e-6 relative). */
+#define DSG_UNET_BATCH_INVARIANT 1u
 
 int dsg_unet_create(const dsg_unet_config* cfg, dsg_unet_t** out);
 void dsg_unet_destroy(dsg_unet_t* h);
@@ -488,7 +496,10 @@ int dsg_prof_enable(int32_t on); /* 1 start (clears), 0 stop (clears); 2 pause /
 int dsg_prof_summary(int32_t kernel_class, double* total_ms, double* total_flops, double* total_bytes,
                      int64_t* launches);
 int dsg_prof_dump(const char* csv_path);
-/* Kernel-selection switches for A/B measurements (defaults in brackets; python: env DSG_TUNING="key=value,..."):
+/* Kernel-selection switches for A/B measurements and tests -- a TEST HOOK, not part of the product surface: the call is
+ * refused (DSG_ERR_INVALID_ARG) unless the process environment has DSG_TESTING=1, so a production process cannot change
+ * process-global state through this header; what a deployment may want to choose per plan is in dsg_unet_config.flags.
+ * (Defaults in brackets; python: env DSG_TUNING="key=value,..." implies DSG_TESTING=1.)
  *   1  K-chunk of the fp32 conv kernel: [0 = by grid size] | 4 | 8
  *   2  fp16x2-split conv kernels: [1] | 0 = every contraction on the f32 MFMA
  *   3  rows per wave of the split conv kernel: [0 = by grid size] | 2 | 4

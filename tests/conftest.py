@@ -3,6 +3,8 @@ import sys
 
 import pytest
 
+os.environ.setdefault("DSG_TESTING", "1")   # dsg_set_tuning (kernel-selection switches for A/B parity tests) is a test hook
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)

@@ -208,3 +208,28 @@ def test_param_update_is_picked_up(tiny):
     assert torch.allclose(b - a, torch.ones_like(a), atol=1e-5)
     with torch.no_grad():
         net.conv_out.bias.sub_(1.0)
+
+
+def test_batch_invariant_flag_and_tuning_gate():
+    """dsg_unet_config.flags / DSG_UNET_BATCH_INVARIANT (UNet2DModel.batch_invariant): per-plan, no process-global state --
+    row i of a batch is bitwise the batch-1 call; the default plan (split-K on small grids) agrees to fp32 round-off.
+    And the process-global switches are a test hook: without DSG_TESTING=1 in the environment dsg_set_tuning refuses."""
+    import subprocess
+    import sys
+    net = synth_weights(d.UNet2DModel(**CFG4_SMALL)).to(DEV).eval().requires_grad_(False)
+    x = noisy_inputs(CFG4_SMALL, 4).to(DEV)
+    t = torch.tensor([900, 500, 100, 3], device=DEV)
+    fast = net(x, t).sample.clone()
+    net.batch_invariant = True
+    full = net(x, t).sample.clone()
+    for i in range(4):
+        assert torch.equal(net(x[i:i + 1], t[i:i + 1]).sample[0], full[i]), i
+    assert rel_l2(fast.cpu(), full.cpu()) <= 2e-6
+    code = ("import os; os.environ.pop('DSG_TESTING', None); os.environ.pop('DSG_TUNING', None)\n"
+            "from drivescenegen_amd import _lib\n"
+            "lib = _lib.load(); rc = lib.dsg_set_tuning(19, 0); print('rc', rc, lib.dsg_last_error().decode()[:120])")
+    env = {k: v for k, v in os.environ.items() if k not in ("DSG_TESTING", "DSG_TUNING")}
+    out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300,
+                         cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    assert out.returncode == 0, out.stderr[-2000:]
+    assert "rc -1" in out.stdout and "test hook" in out.stdout, out.stdout

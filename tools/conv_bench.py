@@ -1,6 +1,7 @@
 """Micro-benchmark of dsg_conv2d_fwd on the layer shapes of the default U-Net (B=16): TF/s per shape.
 Usage: python tools/conv_bench.py [iters]"""
 import os, sys
+os.environ.setdefault("DSG_TESTING", "1")  # dsg_set_tuning is a test hook
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from drivescenegen_amd import ops
