@@ -90,8 +90,12 @@ def gpu_leg(args, rank, world):
         x = step(args.warmup + i, x)
     barrier()
     dt = time.perf_counter() - t0
+    per_rank = [dt]
     if torch.distributed.is_initialized():
         tt = torch.tensor([dt], dtype=torch.float64, device=dev)
+        every = [torch.zeros_like(tt) for _ in range(torch.distributed.get_world_size())]
+        torch.distributed.all_gather(every, tt)     # (each rank's own wall time: the spread shows a slow GPU / link)
+        per_rank = [float(v.item()) for v in every]
         torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
         dt = float(tt.item())
     assert torch.isfinite(x).all()
@@ -114,7 +118,7 @@ def gpu_leg(args, rank, world):
         if args.prof_dump and rank == 0:
             _lib.check(lib.dsg_prof_dump(args.prof_dump.encode()))
         lib.dsg_prof_enable(0)
-    return dt, prof
+    return dt, prof, per_rank
 
 
 def cpu_leg(args):
@@ -256,12 +260,48 @@ def train_leg(args, dtype="fp32", batch=16, steps=3):
     dt = time.perf_counter() - t0
     assert torch.isfinite(loss.detach()).all()
     peak_gib = torch.cuda.max_memory_allocated(dev) / 2 ** 30
+    # one more step under the HIP-event profiler: the step's conv classes (forward + data-gradient convs share the forward
+    # kernels' classes; the 3x3 weight gradient has its own), algorithmic FLOPs / bytes per launch as in the headline leg
+    from drivescenegen_amd import _lib
+    lib = _lib.load()
+    lib.dsg_prof_enable(1)
+    one()
+    torch.cuda.synchronize(dev)
+    base = 0 if dtype == "fp32" else 20
+    rows = _prof_rows(lib, _lib, {base + 6: "conv3x3_fwd_and_dgrad", base + 10: "conv3x3_fwd_and_dgrad_two_wg_per_cu",
+                                   base + 7: "conv3x3_upsample", base + 8: "conv1x1", base + 2: "conv3x3_s2",
+                                   base + 9: "conv3x3_wgrad", 5: "conv_wgrad_f32_mfma", 0: "conv3x3_s1_mfma_f32"})
+    lib.dsg_prof_enable(0)
     del net, opt
     torch.cuda.empty_cache()
-    return {"metric": "training images/sec (fwd + bwd + clip + AdamW)", "value": batch * steps / dt, "unit": "images/s",
-            "ms_per_step": dt / steps * 1e3, "steps": steps, "dtype": dtype, "peak_mem_gib": peak_gib,
-            "config": {"workload": f"BASELINE configs[{2 if dtype == 'fp32' else 4}] network at 256x256x{c}, DDPM training step, "
-                                   f"batch {batch} on 1 GPU, {dtype}", "batch": batch}}
+    rec = {"metric": "training images/sec (fwd + bwd + clip + AdamW)", "value": batch * steps / dt, "unit": "images/s",
+           "ms_per_step": dt / steps * 1e3, "steps": steps, "dtype": dtype, "peak_mem_gib": peak_gib,
+           "config": {"workload": f"BASELINE configs[{2 if dtype == 'fp32' else 4}] network at 256x256x{c}, DDPM training step, "
+                                  f"batch {batch} on 1 GPU, {dtype}", "batch": batch},
+           "kernels": rows}
+    # roofline of the dominant BACKWARD kernel (the 3x3 weight gradient) and of the conv class that carries forward and
+    # data gradients, priced like the headline: fp32-equivalent = 2500 / 3 TF/s-eq, 16-bit = 2500 TF/s; HBM 8 TB/s
+    peak = PEAK_F16_TFLOPS / (3.0 if dtype == "fp32" else 1.0)
+    step_ms = dt / steps * 1e3
+
+    def roof(row, kernel, pmc_pat):
+        t_mfma = row["flops_per_launch"] / (peak * 1e12)
+        t_hbm = row["bytes_per_launch"] / (PEAK_HBM_GBS * 1e9)
+        bound = "hbm" if t_hbm > t_mfma else "mfma"
+        return dict(bound=bound, kernel=kernel, achieved=row["alg_gbs"] if bound == "hbm" else row["tflops"],
+                    peak=PEAK_HBM_GBS if bound == "hbm" else peak, unit="GB/s" if bound == "hbm" else "TFLOP/s",
+                    frac=max(t_mfma, t_hbm) / (row["avg_ms"] * 1e-3), mfma_tflops=row["tflops"], alg_gbs=row["alg_gbs"],
+                    avg_launch_ms=row["avg_ms"], launches=row["launches"], time_share=row["total_ms"] / step_ms,
+                    **pmc_class_traffic(pmc_pat, "_train_" + dtype))
+    wg, fw = rows.get("conv3x3_wgrad"), rows.get("conv3x3_fwd_and_dgrad")
+    if wg:
+        rec["roofline"] = roof(wg, "dsg::conv_wgrad_h2_kernel" if dtype == "fp32" else "dsg::conv_wgrad16_kernel<*, 3, *>",
+                               r"conv_wgrad_h2_kernel" if dtype == "fp32" else r"conv_wgrad16_kernel<\d, 3")
+        if fw:
+            rec["roofline"]["second_kernel"] = roof(fw, "dsg::conv_h2_kernel<0, *, 3, *> (forward and data-gradient 3x3 convs)",
+                                                    r"conv_h2_kernel<0, [24], 3, [02], 4, [12], [03], (64|128), " +
+                                                    ("0" if dtype == "fp32" else "[12]"))
+    return rec
 
 
 def small_batch_leg(args):
@@ -401,7 +441,7 @@ def main():
     if args.gpus != world and rank == 0 and world > 1:
         print(f"warning: --gpus {args.gpus} but WORLD_SIZE={world}", file=sys.stderr)
 
-    dt, prof = gpu_leg(args, rank, world)
+    dt, prof, per_rank = gpu_leg(args, rank, world)
     if rank == 0:
         n_img_steps = args.batch * world * args.steps
         value = n_img_steps / dt
@@ -450,6 +490,10 @@ def main():
                                    "(56,575,748 params), 50-step DDIM (eta=0), batch 16 per GPU, fp32",
                        "batch_per_gpu": args.batch, "global_batch": args.batch * world,
                        "ddim_steps": args.ddim_steps, "parallelism": f"sample-sharded x{world}, no collective"},
+            # the process group the timing barrier / max ran on (RCCL = torch's "nccl" backend on ROCm) and each rank's own
+            # wall time per step: `ms_per_step` is their maximum
+            "rccl_world": torch.distributed.get_world_size() if torch.distributed.is_initialized() else 0,
+            "per_rank_ms_per_step": [t / args.steps * 1e3 for t in per_rank],
             "whole_net_tflops": value * flops_img / 1e12,
             "whole_net_frac_of_f32_peak": value * flops_img / 1e12 / (PEAK_F32_TFLOPS * world),
             "roofline": roofline,

@@ -262,6 +262,16 @@ def _forward(model, st: TrainState, tape: _Tape, sample, timesteps):
             return ops.gn_scale_shift_from_parts_train(s0, g, b, groups, eps, x0.shape[2] * x0.shape[3], stats1=s1)
         return ops.gn_scale_shift_train(x0, g, b, groups, eps, src1=x1)
 
+    bounds = {}
+
+    def bound_of(x):
+        st_x = pstats.get(id(x))
+        if st_x is None:
+            return None
+        if id(x) not in bounds:
+            bounds[id(x)] = ops.range_bound_from_stats(st_x)
+        return bounds[id(x)]
+
     def conv(x0, wname, x1=None, gn=None, silu=False, k=3, stride=1, ups=False, toff=None, res=None,
              need_dx=True, feeds_norm=False):
         wh, whd = st.h2_of(wname + ".weight")
@@ -273,11 +283,20 @@ def _forward(model, st: TrainState, tape: _Tape, sample, timesteps):
         # (up-sampler convs: the folded 2x2 phase kernels of the inference plan instead of the nearest-x2 gather)
         fold = st.pack32(wname + ".weight", ops.PACK_FOLD) if (ups and k == 3 and x1 is None and gn is None
                                                                  and x0.shape[1] % 16 == 0 and cout % 64 == 0) else None
+        # Range guard of the split path: a conv WITHOUT a norm in front (shortcut, up- / down-sampler) reads the
+        # residual stream as it is; where the producing conv left statistics, their per-image bound goes along
+        # (dsg_conv_args.src_bound: exact power-of-two pre-scaling outside [2^-6, 2^12], a no-op inside)
+        b0 = b1 = None
+        if gn is None and (wh is not None or fold is not None):
+            b0 = bound_of(x0)
+            b1 = bound_of(x1) if (x1 is not None and b0 is not None) else None
+            if x1 is not None and b1 is None:
+                b0 = None
         # (wf, the fp32 engine layout, only for the calls whose kernels read it: TrainState.lazy_w)
         y = st.lazy_w(wname + ".weight", "wf", lambda wf: ops.conv2d_fused(
             x0, wf, bias, src1=x1, ksize=k, stride=stride, upsample=ups, gn_scale_shift=ss, silu=silu,
             temb=None if toff is None else tproj[:, toff:], temb_stride=tproj.stride(0), residual=res, cout=cout,
-            weight_h2=wh, weight_h2_fold=fold, want_stats=feeds_norm))
+            weight_h2=wh, weight_h2_fold=fold, want_stats=feeds_norm, src_bound=b0, src_bound1=b1))
         if feeds_norm:
             y, ystats = y
             if ystats is not None:
@@ -804,7 +823,7 @@ def _backward16(model, st: TrainState, tape: _Tape, dout):
             # down-sampler conv: its weight gradient is the stride-1 one against dY with zeros between its pixels
             # (dY_up[2y, 2x] = dY[y, x]): the 16-bit kernel at full resolution instead of two conversions to fp32 and the
             # exact f32 kernel.  The zero positions of the buffer are written once and kept between steps.
-            key = ("dyup", wname, tuple(dy.shape))
+            key = ("dyup", dt, wname, tuple(dy.shape))
             up = st.scratch16.get(key)
             if up is None:
                 up = st.scratch16[key] = torch.zeros((dy.shape[0], dy.shape[1], x0.shape[2], x0.shape[3], 8), dtype=dy.dtype,

@@ -747,8 +747,13 @@ int conv2d_fwd_impl(const dsg_conv_args* a, hipStream_t st, int force_direct) {
                     "conv on its own and pass its result as residual");
     return conv_h2_launch(a, p.hout, p.wout, st);
   }
-  if (!force_direct && conv_in_eligible(a, p.hout, p.wout)) return conv_in_launch(a, p.hout, p.wout, st);
-  if (!force_direct && conv_out_eligible(a, p.hout, p.wout)) return conv_out_launch(a, p.hout, p.wout, st);
+  // (kernel selection never depends on whether `weight` was passed: conv_in / conv_out READ the fp32 engine layout, so a
+  //  call without it is refused -- with the message TrainState.lazy_w retries on -- instead of silently taking another kernel)
+  if (!force_direct && (conv_in_eligible(a, p.hout, p.wout) || conv_out_eligible(a, p.hout, p.wout))) {
+    DSG_CHECK_ARG(a->weight != nullptr,
+                  "dsg_conv2d_fwd: weight is NULL and this call is served by the conv_in / conv_out kernel (needs the fp32 engine layout)");
+    return conv_in_eligible(a, p.hout, p.wout) ? conv_in_launch(a, p.hout, p.wout, st) : conv_out_launch(a, p.hout, p.wout, st);
+  }
   if (!force_direct && conv_h2_eligible(a, p.hout, p.wout)) return conv_h2_launch(a, p.hout, p.wout, st);
   // (`weight`, the fp32 engine layout, may be NULL for a call the operand-image kernels serve: a training step re-lays
   // out every weight it passes here, and most calls never read it)

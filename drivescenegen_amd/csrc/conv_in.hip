@@ -272,7 +272,7 @@ bool conv_in_eligible(const dsg_conv_args* a, int hout, int wout) {
   const int cin = a->c0 + a->c1;
   const int wstride = a->weight_cout_stride ? a->weight_cout_stride : a->cout;
   return a->ksize == 3 && a->stride == 1 && !a->upsample && !a->pool2 && a->c1 == 0 && cin <= 8 && a->src_layout == 0 &&
-         a->dst_layout == 1 && !a->gn_scale_shift && !a->temb && !a->residual && a->weight != nullptr && a->cout % 32 == 0 &&
+         a->dst_layout == 1 && !a->gn_scale_shift && !a->temb && !a->residual && a->cout % 32 == 0 &&
          wstride >= a->cout && hout % CI_TH == 0 && wout % CI_TW == 0;
 }
 

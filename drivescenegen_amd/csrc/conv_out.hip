@@ -246,7 +246,7 @@ bool conv_out_eligible(const dsg_conv_args* a, int hout, int wout) {
   if (!g_conv_out) return false;
   return a->ksize == 3 && a->stride == 1 && !a->upsample && !a->pool2 && a->c1 == 0 && a->c0 % 16 == 0 && a->c0 <= CO_MAXC &&
          a->src_layout == 1 && a->dst_layout == 0 && a->gn_scale_shift && !a->temb && !a->residual && !a->stats_out &&
-         a->weight != nullptr && a->cout <= 8 && hout % CO_TH == 0 && wout % CO_TW == 0;
+         a->cout <= 8 && hout % CO_TH == 0 && wout % CO_TW == 0;
 }
 
 int conv_out_launch(const dsg_conv_args* a, int hout, int wout, hipStream_t st) {
