@@ -56,7 +56,7 @@ bool conv_h2_eligible(const dsg_conv_args* a, int hout, int wout) {
 
 // Fused shortcut (dsg_conv_args.sc_*): a resnet's conv2 -- 3x3, stride 1, GroupNorm + SiLU in front, every tensor
 // channel-blocked, no residual -- takes the 1x1 conv_shortcut over the resnet's raw input into its own K loop.
-// Every dsg_dtype; a call that would split K (small batches, fp32-equivalent mode) keeps the separate shortcut kernel.
+// Every dsg_dtype; with split-K (small batches, fp32-equivalent mode) each K slice contracts its share of the shortcut too.
 bool conv_h2_sc_fusable(const dsg_conv_args* a, int hout, int wout) {
   if (!g_h2.enabled || !g_h2.fuse_sc) return false;
   if (a->ksize != 3 || a->stride != 1 || a->upsample || a->pool2 || !a->gn_scale_shift || !a->silu || a->residual) return false;
@@ -65,7 +65,13 @@ bool conv_h2_sc_fusable(const dsg_conv_args* a, int hout, int wout) {
   if (!conv_h2_eligible(a, hout, wout) || wout % H2_TW != 0) return false;
   const int cin = a->c0 + a->c1, sc_cin = a->sc_c0 + (a->sc_src1 ? a->sc_c1 : 0);
   if (cin < 2 * H2_KC || sc_cin < 4 * H2_KC || sc_cin % H2_KC || (a->sc_src1 && a->sc_c0 % H2_KC)) return false;  // (ring depth 4)
-  if (a->splitk_ws && conv_h2_splitk_slices(a, hout, wout, nullptr) > 1) return false;
+  if (a->splitk_ws) {  // split-K (small grids): every slice takes an equal share of the shortcut's chunks, at least the ring's depth
+    const int slices = conv_h2_splitk_slices(a, hout, wout, nullptr);
+    if (slices > 1) {
+      const int ns = sc_cin / H2_KC, per = (ns + slices - 1) / slices;
+      if (ns - (slices - 1) * per < 4) return false;
+    }
+  }
   return true;
 }
 
@@ -127,7 +133,7 @@ int conv_h2_splitk_slices(const dsg_conv_args* a, int hout, int wout, int* stat_
 // out = sum over the K slices (in slice order) + bias + temb + residual, channel-blocked fp32; grid = (C/8, n, stat
 // splits): a thread owns a pixel's 8 channels; per-(n, c, split) (sum, sum of squares) for the GroupNorm that follows
 __global__ __launch_bounds__(256) void splitk_reduce_blk_kernel(const float* __restrict__ part, int slices, size_t slab,
-                                                                const float* __restrict__ bias,
+                                                                const float* __restrict__ bias, const float* __restrict__ bias2,
                                                                 const float* __restrict__ temb, int temb_stride,
                                                                 const float* __restrict__ res, float* __restrict__ dst,
                                                                 int c, int hw_total, double* __restrict__ stats) {
@@ -138,6 +144,10 @@ __global__ __launch_bounds__(256) void splitk_reduce_blk_kernel(const float* __r
 #pragma unroll
   for (int j = 0; j < 8; ++j)
     add[j] = (bias ? bias[cb * 8 + j] : 0.f) + (temb ? temb[(size_t)n * temb_stride + cb * 8 + j] : 0.f);
+  if (bias2) {  // (the fused shortcut's bias: added after bias + temb, as the one-slice kernel's epilogue does)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) add[j] += bias2[cb * 8 + j];
+  }
   double s[8], ss[8];
 #pragma unroll
   for (int j = 0; j < 8; ++j) s[j] = ss[j] = 0.0;
@@ -196,7 +206,8 @@ int splitk_reduce_launch(const float* part, int slices, const dsg_conv_args* a, 
   const int hw = hout * wout;
   const size_t slab = (size_t)a->n * a->cout * hw;
   hipLaunchKernelGGL(splitk_reduce_blk_kernel, dim3(a->cout / 8, a->n, a->stats_out ? stat_splits : 1), dim3(256), 0, st, part,
-                     slices, slab, a->bias, a->temb, a->temb_stride, a->residual, a->dst, a->cout, hw, a->stats_out);
+                     slices, slab, a->bias, a->sc_weight_h2 ? a->sc_bias : nullptr, a->temb, a->temb_stride, a->residual, a->dst,
+                     a->cout, hw, a->stats_out);
   return DSG_OK;
 }
 

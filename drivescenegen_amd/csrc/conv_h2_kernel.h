@@ -165,7 +165,7 @@ __device__ __forceinline__ float silu_fast_h(float x) { return x * __builtin_amd
 template <int GM, int NT, int KS, int ACT = 3, int NW = 4, int OCC = 1, int LAY = 0, int BM = 64, int PREC = 0, int WS = 0, int SC = 0>
 __global__ __launch_bounds__(64 * NW, OCC * NW / 4) void conv_h2_kernel(ConvH2P p) {
   static_assert(!WS || KS == 3, "the one-slab layout is for the 3x3 kernels");
-  static_assert(!SC || (KS == 3 && GM == 0 && ACT == 2 && BM >= 64 && LAY == 3),
+  static_assert(!SC || (KS == 3 && GM == 0 && ACT == 2 && LAY == 3),
                 "fused shortcut: plain 3x3 conv2 of a resnet, channel-blocked tensors");
   using K0 = std::integral_constant<int, 0>;   // operand kinds: 0 = the main source (GroupNorm affine + SiLU as configured),
   using K1 = std::integral_constant<int, 1>;   //                1 = the fused shortcut's raw source
@@ -511,11 +511,12 @@ __global__ __launch_bounds__(64 * NW, OCC * NW / 4) void conv_h2_kernel(ConvH2P 
     const int u = min(wave + NW * k, NUNIT_SC - 1);
     segoff_sc[k] = __builtin_amdgcn_readfirstlane((u / UPS) * SPU * (int)sc_segb + (u % UPS) * 1024);
   }
+  const int lane16_sc = (lane % (BM < 64 ? BM : 64)) * 16 + (BM < 64 ? (lane / BM) * (int)sc_segb : 0);
   auto dma_weights_sc = [&](int k, const char* wq, unsigned char* buf) {  // wq: sc_wtile + chunk * sc_chunkb (uniform)
     const int unit = min(wave + NW * k, NUNIT_SC - 1);
     const unsigned lds_addr =
         (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)(buf + unit * 1024);
-    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1\n" ::"v"(lane16), "s"(wq + segoff_sc[k]),
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1\n" ::"v"(lane16_sc), "s"(wq + segoff_sc[k]),
                  "s"(__builtin_amdgcn_readfirstlane(lds_addr))
                  : "memory");
   };
@@ -572,7 +573,14 @@ __global__ __launch_bounds__(64 * NW, OCC * NW / 4) void conv_h2_kernel(ConvH2P 
     static_assert(SCD == 4, "the tail below is written out for three chunks in flight");
     static_assert(!SC || SCW_OFF + SCD * SCW_BYTES <= 160 * 1024 / OCC, "the shortcut ring must fit the workgroup's share of LDS");
     static_assert(!SC || (SCD - 2) * PER <= 63, "vmcnt range");
-    const int ns = p.sc_cin / H2_KC;                     // (the host dispatches here with ns >= SCD)
+    // this workgroup's shortcut chunks [sb, sb + ns): all of them, or -- split-K (gridDim.y slices of a small grid) -- an
+    // equal share, like its 3x3 chunks (the host dispatches here with at least SCD chunks per slice)
+    int ns = p.sc_cin / H2_KC, sb = 0;
+    if (gridDim.y > 1) {
+      const int per = (ns + (int)gridDim.y - 1) / (int)gridDim.y;
+      sb = (int)blockIdx.y * per;
+      ns = min(per, ns - sb);
+    }
     int rowoff[NRAW], ldsoff[NRAW];                      // this wave's pieces: global / LDS byte offsets (uniform)
 #pragma unroll
     for (int k = 0; k < NRAW; ++k) {
@@ -585,8 +593,8 @@ __global__ __launch_bounds__(64 * NW, OCC * NW / 4) void conv_h2_kernel(ConvH2P 
     auto sc_issue = [&](int j) {  // every DMA of chunk j (uniform)
       unsigned char* slab = smem_raw + SCW_OFF + (j & (SCD - 1)) * SCW_BYTES;
 #pragma unroll
-      for (int k = 0; k < NDMA_SC; ++k) dma_weights_sc(k, sc_wtile + (size_t)j * sc_chunkb, slab);
-      const char* sp = sc_src_of(j);
+      for (int k = 0; k < NDMA_SC; ++k) dma_weights_sc(k, sc_wtile + (size_t)(sb + j) * sc_chunkb, slab);
+      const char* sp = sc_src_of(sb + j);
       unsigned char* ring = smem_raw + (j & (SCD - 1)) * RAW_BYTES;
 #pragma unroll
       for (int k = 0; k < NRAW; ++k) {

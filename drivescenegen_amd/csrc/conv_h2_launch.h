@@ -128,14 +128,14 @@ int conv_h2_launch_t(const dsg_conv_args* a, int hout, int wout, hipStream_t st)
   // split-K (PREC 0, every tensor channel-blocked, plain / stride-2 3x3 and pointwise): the slices write fp32 partials
   // to the caller's scratch, the reduce pass does what the epilogue would have
   int stat_splits = 1;
-  const int slices = (PREC == 0 && a->splitk_ws && !sc) ? conv_h2_splitk_slices(a, hout0, wout0, &stat_splits) : 1;
+  const int slices = (PREC == 0 && a->splitk_ws) ? conv_h2_splitk_slices(a, hout0, wout0, &stat_splits) : 1;
   if (slices > 1) {
     const size_t slab = (size_t)p.n * p.cout * p.hout * p.wout * sizeof(float);
     if (a->splitk_ws_bytes < slab * slices)
       return fail(DSG_ERR_WORKSPACE_TOO_SMALL, "dsg_conv2d_fwd: splitk_ws %zu bytes < required %zu", a->splitk_ws_bytes, slab * slices);
     p.dst = a->splitk_ws;
     p.split_stride = slab;
-    p.bias = nullptr; p.temb = nullptr; p.res = nullptr; p.stats = nullptr;
+    p.bias = nullptr; p.temb = nullptr; p.res = nullptr; p.stats = nullptr; p.sc_bias = nullptr;  // (the reduce pass adds them)
     grid.y = slices;
   } else {
     p.split_stride = 0;
@@ -176,7 +176,7 @@ int conv_h2_launch_t(const dsg_conv_args* a, int hout, int wout, hipStream_t st)
   } while (0)
   // 32-cout workgroups: (a) optional, two per CU on the shallow levels (cin <= 128: LDS); (b) small batches: when
   // even the 8-row x 64-cout grid leaves more than half of the CUs idle, halve the cout tile to double the grid
-  const bool bm32_ok = lay == 3 && !fold && !s2 && !k1 && !a->upsample && wout % H2_TW == 0 && !sc;
+  const bool bm32_ok = lay == 3 && !fold && !s2 && !k1 && !a->upsample && wout % H2_TW == 0 && (!sc || PREC == 0);
   const bool bm32 = bm32_ok && ((g_h2.bm32 && p.cin <= 128 && (int)grid.x >= g_h2.bm32_min) ||
                                 (g_h2.bm32_small && !nt4 && (int)grid.x <= H2_CUS / 2));
   if (s2) {
@@ -203,7 +203,9 @@ int conv_h2_launch_t(const dsg_conv_args* a, int hout, int wout, hipStream_t st)
     const size_t lds32 = 2 * (size_t)H2Geom<2, 3, 4, 9, 32, NP>::BUF_BYTES + (a->gn_scale_shift ? (size_t)p.cin * 2 * sizeof(float) : 0);
     ConvH2P q = p;
     q.tiles_y = hout / 8;
-    if (act == 0) rc = h2_launch<0, 2, 3, 0, 4, 2, 3, 32, PREC>(g32, lds32, st, q);
+    if (sc) {
+      if constexpr (PREC == 0) rc = h2_launch<0, 2, 3, 2, 4, 2, 3, 32, 0, 0, 1>(g32, lds32, st, q);
+    } else if (act == 0) rc = h2_launch<0, 2, 3, 0, 4, 2, 3, 32, PREC>(g32, lds32, st, q);
     else rc = h2_launch<0, 2, 3, 2, 4, 2, 3, 32, PREC>(g32, lds32, st, q);
   } else if (ws2 && !bm32) {
     // shallow levels: 64 couts x 8 rows, ONE weight slab (80 KB of LDS, half the register file): two workgroups per CU

@@ -61,7 +61,7 @@ def _bound_sum(hm, x0, x1, w2, wsc, ss):
     return F.conv2d(act, w2.double().abs(), padding=1) + F.conv2d(xin, wsc.double().abs())
 
 
-def _run(hm, x0, x1, w2, wsc, b2, bsc, ss, tproj, fused, guard=True, want_stats=False):
+def _run(hm, x0, x1, w2, wsc, b2, bsc, ss, tproj, fused, guard=True, want_stats=False, splitk=False):
     g = lambda t: None if t is None else t.to(DEV)
     hb, x0b = ops.to_blocked(g(hm)), ops.to_blocked(g(x0))
     x1b = ops.to_blocked(g(x1)) if x1 is not None else None
@@ -70,7 +70,7 @@ def _run(hm, x0, x1, w2, wsc, b2, bsc, ss, tproj, fused, guard=True, want_stats=
     cout = w2.shape[0]
     wh2, whsc = ops.relayout_conv_weight_h2(g(w2)), ops.relayout_conv_weight_h2(g(wsc))
     common = dict(ksize=3, cout=cout, gn_scale_shift=g(ss), silu=True, temb=g(tproj), temb_stride=cout, src_blocked=True,
-                  dst_blocked=True, weight_h2=wh2, want_stats=want_stats)
+                  dst_blocked=True, weight_h2=wh2, want_stats=want_stats, splitk=splitk)
     if fused:
         sc = dict(src0=x0b, src1=x1b, weight_h2=whsc, bias=g(bsc), bound=bound)
         assert ops.conv2d_fused(hb, None, g(b2), shortcut=dict(sc, query_only=True), **common)
@@ -155,6 +155,26 @@ def test_fused_shortcut_rows_do_not_depend_on_the_batch():
             got, st1 = _run(*one, fused=True, want_stats=True)
             assert torch.equal(got[0], full[i]), i
             assert torch.equal(st1[0], st[i]), i
+
+
+@pytest.mark.parametrize("name,shape", [("deep_4slices", (1, 512, 512, 512, 512, 32, 32)), ("mid_2slices", (1, 256, 256, 512, 256, 64, 64)),
+                                        ("b2_deep", (2, 512, 512, 512, 256, 32, 32))])
+def test_fused_shortcut_under_split_k(name, shape):
+    """Small batches (the reference samples at batch 1 and 5): a conv2 whose grid covers at most half the chip contracts its
+    K in 2-4 parallel slices (32-cout workgroups where that still leaves CUs idle) -- each slice then takes its share of the
+    shortcut's chunks as well, and the reduce pass adds the shortcut's bias.  Same value as the one-slice fused kernel to
+    fp32 round-off, fp64 agreement unchanged, statistics from the reduce pass."""
+    n, c, cout, sc0, sc1, h, w = shape
+    case = _case(n, c, cout, sc0, sc1, h, w, seed=zlib.crc32(name.encode()) % 1000)
+    ref = _ref64(*case)
+    one, _ = _run(*case, fused=True)
+    many, st = _run(*case, fused=True, want_stats=True, splitk=True)
+    plain, _ = _run(*case, fused=False, splitk=True)
+    assert torch.isfinite(many).all() and not torch.equal(one, many)       # (the sliced kernels really ran)
+    assert rel_l2(many, ref) <= 2e-6 and rel_l2(many, one) <= 1e-6 and rel_l2(many, plain) <= 2e-6
+    assert st is not None
+    f64 = many.double()
+    assert ((st.sum(2).cpu()[..., 0] - f64.sum((2, 3))).abs() <= 3e-6 * f64.abs().sum((2, 3)) + 1e-4).all()
 
 
 def test_shapes_that_do_not_fuse_say_so():
