@@ -106,7 +106,8 @@ def gpu_leg(args, rank, world):
                  3: "conv1x1_mfma_f32", 4: "conv_direct_valu", 6: "conv3x3_s1_mfma_f16x2split",
                  7: "conv3x3_upsample_mfma_f16x2split", 8: "conv1x1_mfma_f16x2split",
                  10: "conv3x3_s1_mfma_f16x2split_two_wg_per_cu", 11: "conv_in_image_to_blocked",
-                 12: "conv_out_blocked_to_image"}
+                 12: "conv_out_blocked_to_image", 13: "conv3x3_plus_fused_shortcut_f16x2split",
+                 14: "conv3x3_plus_fused_shortcut_f16x2split_two_wg_per_cu"}
         for kid, nm in names.items():
             ms, fl, by, n = C.c_double(), C.c_double(), C.c_double(), C.c_int64()
             _lib.check(lib.dsg_prof_summary(kid, C.byref(ms), C.byref(fl), C.byref(by), C.byref(n)))
@@ -196,7 +197,7 @@ def mixed_leg(args, dtype="bf16"):
     torch.cuda.synchronize(dev)
     dt = time.perf_counter() - t0
     assert torch.isfinite(x).all()
-    rows = _prof_rows(lib, _lib, {26: "conv3x3_s1_mfma_16bit", 27: "conv3x3_upsample_mfma_16bit", 22: "conv3x3_s2_mfma_16bit",
+    rows = _prof_rows(lib, _lib, {26: "conv3x3_s1_mfma_16bit", 33: "conv3x3_plus_fused_shortcut_16bit", 27: "conv3x3_upsample_mfma_16bit", 22: "conv3x3_s2_mfma_16bit",
                                    28: "conv1x1_mfma_16bit", 0: "conv3x3_s1_mfma_f32", 4: "conv_direct_valu",
                                    11: "conv_in_image_to_blocked", 12: "conv_out_blocked_to_image"})
     lib.dsg_prof_enable(0)
@@ -269,6 +270,7 @@ def train_leg(args, dtype="fp32", batch=16, steps=3):
     torch.cuda.synchronize(dev)
     base = 0 if dtype == "fp32" else 20
     rows = _prof_rows(lib, _lib, {base + 6: "conv3x3_fwd_and_dgrad", base + 10: "conv3x3_fwd_and_dgrad_two_wg_per_cu",
+                                   base + 13: "conv3x3_plus_fused_shortcut",
                                    base + 7: "conv3x3_upsample", base + 8: "conv1x1", base + 2: "conv3x3_s2",
                                    base + 9: "conv3x3_wgrad", 5: "conv_wgrad_f32_mfma", 0: "conv3x3_s1_mfma_f32"})
     lib.dsg_prof_enable(0)
@@ -451,9 +453,9 @@ def main():
             # fp32-equivalent MAC -> the ceiling for ALGORITHMIC (fp32-equivalent) FLOPs is the dense f16 peak / 3
             dom = prof["conv3x3_s1_mfma_f16x2split"]
             peak = PEAK_F16_TFLOPS / 3.0
-            roofline = dict(bound="mfma", kernel="dsg::conv_h2_kernel<0, 4, 3, 2, 4, 1, 3, 64>", achieved=dom["tflops"], peak=peak,
-                            unit="TFLOP/s", frac=dom["tflops"] / peak, **pmc_traffic("dsg::conv_h2_kernel<0, 4, 3, 2, 4, 1, 3, 64>"),
-                            **pmc_mfma("dsg::conv_h2_kernel<0, 4, 3, 2, 4, 1, 3, 64>"),
+            roofline = dict(bound="mfma", kernel="dsg::conv_h2_kernel<0, 4, 3, 2, 4, 1, 3, 64, 0, 0, 0>", achieved=dom["tflops"], peak=peak,
+                            unit="TFLOP/s", frac=dom["tflops"] / peak, **pmc_traffic("dsg::conv_h2_kernel<0, 4, 3, 2, 4, 1, 3, 64, 0, 0, 0>"),
+                            **pmc_mfma("dsg::conv_h2_kernel<0, 4, 3, 2, 4, 1, 3, 64, 0, 0, 0>"),
                             peak_note="2500 TF/s dense f16 MFMA / 3 products per fp32-equivalent MAC (fp16x2 split); "
                                       "issued MFMA rate = 3 x achieved; the pure-fp32 MFMA peak is 157.3",
                             issued_mfma_tflops=3.0 * dom["tflops"],
@@ -465,11 +467,23 @@ def main():
             ws = prof.get("conv3x3_s1_mfma_f16x2split_two_wg_per_cu")
             if ws:  # the same convs at the 64- / 128-channel levels (cin <= 128): 8-row tiles, two workgroups per CU
                 roofline["second_kernel"] = dict(
-                    kernel="dsg::conv_h2_kernel<0, 2, 3, 2, 4, 2, 3, 64, 0, 1>", achieved=ws["tflops"], frac=ws["tflops"] / peak,
+                    kernel="dsg::conv_h2_kernel<0, 2, 3, 2, 4, 2, 3, 64, 0, 1, 0>", achieved=ws["tflops"], frac=ws["tflops"] / peak,
                     avg_launch_ms=ws["avg_ms"], launches=ws["launches"], alg_flops_per_launch=ws["flops_per_launch"],
                     alg_gbs=ws["alg_gbs"],
                     time_share=ws["total_ms"] * 1e-3 * args.steps / len(range(0, args.steps, PROF_EVERY)) / dt,
-                    **pmc_traffic("dsg::conv_h2_kernel<0, 2, 3, 2, 4, 2, 3, 64, 0, 1>"))
+                    **pmc_traffic("dsg::conv_h2_kernel<0, 2, 3, 2, 4, 2, 3, 64, 0, 1, 0>"))
+            # the resnets' conv2 with the 1x1 shortcut contracted in the same kernel (FLOPs / bytes of both convs)
+            for key, cls, kern in (("fused_shortcut_kernel", "conv3x3_plus_fused_shortcut_f16x2split", "dsg::conv_h2_kernel<0, 4, 3, 2, 4, 1, 3, 64, 0, 0, 1>"),
+                                   ("fused_shortcut_two_wg_kernel", "conv3x3_plus_fused_shortcut_f16x2split_two_wg_per_cu",
+                                    "dsg::conv_h2_kernel<0, 2, 3, 2, 4, 2, 3, 64, 0, 1, 1>")):
+                row = prof.get(cls)
+                if row:
+                    roofline[key] = dict(
+                        kernel=kern, achieved=row["tflops"], frac=row["tflops"] / peak, avg_launch_ms=row["avg_ms"],
+                        launches=row["launches"], alg_flops_per_launch=row["flops_per_launch"], alg_gbs=row["alg_gbs"],
+                        hbm_frac=row["alg_gbs"] / PEAK_HBM_GBS,
+                        time_share=row["total_ms"] * 1e-3 * args.steps / len(range(0, args.steps, PROF_EVERY)) / dt,
+                        **pmc_traffic(kern))
         elif "conv3x3_s1_mfma_f32" in prof:
             dom = prof["conv3x3_s1_mfma_f32"]
             roofline = dict(bound="mfma", kernel="dsg::conv_mfma_kernel<3,1,0,2,*>", achieved=dom["tflops"],

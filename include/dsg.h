@@ -489,7 +489,8 @@ int dsg_rasterize_boxes(const float* boxes, int32_t nbox, float* out, int32_t h,
  * stream, used by bench.py's roofline leg.  Classes: 0 conv3x3 stride-1, 1 conv3x3 on the nearest-x2
  * upsampled input, 2 conv3x3 stride-2, 3 conv1x1, 4 direct (VALU) conv, 5 conv weight-gradient, 6 / 7 / 8 conv3x3
  * stride-1 / conv3x3 upsampled / conv1x1 on the fp16x2-split matrix-core path, 9 its 3x3 weight gradient, 10 the 3x3 kernel's
- * two-workgroup instantiation, 11 conv_in.hip, 12 conv_out.hip, 20 + c the 16-bit modes' class c.  FLOPs/bytes are the
+ * two-workgroup instantiation, 11 conv_in.hip, 12 conv_out.hip, 13 / 14 the 3x3 kernel / its two-workgroup instantiation
+ * with a fused resnet shortcut (FLOPs and bytes of both convs), 20 + c the 16-bit modes' class c.  FLOPs/bytes are the
  * algorithmic figures of each launch (2*MACs; input + weights + output once).
  * ---------------------------------------------------------------------------------------- */
 int dsg_prof_enable(int32_t on); /* 1 start (clears), 0 stop (clears); 2 pause / 3 resume, keeping the records */
