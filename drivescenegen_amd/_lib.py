@@ -49,6 +49,7 @@ class ConvArgs(C.Structure):
         ("splitk_ws", C.c_void_p), ("splitk_ws_bytes", C.c_size_t),
         ("sc_src0", C.c_void_p), ("sc_src1", C.c_void_p), ("sc_c0", C.c_int32), ("sc_c1", C.c_int32),
         ("sc_weight_h2", C.c_void_p), ("sc_bias", C.c_void_p), ("sc_src_bound", C.c_void_p), ("sc_src_bound1", C.c_void_p),
+        ("src_operand", C.c_void_p),
     ]
 
 
@@ -120,6 +121,9 @@ SIGNATURES = {
     "dsg_gn_finalize_parts_train": [_vp, _i32, _i32, _vp, _i32, _i32, _vp, _vp, _i32, _i32, _i32, _f32, _vp, _vp, _vp],
     "dsg_conv2d_fwd": [C.POINTER(ConvArgs), _vp],
     "dsg_conv2d_fuses_shortcut": [C.POINTER(ConvArgs), C.POINTER(_i32)],
+    "dsg_conv2d_takes_operand": [C.POINTER(ConvArgs), C.POINTER(_i32)],
+    "dsg_conv_operand_bytes": [_i32, _i32, _i32, _i32, _i32, C.POINTER(_sz)],
+    "dsg_conv_operand_prepare": [_vp, _i32, _vp, _i32, _i32, _i32, _i32, _vp, _i32, _vp, _vp, _vp, _i32, _vp],
     "dsg_layout_convert": [_vp, _vp, _i32, _i32, _i32, _i32, _vp],
     "dsg_conv2d_fwd_direct": [C.POINTER(ConvArgs), _vp],
     "dsg_conv_weight_relayout": [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp],

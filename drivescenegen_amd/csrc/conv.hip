@@ -477,6 +477,9 @@ void conv_h2_set_splitk(int v);
 void conv_h2_set_ws2(int v);
 void conv_h2_set_fuse_sc(int v);
 int conv_h2_get_fuse_sc();
+void conv_h2_set_pre(int v);
+void conv_h2_set_pre_min_ct(int v);
+bool conv_h2_takes_operand(const dsg_conv_args* a, int hout, int wout, bool wanted);
 void attention_set_blocked(int v);
 bool conv_h2_sc_fusable(const dsg_conv_args* a, int hout, int wout);
 int conv_h2_splitk_slices(const dsg_conv_args* a, int hout, int wout, int* stat_splits);
@@ -738,6 +741,10 @@ int conv2d_fwd_impl(const dsg_conv_args* a, hipStream_t st, int force_direct) {
   p.tiles_x = (p.wout + TW - 1) / TW; p.tiles_y = p.hout / TH;
   DSG_CHECK_ARG(!(p.pool && ((p.hout | p.wout) & 1)), "dsg_conv2d_fwd: pool2 needs even output dims");
 
+  if (a->src_operand != nullptr)  // pre-staged operand image: only the split-path kernels that DMA it serve the call
+    DSG_CHECK_SHAPE(!force_direct && conv_h2_takes_operand(a, p.hout, p.wout, false),
+                    "dsg_conv2d_fwd: this call's kernel stages its own patch (dsg_conv2d_takes_operand reports 0): pass "
+                    "src_operand = NULL");
   if (a->sc_weight_h2 != nullptr) {  // fused shortcut: only the split-path kernel that contracts it serves the call
     DSG_CHECK_ARG(a->sc_src0 != nullptr && a->sc_c0 > 0 && a->sc_c1 >= 0 && (a->sc_c1 == 0) == (a->sc_src1 == nullptr) &&
                       a->residual == nullptr,
@@ -887,6 +894,14 @@ DSG_API int dsg_set_tuning(int32_t key, int32_t value) {
     dsg::conv_h2_set_fuse_sc(value);
     return DSG_OK;
   }
+  if (key == 26 && (value == 0 || value == 1)) {
+    dsg::conv_h2_set_pre(value);
+    return DSG_OK;
+  }
+  if (key == 27 && value >= 1) {
+    dsg::conv_h2_set_pre_min_ct(value);
+    return DSG_OK;
+  }
   if (key == 18 && (value == 0 || value == 1)) {
     dsg::conv_h2_set_bm128(value);
     return DSG_OK;
@@ -954,6 +969,15 @@ DSG_API int dsg_conv2d_fuses_shortcut(const dsg_conv_args* a, int32_t* yes) {
   if (a->sc_weight_h2 == nullptr || a->sc_src0 == nullptr || a->sc_c0 <= 0 || a->ksize != 3 || a->stride != 1 || a->upsample)
     return DSG_OK;
   *yes = dsg::conv_h2_sc_fusable(a, a->hin, a->win) ? 1 : 0;
+  return DSG_OK;
+}
+
+DSG_API int dsg_conv2d_takes_operand(const dsg_conv_args* a, int32_t* yes) {
+  DSG_CHECK_ARG(a != nullptr && yes != nullptr, "dsg_conv2d_takes_operand: NULL pointer");
+  *yes = 0;
+  if (a->ksize != 3 || a->stride != 1 || a->upsample < 0 || a->upsample > 1) return DSG_OK;
+  const int hout = a->upsample ? 2 * a->hin : a->hin, wout = a->upsample ? 2 * a->win : a->win;
+  *yes = dsg::conv_h2_takes_operand(a, hout, wout, true) ? 1 : 0;
   return DSG_OK;
 }
 

@@ -75,6 +75,27 @@ bool conv_h2_sc_fusable(const dsg_conv_args* a, int hout, int wout) {
   return true;
 }
 
+// Pre-staged operand image (dsg_conv_args.src_operand, dsg_conv_operand_prepare): fp32-equivalent mode, every tensor
+// channel-blocked, a stride-1 3x3 conv -- a resnet's conv1 / conv2 (GroupNorm + SiLU in front; with or without the fused
+// shortcut) or the folded up-sampler conv (raw source) -- whose grid takes the 16-row kernel without split-K.  `wanted`
+// adds the pays-off rule: the patch is staged by at least pre_min_ct workgroups (cout tiles x phases), i.e. the image
+// replaces that many normalise + activate + split passes over it.
+bool conv_h2_takes_operand(const dsg_conv_args* a, int hout, int wout, bool wanted) {
+  if (!g_h2.enabled || !g_h2.pre || a->compute_dtype != DSG_F32) return false;
+  if (a->ksize != 3 || a->stride != 1 || a->pool2 || a->src_layout != 1 || a->dst_layout != 1) return false;
+  if (a->weight_h2_cout_stride) return false;
+  const bool fold = conv_h2_fold(a);
+  if (a->upsample && !fold) return false;
+  if (!fold && (a->weight_h2 == nullptr || !a->gn_scale_shift || !a->silu)) return false;
+  if (!conv_h2_eligible(a, hout, wout)) return false;
+  if ((fold ? a->win : wout) % H2_TW != 0 || !conv_h2_rows16(a, hout, wout)) return false;
+  if (a->splitk_ws && conv_h2_splitk_slices(a, hout, wout, nullptr) > 1) return false;
+  const int cin = a->c0 + a->c1;
+  if (g_h2.ws2 && !fold && cin <= 128) return false;  // (the two-workgroup kernel keeps its own staging)
+  if (wanted && ((a->cout + 63) / 64) * (fold ? 4 : 1) < g_h2.pre_min_ct) return false;
+  return true;
+}
+
 // tile geometry shared by the launcher and dsg_conv2d_stats_tiles
 // 16-row tiles (4 rows per wave) are the efficient shape; 8-row tiles double the workgroup count.  The chip runs
 // 256 workgroups at a time, so what counts is the number of ROUNDS: an 8-row workgroup costs ~0.55 of a 16-row one
@@ -240,6 +261,8 @@ void conv_h2_set_bm128(int v) { g_h2.bm128 = v; ++g_h2.epoch; }
 void conv_h2_set_splitk(int v) { g_h2.splitk = v; ++g_h2.epoch; }
 void conv_h2_set_ws2(int v) { g_h2.ws2 = v; ++g_h2.epoch; }
 void conv_h2_set_fuse_sc(int v) { g_h2.fuse_sc = v; ++g_h2.epoch; }
+void conv_h2_set_pre(int v) { g_h2.pre = v; ++g_h2.epoch; }
+void conv_h2_set_pre_min_ct(int v) { g_h2.pre_min_ct = v > 0 ? v : 1; ++g_h2.epoch; }
 int conv_h2_get_fuse_sc() { return g_h2.fuse_sc; }
 int conv_in_tuning_epoch();  // conv_in.hip: its on/off switch moves the plan's statistics buffers too
 int conv_h2_tuning_epoch() { return g_h2.epoch + conv_in_tuning_epoch(); }
@@ -357,7 +380,99 @@ __global__ void weight_pack3x3_kernel(const float* __restrict__ w, unsigned shor
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Pre-staged operand image of a conv source (dsg_conv_operand_prepare; read by conv_h2_kernel's PRE form).
+// One thread per (image, channel block, PADDED pixel): the pixel's 8 channels -> GroupNorm affine + SiLU, or the range
+// guard's power-of-two pre-scale for a raw source -> the (hi, 2^11-scaled lo) fp16 pair, exactly the arithmetic of the
+// conv's own staging pass (conv_h2_kernel.h: to_operand), so a conv gives the same bits either way.  Border pixels are
+// zeros: the conv's zero padding.  grid = (ceil((h+2)(w+2) / 256), (c0 + c1) / 8, n).
+// ---------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void conv_operand_kernel(const float* __restrict__ src0, int c0, const float* __restrict__ src1,
+                                                           int c1, int hin, int win, const float* __restrict__ ss, int silu,
+                                                           const unsigned* __restrict__ bound0,
+                                                           const unsigned* __restrict__ bound1, unsigned short* __restrict__ dst,
+                                                           size_t piece_halfs) {
+  const int cb = blockIdx.y, n = blockIdx.z, c = c0 + c1;
+  const int wp = win + 2, ppos = (hin + 2) * wp;
+  const int pos = blockIdx.x * 256 + threadIdx.x;
+  if (pos >= ppos) return;
+  const int py = pos / wp, px = pos - py * wp;
+  typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+  u32x4 hi = {0u, 0u, 0u, 0u}, lo = {0u, 0u, 0u, 0u};
+  if (py >= 1 && py <= hin && px >= 1 && px <= win) {
+    const float* sp = (cb * 8 < c0) ? src0 + (((size_t)n * (c0 / 8) + cb) * hin * win) * 8
+                                    : src1 + (((size_t)n * (c1 / 8) + (cb - c0 / 8)) * hin * win) * 8;
+    const float4* q = reinterpret_cast<const float4*>(sp + ((size_t)(py - 1) * win + (px - 1)) * 8);
+    const float4 v0 = q[0], v1 = q[1];
+    float v[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+    float xs = 1.f;
+    if (ss == nullptr && bound0 != nullptr) {  // (the conv's own guard: conv_h2_kernel.h, "range guard")
+      unsigned b = bound0[n];
+      if (bound1 != nullptr) b = max(b, bound1[n]);
+      const int e = min(100, max(-100, (int)(b >> 23) - 127));
+      if (b != 0u && (e > 12 || e < -6)) xs = __uint_as_float((unsigned)(127 - e) << 23);
+    }
+    unsigned w1[4], w2[4];
+#pragma unroll
+    for (int jp = 0; jp < 4; ++jp) {
+      float a = v[2 * jp], b = v[2 * jp + 1];
+      if (ss != nullptr) {
+        const float* e = ss + ((size_t)n * c + cb * 8 + 2 * jp) * 2;  // (scale, shift) of the pair's two channels
+        a = a * e[0] + e[1];
+        b = b * e[2] + e[3];
+      } else {
+        a *= xs;
+        b *= xs;
+      }
+      // silu(v) = v * r, r = 1 / (1 + exp(-v)).  The conv kernel's staging pass (ACT = 2: the activation is a compile-time
+      // fact there) takes the low-order piece from the EXACT product, fma(v, r, -hi) -- hipcc contracts its
+      // `v * r - hi` -- and so does this kernel, explicitly: same bits (tests/test_gpu_operand.py holds both to it).
+      float ra = 1.f, rb = 1.f;
+      if (silu) {
+        ra = __builtin_amdgcn_rcpf(1.0f + __expf(-a));
+        rb = __builtin_amdgcn_rcpf(1.0f + __expf(-b));
+      }
+      const _Float16 a1 = (_Float16)(a * ra), b1 = (_Float16)(b * rb);
+      const half2v h = {a1, b1};
+      const half2v l = {(_Float16)(__builtin_fmaf(a, ra, -(float)a1) * 2048.0f), (_Float16)(__builtin_fmaf(b, rb, -(float)b1) * 2048.0f)};
+      w1[jp] = __builtin_bit_cast(unsigned, h);
+      w2[jp] = __builtin_bit_cast(unsigned, l);
+    }
+    hi = u32x4{w1[0], w1[1], w1[2], w1[3]};
+    lo = u32x4{w2[0], w2[1], w2[2], w2[3]};
+  }
+  unsigned short* o = dst + (((size_t)n * (c / 8) + cb) * ppos + pos) * 8;
+  *reinterpret_cast<u32x4*>(o) = hi;
+  *reinterpret_cast<u32x4*>(o + piece_halfs) = lo;
+}
+
 }  // namespace dsg
+
+DSG_API int dsg_conv_operand_bytes(int32_t n, int32_t c, int32_t hin, int32_t win, int32_t dtype, size_t* bytes) {
+  DSG_CHECK_ARG(bytes != nullptr, "dsg_conv_operand_bytes: bytes is NULL");
+  DSG_CHECK_ARG(n > 0 && c > 0 && c % 16 == 0 && hin > 0 && win > 0, "dsg_conv_operand_bytes: bad dims (c %% 16 != 0?)");
+  DSG_CHECK_SHAPE(dtype == DSG_F32, "dsg_conv_operand_bytes: operand images exist for the fp32-equivalent mode only (dtype %d)", dtype);
+  *bytes = 2 * (size_t)n * c * (hin + 2) * (win + 2) * 2;
+  return DSG_OK;
+}
+
+DSG_API int dsg_conv_operand_prepare(const float* src0, int32_t c0, const float* src1, int32_t c1, int32_t n, int32_t hin,
+                                     int32_t win, const float* gn_scale_shift, int32_t silu, const uint32_t* src_bound,
+                                     const uint32_t* src_bound1, void* operand, int32_t dtype, void* stream) {
+  DSG_CHECK_ARG(src0 && operand, "dsg_conv_operand_prepare: NULL pointer");
+  DSG_CHECK_ARG((c1 == 0) == (src1 == nullptr), "dsg_conv_operand_prepare: src1/c1 mismatch");
+  DSG_CHECK_ARG(n > 0 && n <= 65535 && c0 > 0 && c1 >= 0 && c0 % 8 == 0 && c1 % 8 == 0 && (c0 + c1) % 16 == 0 && hin > 0 && win > 0,
+                "dsg_conv_operand_prepare: bad dims (channel-blocked sources: c0 %% 8, c1 %% 8, (c0 + c1) %% 16)");
+  DSG_CHECK_ARG(!(silu && !gn_scale_shift), "dsg_conv_operand_prepare: silu without gn_scale_shift (no conv of the U-Net has that)");
+  DSG_CHECK_SHAPE(dtype == DSG_F32, "dsg_conv_operand_prepare: operand images exist for the fp32-equivalent mode only (dtype %d)", dtype);
+  const int ppos = (hin + 2) * (win + 2);
+  hipLaunchKernelGGL(dsg::conv_operand_kernel, dim3((ppos + 255) / 256, (c0 + c1) / 8, n), dim3(256), 0,
+                     static_cast<hipStream_t>(stream), src0, c0, src1, c1, hin, win, gn_scale_shift, silu,
+                     gn_scale_shift ? nullptr : src_bound, gn_scale_shift ? nullptr : src_bound1,
+                     static_cast<unsigned short*>(operand), (size_t)n * (c0 + c1) * ppos);
+  DSG_LAUNCH_CHECK();
+  return DSG_OK;
+}
 
 static int pack_dims(int32_t cout, int32_t cin, int32_t ksize, int32_t kind, int32_t dtype, int32_t n_total,
                      int* kdim, int* ndim, int* taps, int* phases, int* n_pad) {

@@ -75,6 +75,12 @@ struct ConvH2P {
   const void* sc_wh;   // [sc_cin/16][pieces][1][2][sc_wh_stride][8]
   int sc_wh_stride;
   const float* sc_bias;
+  // Pre-staged operand image (PRE kernels): what the staging pass would have written to LDS -- GroupNorm affine + SiLU
+  // (or the range guard's pre-scale) applied, split into the (hi, scaled lo) fp16 pair -- computed ONCE by
+  // dsg_conv_operand_prepare instead of once per cout tile: [piece][N][cin/8][hin + 2][win + 2][8] 16-bit values with a
+  // zero border, so a tile's halo patch is DMA'd to LDS as it is (no registers, no VALU, no bounds logic).
+  const void* pre;
+  size_t pre_piece_stride;  // bytes between the two pieces
 };
 
 constexpr int H2_TW = 32, H2_KC = 16, H2_BM = 64;
@@ -85,7 +91,7 @@ constexpr int H2_TW = 32, H2_KC = 16, H2_BM = 64;
 // KS = 3 (halo of 1) or 1 (no halo; attention projections and resnet shortcuts)
 // NW = waves per workgroup (4: one per SIMD with the whole register file; 8: two per SIMD with half of it each,
 // so that one wave's staging / LDS / wait time is covered by the other's MFMAs)
-template <int NT, int KS, int NW = 4, int TAPS_ = KS * KS, int BM_ = 64, int NP_ = 2>
+template <int NT, int KS, int NW = 4, int TAPS_ = KS * KS, int BM_ = 64, int NP_ = 2, int PRE_ = 0>
 struct H2Geom {
   static constexpr int NP = NP_;                      // operand pieces: 2 (hi + scaled lo, fp16x2 split) or 1 (bf16 / fp16)
   static constexpr int BM = BM_;                      // output channels per workgroup: 64, or 32 (two workgroups per CU)
@@ -95,8 +101,10 @@ struct H2Geom {
   static constexpr int PH = TH + KS - 1;
   static constexpr int PW = H2_TW + KS - 1;
   static constexpr int PSZ = PW * PH;                 // KS=3: 340 (NT=2) / 612 (NT=4); KS=1: 256 / 512
+  static constexpr int PUNITS = (PSZ + 63) / 64;      // PRE: 1-KB DMA units (64 positions x 16 B) per (piece, k-group) region
+  static constexpr int PSTR = PRE_ ? PUNITS * 64 : PSZ;  // positions between regions (PRE: whole DMA units, so a unit never spills into the next region)
   static constexpr int WHALFS = NP * TAPS * 2 * BM * 8;  // [piece][tap][g][cout][8]: 36864 B / 4096 B at BM = 64, NP = 2
-  static constexpr int XHALFS = NP * 2 * PSZ * 8;     // [piece][g][pos][8]
+  static constexpr int XHALFS = NP * 2 * PSTR * 8;    // [piece][g][pos][8]
   static constexpr int BUF_BYTES = (WHALFS + XHALFS) * 2 + 64;  // + a dump slot for masked lanes
   static constexpr int FULL = PSZ / NTH;              // full NTH-position slabs per k-group
   static constexpr bool HAS_REM = (PSZ % NTH) != 0;   // KS=3 leaves a remainder slab shared by the two k-groups
@@ -122,6 +130,14 @@ __device__ __forceinline__ float half_wave_sum(float x) {
   x = dpp_add<0x140>(x);       // row_mirror: every lane of a 16-row holds the row sum
   x = dpp_add<0x142, 0xA>(x);  // row_bcast15 into rows 1 and 3
   return x;
+}
+
+// a uniform 64-bit address as an SGPR pair, whatever register class the compiler had chosen for it (with the scalar file
+// full it keeps uniform values in VGPRs, which an "s" asm operand cannot take)
+__device__ __forceinline__ const char* sgpr_ptr(const char* p) {
+  const unsigned long long v = reinterpret_cast<unsigned long long>(p);
+  const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+  return reinterpret_cast<const char*>(((unsigned long long)hi << 32) | lo);
 }
 
 __device__ __forceinline__ float silu_fast_h(float x) { return x * __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
@@ -162,11 +178,19 @@ __device__ __forceinline__ float silu_fast_h(float x) { return x * __builtin_amd
 //     the epilogue, covered by the CU's other workgroup.
 // SC: 1 = the fused-shortcut form (see ConvH2P::sc_*): after the nq 3x3 chunks of the normalised source come
 //     sc_cin / 16 one-tap chunks of the raw shortcut source(s), staged through the same patch slots (centre tap only)
-template <int GM, int NT, int KS, int ACT = 3, int NW = 4, int OCC = 1, int LAY = 0, int BM = 64, int PREC = 0, int WS = 0, int SC = 0>
+// PRE: 1 = the main source is a pre-staged operand image (ConvH2P::pre; ACT must be 0: the activation is in the image).
+//      The K loop then stages nothing: a chunk's halo patch -- NP * 2 regions of PSZ positions x 16 B -- goes global -> LDS
+//      in 1-KB DMA units like the weights (lane L of a unit fetches halo position 64 u + L: its address inside a padded
+//      channel block is the only per-lane quantity, computed once per tile), so the loop is MFMAs + fragment reads + ~20
+//      DMA issues per chunk.  For the deep levels, where cout / 64 workgroups would each re-normalise, re-activate and
+//      re-split the same patch (the loop measured 1020 cycles per tap against 755 with nothing staged).
+template <int GM, int NT, int KS, int ACT = 3, int NW = 4, int OCC = 1, int LAY = 0, int BM = 64, int PREC = 0, int WS = 0, int SC = 0, int PRE = 0>
 __global__ __launch_bounds__(64 * NW, OCC * NW / 4) void conv_h2_kernel(ConvH2P p) {
   static_assert(!WS || KS == 3, "the one-slab layout is for the 3x3 kernels");
-  static_assert(!SC || (KS == 3 && GM == 0 && ACT == 2 && LAY == 3),
+  static_assert(!SC || (KS == 3 && GM == 0 && (ACT == 2 || PRE) && LAY == 3),
                 "fused shortcut: plain 3x3 conv2 of a resnet, channel-blocked tensors");
+  static_assert(!PRE || (KS == 3 && (GM == 0 || GM == 2) && ACT == 0 && LAY == 3 && !WS),
+                "pre-staged operands: stride-1 3x3 convs (plain or folded up-sampler) on channel-blocked tensors");
   using K0 = std::integral_constant<int, 0>;   // operand kinds: 0 = the main source (GroupNorm affine + SiLU as configured),
   using K1 = std::integral_constant<int, 1>;   //                1 = the fused shortcut's raw source
   constexpr bool SB = (LAY & 1) != 0, DB = (LAY & 2) != 0;
@@ -175,9 +199,10 @@ __global__ __launch_bounds__(64 * NW, OCC * NW / 4) void conv_h2_kernel(ConvH2P 
   constexpr int ESS = S16 ? 2 : 4;              // bytes per source element
   constexpr int ESD = (PREC != 0 && DB) ? 2 : 4;  // bytes per dst / residual element
   constexpr int MTN = BM / 32;  // 32-channel MFMA tiles per workgroup
-  using G = H2Geom<NT, KS, NW, (GM == 2 || GM == 3) ? 4 : KS * KS, BM, NP>;
+  using G = H2Geom<NT, KS, NW, (GM == 2 || GM == 3) ? 4 : KS * KS, BM, NP, PRE>;
   constexpr int NTH = G::NTH;
   constexpr int H2_TH = G::TH, H2_PSZ = G::PSZ, H2_XHALFS = G::XHALFS, H2_BUF_BYTES = G::BUF_BYTES, H2_NU = G::NU;
+  constexpr int H2_PSTR = G::PSTR;  // positions between the (piece, k-group) regions of a patch
   constexpr int FULL = G::FULL, TAPS = G::TAPS, H2_PW = G::PW, H2_WHALFS = G::WHALFS, PADK = KS / 2;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
 #ifdef DSG_H2_TIMING
@@ -233,11 +258,11 @@ __global__ __launch_bounds__(64 * NW, OCC * NW / 4) void conv_h2_kernel(ConvH2P 
     if (pos < H2_PSZ) {
       const int py = pos / H2_PW, px = pos - py * H2_PW;
       const int gy = oy0 - PADK + py, gx = ox0 - PADK + px;
-      const int slot = H2_WHALFS + (g * H2_PSZ + pos) * 8;  // piece 0; piece 1 is 2*PSZ*8 halfs further
+      const int slot = H2_WHALFS + (g * H2_PSTR + pos) * 8;  // piece 0; piece 1 is 2*PSTR*8 halfs further
       if (gy >= 0 && gy < p.hc && gx >= 0 && gx < p.wc) {
         off = GM == 3 ? (2 * gy) * p.win + 2 * gx : (GM == 1 ? (gy >> 1) : gy) * p.win + (GM == 1 ? (gx >> 1) : gx);
         xo = slot;
-        xo2 = NP == 2 ? slot + 2 * H2_PSZ * 8 : slot;
+        xo2 = NP == 2 ? slot + 2 * H2_PSTR * 8 : slot;
       } else {
         zo = slot;
       }
@@ -495,7 +520,8 @@ __global__ __launch_bounds__(64 * NW, OCC * NW / 4) void conv_h2_kernel(ConvH2P 
     // completion is waited for explicitly before the chunk's closing barrier.
     const unsigned lds_addr =
         (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)(buf + unit * 1024);
-    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1\n" ::"v"(lane16), "s"(wq + segoff[k]),
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1\n" ::"v"(lane16),
+                 "s"(PRE ? sgpr_ptr(wq + segoff[k]) : wq + segoff[k]),
                  "s"(__builtin_amdgcn_readfirstlane(lds_addr))  // (uniform by construction)
                  : "memory");
   };
@@ -517,6 +543,38 @@ __global__ __launch_bounds__(64 * NW, OCC * NW / 4) void conv_h2_kernel(ConvH2P 
     const unsigned lds_addr =
         (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)(buf + unit * 1024);
     asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1\n" ::"v"(lane16_sc), "s"(wq + segoff_sc[k]),
+                 "s"(__builtin_amdgcn_readfirstlane(lds_addr))
+                 : "memory");
+  };
+
+  // PRE: the chunk's patch as NPU 1-KB DMA units; wave w moves units w, w + NW, ...  Unit U = (region r = U / PUNITS,
+  // u = U % PUNITS): LDS [r][64 u ..] <- padded image, piece r / 2, channel block 2 q + (r & 1), halo positions 64 u + lane
+  constexpr int NPU = NP * 2 * G::PUNITS, NPD = PRE ? (NPU + NW - 1) / NW : 1;
+  int pvoff[NPD], pldso[NPD];
+  size_t pgoff[NPD];
+  const int pre_wp = p.win + 2;                                  // padded row length (the fold mode tiles the source grid too)
+  const size_t pre_blk = (size_t)(p.hin + 2) * pre_wp * 16;      // bytes of one padded channel block
+  const char* pre_tile = nullptr;                                // chunk 0, piece 0, k-group 0, first halo position of this tile
+  if constexpr (PRE) {
+#pragma unroll
+    for (int k = 0; k < NPD; ++k) {
+      const int U = min(wave + NW * k, NPU - 1), r = U / G::PUNITS, u = U - r * G::PUNITS;
+      const int pos = min(u * 64 + lane, H2_PSZ - 1);            // (the last unit's spare lanes re-fetch the last position)
+      const int py = pos / H2_PW, px = pos - py * H2_PW;
+      pvoff[k] = (py * pre_wp + px) * 16;
+      pldso[k] = __builtin_amdgcn_readfirstlane((r * H2_PSTR + u * 64) * 16);
+      const size_t go = (size_t)(r >> 1) * p.pre_piece_stride + (size_t)(r & 1) * pre_blk;
+      pgoff[k] = ((size_t)__builtin_amdgcn_readfirstlane((unsigned)(go >> 32)) << 32) |
+                 (size_t)__builtin_amdgcn_readfirstlane((unsigned)go);
+    }
+    // (padded coordinates: halo position (py, px) of the tile at (oy0, ox0) is padded pixel (oy0 + py, ox0 + px))
+    pre_tile = static_cast<const char*>(p.pre) +
+               ((size_t)n * (p.cin / 8) + 2 * (size_t)qb) * pre_blk + ((size_t)oy0 * pre_wp + ox0) * 16;
+  }
+  auto dma_patch = [&](int k, const char* pq, unsigned char* buf) {  // pq: pre_tile + chunk * 2 * pre_blk (uniform)
+    const unsigned lds_addr =
+        (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)(buf + H2_WHALFS * 2 + pldso[k]);
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1\n" ::"v"(pvoff[k]), "s"(sgpr_ptr(pq + pgoff[k])),
                  "s"(__builtin_amdgcn_readfirstlane(lds_addr))
                  : "memory");
   };
@@ -691,8 +749,9 @@ __global__ __launch_bounds__(64 * NW, OCC * NW / 4) void conv_h2_kernel(ConvH2P 
   }
 
   // zero padding: halo positions outside the image are zeroed once in both buffers and never written again
+  // (PRE: the operand image carries its own zero border)
 #pragma unroll
-  for (int i = 0; i < H2_NU; ++i) {
+  for (int i = 0; i < (PRE ? 0 : H2_NU); ++i) {
     if (zoff[i] >= 0) {
       half8 z;
 #pragma unroll
@@ -702,8 +761,8 @@ __global__ __launch_bounds__(64 * NW, OCC * NW / 4) void conv_h2_kernel(ConvH2P 
       *reinterpret_cast<half8*>(b0 + zoff[i]) = z;
       *reinterpret_cast<half8*>(b1 + zoff[i]) = z;
       if constexpr (NP == 2) {
-        *reinterpret_cast<half8*>(b0 + zoff[i] + 2 * H2_PSZ * 8) = z;
-        *reinterpret_cast<half8*>(b1 + zoff[i] + 2 * H2_PSZ * 8) = z;
+        *reinterpret_cast<half8*>(b0 + zoff[i] + 2 * H2_PSTR * 8) = z;
+        *reinterpret_cast<half8*>(b1 + zoff[i] + 2 * H2_PSTR * 8) = z;
       }
     }
   }
@@ -717,7 +776,15 @@ __global__ __launch_bounds__(64 * NW, OCC * NW / 4) void conv_h2_kernel(ConvH2P 
 #else
 #define DSG_PT(i)
 #endif
-  {
+  if constexpr (PRE) {  // chunk 0: weights and patch by DMA, nothing else
+#pragma unroll
+    for (int k = 0; k < G::NDMA; ++k) dma_weights(k, wtile, buf0);
+#pragma unroll
+    for (int k = 0; k < NPD; ++k) dma_patch(k, pre_tile, buf0);
+    DSG_PT(1);
+    DSG_PT(2);
+    DSG_PT(3);
+  } else {
     // Issue order: weight DMAs, chunk 0's patch (into a scratch set), chunk 1's patch (into xr, where the K loop
     // expects it).  The tile waits only for the DMAs and chunk 0 -- vmcnt retires in order, so a counted wait with
     // chunk 1's loads still outstanding covers exactly those -- and chunk 1 lands under chunk 0's MFMAs.
@@ -756,7 +823,7 @@ __global__ __launch_bounds__(64 * NW, OCC * NW / 4) void conv_h2_kernel(ConvH2P 
   }
   // (the DMAs were issued before every patch load: once chunk 0's values have been used they have landed; 8 * NU
   // loads of chunk 1 may still be in flight)
-  if (nq > 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((S16 ? 1 : (SB ? 2 : 8)) * H2_NU) : "memory");
+  if (nq > 1 && !PRE) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((S16 ? 1 : (SB ? 2 : 8)) * H2_NU) : "memory");
   else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
 
@@ -771,8 +838,9 @@ __global__ __launch_bounds__(64 * NW, OCC * NW / 4) void conv_h2_kernel(ConvH2P 
     constexpr bool STAGE = decltype(stage_tag)::value, LOAD = decltype(load_tag)::value;
     unsigned char* cur = (q & 1) ? buf1 : buf0;
     unsigned char* nxt = (q & 1) ? buf0 : buf1;
-    const char* spn = LOAD ? src_of(q + 2) : nullptr;
+    const char* spn = (LOAD && !PRE) ? src_of(q + 2) : nullptr;
     const char* wqn = wtile + (size_t)(q + 1) * chunkb;  // the staged chunk's weights
+    const char* pqn = PRE ? pre_tile + (size_t)(q + 1) * 2 * pre_blk : nullptr;  // ... and its pre-staged patch
     const _Float16* wl = reinterpret_cast<const _Float16*>(WS ? buf0 : cur);
     const _Float16* xl = reinterpret_cast<const _Float16*>(cur) + H2_WHALFS;
     // Operand fragments are fetched one tap ahead into the other half of fa/fb: the reads of tap t+1 are issued
@@ -794,7 +862,7 @@ __global__ __launch_bounds__(64 * NW, OCC * NW / 4) void conv_h2_kernel(ConvH2P 
 #pragma unroll
         for (int pc = 0; pc < NP; ++pc)
           fb[par][nt][pc] = *reinterpret_cast<const half8*>(
-              xl + ((pc * 2 + half) * H2_PSZ + (wave * NT + nt + dy) * H2_PW + l31 + dx) * 8);
+              xl + ((pc * 2 + half) * H2_PSTR + (wave * NT + nt + dy) * H2_PW + l31 + dx) * 8);
     };
     load_frags(0, 0);
 #pragma unroll
@@ -806,9 +874,21 @@ __global__ __launch_bounds__(64 * NW, OCC * NW / 4) void conv_h2_kernel(ConvH2P 
 #endif
       // next tap's scale/shift entries (BEFORE the fragments in program order: LDS returns in order, so a counted wait
       // covers the entries alone); the clear last tap fetches tap 0's entries of the next chunk
-      if (STAGE && tap + 1 < TAPS - 1) load_ss(tap + 1, q + 1);
-      if (LOAD && tap == TAPS - 1) load_ss(0, q + 2);
+      if (!PRE && STAGE && tap + 1 < TAPS - 1) load_ss(tap + 1, q + 1);
+      if (!PRE && LOAD && tap == TAPS - 1) load_ss(0, q + 2);
       if (tap + 1 < TAPS) load_frags(tap + 1, (tap + 1) & 1);
+      if constexpr (PRE) {
+        // the staged chunk's DMAs -- patch units first, then the weight units -- dealt out over taps 0..TAPS-2 (all of the
+        // patch units on the first tap measured slower: -0.6 % against +0.7 % on the step)
+        if (STAGE && tap < TAPS - 1) {
+          constexpr int ND = NPD + G::NDMA, ST = TAPS - 1;
+#pragma unroll
+          for (int d = tap * ND / ST; d < (tap + 1) * ND / ST; ++d) {
+            if (d < NPD) dma_patch(d, pqn, nxt);
+            else dma_weights(d - NPD, wqn, nxt);
+          }
+        }
+      }
       if (KS == 1) {  // one tap: all units and the four weight segments ride on it
 #pragma unroll
         for (int u = 0; u < H2_NU; ++u) {
@@ -819,7 +899,7 @@ __global__ __launch_bounds__(64 * NW, OCC * NW / 4) void conv_h2_kernel(ConvH2P 
       }
       // KS = 3: the chunk's staging steps and weight DMAs are dealt out evenly over taps 0..TAPS-2 (the last tap
       // stays clear so that the newest loads have a tap's worth of MFMAs to land before the closing vmcnt(0))
-      if (KS == 3 && tap < TAPS - 1) {
+      if (KS == 3 && !PRE && tap < TAPS - 1) {
         constexpr int NSTEP = 4 * H2_NU, ST = TAPS > 1 ? TAPS - 1 : 1;
 #pragma unroll
         for (int P = tap * NSTEP / ST; P < (tap + 1) * NSTEP / ST; ++P)
@@ -848,7 +928,7 @@ __global__ __launch_bounds__(64 * NW, OCC * NW / 4) void conv_h2_kernel(ConvH2P 
       // Issue order within the tap: with one wave per SIMD nothing else fills the matrix pipe while this wave
       // issues staging work, so spread that work between the MFMAs (at most ~5 issues hide behind one MFMA)
       // instead of leaving it in one block as the scheduler would.
-      if (KS == 3 && tap < TAPS - 1 && (STAGE || LOAD)) {
+      if (KS == 3 && !PRE && tap < TAPS - 1 && (STAGE || LOAD)) {
 #pragma unroll
         for (int m = 0; m < (NP == 2 ? 3 : 1) * MTN * NT; ++m) {
           __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);  // 1 MFMA
@@ -897,7 +977,8 @@ __global__ __launch_bounds__(64 * NW, OCC * NW / 4) void conv_h2_kernel(ConvH2P 
     }
 #endif
   };
-  if (nq > 1) load_ss(0, 1);  // tap 0 of the first chunk stages chunk 1
+  //
+  if (nq > 1 && !PRE) load_ss(0, 1);  // tap 0 of the first chunk stages chunk 1
 #ifdef DSG_H2_TIMING
   const unsigned long long t_begin = __builtin_readcyclecounter();
   const unsigned long long rt_loop = __builtin_amdgcn_s_memrealtime();

@@ -28,6 +28,10 @@ struct H2Tuning {
   int splitk = 1;       // split-K for grids of at most half the CUs, when the caller gives scratch (key 19)
   int ws2 = 1;          // fp32-equivalent 3x3 convs with cin <= 128: 8-row tiles, one weight slab, two workgroups per CU (key 20)
   int fuse_sc = 1;      // resnet shortcuts fused into conv2's K loop (key 23: A/B against the separate 1x1 kernel)
+  int pre = 1;          // pre-staged operand images for the layers with >= pre_min_ct cout tiles per patch (key 26)
+  int pre_min_ct = 16;  // ... (key 27: the threshold.  Measured, profiles/r03_operand_ablation.txt: at 4 -- every conv of the 256- / 512-channel
+                        // levels -- the convs gain 8.5 % and the prepare passes cost what they gain; at 16 only the folded up-samplers of
+                        // those levels qualify, whose patch is staged by 16-32 workgroups)
   int epoch = 0;        // bumped by every change: plans key their cached workspace sizes on it
 };
 extern H2Tuning g_h2;
@@ -41,12 +45,15 @@ bool conv_h2_rows16(const dsg_conv_args* a, int hout, int wout);
 bool conv_h2_sc_fusable(const dsg_conv_args* a, int hout, int wout);
 // K slices (1 = no split) and statistics splits of the reduce pass for a call that may split (see dsg_conv_args.splitk_ws)
 int conv_h2_splitk_slices(const dsg_conv_args* a, int hout, int wout, int* stat_splits);
+// does the call's kernel read a pre-staged operand image (dsg_conv_args.src_operand)?  `wanted`: also apply the launcher's own
+// pays-off rule (cout tiles per patch); without it the answer is "can", which is what a call that brings an image needs
+bool conv_h2_takes_operand(const dsg_conv_args* a, int hout, int wout, bool wanted);
 int splitk_reduce_launch(const float* part, int slices, const dsg_conv_args* a, int hout, int wout, int stat_splits,
                          hipStream_t st);
 
-template <int GM, int NT, int KS, int ACT, int NW = 4, int OCC = 1, int LAY = 0, int BM = 64, int PREC = 0, int WS = 0, int SC = 0>
+template <int GM, int NT, int KS, int ACT, int NW = 4, int OCC = 1, int LAY = 0, int BM = 64, int PREC = 0, int WS = 0, int SC = 0, int PRE = 0>
 static int h2_launch(dim3 grid, size_t lds, hipStream_t st, const ConvH2P& p) {
-  auto kern = conv_h2_kernel<GM, NT, KS, ACT, NW, OCC, LAY, BM, PREC, WS, SC>;
+  auto kern = conv_h2_kernel<GM, NT, KS, ACT, NW, OCC, LAY, BM, PREC, WS, SC, PRE>;
   static bool raised = false;
   if (!raised) {
     DSG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -106,6 +113,7 @@ int conv_h2_launch_t(const dsg_conv_args* a, int hout, int wout, hipStream_t st)
   // fused shortcut: the 1x1 over the resnet's raw input rides on this conv2 (conv_h2_kernel's SC form)
   const bool sc = a->sc_weight_h2 != nullptr;
   p.sc_src0 = p.sc_src1 = p.sc_wh = nullptr; p.sc_bias = nullptr; p.sc_c0 = p.sc_c1 = p.sc_cin = p.sc_wh_stride = 0;
+  p.pre = nullptr; p.pre_piece_stride = 0;
   if (sc) {
     if (!conv_h2_sc_fusable(a, hout, wout))
       return fail(DSG_ERR_UNSUPPORTED_SHAPE, "dsg_conv2d_fwd: sc_* given for a call that cannot fuse a shortcut (ask dsg_conv2d_fuses_shortcut first)");
@@ -144,6 +152,14 @@ int conv_h2_launch_t(const dsg_conv_args* a, int hout, int wout, hipStream_t st)
   const bool ws2 = PREC == 0 && lay == 3 && g_h2.ws2 && !s2 && !fold && a->ksize == 3 && !a->upsample && p.cin <= 128 &&
                    wout % H2_TW == 0 && slices == 1 &&
                    (wout / H2_TW) * (hout / 8) * p.n * (p.cout_pad / H2_BM) >= 2 * H2_CUS;
+  // pre-staged operand image: the 16-row kernels' PRE form (the image holds what the staging pass would have produced)
+  const bool pre = a->src_operand != nullptr;
+  if (pre) {
+    if (PREC != 0 || !nt4 || ws2 || slices > 1 || !conv_h2_takes_operand(a, hout0, wout0, false))
+      return fail(DSG_ERR_UNSUPPORTED_SHAPE, "dsg_conv2d_fwd: src_operand given for a call whose kernel stages its own patch (ask dsg_conv2d_takes_operand first)");
+    p.pre = a->src_operand;
+    p.pre_piece_stride = (size_t)p.n * p.cin * (p.hin + 2) * (p.win + 2) * 2;
+  }
   int pi = -1;
   if (prof_on()) {
     const double px = (double)p.n * hout * wout * (fold ? 4 : 1);  // output pixels; FLOPs are the reference op's
@@ -179,7 +195,14 @@ int conv_h2_launch_t(const dsg_conv_args* a, int hout, int wout, hipStream_t st)
   const bool bm32_ok = lay == 3 && !fold && !s2 && !k1 && !a->upsample && wout % H2_TW == 0 && (!sc || PREC == 0);
   const bool bm32 = bm32_ok && ((g_h2.bm32 && p.cin <= 128 && (int)grid.x >= g_h2.bm32_min) ||
                                 (g_h2.bm32_small && !nt4 && (int)grid.x <= H2_CUS / 2));
-  if (s2) {
+  if (pre) {
+    if constexpr (PREC == 0) {
+      const size_t lpre = 2 * (size_t)(fold ? H2Geom<4, 3, 4, 4, 64, NP, 1>::BUF_BYTES : H2Geom<4, 3, 4, 9, 64, NP, 1>::BUF_BYTES);
+      if (fold) rc = h2_launch<2, 4, 3, 0, 4, 1, 3, 64, 0, 0, 0, 1>(grid, lpre, st, p);
+      else if (sc) rc = h2_launch<0, 4, 3, 0, 4, 1, 3, 64, 0, 0, 1, 1>(grid, lpre, st, p);
+      else rc = h2_launch<0, 4, 3, 0, 4, 1, 3, 64, 0, 0, 0, 1>(grid, lpre, st, p);
+    }
+  } else if (s2) {
     DSG_H2_LAUNCH_BLK(3, 3, 0, 3);
   } else if (fold) {
     if (lay) DSG_H2_LAUNCH_BLK(2, 3, 0, 3);

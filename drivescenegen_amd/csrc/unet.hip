@@ -397,6 +397,24 @@ struct Runner {
       }
       if (!sc->taken) return y;  // (the caller runs the 1x1 on its own and calls again with its result as the residual)
     }
+    // pre-staged operand image: where the kernel takes one and the patch would be staged by several cout tiles, the
+    // normalise + activate + split work is done once, by a streaming pass, instead of once per cout tile in the K loop
+    T operand;  // (lives until the call has been enqueued: stream order)
+    if (ok() && dt() == DSG_F32 && x.blk && dst_blk) {
+      int32_t yes = 0;
+      rc = dsg_conv2d_takes_operand(&a, &yes);
+      if (ok() && yes) {
+        size_t ob = 0;
+        rc = dsg_conv_operand_bytes(B, x.c + (skip ? skip->c : 0), x.h, x.w, DSG_F32, &ob);
+        if (ok()) {
+          operand = alloc(0, 0, 0, ob / sizeof(float));
+          a.src_operand = operand.p;
+          if (!dry)
+            rc = dsg_conv_operand_prepare(x.p, x.c, skip ? skip->p : nullptr, skip ? skip->c : 0, B, x.h, x.w,
+                                          a.gn_scale_shift, a.silu, a.src_bound, a.src_bound1, operand.p, DSG_F32, st);
+        }
+      }
+    }
     if (want_stats && ok()) {
       int32_t tiles = 0;
       rc = dsg_conv2d_stats_tiles(&a, &tiles);

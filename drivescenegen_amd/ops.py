@@ -136,7 +136,7 @@ def conv2d_fused(src0, weight_r, bias=None, src1=None, ksize=3, stride=1, upsamp
                  silu=False, temb=None, temb_stride=0, residual=None, out=None, direct=False, cout=None,
                  pool2=False, wstride=None, weight_h2=None, want_stats=False, stats_buf=None, weight_h2_col=0, weight_h2_fold=None,
                  src_blocked=False, dst_blocked=False, weight_h2_s2=None, compute_dtype=0, weight_h2_stride=0,
-                 src_bound=None, src_bound1=None, splitk=False, shortcut=None):
+                 src_bound=None, src_bound1=None, splitk=False, shortcut=None, operand=None):
     """dsg_conv2d_fwd: see include/dsg.h.  `weight_r` is in engine layout; `temb` is a [N, temb_stride] view
     whose first `cout` columns (from its data pointer) are added per (n, cout).
     want_stats: also return the per-tile GroupNorm statistics [N][cout][tiles][2] (fp64) of the result, or None
@@ -146,7 +146,10 @@ def conv2d_fused(src0, weight_r, bias=None, src1=None, ksize=3, stride=1, upsamp
     weight_h2* must come from pack_conv_weight(..., dtype=the same); [N, C, H, W] tensors stay fp32.
     shortcut: dict(src0=, src1=None, weight_h2=, bias=None, bound=None, bound1=None) -- the resnet's 1x1 conv_shortcut over
     its raw input, contracted in the same kernel (dsg_conv_args.sc_*); raises when the call cannot fuse it
-    (ask `conv2d_fuses_shortcut` first)."""
+    (ask `conv2d_fuses_shortcut` first).
+    operand: None | "auto" | "query" | a tensor from `conv_operand_prepare` -- the pre-staged operand image of the call's
+    sources (dsg_conv_args.src_operand).  "auto" asks dsg_conv2d_takes_operand and prepares the image when the answer is
+    yes; "query" only returns that answer."""
     lib = _lib.load()
     cdt = dtype_code(compute_dtype)
     blk_dtype = _lib.TORCH_DTYPES[cdt]
@@ -225,6 +228,14 @@ def conv2d_fused(src0, weight_r, bias=None, src1=None, ksize=3, stride=1, upsamp
             stats = stats_buf if stats_buf is not None else torch.empty(
                 (n, cout, tiles.value, 2), dtype=torch.float64, device=src0.device)
             a.stats_out = stats.data_ptr()
+    if isinstance(operand, str):
+        yes = C.c_int32(0)
+        _lib.check(lib.dsg_conv2d_takes_operand(C.byref(a), C.byref(yes)))
+        if operand == "query":
+            return bool(yes.value)
+        operand = conv_operand_prepare(src0, src1, gn_scale_shift, silu, src_bound, src_bound1) if yes.value else None
+    if operand is not None:
+        a.src_operand = operand.data_ptr()
     if shortcut is not None and shortcut.get("query_only"):
         yes = C.c_int32(0)
         _lib.check(lib.dsg_conv2d_fuses_shortcut(C.byref(a), C.byref(yes)))
@@ -233,6 +244,20 @@ def conv2d_fused(src0, weight_r, bias=None, src1=None, ksize=3, stride=1, upsamp
     with torch.cuda.device(src0.device):
         _lib.check(fn(C.byref(a), _st(src0)))
     return (out, stats) if want_stats else out
+
+
+def conv_operand_prepare(src0, src1=None, gn_scale_shift=None, silu=False, src_bound=None, src_bound1=None):
+    """dsg_conv_operand_prepare: the pre-staged operand image [2][N][C/8][H+2][W+2][8] fp16 of cat(src0, src1)
+    (channel-blocked fp32) for `conv2d_fused(..., operand=)`."""
+    n, cb0, hin, win, _ = src0.shape
+    c0 = 8 * cb0
+    c1 = 8 * src1.shape[1] if src1 is not None else 0
+    out = torch.empty((2, n, (c0 + c1) // 8, hin + 2, win + 2, 8), dtype=torch.float16, device=src0.device)
+    with torch.cuda.device(src0.device):
+        _lib.check(_lib.load().dsg_conv_operand_prepare(
+            _lib.ptr(src0), c0, _lib.ptr(src1), c1, n, hin, win, _lib.ptr(gn_scale_shift), int(silu), _lib.ptr(src_bound),
+            _lib.ptr(src_bound1), _lib.ptr(out), 0, _st(src0)))
+    return out
 
 
 def to_blocked(x, dtype=0):

@@ -146,6 +146,15 @@ typedef struct {
   const float* sc_bias;
   const uint32_t* sc_src_bound;
   const uint32_t* sc_src_bound1;
+  /* Pre-staged operand image (optional; fp32-equivalent mode, channel-blocked tensors): the output of
+     dsg_conv_operand_prepare for this call's sources -- GroupNorm affine + SiLU (or the range guard's pre-scale) and the
+     fp16x2 split, which the kernel otherwise performs in its staging pass ONCE PER COUT TILE, done once.  The kernel then
+     DMAs its halo patches from the image straight into LDS and stages nothing.  src0 / src1 / gn_scale_shift / silu /
+     src_bound* still describe the call (and must be what the image was prepared from); results are bit-identical to the
+     same call without the image.  Served for the calls dsg_conv2d_takes_operand accepts (a resnet's conv1 / conv2 and the
+     folded up-sampler conv of the levels with >= 256 output channels at batch sizes that fill the chip); anything else
+     with src_operand set is DSG_ERR_UNSUPPORTED_SHAPE. */
+  const void* src_operand;
 } dsg_conv_args;
 
 int dsg_conv2d_fwd(const dsg_conv_args* a, void* stream);
@@ -164,6 +173,19 @@ int dsg_conv2d_splitk_bytes(const dsg_conv_args* a, size_t* bytes);
  * kernel, 0 when the shortcut has to run as a 1x1 call of its own with its result passed as `residual`.  Host-only; the
  * answer depends on shapes, layouts, dtype and the split-K decision of the call -- not on the batch size as such. */
 int dsg_conv2d_fuses_shortcut(const dsg_conv_args* a, int32_t* yes);
+/* *yes = 1 when a call with these arguments is served by a kernel that reads a pre-staged operand image AND staging once
+ * pays (the patch would otherwise be staged by >= 4 workgroups); the caller then prepares the image and sets src_operand.
+ * Host-only; set splitk_ws before asking.  Reference: the resnet convs of train.py:39-57's network, run at
+ * training_pipeline.py:84 / inside DDPMPipeline.__call__ (training_pipeline.py:26-32, generation.py:14-20). */
+int dsg_conv2d_takes_operand(const dsg_conv_args* a, int32_t* yes);
+/* Operand image of cat(src0, src1) (channel-blocked fp32 [N, c/8, hin, win, 8]) for dsg_conv_args.src_operand:
+ * [piece 2][N][(c0+c1)/8][hin+2][win+2][8] fp16 -- piece 0 = fp16(v), piece 1 = fp16((v - piece 0) * 2^11) of
+ * v = silu(x * scale + shift) (gn_scale_shift [N][c0+c1][2], silu as in the conv call) or, without gn_scale_shift,
+ * v = x * 2^-e (src_bound*: the conv's range guard, NULL = none); a one-pixel zero border stands for the conv's padding. */
+int dsg_conv_operand_bytes(int32_t n, int32_t c, int32_t hin, int32_t win, int32_t dtype, size_t* bytes);
+int dsg_conv_operand_prepare(const float* src0, int32_t c0, const float* src1, int32_t c1, int32_t n, int32_t hin,
+                             int32_t win, const float* gn_scale_shift, int32_t silu, const uint32_t* src_bound,
+                             const uint32_t* src_bound1, void* operand, int32_t dtype, void* stream);
 
 /* OIHW (checkpoint layout) -> engine layout [Cin][k*k][cout_total], written at
  * column offset cout_off (used to fuse to_q/to_k/to_v into one projection). nn.Linear weights
