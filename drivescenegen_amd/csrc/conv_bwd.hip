@@ -377,6 +377,25 @@ constexpr int WH_DSTR = 64 + 8;                     // halfs per (piece, co): 2 
 constexpr int WH_D_HALFS = 2 * 64 * WH_DSTR;        // [piece 2][co 64], double-buffered
 constexpr int WH_LDS_BYTES = (WH_A_HALFS + 2 * WH_D_HALFS) * 2;
 
+// Workgroup -> (pair = (ci block, co block), slab = run of pixels) for the 3x3 weight-gradient kernels, grid = (pairs, slabs).
+// Workgroups go to the 8 XCDs in turn by their linear id, each XCD with an L2 of its own.  With the pair index fast the
+// (ci, co) pairs of one run -- which all stream the SAME rows of x and dY -- were spread over every XCD: each L2 pulled the
+// run through HBM for itself (measured: 779 MB fetched per launch for 134 MB of tensors, profiles/r03_pmc_traffic_train_bf16).
+// Here XCD k takes the runs k, k + 8, ... and walks all pairs of a run on consecutive ids of its own: they run at the same
+// time behind one L2 and the run's rows come from HBM once.  (A bijection of the grid whenever slabs % 8 == 0.)
+__device__ __forceinline__ void wgrad_xcd_ids(int& pair, int& slab) {
+  pair = blockIdx.x;
+  slab = blockIdx.y;
+#ifndef DSG_WGRAD_NO_XCD
+  if ((gridDim.y & 7) == 0) {
+    const unsigned lin = blockIdx.y * gridDim.x + blockIdx.x;
+    const unsigned xcd = lin & 7, j = lin >> 3;
+    slab = (int)(xcd + 8 * (j / gridDim.x));
+    pair = (int)(j % gridDim.x);
+  }
+#endif
+}
+
 // grid = (ci blocks x co blocks, strips x row splits); p.tiles_y = stages (row pairs) per image, p.ci_blocks as usual,
 // p.ntiles = row splits per strip (reused field), strips = n * tiles_x
 __global__ __launch_bounds__(256, 1) void conv_wgrad_h2_kernel(WgradP p) {
@@ -391,8 +410,10 @@ __global__ __launch_bounds__(256, 1) void conv_wgrad_h2_kernel(WgradP p) {
   const int cot = wave & 1;
   const bool first = wave < 2;  // taps 0..4; the other pair 5..8
 
-  const int cib = blockIdx.x % p.ci_blocks;
-  const int cob = blockIdx.x / p.ci_blocks;
+  int pair_id, slab_id;
+  wgrad_xcd_ids(pair_id, slab_id);
+  const int cib = pair_id % p.ci_blocks;
+  const int cob = pair_id / p.ci_blocks;
   const int ci0 = cib * 32, co0 = cob * WG_CO;
   const int plane = p.hin * p.win;
   const int oplane = p.hout * p.wout;
@@ -401,7 +422,7 @@ __global__ __launch_bounds__(256, 1) void conv_wgrad_h2_kernel(WgradP p) {
 
   // this workgroup's run: strip (image n, column tile tx), stages [s0, s1)
   const int nrs = p.ntiles;
-  const int strip = blockIdx.y / nrs, rs = blockIdx.y - strip * nrs;
+  const int strip = slab_id / nrs, rs = slab_id - strip * nrs;
   const int n = strip / p.tiles_x, tx = strip - n * p.tiles_x;
   const int ox0 = tx * 32;
   const int per = (p.tiles_y + nrs - 1) / nrs;
@@ -623,12 +644,12 @@ __global__ __launch_bounds__(256, 1) void conv_wgrad_h2_kernel(WgradP p) {
       t += __shfl_xor(t, 1, 64);
       t += __shfl_xor(t, 2, 64);
       t += __shfl_xor(t, 4, 64);
-      if ((tid & 7) == 0) p.dysum_ws[(size_t)blockIdx.y * p.cout_pad + co0 + ((tid + 256 * u) >> 3)] = t;
+      if ((tid & 7) == 0) p.dysum_ws[(size_t)slab_id * p.cout_pad + co0 + ((tid + 256 * u) >> 3)] = t;
     }
   }
   // epilogue: D[ci][co = l31]; partials to this run's slab [tap][ci][co]
   const int co = co0 + cot * 32 + l31;
-  float* wsb = p.ws + (size_t)blockIdx.y * 9 * p.cin_pad * p.cout_pad;
+  float* wsb = p.ws + (size_t)slab_id * 9 * p.cin_pad * p.cout_pad;
   const int t0 = first ? 0 : 5, ntp = first ? 5 : 4;
 #pragma unroll
   for (int tp = 0; tp < 5; ++tp) {
@@ -1080,14 +1101,16 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad16_kernel(Wgrad16P p) {
   const int half = lane >> 5, l31 = lane & 31;
   const int cit = wave >> 1, cot = wave & 1;
 
-  const int cib = blockIdx.x % p.ci_blocks, cob = blockIdx.x / p.ci_blocks;
+  int pair_id, slab_id;
+  wgrad_xcd_ids(pair_id, slab_id);
+  const int cib = pair_id % p.ci_blocks, cob = pair_id / p.ci_blocks;
   const int ci0 = cib * 64, co0 = cob * 64;
   const int plane = p.h * p.w;
   const bool has_ss = ACT == 2 ? p.ss != nullptr : ACT == 1;
   const bool do_silu = ACT == 2 ? (has_ss && p.silu) : ACT == 1;
 
   // this workgroup's runs: strips [run * spw, (run + 1) * spw) (image n, column tile tx), stages [s0, s1) of each
-  const int run = blockIdx.y / p.nrs, rs = blockIdx.y - run * p.nrs;
+  const int run = slab_id / p.nrs, rs = slab_id - run * p.nrs;
   const int per = (p.stages + p.nrs - 1) / p.nrs;
   const int s0 = rs * per, s1 = min(p.stages, s0 + per);
   int n = 0, ox0 = 0;
@@ -1151,6 +1174,10 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad16_kernel(Wgrad16P p) {
       unsigned o4[4];
 #pragma unroll
       for (int jp = 0; jp < 4; ++jp) {
+#if defined(DSG_W16_ABL_NOSTAGE)
+        o4[jp] = va[u] ? w4[jp] : 0u;
+        continue;
+#endif
         float a = lo16<PREC>(w4[jp]), b = hi16<PREC>(w4[jp]);
         if (has_ss) {
           a = a * sc[2 * jp] + sh[2 * jp];
@@ -1230,20 +1257,49 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad16_kernel(Wgrad16P p) {
     load_rows(s + 3);
     load_dy(s + 2);
     const unsigned short* dl = d_lane + par * W16_D_HALFS;
-#pragma unroll
-    for (int kk = 0; kk < 4; ++kk) {
+    // Fragments are fetched ONE K-STEP AHEAD, each into the registers its MFMA has just read: a tap's operand is in flight
+    // for the nine MFMAs of a k-step instead of being waited for right behind its read (left to itself the compiler issued
+    // most reads directly in front of their MFMA: an LDS round trip per matrix instruction).
+    auto b_frag = [&](int kk) -> half8 {
+#if defined(DSG_W16_ABL_NOREAD)
+      return __builtin_bit_cast(half8, wg_s8{(short)kk, 1, 2, 3, 4, 5, 6, 7});
+#endif
       const int orow = kk >> 1, colb = (kk & 1) * 16 + half * 8 + t_px;  // this lane's first pixel of the k-step
       const wg_s4 b0 = tr4(dl + (orow * 32 + colb) * 32), b1 = tr4(dl + (orow * 32 + colb + 4) * 32);
-      const half8 fb = __builtin_bit_cast(half8, wg_s8{b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w});
+      return __builtin_bit_cast(half8, wg_s8{b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w});
+    };
+    auto a_frag = [&](int kk, int tp) -> half8 {
+#if defined(DSG_W16_ABL_NOREAD)
+      return __builtin_bit_cast(half8, wg_s8{(short)kk, (short)tp, 2, 3, 4, 5, 6, 7});
+#endif
+      const int orow = kk >> 1, colb = (kk & 1) * 16 + half * 8 + t_px;
+      const int dy = tp / KS, dx = tp % KS;
+      const int slot = (2 * s + orow + dy) % W16_SLOTS;  // input row 2s - PADK + orow + dy
+      const unsigned short* ap = a_lane + (slot * W16_PW + colb + dx) * 32;
+      const wg_s4 a0 = tr4(ap), a1 = tr4(ap + 4 * 32);
+      return __builtin_bit_cast(half8, wg_s8{a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w});
+    };
+    // the stage's 4 * TAPS (k-step, tap) products in one sequence; operand g + AHEAD is fetched right behind MFMA g, into
+    // the ring slot MFMA g - 1 has just read (the LDS counter is four bits wide: a whole k-step of reads in flight --
+    // 18 -- made every wait a wait for all of them)
+    constexpr int NG = 4 * TAPS, AHEAD = TAPS >= 3 ? 3 : 1, RING = AHEAD + 1;
+    half8 fa[RING], fb[2];
+    fb[0] = b_frag(0);
 #pragma unroll
-      for (int tp = 0; tp < TAPS; ++tp) {
-        const int dy = tp / KS, dx = tp % KS;
-        const int slot = (2 * s + orow + dy) % W16_SLOTS;  // input row 2s - PADK + orow + dy
-        const unsigned short* ap = a_lane + (slot * W16_PW + colb + dx) * 32;
-        const wg_s4 a0 = tr4(ap), a1 = tr4(ap + 4 * 32);
-        const half8 fa = __builtin_bit_cast(half8, wg_s8{a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w});
-        acc[tp] = mma16<PREC>(fa, fb, acc[tp]);
-      }
+    for (int g = 0; g < AHEAD && g < NG; ++g) fa[g % RING] = a_frag(g / TAPS, g % TAPS);
+#pragma unroll
+    for (int g = 0; g < NG; ++g) {
+      const int kk = g / TAPS, tp = g % TAPS;
+#if defined(DSG_W16_ABL_NOMMA)   // (tools/ timing experiments only: wrong results, the loop's time without a component)
+      asm volatile("" ::"v"(fa[g % RING]), "v"(fb[kk & 1]));
+#else
+      acc[tp] = mma16<PREC>(fa[g % RING], fb[kk & 1], acc[tp]);
+#endif
+      if (g + AHEAD < NG) fa[(g + AHEAD) % RING] = a_frag((g + AHEAD) / TAPS, (g + AHEAD) % TAPS);
+      if (tp == (TAPS > 1 ? TAPS - 2 : 0) && kk < 3) fb[(kk + 1) & 1] = b_frag(kk + 1);
+      // pin the order of matrix instructions and LDS reads (everything else -- the staging arithmetic, its loads and LDS
+      // writes -- may still be moved between them): left alone the scheduler sinks each read to its use
+      __builtin_amdgcn_sched_barrier(0x216);
     }
     __syncthreads();
   }
@@ -1267,7 +1323,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad16_kernel(Wgrad16P p) {
   }  // strips of this workgroup
   // epilogue: D[ci rows][co = l31]; partials to this run's slab [tap][ci][co]
   const int co = co0 + cot * 32 + l31;
-  float* wsb = p.ws + (size_t)blockIdx.y * TAPS * p.cin * p.cout;
+  float* wsb = p.ws + (size_t)slab_id * TAPS * p.cin * p.cout;
 #pragma unroll
   for (int tp = 0; tp < TAPS; ++tp)
 #pragma unroll
