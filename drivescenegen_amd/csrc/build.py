@@ -18,7 +18,10 @@ SOURCES = ["common.hip", "conv.hip", "groupnorm.hip", "attention.hip", "temb.hip
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fvisibility=hidden", "-Wall", "-Wno-unused-function"]
 # scheduler.hip must round every fp32 operation individually (bit parity with the reference's torch-CPU
 # expressions); the in-source pragma alone does not stop the backend from forming v_pk_fma_f32.
-EXTRA_FLAGS = {"scheduler.hip": ["-ffp-contract=off"]}
+# the 16-bit conv instantiations: no SLP vectorisation -- packed fp32 VALU (v_pk_fma / v_pk_mul / v_pk_add_f32) beside MFMAs is an
+# anti-lever on this part (MI355X_MICROARCH.md); measured on one box: bf16 forward 22.62 -> 22.44 ms, bf16 training step
+# 58.1 -> 57.3 ms; the fp32-equivalent instantiations do not change (15.56 / 15.58 ms)
+EXTRA_FLAGS = {"scheduler.hip": ["-ffp-contract=off"], "conv_h2_bf16.hip": ["-fno-slp-vectorize"], "conv_h2_f16.hip": ["-fno-slp-vectorize"]}
 LIB = os.path.join(ROOT, "lib", "libdsg.so")
 
 
