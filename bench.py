@@ -453,9 +453,9 @@ def main():
             # fp32-equivalent MAC -> the ceiling for ALGORITHMIC (fp32-equivalent) FLOPs is the dense f16 peak / 3
             dom = prof["conv3x3_s1_mfma_f16x2split"]
             peak = PEAK_F16_TFLOPS / 3.0
-            roofline = dict(bound="mfma", kernel="dsg::conv_h2_kernel<0, 4, 3, 2, 4, 1, 3, 64, 0, 0, 0>", achieved=dom["tflops"], peak=peak,
-                            unit="TFLOP/s", frac=dom["tflops"] / peak, **pmc_traffic("dsg::conv_h2_kernel<0, 4, 3, 2, 4, 1, 3, 64, 0, 0, 0>"),
-                            **pmc_mfma("dsg::conv_h2_kernel<0, 4, 3, 2, 4, 1, 3, 64, 0, 0, 0>"),
+            roofline = dict(bound="mfma", kernel="dsg::conv_h2_kernel<0, 4, 3, 2, 4, 1, 3, 64, 0, 0, 0, 0>", achieved=dom["tflops"], peak=peak,
+                            unit="TFLOP/s", frac=dom["tflops"] / peak, **pmc_traffic("dsg::conv_h2_kernel<0, 4, 3, 2, 4, 1, 3, 64, 0, 0, 0, 0>"),
+                            **pmc_mfma("dsg::conv_h2_kernel<0, 4, 3, 2, 4, 1, 3, 64, 0, 0, 0, 0>"),
                             peak_note="2500 TF/s dense f16 MFMA / 3 products per fp32-equivalent MAC (fp16x2 split); "
                                       "issued MFMA rate = 3 x achieved; the pure-fp32 MFMA peak is 157.3",
                             issued_mfma_tflops=3.0 * dom["tflops"],
@@ -467,15 +467,15 @@ def main():
             ws = prof.get("conv3x3_s1_mfma_f16x2split_two_wg_per_cu")
             if ws:  # the same convs at the 64- / 128-channel levels (cin <= 128): 8-row tiles, two workgroups per CU
                 roofline["second_kernel"] = dict(
-                    kernel="dsg::conv_h2_kernel<0, 2, 3, 2, 4, 2, 3, 64, 0, 1, 0>", achieved=ws["tflops"], frac=ws["tflops"] / peak,
+                    kernel="dsg::conv_h2_kernel<0, 2, 3, 2, 4, 2, 3, 64, 0, 1, 0, 0>", achieved=ws["tflops"], frac=ws["tflops"] / peak,
                     avg_launch_ms=ws["avg_ms"], launches=ws["launches"], alg_flops_per_launch=ws["flops_per_launch"],
                     alg_gbs=ws["alg_gbs"],
                     time_share=ws["total_ms"] * 1e-3 * args.steps / len(range(0, args.steps, PROF_EVERY)) / dt,
-                    **pmc_traffic("dsg::conv_h2_kernel<0, 2, 3, 2, 4, 2, 3, 64, 0, 1, 0>"))
+                    **pmc_traffic("dsg::conv_h2_kernel<0, 2, 3, 2, 4, 2, 3, 64, 0, 1, 0, 0>"))
             # the resnets' conv2 with the 1x1 shortcut contracted in the same kernel (FLOPs / bytes of both convs)
-            for key, cls, kern in (("fused_shortcut_kernel", "conv3x3_plus_fused_shortcut_f16x2split", "dsg::conv_h2_kernel<0, 4, 3, 2, 4, 1, 3, 64, 0, 0, 1>"),
+            for key, cls, kern in (("fused_shortcut_kernel", "conv3x3_plus_fused_shortcut_f16x2split", "dsg::conv_h2_kernel<0, 4, 3, 2, 4, 1, 3, 64, 0, 0, 1, 0>"),
                                    ("fused_shortcut_two_wg_kernel", "conv3x3_plus_fused_shortcut_f16x2split_two_wg_per_cu",
-                                    "dsg::conv_h2_kernel<0, 2, 3, 2, 4, 2, 3, 64, 0, 1, 1>")):
+                                    "dsg::conv_h2_kernel<0, 2, 3, 2, 4, 2, 3, 64, 0, 1, 1, 0>")):
                 row = prof.get(cls)
                 if row:
                     roofline[key] = dict(

@@ -934,6 +934,15 @@ __global__ __launch_bounds__(64 * NW, OCC * NW / 4) void conv_h2_kernel(ConvH2P 
           __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);  // 1 MFMA
           // 2 VALU per MFMA (a third of the MFMAs: 5; 128 couts, twice the MFMAs per tap again: 3)
           __builtin_amdgcn_sched_group_barrier(0x002, NP == 2 ? 2 : (BM == 128 ? 3 : 5), 0);
+#ifdef DSG_H2_SPREAD_READS
+          // ... and the next tap's fragment reads dealt out over this tap's MFMAs (left alone the scheduler bunches them
+          // at the tap's end: four waves' 48 KB leave together and the next tap's first MFMAs wait for them in turn)
+          {
+            constexpr int NM = (NP == 2 ? 3 : 1) * MTN * NT, NR = (MTN + NT) * NP;
+            if ((m + 1) * NR / NM > m * NR / NM) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+            if ((m + 1) * NR / NM > m * NR / NM + 1) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+          }
+#endif
         }
       }
 #ifdef DSG_H2_TIMING
