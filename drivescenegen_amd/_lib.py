@@ -53,6 +53,12 @@ class ConvArgs(C.Structure):
     ]
 
 
+class PackJob(C.Structure):
+    """Mirror of ``dsg_pack_job`` (include/dsg.h)."""
+    _fields_ = [("w", C.c_void_p), ("dst", C.c_void_p), ("cout", C.c_int32), ("cin", C.c_int32), ("ksize", C.c_int32),
+                ("kind", C.c_int32), ("dtype", C.c_int32), ("n_total", C.c_int32), ("n_off", C.c_int32), ("n_pad", C.c_int32)]
+
+
 class ConvWgradArgs(C.Structure):
     """Mirror of ``dsg_conv_wgrad_args`` (include/dsg.h)."""
     _fields_ = [
@@ -99,6 +105,8 @@ SIGNATURES = {
     "dsg_conv2d_splitk_bytes": [_vp, C.POINTER(_sz)],
     "dsg_conv_weight_pack": [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp],
     "dsg_conv_weight_pack_bytes": [_i32, _i32, _i32, _i32, _i32, _i32, C.POINTER(_sz)],
+    "dsg_conv_weight_pack_batch_items": [C.POINTER(PackJob), C.POINTER(_i64)],
+    "dsg_conv_weight_pack_batch": [_vp, _vp, _i32, _i64, _vp],
     "dsg_layout_convert_dt": [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp],
     "dsg_gn_channel_stats_blocked_dt": [_vp, _i32, _i32, _i32, _i32, _vp, _i32, _vp],
     "dsg_unscale_check": [_vp, _i64, _f32, _vp, _vp],

@@ -572,21 +572,59 @@ class _Packs:
 
     def __init__(self, st, dt):
         self.st, self.dt, self.cache, self.sig = st, dt, {}, {}
+        # every image / row copy made so far as a job of ops.PackTable: from the second step on, one launch at the start of the
+        # forward refreshes all of them (refresh_all) instead of ~190 small ones on first use
+        self.jobs, self.job_params, self.table = {}, {}, None
+
+    def _sig(self, names):
+        return tuple((self.st.params[n].data_ptr(), self.st.params[n]._version) for n in names)
+
+    def _job(self, key, names, specs):
+        """remember how `key` is refreshed: `specs` = PackTable jobs, `names` = the parameters whose change makes it stale"""
+        if key not in self.jobs:
+            self.table = None
+        self.jobs[key], self.job_params[key] = specs, names
+
+    def refresh_all(self):
+        """One launch for every stale image (dsg_conv_weight_pack_batch) once the set of images is known -- same bits as the
+        one-by-one path, which still serves anything new."""
+        if len(self.jobs) < 16 or os.environ.get("DSG_NO_PACK_BATCH") == "1":
+            return
+        sigs = {key: self._sig(names) for key, names in self.job_params.items()}
+        if all(self.sig.get(key) == sg for key, sg in sigs.items()):
+            return
+        # (a job names its parameter: the optimizer may have moved the parameters into its own slab since the job was recorded)
+        flat = [dict(spec, w=self.st.params[spec["name"]].detach()) for specs in self.jobs.values() for spec in specs]
+        ptrs = tuple((j["w"].data_ptr(), j["dst"].data_ptr()) for j in flat)
+        if self.table is None or self.table.ptrs != ptrs:
+            self.table = ops.PackTable(flat)
+        self.table.run()
+        self.sig.update(sigs)
 
     def get(self, name, kind):
-        p = self.st.params[name]
-        sig = (p.data_ptr(), p._version)
         key = (name, kind)
+        sig = self._sig((name,))
         if self.sig.get(key) != sig:
+            p = self.st.params[name]
             self.cache[key] = ops.pack_conv_weight(p.detach(), kind, self.dt, out=self.cache.get(key))
             self.sig[key] = sig
+            self._job(key, (name,), [dict(name=name, dst=self.cache[key], kind=kind, dtype=self.dt)])
         return self.cache[key]
+
+    def copy_rows(self, key, name, dst):
+        """dst <- the parameter's elements (rows of the fused time_emb_proj matrix), refreshed when it changes"""
+        sig = self._sig((name,))
+        if self.sig.get(key) != sig:
+            p = self.st.params[name].detach()
+            dst.copy_(p.reshape(dst.shape))
+            self.sig[key] = sig
+            self._job(key, (name,), [dict(name=name, dst=dst, kind=-1)])
 
     def qkv(self, prefix, kind):
         """Fused q/k/v projection: forward = three column windows of one [C] x [3C] image; data gradient = the three
         [C -> C] images back to back along K."""
         names = [f"{prefix}.{t}.weight" for t in ("to_q", "to_k", "to_v")]
-        sig = tuple((self.st.params[n].data_ptr(), self.st.params[n]._version) for n in names)
+        sig = self._sig(names)
         key = (prefix, "qkv", kind)
         if self.sig.get(key) != sig:
             ws = [self.st.params[n].detach() for n in names]
@@ -604,6 +642,12 @@ class _Packs:
                     ops.pack_conv_weight(w, ops.PACK_DGRAD, self.dt, out=buf[i * one.numel():(i + 1) * one.numel()])
             self.cache[key] = buf
             self.sig[key] = sig
+            if kind == ops.PACK_FWD:
+                specs = [dict(name=n, dst=buf, kind=kind, dtype=self.dt, n_total=3 * c, n_off=i * c) for i, n in enumerate(names)]
+            else:
+                per = buf.numel() // 3
+                specs = [dict(name=n, dst=buf[i * per:(i + 1) * per], kind=kind, dtype=self.dt) for i, n in enumerate(names)]
+            self._job(key, tuple(names), specs)
         return self.cache[key]
 
 
@@ -619,6 +663,7 @@ def _forward16(model, st: TrainState, tape: _Tape, sample, timesteps, dt):
         raise NotImplementedError("mixed-precision training needs block_out_channels % 8 == 0 (channel-blocked tensors)")
     packs = st.packs16.setdefault(dt, _Packs(st, dt))
     tape.packs, tape.dt = packs, dt
+    packs.refresh_all()
 
     resnets, toffs, proj_total = [], {}, 0
     for pre in _resnet_prefixes(model):
@@ -637,9 +682,9 @@ def _forward16(model, st: TrainState, tape: _Tape, sample, timesteps, dt):
     wp, bp = st.wf["_tproj"], st.wf["_tproj.bias"]
     for pre in resnets:
         o = toffs[pre]
-        w = P[pre + ".time_emb_proj.weight"].detach()
-        wp[o:o + w.shape[0]].copy_(w)
-        bp[o:o + w.shape[0]].copy_(P[pre + ".time_emb_proj.bias"].detach())
+        n = P[pre + ".time_emb_proj.bias"].numel()
+        packs.copy_rows((pre, "tproj.w"), pre + ".time_emb_proj.weight", wp[o:o + n])
+        packs.copy_rows((pre, "tproj.b"), pre + ".time_emb_proj.bias", bp[o:o + n])
     tproj = ops.linear(act, wp, bp)
     dtproj = torch.zeros_like(tproj)
     tape.temb = dict(act=act, emb=emb, z1=z1, z2=z2, wp=wp, dtproj=dtproj, toffs=toffs, resnets=resnets, w2=w2)

@@ -286,17 +286,15 @@ int conv_h2_tuning_epoch() { return g_h2.epoch + conv_in_tuning_epoch(); }
 //     the LOW-resolution dY; input pixel 2m + py receives dY[m] * W[1] (py = 0) or dY[m] * W[2] + dY[m+1] * W[0]
 //     (py = 1), i.e. corner row tr of phase py is the 3x3 row {-, 1} / {2, 0}; the same in x
 // ---------------------------------------------------------------------------------------------------------------
-__global__ void weight_pack_kernel(const float* __restrict__ w, unsigned short* __restrict__ dst, int cout_w, int cin_w,
-                                   int ksize, int kind, int dt, int n_pad, int n_off) {
+// element i of the operand image of one weight (the body of weight_pack_kernel; weight_pack_batch_kernel runs it too)
+__device__ __forceinline__ void weight_pack_elem(const float* __restrict__ w, unsigned short* __restrict__ dst, int cout_w,
+                                                 int cin_w, int ksize, int kind, int dt, int n_pad, int n_off, int64_t i) {
   const int taps_w = ksize * ksize;
-  const bool phased = kind == 1 || kind == 4;
   const int taps = (kind == 1 || kind == 2 || kind == 4) ? 4 : taps_w;
   const int kdim = kind == 2 ? 4 * cin_w : ((kind == 3 || kind == 4) ? cout_w : cin_w);
   const int ndim = (kind == 3 || kind == 4) ? cin_w : cout_w;
   const int nq = kdim / 16, np = dt == 0 ? 2 : 1;
-  const int64_t per_phase = (int64_t)nq * taps * 2 * ndim * 8;
-  const int64_t total = (phased ? 4 : 1) * per_phase;
-  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+  {
     const int j = (int)(i % 8);
     int64_t r = i / 8;
     const int nn = (int)(r % ndim);
@@ -343,17 +341,27 @@ __global__ void weight_pack_kernel(const float* __restrict__ w, unsigned short* 
   }
 }
 
+__global__ void weight_pack_kernel(const float* __restrict__ w, unsigned short* __restrict__ dst, int cout_w, int cin_w,
+                                   int ksize, int kind, int dt, int n_pad, int n_off) {
+  const bool phased = kind == 1 || kind == 4;
+  const int taps = (kind == 1 || kind == 2 || kind == 4) ? 4 : ksize * ksize;
+  const int kdim = kind == 2 ? 4 * cin_w : ((kind == 3 || kind == 4) ? cout_w : cin_w);
+  const int ndim = (kind == 3 || kind == 4) ? cin_w : cout_w;
+  const int64_t total = (phased ? 4 : 1) * (int64_t)(kdim / 16) * taps * 2 * ndim * 8;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x)
+    weight_pack_elem(w, dst, cout_w, cin_w, ksize, kind, dt, n_pad, n_off, i);
+}
+
 // Kinds 0 and 3 of a 3x3 weight, one thread per (k, n) pair: it reads the pair's nine taps -- 36 contiguous bytes; the
 // eight k (kind 0) or eight n (kind 3) neighbours of a wave make 288-byte runs, every fetched line is used whole -- and
 // writes nine (x pieces) 16-bit values, each of them one of 64 consecutive ones of the wave (128-byte stores).  The
 // one-thread-per-output-value kernel above fetched every line nine times, 4 bytes of 36 at a time (weights are re-packed
 // after every optimizer step: 138 launches per training step).
-__global__ void weight_pack3x3_kernel(const float* __restrict__ w, unsigned short* __restrict__ dst, int cout_w, int cin_w,
-                                      int kind, int dt, int n_pad, int n_off) {
-  const int kdim = kind == 3 ? cout_w : cin_w, ndim = kind == 3 ? cin_w : cout_w;
-  const int nq = kdim / 16, np = dt == 0 ? 2 : 1;
-  const int64_t total = (int64_t)nq * 2 * ndim * 8;
-  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+__device__ __forceinline__ void weight_pack3x3_pair(const float* __restrict__ w, unsigned short* __restrict__ dst, int cout_w,
+                                                    int cin_w, int kind, int dt, int n_pad, int n_off, int64_t i) {
+  const int ndim = kind == 3 ? cin_w : cout_w;
+  const int np = dt == 0 ? 2 : 1;
+  {
     const int j = (int)(i % 8);
     int64_t r = i / 8;
     const int nn = (int)(r % ndim);
@@ -378,6 +386,39 @@ __global__ void weight_pack3x3_kernel(const float* __restrict__ w, unsigned shor
         dst[at] = cvt16(x, dt);
       }
     }
+  }
+}
+
+__global__ void weight_pack3x3_kernel(const float* __restrict__ w, unsigned short* __restrict__ dst, int cout_w, int cin_w,
+                                      int kind, int dt, int n_pad, int n_off) {
+  const int kdim = kind == 3 ? cout_w : cin_w, ndim = kind == 3 ? cin_w : cout_w;
+  const int64_t total = (int64_t)(kdim / 16) * 2 * ndim * 8;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x)
+    weight_pack3x3_pair(w, dst, cout_w, cin_w, kind, dt, n_pad, n_off, i);
+}
+
+// One launch for a whole table of weight-refresh jobs (dsg_conv_weight_pack_batch): a training step re-packs every conv
+// weight after the optimizer step -- 140 launches of ~5 us of work each in the mixed-precision tape, plus 44 device copies
+// of the time-embedding projection rows.  Job j owns the work items [first[j], first[j + 1]); a thread finds its job by
+// bisection and runs the body of the kernel that would have served it (same arithmetic, same bits).
+__global__ __launch_bounds__(256) void weight_pack_batch_kernel(const dsg_pack_job* __restrict__ jobs, const int64_t* __restrict__ first,
+                                                                int njobs) {
+  const int64_t i = blockIdx.x * (int64_t)256 + threadIdx.x;
+  if (i >= first[njobs]) return;
+  int lo = 0, hi = njobs;  // first[lo] <= i < first[hi]
+  while (hi - lo > 1) {
+    const int mid = (lo + hi) >> 1;
+    if (first[mid] <= i) lo = mid;
+    else hi = mid;
+  }
+  const dsg_pack_job jb = jobs[lo];
+  const int64_t k = i - first[lo];
+  if (jb.kind < 0) {  // plain copy of fp32 elements
+    static_cast<float*>(jb.dst)[k] = jb.w[k];
+  } else if (jb.ksize == 3 && (jb.kind == 0 || jb.kind == 3)) {
+    weight_pack3x3_pair(jb.w, static_cast<unsigned short*>(jb.dst), jb.cout, jb.cin, jb.kind, jb.dtype, jb.n_pad, jb.n_off, k);
+  } else {
+    weight_pack_elem(jb.w, static_cast<unsigned short*>(jb.dst), jb.cout, jb.cin, jb.ksize, jb.kind, jb.dtype, jb.n_pad, jb.n_off, k);
   }
 }
 
@@ -522,6 +563,34 @@ DSG_API int dsg_conv_weight_pack(const float* w_oihw, void* dst, int32_t cout, i
   const int blocks = (int)std::min<int64_t>(dsg::cdiv64(total, 256), 4096);
   hipLaunchKernelGGL(dsg::weight_pack_kernel, dim3(blocks), dim3(256), 0, static_cast<hipStream_t>(stream), w_oihw,
                      static_cast<unsigned short*>(dst), cout, cin, ksize, kind, dtype, n_pad, n_off);
+  DSG_LAUNCH_CHECK();
+  return DSG_OK;
+}
+
+// work items of one job (threads of weight_pack_batch_kernel): pairs for the 3x3 forward / data-gradient forms, output
+// elements otherwise, fp32 elements for a copy
+DSG_API int dsg_conv_weight_pack_batch_items(const dsg_pack_job* job, int64_t* items) {
+  DSG_CHECK_ARG(job != nullptr && items != nullptr, "dsg_conv_weight_pack_batch_items: NULL pointer");
+  if (job->kind < 0) {
+    DSG_CHECK_ARG(job->cout > 0, "dsg_conv_weight_pack_batch_items: a copy job needs its element count in `cout`");
+    *items = job->cout;
+    return DSG_OK;
+  }
+  int kdim, ndim, taps, phases, n_pad;
+  const int rc = pack_dims(job->cout, job->cin, job->ksize, job->kind, job->dtype, job->n_total, &kdim, &ndim, &taps, &phases, &n_pad);
+  if (rc != DSG_OK) return rc;
+  DSG_CHECK_ARG(job->n_pad == n_pad, "dsg_conv_weight_pack_batch_items: n_pad %d != %d (cout padded to 64 of the packed matrix)", job->n_pad, n_pad);
+  if (job->ksize == 3 && (job->kind == 0 || job->kind == 3)) *items = (int64_t)(kdim / 16) * 2 * ndim * 8;
+  else *items = (int64_t)phases * (kdim / 16) * taps * 2 * ndim * 8;
+  return DSG_OK;
+}
+
+DSG_API int dsg_conv_weight_pack_batch(const dsg_pack_job* jobs_dev, const int64_t* first_dev, int32_t njobs, int64_t total_items,
+                                       void* stream) {
+  DSG_CHECK_ARG(jobs_dev && first_dev && njobs > 0 && total_items > 0, "dsg_conv_weight_pack_batch: bad argument");
+  DSG_CHECK_ARG(total_items <= (int64_t)256 * 0x7FFFFFFF, "dsg_conv_weight_pack_batch: too many work items");
+  hipLaunchKernelGGL(dsg::weight_pack_batch_kernel, dim3((unsigned)dsg::cdiv64(total_items, 256)), dim3(256), 0,
+                     static_cast<hipStream_t>(stream), jobs_dev, first_dev, njobs);
   DSG_LAUNCH_CHECK();
   return DSG_OK;
 }

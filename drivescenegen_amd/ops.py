@@ -68,6 +68,43 @@ def pack_conv_weight(w_oihw: torch.Tensor, kind: int = PACK_FWD, dtype=0, n_tota
     return out
 
 
+class PackTable:
+    """A device-resident table of weight-refresh jobs for dsg_conv_weight_pack_batch: every job is one
+    `pack_conv_weight(w, kind, dtype, n_total, n_off, out=dst)` call -- or, kind < 0, a copy of w's elements into dst --
+    and `run()` refreshes all of them in ONE launch (a training step re-packs every conv weight after optimizer.step()).
+    jobs: list of dict(w=, dst=, kind=, dtype=, n_total=0, n_off=0); the tensors must stay where they are."""
+
+    def __init__(self, jobs):
+        lib = _lib.load()
+        n = len(jobs)
+        arr = (_lib.PackJob * n)()
+        first = [0]
+        for j, job in zip(arr, jobs):
+            w, dst, kind = job["w"], job["dst"], int(job["kind"])
+            j.w, j.dst, j.kind = w.data_ptr(), dst.data_ptr(), kind
+            if kind < 0:
+                j.cout = w.numel()
+            else:
+                j.cout, j.cin = w.shape[0], w.shape[1]
+                j.ksize = w.shape[2] if w.dim() == 4 else 1
+                j.dtype, j.n_total, j.n_off = dtype_code(job.get("dtype", 0)), int(job.get("n_total", 0)), int(job.get("n_off", 0))
+                ndim = j.cin if kind in (PACK_DGRAD, PACK_DGRAD_S2) else j.cout
+                j.n_pad = ((j.n_total or ndim) + 63) // 64 * 64
+            items = C.c_int64()
+            _lib.check(lib.dsg_conv_weight_pack_batch_items(C.byref(j), C.byref(items)))
+            first.append(first[-1] + items.value)
+        dev = jobs[0]["w"].device
+        self.n, self.total = n, first[-1]
+        self.jobs = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(dev)
+        self.first = torch.tensor(first, dtype=torch.int64).to(dev)
+        self.ptrs = tuple((job["w"].data_ptr(), job["dst"].data_ptr()) for job in jobs)
+
+    def run(self):
+        with torch.cuda.device(self.jobs.device):
+            _lib.check(_lib.load().dsg_conv_weight_pack_batch(self.jobs.data_ptr(), self.first.data_ptr(), self.n, self.total,
+                                                              _st(self.jobs)))
+
+
 def relayout_conv_weight_h2(w_oihw: torch.Tensor, out: torch.Tensor = None, cout_total: int = None,
                             cout_off: int = 0) -> torch.Tensor:
     """OIHW 3x3 / 1x1 / Linear (cin % 16 == 0) -> fp16x2-split engine layout [Cin/16][2][k*k][2][cout_pad64][8]."""

@@ -207,6 +207,20 @@ int dsg_conv_weight_pack(const float* w_oihw, void* dst, int32_t cout, int32_t c
                          int32_t dtype, int32_t n_total, int32_t n_off, void* stream);
 int dsg_conv_weight_pack_bytes(int32_t cout, int32_t cin, int32_t ksize, int32_t kind, int32_t dtype, int32_t n_total,
                                size_t* bytes);
+/* The same for a whole table of weights in ONE launch: a training step re-packs every conv weight after the optimizer
+ * step (the reference's loop: training_pipeline.py:84-91 -- optimizer.step() at :89 changes all of them), 140 calls of ~5 us
+ * of work each in the mixed-precision tape.  A job is one dsg_conv_weight_pack call (same fields; n_pad = n_total, or cout
+ * for kinds 0-2 / cin for kinds 3-4, rounded up to 64), or -- kind < 0 -- a plain copy of `cout` fp32 elements w -> dst.
+ * The caller keeps two device arrays: the jobs and first[njobs + 1], the running sum of dsg_conv_weight_pack_batch_items
+ * (host-only helper); total_items = first[njobs].  Same bits as the one-by-one calls. */
+typedef struct {
+  const float* w;
+  void* dst;
+  int32_t cout, cin, ksize, kind, dtype, n_total, n_off, n_pad;
+} dsg_pack_job;
+int dsg_conv_weight_pack_batch_items(const dsg_pack_job* job, int64_t* items);
+int dsg_conv_weight_pack_batch(const dsg_pack_job* jobs_dev, const int64_t* first_dev, int32_t njobs, int64_t total_items,
+                               void* stream);
 /* OIHW 3x3 -> [phase 4][Cin/16][2][2x2 taps][2][cout padded to 64][8] fp16: Upsample2D (nearest x2) + this conv as
  * four 2x2 convs of the low-resolution input, one per output-pixel parity; taps that land on the same source pixel
  * are summed in fp32 before the split. */
