@@ -72,6 +72,7 @@ class ConvWgradArgs(C.Structure):
         ("workspace", C.c_void_p), ("workspace_bytes", C.c_size_t),
         ("compute_dtype", C.c_int32),
         ("dy_sums", C.c_void_p), ("dy_sums_stride", C.c_int32),
+        ("dy_bias_grad", C.c_void_p),
     ]
 
 

@@ -389,7 +389,8 @@ def _backward(model, st: TrainState, tape: _Tape, dout):
                 sstride = cout
             byp = ops.wgrad_h2_supported(x0.shape[1], 0 if (x1 is None or ups_h2) else x1.shape[1], cout, dy.shape[2], dy.shape[3],
                                          k, 1 if ups_h2 else rec["stride"], False if ups_h2 else bool(rec["ups"]))
-            kw = dict(dy_sums=sums, dy_sums_stride=sstride) if byp else {}
+            # (with the sums, the same pass adds their total over the batch to the bias gradient: dy_bias_grad)
+            kw = dict(dy_sums=sums, dy_sums_stride=sstride, bias_grad=st.grad(wname + ".bias")) if byp else {}
             if ups_h2:
                 ops.conv_wgrad(ops.upsample_nearest2x(x0), dy, st.grad(wname + ".weight"), ksize=k, **kw)
             else:
@@ -397,7 +398,7 @@ def _backward(model, st: TrainState, tape: _Tape, dout):
                                upsample=rec["ups"], gn_scale_shift=rec["ss"], silu=rec["silu"], **kw)
             if not byp:
                 ops.channel_sums(dy, out=sums, out_stride=sstride)
-            ops.reduce_rows_add(sums, st.grad(wname + ".bias"), stride=sstride)
+                ops.reduce_rows_add(sums, st.grad(wname + ".bias"), stride=sstride)
             done(wname + ".weight", wname + ".bias")
             if rec["toff"] is not None:
                 _temb_proj_grads(st, tb, wname[:-len(".conv1")], done)
@@ -875,8 +876,9 @@ def _backward16(model, st: TrainState, tape: _Tape, dout):
         out[:, :c].copy_(ss)
         return out
 
-    def wgrad(x0, x1, dy, wname, k, stride, ups, ss, silu, cout=None, dy_coff=0, sums=None, sums_stride=0):
-        """weight gradient; returns True when `sums` (per-(n, cout) sums of dy) was filled as a by-product"""
+    def wgrad(x0, x1, dy, wname, k, stride, ups, ss, silu, cout=None, dy_coff=0, sums=None, sums_stride=0, bias_grad=None):
+        """weight gradient; returns True when `sums` (per-(n, cout) sums of dy) was filled as a by-product -- and, with
+        `bias_grad`, 2 when their sum over the batch was added to it in the same pass"""
         c0, c1 = chans(x0), (chans(x1) if x1 is not None else 0)
         co = cout or chans(dy)
         if (blocked(dy) and (blocked(x0) or x1 is None)
@@ -884,8 +886,8 @@ def _backward16(model, st: TrainState, tape: _Tape, dout):
             # (an fp32 [N, C, H, W] source -- the attention output in front of to_out -- is rounded to the tape's type first)
             xb = x0 if blocked(x0) else ops.to_blocked(x0.contiguous(), dt)
             ops.conv_wgrad(xb, dy, st.grad(wname), src1=x1, ksize=k, gn_scale_shift=ss, silu=silu, cout=co, dy_coff=dy_coff,
-                           dy_sums=sums, dy_sums_stride=sums_stride)
-            return sums is not None
+                           dy_sums=sums, dy_sums_stride=sums_stride, bias_grad=bias_grad if sums is not None else None)
+            return (2 if bias_grad is not None else True) if sums is not None else False
         elif (k == 3 and stride == 2 and not ups and x1 is None and dy_coff == 0 and blocked(x0) and blocked(dy) and ss is None
               and ops.wgrad16_supported(c0, 0, co, x0.shape[2], x0.shape[3], 3)):
             # down-sampler conv: its weight gradient is the stride-1 one against dY with zeros between its pixels
@@ -966,15 +968,17 @@ def _backward16(model, st: TrainState, tape: _Tape, dout):
                 sstride = cout
             if rec["res"] is not None:
                 tape.addg(rec["res"], dy)
+            bg = st.grad(wname + ".bias")
             if rec["ups"]:   # weight gradient from the materialised nearest-x2 input, data gradient at full resolution
                 have = wgrad(ops.upsample_nearest2x(x0), None, dy, wname + ".weight", k, 1, False, None, False,
-                             sums=sums, sums_stride=sstride)
+                             sums=sums, sums_stride=sstride, bias_grad=bg)
             else:
                 have = wgrad(x0, x1, dy, wname + ".weight", k, rec["stride"], False, rec["ss"], rec["silu"],
-                             sums=sums, sums_stride=sstride)
+                             sums=sums, sums_stride=sstride, bias_grad=bg)
             if not have:
                 ops.channel_sums(dy, out=sums, out_stride=sstride)
-            ops.reduce_rows_add(sums, st.grad(wname + ".bias"), stride=sstride)
+            if have != 2:   # (2: the weight-gradient call finished the bias gradient with the sums)
+                ops.reduce_rows_add(sums, bg, stride=sstride)
             done(wname + ".weight", wname + ".bias")
             if rec["toff"] is not None:
                 _temb_proj_grads(st, tb, wname[:-len(".conv1")], done)

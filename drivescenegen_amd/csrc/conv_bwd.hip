@@ -719,8 +719,21 @@ static void wgrad_h2_runs(int cin, int cout, int n, int hout, int wout, int* str
 
 __global__ void wgrad16_dysum_reduce_kernel(const float* __restrict__ part, int slabs_per_image, int cout,
                                             float* __restrict__ out, int out_stride);
+__global__ void wgrad16_dysum_reduce_bias_kernel(const float* __restrict__ part, int slabs_per_image, int cout, int n,
+                                                 float* __restrict__ out, int out_stride, float* __restrict__ bias_grad);
+// the per-run dY sums -> per-(n, cout) sums (and, with bias_grad, their sum over the batch added to it: one launch less)
+static void launch_dysum_reduce(const float* part, int slabs_per_image, int cout, int n, float* out, int out_stride,
+                                float* bias_grad, hipStream_t st) {
+  if (bias_grad)
+    hipLaunchKernelGGL(wgrad16_dysum_reduce_bias_kernel, dim3(cdiv(cout, 32)), dim3(256), 0, st, part, slabs_per_image, cout, n, out,
+                       out_stride, bias_grad);
+  else
+    hipLaunchKernelGGL(wgrad16_dysum_reduce_kernel, dim3(cdiv(cout, 256), n), dim3(256), 0, st, part, slabs_per_image, cout, out,
+                       out_stride);
+}
 
-static int launch_wgrad_h2(WgradP p, size_t ws_bytes, hipStream_t st, float* dy_sums = nullptr, int dy_sums_stride = 0) {
+static int launch_wgrad_h2(WgradP p, size_t ws_bytes, hipStream_t st, float* dy_sums = nullptr, int dy_sums_stride = 0,
+                           float* dy_bias_grad = nullptr) {
   p.ci_blocks = p.cin / 32;
   const int co_blocks = p.cout / WG_CO;
   const int pairs = p.ci_blocks * co_blocks;
@@ -751,8 +764,7 @@ static int launch_wgrad_h2(WgradP p, size_t ws_bytes, hipStream_t st, float* dy_
   launch_wgrad_reduce(p.ws, nslab, 9, p.cin, p.cout, p.cin_pad, p.cout_pad, p.dw, st);
   if (dy_sums) {  // run index = (image, column tile, row split): an image's runs are consecutive
     DSG_LAUNCH_CHECK();
-    hipLaunchKernelGGL(wgrad16_dysum_reduce_kernel, dim3(cdiv(p.cout, 256), p.n), dim3(256), 0, st, p.dysum_ws, p.tiles_x * rsplit,
-                       p.cout, dy_sums, dy_sums_stride ? dy_sums_stride : p.cout);
+    launch_dysum_reduce(p.dysum_ws, p.tiles_x * rsplit, p.cout, p.n, dy_sums, dy_sums_stride ? dy_sums_stride : p.cout, dy_bias_grad, st);
   }
   prof_end(pi, st);
   DSG_LAUNCH_CHECK();
@@ -1343,6 +1355,32 @@ __global__ void wgrad16_dysum_reduce_kernel(const float* __restrict__ part, int 
   out[(size_t)n * out_stride + co] = t;
 }
 
+// the same, and bias_grad[co] += sum over n of out[n][co] (what dsg_reduce_rows_add did in a launch of its own after every
+// conv: 66 per training step).  A block = 32 channels x 8 image groups; fp64 across the batch, fixed order.
+__global__ __launch_bounds__(256) void wgrad16_dysum_reduce_bias_kernel(const float* __restrict__ part, int slabs_per_image, int cout,
+                                                                        int n, float* __restrict__ out, int out_stride,
+                                                                        float* __restrict__ bias_grad) {
+  __shared__ double red[8][32];
+  const int cl = threadIdx.x & 31, g = threadIdx.x >> 5, co = blockIdx.x * 32 + cl;
+  double acc = 0.0;
+  if (co < cout) {
+    for (int ni = g; ni < n; ni += 8) {
+      float t = 0.f;
+      for (int k = 0; k < slabs_per_image; ++k) t += part[((size_t)ni * slabs_per_image + k) * cout + co];
+      out[(size_t)ni * out_stride + co] = t;
+      acc += (double)t;
+    }
+  }
+  red[g][cl] = acc;
+  __syncthreads();
+  if (g == 0 && co < cout) {
+    double t = 0.0;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) t += red[k][cl];
+    bias_grad[co] += (float)t;
+  }
+}
+
 static void wgrad16_runs(int cin, int cout, int n, int hout, int wout, int* strips, int* rsplit, int* spw = nullptr) {
   const int pairs = (cin / 64) * (cout / 64);
   *strips = n * (wout / 32);
@@ -1422,8 +1460,8 @@ static int launch_wgrad16(const dsg_conv_wgrad_args* a, int hout, int wout, hipS
   launch_wgrad_reduce(p.ws, nslab, taps, p.cin, p.cout, p.cin, p.cout, a->dw, st);
   if (a->dy_sums) {
     DSG_LAUNCH_CHECK();
-    hipLaunchKernelGGL(wgrad16_dysum_reduce_kernel, dim3(cdiv(p.cout, 256), p.n), dim3(256), 0, st, p.dysum_ws,
-                       p.tiles_x * rsplit, p.cout, a->dy_sums, a->dy_sums_stride ? a->dy_sums_stride : p.cout);
+    launch_dysum_reduce(p.dysum_ws, p.tiles_x * rsplit, p.cout, p.n, a->dy_sums, a->dy_sums_stride ? a->dy_sums_stride : p.cout,
+                        a->dy_bias_grad, st);
   }
   prof_end(pi, st);
   DSG_LAUNCH_CHECK();
@@ -1469,6 +1507,7 @@ DSG_API int dsg_conv2d_wgrad(const dsg_conv_wgrad_args* a, void* stream) {
                 "dsg_conv2d_wgrad: dy channel window out of range");
   hipStream_t st = static_cast<hipStream_t>(stream);
   DSG_CHECK_ARG(a->compute_dtype >= DSG_F32 && a->compute_dtype <= DSG_F16, "dsg_conv2d_wgrad: bad compute_dtype %d", a->compute_dtype);
+  DSG_CHECK_ARG(a->dy_bias_grad == nullptr || a->dy_sums != nullptr, "dsg_conv2d_wgrad: dy_bias_grad rides on dy_sums (give both)");
 
   if (a->compute_dtype != DSG_F32) {  // mixed-precision tape: channel-blocked 16-bit x and dY
     DSG_CHECK_SHAPE(wgrad16_ok(a, a->hin, a->win) && !a->force_direct,
@@ -1495,7 +1534,7 @@ DSG_API int dsg_conv2d_wgrad(const dsg_conv_wgrad_args* a, void* stream) {
   if (tile_ok) {
     const int k = a->ksize, s = a->stride, u = a->upsample;
     const bool small_ci = p.cin <= 32;
-    if (wgrad_h2_eligible(p, k, s, u)) return launch_wgrad_h2(p, a->workspace_bytes, st, a->dy_sums, a->dy_sums_stride);
+    if (wgrad_h2_eligible(p, k, s, u)) return launch_wgrad_h2(p, a->workspace_bytes, st, a->dy_sums, a->dy_sums_stride, a->dy_bias_grad);
     DSG_CHECK_ARG(a->dy_sums == nullptr,
                   "dsg_conv2d_wgrad: dy_sums is a by-product of the 16-bit kernel and of the fp32 split 3x3 kernel (stride 1, "
                   "cin %% 32 == 0, cout %% 64 == 0, wout %% 32 == 0, hout %% 2 == 0) only");

@@ -95,20 +95,27 @@ __global__ __launch_bounds__(256) void gn_bwd_stats_kernel(const float* __restri
 
 // one thread per (n, c): coef[n][c] = (rstd*gamma, rstd*g1/M, rstd*g2/M); thread n == 0 of each c also folds
 // dgamma[c] += sum_n s2, dbeta[c] += sum_n s1
+// (splits > 1: s12 holds [N][C][splits][2] partial sums, added here in split order -- what a pass of its own used to do, 46
+//  launches per training step)
 __global__ void gn_bwd_finalize_kernel(const double* __restrict__ s12, const float* __restrict__ gamma,
                                        const float* __restrict__ mr, int n, int c, int groups, int hw,
                                        float* __restrict__ coef, float* __restrict__ dgamma,
-                                       float* __restrict__ dbeta) {
+                                       float* __restrict__ dbeta, int splits) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n * c) return;
   const int ni = i / c, ci = i - ni * c;
   const int cpg = c / groups;
   const int g0 = (ci / cpg) * cpg;
+  auto sum_of = [&](size_t nc, int which) -> double {
+    double t = 0.0;
+    for (int k = 0; k < splits; ++k) t += s12[(nc * splits + k) * 2 + which];
+    return t;
+  };
   double g1 = 0.0, g2 = 0.0;
   for (int k = 0; k < cpg; ++k) {
-    const double* p = s12 + ((size_t)ni * c + g0 + k) * 2;
-    g1 += (double)gamma[g0 + k] * p[0];
-    g2 += (double)gamma[g0 + k] * p[1];
+    const size_t nc = (size_t)ni * c + g0 + k;
+    g1 += (double)gamma[g0 + k] * sum_of(nc, 0);
+    g2 += (double)gamma[g0 + k] * sum_of(nc, 1);
   }
   const double m = (double)cpg * (double)hw;
   const float rstd = mr[2 * (size_t)i + 1];
@@ -118,8 +125,8 @@ __global__ void gn_bwd_finalize_kernel(const double* __restrict__ s12, const flo
   if (ni == 0) {
     double dg = 0.0, db = 0.0;
     for (int k = 0; k < n; ++k) {
-      db += s12[((size_t)k * c + ci) * 2];
-      dg += s12[((size_t)k * c + ci) * 2 + 1];
+      db += sum_of((size_t)k * c + ci, 0);
+      dg += sum_of((size_t)k * c + ci, 1);
     }
     dgamma[ci] += (float)dg;
     dbeta[ci] += (float)db;
@@ -359,7 +366,7 @@ DSG_API int dsg_gn_bwd(const float* src0, int32_t c0, const float* src1, int32_t
                      mean_rstd, silu, hw, ws_s12);
   DSG_LAUNCH_CHECK();
   hipLaunchKernelGGL(dsg::gn_bwd_finalize_kernel, dim3(cdiv(n * c, 256)), dim3(256), 0, st, ws_s12, gamma, mean_rstd, n,
-                     c, groups, hw, ws_coef, dgamma, dbeta);
+                     c, groups, hw, ws_coef, dgamma, dbeta, 1);
   DSG_LAUNCH_CHECK();
   if ((hw & 3) == 0)
     hipLaunchKernelGGL(dsg::gn_bwd_apply_kernel<4>, dim3(cdiv(hw, 1024), c, n), dim3(256), 0, st, src0, c0, src1, c1, dy,
@@ -696,11 +703,16 @@ DSG_API int dsg_gn_bwd_blocked(const void* src0, int32_t c0, const void* src1, i
     hipLaunchKernelGGL(gn_bwd_stats_blk_kernel<2>, dim3(c / 8, n, splits), dim3(256), 0, st, src0, c0, src1, c1, dy, scale_shift,
                        mean_rstd, silu, hw, part);
   DSG_LAUNCH_CHECK();
-  hipLaunchKernelGGL(sum_splits_kernel, dim3((unsigned)cdiv64((int64_t)n * c * 2, 256)), dim3(256), 0, st, part,
-                     (int64_t)n * c * 2, splits, ws_s12);
-  DSG_LAUNCH_CHECK();
-  hipLaunchKernelGGL(gn_bwd_finalize_kernel, dim3(cdiv(n * c, 256)), dim3(256), 0, st, ws_s12, gamma, mean_rstd, n, c, groups,
-                     hw, ws_coef, dgamma, dbeta);
+  if (splits <= 2) {  // (the deep levels: the finalize pass adds the one or two partials itself, in the same order)
+    hipLaunchKernelGGL(gn_bwd_finalize_kernel, dim3(cdiv(n * c, 256)), dim3(256), 0, st, part, gamma, mean_rstd, n, c, groups,
+                       hw, ws_coef, dgamma, dbeta, splits);
+  } else {
+    hipLaunchKernelGGL(sum_splits_kernel, dim3((unsigned)cdiv64((int64_t)n * c * 2, 256)), dim3(256), 0, st, part,
+                       (int64_t)n * c * 2, splits, ws_s12);
+    DSG_LAUNCH_CHECK();
+    hipLaunchKernelGGL(gn_bwd_finalize_kernel, dim3(cdiv(n * c, 256)), dim3(256), 0, st, ws_s12, gamma, mean_rstd, n, c, groups,
+                       hw, ws_coef, dgamma, dbeta, 1);
+  }
   DSG_LAUNCH_CHECK();
   if (dtype == DSG_BF16)
     hipLaunchKernelGGL(gn_bwd_apply_blk_kernel<1>, dim3(cdiv(hw, 1024), c / 8, n), dim3(256), 0, st, src0, c0, src1, c1, dy,

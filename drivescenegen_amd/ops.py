@@ -476,7 +476,7 @@ def wgrad_h2_supported(c0, c1, cout, h, w, ksize=3, stride=1, upsample=False) ->
 
 
 def conv_wgrad(src0, dy, dw, src1=None, ksize=3, stride=1, upsample=False, gn_scale_shift=None, silu=False,
-               direct=False, cout=None, dy_coff=0, dy_sums=None, dy_sums_stride=0):
+               direct=False, cout=None, dy_coff=0, dy_sums=None, dy_sums_stride=0, bias_grad=None):
     """dw[cout][cin][k][k] += wgrad; the activation is recomputed from (src, gn_scale_shift).  Channel-blocked 16-bit
     src / dy tensors ([N, C/8, H, W, 8] bf16 / fp16, the mixed-precision tape) select the 16-bit kernel."""
     a = _lib.ConvWgradArgs()
@@ -500,6 +500,8 @@ def conv_wgrad(src0, dy, dw, src1=None, ksize=3, stride=1, upsample=False, gn_sc
     a.dw, a.force_direct = _lib.ptr(dw), int(direct)
     if dy_sums is not None:   # per-(n, cout) sums of dy as a by-product (bias / temb gradients): see wgrad*_supported
         a.dy_sums, a.dy_sums_stride = dy_sums.data_ptr(), int(dy_sums_stride or dy_sums.stride(0))
+        if bias_grad is not None:   # ... and their sum over the batch straight into the bias gradient (dy_bias_grad)
+            a.dy_bias_grad = bias_grad.data_ptr()
     lib = _lib.load()
     need = C.c_size_t()
     _lib.check(lib.dsg_conv2d_wgrad_workspace_bytes(C.byref(a), C.byref(need)))

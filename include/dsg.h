@@ -421,6 +421,9 @@ typedef struct {
                                    conv's cout channels), the bias / time-embedding gradient -- a by-product of the dY tiles
                                    the kernel stages anyway (no pass of its own over dY: dsg_channel_sums_blocked) */
   int32_t dy_sums_stride;       /* 0 = cout */
+  float* dy_bias_grad;          /* optional, with dy_sums: dy_bias_grad[co] += sum over n of dy_sums[n][co] -- the conv's bias gradient
+                                   (training_pipeline.py:86 accumulates it in .grad), from the pass that finishes dy_sums instead of a
+                                   dsg_reduce_rows_add launch after every conv */
 } dsg_conv_wgrad_args;
 int dsg_conv2d_wgrad(const dsg_conv_wgrad_args* a, void* stream);
 int dsg_conv2d_wgrad_workspace_bytes(const dsg_conv_wgrad_args* a, size_t* bytes);

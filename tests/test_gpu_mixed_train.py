@@ -61,6 +61,31 @@ def test_wgrad16(case, mode):
     assert rel_l2(got, ref) <= (2e-4 if gn else 2e-5), rel_l2(got, ref)
 
 
+@pytest.mark.parametrize("mode", ["bf16", "fp32"])
+def test_wgrad_finishes_the_bias_gradient_with_the_dy_sums(mode):
+    """dsg_conv_wgrad_args.dy_bias_grad: the pass that turns the per-run sums of dY into per-(n, cout) sums also adds their
+    sum over the batch to the bias gradient (one dsg_reduce_rows_add launch per conv less)."""
+    n, c, cout, h, w = 5, 64, 128, 16, 32
+    dy = _t(3, (n, cout, h, w), 0.3)
+    x = _t(1, (n, c, h, w))
+    if mode == "fp32":
+        xs, dys = x.to(DEV), dy.to(DEV)
+    else:
+        dy, x = _rnd(dy, mode), _rnd(x, mode)
+        xs, dys = ops.to_blocked(x.to(DEV), mode), ops.to_blocked(dy.to(DEV), mode)
+    dw = torch.zeros((cout, c, 3, 3), dtype=torch.float32, device=DEV)
+    sums = torch.zeros((n, cout), dtype=torch.float32, device=DEV)
+    bg = torch.full((cout,), 0.5, dtype=torch.float32, device=DEV)
+    ops.conv_wgrad(xs, dys, dw, ksize=3, dy_sums=sums, bias_grad=bg)
+    ref = dy.double().sum((2, 3))
+    assert torch.allclose(sums.cpu().double(), ref, rtol=1e-5, atol=1e-4)
+    assert torch.allclose(bg.cpu().double(), 0.5 + ref.sum(0), rtol=1e-5, atol=1e-4)
+    # and the weight gradient is what it is without the by-products
+    dw2 = torch.zeros_like(dw)
+    ops.conv_wgrad(xs, dys, dw2, ksize=3)
+    assert torch.equal(dw, dw2)
+
+
 @pytest.mark.parametrize("mode", ["bf16", "fp16"])
 def test_streaming_backward_ops_blocked16(mode):
     n, c0, c1, h, w = 2, 32, 16, 16, 32
