@@ -93,40 +93,54 @@ __global__ __launch_bounds__(256) void gn_bwd_stats_kernel(const float* __restri
   }
 }
 
-// one thread per (n, c): coef[n][c] = (rstd*gamma, rstd*g1/M, rstd*g2/M); thread n == 0 of each c also folds
-// dgamma[c] += sum_n s2, dbeta[c] += sum_n s1
-// (splits > 1: s12 holds [N][C][splits][2] partial sums, added here in split order -- what a pass of its own used to do, 46
-//  launches per training step)
-__global__ void gn_bwd_finalize_kernel(const double* __restrict__ s12, const float* __restrict__ gamma,
-                                       const float* __restrict__ mr, int n, int c, int groups, int hw,
-                                       float* __restrict__ coef, float* __restrict__ dgamma,
-                                       float* __restrict__ dbeta, int splits) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n * c) return;
-  const int ni = i / c, ci = i - ni * c;
+// coef[n][c] = (rstd*gamma, rstd*g1/M, rstd*g2/M) and dgamma[c] += sum_n s2, dbeta[c] += sum_n s1 from the statistics pass's sums
+// s12 = [N][C][splits][2] (split partials are added here, in split order).  A block owns 256 / n channels and ALL their images
+// (thread = (channel, image)): the sums over the batch come out of LDS in image order -- the one-thread-per-(n, c) version had
+// thread (0, c) walk the batch through global memory, 2 n dependent loads that were the kernel's whole 10.7 us, 46 times a step.
+// (n <= 256; larger batches: cpb = 1 and a thread strides over the images)
+__global__ __launch_bounds__(256) void gn_bwd_finalize_kernel(const double* __restrict__ s12, const float* __restrict__ gamma,
+                                                              const float* __restrict__ mr, int n, int c, int groups, int hw,
+                                                              float* __restrict__ coef, float* __restrict__ dgamma,
+                                                              float* __restrict__ dbeta, int splits, int cpb) {
+  __shared__ double sh1[256], sh2[256];
+  const int nn = n < 256 ? n : 256;          // threads per channel
+  const int cl = threadIdx.x / nn, t = threadIdx.x - cl * nn;
+  const int ci = blockIdx.x * cpb + cl;
+  const bool live = cl < cpb && ci < c;
   const int cpg = c / groups;
-  const int g0 = (ci / cpg) * cpg;
   auto sum_of = [&](size_t nc, int which) -> double {
-    double t = 0.0;
-    for (int k = 0; k < splits; ++k) t += s12[(nc * splits + k) * 2 + which];
-    return t;
+    double v = 0.0;
+    for (int k = 0; k < splits; ++k) v += s12[(nc * splits + k) * 2 + which];
+    return v;
   };
-  double g1 = 0.0, g2 = 0.0;
-  for (int k = 0; k < cpg; ++k) {
-    const size_t nc = (size_t)ni * c + g0 + k;
-    g1 += (double)gamma[g0 + k] * sum_of(nc, 0);
-    g2 += (double)gamma[g0 + k] * sum_of(nc, 1);
+  double own1 = 0.0, own2 = 0.0;  // this thread's images' (s1, s2) of its channel, in image order
+  if (live) {
+    const int g0 = (ci / cpg) * cpg;
+    for (int ni = t; ni < n; ni += nn) {
+      double g1 = 0.0, g2 = 0.0;
+      for (int k = 0; k < cpg; ++k) {
+        const size_t nc = (size_t)ni * c + g0 + k;
+        g1 += (double)gamma[g0 + k] * sum_of(nc, 0);
+        g2 += (double)gamma[g0 + k] * sum_of(nc, 1);
+      }
+      const size_t i = (size_t)ni * c + ci;
+      const double m = (double)cpg * (double)hw;
+      const float rstd = mr[2 * i + 1];
+      coef[3 * i] = rstd * gamma[ci];
+      coef[3 * i + 1] = (float)(rstd * g1 / m);
+      coef[3 * i + 2] = (float)(rstd * g2 / m);
+      own1 += sum_of(i, 0);
+      own2 += sum_of(i, 1);
+    }
   }
-  const double m = (double)cpg * (double)hw;
-  const float rstd = mr[2 * (size_t)i + 1];
-  coef[3 * (size_t)i] = rstd * gamma[ci];
-  coef[3 * (size_t)i + 1] = (float)(rstd * g1 / m);
-  coef[3 * (size_t)i + 2] = (float)(rstd * g2 / m);
-  if (ni == 0) {
-    double dg = 0.0, db = 0.0;
-    for (int k = 0; k < n; ++k) {
-      db += sum_of((size_t)k * c + ci, 0);
-      dg += sum_of((size_t)k * c + ci, 1);
+  sh1[threadIdx.x] = own1;
+  sh2[threadIdx.x] = own2;
+  __syncthreads();
+  if (live && t == 0) {
+    double db = 0.0, dg = 0.0;
+    for (int k = 0; k < nn; ++k) {
+      db += sh1[cl * nn + k];
+      dg += sh2[cl * nn + k];
     }
     dgamma[ci] += (float)dg;
     dbeta[ci] += (float)db;
@@ -365,8 +379,11 @@ DSG_API int dsg_gn_bwd(const float* src0, int32_t c0, const float* src1, int32_t
   hipLaunchKernelGGL(dsg::gn_bwd_stats_kernel, dim3(c, n), dim3(256), 0, st, src0, c0, src1, c1, dy, scale_shift,
                      mean_rstd, silu, hw, ws_s12);
   DSG_LAUNCH_CHECK();
-  hipLaunchKernelGGL(dsg::gn_bwd_finalize_kernel, dim3(cdiv(n * c, 256)), dim3(256), 0, st, ws_s12, gamma, mean_rstd, n,
-                     c, groups, hw, ws_coef, dgamma, dbeta, 1);
+  {
+    const int cpb = n < 256 ? 256 / n : 1;
+    hipLaunchKernelGGL(dsg::gn_bwd_finalize_kernel, dim3(cdiv(c, cpb)), dim3(256), 0, st, ws_s12, gamma, mean_rstd, n, c, groups, hw,
+                       ws_coef, dgamma, dbeta, 1, cpb);
+  }
   DSG_LAUNCH_CHECK();
   if ((hw & 3) == 0)
     hipLaunchKernelGGL(dsg::gn_bwd_apply_kernel<4>, dim3(cdiv(hw, 1024), c, n), dim3(256), 0, st, src0, c0, src1, c1, dy,
@@ -703,15 +720,16 @@ DSG_API int dsg_gn_bwd_blocked(const void* src0, int32_t c0, const void* src1, i
     hipLaunchKernelGGL(gn_bwd_stats_blk_kernel<2>, dim3(c / 8, n, splits), dim3(256), 0, st, src0, c0, src1, c1, dy, scale_shift,
                        mean_rstd, silu, hw, part);
   DSG_LAUNCH_CHECK();
+  const int cpb = n < 256 ? 256 / n : 1;
   if (splits <= 2) {  // (the deep levels: the finalize pass adds the one or two partials itself, in the same order)
-    hipLaunchKernelGGL(gn_bwd_finalize_kernel, dim3(cdiv(n * c, 256)), dim3(256), 0, st, part, gamma, mean_rstd, n, c, groups,
-                       hw, ws_coef, dgamma, dbeta, splits);
+    hipLaunchKernelGGL(gn_bwd_finalize_kernel, dim3(cdiv(c, cpb)), dim3(256), 0, st, part, gamma, mean_rstd, n, c, groups, hw, ws_coef,
+                       dgamma, dbeta, splits, cpb);
   } else {
     hipLaunchKernelGGL(sum_splits_kernel, dim3((unsigned)cdiv64((int64_t)n * c * 2, 256)), dim3(256), 0, st, part,
                        (int64_t)n * c * 2, splits, ws_s12);
     DSG_LAUNCH_CHECK();
-    hipLaunchKernelGGL(gn_bwd_finalize_kernel, dim3(cdiv(n * c, 256)), dim3(256), 0, st, ws_s12, gamma, mean_rstd, n, c, groups,
-                       hw, ws_coef, dgamma, dbeta, 1);
+    hipLaunchKernelGGL(gn_bwd_finalize_kernel, dim3(cdiv(c, cpb)), dim3(256), 0, st, ws_s12, gamma, mean_rstd, n, c, groups, hw, ws_coef,
+                       dgamma, dbeta, 1, cpb);
   }
   DSG_LAUNCH_CHECK();
   if (dtype == DSG_BF16)
