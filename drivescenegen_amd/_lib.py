@@ -168,7 +168,9 @@ SIGNATURES = {
     "dsg_time_embed_fwd_train": [_vp, _vp, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "dsg_reduce_rows_add": [_vp, _i32, _i32, _i32, _vp, _vp],
     "dsg_attention_fwd_train": [_vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp],
+    "dsg_attention_fwd_train_dt": [_vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp],
     "dsg_attention_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp],
+    "dsg_attention_bwd_dt": [_vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp],
     "dsg_linear_bwd": [_vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp],
     "dsg_scale": [_vp, _i64, _vp, _f32, _vp, _vp],
     "dsg_silu_fwd": [_vp, _i64, _vp, _vp],

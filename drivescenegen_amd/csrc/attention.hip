@@ -504,6 +504,15 @@ DSG_API int dsg_attention_fwd_train(const float* qkv, float* out, float* lse, in
   return attention_fwd_impl(qkv, out, lse, n, c, heads, l, stream);
 }
 
+// the same in the arithmetic of the mixed-precision tape (DSG_BF16: the forward of dsg_attention_bwd_dt's matrix-core kernels --
+// both round q * scale and k alike, so the backward recomputes exactly the probabilities the forward used)
+DSG_API int dsg_attention_fwd_train_dt(const float* qkv, float* out, float* lse, int32_t n, int32_t c, int32_t heads,
+                                       int32_t l, int32_t dtype, void* stream) {
+  DSG_CHECK_ARG(lse != nullptr, "dsg_attention_fwd_train_dt: lse is NULL");
+  DSG_CHECK_ARG(dtype >= DSG_F32 && dtype <= DSG_F16, "dsg_attention_fwd_train_dt: bad dtype %d", dtype);
+  return attention_fwd_impl(qkv, out, lse, n, c, heads, l, stream, false, dtype == DSG_BF16 ? DSG_BF16 : DSG_F32);
+}
+
 // ---------------------------------------------------------------------------------------------------
 // Backward of the attention core (flash-style recompute from the saved log-sum-exp):
 //   P = exp2(s - lse), dP = dO . V, dS = P * (dP - D), D = rowsum(dO * O)
@@ -717,6 +726,207 @@ __global__ __launch_bounds__(256) void attention_bwd_dkv_kernel(const float* __r
   }
 }
 
+// ---------------------------------------------------------------------------------------------------
+// The same backward on the matrix cores for head_dim 8 in the mixed-precision (bf16) tape: q, k, v, dO, P and dS are rounded
+// once to bf16, one MFMA per product, fp32 scores / accumulators -- torch.autocast's split for the attention core (the fp32 tape
+// keeps the exact VALU kernels above: with fp16-pair operands the split arithmetic would cost what the packed-fp32 loops do).
+// Layouts are the forward kernel's (attention_mfma8_kernel): a 32 x 32 tile of S^T = K^T Q leaves a lane with ONE column and 16
+// rows, and registers 8b .. 8b + 7 are the B operand of a 16-deep step over those rows.
+//   kernel A (dQ): columns = this wave's 32 queries (q, dO, lse, D = rowsum(dO * O) live in registers), rows = keys from LDS:
+//                  S^T = K^T Q, dP^T = V^T dO, dS = P (dP - D), dQ^T += K^T(as [d][key]) dS
+//   kernel B (dK, dV): columns = this wave's 32 keys, rows = queries from LDS (with their lse and D):
+//                  S = Q^T K, dP = dO^T V, dV^T += dO(as [d][query]) P, dK^T += Q(as [d][query]) dS
+// ---------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64 * ATM_NW, 2) void attention_bwd_dq_mfma8_kernel(const float* __restrict__ qkv, const float* __restrict__ o,
+                                                                               const float* __restrict__ dout, const float* __restrict__ lse,
+                                                                               float* __restrict__ dqkv, float* __restrict__ dsum, int c,
+                                                                               int heads, int l, float qscale) {
+  constexpr int PREC = 1;
+  __shared__ __attribute__((aligned(16))) _Float16 Kh[ATM_KT * 8], Vk[ATM_KT * 8];   // [key][d]: A operands of S^T and dP^T
+  __shared__ __attribute__((aligned(16))) _Float16 Kd[8 * ATM_VSTR];                  // [d][key]: A operand of dQ^T += K dS
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, l31 = lane & 31;
+  const int qtiles = (l + 32 * ATM_NW - 1) / (32 * ATM_NW);
+  int bid = blockIdx.x;
+  if ((gridDim.x & 7) == 0) bid = (blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3);  // (a head's tiles behind one L2)
+  const int qt = bid % qtiles, hn = bid / qtiles;
+  const int h = hn % heads, n = hn / heads;
+  const float* qp = qkv + ((size_t)n * 3 * c + h * 8) * l;
+  const float* kp = qp + (size_t)c * l;
+  const float* vp = kp + (size_t)c * l;
+  const size_t obase = ((size_t)n * c + h * 8) * l;
+  const int q0 = (qt * ATM_NW + wave) * 32;
+  const bool active = q0 < l;
+  const int qi = min(q0 + l31, l - 1);
+  att_half4 qh, dh;
+  float dpart = 0.f;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const size_t at = (size_t)(4 * half + i) * l + qi;
+    const float dov = dout[obase + at];
+    qh[i] = att_cvt<PREC>(qp[at] * qscale);
+    dh[i] = att_cvt<PREC>(dov);
+    dpart = fmaf(dov, o[obase + at], dpart);
+  }
+  const float dd = dpart + __shfl_xor(dpart, 32, 64);   // D = rowsum(dO * O) of this lane's query
+  const float ls = lse[((size_t)n * heads + h) * l + qi];
+  f32x16 dq;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) dq[r] = 0.f;
+  const int vrow = min(l31, 7);
+  const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  for (int j0 = 0; j0 < l; j0 += ATM_KT) {
+    const int kt = min(ATM_KT, l - j0);
+    __syncthreads();
+    for (int e = tid; e < 8 * ATM_KT; e += 64 * ATM_NW) {
+      const int i = e / ATM_KT, j = e - i * ATM_KT;  // coalesced along the keys
+      float kv = 0.f, vv = 0.f;
+      if (j < kt) {
+        kv = kp[(size_t)i * l + j0 + j];
+        vv = vp[(size_t)i * l + j0 + j];
+      }
+      const _Float16 kb = att_cvt<PREC>(kv);
+      Kh[j * 8 + i] = kb;
+      Kd[i * ATM_VSTR + j] = kb;
+      Vk[j * 8 + i] = att_cvt<PREC>(vv);
+    }
+    __syncthreads();
+    if (!active) continue;
+    for (int t = 0; t < kt; t += 32) {
+      const att_half4 ka = *reinterpret_cast<const att_half4*>(&Kh[(t + l31) * 8 + 4 * half]);
+      const att_half4 va = *reinterpret_cast<const att_half4*>(&Vk[(t + l31) * 8 + 4 * half]);
+      const f32x16 sc = att_mma8<PREC>(ka, qh, zero);   // S^T: rows = keys, this lane's column = its query
+      const f32x16 dp = att_mma8<PREC>(va, dh, zero);   // dP^T
+#pragma unroll
+      for (int b = 0; b < 2; ++b) {
+        att_half8 dsh;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          const float pv = __builtin_amdgcn_exp2f(sc[8 * b + i] - ls);
+          dsh[i] = att_cvt<PREC>(pv * (dp[8 * b + i] - dd));
+        }
+        const _Float16* kdp = &Kd[vrow * ATM_VSTR + t + 16 * b + 4 * half];
+        const att_half4 k0 = *reinterpret_cast<const att_half4*>(kdp), k1 = *reinterpret_cast<const att_half4*>(kdp + 8);
+        const att_half8 kd = {k0[0], k0[1], k0[2], k0[3], k1[0], k1[1], k1[2], k1[3]};
+        dq = mma16<PREC>(kd, dsh, dq);
+      }
+    }
+  }
+  if (!active || q0 + l31 >= l) return;
+  const float sm = qscale * 0.6931471805599453f;  // qscale = log2(e)/sqrt(D); the softmax scale alone is 1/sqrt(D)
+  float* dqp = dqkv + ((size_t)n * 3 * c + h * 8) * l;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) dqp[(size_t)(r + 4 * half) * l + q0 + l31] = dq[r] * sm;
+  if (half == 0) dsum[((size_t)n * heads + h) * l + q0 + l31] = dd;
+}
+
+__global__ __launch_bounds__(64 * ATM_NW, 2) void attention_bwd_dkv_mfma8_kernel(const float* __restrict__ qkv, const float* __restrict__ dout,
+                                                                                const float* __restrict__ lse, const float* __restrict__ dsum,
+                                                                                float* __restrict__ dqkv, int c, int heads, int l,
+                                                                                float qscale) {
+  constexpr int PREC = 1;
+  __shared__ __attribute__((aligned(16))) _Float16 Qh[ATM_KT * 8], Gh[ATM_KT * 8];            // [query][d]: A operands of S and dP
+  __shared__ __attribute__((aligned(16))) _Float16 Qd[8 * ATM_VSTR], Gd[8 * ATM_VSTR];        // [d][query]: A operands of dK^T, dV^T
+  __shared__ __attribute__((aligned(16))) float Ls[ATM_KT], Ds[ATM_KT];                        // lse and D of the tile's queries
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, l31 = lane & 31;
+  const int ktiles = (l + 32 * ATM_NW - 1) / (32 * ATM_NW);
+  int bid = blockIdx.x;
+  if ((gridDim.x & 7) == 0) bid = (blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3);
+  const int kt_i = bid % ktiles, hn = bid / ktiles;
+  const int h = hn % heads, n = hn / heads;
+  const float* qp = qkv + ((size_t)n * 3 * c + h * 8) * l;
+  const float* kp = qp + (size_t)c * l;
+  const float* vp = kp + (size_t)c * l;
+  const size_t obase = ((size_t)n * c + h * 8) * l;
+  const size_t lbase = ((size_t)n * heads + h) * l;
+  const int k0 = (kt_i * ATM_NW + wave) * 32;
+  const bool active = k0 < l;
+  const int ki = min(k0 + l31, l - 1);
+  att_half4 kh, vh;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    kh[i] = att_cvt<PREC>(kp[(size_t)(4 * half + i) * l + ki]);
+    vh[i] = att_cvt<PREC>(vp[(size_t)(4 * half + i) * l + ki]);
+  }
+  f32x16 dk, dv;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) dk[r] = dv[r] = 0.f;
+  const int vrow = min(l31, 7);
+  const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  for (int j0 = 0; j0 < l; j0 += ATM_KT) {
+    const int qt = min(ATM_KT, l - j0);
+    __syncthreads();
+    for (int e = tid; e < 8 * ATM_KT; e += 64 * ATM_NW) {
+      const int i = e / ATM_KT, j = e - i * ATM_KT;  // coalesced along the queries
+      float qv = 0.f, gv = 0.f;
+      if (j < qt) {
+        qv = qp[(size_t)i * l + j0 + j] * qscale;
+        gv = dout[obase + (size_t)i * l + j0 + j];
+      }
+      const _Float16 qb = att_cvt<PREC>(qv), gb = att_cvt<PREC>(gv);
+      Qh[j * 8 + i] = qb;
+      Qd[i * ATM_VSTR + j] = qb;
+      Gh[j * 8 + i] = gb;
+      Gd[i * ATM_VSTR + j] = gb;
+    }
+    for (int j = tid; j < ATM_KT; j += 64 * ATM_NW) {
+      Ls[j] = j < qt ? lse[lbase + j0 + j] : 0.f;
+      Ds[j] = j < qt ? dsum[lbase + j0 + j] : 0.f;
+    }
+    __syncthreads();
+    if (!active) continue;
+    for (int t = 0; t < qt; t += 32) {
+      const att_half4 qa = *reinterpret_cast<const att_half4*>(&Qh[(t + l31) * 8 + 4 * half]);
+      const att_half4 ga = *reinterpret_cast<const att_half4*>(&Gh[(t + l31) * 8 + 4 * half]);
+      const f32x16 sc = att_mma8<PREC>(qa, kh, zero);   // S: rows = queries, this lane's column = its key
+      const f32x16 dp = att_mma8<PREC>(ga, vh, zero);   // dP
+#pragma unroll
+      for (int b = 0; b < 2; ++b) {
+        // registers 8b .. 8b + 7 = queries t + 16 b + 4 half + {0..3, 8..11}
+        const float4 l0 = *reinterpret_cast<const float4*>(&Ls[t + 16 * b + 4 * half]);
+        const float4 l1 = *reinterpret_cast<const float4*>(&Ls[t + 16 * b + 4 * half + 8]);
+        const float4 d0 = *reinterpret_cast<const float4*>(&Ds[t + 16 * b + 4 * half]);
+        const float4 d1 = *reinterpret_cast<const float4*>(&Ds[t + 16 * b + 4 * half + 8]);
+        const float lsr[8] = {l0.x, l0.y, l0.z, l0.w, l1.x, l1.y, l1.z, l1.w};
+        const float ddr[8] = {d0.x, d0.y, d0.z, d0.w, d1.x, d1.y, d1.z, d1.w};
+        att_half8 ph, dsh;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          const float pv = __builtin_amdgcn_exp2f(sc[8 * b + i] - lsr[i]);
+          ph[i] = att_cvt<PREC>(pv);
+          dsh[i] = att_cvt<PREC>(pv * (dp[8 * b + i] - ddr[i]));
+        }
+        const _Float16* gdp = &Gd[vrow * ATM_VSTR + t + 16 * b + 4 * half];
+        const _Float16* qdp = &Qd[vrow * ATM_VSTR + t + 16 * b + 4 * half];
+        const att_half4 g0 = *reinterpret_cast<const att_half4*>(gdp), g1 = *reinterpret_cast<const att_half4*>(gdp + 8);
+        const att_half4 x0 = *reinterpret_cast<const att_half4*>(qdp), x1 = *reinterpret_cast<const att_half4*>(qdp + 8);
+        const att_half8 gd = {g0[0], g0[1], g0[2], g0[3], g1[0], g1[1], g1[2], g1[3]};
+        const att_half8 qd = {x0[0], x0[1], x0[2], x0[3], x1[0], x1[1], x1[2], x1[3]};
+        dv = mma16<PREC>(gd, ph, dv);
+        dk = mma16<PREC>(qd, dsh, dk);
+      }
+    }
+  }
+  if (!active || k0 + l31 >= l) return;
+  float* dkp = dqkv + ((size_t)n * 3 * c + c + h * 8) * l;
+  float* dvp = dkp + (size_t)c * l;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    dkp[(size_t)(r + 4 * half) * l + k0 + l31] = dk[r] * 0.6931471805599453f;  // (q came pre-scaled by log2(e)/sqrt(D))
+    dvp[(size_t)(r + 4 * half) * l + k0 + l31] = dv[r];
+  }
+}
+
+static int launch_attention_bwd_mfma8(const float* qkv, const float* o, const float* dout, const float* lse, float* dqkv,
+                                      float* dsum, int n, int c, int heads, int l, hipStream_t st) {
+  const float qscale = 1.4426950408889634f / sqrtf(8.0f);
+  const dim3 grid(cdiv(l, 32 * ATM_NW) * heads * n), block(64 * ATM_NW);
+  hipLaunchKernelGGL(attention_bwd_dq_mfma8_kernel, grid, block, 0, st, qkv, o, dout, lse, dqkv, dsum, c, heads, l, qscale);
+  DSG_LAUNCH_CHECK();
+  hipLaunchKernelGGL(attention_bwd_dkv_mfma8_kernel, grid, block, 0, st, qkv, dout, lse, dsum, dqkv, c, heads, l, qscale);
+  DSG_LAUNCH_CHECK();
+  return DSG_OK;
+}
+
 template <int D>
 static int launch_attention_bwd(const float* qkv, const float* o, const float* dout, const float* lse, float* dqkv,
                                 float* dsum, int n, int c, int heads, int l, hipStream_t st) {
@@ -732,6 +942,17 @@ static int launch_attention_bwd(const float* qkv, const float* o, const float* d
 }
 
 }  // namespace dsg
+
+// dtype: DSG_F32 = the exact kernels; DSG_BF16 = the matrix-core kernels (head_dim 8, l % 32 == 0; anything else: the exact ones)
+DSG_API int dsg_attention_bwd_dt(const float* qkv, const float* out, const float* dout, const float* lse, float* dqkv,
+                                 float* dsum_ws, int32_t n, int32_t c, int32_t heads, int32_t l, int32_t dtype, void* stream) {
+  DSG_CHECK_ARG(qkv && out && dout && lse && dqkv && dsum_ws, "dsg_attention_bwd_dt: NULL pointer");
+  DSG_CHECK_ARG(n > 0 && c > 0 && heads > 0 && l > 0 && c % heads == 0, "dsg_attention_bwd_dt: bad dims");
+  DSG_CHECK_ARG(dtype >= DSG_F32 && dtype <= DSG_F16, "dsg_attention_bwd_dt: bad dtype %d", dtype);
+  if (dtype == DSG_BF16 && c / heads == 8 && l % 32 == 0 && dsg::g_att_mfma)
+    return dsg::launch_attention_bwd_mfma8(qkv, out, dout, lse, dqkv, dsum_ws, n, c, heads, l, static_cast<hipStream_t>(stream));
+  return dsg_attention_bwd(qkv, out, dout, lse, dqkv, dsum_ws, n, c, heads, l, stream);
+}
 
 DSG_API int dsg_attention_bwd(const float* qkv, const float* out, const float* dout, const float* lse, float* dqkv,
                               float* dsum_ws, int32_t n, int32_t c, int32_t heads, int32_t l, void* stream) {

@@ -664,26 +664,30 @@ def reduce_rows_add(src, dst, stride=None):
     return dst
 
 
-def attention_train(qkv, heads):
+def attention_train(qkv, heads, dtype=0):
+    """attention core + the log2-domain log-sum-exp the backward recomputes from; dtype "bf16": the mixed-precision tape's
+    arithmetic (operands rounded once to bf16 on the matrix cores)."""
     n, c3, l = qkv.shape
     c = c3 // 3
     out = torch.empty((n, c, l), dtype=torch.float32, device=qkv.device)
     lse = torch.empty((n, heads, l), dtype=torch.float32, device=qkv.device)
     with torch.cuda.device(qkv.device):
-        _lib.check(_lib.load().dsg_attention_fwd_train(_lib.ptr(qkv), _lib.ptr(out), _lib.ptr(lse), n, c, heads, l,
-                                                      _st(qkv)))
+        _lib.check(_lib.load().dsg_attention_fwd_train_dt(_lib.ptr(qkv), _lib.ptr(out), _lib.ptr(lse), n, c, heads, l,
+                                                         dtype_code(dtype), _st(qkv)))
     return out, lse
 
 
-def attention_bwd(qkv, out, dout, lse, heads):
+def attention_bwd(qkv, out, dout, lse, heads, dtype=0):
+    """dsg_attention_bwd_dt: gradient of the attention core w.r.t. the fused [N, 3C, L] q / k / v tensor.  dtype "bf16": the
+    mixed-precision tape's arithmetic (matrix cores for head_dim 8; everything else and dtype 0: the exact kernels)."""
     n, c3, l = qkv.shape
     c = c3 // 3
     dqkv = torch.empty_like(qkv)
     dsum = torch.empty((n, heads, l), dtype=torch.float32, device=qkv.device)
     with torch.cuda.device(qkv.device):
-        _lib.check(_lib.load().dsg_attention_bwd(_lib.ptr(qkv), _lib.ptr(out), _lib.ptr(dout.contiguous()),
-                                                _lib.ptr(lse), _lib.ptr(dqkv), _lib.ptr(dsum), n, c, heads, l,
-                                                _st(qkv)))
+        _lib.check(_lib.load().dsg_attention_bwd_dt(_lib.ptr(qkv), _lib.ptr(out), _lib.ptr(dout.contiguous()),
+                                                   _lib.ptr(lse), _lib.ptr(dqkv), _lib.ptr(dsum), n, c, heads, l,
+                                                   dtype_code(dtype), _st(qkv)))
     return dqkv
 
 

@@ -468,8 +468,15 @@ int dsg_reduce_rows_add(const float* src, int32_t n, int32_t c, int32_t stride, 
  * (dqkv [N][3C][L]; dsum_ws [N][heads][L] scratch). */
 int dsg_attention_fwd_train(const float* qkv, float* out, float* lse, int32_t n, int32_t c, int32_t heads, int32_t l,
                             void* stream);
+int dsg_attention_fwd_train_dt(const float* qkv, float* out, float* lse, int32_t n, int32_t c, int32_t heads, int32_t l,
+                               int32_t dtype /* DSG_BF16: the mixed-precision tape's arithmetic, as dsg_attention_fwd_dt */, void* stream);
 int dsg_attention_bwd(const float* qkv, const float* out, const float* dout, const float* lse, float* dqkv,
                       float* dsum_ws, int32_t n, int32_t c, int32_t heads, int32_t l, void* stream);
+/* The same with the arithmetic of the mixed-precision tape: dtype DSG_BF16 and head_dim 8, l % 32 == 0 run on the matrix cores
+ * (q, k, v, dO, P and dS rounded once to bf16, fp32 scores and accumulators: torch.autocast's split for the attention core of
+ * training_pipeline.py:84-86 under mixed_precision); DSG_F32 / DSG_F16 and every other shape: the exact kernels of dsg_attention_bwd. */
+int dsg_attention_bwd_dt(const float* qkv, const float* out, const float* dout, const float* lse, float* dqkv,
+                         float* dsum_ws, int32_t n, int32_t c, int32_t heads, int32_t l, int32_t dtype, void* stream);
 /* y = x W^T + b backward: dw [out][in] and db [out] are accumulated (skipped when NULL), dx [n][in] written. */
 int dsg_linear_bwd(const float* x, const float* w, const float* dy, int32_t dy_stride, int32_t n, int32_t in_f,
                    int32_t out_f, float* dw, float* db, float* dx, void* stream);
