@@ -1088,12 +1088,30 @@ struct Wgrad16P {
 
 typedef short wg_s4 __attribute__((ext_vector_type(4)));
 constexpr int W16_SLOTS = 6;
-constexpr int W16_D_HALFS = 2 * 64 * 32;                  // [co tile 2][px 64][32 co], double-buffered
-template <int KS>
+// The same matrix instruction with its accumulator pinned to ARCHITECTURAL registers.  A kernel compiled for 512 registers
+// gets the AGPR form of every MFMA builtin: accumulators must sit in the 256 AGPRs, and the 18 tiles (288 registers) of the
+// wide weight-gradient workgroup made hipcc shuttle tiles between the files (880 v_accvgpr moves per 72 MFMAs).  Sixteen
+// tiles stay with the builtin, two go through here.  The hazard recogniser does not see inside: callers keep any other
+// access to `c` at least one k-step (16 passes) away.
+// a copy the register allocator cannot fold away: the source registers are free for the next loads from here on
+__device__ __forceinline__ uint4 pinned_copy(const uint4& v) {
+  uint4 r;
+  asm volatile("v_mov_b32 %0, %4\n\tv_mov_b32 %1, %5\n\tv_mov_b32 %2, %6\n\tv_mov_b32 %3, %7"
+               : "=&v"(r.x), "=&v"(r.y), "=&v"(r.z), "=&v"(r.w)
+               : "v"(v.x), "v"(v.y), "v"(v.z), "v"(v.w));
+  return r;
+}
+template <int PREC>
+__device__ __forceinline__ void mma16_vgpr_acc(const half8& a, const half8& b, wf32x16& c) {
+  if constexpr (PREC == 1) asm("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(c) : "v"(a), "v"(b));
+  else asm("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+v"(c) : "v"(a), "v"(b));
+}
+template <int KS, int COT = 1>
 struct W16Geom {
   static constexpr int PW = 32 + 2 * (KS / 2);                  // patch columns (halo of KS / 2)
   static constexpr int A_HALFS = 2 * W16_SLOTS * PW * 32;       // [ci tile 2][slot][col][32 ch]
-  static constexpr int LDS_BYTES = (A_HALFS + 2 * W16_D_HALFS) * 2;
+  static constexpr int D_HALFS = 2 * COT * 64 * 32;             // [co tile 2 COT][px 64][32 co], double-buffered
+  static constexpr int LDS_BYTES = (A_HALFS + 2 * D_HALFS) * 2 + (COT == 2 ? 256 * 16 : 0);  // (+ a 16-byte sink per thread)
 };
 
 // KS = 3: 3x3, padding 1.  KS = 1: pointwise (shortcuts, attention projections): the map is re-tiled by the host as
@@ -1101,9 +1119,14 @@ struct W16Geom {
 // ACT: 1 = the sources go through GroupNorm affine + SiLU (every resnet conv), 0 = used as they are (shortcuts, samplers),
 // 2 = decided at run time (affine without SiLU: the attention projections) -- compile-time in the two common cases: the
 // run-time flags cost branches in the staging code and registers the kernel does not have
-template <int PREC, int KS, int ACT = 2>
-__global__ __launch_bounds__(256, 2) void conv_wgrad16_kernel(Wgrad16P p) {
+// COT = 2 (cout % 128 == 0): the workgroup covers 64 ci x 128 co and a wave keeps TWO co tiles of its ci tile -- 18
+// accumulator tiles, 512 registers, one workgroup per CU.  An activation fragment then feeds two matrix instructions (11
+// LDS fragments per 18 instead of 10 per 9: at COT = 1 the LDS pipe is as busy as the matrix pipe), the activation
+// arithmetic of the staging is paid once per 128 output channels instead of per 64, and x is re-read cout / 128 times.
+template <int PREC, int KS, int ACT = 2, int COT = 1>
+__global__ __launch_bounds__(256, COT == 2 ? 1 : 2) void conv_wgrad16_kernel(Wgrad16P p) {
   constexpr int W16_PW = W16Geom<KS>::PW, W16_A_HALFS = W16Geom<KS>::A_HALFS, PADK = KS / 2, TAPS = KS * KS;
+  constexpr int W16_D_HALFS = W16Geom<KS, COT>::D_HALFS, COW = 64 * COT, DCB = 8 * COT, DSH = COT == 2 ? 4 : 3;
   extern __shared__ __attribute__((aligned(16))) unsigned char wsm16[];
   unsigned short* Ab = reinterpret_cast<unsigned short*>(wsm16);
   unsigned short* Db = Ab + W16_A_HALFS;
@@ -1111,12 +1134,12 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad16_kernel(Wgrad16P p) {
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int half = lane >> 5, l31 = lane & 31;
-  const int cit = wave >> 1, cot = wave & 1;
+  const int cit = wave >> 1, cot = (wave & 1) * COT;  // (the wave's first co tile)
 
   int pair_id, slab_id;
   wgrad_xcd_ids(pair_id, slab_id);
   const int cib = pair_id % p.ci_blocks, cob = pair_id / p.ci_blocks;
-  const int ci0 = cib * 64, co0 = cob * 64;
+  const int ci0 = cib * 64, co0 = cob * COW;
   const int plane = p.h * p.w;
   const bool has_ss = ACT == 2 ? p.ss != nullptr : ACT == 1;
   const bool do_silu = ACT == 2 ? (has_ss && p.silu) : ACT == 1;
@@ -1130,7 +1153,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad16_kernel(Wgrad16P p) {
   const unsigned short* dsrc = nullptr;
   const bool in0 = ci0 < p.c0;  // the 64-channel ci block sits entirely in one of the two concatenated sources (c0 % 64 == 0)
 
-  // staging items.  A: (row of the pair, column 0..33, channel block 0..7) = 544, three rounds; dY: (pixel 0..63, co block) = 512
+  // staging items.  A: (row of the pair, column 0..33, channel block 0..7) = 544, three rounds; dY: (pixel 0..63, co block) = 512 COT
   const int a_cb = tid & 7;  // the same channel block in every round: its scale / shift live in registers
   float sc[8], sh[8];
   auto begin_strip = [&](int strip) {  // per-strip state: image, column tile, source bases, the image's scale / shift
@@ -1159,86 +1182,160 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad16_kernel(Wgrad16P p) {
     a_row[u] = pc / W16_PW;
     a_col[u] = pc - a_row[u] * W16_PW;
   }
-  uint4 xa[3], xd[2];
+  uint4 xa[3], xd[2 * COT];
   bool va[3];
-  auto load_rows = [&](int k) {  // input rows 2k - PADK, 2k + 1 - PADK of the strip (columns ox0 - PADK ...)
+  auto load_rows_to = [&](int k, uint4 (&dst)[3], bool (&valid)[3]) {  // input rows 2k - PADK, 2k + 1 - PADK of the strip (columns ox0 - PADK ...)
 #pragma unroll
     for (int u = 0; u < 3; ++u) {
       const int y = 2 * k - PADK + a_row[u], x = ox0 - PADK + a_col[u];
-      va[u] = a_use[u] && (unsigned)y < (unsigned)p.h && (unsigned)x < (unsigned)p.w;
-      const size_t off = (size_t)a_cb * 8 * plane + ((size_t)(va[u] ? y : 0) * p.w + (va[u] ? x : 0)) * 8;
-      xa[u] = *reinterpret_cast<const uint4*>(xsrc + off);
+      valid[u] = a_use[u] && (unsigned)y < (unsigned)p.h && (unsigned)x < (unsigned)p.w;
+      const size_t off = (size_t)a_cb * 8 * plane + ((size_t)(valid[u] ? y : 0) * p.w + (valid[u] ? x : 0)) * 8;
+      dst[u] = *reinterpret_cast<const uint4*>(xsrc + off);
     }
   };
-  auto load_dy = [&](int s) {  // output rows 2s, 2s+1 (clamped past the image: never used)
+  auto load_rows = [&](int k) { load_rows_to(k, xa, va); };
+  auto load_dy_to = [&](int s, uint4 (&dst)[2 * COT]) {  // output rows 2s, 2s+1 (clamped past the image: never used)
 #pragma unroll
-    for (int u = 0; u < 2; ++u) {
-      const int id = tid + 256 * u, cb = id & 7, px = id >> 3;
+    for (int u = 0; u < 2 * COT; ++u) {
+      const int id = tid + 256 * u, cb = id & (DCB - 1), px = id >> DSH;
       const int y = min(2 * s + (px >> 5), p.h - 1), x = ox0 + (px & 31);
-      xd[u] = *reinterpret_cast<const uint4*>(dsrc + (size_t)cb * 8 * plane + ((size_t)y * p.w + x) * 8);
+      dst[u] = *reinterpret_cast<const uint4*>(dsrc + (size_t)cb * 8 * plane + ((size_t)y * p.w + x) * 8);
     }
   };
-  auto commit_rows = [&](int k) {  // -> ring slots (2k) % 6, (2k) % 6 + 1
+  auto load_dy = [&](int s) { load_dy_to(s, xd); };
+  // staging of a row pair in pieces (the wide workgroup deals them over the k loop: one wave per SIMD, nobody else's
+  // matrix instructions to hide the arithmetic behind): act_piece = two channels of round u, write_rows = round u's 16 bytes
+  unsigned oa[3][4];
+  uint4 ca[3], cd[2 * COT];  // the pair / dY tile being staged (COT 2: pinned copies, xa / xd already take the next loads)
+  bool cva[3];
+  auto act_piece = [&](int u, int jp) {
+    const unsigned w = jp == 0 ? ca[u].x : jp == 1 ? ca[u].y : jp == 2 ? ca[u].z : ca[u].w;
+#if defined(DSG_W16_ABL_NOSTAGE)
+    oa[u][jp] = cva[u] ? w : 0u;
+    return;
+#endif
+    float a = lo16<PREC>(w), b = hi16<PREC>(w);
+    if (has_ss) {
+      a = a * sc[2 * jp] + sh[2 * jp];
+      b = b * sc[2 * jp + 1] + sh[2 * jp + 1];
+    }
+    if (do_silu) {
+      a = silu_fast_b(a);
+      b = silu_fast_b(b);
+    }
+    oa[u][jp] = cva[u] ? pack2<PREC>(a, b) : 0u;  // zero padding applies to the ACTIVATED map
+  };
+  // the same arithmetic in three phases, each dealt to a later slot (wide workgroup): with one wave per SIMD the chain
+  // unpack -> affine -> exp -> 1 + e -> rcp -> x * r -> pack of ONE piece issues as a string of dependent instructions
+  // (and hazard nops behind the two transcendentals); three pieces in flight give every slot independent work
+  float pa[12], pb[12], ea[12], eb[12];
+  auto piece_p0 = [&](int q) {
+    const int u = q >> 2, jp = q & 3;
+    const unsigned w = jp == 0 ? ca[u].x : jp == 1 ? ca[u].y : jp == 2 ? ca[u].z : ca[u].w;
+#if defined(DSG_W16_ABL_NOSTAGE)
+    oa[u][jp] = cva[u] ? w : 0u;
+    return;
+#endif
+    float a = lo16<PREC>(w), b = hi16<PREC>(w);
+    if (has_ss) {
+      a = a * sc[2 * jp] + sh[2 * jp];
+      b = b * sc[2 * jp + 1] + sh[2 * jp + 1];
+    }
+    pa[q] = a;
+    pb[q] = b;
+    if (do_silu) {
+      ea[q] = __expf(-a);
+      eb[q] = __expf(-b);
+    }
+  };
+  auto piece_p1 = [&](int q) {
+#if defined(DSG_W16_ABL_NOSTAGE)
+    return;
+#endif
+    if (do_silu) {
+      ea[q] = __builtin_amdgcn_rcpf(1.0f + ea[q]);
+      eb[q] = __builtin_amdgcn_rcpf(1.0f + eb[q]);
+    }
+  };
+  auto piece_p2 = [&](int q) {
+#if defined(DSG_W16_ABL_NOSTAGE)
+    return;
+#endif
+    const int u = q >> 2, jp = q & 3;
+    float a = pa[q], b = pb[q];
+    if (do_silu) {
+      a *= ea[q];
+      b *= eb[q];
+    }
+    oa[u][jp] = pack2<PREC>(a, b) & (cva[u] ? ~0u : 0u);  // (an AND, not a select: hipcc turns a select between 0 and the
+                                                          // end of a chain with transcendentals into a branch and sinks the
+                                                          // whole chain -- all three phases -- into it)
+  };
+  auto write_rows = [&](int k, int u) {  // -> ring slots (2k) % 6, (2k) % 6 + 1
+    const int slot = (2 * k) % W16_SLOTS + a_row[u];
+    unsigned short* dst = Ab + (a_cb >> 2) * (W16_SLOTS * W16_PW * 32) + (slot * W16_PW + a_col[u]) * 32 + (a_cb & 3) * 8;
+    if constexpr (COT == 2) {  // no branch (the pieces would sink into it, back into one lump): idle threads write to their sink
+      if (!a_use[u]) dst = Db + 2 * W16_D_HALFS + tid * 8;
+    } else {
+      if (!a_use[u]) return;
+    }
+    *reinterpret_cast<uint4*>(dst) = make_uint4(oa[u][0], oa[u][1], oa[u][2], oa[u][3]);
+  };
+  auto commit_rows = [&](int k) {
 #pragma unroll
     for (int u = 0; u < 3; ++u) {
-      if (!a_use[u]) continue;
-      const unsigned w4[4] = {xa[u].x, xa[u].y, xa[u].z, xa[u].w};
-      unsigned o4[4];
+      ca[u] = xa[u];
+      cva[u] = va[u];
 #pragma unroll
-      for (int jp = 0; jp < 4; ++jp) {
-#if defined(DSG_W16_ABL_NOSTAGE)
-        o4[jp] = va[u] ? w4[jp] : 0u;
-        continue;
-#endif
-        float a = lo16<PREC>(w4[jp]), b = hi16<PREC>(w4[jp]);
-        if (has_ss) {
-          a = a * sc[2 * jp] + sh[2 * jp];
-          b = b * sc[2 * jp + 1] + sh[2 * jp + 1];
-        }
-        if (do_silu) {
-          a = silu_fast_b(a);
-          b = silu_fast_b(b);
-        }
-        o4[jp] = va[u] ? pack2<PREC>(a, b) : 0u;  // zero padding applies to the ACTIVATED map
-      }
-      const int slot = (2 * k) % W16_SLOTS + a_row[u];
-      unsigned short* dst = Ab + (a_cb >> 2) * (W16_SLOTS * W16_PW * 32) + (slot * W16_PW + a_col[u]) * 32 + (a_cb & 3) * 8;
-      *reinterpret_cast<uint4*>(dst) = make_uint4(o4[0], o4[1], o4[2], o4[3]);
+      for (int jp = 0; jp < 4; ++jp) act_piece(u, jp);
+      write_rows(k, u);
     }
   };
   const bool want_dysum = p.dysum_ws != nullptr && cib == 0;  // (one ci block per co block owns the by-product)
-  float dsum[8];  // this thread's channel block (tid & 7) of dY, summed over its pixels of the run
+  float dsum[8];  // this thread's channel block (tid & (DCB - 1)) of dY, summed over its pixels of the run
 #pragma unroll
   for (int j = 0; j < 8; ++j) dsum[j] = 0.f;
-  auto commit_dy = [&](int par, bool count) {
+  auto commit_dy_u = [&](int par, bool count, int u) {
+    const int id = tid + 256 * u, cb = id & (DCB - 1), px = id >> DSH;
+    unsigned short* dst = Db + par * W16_D_HALFS + (cb >> 2) * (64 * 32) + px * 32 + (cb & 3) * 8;
+    *reinterpret_cast<uint4*>(dst) = cd[u];
+    if (want_dysum && count) {
+      const unsigned w4[4] = {cd[u].x, cd[u].y, cd[u].z, cd[u].w};
 #pragma unroll
-    for (int u = 0; u < 2; ++u) {
-      const int id = tid + 256 * u, cb = id & 7, px = id >> 3;
-      unsigned short* dst = Db + par * W16_D_HALFS + (cb >> 2) * (64 * 32) + px * 32 + (cb & 3) * 8;
-      *reinterpret_cast<uint4*>(dst) = xd[u];
-      if (want_dysum && count) {
-        const unsigned w4[4] = {xd[u].x, xd[u].y, xd[u].z, xd[u].w};
-#pragma unroll
-        for (int jp = 0; jp < 4; ++jp) {
-          dsum[2 * jp] += lo16<PREC>(w4[jp]);
-          dsum[2 * jp + 1] += hi16<PREC>(w4[jp]);
-        }
+      for (int jp = 0; jp < 4; ++jp) {
+        dsum[2 * jp] += lo16<PREC>(w4[jp]);
+        dsum[2 * jp + 1] += hi16<PREC>(w4[jp]);
       }
     }
   };
+  auto commit_dy = [&](int par, bool count) {
+#pragma unroll
+    for (int u = 0; u < 2 * COT; ++u) {
+      cd[u] = xd[u];
+      commit_dy_u(par, count, u);
+    }
+  };
 
-  wf32x16 acc[TAPS];
+  wf32x16 acc[COT][TAPS];
 #pragma unroll
-  for (int t = 0; t < TAPS; ++t)
+  for (int ct = 0; ct < COT; ++ct)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+    for (int t = 0; t < TAPS; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[ct][t][r] = 0.f;
+  wf32x16 accv[COT];  // COT 2: tap 0 of both co tiles, in architectural registers (mma16_vgpr_acc)
+#pragma unroll
+  for (int ct = 0; ct < COT; ++ct)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) accv[ct][r] = 0.f;
 
   // transposing-read addressing of this lane: source lane s = lane & 15 -> pixel + (s >> 2), channel quad (s & 3) of the
   // 16-channel group (lane >> 4) & 1 of the wave's 32-channel tile
   const int s16 = lane & 15, g16 = (lane >> 4) & 1;
   const int t_px = s16 >> 2, t_ch = g16 * 16 + (s16 & 3) * 4;
-  const unsigned short* a_lane = Ab + cit * (W16_SLOTS * W16_PW * 32) + t_ch;
-  const unsigned short* d_lane = Db + cot * (64 * 32) + t_ch;
+  // (the lane's pixel offset inside a k-step folded into the bases: what is left per fragment is a compile-time offset)
+  const unsigned short* a_lane = Ab + cit * (W16_SLOTS * W16_PW * 32) + t_ch + (half * 8 + t_px) * 32;
+  const unsigned short* d_lane = Db + cot * (64 * 32) + t_ch + (half * 8 + t_px) * 32;
   auto tr4 = [](const unsigned short* q) -> wg_s4 {
     return __builtin_amdgcn_ds_read_tr16_b64_v4i16(
         (__attribute__((address_space(3))) wg_s4*)(const_cast<unsigned short*>(q)));
@@ -1264,59 +1361,99 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad16_kernel(Wgrad16P p) {
   for (int s = s0; s < s1; ++s) {
     const int par = (s - s0) & 1;
     // stage the next pair / dY tile (other ring slots, other dY buffer), then fetch the ones after them
-    commit_rows(s + 2);
-    commit_dy(par ^ 1, s + 1 < s1);  // (the tile after the run's last one is loaded clamped and never used)
-    load_rows(s + 3);
-    load_dy(s + 2);
+    if constexpr (COT == 1) {
+      commit_rows(s + 2);
+      commit_dy(par ^ 1, s + 1 < s1);  // (the tile after the run's last one is loaded clamped and never used)
+      load_rows(s + 3);
+      load_dy(s + 2);
+    }
     const unsigned short* dl = d_lane + par * W16_D_HALFS;
+    const unsigned short* arow[KS + 1];  // ring rows of input rows 2s - PADK + j: one address per row and stage
+#pragma unroll
+    for (int j = 0; j <= KS; ++j) arow[j] = a_lane + ((2 * s + j) % W16_SLOTS) * (W16_PW * 32);
     // Fragments are fetched ONE K-STEP AHEAD, each into the registers its MFMA has just read: a tap's operand is in flight
     // for the nine MFMAs of a k-step instead of being waited for right behind its read (left to itself the compiler issued
     // most reads directly in front of their MFMA: an LDS round trip per matrix instruction).
-    auto b_frag = [&](int kk) -> half8 {
+    auto b_frag = [&](int kk, int ct) -> half8 {
 #if defined(DSG_W16_ABL_NOREAD)
-      return __builtin_bit_cast(half8, wg_s8{(short)kk, 1, 2, 3, 4, 5, 6, 7});
+      return __builtin_bit_cast(half8, wg_s8{(short)kk, (short)ct, 2, 3, 4, 5, 6, 7});
 #endif
-      const int orow = kk >> 1, colb = (kk & 1) * 16 + half * 8 + t_px;  // this lane's first pixel of the k-step
-      const wg_s4 b0 = tr4(dl + (orow * 32 + colb) * 32), b1 = tr4(dl + (orow * 32 + colb + 4) * 32);
+      const int orow = kk >> 1, colb = (kk & 1) * 16;  // (+ this lane's first pixel of the k-step: in d_lane)
+      const wg_s4 b0 = tr4(dl + ct * (64 * 32) + (orow * 32 + colb) * 32), b1 = tr4(dl + ct * (64 * 32) + (orow * 32 + colb + 4) * 32);
       return __builtin_bit_cast(half8, wg_s8{b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w});
     };
     auto a_frag = [&](int kk, int tp) -> half8 {
 #if defined(DSG_W16_ABL_NOREAD)
       return __builtin_bit_cast(half8, wg_s8{(short)kk, (short)tp, 2, 3, 4, 5, 6, 7});
 #endif
-      const int orow = kk >> 1, colb = (kk & 1) * 16 + half * 8 + t_px;
+      const int orow = kk >> 1, colb = (kk & 1) * 16;
       const int dy = tp / KS, dx = tp % KS;
-      const int slot = (2 * s + orow + dy) % W16_SLOTS;  // input row 2s - PADK + orow + dy
-      const unsigned short* ap = a_lane + (slot * W16_PW + colb + dx) * 32;
+      const unsigned short* ap = arow[orow + dy] + (colb + dx) * 32;  // input row 2s - PADK + orow + dy
       const wg_s4 a0 = tr4(ap), a1 = tr4(ap + 4 * 32);
       return __builtin_bit_cast(half8, wg_s8{a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w});
     };
     // the stage's 4 * TAPS (k-step, tap) products in one sequence; operand g + AHEAD is fetched right behind MFMA g, into
     // the ring slot MFMA g - 1 has just read (the LDS counter is four bits wide: a whole k-step of reads in flight --
     // 18 -- made every wait a wait for all of them)
+#if defined(DSG_W16_AHEAD)  // (tools/ timing experiments)
+    constexpr int NG = 4 * TAPS, AHEAD = COT == 2 ? DSG_W16_AHEAD : (TAPS >= 3 ? 3 : 1), RING = AHEAD + 1;
+#else
     constexpr int NG = 4 * TAPS, AHEAD = TAPS >= 3 ? 3 : 1, RING = AHEAD + 1;
-    half8 fa[RING], fb[2];
-    fb[0] = b_frag(0);
+#endif
+    half8 fa[RING], fb[2][COT];
+#pragma unroll
+    for (int ct = 0; ct < COT; ++ct) fb[0][ct] = b_frag(0, ct);
 #pragma unroll
     for (int g = 0; g < AHEAD && g < NG; ++g) fa[g % RING] = a_frag(g / TAPS, g % TAPS);
 #pragma unroll
     for (int g = 0; g < NG; ++g) {
       const int kk = g / TAPS, tp = g % TAPS;
+      if constexpr (COT == 2) {  // this slot's share of the staging (two matrix instructions = 64 cycles per slot)
+        if (g == 0) {  // the loads of a whole stage ahead go out first, into the registers the pinned copies have freed
+#pragma unroll
+          for (int u = 0; u < 3; ++u) {
+            ca[u] = pinned_copy(xa[u]);
+            cva[u] = va[u];
+          }
+#pragma unroll
+          for (int u = 0; u < 2 * COT; ++u) cd[u] = pinned_copy(xd[u]);
+          load_rows(s + 3);
+          load_dy(s + 2);
+        } else if (g <= 14) {
+          if (g - 1 < 12) piece_p0(g - 1);
+          if (g >= 2 && g - 2 < 12) piece_p1(g - 2);
+          if (g >= 3) {
+            piece_p2(g - 3);
+            if (((g - 3) & 3) == 3) write_rows(s + 2, (g - 3) >> 2);
+          }
+        } else if (g <= 18) {
+          commit_dy_u(par ^ 1, s + 1 < s1, g - 15);
+        }
+      }
 #if defined(DSG_W16_ABL_NOMMA)   // (tools/ timing experiments only: wrong results, the loop's time without a component)
-      asm volatile("" ::"v"(fa[g % RING]), "v"(fb[kk & 1]));
+      asm volatile("" ::"v"(fa[g % RING]), "v"(fb[kk & 1][0]));
 #else
-      acc[tp] = mma16<PREC>(fa[g % RING], fb[kk & 1], acc[tp]);
+#pragma unroll
+      for (int ct = 0; ct < COT; ++ct) {
+        if (COT == 2 && tp == 0) mma16_vgpr_acc<PREC>(fa[g % RING], fb[kk & 1][ct], accv[ct]);  // (16 more MFMAs before anything else touches it)
+        else acc[ct][tp] = mma16<PREC>(fa[g % RING], fb[kk & 1][ct], acc[ct][tp]);
+      }
 #endif
       if (g + AHEAD < NG) fa[(g + AHEAD) % RING] = a_frag((g + AHEAD) / TAPS, (g + AHEAD) % TAPS);
-      if (tp == (TAPS > 1 ? TAPS - 2 : 0) && kk < 3) fb[(kk + 1) & 1] = b_frag(kk + 1);
+      if (kk < 3) {  // the next k-step's dY fragments: one per product near the end of this k-step
+#pragma unroll
+        for (int ct = 0; ct < COT; ++ct)
+          if (tp == (TAPS > 1 ? TAPS - 1 - COT + ct : 0)) fb[(kk + 1) & 1][ct] = b_frag(kk + 1, ct);
+      }
       // pin the order of matrix instructions and LDS reads (everything else -- the staging arithmetic, its loads and LDS
       // writes -- may still be moved between them): left alone the scheduler sinks each read to its use
-      __builtin_amdgcn_sched_barrier(0x216);
+      if constexpr (COT == 2) __builtin_amdgcn_sched_barrier(0);  // (the dealt staging stays in its slot)
+      else __builtin_amdgcn_sched_barrier(0x216);
     }
     __syncthreads();
   }
 
-  if (want_dysum) {  // 32 threads share a channel block: fixed-order sum through LDS (the strip's K loop is done with it)
+  if (want_dysum) {  // 32 / COT threads share a channel block: fixed-order sum through LDS (the strip's K loop is done with it)
     float* red = reinterpret_cast<float*>(wsm16);
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
@@ -1324,25 +1461,28 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad16_kernel(Wgrad16P p) {
       dsum[j] = 0.f;
     }
     __syncthreads();
-    if (tid < 64) {
+    if (tid < COW) {
       const int cb = tid >> 3, j = tid & 7;
       float t = 0.f;
-      for (int k = 0; k < 32; ++k) t += red[(cb + 8 * k) * 8 + j];
+      for (int k = 0; k < 256 / DCB; ++k) t += red[(cb + DCB * k) * 8 + j];
       p.dysum_ws[((size_t)strip * p.nrs + rs) * p.cout + co0 + tid] = t;  // (per strip: the sums are per image)
     }
     __syncthreads();  // the next strip's prologue writes the same LDS
   }
   }  // strips of this workgroup
   // epilogue: D[ci rows][co = l31]; partials to this run's slab [tap][ci][co]
-  const int co = co0 + cot * 32 + l31;
   float* wsb = p.ws + (size_t)slab_id * TAPS * p.cin * p.cout;
 #pragma unroll
-  for (int tp = 0; tp < TAPS; ++tp)
+  for (int ct = 0; ct < COT; ++ct) {
+    const int co = co0 + (cot + ct) * 32 + l31;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int ci = ci0 + cit * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-      wsb[((size_t)tp * p.cin + ci) * p.cout + co] = acc[tp][r];
-    }
+    for (int tp = 0; tp < TAPS; ++tp)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int ci = ci0 + cit * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+        wsb[((size_t)tp * p.cin + ci) * p.cout + co] = (COT == 2 && tp == 0) ? accv[ct][r] : acc[ct][tp][r];
+      }
+  }
 }
 
 // out[n][co] = sum over the image's runs of the per-run dY sums
@@ -1381,11 +1521,39 @@ __global__ __launch_bounds__(256) void wgrad16_dysum_reduce_bias_kernel(const fl
   }
 }
 
-static void wgrad16_runs(int cin, int cout, int n, int hout, int wout, int* strips, int* rsplit, int* spw = nullptr) {
-  const int pairs = (cin / 64) * (cout / 64);
+static int g_wgrad16_wide = 1;  // dsg_set_tuning key 29 (tests / A-B runs): 0 = the 64 x 64 workgroup everywhere
+void conv_wgrad16_set_wide(int v) { g_wgrad16_wide = v; }
+// co tiles per wave: 2 (a 64 ci x 128 co workgroup, one per CU) for the 3x3 gradients whose cout allows it
+static int wgrad16_cot(int cout, int ksize) { return (g_wgrad16_wide && ksize == 3 && cout % 128 == 0) ? 2 : 1; }
+
+static void wgrad16_runs(int cin, int cout, int n, int hout, int wout, int cot, int* strips, int* rsplit, int* spw = nullptr) {
+  const int pairs = (cin / 64) * (cout / (64 * cot));
   *strips = n * (wout / 32);
   const int stages = hout / 2;
-  const int want = std::max(1, cdiv(512, pairs));  // workgroups wanted per (ci, co) block pair (2 per CU in all)
+  if (cot == 2) {
+    // One workgroup per CU: a grid of 1.5 x 256 workgroups runs as two rounds, the second half empty (measured: the 384-channel
+    // layers 10 % SLOWER than with 64 x 64 workgroups, which share a CU and finish a ragged tail faster).  Among the splits
+    // (several strips per workgroup, or several row ranges per strip) take the one that fills its rounds best, then the
+    // smallest grid (fewest partial slabs); grids below one round only when nothing larger exists.
+    int best_wg = 0, best_d = 1, best_r = 1;
+    double best_eff = -1.0;
+    auto offer = [&](int d, int r) {
+      const int wg = pairs * (*strips / d) * r;
+      if (wg > 4096 && best_wg) return;
+      const double eff = wg < 256 ? wg / 256.0 - 1.0 : (double)wg / (256.0 * cdiv(wg, 256));
+      if (eff > best_eff + 1e-9 || (eff > best_eff - 1e-9 && wg < best_wg)) {
+        best_eff = eff; best_wg = wg; best_d = d; best_r = r;
+      }
+    };
+    for (int d = 1; d <= *strips; ++d)
+      if (*strips % d == 0) offer(d, 1);
+    for (int r = 2; r <= stages; ++r)
+      if (stages % r == 0) offer(1, r);
+    *rsplit = best_r;
+    if (spw) *spw = best_d;
+    return;
+  }
+  const int want = std::max(1, cdiv(cot == 2 ? 256 : 512, pairs));  // workgroups wanted per (ci, co) block pair (2 per CU in all; 1 at cot 2)
   *rsplit = std::max(1, std::min(stages, cdiv(want, *strips)));
   int per = 1;  // strips per workgroup: the largest divisor of `strips` that still leaves `want` workgroups per pair
   if (*rsplit == 1)
@@ -1407,9 +1575,13 @@ static size_t wgrad16_ws_bytes(int cin, int cout, int ksize, int n, int hout, in
     hout = hout * wout / 32;
     wout = 32;
   }
-  int strips, rsplit, spw;
-  wgrad16_runs(cin, cout, n, hout, wout, &strips, &rsplit, &spw);
-  return ((size_t)(strips / spw) * rsplit * ksize * ksize * cin * cout + (size_t)strips * rsplit * cout) * sizeof(float);  // + the dY-sum rows
+  size_t most = 0;  // (of the two workgroup shapes: the tuning key may change between the query and the launch)
+  for (int cot = 1; cot <= (ksize == 3 && cout % 128 == 0 ? 2 : 1); ++cot) {
+    int strips, rsplit, spw;
+    wgrad16_runs(cin, cout, n, hout, wout, cot, &strips, &rsplit, &spw);
+    most = std::max(most, ((size_t)(strips / spw) * rsplit * ksize * ksize * cin * cout + (size_t)strips * rsplit * cout) * sizeof(float));  // + the dY-sum rows
+  }
+  return most;
 }
 
 static int launch_wgrad16(const dsg_conv_wgrad_args* a, int hout, int wout, hipStream_t st) {
@@ -1425,7 +1597,8 @@ static int launch_wgrad16(const dsg_conv_wgrad_args* a, int hout, int wout, hipS
   p.ss = a->gn_scale_shift; p.silu = a->silu; p.ws = static_cast<float*>(a->workspace);
   p.tiles_x = wout / 32; p.stages = hout / 2; p.ci_blocks = p.cin / 64;
   int strips, rsplit, spw;
-  wgrad16_runs(p.cin, p.cout, p.n, hout, wout, &strips, &rsplit, &spw);
+  const int cot = wgrad16_cot(p.cout, a->ksize);
+  wgrad16_runs(p.cin, p.cout, p.n, hout, wout, cot, &strips, &rsplit, &spw);
   p.nrs = rsplit;
   p.spw = spw;
   const int nslab = (strips / spw) * rsplit;
@@ -1437,7 +1610,7 @@ static int launch_wgrad16(const dsg_conv_wgrad_args* a, int hout, int wout, hipS
   if (prof_on())
     pi = prof_begin(29, 2.0 * p.n * hout * wout * (double)p.cout * p.cin * taps,
                     2.0 * ((double)p.n * p.cin * p.h * p.w + (double)p.n * p.cout * hout * wout), st);
-  const dim3 grid(p.ci_blocks * (p.cout / 64), nslab);
+  const dim3 grid(p.ci_blocks * (p.cout / (64 * cot)), nslab);
   const bool bf = a->compute_dtype == DSG_BF16;
   const int act = p.ss == nullptr ? 0 : (p.silu ? 1 : 2);
 #define DSG_W16_LAUNCH(PRC, KSZ)                                                                                            \
@@ -1446,7 +1619,17 @@ static int launch_wgrad16(const dsg_conv_wgrad_args* a, int hout, int wout, hipS
     else if (act == 1) hipLaunchKernelGGL((conv_wgrad16_kernel<PRC, KSZ, 1>), grid, dim3(256), (size_t)W16Geom<KSZ>::LDS_BYTES, st, p); \
     else hipLaunchKernelGGL((conv_wgrad16_kernel<PRC, KSZ, 2>), grid, dim3(256), (size_t)W16Geom<KSZ>::LDS_BYTES, st, p);    \
   } while (0)
-  if (a->ksize == 3) {
+#define DSG_W16_LAUNCH_WIDE(PRC)                                                                                             \
+  do {                                                                                                                      \
+    constexpr size_t lds = (size_t)W16Geom<3, 2>::LDS_BYTES;                                                                \
+    if (act == 0) hipLaunchKernelGGL((conv_wgrad16_kernel<PRC, 3, 0, 2>), grid, dim3(256), lds, st, p);                     \
+    else if (act == 1) hipLaunchKernelGGL((conv_wgrad16_kernel<PRC, 3, 1, 2>), grid, dim3(256), lds, st, p);                \
+    else hipLaunchKernelGGL((conv_wgrad16_kernel<PRC, 3, 2, 2>), grid, dim3(256), lds, st, p);                              \
+  } while (0)
+  if (cot == 2) {
+    if (bf) DSG_W16_LAUNCH_WIDE(1);
+    else DSG_W16_LAUNCH_WIDE(2);
+  } else if (a->ksize == 3) {
     if (bf) DSG_W16_LAUNCH(1, 3);
     else DSG_W16_LAUNCH(2, 3);
   } else {
@@ -1454,6 +1637,7 @@ static int launch_wgrad16(const dsg_conv_wgrad_args* a, int hout, int wout, hipS
     else DSG_W16_LAUNCH(2, 1);
   }
 #undef DSG_W16_LAUNCH
+#undef DSG_W16_LAUNCH_WIDE
   DSG_LAUNCH_CHECK();
   const int64_t slab = (int64_t)taps * p.cin * p.cout;
   (void)slab;

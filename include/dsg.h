@@ -566,6 +566,8 @@ int dsg_prof_dump(const char* csv_path);
  *  19  split-K for grids of at most half the CUs (needs dsg_conv_args.splitk_ws): [1] | 0
  *  25  dsg_unet_forward keeps q, k, v and the attention output channel-blocked (head_dim 8): [1] | 0
  *  23  resnet shortcuts fused into conv2's K loop (dsg_conv_args.sc_*): [1] | 0 (0: dsg_conv2d_fuses_shortcut answers no)
+ *  29  16-bit 3x3 weight gradients with cout % 128 == 0 as 64 ci x 128 co workgroups (a wave keeps two co tiles, one
+ *      workgroup per CU): [1] | 0 = 64 x 64 workgroups, two per CU
  *  20  fp32-equivalent 3x3 convs with cin <= 128 on channel-blocked tensors: 8-row tiles with ONE weight slab in LDS,
  *      two workgroups per CU (grids of at least 512 workgroups): [1] | 0
  *  21  conv_in (fp32 [N,C<=8,H,W] image -> channel-blocked result, 16 x 32 pixel tiles, cout % 32 == 0) on its own kernel

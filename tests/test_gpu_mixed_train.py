@@ -32,6 +32,8 @@ def _rnd(x, mode):
 @pytest.mark.parametrize("mode", ["bf16", "fp16"])
 @pytest.mark.parametrize("case", [("gn_silu", 64, 0, 64, 32, 64, 2, True, 3), ("concat", 128, 64, 128, 16, 32, 3, True, 3),
                                   ("plain_wide", 64, 0, 192, 8, 96, 2, False, 3),
+                                  ("two_co_blocks_of_128", 64, 0, 256, 8, 64, 5, True, 3),
+                                  ("plain_128_couts", 192, 0, 128, 4, 32, 2, False, 3),
                                   ("pointwise_shortcut", 128, 64, 64, 16, 32, 3, False, 1),
                                   ("pointwise_odd_rows", 64, 0, 128, 6, 32, 2, True, 1)], ids=lambda c: c[0])
 def test_wgrad16(case, mode):
@@ -59,6 +61,38 @@ def test_wgrad16(case, mode):
     assert float(sums[:, 0].min()) == -7.0 and float(sums[:, cout + 1:].max()) == -7.0   # nothing outside the window
     got = dw.cpu().double() - 0.25
     assert rel_l2(got, ref) <= (2e-4 if gn else 2e-5), rel_l2(got, ref)
+
+
+@pytest.mark.parametrize("act", ["plain", "gn_silu", "gn_affine"])
+@pytest.mark.parametrize("shape", [(128, 64, 128, 16, 32, 3), (64, 0, 256, 12, 64, 5), (384, 0, 128, 32, 32, 4)],
+                         ids=["concat_192_128", "64_256_two_strips", "384_128"])
+def test_wgrad16_wide_workgroups_match_the_64x64_ones(shape, act):
+    """cout % 128 == 0 selects 64 ci x 128 co workgroups (a wave keeps two co tiles, one workgroup per CU; dsg_set_tuning
+    key 29): the same products in the same order per run, other runs of pixels per partial slab -- equal to fp32 round-off
+    of the slab sum, and the dY sums likewise."""
+    from drivescenegen_amd import _lib
+    c0, c1, cout, h, w, n = shape
+    cin = c0 + c1
+    b0 = ops.to_blocked(_t(21, (n, c0, h, w)).to(DEV), "bf16")
+    b1 = ops.to_blocked(_t(22, (n, c1, h, w)).to(DEV), "bf16") if c1 else None
+    dy = ops.to_blocked(_t(23, (n, cout, h, w), 0.3).to(DEV), "bf16")
+    ss = None
+    if act != "plain":
+        ss = torch.stack([1 + _t(24, (n, cin), 0.1), _t(25, (n, cin), 0.1)], -1).contiguous().to(DEV)
+    res = []
+    try:
+        for wide in (0, 1):
+            _lib.check(_lib.load().dsg_set_tuning(29, wide))
+            dw = torch.zeros((cout, cin, 3, 3), dtype=torch.float32, device=DEV)
+            sums = torch.zeros((n, cout), dtype=torch.float32, device=DEV)
+            bg = torch.zeros(cout, dtype=torch.float32, device=DEV)
+            ops.conv_wgrad(b0, dy, dw, src1=b1, ksize=3, gn_scale_shift=ss, silu=act == "gn_silu", dy_sums=sums, bias_grad=bg)
+            res.append((dw, sums, bg))
+    finally:
+        _lib.load().dsg_set_tuning(29, 1)
+    for a, b in zip(*res):
+        assert torch.isfinite(b).all()
+        assert float((a - b).abs().max()) <= 2e-6 * float(a.abs().max()), float((a - b).abs().max())
 
 
 @pytest.mark.parametrize("mode", ["bf16", "fp32"])
