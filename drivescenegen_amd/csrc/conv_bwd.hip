@@ -217,13 +217,52 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(WgradP p) {
   }
 }
 
+// The per-run sums of dY a weight-gradient kernel leaves behind (bias / time-embedding gradients) are finished by extra
+// workgroups of the SAME launch that reduces its partial slabs: out[n][co] = sum over the image's runs, and bias_grad[co] +=
+// their sum over the batch (fp64 across the batch, fixed order).  Was a launch of its own after every conv: 63 per training step.
+struct DysumJob {
+  const float* part;  // [n][slabs_per_image][cout]; nullptr = no job
+  int slabs_per_image, cout, n;
+  float* out;
+  int out_stride;
+  float* bias_grad;   // may be null
+  int blocks;         // cdiv(cout, 32)
+};
+// block b of the job: 32 channels x 8 image groups
+__device__ __forceinline__ void dysum_job_block(const DysumJob& j, int b) {
+  __shared__ double red[8][32];
+  const int cl = threadIdx.x & 31, g = threadIdx.x >> 5, co = b * 32 + cl;
+  double acc = 0.0;
+  if (co < j.cout) {
+    for (int ni = g; ni < j.n; ni += 8) {
+      float t = 0.f;
+      for (int k = 0; k < j.slabs_per_image; ++k) t += j.part[((size_t)ni * j.slabs_per_image + k) * j.cout + co];
+      j.out[(size_t)ni * j.out_stride + co] = t;
+      acc += (double)t;
+    }
+  }
+  if (j.bias_grad == nullptr) return;  // (uniform)
+  red[g][cl] = acc;
+  __syncthreads();
+  if (g == 0 && co < j.cout) {
+    double t = 0.0;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) t += red[k][cl];
+    j.bias_grad[co] += (float)t;
+  }
+}
+
 // dw[co][ci][tp] += sum_s ws[s][tp][ci][co]; 16-byte reads (cout_pad is a multiple of 64).  A workgroup owns 64
 // consecutive float4 elements; its four waves each sum every fourth slab (four loads in flight per lane), the four
 // partial sums meet in LDS and are added in a fixed order -- deterministic, and the small layers (9 K elements, up to
 // 256 slabs) still put four times as many waves on the chip as one thread per element would.
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ ws, int nslab, int taps, int cin,
                                                            int cout, int cin_pad, int cout_pad,
-                                                           float* __restrict__ dw) {
+                                                           float* __restrict__ dw, DysumJob job, int main_blocks) {
+  if ((int)blockIdx.x >= main_blocks) {  // (the launch's extra workgroups)
+    dysum_job_block(job, blockIdx.x - main_blocks);
+    return;
+  }
   __shared__ float4 part[4][64];
   const int e = threadIdx.x & 63, sl = threadIdx.x >> 6;
   const int64_t i4 = blockIdx.x * (int64_t)64 + e;
@@ -271,7 +310,12 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
 constexpr int WRT_CO = 32, WRT_CI = 2;
 __global__ __launch_bounds__(256) void wgrad_reduce_t_kernel(const float* __restrict__ ws, int nslab, int taps, int cin,
                                                              int cout, int cin_pad, int cout_pad,
-                                                             float* __restrict__ dw) {
+                                                             float* __restrict__ dw, DysumJob job, int main_rows) {
+  if ((int)blockIdx.y >= main_rows) {  // (the launch's extra rows of workgroups)
+    const int b = (blockIdx.y - main_rows) * gridDim.x + blockIdx.x;
+    if (b < job.blocks) dysum_job_block(job, b);
+    return;
+  }
   __shared__ float tile[4][WRT_CO][WRT_CI * 9 + 1];  // [slab wave][co][ci * taps + tp]
   const int co0 = blockIdx.x * WRT_CO, ci0 = blockIdx.y * WRT_CI;
   const int t = threadIdx.x, sl = t >> 6, co = t & 31, ci = (t >> 5) & 1;
@@ -299,15 +343,26 @@ __global__ __launch_bounds__(256) void wgrad_reduce_t_kernel(const float* __rest
   }
 }
 
+static DysumJob dysum_job(const float* part, int slabs_per_image, int cout, int n, float* out, int out_stride, float* bias_grad) {
+  DysumJob j;
+  j.part = part; j.slabs_per_image = slabs_per_image; j.cout = cout; j.n = n; j.out = out; j.out_stride = out_stride;
+  j.bias_grad = bias_grad; j.blocks = part ? cdiv(cout, 32) : 0;
+  return j;
+}
+
 static void launch_wgrad_reduce(const float* ws, int nslab, int taps, int cin, int cout, int cin_pad, int cout_pad, float* dw,
-                                hipStream_t st) {
+                                hipStream_t st, const DysumJob* job = nullptr) {
   const int64_t slab = (int64_t)taps * cin_pad * cout_pad;
-  if (nslab <= 32 && slab >= (int64_t)256 * 256 && cin_pad % WRT_CI == 0)
-    hipLaunchKernelGGL(wgrad_reduce_t_kernel, dim3(cdiv(cout_pad, WRT_CO), cdiv(cin_pad, WRT_CI)), dim3(256), 0, st, ws, nslab, taps,
-                       cin, cout, cin_pad, cout_pad, dw);
-  else
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)cdiv64(slab / 4, 64)), dim3(256), 0, st, ws, nslab, taps, cin, cout,
-                       cin_pad, cout_pad, dw);
+  const DysumJob j = job ? *job : dysum_job(nullptr, 0, 0, 0, nullptr, 0, nullptr);
+  if (nslab <= 32 && slab >= (int64_t)256 * 256 && cin_pad % WRT_CI == 0) {
+    const int gx = cdiv(cout_pad, WRT_CO), rows = cdiv(cin_pad, WRT_CI);
+    hipLaunchKernelGGL(wgrad_reduce_t_kernel, dim3(gx, rows + cdiv(j.blocks, gx)), dim3(256), 0, st, ws, nslab, taps,
+                       cin, cout, cin_pad, cout_pad, dw, j, rows);
+  } else {
+    const int main_blocks = (int)cdiv64(slab / 4, 64);
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)(main_blocks + j.blocks)), dim3(256), 0, st, ws, nslab, taps, cin, cout,
+                       cin_pad, cout_pad, dw, j, main_blocks);
+  }
 }
 
 // Generic VALU fallback (odd spatial sizes): one thread per (co, ci, tap), loops over all pixels.
@@ -717,21 +772,6 @@ static void wgrad_h2_runs(int cin, int cout, int n, int hout, int wout, int* str
   *rsplit = std::max(1, std::min(stages, cdiv(want, *strips)));
 }
 
-__global__ void wgrad16_dysum_reduce_kernel(const float* __restrict__ part, int slabs_per_image, int cout,
-                                            float* __restrict__ out, int out_stride);
-__global__ void wgrad16_dysum_reduce_bias_kernel(const float* __restrict__ part, int slabs_per_image, int cout, int n,
-                                                 float* __restrict__ out, int out_stride, float* __restrict__ bias_grad);
-// the per-run dY sums -> per-(n, cout) sums (and, with bias_grad, their sum over the batch added to it: one launch less)
-static void launch_dysum_reduce(const float* part, int slabs_per_image, int cout, int n, float* out, int out_stride,
-                                float* bias_grad, hipStream_t st) {
-  if (bias_grad)
-    hipLaunchKernelGGL(wgrad16_dysum_reduce_bias_kernel, dim3(cdiv(cout, 32)), dim3(256), 0, st, part, slabs_per_image, cout, n, out,
-                       out_stride, bias_grad);
-  else
-    hipLaunchKernelGGL(wgrad16_dysum_reduce_kernel, dim3(cdiv(cout, 256), n), dim3(256), 0, st, part, slabs_per_image, cout, out,
-                       out_stride);
-}
-
 static int launch_wgrad_h2(WgradP p, size_t ws_bytes, hipStream_t st, float* dy_sums = nullptr, int dy_sums_stride = 0,
                            float* dy_bias_grad = nullptr) {
   p.ci_blocks = p.cin / 32;
@@ -761,11 +801,10 @@ static int launch_wgrad_h2(WgradP p, size_t ws_bytes, hipStream_t st, float* dy_
   DSG_LAUNCH_CHECK();
   const int64_t slab = (int64_t)9 * p.cin_pad * p.cout_pad;
   (void)slab;
-  launch_wgrad_reduce(p.ws, nslab, 9, p.cin, p.cout, p.cin_pad, p.cout_pad, p.dw, st);
-  if (dy_sums) {  // run index = (image, column tile, row split): an image's runs are consecutive
-    DSG_LAUNCH_CHECK();
-    launch_dysum_reduce(p.dysum_ws, p.tiles_x * rsplit, p.cout, p.n, dy_sums, dy_sums_stride ? dy_sums_stride : p.cout, dy_bias_grad, st);
-  }
+  // (run index = (image, column tile, row split): an image's runs are consecutive)
+  const DysumJob job = dysum_job(dy_sums ? p.dysum_ws : nullptr, p.tiles_x * rsplit, p.cout, p.n, dy_sums,
+                                 dy_sums_stride ? dy_sums_stride : p.cout, dy_bias_grad);
+  launch_wgrad_reduce(p.ws, nslab, 9, p.cin, p.cout, p.cin_pad, p.cout_pad, p.dw, st, &job);
   prof_end(pi, st);
   DSG_LAUNCH_CHECK();
   return DSG_OK;
@@ -1485,42 +1524,6 @@ __global__ __launch_bounds__(256, COT == 2 ? 1 : 2) void conv_wgrad16_kernel(Wgr
   }
 }
 
-// out[n][co] = sum over the image's runs of the per-run dY sums
-__global__ void wgrad16_dysum_reduce_kernel(const float* __restrict__ part, int slabs_per_image, int cout,
-                                            float* __restrict__ out, int out_stride) {
-  const int co = blockIdx.x * blockDim.x + threadIdx.x, n = blockIdx.y;
-  if (co >= cout) return;
-  float t = 0.f;
-  for (int k = 0; k < slabs_per_image; ++k) t += part[((size_t)n * slabs_per_image + k) * cout + co];
-  out[(size_t)n * out_stride + co] = t;
-}
-
-// the same, and bias_grad[co] += sum over n of out[n][co] (what dsg_reduce_rows_add did in a launch of its own after every
-// conv: 66 per training step).  A block = 32 channels x 8 image groups; fp64 across the batch, fixed order.
-__global__ __launch_bounds__(256) void wgrad16_dysum_reduce_bias_kernel(const float* __restrict__ part, int slabs_per_image, int cout,
-                                                                        int n, float* __restrict__ out, int out_stride,
-                                                                        float* __restrict__ bias_grad) {
-  __shared__ double red[8][32];
-  const int cl = threadIdx.x & 31, g = threadIdx.x >> 5, co = blockIdx.x * 32 + cl;
-  double acc = 0.0;
-  if (co < cout) {
-    for (int ni = g; ni < n; ni += 8) {
-      float t = 0.f;
-      for (int k = 0; k < slabs_per_image; ++k) t += part[((size_t)ni * slabs_per_image + k) * cout + co];
-      out[(size_t)ni * out_stride + co] = t;
-      acc += (double)t;
-    }
-  }
-  red[g][cl] = acc;
-  __syncthreads();
-  if (g == 0 && co < cout) {
-    double t = 0.0;
-#pragma unroll
-    for (int k = 0; k < 8; ++k) t += red[k][cl];
-    bias_grad[co] += (float)t;
-  }
-}
-
 static int g_wgrad16_wide = 1;  // dsg_set_tuning key 29 (tests / A-B runs): 0 = the 64 x 64 workgroup everywhere
 void conv_wgrad16_set_wide(int v) { g_wgrad16_wide = v; }
 // co tiles per wave: 2 (a 64 ci x 128 co workgroup, one per CU) for the 3x3 gradients whose cout allows it
@@ -1641,12 +1644,9 @@ static int launch_wgrad16(const dsg_conv_wgrad_args* a, int hout, int wout, hipS
   DSG_LAUNCH_CHECK();
   const int64_t slab = (int64_t)taps * p.cin * p.cout;
   (void)slab;
-  launch_wgrad_reduce(p.ws, nslab, taps, p.cin, p.cout, p.cin, p.cout, a->dw, st);
-  if (a->dy_sums) {
-    DSG_LAUNCH_CHECK();
-    launch_dysum_reduce(p.dysum_ws, p.tiles_x * rsplit, p.cout, p.n, a->dy_sums, a->dy_sums_stride ? a->dy_sums_stride : p.cout,
-                        a->dy_bias_grad, st);
-  }
+  const DysumJob job = dysum_job(a->dy_sums ? p.dysum_ws : nullptr, p.tiles_x * rsplit, p.cout, p.n, a->dy_sums,
+                                 a->dy_sums_stride ? a->dy_sums_stride : p.cout, a->dy_bias_grad);
+  launch_wgrad_reduce(p.ws, nslab, taps, p.cin, p.cout, p.cin, p.cout, a->dw, st, &job);
   prof_end(pi, st);
   DSG_LAUNCH_CHECK();
   return DSG_OK;
