@@ -778,7 +778,7 @@ def _forward16(model, st: TrainState, tape: _Tape, sample, timesteps, dt):
         qkv = ops.conv2d_fused(x, wf, bias, ksize=1, gn_scale_shift=ss, silu=False, cout=3 * c, src_blocked=True,
                                dst_blocked=False, compute_dtype=dt, weight_h2=packs.qkv(pre, ops.PACK_FWD),
                                weight_h2_stride=_pad64(3 * c))
-        o, lse = ops.attention_train(qkv.view(n, 3 * c, hh * ww), heads, dtype=dt if dt == _lib.DSG_BF16 else 0)
+        o, lse = ops.attention_train(qkv.view(n, 3 * c, hh * ww), heads, dtype=dt)
         o = o.view(n, c, hh, ww)
         tape.recs.append(dict(kind="qkv", x=x, ss=ss, mr=mr, gn=gnn, pre=pre, qkv=qkv))
         tape.recs.append(dict(kind="attn", qkv=qkv, o=o, lse=lse, heads=heads))
@@ -1013,11 +1013,11 @@ def _backward16(model, st: TrainState, tape: _Tape, dout):
             do = tape.g(rec["o"])
             qkv = rec["qkv"]
             n, c3, hh, ww = qkv.shape
-            # (bf16 tape: the attention core's backward on the matrix cores, operands rounded once -- autocast's split; the
-            #  fp16 tape keeps the exact kernels: dS is too small for fp16's range even under the loss scale)
+            # (the attention core's backward on the matrix cores, operands rounded once to the tape's 16-bit type --
+            #  autocast's split; in fp16 dO is scaled by a power of two inside the kernels, so dS stays in fp16's range)
             dqkv = ops.attention_bwd(qkv.view(n, c3, hh * ww), rec["o"].view(n, c3 // 3, hh * ww),
                                      do.view(n, c3 // 3, hh * ww), rec["lse"], rec["heads"],
-                                     dtype=dt if dt == _lib.DSG_BF16 else 0)
+                                     dtype=dt)
             tape.setg(qkv, dqkv.view(n, c3, hh, ww))
         elif kind == "qkv":
             dqkv = tape.g(rec["qkv"])

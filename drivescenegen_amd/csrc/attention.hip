@@ -510,7 +510,7 @@ DSG_API int dsg_attention_fwd_train_dt(const float* qkv, float* out, float* lse,
                                        int32_t l, int32_t dtype, void* stream) {
   DSG_CHECK_ARG(lse != nullptr, "dsg_attention_fwd_train_dt: lse is NULL");
   DSG_CHECK_ARG(dtype >= DSG_F32 && dtype <= DSG_F16, "dsg_attention_fwd_train_dt: bad dtype %d", dtype);
-  return attention_fwd_impl(qkv, out, lse, n, c, heads, l, stream, false, dtype == DSG_BF16 ? DSG_BF16 : DSG_F32);
+  return attention_fwd_impl(qkv, out, lse, n, c, heads, l, stream, false, dtype);
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -727,8 +727,12 @@ __global__ __launch_bounds__(256) void attention_bwd_dkv_kernel(const float* __r
 }
 
 // ---------------------------------------------------------------------------------------------------
-// The same backward on the matrix cores for head_dim 8 in the mixed-precision (bf16) tape: q, k, v, dO, P and dS are rounded
-// once to bf16, one MFMA per product, fp32 scores / accumulators -- torch.autocast's split for the attention core (the fp32 tape
+// The same backward on the matrix cores for head_dim 8 in the mixed-precision tapes: q, k, v, dO, P and dS are rounded
+// once to 16 bits, one MFMA per product (PREC 1: bf16.  PREC 2, the fp16 tape: dS = P (dP - D) is a probability times a
+// gradient, 1e-3 x 1e-6 without a loss scale -- below fp16's normal range, flushed bits that the test of a whole training step
+// caught.  The gradients are linear in dO, so dO is multiplied by a power of two that brings its largest entry to [1, 2) before
+// it is rounded and the results are divided by it: per query in kernel A, per (image, head) in kernel B, whose sums run over the
+// queries), fp32 scores / accumulators -- torch.autocast's split for the attention core (the fp32 tape
 // keeps the exact VALU kernels above: with fp16-pair operands the split arithmetic would cost what the packed-fp32 loops do).
 // Layouts are the forward kernel's (attention_mfma8_kernel): a 32 x 32 tile of S^T = K^T Q leaves a lane with ONE column and 16
 // rows, and registers 8b .. 8b + 7 are the B operand of a 16-deep step over those rows.
@@ -737,11 +741,12 @@ __global__ __launch_bounds__(256) void attention_bwd_dkv_kernel(const float* __r
 //   kernel B (dK, dV): columns = this wave's 32 keys, rows = queries from LDS (with their lse and D):
 //                  S = Q^T K, dP = dO^T V, dV^T += dO(as [d][query]) P, dK^T += Q(as [d][query]) dS
 // ---------------------------------------------------------------------------------------------------
+template <int PREC>
 __global__ __launch_bounds__(64 * ATM_NW, 2) void attention_bwd_dq_mfma8_kernel(const float* __restrict__ qkv, const float* __restrict__ o,
                                                                                const float* __restrict__ dout, const float* __restrict__ lse,
                                                                                float* __restrict__ dqkv, float* __restrict__ dsum, int c,
                                                                                int heads, int l, float qscale) {
-  constexpr int PREC = 1;
+  constexpr bool SCALE = PREC == 2;  // fp16: dO is brought to [1, 2) by a power of two before it is rounded (see above)
   __shared__ __attribute__((aligned(16))) _Float16 Kh[ATM_KT * 8], Vk[ATM_KT * 8];   // [key][d]: A operands of S^T and dP^T
   __shared__ __attribute__((aligned(16))) _Float16 Kd[8 * ATM_VSTR];                  // [d][key]: A operand of dQ^T += K dS
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, l31 = lane & 31;
@@ -759,15 +764,30 @@ __global__ __launch_bounds__(64 * ATM_NW, 2) void attention_bwd_dq_mfma8_kernel(
   const int qi = min(q0 + l31, l - 1);
   att_half4 qh, dh;
   float dpart = 0.f;
+  float dov4[4], amax = 0.f;
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     const size_t at = (size_t)(4 * half + i) * l + qi;
-    const float dov = dout[obase + at];
+    dov4[i] = dout[obase + at];
     qh[i] = att_cvt<PREC>(qp[at] * qscale);
-    dh[i] = att_cvt<PREC>(dov);
-    dpart = fmaf(dov, o[obase + at], dpart);
+    dpart = fmaf(dov4[i], o[obase + at], dpart);
+    amax = fmaxf(amax, fabsf(dov4[i]));
   }
-  const float dd = dpart + __shfl_xor(dpart, 32, 64);   // D = rowsum(dO * O) of this lane's query
+  // this query's power-of-two scale (lanes l31 and l31 + 32 hold its two halves): dQ_i is linear in dO_i, undone at the end
+  float qs = 1.f, qs_inv = 1.f;
+  if constexpr (SCALE) {
+    amax = fmaxf(amax, __shfl_xor(amax, 32, 64));
+    if (amax > 0.f && amax < 3.0e38f) {
+      int ex;
+      (void)frexpf(amax, &ex);
+      qs = ldexpf(1.0f, 1 - ex);
+      qs_inv = ldexpf(1.0f, ex - 1);
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i) dh[i] = att_cvt<PREC>(dov4[i] * qs);
+  const float dd_true = dpart + __shfl_xor(dpart, 32, 64);   // D = rowsum(dO * O) of this lane's query
+  const float dd = dd_true * qs;
   const float ls = lse[((size_t)n * heads + h) * l + qi];
   f32x16 dq;
 #pragma unroll
@@ -784,9 +804,8 @@ __global__ __launch_bounds__(64 * ATM_NW, 2) void attention_bwd_dq_mfma8_kernel(
         kv = kp[(size_t)i * l + j0 + j];
         vv = vp[(size_t)i * l + j0 + j];
       }
-      const _Float16 kb = att_cvt<PREC>(kv);
-      Kh[j * 8 + i] = kb;
-      Kd[i * ATM_VSTR + j] = kb;
+      Kh[j * 8 + i] = att_cvt<PREC>(kv);
+      Kd[i * ATM_VSTR + j] = att_cvt<PREC>(kv);
       Vk[j * 8 + i] = att_cvt<PREC>(vv);
     }
     __syncthreads();
@@ -812,18 +831,19 @@ __global__ __launch_bounds__(64 * ATM_NW, 2) void attention_bwd_dq_mfma8_kernel(
     }
   }
   if (!active || q0 + l31 >= l) return;
-  const float sm = qscale * 0.6931471805599453f;  // qscale = log2(e)/sqrt(D); the softmax scale alone is 1/sqrt(D)
+  const float sm = qscale * 0.6931471805599453f * qs_inv;  // qscale = log2(e)/sqrt(D); the softmax scale alone is 1/sqrt(D)
   float* dqp = dqkv + ((size_t)n * 3 * c + h * 8) * l;
 #pragma unroll
   for (int r = 0; r < 4; ++r) dqp[(size_t)(r + 4 * half) * l + q0 + l31] = dq[r] * sm;
-  if (half == 0) dsum[((size_t)n * heads + h) * l + q0 + l31] = dd;
+  if (half == 0) dsum[((size_t)n * heads + h) * l + q0 + l31] = dd_true;
 }
 
+template <int PREC>
 __global__ __launch_bounds__(64 * ATM_NW, 2) void attention_bwd_dkv_mfma8_kernel(const float* __restrict__ qkv, const float* __restrict__ dout,
                                                                                 const float* __restrict__ lse, const float* __restrict__ dsum,
                                                                                 float* __restrict__ dqkv, int c, int heads, int l,
                                                                                 float qscale) {
-  constexpr int PREC = 1;
+  constexpr bool SCALE = PREC == 2;  // fp16: dO is brought to [1, 2) by a power of two before it is rounded (see above)
   __shared__ __attribute__((aligned(16))) _Float16 Qh[ATM_KT * 8], Gh[ATM_KT * 8];            // [query][d]: A operands of S and dP
   __shared__ __attribute__((aligned(16))) _Float16 Qd[8 * ATM_VSTR], Gd[8 * ATM_VSTR];        // [d][query]: A operands of dK^T, dV^T
   __shared__ __attribute__((aligned(16))) float Ls[ATM_KT], Ds[ATM_KT];                        // lse and D of the tile's queries
@@ -847,6 +867,27 @@ __global__ __launch_bounds__(64 * ATM_NW, 2) void attention_bwd_dkv_mfma8_kernel
     kh[i] = att_cvt<PREC>(kp[(size_t)(4 * half + i) * l + ki]);
     vh[i] = att_cvt<PREC>(vp[(size_t)(4 * half + i) * l + ki]);
   }
+  // dK_j and dV_j sum over the queries: ONE scale for the head's whole dO (its 8 l values are contiguous; every workgroup of
+  // the head finds the same maximum -- no atomics, no extra buffer); rows far below the maximum lose bits that do not show in the sum
+  float gs = 1.f, gs_inv = 1.f;
+  if constexpr (SCALE) {
+    __shared__ float wmax[ATM_NW];
+    float m = 0.f;
+    for (int e = tid; e < 8 * l; e += 64 * ATM_NW) m = fmaxf(m, fabsf(dout[obase + e]));
+#pragma unroll
+    for (int sft = 32; sft >= 1; sft >>= 1) m = fmaxf(m, __shfl_xor(m, sft, 64));
+    if (lane == 0) wmax[wave] = m;
+    __syncthreads();
+    m = wmax[0];
+#pragma unroll
+    for (int w = 1; w < ATM_NW; ++w) m = fmaxf(m, wmax[w]);
+    if (m > 0.f && m < 3.0e38f) {
+      int ex;
+      (void)frexpf(m, &ex);
+      gs = ldexpf(1.0f, 1 - ex);
+      gs_inv = ldexpf(1.0f, ex - 1);
+    }
+  }
   f32x16 dk, dv;
 #pragma unroll
   for (int r = 0; r < 16; ++r) dk[r] = dv[r] = 0.f;
@@ -860,17 +901,17 @@ __global__ __launch_bounds__(64 * ATM_NW, 2) void attention_bwd_dkv_mfma8_kernel
       float qv = 0.f, gv = 0.f;
       if (j < qt) {
         qv = qp[(size_t)i * l + j0 + j] * qscale;
-        gv = dout[obase + (size_t)i * l + j0 + j];
+        gv = dout[obase + (size_t)i * l + j0 + j] * gs;
       }
-      const _Float16 qb = att_cvt<PREC>(qv), gb = att_cvt<PREC>(gv);
-      Qh[j * 8 + i] = qb;
-      Qd[i * ATM_VSTR + j] = qb;
+      const _Float16 gb = att_cvt<PREC>(gv);
+      Qh[j * 8 + i] = att_cvt<PREC>(qv);
+      Qd[i * ATM_VSTR + j] = att_cvt<PREC>(qv);
       Gh[j * 8 + i] = gb;
       Gd[i * ATM_VSTR + j] = gb;
     }
     for (int j = tid; j < ATM_KT; j += 64 * ATM_NW) {
       Ls[j] = j < qt ? lse[lbase + j0 + j] : 0.f;
-      Ds[j] = j < qt ? dsum[lbase + j0 + j] : 0.f;
+      Ds[j] = j < qt ? dsum[lbase + j0 + j] * gs : 0.f;
     }
     __syncthreads();
     if (!active) continue;
@@ -911,18 +952,19 @@ __global__ __launch_bounds__(64 * ATM_NW, 2) void attention_bwd_dkv_mfma8_kernel
   float* dvp = dkp + (size_t)c * l;
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
-    dkp[(size_t)(r + 4 * half) * l + k0 + l31] = dk[r] * 0.6931471805599453f;  // (q came pre-scaled by log2(e)/sqrt(D))
-    dvp[(size_t)(r + 4 * half) * l + k0 + l31] = dv[r];
+    dkp[(size_t)(r + 4 * half) * l + k0 + l31] = dk[r] * (0.6931471805599453f * gs_inv);  // (q came pre-scaled by log2(e)/sqrt(D))
+    dvp[(size_t)(r + 4 * half) * l + k0 + l31] = dv[r] * gs_inv;
   }
 }
 
+template <int PREC>
 static int launch_attention_bwd_mfma8(const float* qkv, const float* o, const float* dout, const float* lse, float* dqkv,
                                       float* dsum, int n, int c, int heads, int l, hipStream_t st) {
   const float qscale = 1.4426950408889634f / sqrtf(8.0f);
   const dim3 grid(cdiv(l, 32 * ATM_NW) * heads * n), block(64 * ATM_NW);
-  hipLaunchKernelGGL(attention_bwd_dq_mfma8_kernel, grid, block, 0, st, qkv, o, dout, lse, dqkv, dsum, c, heads, l, qscale);
+  hipLaunchKernelGGL(attention_bwd_dq_mfma8_kernel<PREC>, grid, block, 0, st, qkv, o, dout, lse, dqkv, dsum, c, heads, l, qscale);
   DSG_LAUNCH_CHECK();
-  hipLaunchKernelGGL(attention_bwd_dkv_mfma8_kernel, grid, block, 0, st, qkv, dout, lse, dsum, dqkv, c, heads, l, qscale);
+  hipLaunchKernelGGL(attention_bwd_dkv_mfma8_kernel<PREC>, grid, block, 0, st, qkv, dout, lse, dsum, dqkv, c, heads, l, qscale);
   DSG_LAUNCH_CHECK();
   return DSG_OK;
 }
@@ -943,14 +985,17 @@ static int launch_attention_bwd(const float* qkv, const float* o, const float* d
 
 }  // namespace dsg
 
-// dtype: DSG_F32 = the exact kernels; DSG_BF16 = the matrix-core kernels (head_dim 8, l % 32 == 0; anything else: the exact ones)
+// dtype: DSG_F32 = the exact kernels; DSG_BF16 / DSG_F16 = the matrix-core kernels (head_dim 8, l % 32 == 0; anything else: the
+// exact ones).  DSG_F16: dO enters the fp16 products scaled by a power of two (kernel comments), whatever the loss scale is.
 DSG_API int dsg_attention_bwd_dt(const float* qkv, const float* out, const float* dout, const float* lse, float* dqkv,
                                  float* dsum_ws, int32_t n, int32_t c, int32_t heads, int32_t l, int32_t dtype, void* stream) {
   DSG_CHECK_ARG(qkv && out && dout && lse && dqkv && dsum_ws, "dsg_attention_bwd_dt: NULL pointer");
   DSG_CHECK_ARG(n > 0 && c > 0 && heads > 0 && l > 0 && c % heads == 0, "dsg_attention_bwd_dt: bad dims");
   DSG_CHECK_ARG(dtype >= DSG_F32 && dtype <= DSG_F16, "dsg_attention_bwd_dt: bad dtype %d", dtype);
-  if (dtype == DSG_BF16 && c / heads == 8 && l % 32 == 0 && dsg::g_att_mfma)
-    return dsg::launch_attention_bwd_mfma8(qkv, out, dout, lse, dqkv, dsum_ws, n, c, heads, l, static_cast<hipStream_t>(stream));
+  if (dtype != DSG_F32 && c / heads == 8 && l % 32 == 0 && dsg::g_att_mfma)
+    return dtype == DSG_BF16
+               ? dsg::launch_attention_bwd_mfma8<1>(qkv, out, dout, lse, dqkv, dsum_ws, n, c, heads, l, static_cast<hipStream_t>(stream))
+               : dsg::launch_attention_bwd_mfma8<2>(qkv, out, dout, lse, dqkv, dsum_ws, n, c, heads, l, static_cast<hipStream_t>(stream));
   return dsg_attention_bwd(qkv, out, dout, lse, dqkv, dsum_ws, n, c, heads, l, stream);
 }
 

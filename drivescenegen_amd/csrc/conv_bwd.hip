@@ -1536,16 +1536,19 @@ static void wgrad16_runs(int cin, int cout, int n, int hout, int wout, int cot, 
   if (cot == 2) {
     // One workgroup per CU: a grid of 1.5 x 256 workgroups runs as two rounds, the second half empty (measured: the 384-channel
     // layers 10 % SLOWER than with 64 x 64 workgroups, which share a CU and finish a ragged tail faster).  Among the splits
-    // (several strips per workgroup, or several row ranges per strip) take the one that fills its rounds best, then the
-    // smallest grid (fewest partial slabs); grids below one round only when nothing larger exists.
-    int best_wg = 0, best_d = 1, best_r = 1;
-    double best_eff = -1.0;
+    // (several strips per workgroup, or several row ranges per strip) take the cheapest by a small model, in units of one
+    // stage (~2.6 us): rounds x (stages per workgroup + 6 for its prologue and the 18-tile slab write) + 0.012 per workgroup
+    // for its 295-KB partial slab going out and coming back through the reduce pass (calibrated on 384 -> 256 @ 64^2, B=32: 768
+    // workgroups in 301 us -- the slabs mostly live in the Infinity Cache); ties go to the smaller grid.
+    // (A pure "fill the rounds" rule took 3584 two-stage workgroups for 256 -> 256 @ 64^2 at batch 14.)
+    int best_d = 1, best_r = 1, best_wg = 0;
+    double best = 1e30;
     auto offer = [&](int d, int r) {
       const int wg = pairs * (*strips / d) * r;
-      if (wg > 4096 && best_wg) return;
-      const double eff = wg < 256 ? wg / 256.0 - 1.0 : (double)wg / (256.0 * cdiv(wg, 256));
-      if (eff > best_eff + 1e-9 || (eff > best_eff - 1e-9 && wg < best_wg)) {
-        best_eff = eff; best_wg = wg; best_d = d; best_r = r;
+      const double per_wg = (double)d * (stages / r);
+      const double cost = cdiv(wg, 256) * (per_wg + 6.0) + 0.012 * wg;
+      if (cost < best - 1e-9 || (cost < best + 1e-9 && wg < best_wg)) {
+        best = cost; best_wg = wg; best_d = d; best_r = r;
       }
     };
     for (int d = 1; d <= *strips; ++d)
