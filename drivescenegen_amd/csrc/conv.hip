@@ -488,6 +488,7 @@ void unet_set_blocked(int v);
 void attention_set_mfma(int v);
 void wgrad_h2_set_enabled(int on);
 void conv_wgrad16_set_wide(int v);
+void conv_wgrad16_set_pw(int v);
 void conv_h2_set_fold(int on);
 
 static int g_conv_fewout = 1;  // VALU kernel for cout <= 4 (tuning key 10: A/B against the zero-padded MFMA tile)
@@ -902,6 +903,10 @@ DSG_API int dsg_set_tuning(int32_t key, int32_t value) {
   }
   if (key == 28 && (value == 0 || value == 1)) {
     dsg::conv_h2_set_pc(value);
+    return DSG_OK;
+  }
+  if (key == 30 && (value == 0 || value == 1)) {
+    dsg::conv_wgrad16_set_pw(value);
     return DSG_OK;
   }
   if (key == 29 && (value == 0 || value == 1)) {

@@ -1524,6 +1524,216 @@ __global__ __launch_bounds__(256, COT == 2 ? 1 : 2) void conv_wgrad16_kernel(Wgr
   }
 }
 
+// ---------------------------------------------------------------------------------------------------
+// Pointwise (1x1) 16-bit weight gradient on tiles of its own (shortcuts, attention projections; tuning key 30).  With one tap a
+// 64 x 64 workgroup of the kernel above has four MFMAs per wave between two barriers, two transposing reads per MFMA, and
+// re-reads x cout / 64 and dY cin / 64 times: 115-295 us per layer for 26-52 GF, neither matrix- nor memory-bound.  Here a
+// workgroup covers 64 MI ci x 64 NJ co (MI, NJ in {1, 2}: 128 x 128 where the channel counts allow), wave (wm, wn) owns the MI x NJ
+// tiles (2 wm + i, 2 wn + j)/2 ... of it: per 16-pixel k-step MI + NJ fragments feed MI x NJ MFMAs, and x / dY are re-read
+// cout / (64 NJ) / cin / (64 MI) times.  A stage is 64 consecutive pixels of one image ([N][C/8][H W][8] is linear in the pixel);
+// LDS [buffer 2][tile][64 px][32 ch] for both operands, one barrier per stage, loads a stage ahead, fragments a k-step ahead.
+// A run = consecutive stages of ONE image (the scale / shift table and the dY-sum by-product are per image).
+// ---------------------------------------------------------------------------------------------------
+struct Wgrad16PwP {
+  const void* src0;
+  const void* src1;
+  int c0, c1, cin, n, plane, cout;
+  const void* dy;
+  int dy_ctotal, dy_coff;
+  const float* ss;
+  int silu;
+  float* ws;        // [slab][cin][cout]
+  int ci_blocks;    // cin / (64 MI)
+  int rpi;          // runs per image
+  float* dysum_ws;  // optional [slab][cout]
+};
+
+template <int PREC, int ACT, int MI, int NJ>
+__global__ __launch_bounds__(256, 2) void conv_wgrad16_pw_kernel(Wgrad16PwP p) {
+  constexpr int TM = 64 * MI, TN = 64 * NJ, AT = 2 * MI, DT = 2 * NJ;      // channels / 32-channel tiles per workgroup
+  constexpr int TILE = 64 * 32;                                             // halfs of one [64 px][32 ch] tile
+  constexpr int BUF = (AT + DT) * TILE;
+  constexpr int AU = TM / 32, DU = TN / 32;                                 // 16-byte pieces per thread and stage
+  constexpr int ACB = TM / 8, DCB = TN / 8;                                 // channel blocks per workgroup
+  extern __shared__ __attribute__((aligned(16))) unsigned char wsmpw[];
+  unsigned short* L = reinterpret_cast<unsigned short*>(wsmpw);
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int half = lane >> 5, l31 = lane & 31, wm = wave >> 1, wn = wave & 1;
+  int pair_id, slab_id;
+  wgrad_xcd_ids(pair_id, slab_id);
+  const int cib = pair_id % p.ci_blocks, cob = pair_id / p.ci_blocks;
+  const int ci0 = cib * TM, co0 = cob * TN;
+  const int n = slab_id / p.rpi, run = slab_id - n * p.rpi;
+  const int stages = p.plane / 64, per = (stages + p.rpi - 1) / p.rpi;
+  const int s0 = run * per, s1 = min(stages, s0 + per);
+  const bool has_ss = ACT == 2 ? p.ss != nullptr : ACT == 1;
+  const bool do_silu = ACT == 2 ? (has_ss && p.silu) : ACT == 1;
+  const bool in0 = ci0 < p.c0;  // (the ci block sits in one source: c0 % TM == 0)
+  const unsigned short* xsrc = in0 ? static_cast<const unsigned short*>(p.src0) + ((size_t)n * p.c0 + ci0) * p.plane
+                                   : static_cast<const unsigned short*>(p.src1) + ((size_t)n * p.c1 + (ci0 - p.c0)) * p.plane;
+  const unsigned short* dsrc = static_cast<const unsigned short*>(p.dy) + ((size_t)n * p.dy_ctotal + p.dy_coff + co0) * p.plane;
+
+  // staging items: piece id = tid + 256 u -> (pixel id / CB, channel block id % CB): the channel block is the same in every round
+  const int a_cb = tid & (ACB - 1), d_cb = tid & (DCB - 1);
+  float sc[8], sh[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    sc[j] = 1.f;
+    sh[j] = 0.f;
+    if (has_ss) {
+      const float2 t2 = *reinterpret_cast<const float2*>(p.ss + ((size_t)n * p.cin + ci0 + a_cb * 8 + j) * 2);
+      sc[j] = t2.x;
+      sh[j] = t2.y;
+    }
+  }
+  uint4 xa[AU], xd[DU];
+  auto load_stage = [&](int s) {  // (clamped past the image: never used)
+    const int px0 = min(s, stages - 1) * 64;
+#pragma unroll
+    for (int u = 0; u < AU; ++u) {
+      const int px = (tid + 256 * u) / ACB;
+      xa[u] = *reinterpret_cast<const uint4*>(xsrc + ((size_t)a_cb * p.plane + px0 + px) * 8);
+    }
+#pragma unroll
+    for (int u = 0; u < DU; ++u) {
+      const int px = (tid + 256 * u) / DCB;
+      xd[u] = *reinterpret_cast<const uint4*>(dsrc + ((size_t)d_cb * p.plane + px0 + px) * 8);
+    }
+  };
+  const bool want_dysum = p.dysum_ws != nullptr && cib == 0;
+  float dsum[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) dsum[j] = 0.f;
+  auto commit_stage = [&](int par, bool count) {
+    unsigned short* Ab = L + par * BUF;
+    unsigned short* Db = Ab + AT * TILE;
+#pragma unroll
+    for (int u = 0; u < AU; ++u) {
+      const int px = (tid + 256 * u) / ACB;
+      const unsigned w4[4] = {xa[u].x, xa[u].y, xa[u].z, xa[u].w};
+      unsigned o4[4];
+#pragma unroll
+      for (int jp = 0; jp < 4; ++jp) {
+        float a = lo16<PREC>(w4[jp]), b = hi16<PREC>(w4[jp]);
+        if (has_ss) {
+          a = a * sc[2 * jp] + sh[2 * jp];
+          b = b * sc[2 * jp + 1] + sh[2 * jp + 1];
+        }
+        if (do_silu) {
+          a = silu_fast_b(a);
+          b = silu_fast_b(b);
+        }
+        o4[jp] = (has_ss || do_silu) ? pack2<PREC>(a, b) : w4[jp];
+      }
+      *reinterpret_cast<uint4*>(Ab + (a_cb >> 2) * TILE + px * 32 + (a_cb & 3) * 8) = make_uint4(o4[0], o4[1], o4[2], o4[3]);
+    }
+#pragma unroll
+    for (int u = 0; u < DU; ++u) {
+      const int px = (tid + 256 * u) / DCB;
+      *reinterpret_cast<uint4*>(Db + (d_cb >> 2) * TILE + px * 32 + (d_cb & 3) * 8) = xd[u];
+      if (want_dysum && count) {
+        const unsigned w4[4] = {xd[u].x, xd[u].y, xd[u].z, xd[u].w};
+#pragma unroll
+        for (int jp = 0; jp < 4; ++jp) {
+          dsum[2 * jp] += lo16<PREC>(w4[jp]);
+          dsum[2 * jp + 1] += hi16<PREC>(w4[jp]);
+        }
+      }
+    }
+  };
+
+  wf32x16 acc[MI][NJ];
+#pragma unroll
+  for (int i = 0; i < MI; ++i)
+#pragma unroll
+    for (int j = 0; j < NJ; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  // transposing-read addressing (see conv_wgrad16_kernel): source lane s = lane & 15 -> pixel + (s >> 2), channel quad s & 3
+  const int s16 = lane & 15, g16 = (lane >> 4) & 1;
+  const int lane_off = g16 * 16 + (s16 & 3) * 4 + (half * 8 + (s16 >> 2)) * 32;
+  auto tr4 = [](const unsigned short* q) -> wg_s4 {
+    return __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) wg_s4*)(const_cast<unsigned short*>(q)));
+  };
+  typedef short wg_s8 __attribute__((ext_vector_type(8)));
+  auto frag = [&](const unsigned short* tile, int kk) -> half8 {
+    const wg_s4 v0 = tr4(tile + kk * 16 * 32), v1 = tr4(tile + (kk * 16 + 4) * 32);
+    return __builtin_bit_cast(half8, wg_s8{v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w});
+  };
+
+  if (s0 < s1) {
+    load_stage(s0);
+    commit_stage(0, true);
+    load_stage(s0 + 1);
+  }
+  __syncthreads();
+  for (int s = s0; s < s1; ++s) {
+    const int par = (s - s0) & 1;
+    commit_stage(par ^ 1, s + 1 < s1);
+    load_stage(s + 2);
+    const unsigned short* at = L + par * BUF + (wm * MI) * TILE + lane_off;
+    const unsigned short* dt = L + par * BUF + (AT + wn * NJ) * TILE + lane_off;
+    half8 fa[2][MI], fb[2][NJ];
+#pragma unroll
+    for (int i = 0; i < MI; ++i) fa[0][i] = frag(at + i * TILE, 0);
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) fb[0][j] = frag(dt + j * TILE, 0);
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+      if (kk < 3) {
+#pragma unroll
+        for (int i = 0; i < MI; ++i) fa[(kk + 1) & 1][i] = frag(at + i * TILE, kk + 1);
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) fb[(kk + 1) & 1][j] = frag(dt + j * TILE, kk + 1);
+      }
+#pragma unroll
+      for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) acc[i][j] = mma16<PREC>(fa[kk & 1][i], fb[kk & 1][j], acc[i][j]);
+    }
+    __syncthreads();
+  }
+
+  if (want_dysum) {  // 256 / DCB threads share a channel block: fixed-order sum through LDS
+    float* red = reinterpret_cast<float*>(wsmpw);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) red[tid * 8 + j] = dsum[j];
+    __syncthreads();
+    if (tid < TN) {
+      const int cb = tid >> 3, j = tid & 7;
+      float t = 0.f;
+      for (int k = 0; k < 256 / DCB; ++k) t += red[(cb + DCB * k) * 8 + j];
+      p.dysum_ws[(size_t)slab_id * p.cout + co0 + tid] = t;
+    }
+  }
+  float* wsb = p.ws + (size_t)slab_id * p.cin * p.cout;
+#pragma unroll
+  for (int i = 0; i < MI; ++i)
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+      const int co = co0 + (wn * NJ + j) * 32 + l31;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int ci = ci0 + (wm * MI + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+        wsb[(size_t)ci * p.cout + co] = acc[i][j][r];
+      }
+    }
+}
+
+static int g_wgrad16_pw = 1;  // dsg_set_tuning key 30 (tests / A-B runs): 0 = the 3x3 kernel's one-tap instantiation
+void conv_wgrad16_set_pw(int v) { g_wgrad16_pw = v; }
+// tile multiples of the pointwise kernel for these channel counts, and its runs per image (>= 512 workgroups where the map allows)
+static void wgrad16_pw_plan(int c0, int c1, int cout, int n, int plane, int* mi, int* nj, int* rpi) {
+  const int cin = c0 + c1;
+  *mi = (cin % 128 == 0 && (c1 == 0 || c0 % 128 == 0)) ? 2 : 1;
+  *nj = cout % 128 == 0 ? 2 : 1;
+  const int pairs = (cin / (64 * *mi)) * (cout / (64 * *nj)), stages = plane / 64;
+  int r = std::max(1, std::min(stages, cdiv(512, pairs * n)));
+  while (stages % r != 0) ++r;  // (equal runs)
+  *rpi = r;
+}
+
 static int g_wgrad16_wide = 1;  // dsg_set_tuning key 29 (tests / A-B runs): 0 = the 64 x 64 workgroup everywhere
 void conv_wgrad16_set_wide(int v) { g_wgrad16_wide = v; }
 // co tiles per wave: 2 (a 64 ci x 128 co workgroup, one per CU) for the 3x3 gradients whose cout allows it
@@ -1582,6 +1792,13 @@ static size_t wgrad16_ws_bytes(int cin, int cout, int ksize, int n, int hout, in
     wout = 32;
   }
   size_t most = 0;  // (of the two workgroup shapes: the tuning key may change between the query and the launch)
+  if (ksize == 1) {  // (hout, wout: already re-tiled as rows of 32 pixels)
+    int mi, nj, rpi;
+    wgrad16_pw_plan(cin, 0, cout, n, hout * wout, &mi, &nj, &rpi);   // (nslab does not depend on the split between c0 and c1 ...
+    int mi1, nj1, rpi1;
+    wgrad16_pw_plan(64, cin - 64 > 0 ? cin - 64 : 0, cout, n, hout * wout, &mi1, &nj1, &rpi1);  // ... beyond MI = 1 vs 2)
+    most = (size_t)n * std::max(rpi, rpi1) * ((size_t)cin * cout + cout) * sizeof(float);
+  }
   for (int cot = 1; cot <= (ksize == 3 && cout % 128 == 0 ? 2 : 1); ++cot) {
     int strips, rsplit, spw;
     wgrad16_runs(cin, cout, n, hout, wout, cot, &strips, &rsplit, &spw);
@@ -1590,7 +1807,57 @@ static size_t wgrad16_ws_bytes(int cin, int cout, int ksize, int n, int hout, in
   return most;
 }
 
+static int launch_wgrad16_pw(const dsg_conv_wgrad_args* a, int plane, hipStream_t st) {
+  Wgrad16PwP p;
+  p.src0 = a->src0; p.src1 = a->src1; p.c0 = a->c0; p.c1 = a->c1; p.cin = a->c0 + a->c1; p.n = a->n; p.plane = plane;
+  p.cout = a->cout; p.dy = a->dy; p.dy_ctotal = a->dy_ctotal ? a->dy_ctotal : a->cout; p.dy_coff = a->dy_coff;
+  p.ss = a->gn_scale_shift; p.silu = a->silu; p.ws = static_cast<float*>(a->workspace);
+  int mi, nj, rpi;
+  wgrad16_pw_plan(p.c0, p.c1, p.cout, p.n, plane, &mi, &nj, &rpi);
+  p.ci_blocks = p.cin / (64 * mi);
+  p.rpi = rpi;
+  const int nslab = p.n * rpi;
+  const size_t need = (size_t)nslab * ((size_t)p.cin * p.cout + p.cout) * sizeof(float);
+  if (p.ws == nullptr || a->workspace_bytes < need)
+    return fail(DSG_ERR_WORKSPACE_TOO_SMALL, "dsg_conv2d_wgrad: workspace %zu bytes < required %zu", a->workspace_bytes, need);
+  p.dysum_ws = a->dy_sums ? p.ws + (size_t)nslab * p.cin * p.cout : nullptr;
+  int pi = -1;
+  if (prof_on())
+    pi = prof_begin(29, 2.0 * p.n * plane * (double)p.cout * p.cin, 2.0 * ((double)p.n * p.cin * plane + (double)p.n * p.cout * plane), st);
+  const dim3 grid(p.ci_blocks * (p.cout / (64 * nj)), nslab);
+  const bool bf = a->compute_dtype == DSG_BF16;
+  const int act = p.ss == nullptr ? 0 : (p.silu ? 1 : 2);
+#define DSG_W16PW_L(PRC, ACTV, MIV, NJV)                                                                                     \
+  hipLaunchKernelGGL((conv_wgrad16_pw_kernel<PRC, ACTV, MIV, NJV>), grid, dim3(256), (size_t)(2 * (2 * MIV + 2 * NJV) * 64 * 32 * 2), st, p)
+#define DSG_W16PW_A(PRC, MIV, NJV)                                                                                           \
+  do {                                                                                                                       \
+    if (act == 0) DSG_W16PW_L(PRC, 0, MIV, NJV);                                                                             \
+    else if (act == 1) DSG_W16PW_L(PRC, 1, MIV, NJV);                                                                        \
+    else DSG_W16PW_L(PRC, 2, MIV, NJV);                                                                                      \
+  } while (0)
+#define DSG_W16PW_T(PRC)                                                                                                     \
+  do {                                                                                                                       \
+    if (mi == 2 && nj == 2) DSG_W16PW_A(PRC, 2, 2);                                                                          \
+    else if (mi == 2) DSG_W16PW_A(PRC, 2, 1);                                                                                \
+    else if (nj == 2) DSG_W16PW_A(PRC, 1, 2);                                                                                \
+    else DSG_W16PW_A(PRC, 1, 1);                                                                                             \
+  } while (0)
+  if (bf) DSG_W16PW_T(1);
+  else DSG_W16PW_T(2);
+#undef DSG_W16PW_T
+#undef DSG_W16PW_A
+#undef DSG_W16PW_L
+  DSG_LAUNCH_CHECK();
+  const DysumJob job = dysum_job(a->dy_sums ? p.dysum_ws : nullptr, rpi, p.cout, p.n, a->dy_sums,
+                                 a->dy_sums_stride ? a->dy_sums_stride : p.cout, a->dy_bias_grad);
+  launch_wgrad_reduce(p.ws, nslab, 1, p.cin, p.cout, p.cin, p.cout, a->dw, st, &job);
+  prof_end(pi, st);
+  DSG_LAUNCH_CHECK();
+  return DSG_OK;
+}
+
 static int launch_wgrad16(const dsg_conv_wgrad_args* a, int hout, int wout, hipStream_t st) {
+  if (a->ksize == 1 && g_wgrad16_pw) return launch_wgrad16_pw(a, hout * wout, st);
   Wgrad16P p;
   const int taps = a->ksize * a->ksize;
   if (a->ksize == 1) {  // pointwise: rows of 32 pixels

@@ -469,12 +469,14 @@ int dsg_reduce_rows_add(const float* src, int32_t n, int32_t c, int32_t stride, 
 int dsg_attention_fwd_train(const float* qkv, float* out, float* lse, int32_t n, int32_t c, int32_t heads, int32_t l,
                             void* stream);
 int dsg_attention_fwd_train_dt(const float* qkv, float* out, float* lse, int32_t n, int32_t c, int32_t heads, int32_t l,
-                               int32_t dtype /* DSG_BF16: the mixed-precision tape's arithmetic, as dsg_attention_fwd_dt */, void* stream);
+                               int32_t dtype /* DSG_BF16 / DSG_F16: the mixed-precision tapes' arithmetic, as dsg_attention_fwd_dt */, void* stream);
 int dsg_attention_bwd(const float* qkv, const float* out, const float* dout, const float* lse, float* dqkv,
                       float* dsum_ws, int32_t n, int32_t c, int32_t heads, int32_t l, void* stream);
-/* The same with the arithmetic of the mixed-precision tape: dtype DSG_BF16 and head_dim 8, l % 32 == 0 run on the matrix cores
- * (q, k, v, dO, P and dS rounded once to bf16, fp32 scores and accumulators: torch.autocast's split for the attention core of
- * training_pipeline.py:84-86 under mixed_precision); DSG_F32 / DSG_F16 and every other shape: the exact kernels of dsg_attention_bwd. */
+/* The same with the arithmetic of the mixed-precision tapes: dtype DSG_BF16 / DSG_F16 and head_dim 8, l % 32 == 0 run on the
+ * matrix cores (q, k, v, dO, P and dS rounded once to the 16-bit type, fp32 scores and accumulators: torch.autocast's split for the
+ * attention core of training_pipeline.py:84-86 under mixed_precision; DSG_F16: dO is multiplied by a power of two before it is
+ * rounded and the results are divided by it, so dS stays in fp16's range with or without a loss scale -- the forward must have
+ * been dsg_attention_fwd_train_dt with the same dtype); DSG_F32 and every other shape: the exact kernels of dsg_attention_bwd. */
 int dsg_attention_bwd_dt(const float* qkv, const float* out, const float* dout, const float* lse, float* dqkv,
                          float* dsum_ws, int32_t n, int32_t c, int32_t heads, int32_t l, int32_t dtype, void* stream);
 /* y = x W^T + b backward: dw [out][in] and db [out] are accumulated (skipped when NULL), dx [n][in] written. */
@@ -566,6 +568,8 @@ int dsg_prof_dump(const char* csv_path);
  *  19  split-K for grids of at most half the CUs (needs dsg_conv_args.splitk_ws): [1] | 0
  *  25  dsg_unet_forward keeps q, k, v and the attention output channel-blocked (head_dim 8): [1] | 0
  *  23  resnet shortcuts fused into conv2's K loop (dsg_conv_args.sc_*): [1] | 0 (0: dsg_conv2d_fuses_shortcut answers no)
+ *  30  16-bit pointwise weight gradients on a kernel of their own (tiles up to 128 ci x 128 co): [1] | 0 = the 3x3 kernel's
+ *      one-tap instantiation (64 x 64 workgroups)
  *  29  16-bit 3x3 weight gradients with cout % 128 == 0 as 64 ci x 128 co workgroups (a wave keeps two co tiles, one
  *      workgroup per CU): [1] | 0 = 64 x 64 workgroups, two per CU
  *  20  fp32-equivalent 3x3 convs with cin <= 128 on channel-blocked tensors: 8-row tiles with ONE weight slab in LDS,

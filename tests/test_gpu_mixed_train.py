@@ -35,7 +35,9 @@ def _rnd(x, mode):
                                   ("two_co_blocks_of_128", 64, 0, 256, 8, 64, 5, True, 3),
                                   ("plain_128_couts", 192, 0, 128, 4, 32, 2, False, 3),
                                   ("pointwise_shortcut", 128, 64, 64, 16, 32, 3, False, 1),
-                                  ("pointwise_odd_rows", 64, 0, 128, 6, 32, 2, True, 1)], ids=lambda c: c[0])
+                                  ("pointwise_odd_rows", 64, 0, 128, 6, 32, 2, True, 1),
+                                  ("pointwise_128x128_tiles", 128, 128, 256, 8, 32, 3, True, 1),
+                                  ("pointwise_128x64_tiles", 256, 0, 64, 16, 32, 2, False, 1)], ids=lambda c: c[0])
 def test_wgrad16(case, mode):
     """dsg_conv2d_wgrad on blocked 16-bit x / dY (transposing LDS reads) vs an fp64 evaluation of the same rounded
     operands; 3x3 and pointwise."""
