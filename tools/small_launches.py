@@ -41,11 +41,11 @@ for ev in prof.events():
     if ev.device_type != torch.autograd.DeviceType.CPU or not ev.name.startswith("aten::"):
         continue
     dev_us = sum(k.duration for k in ev.kernels) if ev.kernels else 0.0
-    if not ev.kernels:
+    if not ev.kernels and ev.name not in ("aten::copy_", "aten::fill_", "aten::zero_"):   # (plain memcpys / memsets carry no kernel record)
         continue
     frame = next((f for f in ev.stack if "drivescenegen_amd" in f or "tools/" in f), ev.stack[0] if ev.stack else "?")
     key = (ev.name, frame.strip()[-90:])
-    agg[key][0] += len(ev.kernels)
+    agg[key][0] += max(1, len(ev.kernels))
     agg[key][1] += dev_us
 rows = sorted(agg.items(), key=lambda kv: -kv[1][0])
 tot = sum(v[0] for _, v in rows)
