@@ -116,6 +116,8 @@ SIGNATURES = {
     "dsg_abs_max": [_vp, _i64, _vp, _vp],
     "dsg_gn_bwd_blocked": [_vp, _i32, _vp, _i32, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp,
                            _vp, _vp, _i32, _vp],
+    "dsg_gn_bwd_blocked_add2": [_vp, _i32, _vp, _i32, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp,
+                                _vp, _vp, _vp, _i32, _vp],
     "dsg_gn_bwd_blocked_splits": [_i32],
     "dsg_channel_sums_blocked": [_vp, _i32, _i32, _i32, _vp, _i32, _i32, _vp],
     "dsg_add_dt": [_vp, _vp, _i64, _vp, _i32, _vp],

@@ -193,17 +193,32 @@ class _Tape:
     def __init__(self):
         self.recs = []
         self.grads = {}
+        self.pend = {}   # id(tensor) -> (gradient, second contribution) not summed yet (addg(lazy=True))
 
     def g(self, t):
+        pair = self.pend.pop(id(t), None) if self.pend else None
+        if pair is not None:
+            self.grads[id(t)] = ops.add(pair[0], pair[1])
         return self.grads.get(id(t))
 
     def setg(self, t, g):
         self.grads[id(t)] = g
 
-    def addg(self, t, g):
-        """Fan-in: an existing gradient and a new contribution are summed out of place."""
-        cur = self.grads.get(id(t))
+    def addg(self, t, g, lazy=False):
+        """Fan-in: an existing gradient and a new contribution are summed out of place.  lazy (the 16-bit tape's residual
+        branch): the pair is kept as it is -- the GroupNorm backward that runs next on `t` adds both in its own pass (g2) --
+        and summed only if somebody else asks for the gradient first (g)."""
+        cur = self.g(t)
+        if cur is not None and lazy:
+            self.pend[id(t)] = (cur, g)
+            self.grads.pop(id(t), None)
+            return
         self.grads[id(t)] = g if cur is None else ops.add(cur, g)
+
+    def g2(self, t):
+        """(gradient, second term or None) of `t` without materialising a pending pair"""
+        pair = self.pend.pop(id(t), None)
+        return pair if pair is not None else (self.grads.get(id(t)), None)
 
 
 def _forward(model, st: TrainState, tape: _Tape, sample, timesteps):
@@ -967,7 +982,7 @@ def _backward16(model, st: TrainState, tape: _Tape, dout):
                 sums = torch.empty((dy.shape[0], cout), dtype=torch.float32, device=dy.device)
                 sstride = cout
             if rec["res"] is not None:
-                tape.addg(rec["res"], dy)
+                tape.addg(rec["res"], dy, lazy=True)
             bg = st.grad(wname + ".bias")
             if rec["ups"]:   # weight gradient from the materialised nearest-x2 input, data gradient at full resolution
                 have = wgrad(ops.upsample_nearest2x(x0), None, dy, wname + ".weight", k, 1, False, None, False,
@@ -993,8 +1008,9 @@ def _backward16(model, st: TrainState, tape: _Tape, dout):
             if rec["gn"] is not None:
                 da = dgrad(dy, wn, k, cin0 + cin1, stride=rec["stride"])
                 gnn = rec["gn"]
+                a0, a0b = tape.g2(x0)
                 dx0, dx1 = ops.gn_bwd_blocked(x0, da, rec["ss"], rec["mr"], P[gnn + ".weight"].detach(), groups, rec["silu"],
-                                              st.grad(gnn + ".weight"), st.grad(gnn + ".bias"), src1=x1, add0=tape.g(x0),
+                                              st.grad(gnn + ".weight"), st.grad(gnn + ".bias"), src1=x1, add0=a0, add0b=a0b,
                                               add1=tape.g(x1) if x1 is not None else None)
                 done(gnn + ".weight", gnn + ".bias")
                 tape.setg(x0, dx0)

@@ -578,7 +578,7 @@ __global__ __launch_bounds__(256) void gn_bwd_apply_blk_kernel(const void* __res
                                                                const float* __restrict__ mr, const float* __restrict__ coef,
                                                                int silu, int hw, const void* __restrict__ add0,
                                                                const void* __restrict__ add1, void* __restrict__ dx0,
-                                                               void* __restrict__ dx1) {
+                                                               void* __restrict__ dx1, const void* __restrict__ add0b) {
   constexpr int PX = 4;
   const int cb = blockIdx.y, n = blockIdx.z, ct = c0 + c1;
   const int i0 = blockIdx.x * (256 * PX) + threadIdx.x;
@@ -586,6 +586,7 @@ __global__ __launch_bounds__(256) void gn_bwd_apply_blk_kernel(const void* __res
   const size_t xbase = (first ? ((size_t)n * c0 + cb * 8) : ((size_t)n * c1 + (cb * 8 - c0))) * hw;  // elements
   const unsigned short* xs = static_cast<const unsigned short*>(first ? src0 : src1) + xbase;
   const unsigned short* as = static_cast<const unsigned short*>(first ? add0 : add1);
+  const unsigned short* as2 = static_cast<const unsigned short*>(first ? add0b : nullptr);  // (a second fan-in term of source 0)
   unsigned short* ds = static_cast<unsigned short*>(first ? dx0 : dx1) + xbase;
   const size_t k = (size_t)n * ct + cb * 8;
   const unsigned short* dys = static_cast<const unsigned short*>(dy) + k * hw;
@@ -596,26 +597,29 @@ __global__ __launch_bounds__(256) void gn_bwd_apply_blk_kernel(const void* __res
     sc[j] = ss[2 * kj]; sh[j] = ss[2 * kj + 1]; mean[j] = mr[2 * kj]; rstd[j] = mr[2 * kj + 1];
     q0[j] = coef[3 * kj]; q1[j] = coef[3 * kj + 1]; q2[j] = coef[3 * kj + 2];
   }
-  uint4 xq[PX], dq[PX], aq[PX];
+  uint4 xq[PX], dq[PX], aq[PX], bq[PX];
 #pragma unroll
   for (int u = 0; u < PX; ++u) {
     const int i = min(i0 + 256 * u, hw - 1);  // (clamped: the tail's extra loads are not stored)
     xq[u] = *reinterpret_cast<const uint4*>(xs + (size_t)i * 8);
     dq[u] = *reinterpret_cast<const uint4*>(dys + (size_t)i * 8);
     if (as) aq[u] = *reinterpret_cast<const uint4*>(as + xbase + (size_t)i * 8);
+    if (as2) bq[u] = *reinterpret_cast<const uint4*>(as2 + xbase + (size_t)i * 8);
   }
 #pragma unroll
   for (int u = 0; u < PX; ++u) {
-    float x[8], du[8], ad[8], v[8];
+    float x[8], du[8], ad[8], ad2[8], v[8];
     unpack8t<DT>(xq[u], x);
     unpack8t<DT>(dq[u], du);
     if (as) unpack8t<DT>(aq[u], ad);
+    if (as2) unpack8t<DT>(bq[u], ad2);
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
       float d = du[j];
       if (silu) d *= dsilu(x[j] * sc[j] + sh[j]);
       v[j] = q0[j] * d - q1[j] - ((x[j] - mean[j]) * rstd[j]) * q2[j];
       if (as) v[j] += ad[j];
+      if (as2) v[j] += ad2[j];
     }
     const int i = i0 + 256 * u;
     if (i < hw) *reinterpret_cast<uint4*>(ds + (size_t)i * 8) = pack8t<DT>(v);
@@ -701,7 +705,17 @@ DSG_API int dsg_gn_bwd_blocked(const void* src0, int32_t c0, const void* src1, i
                                int32_t n, int32_t hw, int32_t groups, const void* add0, const void* add1, void* dx0,
                                void* dx1, float* dgamma, float* dbeta, double* ws_s12, float* ws_coef, int32_t dtype,
                                void* stream) {
+  return dsg_gn_bwd_blocked_add2(src0, c0, src1, c1, dy, scale_shift, mean_rstd, gamma, silu, n, hw, groups, add0, nullptr, add1,
+                                 dx0, dx1, dgamma, dbeta, ws_s12, ws_coef, dtype, stream);
+}
+
+DSG_API int dsg_gn_bwd_blocked_add2(const void* src0, int32_t c0, const void* src1, int32_t c1, const void* dy,
+                                    const float* scale_shift, const float* mean_rstd, const float* gamma, int32_t silu,
+                                    int32_t n, int32_t hw, int32_t groups, const void* add0, const void* add0b, const void* add1,
+                                    void* dx0, void* dx1, float* dgamma, float* dbeta, double* ws_s12, float* ws_coef,
+                                    int32_t dtype, void* stream) {
   using namespace dsg;
+  DSG_CHECK_ARG(add0b == nullptr || add0 != nullptr, "dsg_gn_bwd_blocked_add2: add0b without add0");
   DSG_CHECK_ARG(src0 && dy && scale_shift && mean_rstd && gamma && dx0 && dgamma && dbeta && ws_s12 && ws_coef,
                 "dsg_gn_bwd_blocked: NULL pointer");
   DSG_CHECK_DT16(dtype, "dsg_gn_bwd_blocked");
@@ -734,10 +748,10 @@ DSG_API int dsg_gn_bwd_blocked(const void* src0, int32_t c0, const void* src1, i
   DSG_LAUNCH_CHECK();
   if (dtype == DSG_BF16)
     hipLaunchKernelGGL(gn_bwd_apply_blk_kernel<1>, dim3(cdiv(hw, 1024), c / 8, n), dim3(256), 0, st, src0, c0, src1, c1, dy,
-                       scale_shift, mean_rstd, ws_coef, silu, hw, add0, add1, dx0, dx1);
+                       scale_shift, mean_rstd, ws_coef, silu, hw, add0, add1, dx0, dx1, add0b);
   else
     hipLaunchKernelGGL(gn_bwd_apply_blk_kernel<2>, dim3(cdiv(hw, 1024), c / 8, n), dim3(256), 0, st, src0, c0, src1, c1, dy,
-                       scale_shift, mean_rstd, ws_coef, silu, hw, add0, add1, dx0, dx1);
+                       scale_shift, mean_rstd, ws_coef, silu, hw, add0, add1, dx0, dx1, add0b);
   DSG_LAUNCH_CHECK();
   return DSG_OK;
 }

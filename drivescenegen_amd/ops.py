@@ -563,8 +563,9 @@ def gn_bwd(src0, dy, ss, mr, gamma, groups, silu, dgamma, dbeta, src1=None, add0
     return dx0, dx1
 
 
-def gn_bwd_blocked(src0, dy, ss, mr, gamma, groups, silu, dgamma, dbeta, src1=None, add0=None, add1=None):
-    """gn_bwd on channel-blocked 16-bit tensors [N, C/8, H, W, 8] (dy covers cat(src0, src1)); returns (dx0, dx1)."""
+def gn_bwd_blocked(src0, dy, ss, mr, gamma, groups, silu, dgamma, dbeta, src1=None, add0=None, add1=None, add0b=None):
+    """gn_bwd on channel-blocked 16-bit tensors [N, C/8, H, W, 8] (dy covers cat(src0, src1)); returns (dx0, dx1).
+    add0 / add0b / add1: gradients already waiting on the sources (fan-in), added in the same pass."""
     n, cb0, h, w, _ = src0.shape
     c0, c1 = 8 * cb0, (8 * src1.shape[1] if src1 is not None else 0)
     c, hw = c0 + c1, h * w
@@ -575,10 +576,10 @@ def gn_bwd_blocked(src0, dy, ss, mr, gamma, groups, silu, dgamma, dbeta, src1=No
     s12 = torch.empty(n * c * 2 * (1 + splits), dtype=torch.float64, device=src0.device)
     coef = torch.empty((n, c, 3), dtype=torch.float32, device=src0.device)
     with torch.cuda.device(src0.device):
-        _lib.check(lib.dsg_gn_bwd_blocked(_lib.ptr(src0), c0, _lib.ptr(src1), c1, _lib.ptr(dy), _lib.ptr(ss), _lib.ptr(mr),
-                                          _lib.ptr(gamma), int(silu), n, hw, groups, _lib.ptr(add0), _lib.ptr(add1),
-                                          _lib.ptr(dx0), _lib.ptr(dx1), _lib.ptr(dgamma), _lib.ptr(dbeta), _lib.ptr(s12),
-                                          _lib.ptr(coef), _DT_OF[src0.dtype], _st(src0)))
+        _lib.check(lib.dsg_gn_bwd_blocked_add2(_lib.ptr(src0), c0, _lib.ptr(src1), c1, _lib.ptr(dy), _lib.ptr(ss), _lib.ptr(mr),
+                                               _lib.ptr(gamma), int(silu), n, hw, groups, _lib.ptr(add0), _lib.ptr(add0b),
+                                               _lib.ptr(add1), _lib.ptr(dx0), _lib.ptr(dx1), _lib.ptr(dgamma), _lib.ptr(dbeta),
+                                               _lib.ptr(s12), _lib.ptr(coef), _DT_OF[src0.dtype], _st(src0)))
     return dx0, dx1
 
 

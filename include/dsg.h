@@ -444,6 +444,14 @@ int dsg_gn_bwd_blocked(const void* src0, int32_t c0, const void* src1, int32_t c
                        const float* scale_shift, const float* mean_rstd, const float* gamma, int32_t silu, int32_t n,
                        int32_t hw, int32_t groups, const void* add0, const void* add1, void* dx0, void* dx1,
                        float* dgamma, float* dbeta, double* ws_s12, float* ws_coef, int32_t dtype, void* stream);
+/* The same with a second fan-in term for source 0 (dx0 += add0 + add0b in fp32, rounded once): a resnet input that is both a
+ * skip connection and the residual of its own block has two incoming gradients when its GroupNorm's backward runs -- this
+ * saves the pass that added them (6 per training step of the configs[4] network). */
+int dsg_gn_bwd_blocked_add2(const void* src0, int32_t c0, const void* src1, int32_t c1, const void* dy,
+                            const float* scale_shift, const float* mean_rstd, const float* gamma, int32_t silu,
+                            int32_t n, int32_t hw, int32_t groups, const void* add0, const void* add0b, const void* add1,
+                            void* dx0, void* dx1, float* dgamma, float* dbeta, double* ws_s12, float* ws_coef,
+                            int32_t dtype, void* stream);
 int dsg_gn_bwd_blocked_splits(int32_t hw);
 int dsg_channel_sums_blocked(const void* x, int32_t n, int32_t c, int32_t hw, float* out_nc, int32_t out_stride,
                              int32_t dtype, void* stream);
