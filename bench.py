@@ -225,6 +225,39 @@ def mixed_leg(args, dtype="bf16"):
     return rec
 
 
+def train_ref_leg(args, steps=5):
+    """Extra record: the reference's OWN training operating point (train.py:16,24,39-57: the 3-channel default network,
+    mixed_precision='fp16', train_batch_size 14) through the Accelerator mirror's loop body (training_pipeline.py:70-91 =
+    train_loop.train_step: add_noise, forward, MSE, scaled backward, unscale + clip 1.0, AdamW, cosine LR)."""
+    import drivescenegen_amd as d
+    from drivescenegen_amd import synth
+    from drivescenegen_amd.configs import DEFAULT3, synth_weights
+    from drivescenegen_amd.train_loop import train_step
+    dev = torch.device("cuda", int(os.environ.get("LOCAL_RANK", 0)))
+    batch = 14
+    acc = d.Accelerator(mixed_precision="fp16")
+    net = synth_weights(d.UNet2DModel(**DEFAULT3)).to(dev)
+    opt = d.AdamW(net.parameters(), lr=1e-4)
+    lrs = d.get_cosine_schedule_with_warmup(optimizer=opt, num_warmup_steps=500, num_training_steps=50000)
+    net, opt, lrs = acc.prepare(net, opt, lrs)
+    sch = d.DDPMScheduler()
+    x0 = torch.from_numpy(synth.synth_scene_rasters(batch, 3, 256, 256, 14555)).to(dev)
+    for _ in range(3):
+        train_step(acc, net, sch, opt, lrs, x0)
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        loss = train_step(acc, net, sch, opt, lrs, x0)
+    torch.cuda.synchronize(dev)
+    dt = time.perf_counter() - t0
+    assert torch.isfinite(loss).all()
+    return {"metric": "training throughput, the reference's own configuration (train.py: default 3-channel U-Net, fp16 AMP + "
+                      "GradScaler, batch 14)", "value": batch * steps / dt, "unit": "images/s", "ms_per_step": dt / steps * 1e3,
+            "steps": steps, "batch": batch, "dtype": "f16 storage / MFMA, f32 accumulate and master weights",
+            "loss": float(loss), "loss_scale": float(acc.scaler.get_scale()) if acc.scaler is not None else None,
+            "peak_mem_gib": torch.cuda.max_memory_allocated(dev) / 2 ** 30}
+
+
 def train_leg(args, dtype="fp32", batch=16, steps=3):
     """Extra record: optimizer steps of the training loop (training_pipeline.py:70-91: add_noise, U-Net forward, MSE,
     backward, clip 1.0, AdamW, cosine LR) on BASELINE configs[2]'s network at `batch` samples on one GPU; images/s."""
@@ -517,6 +550,7 @@ def main():
             extras = {}
             for name, fn in (("mixed_bf16", lambda: mixed_leg(args, "bf16")), ("train_fp32", lambda: train_leg(args, "fp32")),
                              ("train_bf16", lambda: train_leg(args, "bf16", batch=32)),
+                             ("train_fp16_reference_point", lambda: train_ref_leg(args)),
                              ("small_batch_sampling", lambda: small_batch_leg(args))):
                 try:
                     extras[name] = fn()
