@@ -172,30 +172,58 @@ __global__ __launch_bounds__(256) void splitk_reduce_blk_kernel(const float* __r
   double s[8], ss[8];
 #pragma unroll
   for (int j = 0; j < 8; ++j) s[j] = ss[j] = 0.0;
-  for (int i = threadIdx.x; i < hw; i += 256) {
-    const size_t at = base + (size_t)i * 8;
-    float v[8];
+  // Four pixels per thread and trip, every load of the trip issued before the first use (at most 4 slices: conv_h2_splitk_slices):
+  // the maps this pass serves are small (64 .. 4096 pixels per image) and one pixel per trip made it a chain of hw / 256
+  // dependent round trips -- 11 us per launch, 29 launches in a batch-1 step.  Same sums in the same order per thread.
+  constexpr int RPX = 4, MAXS = 4;
+  for (int i0 = threadIdx.x; i0 < hw; i0 += 256 * RPX) {
+    float4 pa[RPX][MAXS][2], ra[RPX][2];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) v[j] = 0.f;
-    for (int k = 0; k < slices; ++k) {
-      const float4 a0 = *reinterpret_cast<const float4*>(part + k * slab + at);
-      const float4 a1 = *reinterpret_cast<const float4*>(part + k * slab + at + 4);
-      v[0] += a0.x; v[1] += a0.y; v[2] += a0.z; v[3] += a0.w;
-      v[4] += a1.x; v[5] += a1.y; v[6] += a1.z; v[7] += a1.w;
+    for (int u = 0; u < RPX; ++u) {
+      const int i = i0 + 256 * u;
+      if (i < hw) {
+        const size_t at = base + (size_t)i * 8;
+#pragma unroll
+        for (int k = 0; k < MAXS; ++k)
+          if (k < slices) {
+            pa[u][k][0] = *reinterpret_cast<const float4*>(part + k * slab + at);
+            pa[u][k][1] = *reinterpret_cast<const float4*>(part + k * slab + at + 4);
+          }
+        if (res) {
+          ra[u][0] = *reinterpret_cast<const float4*>(res + at);
+          ra[u][1] = *reinterpret_cast<const float4*>(res + at + 4);
+        }
+      }
     }
 #pragma unroll
-    for (int j = 0; j < 8; ++j) v[j] += add[j];   // (the epilogue's order: accumulators + (bias + temb), then + residual)
-    if (res) {
-      const float4 r0 = *reinterpret_cast<const float4*>(res + at), r1 = *reinterpret_cast<const float4*>(res + at + 4);
-      v[0] += r0.x; v[1] += r0.y; v[2] += r0.z; v[3] += r0.w;
-      v[4] += r1.x; v[5] += r1.y; v[6] += r1.z; v[7] += r1.w;
-    }
-    *reinterpret_cast<float4*>(dst + at) = make_float4(v[0], v[1], v[2], v[3]);
-    *reinterpret_cast<float4*>(dst + at + 4) = make_float4(v[4], v[5], v[6], v[7]);
+    for (int u = 0; u < RPX; ++u) {
+      const int i = i0 + 256 * u;
+      if (i >= hw) break;
+      const size_t at = base + (size_t)i * 8;
+      float v[8];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      s[j] += (double)v[j];
-      ss[j] += (double)v[j] * v[j];
+      for (int j = 0; j < 8; ++j) v[j] = 0.f;
+#pragma unroll
+      for (int k = 0; k < MAXS; ++k)
+        if (k < slices) {
+          const float4 a0 = pa[u][k][0], a1 = pa[u][k][1];
+          v[0] += a0.x; v[1] += a0.y; v[2] += a0.z; v[3] += a0.w;
+          v[4] += a1.x; v[5] += a1.y; v[6] += a1.z; v[7] += a1.w;
+        }
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[j] += add[j];   // (the epilogue's order: accumulators + (bias + temb), then + residual)
+      if (res) {
+        const float4 r0 = ra[u][0], r1 = ra[u][1];
+        v[0] += r0.x; v[1] += r0.y; v[2] += r0.z; v[3] += r0.w;
+        v[4] += r1.x; v[5] += r1.y; v[6] += r1.z; v[7] += r1.w;
+      }
+      *reinterpret_cast<float4*>(dst + at) = make_float4(v[0], v[1], v[2], v[3]);
+      *reinterpret_cast<float4*>(dst + at + 4) = make_float4(v[4], v[5], v[6], v[7]);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        s[j] += (double)v[j];
+        ss[j] += (double)v[j] * v[j];
+      }
     }
   }
   if (stats == nullptr) return;

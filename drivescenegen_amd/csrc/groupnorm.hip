@@ -157,6 +157,13 @@ __global__ __launch_bounds__(FP_T) void gn_finalize_parts_kernel(const double* _
   double s = 0.0, ss = 0.0;
   float sq_max = 0.f;  // largest per-tile sum of squares: its square root bounds every |value| of the group
   const int ch0 = g * cpg, ch1 = ch0 + cpg;
+  // gamma / beta of this lane's first channel go out with the partials' loads, not in a round trip of their own behind the
+  // reduction (a launch of this kernel is 5 us of dependent latencies, 46 times a step)
+  float gam0 = 0.f, bet0 = 0.f;
+  if (lane < cpg) {
+    gam0 = gamma[ch0 + lane];
+    bet0 = beta[ch0 + lane];
+  }
   {
     const int a = min(ch0, c0), b = min(ch1, c0);  // the group's channels that live in source 0
     const double2* p = reinterpret_cast<const double2*>(st0 + ((size_t)ni * c0 + a) * t0 * 2);
@@ -207,9 +214,9 @@ __global__ __launch_bounds__(FP_T) void gn_finalize_parts_kernel(const double* _
   const float meanf = (float)mean;
   for (int k = lane; k < cpg; k += FP_T) {
     const int ch = g * cpg + k;
-    const float sc = rstd * gamma[ch];
+    const float sc = rstd * (k == lane ? gam0 : gamma[ch]);
     out[2 * ((size_t)ni * c + ch)] = sc;
-    out[2 * ((size_t)ni * c + ch) + 1] = beta[ch] - meanf * sc;
+    out[2 * ((size_t)ni * c + ch) + 1] = (k == lane ? bet0 : beta[ch]) - meanf * sc;
     if (mr) {  // training keeps (mean, rstd) per (n, c) for the backward pass
       mr[2 * ((size_t)ni * c + ch)] = meanf;
       mr[2 * ((size_t)ni * c + ch) + 1] = rstd;
