@@ -856,7 +856,7 @@ DSG_API int dsg_set_tuning(int32_t key, int32_t value) {
     dsg::conv_h2_set_enabled(value);
     return DSG_OK;
   }
-  if (key == 3 && (value == 0 || value == 2 || value == 4)) {
+  if (key == 3 && (value == 0 || value == 2 || value == 3 || value == 4)) {
     dsg::conv_h2_set_rows(value);
     return DSG_OK;
   }

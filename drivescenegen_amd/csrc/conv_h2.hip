@@ -103,7 +103,10 @@ bool conv_h2_takes_operand(const dsg_conv_args* a, int hout, int wout, bool want
 static bool rows16_pays(int b16) {
   if (g_h2.rows == 2 || b16 <= 0) return false;
   if (g_h2.rows == 4) return true;
-  if (b16 < 256) return false;
+  // up to 128 tiles the 8-row grid still fits one round at 0.55 each.  129 .. 255 tiles go by the rounds rule as well: 160
+  // workgroups of 16 rows on 62 % of the CUs beat 320 of 8 rows in two rounds (batch-5 sampling 6.03 -> 5.81 ms per step,
+  // batch 3 4.05 -> 3.94, same-box A/B; the rule used to be "never below 256 tiles": key 3 = 3 keeps it for comparisons)
+  if (g_h2.rows == 3 ? b16 < 256 : b16 <= 128) return false;
   const int r16 = (b16 + 255) / 256, r8 = (2 * b16 + 255) / 256;
   return 100 * r16 <= 55 * r8;
 }

@@ -559,7 +559,8 @@ int dsg_prof_dump(const char* csv_path);
  * (Defaults in brackets; python: env DSG_TUNING="key=value,..." implies DSG_TESTING=1.)
  *   1  K-chunk of the fp32 conv kernel: [0 = by grid size] | 4 | 8
  *   2  fp16x2-split conv kernels: [1] | 0 = every contraction on the f32 MFMA
- *   3  rows per wave of the split conv kernel: [0 = by grid size] | 2 | 4
+ *   3  rows per wave of the split conv kernel: [0 = by grid size: rounds of 256 workgroups] | 2 | 4 | 3 = by grid size, but never 16-row tiles
+ *      below 256 of them (the rule before round 3's end)
  *   5  GroupNorm statistics from the producing conv's epilogue: [1] | 0 = a pass of their own
  *   6  waves per workgroup of the 16-row split conv: [4] | 8 (two per SIMD)
  *   7  3x3 weight gradient on the split path: [1] | 0 = f32 MFMA
