@@ -154,3 +154,31 @@ def test_small_grid_split_k_matches_the_one_slice_kernel(kind):
     a, b = ops.from_blocked(one).cpu(), ops.from_blocked(many).cpu()
     assert rel_l2(b, a) <= 1e-6 and rel_l2(b, ref) <= 2e-6 and rel_l2(a, ref) <= 2e-6
     assert torch.allclose(st_many.cpu().sum(2), st_one.cpu().sum(2), rtol=1e-5, atol=1e-3)
+
+
+def test_tile_height_rule_keeps_the_bits_at_batch_5():
+    """Batch-5 sampling (generation.py:14-20): the 64 x 64 level's convs are 160 tiles of 16 rows -- one round on 62 % of the CUs
+    -- where the rule before the end of round 3 took 320 tiles of 8 rows in two rounds (dsg_set_tuning key 3 = 3 keeps that rule).
+    The tile height moves pixels between workgroups, not products between sums: results and statistics are bit-identical."""
+    from drivescenegen_amd import _lib
+    n, c, cout, h, w = 5, 256, 256, 64, 64
+    x, wt = _t(31, (n, c, h, w)), _t(32, (cout, c, 3, 3), 1.0 / np.sqrt(c * 9))
+    bias, tproj = _t(33, (cout,), 0.1), _t(34, (n, cout), 0.3)
+    xb = ops.to_blocked(x.to(DEV))
+    gamma, beta = (1 + _t(35, (c,), 0.1)), _t(36, (c,), 0.1)
+    ss = ops.gn_scale_shift_from_parts(ops.gn_channel_stats_blocked(xb), gamma.to(DEV), beta.to(DEV), 32, 1e-5, h * w)
+    call = lambda: ops.conv2d_fused(xb, ops.relayout_conv_weight(wt.to(DEV)), bias.to(DEV), ksize=3, gn_scale_shift=ss, silu=True,
+                                    cout=cout, temb=tproj.to(DEV), temb_stride=cout, src_blocked=True, dst_blocked=True,
+                                    want_stats=True, weight_h2=ops.relayout_conv_weight_h2(wt.to(DEV)))
+    lib = _lib.load()
+    try:
+        _lib.check(lib.dsg_set_tuning(3, 3))
+        old, st_old = call()
+        _lib.check(lib.dsg_set_tuning(3, 0))
+        new, st_new = call()
+    finally:
+        lib.dsg_set_tuning(3, 0)
+    assert torch.equal(old, new) and torch.equal(st_old, st_new)
+    act = F.silu(F.group_norm(x.double(), 32, gamma.double(), beta.double(), 1e-5))
+    ref = F.conv2d(act, wt.double(), bias.double(), padding=1) + tproj.double()[:, :, None, None]
+    assert rel_l2(ops.from_blocked(new).cpu(), ref) <= 2e-6
