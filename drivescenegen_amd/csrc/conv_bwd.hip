@@ -304,10 +304,10 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
 
 // The same reduction for the layers with FEW slabs and a big gradient (256 / 512 channels: 2.4 M elements, 8-32 slabs),
 // where the kernel above is dominated by its output: each lane's four results go to [co][ci][tp] addresses a whole
-// cin x taps row apart -- scattered 4-byte read-modify-writes.  Here a workgroup owns a 32 co x 2 ci x all-taps tile: its
-// four waves each sum every fourth slab (thread = (co, ci), one value per tap: 128-byte runs along co), the partial tiles
-// meet in LDS in a fixed order, and dw is updated in runs of 2 ci x taps contiguous floats per co.
-constexpr int WRT_CO = 32, WRT_CI = 2;
+// cin x taps row apart -- scattered 4-byte read-modify-writes.  Here a workgroup owns a 64 co x 4 ci x all-taps tile: its
+// four waves each sum every fourth slab (thread = (4 co, ci), one float4 per tap: 256-byte runs along co), the partial tiles
+// meet in LDS in a fixed order, and dw is updated in runs of 4 ci x taps contiguous floats per co.
+constexpr int WRT_CO = 64, WRT_CI = 4;  // (16 lanes x float4 along co, 4 ci rows per wave: 256-byte runs, 16 bytes per lane)
 __global__ __launch_bounds__(256) void wgrad_reduce_t_kernel(const float* __restrict__ ws, int nslab, int taps, int cin,
                                                              int cout, int cin_pad, int cout_pad,
                                                              float* __restrict__ dw, DysumJob job, int main_rows) {
@@ -318,22 +318,41 @@ __global__ __launch_bounds__(256) void wgrad_reduce_t_kernel(const float* __rest
   }
   __shared__ float tile[4][WRT_CO][WRT_CI * 9 + 1];  // [slab wave][co][ci * taps + tp]
   const int co0 = blockIdx.x * WRT_CO, ci0 = blockIdx.y * WRT_CI;
-  const int t = threadIdx.x, sl = t >> 6, co = t & 31, ci = (t >> 5) & 1;
+  const int t = threadIdx.x, sl = t >> 6, co = (t & 15) * 4, ci = (t >> 4) & 3;
   const int64_t tstride = (int64_t)cin_pad * cout_pad, slab = (int64_t)taps * tstride;
-  float acc[9];
+  float4 acc[9];
 #pragma unroll
-  for (int tp = 0; tp < 9; ++tp) acc[tp] = 0.f;
-  if (ci0 + ci < cin_pad && co0 + co < cout_pad) {
+  for (int tp = 0; tp < 9; ++tp) acc[tp] = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (ci0 + ci < cin_pad && co0 + co < cout_pad) {  // (cout_pad % 64 == 0: a float4 never straddles the row's end)
     const float* p = ws + (int64_t)sl * slab + (int64_t)(ci0 + ci) * cout_pad + co0 + co;
-    for (int k = sl; k < nslab; k += 4, p += 4 * slab) {
+    int k = sl;
+    for (; k + 4 < nslab; k += 8, p += 8 * slab) {  // two of this wave's slabs per trip: 18 loads in flight (256 workgroups of
+#pragma unroll                                  // four waves are one per CU: the loop is a chain of round trips)
+      for (int tp = 0; tp < 9; ++tp)
+        if (tp < taps) {
+          const float4 v = *reinterpret_cast<const float4*>(p + tp * tstride);
+          const float4 u = *reinterpret_cast<const float4*>(p + 4 * slab + tp * tstride);
+          acc[tp].x += v.x; acc[tp].y += v.y; acc[tp].z += v.z; acc[tp].w += v.w;
+          acc[tp].x += u.x; acc[tp].y += u.y; acc[tp].z += u.z; acc[tp].w += u.w;
+        }
+    }
+    for (; k < nslab; k += 4, p += 4 * slab) {
 #pragma unroll
       for (int tp = 0; tp < 9; ++tp)
-        if (tp < taps) acc[tp] += p[tp * tstride];
+        if (tp < taps) {
+          const float4 v = *reinterpret_cast<const float4*>(p + tp * tstride);
+          acc[tp].x += v.x; acc[tp].y += v.y; acc[tp].z += v.z; acc[tp].w += v.w;
+        }
     }
   }
 #pragma unroll
   for (int tp = 0; tp < 9; ++tp)
-    if (tp < taps) tile[sl][co][ci * taps + tp] = acc[tp];
+    if (tp < taps) {
+      tile[sl][co][ci * taps + tp] = acc[tp].x;
+      tile[sl][co + 1][ci * taps + tp] = acc[tp].y;
+      tile[sl][co + 2][ci * taps + tp] = acc[tp].z;
+      tile[sl][co + 3][ci * taps + tp] = acc[tp].w;
+    }
   __syncthreads();
   const int run = WRT_CI * taps;  // contiguous floats per co in dw
   for (int o = t; o < WRT_CO * run; o += 256) {
