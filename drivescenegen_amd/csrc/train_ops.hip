@@ -118,6 +118,7 @@ __global__ __launch_bounds__(256) void gn_bwd_finalize_kernel(const double* __re
     const int g0 = (ci / cpg) * cpg;
     for (int ni = t; ni < n; ni += nn) {
       double g1 = 0.0, g2 = 0.0;
+#pragma unroll 4
       for (int k = 0; k < cpg; ++k) {
         const size_t nc = (size_t)ni * c + g0 + k;
         g1 += (double)gamma[g0 + k] * sum_of(nc, 0);
@@ -219,6 +220,7 @@ __global__ void reduce_rows_kernel(const float* __restrict__ src, int n, int c, 
   const int ci = blockIdx.x * blockDim.x + threadIdx.x;
   if (ci >= c) return;
   double s = 0.0;
+#pragma unroll 8   // (loads in flight together; the sum stays in row order)
   for (int k = 0; k < n; ++k) s += src[(size_t)k * stride + ci];
   dst[ci] += (float)s;
 }
@@ -237,6 +239,7 @@ __global__ void linear_wgrad_kernel(const float* __restrict__ x, const float* __
   if (i >= (int64_t)in_f * out_f) return;
   const int k = (int)(i % in_f), m = (int)(i / in_f);
   float s = 0.f;
+#pragma unroll 8   // (the batch's loads in flight together: 24 launches of this kernel per step are chains of round trips otherwise)
   for (int j = 0; j < n; ++j) s = fmaf(dy[(size_t)j * dy_stride + m], x[(size_t)j * in_f + k], s);
   dw[i] += s;
 }
