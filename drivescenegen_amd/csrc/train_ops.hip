@@ -309,10 +309,15 @@ __global__ __launch_bounds__(256) void sqdiff_partial_kernel(const float* __rest
 // out[0] = scale * sum(partial) (mode 0) or sqrt(sum(partial)) (mode 1); fixed order -> deterministic
 __global__ void finish_sum_kernel(const double* __restrict__ partial, int nb, double scale, int mode,
                                   float* __restrict__ out) {
-  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  // one wave: lane t sums partials t, t + 64, ... in order, then a fixed butterfly (one thread walking all of them -- a few
+  // thousand dependent adds behind as many loads -- was 135 us, twice a training step)
+  if (blockIdx.x != 0 || threadIdx.x >= 64) return;
   double s = 0.0;
-  for (int i = 0; i < nb; ++i) s += partial[i];
-  out[0] = mode == 0 ? (float)(s * scale) : (float)sqrt(s);
+#pragma unroll 8
+  for (int i = threadIdx.x; i < nb; i += 64) s += partial[i];
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+  if (threadIdx.x == 0) out[0] = mode == 0 ? (float)(s * scale) : (float)sqrt(s);
 }
 
 // torch.optim.AdamW single-tensor semantics (decoupled weight decay), gradient scaled on the fly by
