@@ -72,6 +72,7 @@ __global__ __launch_bounds__(256) void gn_channel_stats_blk_kernel(const void* _
   double s[8], ss[8];
 #pragma unroll
   for (int j = 0; j < 8; ++j) s[j] = ss[j] = 0.0;
+#pragma unroll 4   // (several pixels' loads in flight per thread; the sums stay in pixel order)
   for (int i = threadIdx.x; i < hw; i += 256) {
     float v[8];
     if (dt) {
