@@ -393,12 +393,15 @@ __device__ __forceinline__ void weight_pack3x3_pair(const float* __restrict__ w,
   const int ndim = kind == 3 ? cin_w : cout_w;
   const int np = dt == 0 ? 2 : 1;
   {
-    const int j = (int)(i % 8);
-    int64_t r = i / 8;
-    const int nn = (int)(r % ndim);
-    r /= ndim;
-    const int g = (int)(r % 2);
-    const int q = (int)(r / 2);
+    // (32-bit index arithmetic: an item index is below cout x cin < 2^31, and a 64-bit division is ~100 instructions -- the batched
+    //  refresh of all weights was bound by them)
+    const unsigned u = (unsigned)i;
+    const int j = (int)(u & 7u);
+    unsigned r = u >> 3;
+    const unsigned rq = r / (unsigned)ndim;
+    const int nn = (int)(r - rq * (unsigned)ndim);
+    const int g = (int)(rq & 1u);
+    const int q = (int)(rq >> 1);
     const int kk = q * 16 + g * 8 + j;
     const float* wp = w + (kind == 0 ? ((int64_t)nn * cin_w + kk) : ((int64_t)kk * cin_w + nn)) * 9;
     float v[9];
