@@ -34,6 +34,7 @@ import torch  # noqa: E402
 PEAK_F32_TFLOPS = 157.3  # /opt/skills/guides/MI355X_MICROARCH.md: f32 vector = f32 MFMA peak
 PEAK_F16_TFLOPS = 2500.0  # dense f16/bf16 MFMA peak (same guide)
 PEAK_HBM_GBS = 8000.0
+CFG4_FLOPS_IMG = 531e9   # configs[3] forward, per image
 
 
 def _cfg():
@@ -83,11 +84,14 @@ def gpu_leg(args, rank, world):
     # HIP events bracket the conv launches of every PROF_EVERY-th step of the timed region (all 50 DDIM timesteps run
     # the same launches): the roofline figures are live, from inside the timed region, at ~1/5 of the event cost
     lib.dsg_prof_enable(1 if not args.no_prof else 0)
+    clock = StepClock(dev)
     t0 = time.perf_counter()
+    clock.tick()
     for i in range(args.steps):
         if not args.no_prof:
             lib.dsg_prof_enable(3 if i % PROF_EVERY == 0 else 2)
         x = step(args.warmup + i, x)
+        clock.tick()
     barrier()
     dt = time.perf_counter() - t0
     per_rank = [dt]
@@ -119,7 +123,7 @@ def gpu_leg(args, rank, world):
         if args.prof_dump and rank == 0:
             _lib.check(lib.dsg_prof_dump(args.prof_dump.encode()))
         lib.dsg_prof_enable(0)
-    return dt, prof, per_rank
+    return dt, prof, per_rank, clock.spread()
 
 
 def cpu_leg(args):
@@ -154,6 +158,25 @@ def cpu_leg(args):
 PROF_EVERY = 5
 
 
+class StepClock:
+    """GPU time of each step of a timed loop from events recorded on the launch stream at the step boundaries (no host
+    synchronisation inside the loop); `spread()` = min / median / max ms over the steps -- box noise made visible."""
+
+    def __init__(self, dev):
+        self.dev, self.ev = dev, []
+
+    def tick(self):
+        e = torch.cuda.Event(enable_timing=True)
+        e.record(torch.cuda.current_stream(self.dev))
+        self.ev.append(e)
+
+    def spread(self):
+        if len(self.ev) < 2:
+            return None
+        ms = sorted(a.elapsed_time(b) for a, b in zip(self.ev[:-1], self.ev[1:]))
+        return {"min": ms[0], "median": ms[len(ms) // 2], "max": ms[-1], "n": len(ms)}
+
+
 def _prof_rows(lib, _lib, names):
     rows = {}
     for kid, nm in names.items():
@@ -166,21 +189,43 @@ def _prof_rows(lib, _lib, names):
     return rows
 
 
-def mixed_leg(args, dtype="bf16"):
-    """Extra record: BASELINE configs[4]'s network (256x256x8 raster, default U-Net, 56,580,360 parameters) in mixed
-    precision -- bf16 matrix-core products, 16-bit channel-blocked activations, fp32 statistics / accumulators --
-    as denoising steps (dsg_unet_forward + dsg_ddim_step) at --mixed-batch samples.  Its dominant kernel is priced against
-    BOTH roofs: 2.5 PF/s dense bf16 MFMA and 8 TB/s HBM (the 64 / 128-channel layers are HBM-bound in 16 bits)."""
+FWD_CLASSES_F32 = {6: "conv3x3_s1_mfma_f16x2split", 10: "conv3x3_s1_mfma_f16x2split_two_wg_per_cu",
+                   13: "conv3x3_plus_fused_shortcut_f16x2split", 14: "conv3x3_plus_fused_shortcut_f16x2split_two_wg_per_cu",
+                   7: "conv3x3_upsample_mfma_f16x2split", 2: "conv3x3_s2_mfma_f16x2split", 8: "conv1x1_mfma_f16x2split",
+                   0: "conv3x3_s1_mfma_f32", 4: "conv_direct_valu", 11: "conv_in_image_to_blocked", 12: "conv_out_blocked_to_image"}
+FWD_CLASSES_16 = {26: "conv3x3_s1_mfma_16bit", 30: "conv3x3_s1_mfma_16bit_two_wg_per_cu", 33: "conv3x3_plus_fused_shortcut_16bit",
+                  34: "conv3x3_plus_fused_shortcut_16bit_two_wg_per_cu", 27: "conv3x3_upsample_mfma_16bit", 22: "conv3x3_s2_mfma_16bit",
+                  28: "conv1x1_mfma_16bit", 0: "conv3x3_s1_mfma_f32", 4: "conv_direct_valu", 11: "conv_in_image_to_blocked",
+                  12: "conv_out_blocked_to_image"}
+
+
+def class_roofline(row, peak_tflops, step_ms, sampled_frac=1.0):
+    """One conv class against BOTH roofs: time at the matrix-core peak for its algorithmic FLOPs, time at 8 TB/s for its
+    algorithmic bytes; `bound` is the longer of the two, `frac` = that time / the measured launch time."""
+    t_mfma = row["flops_per_launch"] / (peak_tflops * 1e12)
+    t_hbm = row["bytes_per_launch"] / (PEAK_HBM_GBS * 1e9)
+    bound = "hbm" if t_hbm > t_mfma else "mfma"
+    return dict(bound=bound, achieved=row["alg_gbs"] if bound == "hbm" else row["tflops"],
+                peak=PEAK_HBM_GBS if bound == "hbm" else peak_tflops, unit="GB/s" if bound == "hbm" else "TFLOP/s",
+                frac=max(t_mfma, t_hbm) / (row["avg_ms"] * 1e-3), mfma_tflops=row["tflops"], mfma_frac=row["tflops"] / peak_tflops,
+                alg_gbs=row["alg_gbs"], hbm_frac=row["alg_gbs"] / PEAK_HBM_GBS, avg_launch_ms=row["avg_ms"],
+                launches=row["launches"], time_share=row["total_ms"] / sampled_frac / step_ms)
+
+
+def forward_leg(args, cfg, dtype, batch, steps, ddim_steps, workload, flops_img, pmc_suffix, pmc_patterns):
+    """Denoising steps (dsg_unet_forward + dsg_ddim_step) of one BASELINE network / precision / batch on one GPU, with the
+    HIP-event class records of every PROF_EVERY-th step and a roofline object for the class that takes the most time."""
     import drivescenegen_amd as d
     from drivescenegen_amd import _lib, synth
-    from drivescenegen_amd.configs import CFG5, synth_weights
+    from drivescenegen_amd.configs import synth_weights
     dev = torch.device("cuda", int(os.environ.get("LOCAL_RANK", 0)))
-    net = synth_weights(d.UNet2DModel(**CFG5)).to(dev).eval().requires_grad_(False).set_compute_dtype(dtype)
+    net = synth_weights(d.UNet2DModel(**cfg)).to(dev).eval().requires_grad_(False).set_compute_dtype(dtype)
     sch = d.DDIMScheduler()
-    sch.set_timesteps(args.ddim_steps)
+    sch.set_timesteps(ddim_steps)
     ts = [int(t) for t in sch.timesteps]
-    b, steps = args.mixed_batch, args.mixed_steps
-    x = torch.from_numpy(synth.normal(14555, (b, 8, 256, 256), stream=11)).to(dev)
+    ss = cfg["sample_size"]
+    h, w = (ss, ss) if isinstance(ss, int) else ss
+    x = torch.from_numpy(synth.normal(14555, (batch, cfg["in_channels"], h, w), stream=11)).to(dev)
     lib = _lib.load()
 
     def step(i, x):
@@ -190,39 +235,70 @@ def mixed_leg(args, dtype="bf16"):
         x = step(i, x)
     torch.cuda.synchronize(dev)
     lib.dsg_prof_enable(1)
+    clock = StepClock(dev)
     t0 = time.perf_counter()
+    clock.tick()
     for i in range(steps):
         lib.dsg_prof_enable(3 if i % PROF_EVERY == 0 else 2)
         x = step(4 + i, x)
+        clock.tick()
     torch.cuda.synchronize(dev)
     dt = time.perf_counter() - t0
     assert torch.isfinite(x).all()
-    rows = _prof_rows(lib, _lib, {26: "conv3x3_s1_mfma_16bit", 33: "conv3x3_plus_fused_shortcut_16bit", 27: "conv3x3_upsample_mfma_16bit", 22: "conv3x3_s2_mfma_16bit",
-                                   28: "conv1x1_mfma_16bit", 0: "conv3x3_s1_mfma_f32", 4: "conv_direct_valu",
-                                   11: "conv_in_image_to_blocked", 12: "conv_out_blocked_to_image"})
+    rows = _prof_rows(lib, _lib, FWD_CLASSES_F32 if dtype == "fp32" else FWD_CLASSES_16)
     lib.dsg_prof_enable(0)
     del net
-    flops_img = 353.58e9  # SURVEY 8d, cfg5 forward
-    rec = {"metric": "denoising-steps/sec (U-Net fwd)", "value": b * steps / dt, "unit": "image-steps/s",
-           "ms_per_step": dt / steps * 1e3, "steps": steps, "dtype": dtype,
-           "config": {"workload": "BASELINE configs[4] network: 256x256x8 map+agent raster, default U-Net (56,580,360 params), "
-                                  f"mixed {dtype}, DDIM step, batch {b} on 1 GPU", "batch": b},
-           "whole_net_tflops": b * steps / dt * flops_img / 1e12, "kernels": rows}
-    dom = rows.get("conv3x3_s1_mfma_16bit")
-    if dom:
-        t_mfma = dom["flops_per_launch"] / (PEAK_F16_TFLOPS * 1e12)
-        t_hbm = dom["bytes_per_launch"] / (PEAK_HBM_GBS * 1e9)
-        bound = "hbm" if t_hbm > t_mfma else "mfma"
-        rec["roofline"] = dict(
-            bound=bound, kernel="dsg::conv_h2_kernel<0, *, 3, 2, 4, 1, 3, 64, 1>",
-            achieved=dom["alg_gbs"] if bound == "hbm" else dom["tflops"],
-            peak=PEAK_HBM_GBS if bound == "hbm" else PEAK_F16_TFLOPS, unit="GB/s" if bound == "hbm" else "TFLOP/s",
-            frac=max(t_mfma, t_hbm) / (dom["avg_ms"] * 1e-3), mfma_tflops=dom["tflops"], mfma_frac=dom["tflops"] / PEAK_F16_TFLOPS,
-            alg_gbs=dom["alg_gbs"], hbm_frac=dom["alg_gbs"] / PEAK_HBM_GBS, avg_launch_ms=dom["avg_ms"],
-            launches=dom["launches"], **pmc_class_traffic(r"conv_h2_kernel<0, [24], 3, [02], 4, [12], 3, (64|128), 1[,>]", "_bf16"),
-            note="mean over the 44 resnet convs of a step (three instantiations: 128-cout / 64-cout workgroups, 16- / 8-row "
-                 "tiles): frac = max(alg FLOPs / 2.5 PF, alg bytes / 8 TB/s) / measured time")
+    torch.cuda.empty_cache()
+    step_ms = dt / steps * 1e3
+    rec = {"metric": "denoising-steps/sec (U-Net fwd)", "value": batch * steps / dt, "unit": "image-steps/s",
+           "ms_per_step": step_ms, "step_ms_spread": clock.spread(), "steps": steps, "dtype": dtype,
+           "config": {"workload": workload, "batch": batch},
+           "whole_net_tflops": batch * steps / dt * flops_img / 1e12,
+           "alg_hbm_gbs_whole_step": None, "kernels": rows}
+    peak = PEAK_F16_TFLOPS / (3.0 if dtype == "fp32" else 1.0)
+    sampled = len(range(0, steps, PROF_EVERY)) / steps
+    conv_rows = {k: v for k, v in rows.items() if k.startswith("conv3x3_s1") or k.startswith("conv3x3_plus")}
+    if conv_rows:
+        # every 3x3 stride-1 class priced the same way; the headline object is the class with the largest share of the step
+        per_class = {k: dict(class_roofline(v, peak, step_ms, sampled), **pmc_class_traffic(pmc_patterns.get(k, r"$^"), pmc_suffix))
+                     for k, v in conv_rows.items()}
+        dom = max(per_class, key=lambda k: per_class[k]["time_share"])
+        rec["roofline"] = dict(per_class[dom], kernel_class=dom, peak_note=(
+            "2500 TF/s dense f16 MFMA / 3 products per fp32-equivalent MAC" if dtype == "fp32" else "2500 TF/s dense 16-bit MFMA") +
+            "; 8 TB/s HBM; frac = max(alg FLOPs / MFMA peak, alg bytes / HBM peak) / measured time",
+            other_classes={k: v for k, v in per_class.items() if k != dom})
+    rec["alg_hbm_gbs_whole_step"] = sum(v["bytes_per_launch"] * v["launches"] for v in rows.values()) / sampled / steps / (step_ms * 1e-3) / 1e9
     return rec
+
+
+def mixed_leg(args, dtype="bf16"):
+    """Extra record: BASELINE configs[4]'s network (256x256x8 raster, default U-Net, 56,580,360 parameters) in mixed
+    precision -- bf16 matrix-core products, 16-bit channel-blocked activations, fp32 statistics / accumulators --
+    as denoising steps at --mixed-batch samples.  Priced against BOTH roofs: 2.5 PF/s dense bf16 MFMA and 8 TB/s HBM (the
+    64 / 128-channel layers are HBM-bound in 16 bits)."""
+    from drivescenegen_amd.configs import CFG5
+    b = args.mixed_batch
+    pats = {"conv3x3_s1_mfma_16bit": r"conv_h2_kernel<0, 4, 3, [02], 4, 1, 3, (64|128), 1, 0, 0",
+            "conv3x3_s1_mfma_16bit_two_wg_per_cu": r"conv_h2_kernel<0, [24], 3, [02], 4, 2, 3, (64|128), 1, \d, 0",
+            "conv3x3_plus_fused_shortcut_16bit": r"conv_h2_kernel<0, 4, 3, [02], 4, 1, 3, (64|128), 1, \d, 1",
+            "conv3x3_plus_fused_shortcut_16bit_two_wg_per_cu": r"conv_h2_kernel<0, [24], 3, [02], 4, 2, 3, (64|128), 1, \d, 1"}
+    return forward_leg(args, CFG5, dtype, b, args.mixed_steps, args.ddim_steps,
+                       "BASELINE configs[4] network: 256x256x8 map+agent raster, default U-Net (56,580,360 params), "
+                       f"mixed {dtype}, DDIM step, batch {b} on 1 GPU", 353.58e9, "_bf16", pats)
+
+
+def cfg4_leg(args):
+    """Extra record: BASELINE configs[3] at its own size -- 512x512x4 raster, the 6-level network with attention at 32^2 and
+    16^2 (66,294,660 parameters), 100-step DDIM, batch 8 on one GPU, fp32-equivalent.  BASELINE calls it the 'HBM-bound
+    conv path': four of its six levels are 64 / 128 channels wide at 512^2 ... 64^2."""
+    from drivescenegen_amd.configs import CFG4
+    pats = {"conv3x3_s1_mfma_f16x2split": r"conv_h2_kernel<0, 4, 3, 2, 4, 1, 3, 64, 0, 0, 0",
+            "conv3x3_s1_mfma_f16x2split_two_wg_per_cu": r"conv_h2_kernel<0, 2, 3, 2, 4, 2, 3, 64, 0, 1, 0",
+            "conv3x3_plus_fused_shortcut_f16x2split": r"conv_h2_kernel<0, 4, 3, 2, 4, 1, 3, 64, 0, 0, 1",
+            "conv3x3_plus_fused_shortcut_f16x2split_two_wg_per_cu": r"conv_h2_kernel<0, 2, 3, 2, 4, 2, 3, 64, 0, 1, 1"}
+    return forward_leg(args, CFG4, "fp32", 8, 20, 100,
+                       "BASELINE configs[3]: 512x512x4 high-res raster, U-Net with attention at 16^2 and 32^2 (6 levels, "
+                       "66,294,660 params), 100-step DDIM (eta=0), batch 8 on 1 GPU, fp32-equivalent", CFG4_FLOPS_IMG, "_cfg4", pats)
 
 
 def train_ref_leg(args, steps=5):
@@ -232,7 +308,7 @@ def train_ref_leg(args, steps=5):
     import drivescenegen_amd as d
     from drivescenegen_amd import synth
     from drivescenegen_amd.configs import DEFAULT3, synth_weights
-    from drivescenegen_amd.train_loop import train_step
+    from drivescenegen_amd.train_loop import train_steps
     dev = torch.device("cuda", int(os.environ.get("LOCAL_RANK", 0)))
     batch = 14
     acc = d.Accelerator(mixed_precision="fp16")
@@ -242,23 +318,28 @@ def train_ref_leg(args, steps=5):
     net, opt, lrs = acc.prepare(net, opt, lrs)
     sch = d.DDPMScheduler()
     x0 = torch.from_numpy(synth.synth_scene_rasters(batch, 3, 256, 256, 14555)).to(dev)
-    for _ in range(3):
-        train_step(acc, net, sch, opt, lrs, x0)
+    # train_loop.train_steps = fit's inner loop: step k+1's host noise (training_pipeline.py:72) is drawn by a worker thread
+    # while the GPU runs step k (same generator, same order, same values)
+    for loss in train_steps(acc, net, sch, opt, lrs, [x0] * 3):
+        pass
     torch.cuda.synchronize(dev)
+    clock = StepClock(dev)
     t0 = time.perf_counter()
-    for _ in range(steps):
-        loss = train_step(acc, net, sch, opt, lrs, x0)
+    clock.tick()
+    for loss in train_steps(acc, net, sch, opt, lrs, [x0] * steps):
+        clock.tick()
     torch.cuda.synchronize(dev)
     dt = time.perf_counter() - t0
     assert torch.isfinite(loss).all()
     return {"metric": "training throughput, the reference's own configuration (train.py: default 3-channel U-Net, fp16 AMP + "
                       "GradScaler, batch 14)", "value": batch * steps / dt, "unit": "images/s", "ms_per_step": dt / steps * 1e3,
+            "step_ms_spread": clock.spread(), "host_noise": "drawn one step ahead on a worker thread (train_loop.NoiseAhead)",
             "steps": steps, "batch": batch, "dtype": "f16 storage / MFMA, f32 accumulate and master weights",
             "loss": float(loss), "loss_scale": float(acc.scaler.get_scale()) if acc.scaler is not None else None,
             "peak_mem_gib": torch.cuda.max_memory_allocated(dev) / 2 ** 30}
 
 
-def train_leg(args, dtype="fp32", batch=16, steps=3):
+def train_leg(args, dtype="fp32", batch=64, steps=3):
     """Extra record: optimizer steps of the training loop (training_pipeline.py:70-91: add_noise, U-Net forward, MSE,
     backward, clip 1.0, AdamW, cosine LR) on BASELINE configs[2]'s network at `batch` samples on one GPU; images/s."""
     import drivescenegen_amd as d
@@ -287,9 +368,12 @@ def train_leg(args, dtype="fp32", batch=16, steps=3):
     for _ in range(2):
         one()
     torch.cuda.synchronize(dev)
+    clock = StepClock(dev)
     t0 = time.perf_counter()
+    clock.tick()
     for _ in range(steps):
         loss = one()
+        clock.tick()
     torch.cuda.synchronize(dev)
     dt = time.perf_counter() - t0
     assert torch.isfinite(loss.detach()).all()
@@ -310,9 +394,11 @@ def train_leg(args, dtype="fp32", batch=16, steps=3):
     del net, opt
     torch.cuda.empty_cache()
     rec = {"metric": "training images/sec (fwd + bwd + clip + AdamW)", "value": batch * steps / dt, "unit": "images/s",
-           "ms_per_step": dt / steps * 1e3, "steps": steps, "dtype": dtype, "peak_mem_gib": peak_gib,
-           "config": {"workload": f"BASELINE configs[{2 if dtype == 'fp32' else 4}] network at 256x256x{c}, DDPM training step, "
-                                  f"batch {batch} on 1 GPU, {dtype}", "batch": batch},
+           "ms_per_step": dt / steps * 1e3, "step_ms_spread": clock.spread(), "steps": steps, "dtype": dtype,
+           "peak_mem_gib": peak_gib,
+           "config": {"workload": f"BASELINE configs[{2 if dtype == 'fp32' else 4}]: 256x256x{c} raster, DDPM training step (add_noise, "
+                                  f"fwd, MSE, bwd, clip 1.0, AdamW, cosine LR), batch {batch} per GPU (the config's own), {dtype}, "
+                                  "one GPU's share of the data-parallel step (no all-reduce at N = 1)", "batch": batch},
            "kernels": rows}
     # roofline of the dominant BACKWARD kernel (the 3x3 weight gradient) and of the conv class that carries forward and
     # data gradients, priced like the headline: fp32-equivalent = 2500 / 3 TF/s-eq, 16-bit = 2500 TF/s; HBM 8 TB/s
@@ -370,6 +456,13 @@ def small_batch_leg(args):
     return out
 
 
+def _pmc_stamp(d):
+    """Where a quoted counter file came from: the git head its collection ran on (tools/gpu.sh writes it before the call)
+    and the profiled command -- a kernel whose template arguments changed since then no longer matches and reads None;
+    one whose code changed under the same name shows here as an older head."""
+    return dict(traffic_git_head=d.get("git_head"), traffic_cmd=(d.get("source") or "").split("over: ")[-1] or None)
+
+
 def pmc_traffic(kernel, suffix=""):
     """HBM bytes per launch of `kernel` from the committed PMC pass (tools/pmc_bench.sh -> profiles/*_pmc_traffic.json:
     rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes over this same bench command line, FETCH_SIZE doubled as
@@ -385,7 +478,7 @@ def pmc_traffic(kernel, suffix=""):
         k = next(v for name, v in sorted(d["kernels"].items()) if name.startswith(kernel.rstrip(">")))
         return dict(traffic=k["hbm_bytes_per_launch"], traffic_unit="bytes/launch (HBM read + write, mean over launches)",
                     traffic_read=k["fetch_bytes_per_launch"], traffic_write=k["write_bytes_per_launch"],
-                    traffic_source="profiles/" + os.path.basename(files[-1]))
+                    traffic_source="profiles/" + os.path.basename(files[-1]), **_pmc_stamp(d))
     except (KeyError, ValueError, OSError, StopIteration):
         return dict(traffic=None)
 
@@ -399,13 +492,14 @@ def pmc_class_traffic(pattern, suffix):
     if not files:
         return dict(traffic=None)
     try:
-        ks = [v for name, v in json.load(open(files[-1]))["kernels"].items() if re.search(pattern, name)]
+        d = json.load(open(files[-1]))
+        ks = [v for name, v in d["kernels"].items() if re.search(pattern, name)]
         n = sum(k["launches"] for k in ks)
         if not n:
             return dict(traffic=None)
         return dict(traffic=sum(k["hbm_bytes_per_launch"] * k["launches"] for k in ks) / n,
                     traffic_unit="bytes/launch (HBM read + write, launch-weighted mean over the class's instantiations)",
-                    traffic_source="profiles/" + os.path.basename(files[-1]))
+                    traffic_source="profiles/" + os.path.basename(files[-1]), **_pmc_stamp(d))
     except (KeyError, ValueError, OSError):
         return dict(traffic=None)
 
@@ -421,9 +515,38 @@ def pmc_mfma(kernel, suffix=""):
     try:
         d = json.load(open(files[-1]))
         k = next(v for name, v in sorted(d["kernels"].items()) if name.startswith(kernel.rstrip(">")))
-        return dict(mfma_pipe_util=k["mfma_util_issued"], mfma_pipe_util_source="profiles/" + os.path.basename(files[-1]))
+        return dict(mfma_pipe_util=k["mfma_util_issued"], mfma_pipe_util_source="profiles/" + os.path.basename(files[-1]),
+                    mfma_pipe_util_git_head=d.get("git_head"))
     except (KeyError, ValueError, OSError, StopIteration):
         return {}
+
+
+def summary_of(out):
+    """Flat digest of the line, printed as its last key: value / ms_per_step / roofline.frac of the headline and of every
+    extra record, and the CPU baseline."""
+    def short(r):
+        if not isinstance(r, dict):
+            return r
+        if "error" in r:
+            return {"error": r["error"][:200]}
+        d = {k: r[k] for k in ("value", "unit", "ms_per_step", "batch1_ms_per_step", "batch5_ms_per_step", "peak_mem_gib") if k in r}
+        if isinstance(r.get("config"), dict) and "batch" in r["config"]:
+            d["batch"] = r["config"]["batch"]
+        rf = r.get("roofline")
+        if isinstance(rf, dict):
+            d["roofline"] = {k: rf.get(k) for k in ("bound", "frac", "achieved", "unit", "traffic", "time_share") if k in rf}
+            for sub in ("second_kernel", "fused_shortcut_kernel", "fused_shortcut_two_wg_kernel"):
+                if isinstance(rf.get(sub), dict):
+                    d["roofline"][sub + "_frac"] = rf[sub].get("frac")
+        if isinstance(r.get("step_ms_spread"), dict):
+            d["step_ms_min_med_max"] = [round(r["step_ms_spread"][k], 3) for k in ("min", "median", "max")]
+        return d
+    s = {"headline": short(out)}
+    for name, rec in (out.get("extra_records") or {}).items():
+        s[name] = short(rec)
+    if "cpu_baseline" in out:
+        s["cpu_baseline"] = {k: out["cpu_baseline"][k] for k in ("value", "unit", "cores", "kind")}
+    return s
 
 
 def main():
@@ -445,6 +568,8 @@ def main():
                          "32/64/128/256 threads run 1.1x/2x/4.4x/36x slower)")
     ap.add_argument("--no-extras", action="store_true",
                     help="skip the extra records (mixed-precision forward, training step, small-batch sampling)")
+    ap.add_argument("--train-fp32-batch", type=int, default=64, help="BASELINE configs[2]: 64 per GPU")
+    ap.add_argument("--train-bf16-batch", type=int, default=128, help="BASELINE configs[4]: 128 per GPU")
     ap.add_argument("--mixed-batch", type=int, default=64)
     ap.add_argument("--mixed-steps", type=int, default=20)
     args = ap.parse_args()
@@ -476,7 +601,7 @@ def main():
     if args.gpus != world and rank == 0 and world > 1:
         print(f"warning: --gpus {args.gpus} but WORLD_SIZE={world}", file=sys.stderr)
 
-    dt, prof, per_rank = gpu_leg(args, rank, world)
+    dt, prof, per_rank, spread = gpu_leg(args, rank, world)
     if rank == 0:
         n_img_steps = args.batch * world * args.steps
         value = n_img_steps / dt
@@ -528,7 +653,7 @@ def main():
         out = {
             "metric": "denoising-steps/sec (U-Net fwd) on 256x256 BEV rasters", "value": value,
             "unit": "image-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "ms_per_step": dt / args.steps * 1e3, "step_ms_spread": spread, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None,
             "dtype": "f32 (3x3 and 1x1 convs: fp32-equivalent contraction as an fp16x2 split on the f16 MFMA, fp32 "
                      "accumulate; everything else f32)" if "conv3x3_s1_mfma_f16x2split" in prof else "f32",
@@ -548,17 +673,22 @@ def main():
         }
         if not args.no_extras and world == 1:  # bounded extra legs, N = 1 only; a failure is reported, never hidden
             extras = {}
-            for name, fn in (("mixed_bf16", lambda: mixed_leg(args, "bf16")), ("train_fp32", lambda: train_leg(args, "fp32")),
-                             ("train_bf16", lambda: train_leg(args, "bf16", batch=32)),
+            for name, fn in (("mixed_bf16", lambda: mixed_leg(args, "bf16")), ("configs3_512", lambda: cfg4_leg(args)),
+                             ("train_fp32", lambda: train_leg(args, "fp32", batch=args.train_fp32_batch)),
+                             ("train_bf16", lambda: train_leg(args, "bf16", batch=args.train_bf16_batch)),
                              ("train_fp16_reference_point", lambda: train_ref_leg(args)),
                              ("small_batch_sampling", lambda: small_batch_leg(args))):
                 try:
                     extras[name] = fn()
                 except Exception as e:  # noqa: BLE001
                     extras[name] = {"error": f"{type(e).__name__}: {e}"}
+                import gc
+                gc.collect()
+                torch.cuda.empty_cache()
             out["extra_records"] = extras
         if not args.no_cpu and world == 1:  # (rank 0 at N = 1 only: the other ranks of a multi-GPU run would wait for it)
             out["cpu_baseline"] = cpu_leg(args)
+        out["summary"] = summary_of(out)   # LAST key: the headline numbers of every record survive a truncated tail
         print(json.dumps(out))
     if torch.distributed.is_initialized():
         torch.distributed.barrier()

@@ -156,6 +156,7 @@ SIGNATURES = {
     "dsg_postprocess": [_vp, _vp, _i32, _i32, _i32, _i32, _vp],
     "dsg_unet_create": [C.POINTER(UNetConfig), C.POINTER(_vp)],
     "dsg_unet_set_param": [_vp, C.c_char_p, _vp, _i64, _vp],
+    "dsg_unet_commit_params": [_vp],
     "dsg_unet_num_params": [_vp, C.POINTER(_i64), C.POINTER(_i64), C.POINTER(_i64)],
     "dsg_unet_param_name": [_vp, _i64, C.POINTER(C.c_char_p), C.POINTER(_i64)],
     "dsg_unet_workspace_bytes": [_vp, _i32, C.POINTER(_sz)],
@@ -187,6 +188,7 @@ SIGNATURES = {
     "dsg_mask_lut_u8": [_vp, _i32, _i32, _i32, _i32, _i32, _vp, C.c_uint8, C.c_uint8, _vp, _vp],
     "dsg_prof_enable": [_i32],
     "dsg_set_tuning": [_i32, _i32],
+    "dsg_tuning_epoch": [],
     "dsg_prof_dump": [C.c_char_p],
     "dsg_prof_summary": [_i32, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(_i64)],
 }

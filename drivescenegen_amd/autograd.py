@@ -54,6 +54,7 @@ class TrainState:
         self.post_backward = []     # callables() run when the backward walk is complete, before the internal loss scale
         #                             is taken back out of the slab (the bucketed all-reduce finishes here)
         self.packs16 = {}           # dsg_dtype -> _Packs: 16-bit operand images for the mixed-precision tape
+        self.fuse_cache = {}        # (resnet, shapes, dtype, tuning epoch) -> does conv2 take the 1x1 shortcut into its K loop?
         self.attach()
 
     def grad(self, name):
@@ -728,12 +729,14 @@ def _forward16(model, st: TrainState, tape: _Tape, sample, timesteps, dt):
         return ops.gn_scale_shift_from_parts_train(s0, g, b, groups, eps, hw_of(x0), stats1=s1)
 
     def conv(x0, wname, x1=None, gn=None, silu=False, k=3, stride=1, ups=False, toff=None, res=None, need_dx=True,
-             feeds_norm=False, dst_blocked=True):
+             feeds_norm=False, dst_blocked=True, ss_mr=None):
         bias = P[wname + ".bias"].detach()
         cout = bias.numel()
         src_blocked = x0.dim() == 5
         ss = mr = None
-        if gn is not None:
+        if ss_mr is not None:     # (the caller has finalised this norm already: no second finalize launch)
+            ss, mr = ss_mr
+        elif gn is not None:
             ss, mr = norm_ss(x0, x1, gn)
         cin = chans(x0) + (chans(x1) if x1 is not None else 0)
         kw = {}
@@ -773,7 +776,12 @@ def _forward16(model, st: TrainState, tape: _Tape, sample, timesteps, dt):
             kw = dict(ksize=3, gn_scale_shift=ss, silu=True, cout=cout, src_blocked=True, dst_blocked=True, compute_dtype=dt,
                       weight_h2=packs.get(c2n + ".weight", ops.PACK_FWD), weight_h2_stride=_pad64(cout))
             b2 = P[c2n + ".bias"].detach()
-            if ops.conv2d_fused(h, None, b2, shortcut=dict(sc, query_only=True), **kw):
+            # (the answer depends on shapes, dtype and the kernel-selection switches only: asked once per layer and shape)
+            fkey = (pre, tuple(h.shape), tuple(x.shape), None if skip is None else tuple(skip.shape), dt, ops.tuning_epoch())
+            fuse = st.fuse_cache.get(fkey)
+            if fuse is None:
+                fuse = st.fuse_cache[fkey] = bool(ops.conv2d_fused(h, None, b2, shortcut=dict(sc, query_only=True), **kw))
+            if fuse:
                 y, ystats = ops.conv2d_fused(h, None, b2, shortcut=sc, want_stats=True, **kw)
                 if ystats is not None:
                     pstats[id(y)] = ystats
@@ -782,6 +790,8 @@ def _forward16(model, st: TrainState, tape: _Tape, sample, timesteps, dt):
                 tape.recs.append(dict(kind="conv", x0=h, x1=None, ss=ss, mr=mr, gn=pre + ".norm2", silu=True, k=3, stride=1,
                                       ups=False, toff=None, res=None, y=y, wname=c2n, cout=cout, need_dx=True))
                 return y
+            sc = conv(x, scn, x1=skip, k=1)
+            return conv(h, c2n, gn=pre + ".norm2", silu=True, res=sc, feeds_norm=True, ss_mr=(ss, mr))
         sc = conv(x, scn, x1=skip, k=1)
         return conv(h, c2n, gn=pre + ".norm2", silu=True, res=sc, feeds_norm=True)
 

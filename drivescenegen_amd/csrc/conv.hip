@@ -479,7 +479,6 @@ void conv_h2_set_fuse_sc(int v);
 int conv_h2_get_fuse_sc();
 void conv_h2_set_pre(int v);
 void conv_h2_set_pre_min_ct(int v);
-void conv_h2_set_pc(int v);
 bool conv_h2_takes_operand(const dsg_conv_args* a, int hout, int wout, bool wanted);
 void attention_set_blocked(int v);
 bool conv_h2_sc_fusable(const dsg_conv_args* a, int hout, int wout);
@@ -839,6 +838,9 @@ int conv2d_fwd_impl(const dsg_conv_args* a, hipStream_t st, int force_direct) {
 
 }  // namespace dsg
 
+namespace dsg { int conv_h2_tuning_epoch(); }
+DSG_API int32_t dsg_tuning_epoch(void) { return dsg::conv_h2_tuning_epoch(); }
+
 // Tuning / A-B switches (key 1: K-chunk of the fp32 3x3 kernel, 0 = auto | 4 | 8; key 2: fp16x2-split 3x3 kernel
 // on/off).  Not part of the reference surface.
 DSG_API int dsg_set_tuning(int32_t key, int32_t value) {
@@ -899,10 +901,6 @@ DSG_API int dsg_set_tuning(int32_t key, int32_t value) {
   }
   if (key == 26 && (value == 0 || value == 1)) {
     dsg::conv_h2_set_pre(value);
-    return DSG_OK;
-  }
-  if (key == 28 && (value == 0 || value == 1)) {
-    dsg::conv_h2_set_pc(value);
     return DSG_OK;
   }
   if (key == 30 && (value == 0 || value == 1)) {

@@ -293,7 +293,6 @@ void conv_h2_set_splitk(int v) { g_h2.splitk = v; ++g_h2.epoch; }
 void conv_h2_set_ws2(int v) { g_h2.ws2 = v; ++g_h2.epoch; }
 void conv_h2_set_fuse_sc(int v) { g_h2.fuse_sc = v; ++g_h2.epoch; }
 void conv_h2_set_pre(int v) { g_h2.pre = v; ++g_h2.epoch; }
-void conv_h2_set_pc(int v) { g_h2.pc = v; ++g_h2.epoch; }
 void conv_h2_set_pre_min_ct(int v) { g_h2.pre_min_ct = v > 0 ? v : 1; ++g_h2.epoch; }
 int conv_h2_get_fuse_sc() { return g_h2.fuse_sc; }
 int conv_in_tuning_epoch();  // conv_in.hip: its on/off switch moves the plan's statistics buffers too

@@ -28,8 +28,6 @@ struct H2Tuning {
   int splitk = 1;       // split-K for grids of at most half the CUs, when the caller gives scratch (key 19)
   int ws2 = 1;          // fp32-equivalent 3x3 convs with cin <= 128: 8-row tiles, one weight slab, two workgroups per CU (key 20)
   int fuse_sc = 1;      // resnet shortcuts fused into conv2's K loop (key 23: A/B against the separate 1x1 kernel)
-  int pc = 0;           // wave-specialised persistent kernel for the shallow fp32-equivalent 3x3 convs (conv_pc.hip; key 28): bitwise the
-                        // kernels it replaces and measured 2.5 % slower on the step (profiles/r03_conv_pc_ablation.txt) -- off
   int pre = 1;          // pre-staged operand images for the layers with >= pre_min_ct cout tiles per patch (key 26)
   int pre_min_ct = 16;  // ... (key 27: the threshold.  Measured, profiles/r03_operand_ablation.txt: at 4 -- every conv of the 256- / 512-channel
                         // levels -- the convs gain 8.5 % and the prepare passes cost what they gain; at 16 only the folded up-samplers of
@@ -42,17 +40,17 @@ constexpr int H2_CUS = 256;
 bool conv_h2_fold(const dsg_conv_args* a);
 bool conv_h2_s2(const dsg_conv_args* a, int hout, int wout);
 bool conv_h2_rows16(const dsg_conv_args* a, int hout, int wout);
-// does the call take the fused-shortcut kernel (dsg_conv_args.sc_*)?  Shape and dtype only, never the grid size: whether a
-// resnet's shortcut is fused must not depend on the batch it runs in (row i of a batch == the batch-1 call on row i, bitwise)
+// does the call take the fused-shortcut kernel (dsg_conv_args.sc_*)?  Shapes, layouts and dtype -- and, for a call that brings
+// split-K scratch (splitk_ws), the slice count of that call, which is a function of the grid and therefore of the batch: a slice
+// left with fewer shortcut chunks than the DMA ring is deep refuses the fusion.  "Row i of a batch == the batch-1 call on row i,
+// bitwise" therefore holds for plans without split-K (DSG_UNET_BATCH_INVARIANT, or no splitk_ws); with split-K on, the
+// fused / unfused choice -- a different summation order -- may differ between batch sizes (<= 2e-6 relative, tests/common.py)
 bool conv_h2_sc_fusable(const dsg_conv_args* a, int hout, int wout);
 // K slices (1 = no split) and statistics splits of the reduce pass for a call that may split (see dsg_conv_args.splitk_ws)
 int conv_h2_splitk_slices(const dsg_conv_args* a, int hout, int wout, int* stat_splits);
 // does the call's kernel read a pre-staged operand image (dsg_conv_args.src_operand)?  `wanted`: also apply the launcher's own
 // pays-off rule (cout tiles per patch); without it the answer is "can", which is what a call that brings an image needs
 bool conv_h2_takes_operand(const dsg_conv_args* a, int hout, int wout, bool wanted);
-// conv_pc.hip: the producer / consumer form of the shallow-level 3x3 conv (same results as the kernels here, bit for bit)
-bool conv_pc_eligible(const dsg_conv_args* a, int hout, int wout, int slices);
-int conv_pc_launch(const struct ConvH2P& p, hipStream_t st);
 int splitk_reduce_launch(const float* part, int slices, const dsg_conv_args* a, int hout, int wout, int stat_splits,
                          hipStream_t st);
 
@@ -235,11 +233,6 @@ int conv_h2_launch_t(const dsg_conv_args* a, int hout, int wout, hipStream_t st)
       if constexpr (PREC == 0) rc = h2_launch<0, 2, 3, 2, 4, 2, 3, 32, 0, 0, 1>(g32, lds32, st, q);
     } else if (act == 0) rc = h2_launch<0, 2, 3, 0, 4, 2, 3, 32, PREC>(g32, lds32, st, q);
     else rc = h2_launch<0, 2, 3, 2, 4, 2, 3, 32, PREC>(g32, lds32, st, q);
-  } else if (PREC == 0 && !bm32 && !sc && conv_pc_eligible(a, hout0, wout0, slices)) {
-    // shallow levels, large grids: one persistent workgroup per CU, producer and consumer waves (conv_pc.hip)
-    ConvH2P q = p;
-    q.tiles_y = hout / 8;
-    rc = conv_pc_launch(q, st);
   } else if (ws2 && !bm32) {
     // shallow levels: 64 couts x 8 rows, ONE weight slab (80 KB of LDS, half the register file): two workgroups per CU
     if constexpr (PREC == 0) {

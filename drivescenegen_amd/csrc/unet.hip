@@ -141,10 +141,32 @@ struct dsg_unet {
   std::map<std::tuple<int, int, int>, size_t> ws_cache;  // (batch, blocked layout, tuning epoch) -> workspace bytes
   std::string err;
   int dt() const { return cfg.compute_dtype; }  // dsg_dtype of the channel-blocked intermediates / matrix-core products
-  float* scratch_ = nullptr;
-  float* scratch4() {
-    if (!scratch_) scratch_ = dalloc(4);
-    return scratch_;
+  // range guard of the weights (dsg_unet_set_param): max|w| of every uploaded conv weight lands in wmax_dev[param index],
+  // asynchronously; commit_ranges() fetches the table with ONE copy + ONE synchronisation per parameter refresh and turns
+  // it into the convs' off_split bits
+  float* wmax_dev = nullptr;
+  std::vector<float> wmax_host;
+  std::vector<int> pending;        // parameter indices whose maxima have not been read back yet
+  hipStream_t pending_stream = nullptr;
+  int commit_ranges() {
+    if (pending.empty()) return DSG_OK;
+    wmax_host.resize(params.size());
+    if (hipMemcpyAsync(wmax_host.data(), wmax_dev, params.size() * sizeof(float), hipMemcpyDeviceToHost, pending_stream) != hipSuccess ||
+        hipStreamSynchronize(pending_stream) != hipSuccess)
+      return DSG_ERR_HIP;
+    bool changed = false;
+    for (int i : pending) {
+      Param& p = params[i];
+      const float wmax = wmax_host[i];
+      const bool bad = !(wmax <= 3.0e4f) || (wmax != 0.f && wmax < 0.00390625f);
+      const unsigned before = p.conv->off_split;
+      if (bad) p.conv->off_split |= 1u << p.conv_bit;
+      else p.conv->off_split &= ~(1u << p.conv_bit);
+      changed |= before != p.conv->off_split;
+    }
+    pending.clear();
+    if (changed) ws_cache.clear();  // (a conv that changes kernels may change what the arena holds)
+    return DSG_OK;
   }
 
   ~dsg_unet() {
@@ -686,7 +708,6 @@ DSG_API int dsg_unet_set_param(dsg_unet_t* h, const char* name, const float* dat
                   h->cfg.block_out_channels[0] / 2);
     DSG_HIP(hipMemcpyAsync(h->freqs, data, (size_t)numel * sizeof(float), hipMemcpyDeviceToDevice,
                            static_cast<hipStream_t>(stream)));
-    DSG_HIP(hipStreamSynchronize(static_cast<hipStream_t>(stream)));
     return DSG_OK;
   }
   auto it = h->index.find(key);
@@ -702,17 +723,18 @@ DSG_API int dsg_unet_set_param(dsg_unet_t* h, const char* name, const float* dat
     if (rc != DSG_OK) return rc;
     const int dt = h->dt();
     if (p.conv && dt == DSG_F32 && (p.wh || p.whf || p.whs)) {
-      // range guard: max|w| decides whether the fp16 pairs of the split can carry this tensor (one D2H word per upload)
-      float* dmax = h->scratch4();
-      float wmax = 0.f;
-      DSG_CHECK_ARG(dmax != nullptr, "dsg_unet_set_param: hipMalloc failed");
-      rc = dsg_abs_max(data, numel, dmax, stream);
+      // range guard: max|w| decides whether the fp16 pairs of the split can carry this tensor.  The maximum is left in
+      // the plan's device table; dsg_unet_commit_params (or the next forward) reads the whole table back at once
+      if (!h->wmax_dev) h->wmax_dev = h->dalloc((int64_t)h->params.size());
+      DSG_CHECK_ARG(h->wmax_dev != nullptr, "dsg_unet_set_param: hipMalloc failed");
+      if (!h->pending.empty() && h->pending_stream != st) {  // (maxima queued on another stream: settle them there first)
+        rc = h->commit_ranges();
+        if (rc != DSG_OK) return fail(rc, "dsg_unet_set_param: reading the weight maxima back failed");
+      }
+      rc = dsg_abs_max(data, numel, h->wmax_dev + it->second, stream);
       if (rc != DSG_OK) return rc;
-      DSG_HIP(hipMemcpyAsync(&wmax, dmax, sizeof(float), hipMemcpyDeviceToHost, st));
-      DSG_HIP(hipStreamSynchronize(st));
-      const bool bad = !(wmax <= 3.0e4f) || (wmax != 0.f && wmax < 0.00390625f);
-      if (bad) p.conv->off_split |= 1u << p.conv_bit;
-      else p.conv->off_split &= ~(1u << p.conv_bit);
+      h->pending.push_back(it->second);
+      h->pending_stream = st;
     }
     if (p.wh) {  // (a column window only where the packed matrix is wider than this weight: the fused q/k/v projection)
       const bool window = p.cout_off != 0 || p.cout_total > (p.cout + 63) / 64 * 64;
@@ -728,8 +750,14 @@ DSG_API int dsg_unet_set_param(dsg_unet_t* h, const char* name, const float* dat
       if (rc != DSG_OK) return rc;
     }
   }
-  DSG_HIP(hipStreamSynchronize(st));
   p.set = true;
+  return DSG_OK;
+}
+
+DSG_API int dsg_unet_commit_params(dsg_unet_t* h) {
+  DSG_CHECK_ARG(h != nullptr, "dsg_unet_commit_params: handle is NULL");
+  const int rc = h->commit_ranges();
+  if (rc != DSG_OK) return fail(rc, "dsg_unet_commit_params: reading the weight maxima back failed");
   return DSG_OK;
 }
 
@@ -759,6 +787,8 @@ DSG_API int dsg_unet_workspace_bytes(dsg_unet_t* h, int32_t batch, size_t* bytes
   DSG_CHECK_ARG(h && bytes, "dsg_unet_workspace_bytes: NULL argument");
   DSG_CHECK_ARG(batch > 0, "dsg_unet_workspace_bytes: batch must be positive");
   // (the layout and the kernel-selection switches decide which convs write statistics, hence the arena's layout)
+  int rc0 = h->commit_ranges();  // (kernel selection, hence the arena, depends on the weights' range bits)
+  if (rc0 != DSG_OK) return fail(rc0, "dsg_unet_workspace_bytes: reading the weight maxima back failed");
   const auto key = std::make_tuple((int)batch, dsg::unet_blocked() ? 1 : 0, dsg::conv_h2_tuning_epoch());
   auto it = h->ws_cache.find(key);
   if (it == h->ws_cache.end()) {

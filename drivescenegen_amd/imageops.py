@@ -52,12 +52,15 @@ class GpuImageLoader:
     ``len(loader)`` full-size steps (a rank short of one batch would never join the last gradient all-reduce)."""
 
     def __init__(self, pattern_or_files, size, batch_size, shuffle=True, seed=0, device="cuda", prefetch=2,
-                 rank=0, world=1, drop_last=False):
+                 rank=0, world=1, drop_last=False, trust_pickles=False):
         self.files = sorted(glob.glob(pattern_or_files)) if isinstance(pattern_or_files, str) else list(
             pattern_or_files)
         self.size, self.bs, self.shuffle, self.seed = tuple(size), batch_size, shuffle, seed
         self.device = torch.device(device)
         self.prefetch, self.rank, self.world, self.drop_last = prefetch, rank, world, drop_last
+        # .pkl samples are read with torch.load(weights_only=True) (a {"fig_tensor": tensor} dict needs nothing more);
+        # trust_pickles=True falls back to full unpickling -- which runs code from the data directory -- for other pickles
+        self.trust_pickles = bool(trust_pickles)
         self.epoch = 0
         self.epoch_seed = None
         self._copy_stream = None
@@ -74,17 +77,26 @@ class GpuImageLoader:
         return sharding.shard_batches(idx.tolist(), self.bs, self.rank, self.world, self.drop_last)
 
     def _load_one(self, i):
-        """One file as an HWC array: uint8 for images, float32 for the .pkl branch."""
-        f = self.files[i % len(self.files)]
-        if f.lower().endswith(".pkl"):
+        """One file as an HWC array: uint8 for images, float32 for the .pkl branch.  A .pkl that does not hold a dict is
+        skipped for the next file (the reference's dataset does the same, utils/datasets/dataset.py:31-36); after one full
+        round of the file list without a usable file this raises instead of recursing for ever."""
+        for k in range(len(self.files)):
+            f = self.files[(i + k) % len(self.files)]
+            if not f.lower().endswith(".pkl"):
+                from PIL import Image
+                a = np.asarray(Image.open(f))
+                return a[:, :, None] if a.ndim == 2 else a
             with open(f, "rb") as fh:
-                dd = torch.load(fh, weights_only=False)
-            if not isinstance(dd, dict):
-                return self._load_one(i + 1)
-            return np.ascontiguousarray(dd["fig_tensor"][:, :, :].float().numpy())
-        from PIL import Image
-        a = np.asarray(Image.open(f))
-        return a[:, :, None] if a.ndim == 2 else a
+                try:  # a {"fig_tensor": tensor} dict needs no arbitrary unpickling
+                    dd = torch.load(fh, weights_only=True)
+                except Exception:
+                    if not self.trust_pickles:
+                        raise
+                    fh.seek(0)
+                    dd = torch.load(fh, weights_only=False)
+            if isinstance(dd, dict):
+                return np.ascontiguousarray(dd["fig_tensor"][:, :, :].float().numpy())
+        raise IndexError(f"GpuImageLoader: no usable sample among {len(self.files)} files (every .pkl holds a non-dict object)")
 
     def _decode(self, ids):
         arrs = [self._load_one(i) for i in ids]

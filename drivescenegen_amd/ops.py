@@ -213,7 +213,8 @@ def conv2d_fused(src0, weight_r, bias=None, src1=None, ksize=3, stride=1, upsamp
     pad = ksize // 2
     ho = (hc + 2 * pad - ksize) // stride + 1
     wo = (wc + 2 * pad - ksize) // stride + 1
-    if out is None:
+    query = operand == "query" or (shortcut is not None and bool(shortcut.get("query_only")))  # host-only: nothing allocated
+    if out is None and not query:
         shape = (n, cout, ho // 2, wo // 2) if pool2 else (n, cout, ho, wo)
         if dst_blocked:
             shape = (n, cout // 8, shape[2], shape[3], 8)
@@ -258,7 +259,7 @@ def conv2d_fused(src0, weight_r, bias=None, src1=None, ksize=3, stride=1, upsamp
             scratch = torch.empty(need.value, dtype=torch.uint8, device=src0.device)
             a.splitk_ws, a.splitk_ws_bytes = scratch.data_ptr(), need.value
     stats = None
-    if want_stats and not direct:
+    if want_stats and not direct and not query:
         tiles = C.c_int32(0)
         _lib.check(lib.dsg_conv2d_stats_tiles(C.byref(a), C.byref(tiles)))
         if tiles.value > 0:
@@ -281,6 +282,12 @@ def conv2d_fused(src0, weight_r, bias=None, src1=None, ksize=3, stride=1, upsamp
     with torch.cuda.device(src0.device):
         _lib.check(fn(C.byref(a), _st(src0)))
     return (out, stats) if want_stats else out
+
+
+def tuning_epoch() -> int:
+    """dsg_tuning_epoch: advances with every accepted dsg_set_tuning call (a test hook) -- the key of host-side caches of
+    kernel-selection answers."""
+    return int(_lib.load().dsg_tuning_epoch())
 
 
 def conv_operand_prepare(src0, src1=None, gn_scale_shift=None, silu=False, src_bound=None, src_bound1=None):

@@ -8,6 +8,8 @@
 * every rank runs the SAME number of steps: a ragged tail (short last batch, batch count not a multiple of W) is completed
   with samples from the start of the epoch's order -- a rank with one batch fewer would never join the last gradient
   all-reduce and the others would wait for it forever;
+* ``drop_last=True``: accelerate DROPS the incomplete last round instead of completing it (``BatchSamplerShard.__len__`` =
+  batches // W), so the order is cut to a multiple of batch_size * W;
 * with ONE process nothing is sharded or completed: plain consecutive batches, short last batch included.
 """
 from __future__ import annotations
@@ -32,6 +34,8 @@ def shard_batches(order, batch_size: int, rank: int, world: int, drop_last: bool
     if world == 1:
         return [order[i:i + b] for i in range(0, len(order), b)]
     per_round = b * world
+    if drop_last:  # no completion: the ragged last round goes, as in accelerate's BatchSamplerShard with drop_last
+        order = order[:len(order) // per_round * per_round]
     if order and len(order) % per_round:  # even_batches: complete the last round from the start of the order
         need = per_round - len(order) % per_round
         order = order + [order[i % len(order)] for i in range(need)]
@@ -39,12 +43,19 @@ def shard_batches(order, batch_size: int, rank: int, world: int, drop_last: bool
 
 
 def steps_per_epoch(n: int, batch_size: int, world: int, drop_last: bool = False) -> int:
-    nb = n // batch_size if drop_last else -(-n // batch_size)
+    if drop_last:
+        return n // batch_size // world
+    nb = -(-n // batch_size)
     return -(-nb // world)
 
 
 def broadcast_epoch_seed(rank: int, world: int, device=None) -> int:
     """Rank 0 draws a seed from the global CPU generator (what RandomSampler does) and every rank receives it."""
+    if world > 1 and not dist.is_initialized():
+        # (without the broadcast rank 0 would shuffle by its own seed and every other rank by 0: samples duplicated or
+        # dropped across ranks with no error)
+        raise RuntimeError("broadcast_epoch_seed: world > 1 but torch.distributed is not initialised -- build the "
+                           "Accelerator (or call init_process_group) before iterating a sharded loader with seed=None")
     seed = torch.zeros(1, dtype=torch.int64)
     if rank == 0:
         seed = torch.randint(0, 2 ** 62, (1,), dtype=torch.int64)

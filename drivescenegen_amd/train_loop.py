@@ -10,7 +10,8 @@ PIL image) and ``from accelerate import notebook_launcher`` (train.py:4).  Both 
 (``sample_to_pil``, ``notebook_launcher``), and ``fit`` is the whole loop for users who do not carry the reference's file.
 
 Written from the behaviour listed in SURVEY.md sections 3.1-3.2 / App. A.4-A.6, not from the reference's text:
-  per batch     noise ~ N(0,1) drawn on the HOST and moved (the reference's `torch.randn(shape).to(device)`), t ~ U{0..T-1}
+  per batch     noise ~ N(0,1) drawn on the HOST and moved (the reference's `torch.randn(shape).to(device)`; `NoiseAhead`
+                draws the NEXT step's tensor on a worker thread while the GPU runs this one -- same values), t ~ U{0..T-1}
                 drawn on the device, x_t = add_noise(x0, noise, t); inside accelerator.accumulate: eps = model(x_t, t),
                 loss = mse(eps, noise), backward, clip to 1.0, optimizer / LR-scheduler step, zero_grad; log loss, lr, step
   per epoch     on the main process, when (epoch+1) % save_image_epochs == 0 or it is the last: one 750-step DDPM sample
@@ -49,9 +50,53 @@ def write_sample(config, pipeline, steps: int = 750):
     return path
 
 
-def train_step(accelerator, model, noise_scheduler, optimizer, lr_scheduler, batch):
-    """One optimisation step on a clean batch [B, C, H, W] in [-1, 1]; returns the detached loss (a device scalar)."""
-    noise = torch.randn(batch.shape).to(batch.device)
+class NoiseAhead:
+    """The host-side noise draw of the training step (training_pipeline.py:72: ``torch.randn(batch.shape).to(device)``,
+    2.75 M normals = ~8 ms of a 34-ms step at the reference's batch 14) moved off the critical path: a worker thread
+    draws step k+1's tensor into pinned memory while the GPU runs step k.
+
+    The values are the serial loop's, bit for bit: the same global CPU generator, the same ``torch.randn(shape)`` calls
+    in the same order.  ``schedule(shape)`` is only ever called for a batch that has already been fetched, from the
+    thread that would otherwise draw, while no other consumer of the global generator runs -- ``fit`` fetches batch k+1
+    (whose sampler seed, if any, was drawn when the epoch's iterator was made) BEFORE it schedules, and joins the worker
+    before anything else may draw (``take``).  One draw in flight at most."""
+
+    def __init__(self, enabled: bool = True):
+        self.enabled = bool(enabled)
+        self._thread = None
+        self._shape = None
+        self._out = None
+
+    def schedule(self, shape):
+        if not self.enabled or self._thread is not None:
+            return
+        import threading
+        self._shape = tuple(shape)
+
+        def draw():
+            self._out = torch.randn(self._shape, pin_memory=torch.cuda.is_available())
+        self._thread = threading.Thread(target=draw, daemon=True)
+        self._thread.start()
+
+    def take(self, shape, device):
+        """The noise of the current step on `device`: the scheduled draw when its shape matches, else a draw made now."""
+        shape = tuple(shape)
+        if self._thread is not None:
+            self._thread.join()
+            out, self._thread, self._out = self._out, None, None
+            if self._shape == shape:
+                return out.to(device, non_blocking=True)
+            # (cannot happen in `fit`: it schedules the very batch it takes next; keep the generator's order anyway)
+            raise RuntimeError(f"NoiseAhead: scheduled {self._shape}, asked for {shape}")
+        return torch.randn(shape).to(device)
+
+
+def train_step(accelerator, model, noise_scheduler, optimizer, lr_scheduler, batch, noise=None):
+    """One optimisation step on a clean batch [B, C, H, W] in [-1, 1]; returns the detached loss (a device scalar).
+    `noise`: the step's N(0,1) tensor on the batch's device when the caller drew it ahead (``NoiseAhead``); drawn here, on
+    the host, otherwise -- the reference's own order of operations."""
+    if noise is None:
+        noise = torch.randn(batch.shape).to(batch.device)
     t = torch.randint(0, noise_scheduler.num_train_timesteps, (batch.shape[0],), device=batch.device).long()
     noisy = noise_scheduler.add_noise(batch, noise, t).to(torch.float)
     with accelerator.accumulate(model):
@@ -64,11 +109,35 @@ def train_step(accelerator, model, noise_scheduler, optimizer, lr_scheduler, bat
     return loss.detach()
 
 
+def batches_with_noise(batches, overlap_noise: bool = True):
+    """One pass over `batches` as (batch, noise) pairs, the noise of batch k+1 being drawn on the worker thread while the
+    consumer works on batch k.  Consumers of the global CPU generator keep the serial loop's order -- fetch k, draw k,
+    fetch k+1, draw k+1, ... -- and never overlap: the worker is joined before the next fetch."""
+    ahead = NoiseAhead(overlap_noise)
+    it = iter(batches)
+    batch = next(it, None)
+    while batch is not None:
+        noise = ahead.take(batch.shape, batch.device)
+        nxt = next(it, None)
+        if nxt is not None:
+            ahead.schedule(nxt.shape)
+        yield batch, noise
+        batch = nxt
+
+
+def train_steps(accelerator, model, noise_scheduler, optimizer, lr_scheduler, batches, overlap_noise: bool = True):
+    """Generator over one pass of `batches` (an epoch's loader): yields each step's detached loss.  Batch k+1 is fetched and
+    its noise draw handed to the worker thread before step k's kernels are queued, so the host draw overlaps the GPU."""
+    for batch, noise in batches_with_noise(batches, overlap_noise):
+        yield train_step(accelerator, model, noise_scheduler, optimizer, lr_scheduler, batch, noise=noise)
+
+
 def fit(config, model, noise_scheduler, optimizer, train_dataloader, lr_scheduler, sample_steps: int = 750,
-        on_step=None):
+        on_step=None, overlap_noise: bool = True):
     """Train for ``config.num_epochs`` epochs.  `config` carries the reference's TrainingConfig fields (train.py:13-29):
     mixed_precision, gradient_accumulation_steps, output_dir, num_epochs, save_image_epochs, save_model_epochs,
-    eval_batch_size, seed.  Returns the number of optimisation steps taken on this rank."""
+    eval_batch_size, seed.  Returns the number of optimisation steps taken on this rank.  `overlap_noise=False` draws each
+    step's noise on the critical path like the reference does (same values either way)."""
     accelerator = Accelerator(mixed_precision=config.mixed_precision,
                               gradient_accumulation_steps=config.gradient_accumulation_steps, log_with="tensorboard",
                               project_dir=os.path.join(config.output_dir, "logs"))
@@ -78,8 +147,7 @@ def fit(config, model, noise_scheduler, optimizer, train_dataloader, lr_schedule
     model, optimizer, train_dataloader, lr_scheduler = accelerator.prepare(model, optimizer, train_dataloader, lr_scheduler)
     step = 0
     for epoch in range(config.num_epochs):
-        for batch in train_dataloader:
-            loss = train_step(accelerator, model, noise_scheduler, optimizer, lr_scheduler, batch)
+        for loss in train_steps(accelerator, model, noise_scheduler, optimizer, lr_scheduler, train_dataloader, overlap_noise):
             record = {"loss": loss.item(), "lr": lr_scheduler.get_last_lr()[0], "step": step}
             accelerator.log(record, step=step)
             if on_step is not None:

@@ -310,8 +310,9 @@ class _ShardedLoader:
     def __len__(self):
         if self.world == 1:
             return len(self.loader)
-        nb = self._num_batches() if self.index_mode else len(self.loader)
-        return math.ceil(nb / self.world)
+        if self.index_mode:
+            return sharding.steps_per_epoch(len(self.dataset), self.batch_size, self.world, self.drop_last)
+        return math.ceil(len(self.loader) / self.world)
 
     def _to_device(self, batch):
         return batch.to(self.device, non_blocking=True) if torch.is_tensor(batch) else batch

@@ -171,7 +171,9 @@ int dsg_conv2d_stats_tiles(const dsg_conv_args* a, int32_t* tiles);
 int dsg_conv2d_splitk_bytes(const dsg_conv_args* a, size_t* bytes);
 /* *yes = 1 when a call with these arguments (sc_src0 / sc_c0 / sc_c1 / sc_weight_h2 filled in) takes the fused-shortcut
  * kernel, 0 when the shortcut has to run as a 1x1 call of its own with its result passed as `residual`.  Host-only; the
- * answer depends on shapes, layouts, dtype and the split-K decision of the call -- not on the batch size as such. */
+ * answer depends on shapes, layouts, dtype and the split-K decision of the call.  That decision is taken from the grid
+ * size, i.e. from the batch: with splitk_ws set, whether a resnet's shortcut is fused (a different summation order, equal
+ * to fp32 round-off) can change with the batch size; without splitk_ws (DSG_UNET_BATCH_INVARIANT plans) it cannot. */
 int dsg_conv2d_fuses_shortcut(const dsg_conv_args* a, int32_t* yes);
 /* *yes = 1 when a call with these arguments is served by a kernel that reads a pre-staged operand image AND staging once
  * pays (the patch would otherwise be staged by >= 4 workgroups); the caller then prepares the image and sets src_operand.
@@ -366,10 +368,20 @@ typedef struct {
 int dsg_unet_create(const dsg_unet_config* cfg, dsg_unet_t** out);
 void dsg_unet_destroy(dsg_unet_t* h);
 /* Copies (and re-lays-out) one checkpoint tensor, named by its diffusers state-dict key
- * (SURVEY App. A.5), from device memory into the plan.  Synchronises `stream` before returning.
+ * (SURVEY App. A.5), from device memory into the plan.  Stream-asynchronous like every other entry
+ * point: `data` must stay valid until the work queued on `stream` has run; no host synchronisation,
+ * legal under stream capture.  In the fp32-equivalent mode a conv weight's max|w| (the range guard of
+ * the fp16x2 split) is left in a device table of the plan; dsg_unet_commit_params reads the table back.
  * The extra key "time_proj.freqs" ([block_out_channels[0]/2]) overrides the sinusoid frequency
  * table (default: correctly rounded exp computed on the host at create time). */
 int dsg_unet_set_param(dsg_unet_t* h, const char* name, const float* data, int64_t numel, void* stream);
+/* Settles the range guard of every weight uploaded since the last commit: ONE device-to-host copy of
+ * the maxima table and ONE synchronisation of the stream the uploads were queued on (replaces the
+ * reference-side per-tensor `load_state_dict` walk of train.py:59 with a single hand-over point).
+ * dsg_unet_workspace_bytes / dsg_unet_forward call it themselves when maxima are outstanding; call it
+ * explicitly after a parameter refresh that is followed by stream capture (a synchronisation is
+ * illegal inside a capture).  A no-op when nothing is outstanding. */
+int dsg_unet_commit_params(dsg_unet_t* h);
 /* Number of parameters the plan expects / that have been set. */
 int dsg_unet_num_params(const dsg_unet_t* h, int64_t* expected_tensors, int64_t* set_tensors,
                         int64_t* total_elements);
@@ -590,6 +602,9 @@ int dsg_prof_dump(const char* csv_path);
  *  15  stride-2 convs of channel-blocked tensors on the split path: [1] | 0 = the f32 MFMA kernel
  *  14  attention with head_dim 8 on the matrix cores (fp16x2 split): [1] | 0 = the VALU kernel */
 int dsg_set_tuning(int32_t key, int32_t value);
+/* A counter that advances with every accepted dsg_set_tuning call (0 in a production process): host-side caches of
+ * kernel-selection answers (dsg_conv2d_fuses_shortcut, dsg_conv2d_takes_operand, dsg_unet_workspace_bytes) key on it. */
+int32_t dsg_tuning_epoch(void);
 
 #ifdef __cplusplus
 }

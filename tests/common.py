@@ -68,6 +68,43 @@ def fullsize_train_case(key):
     return cfg, x0, noise, t
 
 
+# ---------------------------------------------------------------------------------------------------------------
+# Free-running sampling trajectories of the oracle (tests/golden/trajectory_golden.npz, made by
+# tests/golden/make_trajectory_golden.py): key -> (config, scheduler, steps, spatial stride of the stored final image,
+# checkpoint interval, batch the x_T row is drawn at | None = the seeded CPU generator of the evaluate call)
+# ---------------------------------------------------------------------------------------------------------------
+TRAJECTORIES = {
+    "cfg2_ddim50": (CFG2, "ddim", 50, 2, 10, 16),            # BASELINE configs[1], row 0 of the batch-16 x_T
+    "cfg4_ddim100": (CFG4, "ddim", 100, 4, 10, 8),           # BASELINE configs[3], row 0 of the batch-8 x_T
+    "default3_ddpm750": (DEFAULT3, "ddpm", 750, 2, 50, None),  # training_pipeline.py:26-32, torch.manual_seed(14555)
+}
+
+
+def trajectory_x_T(key):
+    """(x_T [1,C,H,W] on the CPU, generator or None) of a stored trajectory: the synthetic stream's row 0 for the DDIM
+    cases, the seeded CPU generator's first draw for the evaluate call (it then also supplies every step's noise)."""
+    import torch
+    cfg, _, _, _, _, batch = TRAJECTORIES[key]
+    if batch is not None:
+        return noisy_inputs(cfg, batch, 14555)[:1].contiguous(), None
+    ss = cfg["sample_size"]
+    h, w = (ss, ss) if isinstance(ss, int) else ss
+    gen = torch.manual_seed(14555)
+    return torch.randn((1, cfg["in_channels"], h, w), generator=gen), gen
+
+
+_TRAJ = None
+
+
+def trajectory_golden():
+    global _TRAJ
+    if _TRAJ is None:
+        import os
+        import numpy as np
+        _TRAJ = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "trajectory_golden.npz"))
+    return _TRAJ
+
+
 def grad_sample_stride(numel):
     return max(1, numel // 512)
 

@@ -1,0 +1,83 @@
+#!/usr/bin/env python3
+"""Regenerate tests/golden/trajectory_golden.npz from the CPU oracle (run from the repo root, ~25 minutes on 8 cores):
+
+    python tests/golden/make_trajectory_golden.py [case ...]
+
+FREE-RUNNING sampling trajectories of the fp32 torch-CPU oracle at the BASELINE configurations' own network sizes: the
+image a whole run produces, which is what SURVEY 8c's last tolerance is about ("free-running 10/50-step trajectory:
+rel-L2 <= 1e-3 on the final image; uint8 <= 1 LSB on <= 0.1 % of pixels") and what no single-forward vector can show.
+
+  cfg2_ddim50     BASELINE configs[1]: 50-step DDIM (eta = 0) of the 256x256x4 default U-Net, row 0 of the batch-16 x_T
+  cfg4_ddim100    BASELINE configs[3]: 100-step DDIM of the 6-level 512x512x4 network, row 0 of the batch-8 x_T
+  default3_ddpm750  the reference's own evaluate call (training_pipeline.py:26-32): 750-step ancestral DDPM, batch 1,
+                  x_T and every step's noise from torch.manual_seed(14555) in the order DDPMPipeline draws them
+
+Inputs and weights are the deterministic streams of drivescenegen_amd/synth.py (tests/common.py rebuilds them), so only
+outputs are stored.  Per case: `final` = x_0 at every `stride`-th pixel (fp32), `final_moments` = per-channel fp64 (mean,
+mean square) of the whole x_0, `final_u8` = the whole post-processed image as DDPMPipeline.numpy_to_pil makes it
+((x / 2 + 0.5).clamp(0, 1) -> HWC -> * 255 -> round -> uint8; generation.py:17-20), and `checkpoints` = x_t at every
+`every`-th step at every 8th pixel -- the curve along which an engine run may drift from the oracle's.
+
+Like the other golden files these vectors pin the oracle against drift, not against diffusers (parity unpinned: the
+reference's diffusers 0.20.0 cannot be imported here, see oracle/__init__.py).
+"""
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+
+from oracle.scheduler_oracle import OracleDDIMScheduler, OracleDDPMScheduler  # noqa: E402
+from oracle.unet_oracle import OracleUNet2DModel  # noqa: E402
+from tests.common import TRAJECTORIES, synth_weights, trajectory_x_T  # noqa: E402
+
+PATH = os.path.join(ROOT, "tests", "golden", "trajectory_golden.npz")
+
+
+def to_u8(x):
+    img = (x / 2 + 0.5).clamp(0, 1).permute(0, 2, 3, 1).numpy()
+    return (img * 255).round().astype("uint8")
+
+
+def run(key):
+    cfg, kind, steps, stride, every = TRAJECTORIES[key][:5]
+    net = synth_weights(OracleUNet2DModel(**cfg)).eval()
+    sch = OracleDDIMScheduler() if kind == "ddim" else OracleDDPMScheduler()
+    sch.set_timesteps(steps)
+    x, gen = trajectory_x_T(key)
+    cps = []
+    t0 = time.time()
+    with torch.no_grad():
+        for i, tt in enumerate(sch.timesteps):
+            t = int(tt)
+            if i % every == 0:
+                cps.append(x[:, :, ::8, ::8].clone().numpy())
+            eps = net(x, t).sample
+            if kind == "ddim":
+                x = sch.step(eps, t, x).prev_sample
+            else:
+                noise = torch.randn(tuple(x.shape), generator=gen) if t > 0 else None
+                x = sch.step(eps, t, x, noise=noise).prev_sample
+            if i % 25 == 0:
+                print(key, "step", i, "t", t, f"{time.time() - t0:.0f}s", flush=True)
+    assert torch.isfinite(x).all()
+    return {key + "/final": x[:, :, ::stride, ::stride].contiguous().numpy(),
+            key + "/final_moments": torch.stack([x.double().mean((0, 2, 3)), x.double().pow(2).mean((0, 2, 3))]).numpy(),
+            key + "/final_u8": to_u8(x), key + "/checkpoints": np.stack(cps)}
+
+
+def main():
+    torch.set_num_threads(max(1, os.cpu_count() or 1))
+    out = dict(np.load(PATH)) if os.path.exists(PATH) else {}
+    for key in (sys.argv[1:] or list(TRAJECTORIES)):
+        out.update(run(key))
+        np.savez_compressed(PATH, **out)
+        print("wrote", key, "->", PATH, os.path.getsize(PATH), "bytes", flush=True)
+
+
+if __name__ == "__main__":
+    main()

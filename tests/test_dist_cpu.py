@@ -48,6 +48,7 @@ def _worker(rank, world, port, q):
             assert torch.allclose(flat[o:o + n], torch.full((n,), 0.5)), nm
         # --- dataloader sharding (accelerate's even_batches + synchronised shuffle): every rank runs the same number
         #     of full-size batches; the shards partition the dataset, the ragged tail wraps to the epoch's start ---
+        from drivescenegen_amd.imageops import GpuImageLoader
         ds = torch.arange(40, dtype=torch.float32).view(20, 2)   # 20 samples, batch 4 -> 5 batches: odd for world 2
         for shuffle in (False, True):
             dl = torch.utils.data.DataLoader(ds, batch_size=4, shuffle=shuffle)
@@ -68,12 +69,20 @@ def _worker(rank, world, port, q):
                     assert seeds[0].item() == seeds[1].item()
                 else:
                     assert torch.equal(order[:20], torch.arange(20, dtype=torch.float32))
-        # drop_last: 22 samples, batch 4 -> 5 full batches, the 2 left-over samples are never seen
+        # drop_last: 22 samples, batch 4 -> 5 full batches; accelerate's BatchSamplerShard(drop_last=True) DROPS the
+        # incomplete last round (len = 5 // 2): two steps per rank, samples 0..15 seen once, nothing completed
         dl = torch.utils.data.DataLoader(torch.arange(22, dtype=torch.float32).view(22, 1), batch_size=4, drop_last=True)
-        assert sum(x.shape[0] for x in _ShardedLoader(dl, "cpu", rank, world)) == 12
+        sl = _ShardedLoader(dl, "cpu", rank, world)
+        mine = torch.cat([x for x in sl])[:, 0]
+        assert len(sl) == 2 and mine.numel() == 8
+        allv = [torch.zeros(8) for _ in range(world)]
+        dist.all_gather(allv, mine)
+        assert torch.equal(torch.cat(allv).sort().values, torch.arange(16, dtype=torch.float32))
+        gl = GpuImageLoader([f"f{i}.png" for i in range(22)], (8, 8), batch_size=4, shuffle=False, device="cpu", rank=rank,
+                            world=world, drop_last=True)
+        assert len(gl) == 2 and [len(b) for b in gl._batches()] == [4, 4]
         # --- the GPU input pipeline's loader shards the same way (host logic only here: file indices, no decode):
         #     7 batches of 3 from 21 files -> odd for world 2, plus seed=None -> rank 0's broadcast seed ---
-        from drivescenegen_amd.imageops import GpuImageLoader
         for seed in (None, 11):
             gl = GpuImageLoader([f"f{i}.png" for i in range(20)], (8, 8), batch_size=3, shuffle=True, seed=seed, device="cpu",
                                 rank=rank, world=world)
@@ -222,3 +231,57 @@ def test_one_process_loader_is_the_loader_itself():
     smp = torch.utils.data.RandomSampler(ds, replacement=True, num_samples=12, generator=torch.Generator().manual_seed(3))
     sl = _ShardedLoader(torch.utils.data.DataLoader(ds, batch_size=5, sampler=smp), "cpu", 0, 1)
     assert [b.shape[0] for b in sl] == [5, 5, 2]
+
+
+def test_sharded_loader_without_a_process_group_raises_and_bad_pickles_do_not_recurse(tmp_path):
+    """(1) a sharded loader with seed=None iterated before the process group exists must not let every rank
+    shuffle by its own seed; (2) a directory whose .pkl files hold no dict ends in a clear error, not a RecursionError;
+    (3) a one-process drop_last epoch keeps the loader's own count."""
+    import pytest
+    from drivescenegen_amd import sharding
+    from drivescenegen_amd.imageops import GpuImageLoader
+    with pytest.raises(RuntimeError, match="not initialised"):
+        sharding.broadcast_epoch_seed(1, 2)
+    assert sharding.steps_per_epoch(22, 4, 1, True) == 5 and sharding.steps_per_epoch(22, 4, 2, True) == 2
+    assert sharding.steps_per_epoch(22, 4, 2, False) == 3 and sharding.steps_per_epoch(22, 4, 4, True) == 1
+    assert [len(sharding.shard_batches(range(22), 4, r, 4, True)) for r in range(4)] == [1, 1, 1, 1]
+    for i in range(3):
+        torch.save([i], tmp_path / f"{i}.pkl")
+    ld = GpuImageLoader(str(tmp_path / "*.pkl"), (8, 8), batch_size=1, device="cpu")
+    with pytest.raises(IndexError, match="no usable sample"):
+        ld._load_one(0)
+    torch.save({"fig_tensor": torch.ones(4, 4, 3)}, tmp_path / "9.pkl")
+    ld = GpuImageLoader(str(tmp_path / "*.pkl"), (8, 8), batch_size=1, device="cpu")
+    assert ld._load_one(0).shape == (4, 4, 3)     # the three non-dict pickles are skipped
+
+
+def test_noise_drawn_ahead_is_the_serial_loops_noise():
+    """train_loop.NoiseAhead / batches_with_noise (reference training_pipeline.py:72): the noise of step
+    k+1 is drawn on a worker thread while step k runs, and the stream of values -- and of every other consumer of the global
+    CPU generator: the shuffling sampler's per-epoch seed, a dataset that draws in __getitem__ -- is the serial loop's."""
+    from drivescenegen_amd.train_loop import batches_with_noise
+
+    class Jitter(torch.utils.data.Dataset):     # draws from the global generator when a sample is fetched
+        def __len__(self):
+            return 11
+
+        def __getitem__(self, i):
+            return torch.full((2, 4, 4), float(i)) + torch.rand(())
+
+    def run(overlap):
+        torch.manual_seed(77)
+        dl = torch.utils.data.DataLoader(Jitter(), batch_size=3, shuffle=True)   # 4 batches, the last one short
+        out = []
+        for _epoch in range(2):
+            if overlap is None:     # the reference's loop
+                for batch in dl:
+                    out.append((batch, torch.randn(batch.shape)))
+            else:
+                out.extend(batches_with_noise(dl, overlap))
+        return out
+    ref = run(None)
+    for overlap in (True, False):
+        got = run(overlap)
+        assert len(got) == len(ref) == 8
+        for (b0, n0), (b1, n1) in zip(ref, got):
+            assert torch.equal(b0, b1) and torch.equal(n0, n1) and n1.shape == b1.shape

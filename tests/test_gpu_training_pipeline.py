@@ -178,6 +178,34 @@ def test_fit_runs_epochs_samples_and_checkpoints(tmp_path, tiny_net):
         train_loop.notebook_launcher(lambda: 0, (), num_processes=8)
 
 
+def test_overlapped_noise_draw_trains_bitwise_like_the_serial_loop():
+    """train_loop.fit(overlap_noise=True): step k+1's `torch.randn(batch.shape)` (training_pipeline.py:72) is drawn into pinned
+    memory by a worker thread while the GPU runs step k.  Same generator, same call order: the per-step losses and the final
+    parameters are BITWISE those of the serial loop, and a pinned draw is the pageable draw's values."""
+    from drivescenegen_amd import train_loop
+    torch.manual_seed(5)
+    a = torch.randn(3, 3, 64, 64)
+    torch.manual_seed(5)
+    assert torch.equal(a, torch.randn(3, 3, 64, 64, pin_memory=True))
+    data = torch.from_numpy(synth.synth_scene_rasters(10, 3, 64, 64, 31))
+    runs = {}
+    for overlap in (False, True):
+        torch.manual_seed(123)
+        torch.cuda.manual_seed(123)
+        net = synth_weights(d.UNet2DModel(**CFG1)).to("cuda").train()
+        opt = d.AdamW(net.parameters(), lr=1e-3)
+        loader = torch.utils.data.DataLoader(data, batch_size=4, shuffle=True)        # batches [4, 4, 2] per epoch
+        lrs = d.get_cosine_schedule_with_warmup(optimizer=opt, num_warmup_steps=1, num_training_steps=6)
+        acc = d.Accelerator()
+        net, opt, loader, lrs = acc.prepare(net, opt, loader, lrs)
+        losses = []
+        for _epoch in range(2):
+            losses += [float(l) for l in train_loop.train_steps(acc, net, d.DDPMScheduler(), opt, lrs, loader, overlap)]
+        runs[overlap] = (losses, [p.detach().clone() for p in net.parameters()])
+    assert len(runs[True][0]) == 6 and runs[True][0] == runs[False][0], (runs[True][0], runs[False][0])
+    assert all(torch.equal(p, q) for p, q in zip(runs[True][1], runs[False][1]))
+
+
 def test_loss_goes_down_on_fixed_batch():
     """A few AdamW steps on one fixed (batch, noise, t) reduce the loss: the whole fwd/bwd/update chain is wired
     with the right signs."""

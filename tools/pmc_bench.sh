@@ -12,6 +12,7 @@ tag=$1
 export PMC_SUFFIX=${2:-}
 cmd=${PMC_CMD:-"python bench.py --steps 3 --warmup 1 --no-cpu --no-prof --no-extras"}
 export PMC_CMD_TEXT="$cmd"
+export DSG_GIT_HEAD=$(cat tools/_head.txt 2>/dev/null || echo unknown)
 mkdir -p gpurun_out
 for c in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --pmc $c --kernel-trace -d /tmp/pmcb_${tag}${PMC_SUFFIX}_$c -o p --output-format csv -- \
@@ -37,7 +38,8 @@ for k, v in out.items():
               "fetch_bytes_per_launch": 2.0 * 1024.0 * v["FETCH_SIZE"] / n,   # KiB, x2 (gfx950 correction)
               "write_bytes_per_launch": 1024.0 * v["WRITE_SIZE"] / max(v["n"]["WRITE_SIZE"], 1)}
     res[k]["hbm_bytes_per_launch"] = res[k]["fetch_bytes_per_launch"] + res[k]["write_bytes_per_launch"]
-json.dump({"source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) over: " + os.environ.get("PMC_CMD_TEXT", ""),
+json.dump({"git_head": os.environ.get("DSG_GIT_HEAD", "unknown"),
+           "source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) over: " + os.environ.get("PMC_CMD_TEXT", ""),
            "correction": "FETCH_SIZE x2 (gfx950), KiB units; WRITE_SIZE as reported", "kernels": res},
           open(f"gpurun_out/{tag}_pmc_traffic{sfx}.json", "w"), indent=1)
 for k, v in sorted(res.items(), key=lambda kv: -kv[1]["hbm_bytes_per_launch"] * kv[1]["launches"])[:8]:

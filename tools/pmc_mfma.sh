@@ -17,6 +17,7 @@ tag=$1
 export PMC_SUFFIX=${2:-}
 cmd=${PMC_CMD:-"python bench.py --steps 3 --warmup 1 --no-cpu --no-prof --no-extras"}
 export PMC_CMD_TEXT="$cmd"
+export DSG_GIT_HEAD=$(cat tools/_head.txt 2>/dev/null || echo unknown)
 mkdir -p gpurun_out
 rocprofv3 --pmc SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE --kernel-trace -d /tmp/pmcm_$tag$PMC_SUFFIX -o p \
   --output-format csv -- $cmd > /dev/null 2> gpurun_out/${tag}_pmc_mfma$PMC_SUFFIX.err
@@ -46,7 +47,7 @@ for k, v in acc.items():
     res[k] = {"launches": n, "SQ_INSTS_MFMA": m, "SQ_VALU_MFMA_BUSY_CYCLES": b, "SQ_BUSY_CYCLES": v.get("SQ_BUSY_CYCLES", 0.0) / n,
               "cycles (GRBM_GUI_ACTIVE / 8 XCDs)": g, "mfma_util_issued": (m * 32.0 / (g * 1024.0)) if g else None,
               "mfma_util_counter": (b / (g * 1024.0)) if g else None}
-json.dump({"source": "rocprofv3 --pmc SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE over: " + os.environ.get("PMC_CMD_TEXT", ""),
+json.dump({"git_head": os.environ.get("DSG_GIT_HEAD", "unknown"), "source": "rocprofv3 --pmc SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE over: " + os.environ.get("PMC_CMD_TEXT", ""),
            "kernels": res}, open(f"gpurun_out/{tag}_pmc_mfma{sfx}.json", "w"), indent=1)
 for k, v in sorted(res.items(), key=lambda kv: -kv[1]["cycles (GRBM_GUI_ACTIVE / 8 XCDs)"] * kv[1]["launches"])[:8]:
     print(f'{k[:58]:58s} n={v["launches"]:4d} insts {v["SQ_INSTS_MFMA"]:12.0f} busy {v["SQ_VALU_MFMA_BUSY_CYCLES"]:12.0f} cycles {v["cycles (GRBM_GUI_ACTIVE / 8 XCDs)"]:10.0f} '
