@@ -199,7 +199,7 @@ FWD_CLASSES_16 = {26: "conv3x3_s1_mfma_16bit", 30: "conv3x3_s1_mfma_16bit_two_wg
                   12: "conv_out_blocked_to_image"}
 
 
-def class_roofline(row, peak_tflops, step_ms, sampled_frac=1.0):
+def class_roofline(row, peak_tflops, step_ms, sampled_steps=1):
     """One conv class against BOTH roofs: time at the matrix-core peak for its algorithmic FLOPs, time at 8 TB/s for its
     algorithmic bytes; `bound` is the longer of the two, `frac` = that time / the measured launch time."""
     t_mfma = row["flops_per_launch"] / (peak_tflops * 1e12)
@@ -209,7 +209,7 @@ def class_roofline(row, peak_tflops, step_ms, sampled_frac=1.0):
                 peak=PEAK_HBM_GBS if bound == "hbm" else peak_tflops, unit="GB/s" if bound == "hbm" else "TFLOP/s",
                 frac=max(t_mfma, t_hbm) / (row["avg_ms"] * 1e-3), mfma_tflops=row["tflops"], mfma_frac=row["tflops"] / peak_tflops,
                 alg_gbs=row["alg_gbs"], hbm_frac=row["alg_gbs"] / PEAK_HBM_GBS, avg_launch_ms=row["avg_ms"],
-                launches=row["launches"], time_share=row["total_ms"] / sampled_frac / step_ms)
+                launches=row["launches"], time_share=row["total_ms"] / (sampled_steps * step_ms))
 
 
 def forward_leg(args, cfg, dtype, batch, steps, ddim_steps, workload, flops_img, pmc_suffix, pmc_patterns):
@@ -256,7 +256,7 @@ def forward_leg(args, cfg, dtype, batch, steps, ddim_steps, workload, flops_img,
            "whole_net_tflops": batch * steps / dt * flops_img / 1e12,
            "alg_hbm_gbs_whole_step": None, "kernels": rows}
     peak = PEAK_F16_TFLOPS / (3.0 if dtype == "fp32" else 1.0)
-    sampled = len(range(0, steps, PROF_EVERY)) / steps
+    sampled = len(range(0, steps, PROF_EVERY))   # steps whose launches carry HIP-event records
     conv_rows = {k: v for k, v in rows.items() if k.startswith("conv3x3_s1") or k.startswith("conv3x3_plus")}
     if conv_rows:
         # every 3x3 stride-1 class priced the same way; the headline object is the class with the largest share of the step
@@ -267,7 +267,7 @@ def forward_leg(args, cfg, dtype, batch, steps, ddim_steps, workload, flops_img,
             "2500 TF/s dense f16 MFMA / 3 products per fp32-equivalent MAC" if dtype == "fp32" else "2500 TF/s dense 16-bit MFMA") +
             "; 8 TB/s HBM; frac = max(alg FLOPs / MFMA peak, alg bytes / HBM peak) / measured time",
             other_classes={k: v for k, v in per_class.items() if k != dom})
-    rec["alg_hbm_gbs_whole_step"] = sum(v["bytes_per_launch"] * v["launches"] for v in rows.values()) / sampled / steps / (step_ms * 1e-3) / 1e9
+    rec["alg_hbm_gbs_whole_step"] = sum(v["bytes_per_launch"] * v["launches"] for v in rows.values()) / sampled / (step_ms * 1e-3) / 1e9
     return rec
 
 
@@ -301,7 +301,7 @@ def cfg4_leg(args):
                        "66,294,660 params), 100-step DDIM (eta=0), batch 8 on 1 GPU, fp32-equivalent", CFG4_FLOPS_IMG, "_cfg4", pats)
 
 
-def train_ref_leg(args, steps=5):
+def train_ref_leg(args, steps=8):
     """Extra record: the reference's OWN training operating point (train.py:16,24,39-57: the 3-channel default network,
     mixed_precision='fp16', train_batch_size 14) through the Accelerator mirror's loop body (training_pipeline.py:70-91 =
     train_loop.train_step: add_noise, forward, MSE, scaled backward, unscale + clip 1.0, AdamW, cosine LR)."""
@@ -320,14 +320,16 @@ def train_ref_leg(args, steps=5):
     x0 = torch.from_numpy(synth.synth_scene_rasters(batch, 3, 256, 256, 14555)).to(dev)
     # train_loop.train_steps = fit's inner loop: step k+1's host noise (training_pipeline.py:72) is drawn by a worker thread
     # while the GPU runs step k (same generator, same order, same values)
-    for loss in train_steps(acc, net, sch, opt, lrs, [x0] * 3):
-        pass
-    torch.cuda.synchronize(dev)
-    clock = StepClock(dev)
-    t0 = time.perf_counter()
-    clock.tick()
-    for loss in train_steps(acc, net, sch, opt, lrs, [x0] * steps):
-        clock.tick()
+    # ONE pass of train_steps over warm-up + timed batches, as an epoch of `fit` is: the clock starts when the third step has been
+    # queued (every later step's noise was drawn while its predecessor ran; only an epoch's first step draws on the critical path)
+    clock, t0, warm = StepClock(dev), None, 3
+    for i, loss in enumerate(train_steps(acc, net, sch, opt, lrs, [x0] * (warm + steps))):
+        if i == warm - 1:
+            torch.cuda.synchronize(dev)
+            t0 = time.perf_counter()
+            clock.tick()
+        elif i >= warm:
+            clock.tick()
     torch.cuda.synchronize(dev)
     dt = time.perf_counter() - t0
     assert torch.isfinite(loss).all()
@@ -339,7 +341,7 @@ def train_ref_leg(args, steps=5):
             "peak_mem_gib": torch.cuda.max_memory_allocated(dev) / 2 ** 30}
 
 
-def train_leg(args, dtype="fp32", batch=64, steps=3):
+def train_leg(args, dtype="fp32", batch=64, steps=4):
     """Extra record: optimizer steps of the training loop (training_pipeline.py:70-91: add_noise, U-Net forward, MSE,
     backward, clip 1.0, AdamW, cosine LR) on BASELINE configs[2]'s network at `batch` samples on one GPU; images/s."""
     import drivescenegen_amd as d
@@ -365,7 +367,7 @@ def train_leg(args, dtype="fp32", batch=64, steps=3):
         lrs.step()
         opt.zero_grad()
         return loss
-    for _ in range(2):
+    for _ in range(3):   # (the third warm-up step: at 60 GiB the allocator still grows during the second)
         one()
     torch.cuda.synchronize(dev)
     clock = StepClock(dev)

@@ -487,6 +487,7 @@ void unet_set_blocked(int v);
 void attention_set_mfma(int v);
 void wgrad_h2_set_enabled(int on);
 void conv_wgrad16_set_wide(int v);
+void wgrad_h2_set_wide(int v);
 void conv_wgrad16_set_pw(int v);
 void conv_h2_set_fold(int on);
 
@@ -901,6 +902,10 @@ DSG_API int dsg_set_tuning(int32_t key, int32_t value) {
   }
   if (key == 26 && (value == 0 || value == 1)) {
     dsg::conv_h2_set_pre(value);
+    return DSG_OK;
+  }
+  if (key == 31 && (value == 0 || value == 1)) {
+    dsg::wgrad_h2_set_wide(value);
     return DSG_OK;
   }
   if (key == 30 && (value == 0 || value == 1)) {

@@ -737,6 +737,302 @@ __global__ __launch_bounds__(256, 1) void conv_wgrad_h2_kernel(WgradP p) {
   }
 }
 
+// ---------------------------------------------------------------------------------------------------
+// The same kernel with a 32 ci x 128 co workgroup (cout % 128 == 0; round 4, dsg_set_tuning key 31).  The 32 x 64 workgroup
+// re-reads, re-activates and re-splits A once per 64 output channels and its waves see 12 fragment reads per 15 (12) matrix
+// instructions, waves 0-1 carrying five taps against the others' four.  Here wave w = (co pair cp = w & 1, tap group g = w >> 1)
+// owns the co tiles 2cp, 2cp + 1 with the taps 0..3 (g = 0) or 5..8 (g = 1), and the centre tap for co tile 2cp + g: nine
+// (tap, co tile) units on every wave -- 27 matrix instructions per k-step on every SIMD, fed by 14 fragment reads (an A fragment
+// serves two co tiles), the activation arithmetic of a stage spread over 108 matrix instructions instead of 60 (48), x read
+// cout / 128 times.  18 accumulator tiles (hi + lo) are 288 registers: sixteen live in the 256 AGPRs behind the builtin, the
+// centre unit's two are pinned to architectural registers through the instruction as inline asm (conv_wgrad16_kernel's device).
+// Per (ci, co, tap) the products are accumulated over a run's pixels in the 32 x 64 kernel's order: equal runs, equal bits.
+// LDS: the A ring as before (76.8 KB) + dY [buffer 2][piece 2][co 128][2 rows x 32 columns] (73.7 KB).
+// ---------------------------------------------------------------------------------------------------
+constexpr int WW_CO = 128;
+constexpr int WW_D_HALFS = 2 * WW_CO * WH_DSTR;
+constexpr int WW_LDS_BYTES = (WH_A_HALFS + 2 * WW_D_HALFS) * 2;
+
+__device__ __forceinline__ void mma_f16_vacc(const whalf8& a, const whalf8& b, wf32x16& c) {
+  asm("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+v"(c) : "v"(a), "v"(b));
+}
+
+__global__ __launch_bounds__(256, 1) void conv_wgrad_h2w_kernel(WgradP p) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char wsm[];
+  _Float16* ab = reinterpret_cast<_Float16*>(wsm);
+  _Float16* dbase = ab + WH_A_HALFS;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int half = lane >> 5;
+  const int l31 = lane & 31;
+  const int cp = wave & 1;
+  const bool first = wave < 2;  // tap group 0: taps 0..3 and the centre tap for co tile 2cp; group 1: 5..8, centre for 2cp + 1
+
+  int pair_id, slab_id;
+  wgrad_xcd_ids(pair_id, slab_id);
+  const int cib = pair_id % p.ci_blocks;
+  const int cob = pair_id / p.ci_blocks;
+  const int ci0 = cib * 32, co0 = cob * WW_CO;
+  const int plane = p.hin * p.win;
+  const int oplane = p.hout * p.wout;
+  const bool has_ss = p.ss != nullptr;
+  const bool do_silu = has_ss && p.silu;
+
+  const int nrs = p.ntiles;
+  const int strip = slab_id / nrs, rs = slab_id - strip * nrs;
+  const int n = strip / p.tiles_x, tx = strip - n * p.tiles_x;
+  const int ox0 = tx * 32;
+  const int per = (p.tiles_y + nrs - 1) / nrs;
+  const int s0 = rs * per, s1 = min(p.tiles_y, s0 + per);
+
+  const bool in0 = ci0 < p.c0;
+  const float* srcb = in0 ? p.src0 + ((size_t)n * p.c0 + ci0) * plane : p.src1 + ((size_t)n * p.c1 + (ci0 - p.c0)) * plane;
+  const float* src_all = in0 ? p.src0 : p.src1;
+  const size_t src_bytes = (size_t)p.n * (in0 ? p.c0 : p.c1) * plane * 4;
+  const int src_off = (int)((srcb - src_all) * 4);
+  const __amdgpu_buffer_rsrc_t a_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(src_all), 0, (int)src_bytes, 0x00020000);
+  const float* dyb = p.dy + ((size_t)n * p.dy_ctotal + p.dy_coff + co0) * oplane;
+  const __amdgpu_buffer_rsrc_t d_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(dyb), 0, WW_CO * oplane * 4, 0x00020000);
+  const __amdgpu_buffer_rsrc_t s_rs = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float*>(has_ss ? p.ss + ((size_t)n * p.cin + ci0) * 2 : p.dy), 0, has_ss ? 32 * 8 : 0, 0x00020000);
+
+  // staging items.  A: (ci, row of the pair, 8-column octet) -- one per thread; dY: (co, octet of the 2x32 stage) x 4
+  const int a_oct = tid & 3, a_rr = (tid >> 2) & 1, a_ci = tid >> 3;
+  const int a_voff = src_off + (a_ci * plane + a_rr * p.win + ox0 + a_oct * 8 - 1) * 4;
+  const unsigned a_colmask = 0x3FFu & ~((ox0 == 0 && a_oct == 0) ? 1u : 0u) & ~((ox0 + 32 == p.wc && a_oct == 3) ? 0x200u : 0u);
+  float sca = 1.f, sha = 0.f;
+  if (has_ss) {
+    const float2 s2 = __builtin_bit_cast(float2, __builtin_amdgcn_raw_buffer_load_b64(s_rs, a_ci * 8, 0, 0));
+    sca = s2.x;
+    sha = s2.y;
+  }
+  // dY item u of this thread: co = (tid >> 3) + 32 u, octet tid & 7 (the same octet for its four items)
+  const int d_oct = tid & 7;
+  const int d_voff0 = ((tid >> 3) * oplane + (d_oct >> 2) * p.wout + ox0 + (d_oct & 3) * 8) * 4;  // + u * 32 * oplane * 4, + 2s*wout*4
+  const int d_lds0 = (tid >> 3) * WH_DSTR + d_oct * 8;                                           // + u * 32 * WH_DSTR
+  const int d_ustep = 32 * oplane * 4;
+
+  float xa[10];
+  float4 xd[4][2];
+  unsigned va = 0;
+  auto load_rows = [&](int k) {  // input rows 2k-1, 2k of the strip
+    const int off = a_voff + (2 * k - 1) * p.win * 4;
+    const float4 q0 = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(a_rs, off + 4, 0, 0));
+    const float4 q1 = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(a_rs, off + 20, 0, 0));
+    xa[0] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(a_rs, off, 0, 0));
+    xa[9] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(a_rs, off + 36, 0, 0));
+    xa[1] = q0.x; xa[2] = q0.y; xa[3] = q0.z; xa[4] = q0.w;
+    xa[5] = q1.x; xa[6] = q1.y; xa[7] = q1.z; xa[8] = q1.w;
+    va = ((unsigned)(2 * k - 1 + a_rr) < (unsigned)p.hc) ? a_colmask : 0u;
+  };
+  auto load_dy = [&](int s, int u0, int u1) {
+#pragma unroll
+    for (int u = u0; u < u1; ++u) {
+      const int off = d_voff0 + u * d_ustep + 2 * s * p.wout * 4;
+      xd[u][0] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(d_rs, off, 0, 0));
+      xd[u][1] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(d_rs, off + 16, 0, 0));
+    }
+  };
+  auto split2 = [](float v0, float v1, unsigned& hi, unsigned& lo) {
+    const _Float16 a0 = (_Float16)v0, a1 = (_Float16)v1;
+    const _Float16 b0 = (_Float16)((v0 - (float)a0) * 2048.0f), b1 = (_Float16)((v1 - (float)a1) * 2048.0f);
+    hi = (unsigned)__builtin_bit_cast(unsigned short, a0) | ((unsigned)__builtin_bit_cast(unsigned short, a1) << 16);
+    lo = (unsigned)__builtin_bit_cast(unsigned short, b0) | ((unsigned)__builtin_bit_cast(unsigned short, b1) << 16);
+  };
+  unsigned ph[5], pl[5];
+  auto commit_rows = [&](int k, int part) {
+#pragma unroll
+    for (int j2 = (part == 1 ? 3 : 0); j2 < (part == 0 ? 3 : 5); ++j2) {
+      float v[2];
+#pragma unroll
+      for (int e = 0; e < 2; ++e) {
+        const int j = 2 * j2 + e;
+        float x = xa[j] * sca + sha;
+        const float sx = silu_fast_b(x);
+        x = do_silu ? sx : x;
+        v[e] = ((va >> j) & 1u) ? x : 0.f;
+      }
+      split2(v[0], v[1], ph[j2], pl[j2]);
+    }
+    if (part == 0) return;
+    const int slot = (2 * k) % WH_SLOTS + a_rr;
+    _Float16* dst = ab + a_ci * WH_ASTR + slot * 32 + a_oct * 8;
+#pragma unroll
+    for (int s = 0; s < 3; ++s) {
+      uint4 wh, wl;
+      if (s == 1) {
+        wh = make_uint4(__builtin_amdgcn_alignbit(ph[1], ph[0], 16), __builtin_amdgcn_alignbit(ph[2], ph[1], 16),
+                        __builtin_amdgcn_alignbit(ph[3], ph[2], 16), __builtin_amdgcn_alignbit(ph[4], ph[3], 16));
+        wl = make_uint4(__builtin_amdgcn_alignbit(pl[1], pl[0], 16), __builtin_amdgcn_alignbit(pl[2], pl[1], 16),
+                        __builtin_amdgcn_alignbit(pl[3], pl[2], 16), __builtin_amdgcn_alignbit(pl[4], pl[3], 16));
+      } else {
+        const int o = s >> 1;
+        wh = make_uint4(ph[o], ph[o + 1], ph[o + 2], ph[o + 3]);
+        wl = make_uint4(pl[o], pl[o + 1], pl[o + 2], pl[o + 3]);
+      }
+      *reinterpret_cast<uint4*>(dst + (s * 2 + 0) * 32 * WH_ASTR) = wh;
+      *reinterpret_cast<uint4*>(dst + (s * 2 + 1) * 32 * WH_ASTR) = wl;
+    }
+  };
+  float dsum[4] = {0.f, 0.f, 0.f, 0.f};
+  auto commit_dy = [&](int par, int u0, int u1, float cnt) {
+    _Float16* db = dbase + par * WW_D_HALFS + d_lds0;
+#pragma unroll
+    for (int u = u0; u < u1; ++u) {
+      dsum[u] += cnt * (((xd[u][0].x + xd[u][0].y) + (xd[u][0].z + xd[u][0].w)) +
+                        ((xd[u][1].x + xd[u][1].y) + (xd[u][1].z + xd[u][1].w)));
+      uint4 dh, dl;
+      split2(xd[u][0].x, xd[u][0].y, dh.x, dl.x);
+      split2(xd[u][0].z, xd[u][0].w, dh.y, dl.y);
+      split2(xd[u][1].x, xd[u][1].y, dh.z, dl.z);
+      split2(xd[u][1].z, xd[u][1].w, dh.w, dl.w);
+      *reinterpret_cast<uint4*>(db + u * 32 * WH_DSTR) = dh;
+      *reinterpret_cast<uint4*>(db + WW_CO * WH_DSTR + u * 32 * WH_DSTR) = dl;
+    }
+  };
+
+  wf32x16 acc_hi[8], acc_lo[8], cen_hi, cen_lo;  // [tap of the group 4][co tile of the pair 2]; the centre unit (pinned)
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    cen_hi[r] = 0.f;
+    cen_lo[r] = 0.f;
+  }
+#pragma unroll
+  for (int t = 0; t < 8; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      acc_hi[t][r] = 0.f;
+      acc_lo[t][r] = 0.f;
+    }
+
+  if (s0 < s1) {
+    load_rows(s0);
+    load_dy(s0, 0, 4);
+    commit_rows(s0, 2);
+    load_rows(s0 + 1);
+    commit_dy(0, 0, 4, 1.f);
+    commit_rows(s0 + 1, 2);
+    load_rows(s0 + 2);
+    if (s0 + 1 < s1) load_dy(s0 + 1, 0, 4);
+  }
+  __syncthreads();
+
+  const _Float16* a_lane = ab + l31 * WH_ASTR + half * 8;
+  const _Float16* d_lane = dbase + (cp * 64 + l31) * WH_DSTR + half * 8;
+  auto run = [&](auto first_tag) {
+  for (int s = s0; s < s1; ++s) {
+    const int par = (s - s0) & 1;
+    const bool more = s + 1 < s1;
+    int slot_off[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) slot_off[j] = ((2 * s + j) % WH_SLOTS) * 32;
+    const _Float16* dl = d_lane + par * WW_D_HALFS;
+    {
+      constexpr bool FIRST = decltype(first_tag)::value;
+      constexpr int T0 = FIRST ? 0 : 5, CJ = FIRST ? 0 : 1;
+      whalf8 fa[2][5][2], fb[2][2][2];
+      auto frags = [&](int kk, int fp) {
+        const int orow = kk >> 1, colg = (kk & 1) * 16;
+#pragma unroll
+        for (int cj = 0; cj < 2; ++cj) {
+          fb[fp][cj][0] = *reinterpret_cast<const whalf8*>(dl + cj * 32 * WH_DSTR + orow * 32 + colg);
+          fb[fp][cj][1] = *reinterpret_cast<const whalf8*>(dl + (WW_CO + cj * 32) * WH_DSTR + orow * 32 + colg);
+        }
+#pragma unroll
+        for (int tp = 0; tp < 5; ++tp) {
+          const int tap = tp < 4 ? T0 + tp : 4;
+          const int dy = tap / 3, dx = tap % 3;
+          const _Float16* ap = a_lane + slot_off[orow + dy] + colg;
+          fa[fp][tp][0] = *reinterpret_cast<const whalf8*>(ap + (dx * 2 + 0) * 32 * WH_ASTR);
+          fa[fp][tp][1] = *reinterpret_cast<const whalf8*>(ap + (dx * 2 + 1) * 32 * WH_ASTR);
+        }
+      };
+      frags(0, 0);
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk) {
+        __builtin_amdgcn_sched_barrier(0);
+        if (kk < 3) frags(kk + 1, (kk + 1) & 1);
+        if (kk == 0) commit_rows(s + 2, 0);
+        if (kk == 1) {
+          commit_rows(s + 2, 1);
+          load_rows(s + 3);
+        }
+        if (kk == 2) {
+          commit_dy(par ^ 1, 0, 2, more ? 1.f : 0.f);
+          load_dy(s + 2, 0, 2);
+        }
+        if (kk == 3) {
+          commit_dy(par ^ 1, 2, 4, more ? 1.f : 0.f);
+          load_dy(s + 2, 2, 4);
+        }
+        const int fp = kk & 1;
+        // the centre unit first (inline asm on a pinned tile: a whole k-step of other instructions follows before the
+        // tile is touched again), its two low-order products behind taps 0 and 1
+        mma_f16_vacc(fa[fp][4][0], fb[fp][CJ][0], cen_hi);
+#pragma unroll
+        for (int tp = 0; tp < 4; ++tp) {
+#pragma unroll
+          for (int cj = 0; cj < 2; ++cj) {
+            acc_hi[tp * 2 + cj] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[fp][tp][0], fb[fp][cj][0], acc_hi[tp * 2 + cj], 0, 0, 0);
+            acc_lo[tp * 2 + cj] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[fp][tp][0], fb[fp][cj][1], acc_lo[tp * 2 + cj], 0, 0, 0);
+            acc_lo[tp * 2 + cj] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[fp][tp][1], fb[fp][cj][0], acc_lo[tp * 2 + cj], 0, 0, 0);
+          }
+          if (tp == 0) mma_f16_vacc(fa[fp][4][0], fb[fp][CJ][1], cen_lo);
+          if (tp == 1) mma_f16_vacc(fa[fp][4][1], fb[fp][CJ][0], cen_lo);
+        }
+#pragma unroll
+        for (int m = 0; m < 24; ++m) {
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+          __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    __syncthreads();
+  }
+  };
+  if (first) run(std::true_type{});
+  else run(std::false_type{});
+
+  if (p.dysum_ws != nullptr && cib == 0) {
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      float t = dsum[u];
+      t += __shfl_xor(t, 1, 64);
+      t += __shfl_xor(t, 2, 64);
+      t += __shfl_xor(t, 4, 64);
+      if ((tid & 7) == 0) p.dysum_ws[(size_t)slab_id * p.cout_pad + co0 + (tid >> 3) + 32 * u] = t;
+    }
+  }
+  // epilogue: D[ci][co = l31] per (tap, co tile); partials to this run's slab [tap][ci][co]
+  float* wsb = p.ws + (size_t)slab_id * 9 * p.cin_pad * p.cout_pad;
+  const int t0 = first ? 0 : 5;
+#pragma unroll
+  for (int tp = 0; tp < 4; ++tp)
+#pragma unroll
+    for (int cj = 0; cj < 2; ++cj) {
+      const int co = co0 + (2 * cp + cj) * 32 + l31;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int ci = ci0 + (r & 3) + 8 * (r >> 2) + 4 * half;
+        wsb[((size_t)(t0 + tp) * p.cin_pad + ci) * p.cout_pad + co] = acc_hi[tp * 2 + cj][r] + acc_lo[tp * 2 + cj][r] * (1.0f / 2048.0f);
+      }
+    }
+  {
+    const int co = co0 + (2 * cp + (first ? 0 : 1)) * 32 + l31;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int ci = ci0 + (r & 3) + 8 * (r >> 2) + 4 * half;
+      wsb[((size_t)4 * p.cin_pad + ci) * p.cout_pad + co] = cen_hi[r] + cen_lo[r] * (1.0f / 2048.0f);
+    }
+  }
+}
+
+static int g_wgrad_h2_wide = 1;  // dsg_set_tuning key 31 (tests / A-B runs): 0 = the 32 x 64 workgroup everywhere
+void wgrad_h2_set_wide(int v) { g_wgrad_h2_wide = v; }
+static bool wgrad_h2_wide(int cout) { return g_wgrad_h2_wide && cout % WW_CO == 0; }
+
 static int g_wgrad_h2 = 1;
 void wgrad_h2_set_enabled(int on) { g_wgrad_h2 = on; }
 
@@ -784,7 +1080,7 @@ static int launch_wgrad(WgradP p, size_t ws_bytes, hipStream_t st) {
 
 // runs of the fp16x2-split kernel: every (image, 32-column strip) is cut into `rsplit` runs of consecutive row pairs
 static void wgrad_h2_runs(int cin, int cout, int n, int hout, int wout, int* strips, int* rsplit) {
-  const int pairs = (cin / 32) * (cout / WG_CO);
+  const int pairs = (cin / 32) * (cout / (wgrad_h2_wide(cout) ? WW_CO : WG_CO));
   *strips = n * (wout / 32);
   const int stages = hout / 2;
   const int want = std::max(1, cdiv(512, pairs));             // workgroups wanted per (ci, co) pair (2 per CU in all)
@@ -794,7 +1090,8 @@ static void wgrad_h2_runs(int cin, int cout, int n, int hout, int wout, int* str
 static int launch_wgrad_h2(WgradP p, size_t ws_bytes, hipStream_t st, float* dy_sums = nullptr, int dy_sums_stride = 0,
                            float* dy_bias_grad = nullptr) {
   p.ci_blocks = p.cin / 32;
-  const int co_blocks = p.cout / WG_CO;
+  const bool wide = wgrad_h2_wide(p.cout);
+  const int co_blocks = p.cout / (wide ? WW_CO : WG_CO);
   const int pairs = p.ci_blocks * co_blocks;
   int strips, rsplit;
   wgrad_h2_runs(p.cin, p.cout, p.n, p.hout, p.wout, &strips, &rsplit);
@@ -810,13 +1107,16 @@ static int launch_wgrad_h2(WgradP p, size_t ws_bytes, hipStream_t st, float* dy_
   if (!raised) {
     DSG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wgrad_h2_kernel),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    DSG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wgrad_h2w_kernel),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     raised = true;
   }
   int pi = -1;
   if (prof_on())
     pi = prof_begin(9, 2.0 * p.n * p.hout * p.wout * (double)p.cout * p.cin * 9,
                     4.0 * ((double)p.n * p.cin * p.hin * p.win + (double)p.n * p.cout * p.hout * p.wout), st);
-  hipLaunchKernelGGL(conv_wgrad_h2_kernel, dim3(pairs, nslab), dim3(256), (size_t)WH_LDS_BYTES, st, p);
+  if (wide) hipLaunchKernelGGL(conv_wgrad_h2w_kernel, dim3(pairs, nslab), dim3(256), (size_t)WW_LDS_BYTES, st, p);
+  else hipLaunchKernelGGL(conv_wgrad_h2_kernel, dim3(pairs, nslab), dim3(256), (size_t)WH_LDS_BYTES, st, p);
   DSG_LAUNCH_CHECK();
   const int64_t slab = (int64_t)9 * p.cin_pad * p.cout_pad;
   (void)slab;

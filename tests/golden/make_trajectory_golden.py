@@ -18,6 +18,12 @@ mean square) of the whole x_0, `final_u8` = the whole post-processed image as DD
 ((x / 2 + 0.5).clamp(0, 1) -> HWC -> * 255 -> round -> uint8; generation.py:17-20), and `checkpoints` = x_t at every
 `every`-th step at every 8th pixel -- the curve along which an engine run may drift from the oracle's.
 
+`--sensitivity` adds `self_divergence`: the same oracle run again from an x_T moved by 1e-6 (relative), compared with its own
+unperturbed run at the same checkpoints and at the end.  With the synthetic (untrained, random) weights these networks are
+not contractive: two fp32 runs that differ by one forward's round-off drift apart exponentially, and the free-running
+tolerance of SURVEY 8c can only be asked for inside the horizon where the oracle agrees with ITSELF.  `--early` stores that
+horizon at full resolution: x_t after each of the first 5 steps, and the perturbed run's distance from it.
+
 Like the other golden files these vectors pin the oracle against drift, not against diffusers (parity unpinned: the
 reference's diffusers 0.20.0 cannot be imported here, see oracle/__init__.py).
 """
@@ -43,18 +49,29 @@ def to_u8(x):
     return (img * 255).round().astype("uint8")
 
 
-def run(key):
+PERTURB = 1e-6   # relative size of the x_T perturbation of the sensitivity runs: the class of one forward's fp32 round-off
+
+
+EARLY = 5   # the first steps, stored one by one: the stretch where two fp32 runs still agree to the free-running tolerance
+
+
+def run(key, perturb=0.0, early=False):
     cfg, kind, steps, stride, every = TRAJECTORIES[key][:5]
     net = synth_weights(OracleUNet2DModel(**cfg)).eval()
     sch = OracleDDIMScheduler() if kind == "ddim" else OracleDDPMScheduler()
     sch.set_timesteps(steps)
     x, gen = trajectory_x_T(key)
+    if perturb:   # the SAME oracle from an x_T moved by `perturb` (relative, seeded): how fast two fp32 runs drift apart
+        from drivescenegen_amd import synth
+        x = x + perturb * x.pow(2).mean().sqrt() * torch.from_numpy(synth.normal(999, tuple(x.shape)))
     cps = []
     t0 = time.time()
     with torch.no_grad():
         for i, tt in enumerate(sch.timesteps):
             t = int(tt)
-            if i % every == 0:
+            if early and i == EARLY:
+                return np.stack(cps[1:] + [x[:, :, ::8, ::8].clone().numpy()])   # x after steps 1 .. EARLY
+            if early or i % every == 0:
                 cps.append(x[:, :, ::8, ::8].clone().numpy())
             eps = net(x, t).sample
             if kind == "ddim":
@@ -65,15 +82,43 @@ def run(key):
             if i % 25 == 0:
                 print(key, "step", i, "t", t, f"{time.time() - t0:.0f}s", flush=True)
     assert torch.isfinite(x).all()
+    if perturb:
+        return np.stack(cps), x[:, :, ::stride, ::stride].contiguous().numpy()
     return {key + "/final": x[:, :, ::stride, ::stride].contiguous().numpy(),
             key + "/final_moments": torch.stack([x.double().mean((0, 2, 3)), x.double().pow(2).mean((0, 2, 3))]).numpy(),
             key + "/final_u8": to_u8(x), key + "/checkpoints": np.stack(cps)}
 
 
+def rel(a, b):
+    a, b = a.astype(np.float64).ravel(), b.astype(np.float64).ravel()
+    return float(np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-30))
+
+
 def main():
     torch.set_num_threads(max(1, os.cpu_count() or 1))
     out = dict(np.load(PATH)) if os.path.exists(PATH) else {}
-    for key in (sys.argv[1:] or list(TRAJECTORIES)):
+    args = [a for a in sys.argv[1:] if not a.startswith("--")]
+    if "--early" in sys.argv:
+        # key/early = x_t after each of the first EARLY steps (every 8th pixel); key/early_self_divergence = the perturbed
+        # oracle run against it, step by step
+        for key in (args or list(TRAJECTORIES)):
+            base, pert = run(key, 0.0, True), run(key, PERTURB, True)
+            out[key + "/early"] = base
+            out[key + "/early_self_divergence"] = np.array([rel(a, b) for a, b in zip(pert, base)])
+            np.savez_compressed(PATH, **out)
+            print("early", key, out[key + "/early_self_divergence"], flush=True)
+        return
+    if "--sensitivity" in sys.argv:
+        # key/self_divergence = [rel-L2 between the oracle's run and the oracle's run from the perturbed x_T at every stored
+        # checkpoint ..., at the final image]: the envelope any other fp32 implementation's drift is judged against
+        for key in (args or list(TRAJECTORIES)):
+            cps, fin = run(key, PERTURB)
+            out[key + "/self_divergence"] = np.array([rel(c, g) for c, g in zip(cps, out[key + "/checkpoints"])] +
+                                                     [rel(fin, out[key + "/final"])])
+            np.savez_compressed(PATH, **out)
+            print("sensitivity", key, out[key + "/self_divergence"], flush=True)
+        return
+    for key in (args or list(TRAJECTORIES)):
         out.update(run(key))
         np.savez_compressed(PATH, **out)
         print("wrote", key, "->", PATH, os.path.getsize(PATH), "bytes", flush=True)

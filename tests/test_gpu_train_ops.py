@@ -249,6 +249,45 @@ def test_wgrad_split_path_random_shapes(case):
     _close(dw, wt.grad, rel=3e-5, ab=3e-5)
 
 
+@pytest.mark.parametrize("case", [(64, 0, 128, 32, 64, True, 2), (128, 128, 256, 16, 32, True, 3), (96, 32, 384, 8, 32, False, 1),
+                                  (256, 0, 512, 32, 32, True, 2), (64, 64, 128, 64, 64, True, 1)],
+                         ids=lambda c: "c%d+%d_o%d_%dx%d" % c[:5])
+def test_wgrad_wide_workgroups_match_the_32x64_ones(case):
+    """cout % 128 == 0 selects the 32 ci x 128 co workgroup of the fp32-equivalent 3x3 weight gradient (conv_wgrad_h2w_kernel:
+    two co tiles per wave, the centre tap's unit on pinned registers; dsg_set_tuning key 31 = 0 keeps the 32 x 64 workgroup).
+    Both against fp64 autograd (3e-5 class, as the random-shape test) and against each other: per (ci, co, tap) the products are
+    summed over a run's pixels in the same order, runs are cut by the (smaller) pair count, so the two agree to the rounding of
+    the split-K reduce (1e-6), and the dY-sum by-products likewise."""
+    from drivescenegen_amd import _lib
+    c0, c1, cout, h, w, gn, batch = case
+    cin = c0 + c1
+    x0 = _t(71, (batch, c0, h, w))
+    x1 = _t(72, (batch, c1, h, w)) if c1 else None
+    gamma, beta = 1 + _t(75, (cin,), 0.1), _t(76, (cin,), 0.1)
+    xin = torch.cat([x0, x1], 1) if c1 else x0
+    a = (F.silu(F.group_norm(xin.double(), 8, gamma.double(), beta.double(), 1e-5)) if gn else xin.double())
+    dy = _t(79, (batch, cout, h, w))
+    want = torch.nn.grad.conv2d_weight(a, (cout, cin, 3, 3), dy.double(), padding=1)
+    d = lambda t: None if t is None else t.to(DEV)
+    ss = ops.gn_scale_shift(d(x0), d(gamma), d(beta), 8, 1e-5, src1=d(x1)) if gn else None
+    got = {}
+    lib = _lib.load()
+    try:
+        for wide in (0, 1):
+            _lib.check(lib.dsg_set_tuning(31, wide))
+            dw = torch.zeros((cout, cin, 3, 3), device=DEV)
+            sums = torch.zeros((batch, cout), device=DEV)
+            ops.conv_wgrad(d(x0), d(dy), dw, src1=d(x1), ksize=3, gn_scale_shift=ss, silu=gn, dy_sums=sums, dy_sums_stride=cout)
+            got[wide] = (dw.cpu(), sums.cpu())
+    finally:
+        lib.dsg_set_tuning(31, 1)
+    for wide in (0, 1):
+        _close(got[wide][0], want.float(), rel=3e-5, ab=3e-5)
+    scale = float(want.abs().max())
+    assert float((got[0][0].double() - got[1][0].double()).abs().max()) <= 2e-6 * scale
+    assert torch.allclose(got[0][1], got[1][1], rtol=0, atol=2e-6 * float(dy.double().sum((2, 3)).abs().max()))
+
+
 def test_wgrad_dy_sums_refused_where_not_a_by_product():
     """dy_sums is a by-product of the split 3x3 kernel (and of the 16-bit one); a call another kernel serves reports
     the request as unsupported instead of leaving the table unwritten."""

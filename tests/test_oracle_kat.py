@@ -145,3 +145,64 @@ def test_fullsize_golden_vectors_are_what_the_oracle_computes():
     assert rel_l2(y[:, :, ::stride, ::stride], torch.from_numpy(gold[key])) <= 1e-6
     mom = torch.from_numpy(gold[key + "/moments"])
     assert torch.allclose(y.double().pow(2).mean((0, 2, 3)), mom[1], rtol=1e-6)
+
+
+def test_training_golden_is_what_the_oracle_computes():
+    """the stored training-step vectors were only shape-checked.  One of them -- the reference's own 3-channel
+    network at batch 2 (default3_train_b2) -- is re-derived here from the oracle's autograd: loss, every gradient tensor's
+    L2 norm and the stored gradient entries."""
+    import numpy as np
+    import torch
+    import torch.nn.functional as F
+    from oracle.scheduler_oracle import OracleDDPMScheduler
+    from oracle.unet_oracle import OracleUNet2DModel
+    from tests.common import fullsize_golden, fullsize_train_case, grad_sample_stride, synth_weights
+    key = "default3_train_b2"
+    gold = fullsize_golden()
+    cfg, x0, noise, t = fullsize_train_case(key)
+    ora = synth_weights(OracleUNet2DModel(**cfg)).train()
+    loss = F.mse_loss(ora(OracleDDPMScheduler().add_noise(x0, noise, t), t, return_dict=False)[0], noise)
+    loss.backward()
+    assert abs(float(loss.detach()) - float(gold[key + "/loss"][0])) <= 1e-5 * float(gold[key + "/loss"][0])
+    norms, samples = [], []
+    for _, p in ora.named_parameters():
+        g = p.grad.detach().flatten()
+        norms.append(float(g.double().norm()))
+        samples.append(g[::grad_sample_stride(g.numel())].numpy())
+    norms, samples = np.array(norms), np.concatenate(samples)
+    want_n, want_s = gold[key + "/grad_norms"], gold[key + "/grad_samples"]
+    assert norms.shape == want_n.shape and samples.shape == want_s.shape
+    assert np.all(np.abs(norms - want_n) <= 1e-4 * want_n + 1e-12)          # (thread counts reorder torch-CPU's sums)
+    assert np.linalg.norm(samples - want_s) <= 1e-4 * np.linalg.norm(want_s)
+
+
+def test_trajectory_golden_is_complete_and_self_consistent():
+    """tests/golden/trajectory_golden.npz: every case of tests/common.TRAJECTORIES is there with its four arrays; the stored
+    uint8 image is the rounding of the stored float image where both exist; the first checkpoint is x_T itself; and the
+    first stored stretch of the configs[1] run (10 DDIM steps from x_T) is what the oracle computes on this host."""
+    import numpy as np
+    import torch
+    from oracle.scheduler_oracle import OracleDDIMScheduler
+    from oracle.unet_oracle import OracleUNet2DModel
+    from tests.common import TRAJECTORIES, rel_l2, synth_weights, trajectory_golden, trajectory_x_T
+    gold = trajectory_golden()
+    for key, (cfg, kind, steps, stride, every, _) in TRAJECTORIES.items():
+        fin, u8, cps = gold[key + "/final"], gold[key + "/final_u8"], gold[key + "/checkpoints"]
+        ss = cfg["sample_size"]
+        h, w = (ss, ss) if isinstance(ss, int) else ss
+        assert fin.shape == (1, cfg["in_channels"], h // stride, w // stride) and u8.shape == (1, h, w, cfg["out_channels"])
+        assert cps.shape[0] == -(-steps // every) and gold[key + "/final_moments"].shape == (2, cfg["in_channels"])
+        x_T, _ = trajectory_x_T(key)
+        assert np.array_equal(cps[0], x_T[:, :, ::8, ::8].numpy())
+        img = np.clip(fin / 2 + 0.5, 0, 1).transpose(0, 2, 3, 1)
+        assert np.array_equal((img * 255).round().astype("uint8"), u8[:, ::stride, ::stride])
+    key = "cfg2_ddim50"
+    cfg, _, steps, _, every, _ = TRAJECTORIES[key]
+    net = synth_weights(OracleUNet2DModel(**cfg)).eval()
+    sch = OracleDDIMScheduler()
+    sch.set_timesteps(steps)
+    x, _ = trajectory_x_T(key)
+    with torch.no_grad():
+        for tt in sch.timesteps[:every]:
+            x = sch.step(net(x, int(tt)).sample, int(tt), x).prev_sample
+    assert rel_l2(x[:, :, ::8, ::8], torch.from_numpy(gold[key + "/checkpoints"][1])) <= 1e-5
