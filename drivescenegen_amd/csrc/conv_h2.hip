@@ -15,7 +15,8 @@ int conv_h2_launch_f16(const dsg_conv_args* a, int hout, int wout, hipStream_t s
 bool conv_h2_fold(const dsg_conv_args* a) {
   return g_h2.enabled && g_h2.fold && a->weight_h2_fold != nullptr && a->upsample == 1 && a->ksize == 3 && a->stride == 1 &&
          !a->pool2 && !a->gn_scale_shift && !a->weight_h2_cout_stride && (a->c0 + a->c1) % 16 == 0 &&
-         (a->c1 == 0 || a->c0 % 16 == 0) && a->win % H2_TW == 0 && a->hin % 8 == 0 && a->cout % 8 == 0 &&
+         (a->c1 == 0 || a->c0 % 16 == 0) && (a->win % H2_TW == 0 || (g_h2.narrow && (a->win == 16 || a->win == 8))) &&
+         a->hin % 8 == 0 && a->cout % 8 == 0 &&
          (a->c0 + a->c1) <= 1024 && (a->compute_dtype == DSG_F32 || (a->src_layout == 1 && a->dst_layout == 1));
 }
 
@@ -23,7 +24,8 @@ bool conv_h2_fold(const dsg_conv_args* a) {
 bool conv_h2_s2(const dsg_conv_args* a, int hout, int wout) {
   return g_h2.enabled && g_h2.s2 && a->weight_h2_s2 != nullptr && a->stride == 2 && a->ksize == 3 && !a->upsample &&
          !a->pool2 && !a->gn_scale_shift && a->src_layout == 1 && a->dst_layout == 1 && a->c1 == 0 && a->c0 % 8 == 0 &&
-         a->cout % 8 == 0 && a->hin % 2 == 0 && a->win % 2 == 0 && hout % 8 == 0 && wout % H2_TW == 0;
+         a->cout % 8 == 0 && a->hin % 2 == 0 && a->win % 2 == 0 && hout % 8 == 0 &&
+         (wout % H2_TW == 0 || (g_h2.narrow && (wout == 16 || wout == 8)));
 }
 
 bool conv_h2_eligible(const dsg_conv_args* a, int hout, int wout) {
@@ -136,10 +138,13 @@ int conv_h2_splitk_slices(const dsg_conv_args* a, int hout, int wout, int* stat_
     th = hout * wout / H2_TW;
     tw = H2_TW;
   }
-  if (tw % H2_TW != 0 || th % 8 != 0) return 1;  // (narrow maps keep the one-slice kernels)
+  // maps narrower than a tile (16 x 16, 8 x 8: BASELINE configs[3]'s deepest levels -- 512 channels at 16 x 16 -- are ten
+  // convs of a step on 64 workgroups at batch 8) split like the others: the slabs and the reduce pass are layout-only
+  const bool narrow_ok = g_h2.narrow && a->ksize == 3 && (tw == 16 || tw == 8);
+  if ((tw % H2_TW != 0 && !narrow_ok) || th % 8 != 0) return 1;
   const int cout_pad = (a->cout + 63) / 64 * 64;
-  int grid = (tw / H2_TW) * (th / 8) * a->n * (cout_pad / H2_BM);
-  if (a->ksize == 3 && !s2 && g_h2.bm32_small && grid <= H2_CUS / 2) grid *= 2;  // (the launcher's 32-cout workgroups)
+  int grid = ((tw + H2_TW - 1) / H2_TW) * (th / 8) * a->n * (cout_pad / H2_BM);
+  if (a->ksize == 3 && !s2 && g_h2.bm32_small && grid <= H2_CUS / 2 && tw % H2_TW == 0) grid *= 2;  // (the launcher's 32-cout workgroups)
   const int nq = (s2 ? 4 * a->c0 : a->c0 + a->c1) / H2_KC;
   if (grid > H2_CUS / 2 || nq < 8) return 1;
   int slices = std::min(4, std::min(H2_CUS / grid, nq / 4));
@@ -270,6 +275,9 @@ int conv_h2_stats_tiles(const dsg_conv_args* a, int hout, int wout) {
     if (conv_h2_splitk_slices(a, hout, wout, &sp) > 1) return sp;
   }
   if (a->ksize == 1) return hout * wout / (8 * H2_TW);  // (pointwise: the map is re-tiled as rows of 32 pixels)
+  // the folded up-sampler tiles the LOW-resolution grid, four phases per tile (the same count as below while win % 32 == 0;
+  // a 16- or 8-column source still has one -- partly masked -- tile per 8 rows and phase)
+  if (conv_h2_fold(a)) return 4 * (a->hin / 8) * ((a->win + H2_TW - 1) / H2_TW);
   return (hout / 8) * ((wout + H2_TW - 1) / H2_TW);  // 8-row x 32-column statistics tiles for either block height
 }
 
@@ -293,6 +301,7 @@ void conv_h2_set_splitk(int v) { g_h2.splitk = v; ++g_h2.epoch; }
 void conv_h2_set_ws2(int v) { g_h2.ws2 = v; ++g_h2.epoch; }
 void conv_h2_set_fuse_sc(int v) { g_h2.fuse_sc = v; ++g_h2.epoch; }
 void conv_h2_set_pre(int v) { g_h2.pre = v; ++g_h2.epoch; }
+void conv_h2_set_narrow(int v) { g_h2.narrow = v; ++g_h2.epoch; }
 void conv_h2_set_pre_min_ct(int v) { g_h2.pre_min_ct = v > 0 ? v : 1; ++g_h2.epoch; }
 int conv_h2_get_fuse_sc() { return g_h2.fuse_sc; }
 int conv_in_tuning_epoch();  // conv_in.hip: its on/off switch moves the plan's statistics buffers too

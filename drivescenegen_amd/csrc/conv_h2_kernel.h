@@ -1066,10 +1066,10 @@ __global__ __launch_bounds__(64 * NW, OCC * NW / 4) void conv_h2_kernel(ConvH2P 
     if constexpr (DB) {  // [C/8][H][W][8]: pixel * 32 bytes + this half-wave's four channels
       const int oy = GM == 2 ? 2 * (oy0 + wave * NT + nt) + (phase >> 1) : oy0 + wave * NT + nt;
       const int ox = GM == 2 ? 2 * (ox0 + l31) + (phase & 1) : ox0 + l31;
-      voff[nt] = (GM == 2 || ox0 + l31 < p.wout) ? ((oy * (p.wout * oscale) + ox) * 8 + 4 * half) * ESD : 0x7FFFFFF0;
+      voff[nt] = (ox0 + l31 < p.wout) ? ((oy * (p.wout * oscale) + ox) * 8 + 4 * half) * ESD : 0x7FFFFFF0;
     } else {
-      voff[nt] = GM == 2 ? (4 * half * oplane + (2 * (oy0 + wave * NT + nt) + (phase >> 1)) * (2 * p.wout) +
-                            2 * (ox0 + l31) + (phase & 1)) * 4
+      voff[nt] = GM == 2 ? (ox0 + l31 < p.wout ? (4 * half * oplane + (2 * (oy0 + wave * NT + nt) + (phase >> 1)) * (2 * p.wout) +
+                                                   2 * (ox0 + l31) + (phase & 1)) * 4 : 0x7FFFFFF0)
                          : (ox0 + l31 < p.wout ? (4 * half * oplane + (oy0 + wave * NT + nt) * p.wout + ox0 + l31) * 4
                                                : 0x7FFFFFF0);  // (narrow maps: past the last column -> out of range)
     }

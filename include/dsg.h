@@ -591,6 +591,9 @@ int dsg_prof_dump(const char* csv_path);
  *  23  resnet shortcuts fused into conv2's K loop (dsg_conv_args.sc_*): [1] | 0 (0: dsg_conv2d_fuses_shortcut answers no)
  *  30  16-bit pointwise weight gradients on a kernel of their own (tiles up to 128 ci x 128 co): [1] | 0 = the 3x3 kernel's
  *      one-tap instantiation (64 x 64 workgroups)
+ *  32  maps narrower than a 32-column tile (16 x 16, 8 x 8: the deepest levels of BASELINE configs[3]'s 512 x 512 network) also
+ *      take split-K, the folded up-sampler kernel and the stride-2 space-to-depth kernel: [1] | 0 = one-slice plain kernel and
+ *      the exact f32-MFMA kernels for them
  *  31  fp32-equivalent 3x3 weight gradients with cout % 128 == 0 as 32 ci x 128 co workgroups (a wave keeps two co tiles, nine
  *      (tap, co tile) units on every wave; conv_wgrad_h2w_kernel): [1] | 0 = the 32 ci x 64 co workgroup everywhere
  *  29  16-bit 3x3 weight gradients with cout % 128 == 0 as 64 ci x 128 co workgroups (a wave keeps two co tiles, one

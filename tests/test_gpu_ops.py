@@ -403,6 +403,59 @@ def test_conv_h2_stride2_space_to_depth(c, cout, h, w):
     assert torch.allclose(stats.sum(2).cpu(), want_st, rtol=1e-5, atol=1e-5)
 
 
+@pytest.mark.parametrize("mode,c,cout,h,w,batch", [("splitk", 512, 512, 16, 16, 8), ("splitk", 256, 128, 8, 8, 3), ("fold", 512, 512, 16, 16, 2),
+                                                   ("fold", 64, 72, 8, 8, 1), ("s2", 256, 256, 32, 32, 2), ("s2", 64, 128, 16, 16, 3)])
+def test_narrow_maps_take_splitk_fold_and_stride2_kernels(mode, c, cout, h, w, batch):
+    """Maps narrower than the 32-column tile (BASELINE configs[3]: 512 channels at 16 x 16, the up-sampler out of it and the
+    down-sampler into it) on the kernels the wide maps use -- split-K slices + reduce pass, the folded up-sampler, the stride-2
+    space-to-depth kernel (dsg_set_tuning key 32; before round 4: one-slice / exact f32-MFMA kernels).  Against fp64 in the
+    split convs' round-off class, against the key-32-off call of the same arguments (fp32 round-off: another summation order),
+    and the epilogue statistics of what was written."""
+    from drivescenegen_amd import _lib
+    d = lambda t: None if t is None else t.to(DEV)
+    x = _t(61, (batch, c, h, w), 1.2)
+    wt = _t(62, (cout, c, 3, 3), 1.0 / np.sqrt(9 * c))
+    bias = _t(63, (cout,), 0.1)
+    gamma, beta = 1 + _t(64, (c,), 0.1), _t(65, (c,), 0.1)
+    kw = dict(ksize=3, cout=cout, src_blocked=True, dst_blocked=True, want_stats=True)
+    xb = ops.to_blocked(d(x))
+    wr = ops.relayout_conv_weight(d(wt))
+    if mode == "splitk":    # a resnet conv: GroupNorm + SiLU in front, bias + residual behind
+        r = _t(66, (batch, cout, h, w))
+        a = F.silu(F.group_norm(x.double(), 32, gamma.double(), beta.double(), 1e-5))
+        want = F.conv2d(a, wt.double(), bias.double(), padding=1) + r.double()
+        mag = F.conv2d(a.abs(), wt.double().abs(), None, padding=1) + 1e-30
+        ss = ops.gn_scale_shift(d(x), d(gamma), d(beta), 32, 1e-5)
+        kw.update(gn_scale_shift=ss, silu=True, residual=ops.to_blocked(d(r)), weight_h2=ops.relayout_conv_weight_h2(d(wt)), splitk=True)
+    elif mode == "fold":
+        a = F.interpolate(x.double(), scale_factor=2.0, mode="nearest")
+        want = F.conv2d(a, wt.double(), bias.double(), padding=1)
+        mag = F.conv2d(a.abs(), wt.double().abs(), None, padding=1) + 1e-30
+        kw.update(upsample=True, weight_h2_fold=ops.relayout_conv_weight_h2_fold(d(wt)))
+    else:
+        want = F.conv2d(x.double(), wt.double(), bias.double(), stride=2, padding=1)
+        mag = F.conv2d(x.double().abs(), wt.double().abs(), None, stride=2, padding=1) + 1e-30
+        kw.update(stride=2, weight_h2_s2=ops.relayout_conv_weight_h2_s2(d(wt)))
+    lib = _lib.load()
+    got = {}
+    try:
+        for on in (0, 1):
+            _lib.check(lib.dsg_set_tuning(32, on))
+            y, st = ops.conv2d_fused(xb, wr, d(bias), **kw)
+            got[on] = (ops.from_blocked(y).cpu(), st)
+    finally:
+        lib.dsg_set_tuning(32, 1)
+    assert not torch.equal(got[0][0], got[1][0])   # (another kernel really ran)
+    for on in (0, 1):
+        err = float(((got[on][0].double() - want).abs() / mag).max())
+        assert err <= 6e-7, (on, err)
+    assert float((got[0][0].double() - got[1][0].double()).abs().max()) <= 4e-6 * float(want.abs().max())
+    y, st = got[1]
+    assert st is not None
+    ref = torch.stack([y.double().sum((2, 3)), (y.double() ** 2).sum((2, 3))], -1)
+    assert torch.allclose(st.sum(2).cpu(), ref, rtol=3e-6, atol=1e-4)
+
+
 @pytest.mark.parametrize("case", H2_CASES, ids=[c[0] for c in H2_CASES])
 def test_conv_h2_blocked_layout_is_bit_identical(case):
     """Channel-blocked activations (dsg_conv_args.src_layout / dst_layout = 1): the same arithmetic in the same
