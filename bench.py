@@ -418,8 +418,9 @@ def train_leg(args, dtype="fp32", batch=64, steps=4):
                     **pmc_class_traffic(pmc_pat, "_train_" + dtype))
     wg, fw = rows.get("conv3x3_wgrad"), rows.get("conv3x3_fwd_and_dgrad")
     if wg:
-        rec["roofline"] = roof(wg, "dsg::conv_wgrad_h2_kernel" if dtype == "fp32" else "dsg::conv_wgrad16_kernel<*, 3, *>",
-                               r"conv_wgrad_h2_kernel" if dtype == "fp32" else r"conv_wgrad16_kernel<\d, 3")
+        rec["roofline"] = roof(wg, "dsg::conv_wgrad_h2w_kernel (cout % 128 == 0) + dsg::conv_wgrad_h2_kernel (64-cout layers)"
+                               if dtype == "fp32" else "dsg::conv_wgrad16_kernel<*, 3, *>",
+                               r"conv_wgrad_h2w?_kernel" if dtype == "fp32" else r"conv_wgrad16_kernel<\d, 3")
         if fw:
             rec["roofline"]["second_kernel"] = roof(fw, "dsg::conv_h2_kernel<0, *, 3, *> (forward and data-gradient 3x3 convs)",
                                                     r"conv_h2_kernel<0, [24], 3, [02], 4, [12], [03], (64|128), " +
