@@ -20,6 +20,17 @@ int fail(int code, const char* fmt, ...) {
   return code;
 }
 
+__global__ void zero_words_kernel(unsigned* __restrict__ p, size_t n) {
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) p[i] = 0u;
+}
+
+hipError_t zero_words(void* p, size_t words, hipStream_t st) {
+  if (words == 0) return hipSuccess;
+  const unsigned blocks = (unsigned)((words + 255) / 256 < 2048 ? (words + 255) / 256 : 2048);
+  hipLaunchKernelGGL(zero_words_kernel, dim3(blocks), dim3(256), 0, st, static_cast<unsigned*>(p), words);
+  return hipGetLastError();
+}
+
 }  // namespace dsg
 
 DSG_API int dsg_version(void) { return 100; }  // 0.1.0

@@ -41,6 +41,12 @@ int fail(int code, const char* fmt, ...);
                          __FILE__, __LINE__);                                                \
   } while (0)
 
+// Zero-fill of `words` 32-bit words as a KERNEL launch.  Not hipMemsetAsync: captured into a hipGraph a memset becomes a memset
+// node, and on this stack (ROCm 7.2, gfx950) replays 2.. of a captured dsg_unet_forward did not order that node against the
+// kernel nodes behind it -- the range-guard slots were zeroed while their consumers ran (found by
+// tests/test_gpu_unet.py::test_forward_and_scheduler_step_are_legal_under_stream_capture; a kernel node is ordered).
+hipError_t zero_words(void* p, size_t words, hipStream_t st);
+
 static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 static inline int64_t cdiv64(int64_t a, int64_t b) { return (a + b - 1) / b; }
 

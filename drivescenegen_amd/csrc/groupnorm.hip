@@ -281,7 +281,7 @@ DSG_API int dsg_range_bound_from_stats(const double* stats, int32_t n, int32_t c
 
 DSG_API int dsg_abs_max(const float* x, int64_t numel, float* out, void* stream) {
   DSG_CHECK_ARG(x && out && numel > 0, "dsg_abs_max: bad argument");
-  DSG_HIP(hipMemsetAsync(out, 0, sizeof(float), static_cast<hipStream_t>(stream)));
+  DSG_HIP(dsg::zero_words(out, 1, static_cast<hipStream_t>(stream)));
   const int blocks = (int)std::min<int64_t>(dsg::cdiv64(numel, 256 * 16), 512);
   hipLaunchKernelGGL(dsg::abs_max_kernel, dim3(std::max(blocks, 1)), dim3(256), 0, static_cast<hipStream_t>(stream), x, numel, out);
   DSG_LAUNCH_CHECK();

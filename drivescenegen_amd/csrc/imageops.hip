@@ -139,7 +139,7 @@ DSG_API int dsg_hist_u8(const uint8_t* img, int32_t n, int32_t hw, int32_t c, ui
   DSG_CHECK_ARG(img && hist, "dsg_hist_u8: NULL pointer");
   DSG_CHECK_ARG(n > 0 && hw > 0 && c > 0 && n <= 65535 && c <= 65535, "dsg_hist_u8: bad dims");
   hipStream_t st = static_cast<hipStream_t>(stream);
-  DSG_HIP(hipMemsetAsync(hist, 0, (size_t)n * c * 256 * sizeof(uint32_t), st));
+  DSG_HIP(dsg::zero_words(hist, (size_t)n * c * 256, st));
   const int blocks = std::max(1, std::min(64, dsg::cdiv(hw, 4096)));
   hipLaunchKernelGGL(dsg::hist_u8_kernel, dim3(blocks, c, n), dim3(256), 0, st, img, hw, c, hist);
   DSG_LAUNCH_CHECK();

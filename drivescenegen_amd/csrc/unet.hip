@@ -504,8 +504,9 @@ struct Runner {
       const size_t off = arena.alloc(bytes);
       bound_base = reinterpret_cast<unsigned*>(ws + off);
       bound_used = 0;
-      if (!dry && dt() == DSG_F32 && hipMemsetAsync(bound_base, 0, bytes, st) != hipSuccess)
-        return rc = dsg::fail(DSG_ERR_HIP, "dsg_unet_forward: hipMemsetAsync failed");
+      // (a kernel, not hipMemsetAsync: see dsg::zero_words)
+      if (!dry && dt() == DSG_F32 && dsg::zero_words(bound_base, (size_t)kBoundSlots * B, st) != hipSuccess)
+        return rc = dsg::fail(DSG_ERR_HIP, "dsg_unet_forward: zero-fill launch failed");
     }
     blocked = dsg::unet_blocked() != 0 || dt() != DSG_F32;  // (the 16-bit modes exist for channel-blocked tensors only)
     for (int i = 0; i < cfg.num_blocks; ++i) blocked = blocked && cfg.block_out_channels[i] % 8 == 0;

@@ -387,7 +387,11 @@ int dsg_unet_num_params(const dsg_unet_t* h, int64_t* expected_tensors, int64_t*
                         int64_t* total_elements);
 int dsg_unet_param_name(const dsg_unet_t* h, int64_t index, const char** name, int64_t* numel);
 int dsg_unet_workspace_bytes(dsg_unet_t* h, int32_t batch, size_t* bytes);
-/* eps = UNet(x, t).  timesteps: device int64 [batch]. */
+/* eps = UNet(x, t).  timesteps: device int64 [batch].  Stream-asynchronous and legal under stream capture once the plan's
+ * parameters are settled (dsg_unet_commit_params; the first call of a shape also sizes the workspace on the host): a captured
+ * denoising step -- this call + dsg_ddim_step -- replays bit-identically to the eager calls (tests/test_gpu_unet.py).  Nothing
+ * in the library issues hipMemsetAsync on a caller's stream (a memset NODE was found un-ordered against the kernel nodes behind
+ * it under hipGraph replay on ROCm 7.2: zero-fills are kernels). */
 int dsg_unet_forward(dsg_unet_t* h, const float* x, const int64_t* timesteps, float* out, int32_t batch,
                      void* workspace, size_t workspace_bytes, void* stream);
 

@@ -233,3 +233,40 @@ def test_batch_invariant_flag_and_tuning_gate():
                          cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     assert out.returncode == 0, out.stderr[-2000:]
     assert "rc -1" in out.stdout and "test hook" in out.stdout, out.stdout
+
+
+def test_forward_and_scheduler_step_are_legal_under_stream_capture():
+    """include/dsg.h's contract: every entry point is stream-asynchronous.  Until round 4 `dsg_unet_set_param` synchronised the
+    stream per conv weight (illegal inside a capture); now a parameter refresh is asynchronous + ONE `dsg_unet_commit_params`.
+    Here a denoising step -- dsg_unet_forward + dsg_ddim_step -- is captured into a HIP graph after one eager warm-up (which
+    also settles the plan's parameters), replayed on fresh inputs, and must reproduce the eager results bit for bit."""
+    net = synth_weights(d.UNet2DModel(**CFG1)).to(DEV).eval().requires_grad_(False)
+    sch = d.DDIMScheduler()
+    sch.set_timesteps(50)
+    t = int(sch.timesteps[3])
+    x_static = noisy_inputs(CFG1, 2).to(DEV)
+    t_dev = torch.full((2,), t, dtype=torch.long, device=DEV)   # (a host scalar would be an H2D copy inside the capture)
+    eager_eps = net(x_static, t_dev).sample
+    eager_prev = sch.step(eager_eps, t, x_static).prev_sample
+    torch.cuda.synchronize()
+    s = torch.cuda.Stream()
+    s.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(s):      # (torch's capture recipe: warm up on the side stream first)
+        net(x_static, t_dev)
+    torch.cuda.current_stream().wait_stream(s)
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        eps = net(x_static, t_dev).sample
+        prev = sch.step(eps, t, x_static).prev_sample
+    for _ in range(3):   # (replays 2.. are the ones that found the un-ordered memset node: dsg::zero_words)
+        g.replay()
+        torch.cuda.synchronize()
+        assert torch.equal(eps, eager_eps) and torch.equal(prev, eager_prev)
+    for seed in (77, 78, 79):
+        x2 = noisy_inputs(CFG1, 2, seed=seed).to(DEV)
+        want_eps = net(x2, t_dev).sample
+        want_prev = sch.step(want_eps, t, x2).prev_sample
+        x_static.copy_(x2)
+        g.replay()
+        torch.cuda.synchronize()
+        assert torch.equal(eps, want_eps) and torch.equal(prev, want_prev), seed
