@@ -479,6 +479,7 @@ void conv_h2_set_fuse_sc(int v);
 int conv_h2_get_fuse_sc();
 void conv_h2_set_pre(int v);
 void conv_h2_set_narrow(int v);
+void conv_h2_set_splitk_mid(int v);
 void conv_h2_set_pre_min_ct(int v);
 bool conv_h2_takes_operand(const dsg_conv_args* a, int hout, int wout, bool wanted);
 void attention_set_blocked(int v);
@@ -903,6 +904,10 @@ DSG_API int dsg_set_tuning(int32_t key, int32_t value) {
   }
   if (key == 26 && (value == 0 || value == 1)) {
     dsg::conv_h2_set_pre(value);
+    return DSG_OK;
+  }
+  if (key == 34 && (value == 0 || value == 1)) {
+    dsg::conv_h2_set_splitk_mid(value);
     return DSG_OK;
   }
   if (key == 32 && (value == 0 || value == 1)) {

@@ -146,8 +146,19 @@ int conv_h2_splitk_slices(const dsg_conv_args* a, int hout, int wout, int* stat_
   int grid = ((tw + H2_TW - 1) / H2_TW) * (th / 8) * a->n * (cout_pad / H2_BM);
   if (a->ksize == 3 && !s2 && g_h2.bm32_small && grid <= H2_CUS / 2 && tw % H2_TW == 0) grid *= 2;  // (the launcher's 32-cout workgroups)
   const int nq = (s2 ? 4 * a->c0 : a->c0 + a->c1) / H2_KC;
-  if (grid > H2_CUS / 2 || nq < 8) return 1;
-  int slices = std::min(4, std::min(H2_CUS / grid, nq / 4));
+  if (nq < 8) return 1;
+  int slices;
+  if (grid > H2_CUS / 2) {
+    // Grids of 129 .. 170 workgroups (batch-5 sampling -- generation.py:14-20 -- at the 32 x 32 level: 160) leave a third of the
+    // chip idle for one long round (512 -> 512: 288 K-chunks per workgroup, 130 us at 0.22 of the roof).  Three slices make it two
+    // rounds of a third of the work: 0.67 of the time by the rounds model, measured -2.2 % on the batch-5 step (6.25 -> 6.11 ms,
+    // interleaved same-box passes).  Four slices for 171 .. 192 workgroups (three rounds of a quarter, 0.75 by the model) measured
+    // +1.4 % at batch 3 and +2.7 % at batch 6: not taken.  Long K only (24 chunks); key 34.
+    if (!g_h2.splitk_mid || nq < 24 || 3 * grid > 2 * H2_CUS) return 1;
+    slices = 3;
+  } else {
+    slices = std::min(4, std::min(H2_CUS / grid, nq / 4));
+  }
   while (slices > 1 && ((nq + slices - 1) / slices) * (slices - 1) >= nq) --slices;  // (no empty slice)
   if (slices < 2) return 1;
   if (stat_splits) {
@@ -302,6 +313,7 @@ void conv_h2_set_ws2(int v) { g_h2.ws2 = v; ++g_h2.epoch; }
 void conv_h2_set_fuse_sc(int v) { g_h2.fuse_sc = v; ++g_h2.epoch; }
 void conv_h2_set_pre(int v) { g_h2.pre = v; ++g_h2.epoch; }
 void conv_h2_set_narrow(int v) { g_h2.narrow = v; ++g_h2.epoch; }
+void conv_h2_set_splitk_mid(int v) { g_h2.splitk_mid = v; ++g_h2.epoch; }
 void conv_h2_set_pre_min_ct(int v) { g_h2.pre_min_ct = v > 0 ? v : 1; ++g_h2.epoch; }
 int conv_h2_get_fuse_sc() { return g_h2.fuse_sc; }
 int conv_in_tuning_epoch();  // conv_in.hip: its on/off switch moves the plan's statistics buffers too

@@ -28,6 +28,7 @@ struct H2Tuning {
   int splitk = 1;       // split-K for grids of at most half the CUs, when the caller gives scratch (key 19)
   int ws2 = 1;          // fp32-equivalent 3x3 convs with cin <= 128: 8-row tiles, one weight slab, two workgroups per CU (key 20)
   int fuse_sc = 1;      // resnet shortcuts fused into conv2's K loop (key 23: A/B against the separate 1x1 kernel)
+  int splitk_mid = 1;   // split-K also for grids of 129 .. 170 workgroups with K >= 24 chunks: 3 slices (key 34)
   int narrow = 1;       // maps narrower than a tile (16 x 16, 8 x 8) also take split-K, the folded up-sampler and the stride-2 kernel
                         // (key 32: 0 = one-slice plain kernel / exact f32 MFMA kernels for them, the rule before round 4)
   int pre = 1;          // pre-staged operand images for the layers with >= pre_min_ct cout tiles per patch (key 26)

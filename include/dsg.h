@@ -595,6 +595,8 @@ int dsg_prof_dump(const char* csv_path);
  *  23  resnet shortcuts fused into conv2's K loop (dsg_conv_args.sc_*): [1] | 0 (0: dsg_conv2d_fuses_shortcut answers no)
  *  30  16-bit pointwise weight gradients on a kernel of their own (tiles up to 128 ci x 128 co): [1] | 0 = the 3x3 kernel's
  *      one-tap instantiation (64 x 64 workgroups)
+ *  34  split-K also for grids of 129 .. 170 workgroups with at least 24 K-chunks (batch-5 sampling at the 32 x 32 level): three
+ *      slices = two rounds of a third of the work: [1] | 0 = only grids of at most half the CUs split
  *  32  maps narrower than a 32-column tile (16 x 16, 8 x 8: the deepest levels of BASELINE configs[3]'s 512 x 512 network) also
  *      take split-K, the folded up-sampler kernel and the stride-2 space-to-depth kernel: [1] | 0 = one-slice plain kernel and
  *      the exact f32-MFMA kernels for them
