@@ -74,7 +74,10 @@ class NoiseAhead:
         self._shape = tuple(shape)
 
         def draw():
-            self._out = torch.randn(self._shape, pin_memory=torch.cuda.is_available())
+            try:
+                self._out = torch.randn(self._shape, pin_memory=torch.cuda.is_available())
+            except BaseException as e:  # surfaced by take() on the training thread
+                self._out = e
         self._thread = threading.Thread(target=draw, daemon=True)
         self._thread.start()
 
@@ -84,6 +87,8 @@ class NoiseAhead:
         if self._thread is not None:
             self._thread.join()
             out, self._thread, self._out = self._out, None, None
+            if isinstance(out, BaseException):
+                raise out
             if self._shape == shape:
                 return out.to(device, non_blocking=True)
             # (cannot happen in `fit`: it schedules the very batch it takes next; keep the generator's order anyway)
