@@ -457,13 +457,32 @@ constexpr int WH_LDS_BYTES = (WH_A_HALFS + 2 * WH_D_HALFS) * 2;
 // run through HBM for itself (measured: 779 MB fetched per launch for 134 MB of tensors, profiles/r03_pmc_traffic_train_bf16).
 // Here XCD k takes the runs k, k + 8, ... and walks all pairs of a run on consecutive ids of its own: they run at the same
 // time behind one L2 and the run's rows come from HBM once.  (A bijection of the grid whenever slabs % 8 == 0.)
-__device__ __forceinline__ void wgrad_xcd_ids(int& pair, int& slab) {
+// Round 4: the runs that share INPUT ROWS -- the tiles_x column strips of one (image, row split) -- go to one XCD as well, next to
+// each other in time.  A strip's row is exactly one 128-byte line of an fp32 [N,C,H,W] plane, and its two halo columns live in the
+// NEIGHBOURING strips' lines: with neighbouring strips on different XCDs every L2 fetched three lines per row where one is the
+// strip's own (5.8 GB read for 2.6 GB of tensors on the 64-cout layers of the 256 x 256 level, which run at the memory system's
+// rate: profiles/r04_pmc_traffic_train_fp32.json).  slab = (n * tiles_x + tx) * nrs + rs; group = (n, rs); XCD k takes the groups
+// k, k + 8, ... and walks (group, tx, pair) with the pair fastest.  (A bijection when the number of groups is a multiple of 8;
+// nrs = 0: the caller's slabs are not strips -- several strips per workgroup -- and keep the plain run mapping.)
+__device__ __forceinline__ void wgrad_xcd_ids(int& pair, int& slab, int nrs = 0, int tiles_x = 0) {
   pair = blockIdx.x;
   slab = blockIdx.y;
 #ifndef DSG_WGRAD_NO_XCD
+  const unsigned lin = blockIdx.y * gridDim.x + blockIdx.x;
+  const unsigned xcd = lin & 7, j = lin >> 3;
+#ifndef DSG_WGRAD_NO_STRIP_GROUPS
+  if (nrs > 0 && tiles_x > 1) {
+    const unsigned groups = gridDim.y / tiles_x;  // images x row splits
+    if ((groups & 7) == 0 && groups * tiles_x == gridDim.y) {
+      pair = (int)(j % gridDim.x);
+      const unsigned tx = (j / gridDim.x) % tiles_x, gid = xcd + 8 * (j / (gridDim.x * tiles_x));
+      const unsigned n = gid / nrs, rs = gid - n * nrs;
+      slab = (int)((n * tiles_x + tx) * nrs + rs);
+      return;
+    }
+  }
+#endif
   if ((gridDim.y & 7) == 0) {
-    const unsigned lin = blockIdx.y * gridDim.x + blockIdx.x;
-    const unsigned xcd = lin & 7, j = lin >> 3;
     slab = (int)(xcd + 8 * (j / gridDim.x));
     pair = (int)(j % gridDim.x);
   }
@@ -485,7 +504,7 @@ __global__ __launch_bounds__(256, 1) void conv_wgrad_h2_kernel(WgradP p) {
   const bool first = wave < 2;  // taps 0..4; the other pair 5..8
 
   int pair_id, slab_id;
-  wgrad_xcd_ids(pair_id, slab_id);
+  wgrad_xcd_ids(pair_id, slab_id, p.ntiles, p.tiles_x);
   const int cib = pair_id % p.ci_blocks;
   const int cob = pair_id / p.ci_blocks;
   const int ci0 = cib * 32, co0 = cob * WG_CO;
@@ -770,7 +789,7 @@ __global__ __launch_bounds__(256, 1) void conv_wgrad_h2w_kernel(WgradP p) {
   const bool first = wave < 2;  // tap group 0: taps 0..3 and the centre tap for co tile 2cp; group 1: 5..8, centre for 2cp + 1
 
   int pair_id, slab_id;
-  wgrad_xcd_ids(pair_id, slab_id);
+  wgrad_xcd_ids(pair_id, slab_id, p.ntiles, p.tiles_x);
   const int cib = pair_id % p.ci_blocks;
   const int cob = pair_id / p.ci_blocks;
   const int ci0 = cib * 32, co0 = cob * WW_CO;
@@ -1495,7 +1514,7 @@ __global__ __launch_bounds__(256, COT == 2 ? 1 : 2) void conv_wgrad16_kernel(Wgr
   const int cit = wave >> 1, cot = (wave & 1) * COT;  // (the wave's first co tile)
 
   int pair_id, slab_id;
-  wgrad_xcd_ids(pair_id, slab_id);
+  wgrad_xcd_ids(pair_id, slab_id, p.spw == 1 ? p.nrs : 0, p.tiles_x);
   const int cib = pair_id % p.ci_blocks, cob = pair_id / p.ci_blocks;
   const int ci0 = cib * 64, co0 = cob * COW;
   const int plane = p.h * p.w;
