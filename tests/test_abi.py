@@ -69,3 +69,34 @@ def test_product_never_touches_the_oracle():
     leg = bench.index("def cpu_leg(")
     end = bench.index("\ndef ", leg + 1)
     assert hits and all(leg < h < end for h in hits)
+
+
+def test_bench_line_helpers_quote_stamped_counter_files_and_digest_every_record():
+    """bench.py's host-side pieces that need no GPU: the committed PMC files carry the git head and the command they were
+    collected with and every kernel the roofline objects name is found in them (a renamed instantiation would read None);
+    `summary_of` -- the line's last key -- keeps value / ms_per_step / roofline.frac of every record, failed ones included."""
+    import importlib.util
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("dsg_bench", os.path.join(root, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    for kern in ("dsg::conv_h2_kernel<0, 4, 3, 2, 4, 1, 3, 64, 0, 0, 0, 0>", "dsg::conv_h2_kernel<0, 2, 3, 2, 4, 2, 3, 64, 0, 1, 0, 0>",
+                 "dsg::conv_h2_kernel<0, 4, 3, 2, 4, 1, 3, 64, 0, 0, 1, 0>", "dsg::conv_h2_kernel<0, 2, 3, 2, 4, 2, 3, 64, 0, 1, 1, 0>"):
+        t = bench.pmc_traffic(kern)
+        assert t["traffic"] and t["traffic_git_head"] not in (None, "unknown") and "bench.py" in t["traffic_cmd"], (kern, t)
+    assert bench.pmc_mfma("dsg::conv_h2_kernel<0, 4, 3, 2, 4, 1, 3, 64, 0, 0, 0, 0>")["mfma_pipe_util"] > 0.3
+    for pat, sfx in ((r"conv_wgrad_h2w?_kernel", "_train_fp32"), (r"conv_wgrad16_kernel<\d, 3", "_train_bf16"),
+                     (r"conv_h2_kernel<0, 2, 3, 2, 4, 2, 3, 64, 0, 1, 0", "_cfg4"), (r"conv_h2_kernel<0, 4, 3, [02], 4, 1, 3, (64|128), 1, 0, 0", "_bf16")):
+        t = bench.pmc_class_traffic(pat, sfx)
+        assert t["traffic"] and t["traffic_git_head"] not in (None, "unknown"), (pat, t)
+    out = {"value": 1000.0, "unit": "image-steps/s", "ms_per_step": 16.0, "roofline": {"bound": "mfma", "frac": 0.5, "second_kernel": {"frac": 0.4}},
+           "step_ms_spread": {"min": 15.9, "median": 16.0, "max": 16.2, "n": 20},
+           "extra_records": {"train_fp32": {"value": 250.0, "ms_per_step": 256.0, "config": {"batch": 64}, "roofline": {"frac": 0.38}},
+                             "broken": {"error": "RuntimeError: " + "x" * 500}},
+           "cpu_baseline": {"value": 2.0, "unit": "image-steps/s", "cores": 16, "kind": "port", "sample": "..."}}
+    s = bench.summary_of(out)
+    assert s["headline"]["value"] == 1000.0 and s["headline"]["roofline"]["second_kernel_frac"] == 0.4
+    assert s["headline"]["step_ms_min_med_max"] == [15.9, 16.0, 16.2]
+    assert s["train_fp32"]["batch"] == 64 and s["train_fp32"]["roofline"]["frac"] == 0.38
+    assert len(s["broken"]["error"]) <= 200 and s["cpu_baseline"]["kind"] == "port"
