@@ -639,7 +639,15 @@ __global__ __launch_bounds__(256, 2) void conv_fewout_kernel(ConvP p) {
         typedef float f2 __attribute__((ext_vector_type(2)));
         const float4 wq = *reinterpret_cast<const float4*>(wsm + (c * 9 + t) * 4);
         const f2 w01 = {wq.x, wq.y}, w23 = {wq.z, wq.w};
-        const float a0 = xp[(t / 3) * FO_PW + (t % 3)], a1 = xp[(t / 3 + 8) * FO_PW + (t % 3)];
+        // VOLATILE, LDS address space, on purpose (round 4).  Left to itself hipcc 7.2 pairs these reads into ds_read2_b32 and keeps
+        // them in flight together with the broadcast ds_read_b128 of the weight quads behind counted waits (lgkmcnt(1), (2)).
+        // Alone on the GPU that is bit-stable; with OTHER PROCESSES' workgroups sharing the CU it is not: lanes 48-63 of every
+        // wave -- the quarter whose data an LDS return delivers last -- consumed stale registers in ~90 % of the launches (errors of
+        // 1e-3 .. 1e-1 on O(1) outputs: tools/race_ops.sh, profiles/r04_race_under_load.txt).  Single ds_read_b32 with the same
+        // counted waits (this form), or the weights through the scalar cache instead of LDS, are stable: 0 wrong of 600 launches
+        // under the same load, +5 % on the kernel's time.
+        const volatile __attribute__((address_space(3))) float* xv = (const volatile __attribute__((address_space(3))) float*)xp;
+        const float a0 = xv[(t / 3) * FO_PW + (t % 3)], a1 = xv[(t / 3 + 8) * FO_PW + (t % 3)];
         const f2 b0 = {a0, a0}, b1 = {a1, a1};
         f2& c00 = *reinterpret_cast<f2*>(&acc[0][0]);
         f2& c02 = *reinterpret_cast<f2*>(&acc[0][2]);

@@ -486,15 +486,23 @@ class Accelerator:
         if self.collectives and not dist.is_initialized():
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
             os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-            torch.cuda.set_device(self.local_rank)
-            dist.init_process_group("nccl")
-        self.device = torch.device(device) if device else torch.device("cuda", self.local_rank)
+            torch.cuda.set_device(self._device_index())
+            # RCCL ("nccl" on ROCm) is the data path.  DSG_DIST_BACKEND=gloo is a test hook: gloo carries CUDA tensors through
+            # the host, which lets TWO ranks share ONE GPU (RCCL refuses that) -- the only way to run the world-2 step on a
+            # one-GPU box (tests/test_gpu_rccl_one_rank.py)
+            dist.init_process_group(os.environ.get("DSG_DIST_BACKEND", "nccl"))
+        self.device = torch.device(device) if device else torch.device("cuda", self._device_index())
         self.sync_gradients = True
         self._accum = 0
         self._buckets = None
         self._model = None
         self._log_file = None
         self.trackers = []
+
+    def _device_index(self):
+        # one rank per GPU; more local ranks than GPUs (the gloo test hook above) wrap around
+        n = torch.cuda.device_count() if torch.cuda.is_available() else 0
+        return self.local_rank % n if n else self.local_rank
 
     @property
     def is_main_process(self):

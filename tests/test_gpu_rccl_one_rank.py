@@ -3,7 +3,9 @@ DSG_FORCE_COLLECTIVES=1 makes `Accelerator` / `GradBuckets` / bench.py create th
 the launcher and run the rank-0 broadcast, the bucketed asynchronous all-reduce(AVG) of the gradient slab, the barrier
 and the max-over-ranks at WORLD_SIZE 1.  An average over one rank is the identity, so three training steps must
 reproduce the plain single-process run BIT FOR BIT (reference: train.py:121-122 / training_pipeline.py:59-61,86 run the
-same loop under accelerate's DDP).  World 2 is covered on CPU by tests/test_dist_cpu.py (gloo)."""
+same loop under accelerate's DDP).  World 2 runs on the same GPU through gloo (two processes, one device: RCCL refuses that,
+gloo carries the CUDA tensors through the host) -- there the all-reduce changes the gradients, and the host logic of world 2
+is covered on CPU by tests/test_dist_cpu.py."""
 import json
 import os
 import socket
@@ -16,7 +18,7 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _launcher(script_and_args, force, extra_env=None):
+def _launcher(script_and_args, force, extra_env=None, nproc=1):
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
@@ -26,7 +28,7 @@ def _launcher(script_and_args, force, extra_env=None):
     if force:
         env["DSG_FORCE_COLLECTIVES"] = "1"
     env.update(extra_env or {})
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=1", "--master-addr",
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={nproc}", "--master-addr",
            "127.0.0.1", "--master-port", str(port)] + script_and_args
     r = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
@@ -72,6 +74,68 @@ def test_default_net_buckets_launch_back_to_front_inside_the_backward_walk():
     assert tr["in_walk"][0] and tr["ms_before_walk_end"][0] > 1.0, tr   # the first all-reduce has milliseconds of backward to hide under
     assert _lines(forced, "rank") == _lines(plain.stdout, "rank")
     assert _lines(forced, "checksum") == _lines(plain.stdout, "checksum")
+
+
+def _floats(lines, key="loss"):
+    return [float.fromhex(ln.split()[ln.split().index(key) + 1]) for ln in lines]
+
+
+def test_two_ranks_on_the_one_gpu_average_their_gradients():
+    """World size 2 on the hardware the box has: two processes share the GPU, the collectives go through gloo (RCCL refuses two
+    ranks on one device; DSG_DIST_BACKEND is a test hook).  Everything else is the product path: the rank-0 parameter
+    broadcast, the bucketed all-reduce launched asynchronously from inside the backward walk of the HIP tape, SUM + the
+    1 / world scale kernel, clip, AdamW.  Unlike the one-rank run, the all-reduce CHANGES the gradient slab here, so a missing
+    stream dependency between the backward walk, the collective and the optimizer would show as wrong bits.
+      (a) both ranks on the same batch: (g + g) / 2 = g exactly -- losses and final parameters bitwise the one-process run's,
+          on both ranks;
+      (b) the batch split between the ranks (train.py:121-122 under accelerate: each process its own shard): the mean of the
+          two ranks' step-0 losses is the whole-batch loss, the parameters after the update agree between the ranks bit for
+          bit, and the next step's mean loss follows the one-process run (the update differs by the rounding of a sum)."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "DSG_FORCE_COLLECTIVES")}
+    args = [os.path.join("tools", "ddp_smoke.py"), "CFG1", "4", "3"]
+    plain = subprocess.run([sys.executable] + args, env=env, cwd=ROOT, capture_output=True, text=True, timeout=600)
+    assert plain.returncode == 0, plain.stderr[-4000:]
+    p_loss = _floats(_lines(plain.stdout, "rank"))
+    # (a)
+    same = _launcher(args, force=False, extra_env={"DSG_DIST_BACKEND": "gloo"}, nproc=2)
+    f = _lines(same, "collectives")
+    assert len(f) == 2 and all(x.split()[1] == "on" and x.split()[3] == "gloo" and int(x.split()[5]) >= 1 for x in f), f
+    for r in (0, 1):
+        mine = [ln.replace(f"rank {r} of 2", "rank 0 of 1") for ln in _lines(same, f"rank {r} of 2")]
+        assert mine == _lines(plain.stdout, "rank"), (r, mine)
+    assert _lines(same, "checksum") == _lines(plain.stdout, "checksum") * 2
+    # (b)
+    split = _launcher(args, force=False, extra_env={"DSG_DIST_BACKEND": "gloo", "DSG_SMOKE_SHARD": "1"}, nproc=2)
+    l0, l1 = _floats(_lines(split, "rank 0 of 2")), _floats(_lines(split, "rank 1 of 2"))
+    assert len(l0) == 3 and len(l1) == 3 and l0 != l1                      # different shards
+    cs = _lines(split, "checksum")
+    assert len(cs) == 2 and cs[0] == cs[1]                                 # one model on both ranks, bit for bit
+    assert abs((l0[0] + l1[0]) / 2 - p_loss[0]) <= 2e-6 * p_loss[0]        # same parameters, the batch in two halves
+    for i in (1, 2):   # after one / two averaged updates
+        assert abs((l0[i] + l1[i]) / 2 - p_loss[i]) <= 2e-3 * p_loss[i], (i, l0, l1, p_loss)
+
+
+def test_two_ranks_default_net_eight_buckets_overlap_the_backward_walk():
+    """The train.py:39-57 network at world size 2 on the one GPU (gloo, as above): 8 buckets of >= 25 MB leave in descending
+    order from inside the backward walk on both ranks, the averaged step is bitwise the one-process step (both ranks on the
+    same batch), and the two ranks hold the same parameters afterwards."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "DSG_FORCE_COLLECTIVES")}
+    args = [os.path.join("tools", "ddp_smoke.py"), "DEFAULT3", "2", "2"]
+    plain = subprocess.run([sys.executable] + args, env=env, cwd=ROOT, capture_output=True, text=True, timeout=600)
+    assert plain.returncode == 0, plain.stderr[-4000:]
+    two = _launcher(args, force=False, extra_env={"DSG_DIST_BACKEND": "gloo", "DSG_DDP_TRACE": "1"}, nproc=2)
+    f = _lines(two, "collectives")
+    assert len(f) == 2 and all(x.split()[3] == "gloo" and int(x.split()[5]) >= 8 for x in f), f
+    traces = [json.loads(ln[len("trace "):]) for ln in _lines(two, "trace")]
+    assert len(traces) == 2
+    for tr in traces:
+        order = tr["order"]
+        assert order == sorted(order, reverse=True) and len(set(order)) == len(order) >= 8, order
+        assert sum(tr["in_walk"]) >= len(order) - 1 and tr["in_walk"][0], tr["in_walk"]
+    for r in (0, 1):
+        mine = [ln.replace(f"rank {r} of 2", "rank 0 of 1") for ln in _lines(two, f"rank {r} of 2")]
+        assert mine == _lines(plain.stdout, "rank"), (r, mine)
+    assert _lines(two, "checksum") == _lines(plain.stdout, "checksum") * 2
 
 
 def test_bench_line_under_the_launcher_with_rccl_barrier_and_max():
