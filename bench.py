@@ -42,13 +42,20 @@ def _cfg():
     return CFG2
 
 
+def _local_device():
+    """one rank per GPU: LOCAL_RANK; more local ranks than GPUs (the two-ranks-on-one-GPU test) wrap around"""
+    n = torch.cuda.device_count() if torch.cuda.is_available() else 0
+    lr = int(os.environ.get("LOCAL_RANK", 0))
+    return lr % n if n else lr
+
+
 def gpu_leg(args, rank, world):
     import drivescenegen_amd as d
     from drivescenegen_amd import _lib, synth
     from drivescenegen_amd.configs import synth_weights
 
     cfg = _cfg()
-    dev = torch.device("cuda", int(os.environ.get("LOCAL_RANK", 0)))
+    dev = torch.device("cuda", _local_device())
     torch.cuda.set_device(dev)
     net = synth_weights(d.UNet2DModel(**cfg)).to(dev).eval().requires_grad_(False)
     sch = d.DDIMScheduler()
@@ -218,7 +225,7 @@ def forward_leg(args, cfg, dtype, batch, steps, ddim_steps, workload, flops_img,
     import drivescenegen_amd as d
     from drivescenegen_amd import _lib, synth
     from drivescenegen_amd.configs import synth_weights
-    dev = torch.device("cuda", int(os.environ.get("LOCAL_RANK", 0)))
+    dev = torch.device("cuda", _local_device())
     net = synth_weights(d.UNet2DModel(**cfg)).to(dev).eval().requires_grad_(False).set_compute_dtype(dtype)
     sch = d.DDIMScheduler()
     sch.set_timesteps(ddim_steps)
@@ -309,7 +316,7 @@ def train_ref_leg(args, steps=8):
     from drivescenegen_amd import synth
     from drivescenegen_amd.configs import DEFAULT3, synth_weights
     from drivescenegen_amd.train_loop import train_steps
-    dev = torch.device("cuda", int(os.environ.get("LOCAL_RANK", 0)))
+    dev = torch.device("cuda", _local_device())
     batch = 14
     acc = d.Accelerator(mixed_precision="fp16")
     net = synth_weights(d.UNet2DModel(**DEFAULT3)).to(dev)
@@ -348,7 +355,7 @@ def train_leg(args, dtype="fp32", batch=64, steps=4):
     from drivescenegen_amd import synth
     from drivescenegen_amd.configs import CFG3, CFG5, synth_weights
     cfg = CFG3 if dtype == "fp32" else CFG5
-    dev = torch.device("cuda", int(os.environ.get("LOCAL_RANK", 0)))
+    dev = torch.device("cuda", _local_device())
     net = synth_weights(d.UNet2DModel(**cfg)).to(dev).train().set_compute_dtype(dtype)
     opt = d.AdamW(net.parameters(), lr=1e-5)
     lrs = d.get_cosine_schedule_with_warmup(optimizer=opt, num_warmup_steps=500, num_training_steps=50000)
@@ -434,7 +441,7 @@ def small_batch_leg(args):
     import drivescenegen_amd as d
     from drivescenegen_amd import synth
     from drivescenegen_amd.configs import DEFAULT3, synth_weights
-    dev = torch.device("cuda", int(os.environ.get("LOCAL_RANK", 0)))
+    dev = torch.device("cuda", _local_device())
     net = synth_weights(d.UNet2DModel(**DEFAULT3)).to(dev).eval().requires_grad_(False)
     sch = d.DDPMScheduler()
     sch.set_timesteps(750)
@@ -599,8 +606,9 @@ def main():
     if world > 1 or (os.environ.get("DSG_FORCE_COLLECTIVES") == "1" and "RANK" in os.environ):
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", 0)))
-        torch.distributed.init_process_group("nccl")
+        torch.cuda.set_device(_local_device())
+        # RCCL ("nccl" on ROCm).  DSG_DIST_BACKEND=gloo is the test hook that lets two ranks share one GPU (tests/test_gpu_rccl_one_rank.py)
+        torch.distributed.init_process_group(os.environ.get("DSG_DIST_BACKEND", "nccl"))
     if args.gpus != world and rank == 0 and world > 1:
         print(f"warning: --gpus {args.gpus} but WORLD_SIZE={world}", file=sys.stderr)
 
@@ -668,6 +676,7 @@ def main():
             # the process group the timing barrier / max ran on (RCCL = torch's "nccl" backend on ROCm) and each rank's own
             # wall time per step: `ms_per_step` is their maximum
             "rccl_world": torch.distributed.get_world_size() if torch.distributed.is_initialized() else 0,
+            "dist_backend": torch.distributed.get_backend() if torch.distributed.is_initialized() else None,
             "per_rank_ms_per_step": [t / args.steps * 1e3 for t in per_rank],
             "whole_net_tflops": value * flops_img / 1e12,
             "whole_net_frac_of_f32_peak": value * flops_img / 1e12 / (PEAK_F32_TFLOPS * world),

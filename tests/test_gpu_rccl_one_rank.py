@@ -143,3 +143,19 @@ def test_bench_line_under_the_launcher_with_rccl_barrier_and_max():
     rec = json.loads([ln for ln in out.splitlines() if ln.startswith("{")][-1])
     assert rec["n_gpus"] == 1 and rec["steps"] == 3 and rec["value"] > 0 and rec["scaling"] == "weak"
     assert abs(rec["value"] - 16 * 3 / (rec["ms_per_step"] * 3e-3)) <= 1e-6 * rec["value"]
+
+
+def test_bench_line_of_two_ranks_sharing_the_gpu():
+    """`bench.py --gpus 2` as the driver launches it, with both ranks on the box's one GPU (gloo, the test hook): the N > 1 code of
+    the contract really runs -- barrier on both sides of the timed region, each rank's own wall time gathered, the MAXIMUM taken,
+    rank 0 alone printing ONE line whose value is the samples of BOTH ranks over that time."""
+    out = _launcher(["bench.py", "--gpus", "2", "--steps", "3", "--warmup", "1", "--no-cpu", "--no-extras"], force=False,
+                    extra_env={"DSG_DIST_BACKEND": "gloo"}, nproc=2)
+    lines = [ln for ln in out.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, len(lines)
+    rec = json.loads(lines[0])
+    assert rec["n_gpus"] == 2 and rec["steps"] == 3 and rec["scaling"] == "weak" and rec["rccl_world"] == 2
+    per = rec["per_rank_ms_per_step"]
+    assert len(per) == 2 and abs(rec["ms_per_step"] - max(per)) <= 1e-6 * max(per)
+    assert abs(rec["value"] - 2 * 16 * 3 / (rec["ms_per_step"] * 3e-3)) <= 1e-6 * rec["value"]
+    assert rec["config"]["global_batch"] == 32
