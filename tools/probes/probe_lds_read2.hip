@@ -1,0 +1,105 @@
+// Probe (round 4): ds_read2_b32 under LDS contention from other processes, with hand-placed waits.
+// Every thread streams pairs of neighbouring floats out of a 40-KB LDS table (stride 35 floats between the half-waves, as in
+// conv_fewout_kernel) through a two-deep software pipeline and sums them; the sum is known exactly.  Modes:
+//   0  ds_read2_b32 (offset1 = offset0 + 1), counted waits: s_waitcnt lgkmcnt(1) before consuming the older pair
+//   1  ds_read2_b32, full waits: s_waitcnt lgkmcnt(0) before every use
+//   2  two ds_read_b32 per pair, counted waits (lgkmcnt(2))
+//   3  ds_read2_b32 with offset1 = offset0 + 35 (two rows, not neighbours), counted waits
+// Build: hipcc --offload-arch=gfx950 -O3 -o probe_lds_read2 tools/probes/probe_lds_read2.hip
+// Run:   ./probe_lds_read2 [launches]   (alone, then next to loader processes: tools/probes/run_lds_mix.sh)
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+
+constexpr int N = 10080;  // floats in the table
+typedef float f2 __attribute__((ext_vector_type(2)));
+
+template <int MODE>
+__global__ __launch_bounds__(256, 2) void probe(float* out, int iters) {
+  __shared__ float xs[N];
+  const int tid = threadIdx.x;
+  for (int e = tid; e < N; e += 256) xs[e] = (float)((e * 2654435761u) >> 22);  // small integers: sums are exact in fp32
+  __syncthreads();
+  const int col = tid & 31, r0 = tid >> 5;
+  const unsigned base = (unsigned)(size_t)(__attribute__((address_space(3))) float*)(xs + r0 * 35 + col);
+  float acc = 0.f;
+  f2 p0, p1;
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  for (int it = 0; it < iters; ++it) {
+    unsigned a = base + (unsigned)((it * 37) % 9000) * 4;   // (uniform step: the same address pattern every iteration)
+    unsigned b = a + 630 * 4;
+    if constexpr (MODE == 0 || MODE == 1 || MODE == 3) {
+      if constexpr (MODE == 3) {
+        asm volatile("ds_read2_b32 %0, %1 offset1:35" : "=v"(p0) : "v"(a) : "memory");
+        asm volatile("ds_read2_b32 %0, %1 offset1:35" : "=v"(p1) : "v"(b) : "memory");
+      } else {
+        asm volatile("ds_read2_b32 %0, %1 offset1:1" : "=v"(p0) : "v"(a) : "memory");
+        asm volatile("ds_read2_b32 %0, %1 offset1:1" : "=v"(p1) : "v"(b) : "memory");
+      }
+      if constexpr (MODE == 1) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      else asm volatile("s_waitcnt lgkmcnt(1)" ::: "memory");
+      asm volatile("v_add_f32 %0, %0, %1\n\tv_add_f32 %0, %0, %2" : "+v"(acc) : "v"(p0.x), "v"(p0.y));
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      asm volatile("v_add_f32 %0, %0, %1\n\tv_add_f32 %0, %0, %2" : "+v"(acc) : "v"(p1.x), "v"(p1.y));
+    } else {
+      asm volatile("ds_read_b32 %0, %1" : "=v"(s0) : "v"(a) : "memory");
+      asm volatile("ds_read_b32 %0, %1 offset:4" : "=v"(s1) : "v"(a) : "memory");
+      asm volatile("ds_read_b32 %0, %1" : "=v"(s2) : "v"(b) : "memory");
+      asm volatile("ds_read_b32 %0, %1 offset:4" : "=v"(s3) : "v"(b) : "memory");
+      asm volatile("s_waitcnt lgkmcnt(2)" ::: "memory");
+      asm volatile("v_add_f32 %0, %0, %1\n\tv_add_f32 %0, %0, %2" : "+v"(acc) : "v"(s0), "v"(s1));
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      asm volatile("v_add_f32 %0, %0, %1\n\tv_add_f32 %0, %0, %2" : "+v"(acc) : "v"(s2), "v"(s3));
+    }
+  }
+  out[(size_t)blockIdx.x * 256 + tid] = acc;
+}
+
+template <int MODE>
+static void run(int launches, const char* what) {
+  const int blocks = 1024, iters = 600;
+  const size_t n = (size_t)blocks * 256;
+  float* d;
+  hipMalloc(&d, n * sizeof(float));
+  std::vector<float> ref(n), got(n);
+  {  // the exact sums (small integers)
+    std::vector<float> xs(N);
+    for (int e = 0; e < N; ++e) xs[e] = (float)(((unsigned)e * 2654435761u) >> 22);
+    const int second = MODE == 3 ? 35 : 1;
+    for (int tid = 0; tid < 256; ++tid) {
+      const int b0 = (tid >> 5) * 35 + (tid & 31);
+      double sum = 0;
+      for (int it = 0; it < iters; ++it) {
+        const int a = b0 + (it * 37) % 9000, b = a + 630;
+        sum += xs[a] + xs[a + second] + xs[b] + xs[b + second];
+      }
+      for (int blk = 0; blk < blocks; ++blk) ref[(size_t)blk * 256 + tid] = (float)sum;
+    }
+  }
+  int bad = 0;
+  long lanes[4] = {0, 0, 0, 0};
+  for (int it = 1; it <= launches; ++it) {
+    hipLaunchKernelGGL(probe<MODE>, dim3(blocks), dim3(256), 0, 0, d, iters);
+    hipMemcpy(got.data(), d, n * sizeof(float), hipMemcpyDeviceToHost);
+    bool diff = false;
+    for (size_t i = 0; i < n; ++i)
+      if (ref[i] != got[i]) {
+        diff = true;
+        lanes[(i & 63) / 16]++;
+      }
+    bad += diff;
+  }
+  printf("mode %d (%s): launches with wrong sums %d of %d; by lane quarter %ld %ld %ld %ld\n", MODE, what, bad, launches,
+         lanes[0], lanes[1], lanes[2], lanes[3]);
+  hipFree(d);
+}
+
+int main(int argc, char** argv) {
+  const int launches = argc > 1 ? atoi(argv[1]) : 200;
+  run<0>(launches, "ds_read2_b32 neighbours, counted waits");
+  run<1>(launches, "ds_read2_b32 neighbours, full waits");
+  run<2>(launches, "2 x ds_read_b32, counted waits");
+  run<3>(launches, "ds_read2_b32 rows apart, counted waits");
+  return 0;
+}
