@@ -5,6 +5,9 @@
 //   1  ds_read2_b32, full waits: s_waitcnt lgkmcnt(0) before every use
 //   2  two ds_read_b32 per pair, counted waits (lgkmcnt(2))
 //   3  ds_read2_b32 with offset1 = offset0 + 35 (two rows, not neighbours), counted waits
+//   4  MIXED: a far pair (offset1 = offset0 + 218) issued first, a neighbouring pair second, counted wait, the FAR pair consumed first
+//      (what the compiler's loop has in flight: pairs of one 8-byte piece next to pairs of two pieces)
+//   5  the same with the neighbouring pair first
 // Build: hipcc --offload-arch=gfx950 -O3 -o probe_lds_read2 tools/probes/probe_lds_read2.hip
 // Run:   ./probe_lds_read2 [launches]   (alone, then next to loader processes: tools/probes/run_lds_mix.sh)
 #include <hip/hip_runtime.h>
@@ -29,7 +32,19 @@ __global__ __launch_bounds__(256, 2) void probe(float* out, int iters) {
   for (int it = 0; it < iters; ++it) {
     unsigned a = base + (unsigned)((it * 37) % 9000) * 4;   // (uniform step: the same address pattern every iteration)
     unsigned b = a + 630 * 4;
-    if constexpr (MODE == 0 || MODE == 1 || MODE == 3) {
+    if constexpr (MODE == 4 || MODE == 5) {
+      if constexpr (MODE == 4) {
+        asm volatile("ds_read2_b32 %0, %1 offset0:8 offset1:226" : "=v"(p0) : "v"(a) : "memory");
+        asm volatile("ds_read2_b32 %0, %1 offset1:1" : "=v"(p1) : "v"(b) : "memory");
+      } else {
+        asm volatile("ds_read2_b32 %0, %1 offset1:1" : "=v"(p0) : "v"(b) : "memory");
+        asm volatile("ds_read2_b32 %0, %1 offset0:8 offset1:226" : "=v"(p1) : "v"(a) : "memory");
+      }
+      asm volatile("s_waitcnt lgkmcnt(1)" ::: "memory");
+      asm volatile("v_add_f32 %0, %0, %1\n\tv_add_f32 %0, %0, %2" : "+v"(acc) : "v"(p0.x), "v"(p0.y));
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      asm volatile("v_add_f32 %0, %0, %1\n\tv_add_f32 %0, %0, %2" : "+v"(acc) : "v"(p1.x), "v"(p1.y));
+    } else if constexpr (MODE == 0 || MODE == 1 || MODE == 3) {
       if constexpr (MODE == 3) {
         asm volatile("ds_read2_b32 %0, %1 offset1:35" : "=v"(p0) : "v"(a) : "memory");
         asm volatile("ds_read2_b32 %0, %1 offset1:35" : "=v"(p1) : "v"(b) : "memory");
@@ -72,7 +87,9 @@ static void run(int launches, const char* what) {
       double sum = 0;
       for (int it = 0; it < iters; ++it) {
         const int a = b0 + (it * 37) % 9000, b = a + 630;
-        sum += xs[a] + xs[a + second] + xs[b] + xs[b + second];
+        if (MODE == 4) sum += xs[a + 8] + xs[a + 226] + xs[b] + xs[b + 1];
+        else if (MODE == 5) sum += xs[b] + xs[b + 1] + xs[a + 8] + xs[a + 226];
+        else sum += xs[a] + xs[a + second] + xs[b] + xs[b + second];
       }
       for (int blk = 0; blk < blocks; ++blk) ref[(size_t)blk * 256 + tid] = (float)sum;
     }
@@ -101,5 +118,7 @@ int main(int argc, char** argv) {
   run<1>(launches, "ds_read2_b32 neighbours, full waits");
   run<2>(launches, "2 x ds_read_b32, counted waits");
   run<3>(launches, "ds_read2_b32 rows apart, counted waits");
+  run<4>(launches, "far pair then neighbouring pair in flight, counted wait, far consumed first");
+  run<5>(launches, "neighbouring pair then far pair in flight, counted wait, neighbouring consumed first");
   return 0;
 }
