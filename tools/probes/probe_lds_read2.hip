@@ -8,6 +8,7 @@
 //   4  MIXED: a far pair (offset1 = offset0 + 218) issued first, a neighbouring pair second, counted wait, the FAR pair consumed first
 //      (what the compiler's loop has in flight: pairs of one 8-byte piece next to pairs of two pieces)
 //   5  the same with the neighbouring pair first
+//   6  SIX pairs in flight (alternating neighbouring / far), consumed oldest first behind lgkmcnt(5), (4), .. (0)
 // Build: hipcc --offload-arch=gfx950 -O3 -o probe_lds_read2 tools/probes/probe_lds_read2.hip
 // Run:   ./probe_lds_read2 [launches]   (alone, then next to loader processes: tools/probes/run_lds_mix.sh)
 #include <hip/hip_runtime.h>
@@ -32,7 +33,21 @@ __global__ __launch_bounds__(256, 2) void probe(float* out, int iters) {
   for (int it = 0; it < iters; ++it) {
     unsigned a = base + (unsigned)((it * 37) % 9000) * 4;   // (uniform step: the same address pattern every iteration)
     unsigned b = a + 630 * 4;
-    if constexpr (MODE == 4 || MODE == 5) {
+    if constexpr (MODE == 6) {
+      f2 q0, q1, q2, q3, q4, q5;
+      asm volatile("ds_read2_b32 %0, %1 offset1:1" : "=v"(q0) : "v"(a) : "memory");
+      asm volatile("ds_read2_b32 %0, %1 offset0:8 offset1:226" : "=v"(q1) : "v"(a) : "memory");
+      asm volatile("ds_read2_b32 %0, %1 offset0:2 offset1:3" : "=v"(q2) : "v"(a) : "memory");
+      asm volatile("ds_read2_b32 %0, %1 offset0:35 offset1:220" : "=v"(q3) : "v"(a) : "memory");
+      asm volatile("ds_read2_b32 %0, %1 offset0:36 offset1:37" : "=v"(q4) : "v"(a) : "memory");
+      asm volatile("ds_read2_b32 %0, %1 offset0:70 offset1:250" : "=v"(q5) : "v"(a) : "memory");
+      asm volatile("s_waitcnt lgkmcnt(5)\n\tv_add_f32 %0, %0, %1\n\tv_add_f32 %0, %0, %2" : "+v"(acc) : "v"(q0.x), "v"(q0.y));
+      asm volatile("s_waitcnt lgkmcnt(4)\n\tv_add_f32 %0, %0, %1\n\tv_add_f32 %0, %0, %2" : "+v"(acc) : "v"(q1.x), "v"(q1.y));
+      asm volatile("s_waitcnt lgkmcnt(3)\n\tv_add_f32 %0, %0, %1\n\tv_add_f32 %0, %0, %2" : "+v"(acc) : "v"(q2.x), "v"(q2.y));
+      asm volatile("s_waitcnt lgkmcnt(2)\n\tv_add_f32 %0, %0, %1\n\tv_add_f32 %0, %0, %2" : "+v"(acc) : "v"(q3.x), "v"(q3.y));
+      asm volatile("s_waitcnt lgkmcnt(1)\n\tv_add_f32 %0, %0, %1\n\tv_add_f32 %0, %0, %2" : "+v"(acc) : "v"(q4.x), "v"(q4.y));
+      asm volatile("s_waitcnt lgkmcnt(0)\n\tv_add_f32 %0, %0, %1\n\tv_add_f32 %0, %0, %2" : "+v"(acc) : "v"(q5.x), "v"(q5.y));
+    } else if constexpr (MODE == 4 || MODE == 5) {
       if constexpr (MODE == 4) {
         asm volatile("ds_read2_b32 %0, %1 offset0:8 offset1:226" : "=v"(p0) : "v"(a) : "memory");
         asm volatile("ds_read2_b32 %0, %1 offset1:1" : "=v"(p1) : "v"(b) : "memory");
@@ -87,7 +102,8 @@ static void run(int launches, const char* what) {
       double sum = 0;
       for (int it = 0; it < iters; ++it) {
         const int a = b0 + (it * 37) % 9000, b = a + 630;
-        if (MODE == 4) sum += xs[a + 8] + xs[a + 226] + xs[b] + xs[b + 1];
+        if (MODE == 6) sum += xs[a] + xs[a + 1] + xs[a + 8] + xs[a + 226] + xs[a + 2] + xs[a + 3] + xs[a + 35] + xs[a + 220] + xs[a + 36] + xs[a + 37] + xs[a + 70] + xs[a + 250];
+        else if (MODE == 4) sum += xs[a + 8] + xs[a + 226] + xs[b] + xs[b + 1];
         else if (MODE == 5) sum += xs[b] + xs[b + 1] + xs[a + 8] + xs[a + 226];
         else sum += xs[a] + xs[a + second] + xs[b] + xs[b + second];
       }
@@ -120,5 +136,6 @@ int main(int argc, char** argv) {
   run<3>(launches, "ds_read2_b32 rows apart, counted waits");
   run<4>(launches, "far pair then neighbouring pair in flight, counted wait, far consumed first");
   run<5>(launches, "neighbouring pair then far pair in flight, counted wait, neighbouring consumed first");
+  run<6>(launches, "six pairs in flight, consumed oldest first behind lgkmcnt(5) .. (0)");
   return 0;
 }
