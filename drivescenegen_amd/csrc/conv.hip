@@ -639,13 +639,13 @@ __global__ __launch_bounds__(256, 2) void conv_fewout_kernel(ConvP p) {
         typedef float f2 __attribute__((ext_vector_type(2)));
         const float4 wq = *reinterpret_cast<const float4*>(wsm + (c * 9 + t) * 4);
         const f2 w01 = {wq.x, wq.y}, w23 = {wq.z, wq.w};
-        // VOLATILE, LDS address space, on purpose (round 4).  Left to itself hipcc 7.2 pairs these reads into ds_read2_b32 and keeps
-        // them in flight together with the broadcast ds_read_b128 of the weight quads behind counted waits (lgkmcnt(1), (2)).
-        // Alone on the GPU that is bit-stable; with OTHER PROCESSES' workgroups sharing the CU it is not: lanes 48-63 of every
-        // wave -- the quarter whose data an LDS return delivers last -- consumed stale registers in ~90 % of the launches (errors of
-        // 1e-3 .. 1e-1 on O(1) outputs: tools/race_ops.sh, profiles/r04_race_under_load.txt).  Single ds_read_b32 with the same
-        // counted waits (this form), or the weights through the scalar cache instead of LDS, are stable: 0 wrong of 600 launches
-        // under the same load, +5 % on the kernel's time.
+        // VOLATILE, LDS address space, on purpose (round 4).  Left to itself hipcc 7.2 pairs these reads into ds_read2_b32 and then
+        // feeds the packed FMAs below with `op_sel:[0,1,0]` (both lanes take the pair's HIGH dword).  On gfx950 a packed fp32 VALU op
+        // of that form returns wrong values on lanes 48-63 while waves of ANOTHER PROCESS run v_mfma_f32_32x32x16_f16 on the same GPU
+        // (tools/probes/probe_lds_read2.hip modes 13-15 next to probe_neighbour.hip mode 0; profiles/r04_race_under_load.txt): this
+        // kernel was off by 1e-3 .. 1e-1 in ~90 % of its launches next to a second process of this library and bit-stable alone.
+        // Single reads land in registers of their own and the FMAs take `op_sel_hi:[1,0,1]` (low dword twice), which is not
+        // affected; tests/test_isa_policy.py fails any build of the library that contains the other form again.
         const volatile __attribute__((address_space(3))) float* xv = (const volatile __attribute__((address_space(3))) float*)xp;
         const float a0 = xv[(t / 3) * FO_PW + (t % 3)], a1 = xv[(t / 3 + 8) * FO_PW + (t % 3)];
         const f2 b0 = {a0, a0}, b1 = {a1, a1};

@@ -1,0 +1,46 @@
+"""ISA policy of the built library (runs without a GPU: the code objects are disassembled with llvm-objdump).
+
+gfx950 hazard found in round 4 (profiles/r04_race_under_load.txt; reproducers tools/probes/probe_lds_read2.hip modes
+13-15 next to tools/probes/probe_neighbour.hip mode 0): a packed fp32 VALU instruction whose op_sel routes a HIGH dword to the low
+lane -- `v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32 ... op_sel:[0,1,..]` -- returns wrong values on lanes 48-63 while waves of another
+process run `v_mfma_f32_32x32x16_f16` on the same GPU.  hipcc emits that form on its own when it packs scalar fp32 arithmetic whose
+operand sits in the upper half of a register pair; nothing in a kernel's source shows it, and the kernel passes every test that
+runs alone.  The library is kept free of it: this test fails the build that re-introduces one."""
+import os
+import re
+import shutil
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+LIB = os.path.join(ROOT, "drivescenegen_amd", "lib", "libdsg.so")
+OBJDUMP = "/opt/rocm/lib/llvm/bin/llvm-objdump"
+
+# low lane <- high dword of a source: any op_sel:[...] list on a packed fp32 op (the default, all zeros, is not printed)
+BAD = re.compile(r"\bv_pk_(fma|mul|add)_f32\b.*\bop_sel:\[")
+
+
+@pytest.mark.skipif(not os.path.exists(OBJDUMP), reason="llvm-objdump of the ROCm toolchain not found")
+def test_no_packed_fp32_op_takes_a_high_dword_for_its_low_lane(lib_built, tmp_path):
+    work = str(tmp_path)
+    shutil.copy(LIB, os.path.join(work, "libdsg.so"))
+    subprocess.run([OBJDUMP, "--offloading", "libdsg.so"], cwd=work, check=True, capture_output=True)
+    bundles = sorted(f for f in os.listdir(work) if "amdgcn" in f)
+    assert len(bundles) >= 10, bundles   # one code object per HIP source
+    offenders, packed, kernels = [], 0, 0
+    for b in bundles:
+        out = subprocess.run([OBJDUMP, "-d", "--mcpu=gfx950", b], cwd=work, check=True, capture_output=True, text=True).stdout
+        name = "?"
+        for ln in out.splitlines():
+            m = re.match(r"^[0-9a-f]+ <(\S+)>:", ln)
+            if m:
+                name = m.group(1)
+                kernels += 1
+                continue
+            if "v_pk_" in ln and "_f32" in ln:
+                packed += 1
+                if BAD.search(ln):
+                    offenders.append((name, ln.strip()[:120]))
+    assert kernels > 100 and packed > 1000, (kernels, packed)   # (the disassembly really covered the library)
+    assert not offenders, offenders[:10]

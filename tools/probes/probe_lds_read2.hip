@@ -8,6 +8,14 @@
 //   4  MIXED: a far pair (offset1 = offset0 + 218) issued first, a neighbouring pair second, counted wait, the FAR pair consumed first
 //      (what the compiler's loop has in flight: pairs of one 8-byte piece next to pairs of two pieces)
 //   5  the same with the neighbouring pair first
+//   7  a pair by ds_read2_b32, FULL wait, then v_pk_fma_f32 with op_sel:[0,1,0] (both lanes take the pair's HIGH dword)
+//   8  the same with op_sel_hi:[1,0,1] (both lanes take the LOW dword)
+//   9  ds_read2_b32, full wait, the HIGH dword consumed by the very next instruction (v_add_f32)
+//  10  the same with s_nop 7 between the wait and the consumer
+//  11  ds_read2_b64, full wait, the LAST dword consumed by the very next instruction
+//  12  ds_read_b64 (one 8-byte piece), full wait, the high dword consumed at once
+//  13  NO LDS at all: the pair made by VALU moves, then v_pk_fma_f32 op_sel:[0,1,0]
+//  14  ... v_pk_mul_f32 op_sel:[0,1,0] + v_pk_add_f32      15  ... v_pk_add_f32 op_sel:[0,1,0]
 //   6  SIX pairs in flight (alternating neighbouring / far), consumed oldest first behind lgkmcnt(5), (4), .. (0)
 // Build: hipcc --offload-arch=gfx950 -O3 -o probe_lds_read2 tools/probes/probe_lds_read2.hip
 // Run:   ./probe_lds_read2 [launches]   (alone, then next to loader processes: tools/probes/run_lds_mix.sh)
@@ -33,7 +41,47 @@ __global__ __launch_bounds__(256, 2) void probe(float* out, int iters) {
   for (int it = 0; it < iters; ++it) {
     unsigned a = base + (unsigned)((it * 37) % 9000) * 4;   // (uniform step: the same address pattern every iteration)
     unsigned b = a + 630 * 4;
-    if constexpr (MODE == 6) {
+    if constexpr (MODE == 13 || MODE == 14 || MODE == 15) {
+      f2 w = {1.0f, 2.0f}, acc2 = {acc, 0.f}, pr;
+      pr.x = (float)((it * 7 + tid) & 511);
+      pr.y = (float)((it * 13 + tid * 3) & 1023);
+      asm volatile("" : "+v"(pr));
+      if constexpr (MODE == 13) asm volatile("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[0,1,0]" : "+v"(acc2) : "v"(w), "v"(pr));
+      else if constexpr (MODE == 14) {
+        f2 t2;
+        asm volatile("v_pk_mul_f32 %0, %1, %2 op_sel:[0,1]" : "=v"(t2) : "v"(w), "v"(pr));
+        asm volatile("v_pk_add_f32 %0, %0, %1" : "+v"(acc2) : "v"(t2));
+      } else {
+        f2 t2;
+        asm volatile("v_pk_add_f32 %0, %1, %2 op_sel:[0,1]" : "=v"(t2) : "v"(w), "v"(pr));   // (1 + y, 2 + y)
+        acc2.x += t2.x - 1.0f;
+        acc2.y += 2.0f * (t2.y - 2.0f);
+      }
+      asm volatile("s_nop 4" ::: "memory");
+      acc = acc2.x + 0.5f * acc2.y - pr.y;
+    } else if constexpr (MODE == 9 || MODE == 10) {
+      asm volatile("ds_read2_b32 %0, %1 offset0:2 offset1:37" : "=v"(p0) : "v"(a) : "memory");
+      if constexpr (MODE == 9) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\tv_add_f32 %0, %0, %1" : "+v"(acc) : "v"(p0.y) : "memory");
+      else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_nop 7\n\tv_add_f32 %0, %0, %1" : "+v"(acc) : "v"(p0.y) : "memory");
+    } else if constexpr (MODE == 11) {
+      typedef float f4v __attribute__((ext_vector_type(4)));
+      f4v q;
+      const unsigned a8 = a & ~7u;   // (8-byte aligned)
+      asm volatile("ds_read2_b64 %0, %1 offset0:1 offset1:18" : "=v"(q) : "v"(a8) : "memory");
+      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\tv_add_f32 %0, %0, %1" : "+v"(acc) : "v"(q.w) : "memory");
+    } else if constexpr (MODE == 12) {
+      const unsigned a8 = a & ~7u;
+      asm volatile("ds_read_b64 %0, %1 offset:8" : "=v"(p0) : "v"(a8) : "memory");
+      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\tv_add_f32 %0, %0, %1" : "+v"(acc) : "v"(p0.y) : "memory");
+    } else if constexpr (MODE == 7 || MODE == 8) {
+      f2 w = {1.0f, 2.0f}, acc2 = {acc, 0.f};
+      asm volatile("ds_read2_b32 %0, %1 offset0:2 offset1:37" : "=v"(p0) : "v"(a) : "memory");
+      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+      if constexpr (MODE == 7) asm volatile("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[0,1,0]" : "+v"(acc2) : "v"(w), "v"(p0));
+      else asm volatile("v_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[1,0,1]" : "+v"(acc2) : "v"(w), "v"(p0));
+      asm volatile("s_nop 4" ::: "memory");
+      acc = acc2.x + 0.5f * acc2.y - (MODE == 7 ? p0.y : p0.x);   // = acc + 1 * v + 0.5 * (2 * v) - v = acc + v, exactly (small integers)
+    } else if constexpr (MODE == 6) {
       f2 q0, q1, q2, q3, q4, q5;
       asm volatile("ds_read2_b32 %0, %1 offset1:1" : "=v"(q0) : "v"(a) : "memory");
       asm volatile("ds_read2_b32 %0, %1 offset0:8 offset1:226" : "=v"(q1) : "v"(a) : "memory");
@@ -102,7 +150,13 @@ static void run(int launches, const char* what) {
       double sum = 0;
       for (int it = 0; it < iters; ++it) {
         const int a = b0 + (it * 37) % 9000, b = a + 630;
-        if (MODE == 6) sum += xs[a] + xs[a + 1] + xs[a + 8] + xs[a + 226] + xs[a + 2] + xs[a + 3] + xs[a + 35] + xs[a + 220] + xs[a + 36] + xs[a + 37] + xs[a + 70] + xs[a + 250];
+        if (MODE >= 13 && MODE <= 15) sum += (float)((it * 13 + tid * 3) & 1023);
+        else if (MODE == 9 || MODE == 10) sum += xs[a + 37];
+        else if (MODE == 11) sum += xs[(a & ~1) + 2 * 18 + 1];
+        else if (MODE == 12) sum += xs[(a & ~1) + 2 + 1];
+        else if (MODE == 7) sum += xs[a + 37];
+        else if (MODE == 8) sum += xs[a + 2];
+        else if (MODE == 6) sum += xs[a] + xs[a + 1] + xs[a + 8] + xs[a + 226] + xs[a + 2] + xs[a + 3] + xs[a + 35] + xs[a + 220] + xs[a + 36] + xs[a + 37] + xs[a + 70] + xs[a + 250];
         else if (MODE == 4) sum += xs[a + 8] + xs[a + 226] + xs[b] + xs[b + 1];
         else if (MODE == 5) sum += xs[b] + xs[b + 1] + xs[a + 8] + xs[a + 226];
         else sum += xs[a] + xs[a + second] + xs[b] + xs[b + second];
@@ -136,6 +190,15 @@ int main(int argc, char** argv) {
   run<3>(launches, "ds_read2_b32 rows apart, counted waits");
   run<4>(launches, "far pair then neighbouring pair in flight, counted wait, far consumed first");
   run<5>(launches, "neighbouring pair then far pair in flight, counted wait, neighbouring consumed first");
+  run<7>(launches, "ds_read2_b32, full wait, v_pk_fma_f32 op_sel:[0,1,0]");
+  run<8>(launches, "ds_read2_b32, full wait, v_pk_fma_f32 op_sel_hi:[1,0,1]");
+  run<9>(launches, "ds_read2_b32, full wait, high dword consumed by the next instruction");
+  run<10>(launches, "ds_read2_b32, full wait, s_nop 7, high dword consumed");
+  run<11>(launches, "ds_read2_b64, full wait, last dword consumed by the next instruction");
+  run<12>(launches, "ds_read_b64, full wait, high dword consumed by the next instruction");
+  run<13>(launches, "no LDS: v_pk_fma_f32 op_sel:[0,1,0] on a VALU-made pair");
+  run<14>(launches, "no LDS: v_pk_mul_f32 op_sel:[0,1] + v_pk_add_f32");
+  run<15>(launches, "no LDS: v_pk_add_f32 op_sel:[0,1]");
   run<6>(launches, "six pairs in flight, consumed oldest first behind lgkmcnt(5) .. (0)");
   return 0;
 }
