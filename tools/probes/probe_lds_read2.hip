@@ -16,6 +16,8 @@
 //  12  ds_read_b64 (one 8-byte piece), full wait, the high dword consumed at once
 //  13  NO LDS at all: the pair made by VALU moves, then v_pk_fma_f32 op_sel:[0,1,0]
 //  14  ... v_pk_mul_f32 op_sel:[0,1,0] + v_pk_add_f32      15  ... v_pk_add_f32 op_sel:[0,1,0]
+//  16  NO LDS: v_pk_fma_f16 op_sel:[0,1,0] (the 16-bit packed form: both result halves from src1's HIGH half)
+//  17  NO LDS: v_pk_mul_f16 op_sel_hi:[1,0] (both from the LOW half: control)
 //   6  SIX pairs in flight (alternating neighbouring / far), consumed oldest first behind lgkmcnt(5), (4), .. (0)
 // Build: hipcc --offload-arch=gfx950 -O3 -o probe_lds_read2 tools/probes/probe_lds_read2.hip
 // Run:   ./probe_lds_read2 [launches]   (alone, then next to loader processes: tools/probes/run_lds_mix.sh)
@@ -41,7 +43,18 @@ __global__ __launch_bounds__(256, 2) void probe(float* out, int iters) {
   for (int it = 0; it < iters; ++it) {
     unsigned a = base + (unsigned)((it * 37) % 9000) * 4;   // (uniform step: the same address pattern every iteration)
     unsigned b = a + 630 * 4;
-    if constexpr (MODE == 13 || MODE == 14 || MODE == 15) {
+    if constexpr (MODE == 16 || MODE == 17) {
+      typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+      h2 w = {(_Float16)1.0f, (_Float16)2.0f}, pr, r, z = {(_Float16)0.f, (_Float16)0.f};
+      const float lo = (float)((it * 7 + tid) & 255), hi = (float)((it * 13 + tid * 3) & 511);
+      pr.x = (_Float16)lo;
+      pr.y = (_Float16)hi;
+      asm volatile("" : "+v"(pr));
+      if constexpr (MODE == 16) asm volatile("v_pk_fma_f16 %0, %1, %2, %3 op_sel:[0,1,0]" : "=v"(r) : "v"(w), "v"(pr), "v"(z));
+      else asm volatile("v_pk_mul_f16 %0, %1, %2 op_sel_hi:[1,0]" : "=v"(r) : "v"(w), "v"(pr));
+      asm volatile("s_nop 4" ::: "memory");
+      acc += (float)r.x + 0.5f * (float)r.y - (MODE == 16 ? hi : lo);   // = + the selected half, exactly
+    } else if constexpr (MODE == 13 || MODE == 14 || MODE == 15) {
       f2 w = {1.0f, 2.0f}, acc2 = {acc, 0.f}, pr;
       pr.x = (float)((it * 7 + tid) & 511);
       pr.y = (float)((it * 13 + tid * 3) & 1023);
@@ -150,7 +163,9 @@ static void run(int launches, const char* what) {
       double sum = 0;
       for (int it = 0; it < iters; ++it) {
         const int a = b0 + (it * 37) % 9000, b = a + 630;
-        if (MODE >= 13 && MODE <= 15) sum += (float)((it * 13 + tid * 3) & 1023);
+        if (MODE == 16) sum += (float)((it * 13 + tid * 3) & 511);
+        else if (MODE == 17) sum += (float)((it * 7 + tid) & 255);
+        else if (MODE >= 13 && MODE <= 15) sum += (float)((it * 13 + tid * 3) & 1023);
         else if (MODE == 9 || MODE == 10) sum += xs[a + 37];
         else if (MODE == 11) sum += xs[(a & ~1) + 2 * 18 + 1];
         else if (MODE == 12) sum += xs[(a & ~1) + 2 + 1];
@@ -199,6 +214,8 @@ int main(int argc, char** argv) {
   run<13>(launches, "no LDS: v_pk_fma_f32 op_sel:[0,1,0] on a VALU-made pair");
   run<14>(launches, "no LDS: v_pk_mul_f32 op_sel:[0,1] + v_pk_add_f32");
   run<15>(launches, "no LDS: v_pk_add_f32 op_sel:[0,1]");
+  run<16>(launches, "no LDS: v_pk_fma_f16 op_sel:[0,1,0]");
+  run<17>(launches, "no LDS: v_pk_mul_f16 op_sel_hi:[1,0]");
   run<6>(launches, "six pairs in flight, consumed oldest first behind lgkmcnt(5) .. (0)");
   return 0;
 }
