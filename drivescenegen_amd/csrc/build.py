@@ -22,8 +22,8 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fvisibility=hi
 # anti-lever on this part (MI355X_MICROARCH.md); measured on one box: bf16 forward 22.62 -> 22.44 ms, bf16 training step
 # 58.1 -> 57.3 ms; the fp32-equivalent instantiations do not change (15.56 / 15.58 ms)
 # No packed-fp32 VALU ops in the two streaming files that had them with op_sel selecting a HIGH dword for the low lane
-# (v_pk_fma / mul / add_f32 ... op_sel:[0,1,..]): on gfx950 such an instruction returns wrong values on lanes 48-63 while waves of
-# ANOTHER process run v_mfma_f32_32x32x16_f16 on the same GPU (profiles/r04_race_under_load.txt,
+# (v_pk_fma / mul / add_f32 ... op_sel:[0,1,..]): on gfx950 such an instruction returns wrong values on lanes 48-63 while
+# another wave on the same SIMD -- of this or ANY other process -- issues v_mfma_f32_32x32x16_f16 (profiles/r04_race_under_load.txt,
 # tools/probes/probe_lds_read2.hip + probe_neighbour.hip); tests/test_isa_policy.py keeps the whole library free of that form.
 NO_PK_F32 = ["-Xclang", "-target-feature", "-Xclang", "-packed-fp32-ops"]
 EXTRA_FLAGS = {"scheduler.hip": ["-ffp-contract=off"], "conv_h2_bf16.hip": ["-fno-slp-vectorize"], "conv_h2_f16.hip": ["-fno-slp-vectorize"],

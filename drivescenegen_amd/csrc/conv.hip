@@ -641,7 +641,8 @@ __global__ __launch_bounds__(256, 2) void conv_fewout_kernel(ConvP p) {
         const f2 w01 = {wq.x, wq.y}, w23 = {wq.z, wq.w};
         // VOLATILE, LDS address space, on purpose (round 4).  Left to itself hipcc 7.2 pairs these reads into ds_read2_b32 and then
         // feeds the packed FMAs below with `op_sel:[0,1,0]` (both lanes take the pair's HIGH dword).  On gfx950 a packed fp32 VALU op
-        // of that form returns wrong values on lanes 48-63 while waves of ANOTHER PROCESS run v_mfma_f32_32x32x16_f16 on the same GPU
+        // of that form returns wrong values on lanes 48-63 while ANOTHER WAVE on the same SIMD issues v_mfma_f32_32x32x16_f16 (here: a wave
+        // of another process; a kernel's own waves do it too, probe mode 18)
         // (tools/probes/probe_lds_read2.hip modes 13-15 next to probe_neighbour.hip mode 0; profiles/r04_race_under_load.txt): this
         // kernel was off by 1e-3 .. 1e-1 in ~90 % of its launches next to a second process of this library and bit-stable alone.
         // Single reads land in registers of their own and the FMAs take `op_sel_hi:[1,0,1]` (low dword twice), which is not

@@ -2,8 +2,8 @@
 
 gfx950 hazard found in round 4 (profiles/r04_race_under_load.txt; reproducers tools/probes/probe_lds_read2.hip modes
 13-15 next to tools/probes/probe_neighbour.hip mode 0): a packed fp32 VALU instruction whose op_sel routes a HIGH dword to the low
-lane -- `v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32 ... op_sel:[0,1,..]` -- returns wrong values on lanes 48-63 while waves of another
-process run `v_mfma_f32_32x32x16_f16` on the same GPU.  hipcc emits that form on its own when it packs scalar fp32 arithmetic whose
+lane -- `v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32 ... op_sel:[0,1,..]` -- returns wrong values on lanes 48-63 while another wave on the
+same SIMD (of another process, or of the same kernel: probe mode 18) issues `v_mfma_f32_32x32x16_f16`.  hipcc emits that form on its own when it packs scalar fp32 arithmetic whose
 operand sits in the upper half of a register pair; nothing in a kernel's source shows it, and the kernel passes every test that
 runs alone.  The library is kept free of it: this test fails the build that re-introduces one."""
 import os

@@ -18,6 +18,8 @@
 //  14  ... v_pk_mul_f32 op_sel:[0,1,0] + v_pk_add_f32      15  ... v_pk_add_f32 op_sel:[0,1,0]
 //  16  NO LDS: v_pk_fma_f16 op_sel:[0,1,0] (the 16-bit packed form: both result halves from src1's HIGH half)
 //  17  NO LDS: v_pk_mul_f16 op_sel_hi:[1,0] (both from the LOW half: control)
+//  18  ONE process, ONE kernel: waves 1 and 3 of every workgroup loop v_mfma_f32_32x32x16_f16 (AGPR accumulators) while waves 0 and 2
+//      run mode 13's v_pk_fma_f32 op_sel:[0,1,0] -- is another PROCESS needed, or only another WAVE on the SIMD?
 //   6  SIX pairs in flight (alternating neighbouring / far), consumed oldest first behind lgkmcnt(5), (4), .. (0)
 // Build: hipcc --offload-arch=gfx950 -O3 -o probe_lds_read2 tools/probes/probe_lds_read2.hip
 // Run:   ./probe_lds_read2 [launches]   (alone, then next to loader processes: tools/probes/run_lds_mix.sh)
@@ -40,7 +42,21 @@ __global__ __launch_bounds__(256, 2) void probe(float* out, int iters) {
   float acc = 0.f;
   f2 p0, p1;
   float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  typedef float f32x16 __attribute__((ext_vector_type(16)));
+  typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+  f32x16 m0 = {}, m1 = {};
+  half8 fa, fb;
+  for (int j = 0; j < 8; ++j) { fa[j] = (_Float16)(0.001f * tid); fb[j] = (_Float16)(0.002f * j); }
+  const bool mfma_wave = MODE == 18 && ((tid >> 6) & 1);
   for (int it = 0; it < iters; ++it) {
+    if constexpr (MODE == 18) {
+      if (mfma_wave) {   // (wave-uniform branch)
+        asm volatile("v_mfma_f32_32x32x16_f16 %0, %2, %3, %0\n\tv_mfma_f32_32x32x16_f16 %1, %2, %3, %1\n\t"
+                     "v_mfma_f32_32x32x16_f16 %0, %2, %3, %0\n\tv_mfma_f32_32x32x16_f16 %1, %2, %3, %1"
+                     : "+a"(m0), "+a"(m1) : "v"(fa), "v"(fb));
+        continue;
+      }
+    }
     unsigned a = base + (unsigned)((it * 37) % 9000) * 4;   // (uniform step: the same address pattern every iteration)
     unsigned b = a + 630 * 4;
     if constexpr (MODE == 16 || MODE == 17) {
@@ -54,12 +70,12 @@ __global__ __launch_bounds__(256, 2) void probe(float* out, int iters) {
       else asm volatile("v_pk_mul_f16 %0, %1, %2 op_sel_hi:[1,0]" : "=v"(r) : "v"(w), "v"(pr));
       asm volatile("s_nop 4" ::: "memory");
       acc += (float)r.x + 0.5f * (float)r.y - (MODE == 16 ? hi : lo);   // = + the selected half, exactly
-    } else if constexpr (MODE == 13 || MODE == 14 || MODE == 15) {
+    } else if constexpr (MODE == 13 || MODE == 14 || MODE == 15 || MODE == 18) {
       f2 w = {1.0f, 2.0f}, acc2 = {acc, 0.f}, pr;
       pr.x = (float)((it * 7 + tid) & 511);
       pr.y = (float)((it * 13 + tid * 3) & 1023);
       asm volatile("" : "+v"(pr));
-      if constexpr (MODE == 13) asm volatile("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[0,1,0]" : "+v"(acc2) : "v"(w), "v"(pr));
+      if constexpr (MODE == 13 || MODE == 18) asm volatile("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[0,1,0]" : "+v"(acc2) : "v"(w), "v"(pr));
       else if constexpr (MODE == 14) {
         f2 t2;
         asm volatile("v_pk_mul_f32 %0, %1, %2 op_sel:[0,1]" : "=v"(t2) : "v"(w), "v"(pr));
@@ -144,6 +160,11 @@ __global__ __launch_bounds__(256, 2) void probe(float* out, int iters) {
       asm volatile("v_add_f32 %0, %0, %1\n\tv_add_f32 %0, %0, %2" : "+v"(acc) : "v"(s2), "v"(s3));
     }
   }
+  if (mfma_wave) {
+    acc = 0.f;
+    for (int r = 0; r < 16; ++r) acc += (m0[r] + m1[r]) * 0.f;   // (keeps the matrix results alive; contributes exactly 0 or NaN-free junk * 0)
+    acc = -1.0f;                                                   // marker: not a checked value
+  }
   out[(size_t)blockIdx.x * 256 + tid] = acc;
 }
 
@@ -163,7 +184,8 @@ static void run(int launches, const char* what) {
       double sum = 0;
       for (int it = 0; it < iters; ++it) {
         const int a = b0 + (it * 37) % 9000, b = a + 630;
-        if (MODE == 16) sum += (float)((it * 13 + tid * 3) & 511);
+        if (MODE == 18) sum += (float)((it * 13 + tid * 3) & 1023);
+        else if (MODE == 16) sum += (float)((it * 13 + tid * 3) & 511);
         else if (MODE == 17) sum += (float)((it * 7 + tid) & 255);
         else if (MODE >= 13 && MODE <= 15) sum += (float)((it * 13 + tid * 3) & 1023);
         else if (MODE == 9 || MODE == 10) sum += xs[a + 37];
@@ -176,6 +198,7 @@ static void run(int launches, const char* what) {
         else if (MODE == 5) sum += xs[b] + xs[b + 1] + xs[a + 8] + xs[a + 226];
         else sum += xs[a] + xs[a + second] + xs[b] + xs[b + second];
       }
+      if (MODE == 18 && ((tid >> 6) & 1)) sum = -1.0;   // (the matrix waves' marker)
       for (int blk = 0; blk < blocks; ++blk) ref[(size_t)blk * 256 + tid] = (float)sum;
     }
   }
@@ -187,6 +210,7 @@ static void run(int launches, const char* what) {
     bool diff = false;
     for (size_t i = 0; i < n; ++i)
       if (ref[i] != got[i]) {
+        if (!diff && bad == 0 && getenv("PROBE_VERBOSE")) printf("  first mismatch: index %zu (tid %zu) got %.1f want %.1f\n", i, i & 255, got[i], ref[i]);
         diff = true;
         lanes[(i & 63) / 16]++;
       }
@@ -216,6 +240,7 @@ int main(int argc, char** argv) {
   run<15>(launches, "no LDS: v_pk_add_f32 op_sel:[0,1]");
   run<16>(launches, "no LDS: v_pk_fma_f16 op_sel:[0,1,0]");
   run<17>(launches, "no LDS: v_pk_mul_f16 op_sel_hi:[1,0]");
+  run<18>(launches, "ONE kernel: waves 1, 3 loop the 16-deep MFMA, waves 0, 2 v_pk_fma_f32 op_sel:[0,1,0]");
   run<6>(launches, "six pairs in flight, consumed oldest first behind lgkmcnt(5) .. (0)");
   return 0;
 }
