@@ -1,11 +1,13 @@
 """The engine next to OTHER PROCESSES on the same GPU: results must not depend on who else is running.
 
 Found in round 4 by running two ranks on the one GPU (tests/test_gpu_rccl_one_rank.py): the fp32 training forward was bit-stable
-alone and changed values in ~90 % of its runs as soon as another process kept the CUs busy.  One kernel was behind it --
-conv_fewout_kernel (conv_out of the [N,C,H,W] tape): hipcc had paired its patch reads into ds_read2_b32 and kept them in flight
-with the broadcast ds_read_b128 of the weights behind counted waits; under LDS contention lanes 48-63 consumed stale registers
-(csrc/conv.hip, DESIGN section 10, profiles/r04_race_under_load.txt).  A kernel with such a latent hazard passes every test that runs
-alone, so this file runs the engine's legs under a steady background load: two other processes looping U-Net forwards.
+alone and changed values in ~90 % of its runs as soon as another process of the library ran on the GPU.  One kernel was behind it --
+conv_fewout_kernel (conv_out of the [N,C,H,W] tape) -- and behind that one instruction form: on gfx950 a packed fp32 VALU op whose
+op_sel takes a HIGH dword for its low lane (v_pk_fma_f32 ... op_sel:[0,1,0]; hipcc emits it by itself) returns wrong values on lanes
+48-63 while another wave on the same SIMD issues the 16-deep v_mfma_f32_32x32x16_f16 (csrc/conv.hip, DESIGN section 10,
+profiles/r04_race_under_load.txt, tools/probes/).  tests/test_isa_policy.py keeps the form out of the built library; a kernel with such
+a latent hazard passes every test that runs alone, so this file runs the engine's legs under a steady background load: two other
+processes looping U-Net forwards (their pointwise convs are the aggressor kind).
   * single ops and whole forwards, repeated: every repetition must give the same bits;
   * training steps (forward, backward, clip, AdamW): the loaded run must be the solo run, bit for bit.
 Reference: the loops of training_pipeline.py:59-101 and generation.py:14-20 share the GPU with whatever else a node runs."""
@@ -82,6 +84,25 @@ def _conv_out_runs(reps):
     return worst, same
 
 
+def _streaming_rows(reps):
+    """rows f1 / f4 (the two other kernels hipcc had given the vulnerable packed form): repeated runs must return one result"""
+    from drivescenegen_amd import imageops
+    from drivescenegen_amd import rasterization as rz
+    rng = np.random.default_rng(7)
+    imgs = torch.from_numpy(rng.integers(0, 256, (4, 96, 80, 3), dtype=np.uint8)).to(DEV)
+    fimg = torch.from_numpy(rng.random((4, 96, 80, 3), dtype=np.float32)).to(DEV)
+    n = 400   # boxes [N][9] = (cx, cy, ux, uy, hx, hy, r, g, b) in draw order (oracle/raster_oracle.py:69)
+    ang = rng.uniform(0, 3.1, (n, 1))
+    boxes = np.concatenate([rng.uniform(8, 120, (n, 2)), np.cos(ang), -np.sin(ang), rng.uniform(1, 6, (n, 2)), rng.random((n, 3))], axis=1)
+    outs = set()
+    for _ in range(reps):
+        a = imageops.resize_normalize(imgs, (64, 48))
+        b = imageops.resize_normalize(fimg, (64, 48))
+        c = rz.rasterize_boxes(boxes, (128, 128), (0.5, 0.5, 0.5))
+        outs.add((float(a.double().abs().sum()).hex(), float(b.double().abs().sum()).hex(), float(c.double().abs().sum()).hex()))
+    return outs
+
+
 @pytest.fixture
 def background_load():
     """two other processes looping forwards of the default network (fp32-equivalent and bf16) on the same GPU"""
@@ -105,6 +126,7 @@ def test_results_do_not_depend_on_other_processes_on_the_gpu(background_load):
     # (solo references are not needed for the repeated legs: the first repetition is as loaded as the last)
     worst, same = _conv_out_runs(150)
     assert worst <= 2e-5 and same, (worst, same)                    # (was: 1e-3 .. 1e-1 off in ~90 % of the launches)
+    assert len(_streaming_rows(60)) == 1
     for cfg, batch, dtype, reps, train in ((configs.CFG1, 4, "fp32", 60, True), (configs.CFG1, 4, "bf16", 60, True),
                                            (configs.CFG1, 4, "fp32", 60, False), (configs.CFG4_SMALL, 2, "fp32", 30, False),
                                            (configs.DEFAULT3, 2, "fp32", 8, True), (configs.DEFAULT3, 2, "bf16", 8, False)):
