@@ -206,6 +206,24 @@ FWD_CLASSES_16 = {26: "conv3x3_s1_mfma_16bit", 30: "conv3x3_s1_mfma_16bit_two_wg
                   12: "conv_out_blocked_to_image"}
 
 
+# HIP-event classes 26 / 33 hold every 16-bit 3x3 stride-1 instantiation (conv_h2_launch.h: the two-workgroup classes are
+# fp32-equivalent only) -- 128-cout workgroups at one per CU AND 64-cout workgroups at two: the counter pattern takes both
+MIXED_PMC_PATTERNS = {"conv3x3_s1_mfma_16bit": r"conv_h2_kernel<0, [24], 3, [02], 4, [12], 3, (64|128), 1, \d, 0",
+                      "conv3x3_plus_fused_shortcut_16bit": r"conv_h2_kernel<0, [24], 3, [02], 4, [12], 3, (64|128), 1, \d, 1"}
+CFG4_PMC_PATTERNS = {"conv3x3_s1_mfma_f16x2split": r"conv_h2_kernel<0, 4, 3, 2, 4, 1, 3, 64, 0, 0, 0",
+                     "conv3x3_s1_mfma_f16x2split_two_wg_per_cu": r"conv_h2_kernel<0, 2, 3, 2, 4, 2, 3, 64, 0, 1, 0",
+                     "conv3x3_plus_fused_shortcut_f16x2split": r"conv_h2_kernel<0, 4, 3, 2, 4, 1, 3, 64, 0, 0, 1",
+                     "conv3x3_plus_fused_shortcut_f16x2split_two_wg_per_cu": r"conv_h2_kernel<0, 2, 3, 2, 4, 2, 3, 64, 0, 1, 1"}
+
+# what a reader needs next to a class's figures
+CLASS_NOTES = {
+    "conv3x3_upsample_mfma_f16x2split": "algorithmic FLOPs are the reference op's (3x3 conv on the nearest-x2 up-sampled map); the "
+                                         "folded kernel contracts four 2x2 phase filters on the low-resolution map = 4/9 of them, "
+                                         "so tflops / frac of this class read 2.25x what the matrix cores issue",
+    "conv3x3_upsample_mfma_16bit": "as conv3x3_upsample_mfma_f16x2split: FLOPs counted on the up-sampled map, 4/9 of them issued",
+}
+
+
 def class_roofline(row, peak_tflops, step_ms, sampled_steps=1):
     """One conv class against BOTH roofs: time at the matrix-core peak for its algorithmic FLOPs, time at 8 TB/s for its
     algorithmic bytes; `bound` is the longer of the two, `frac` = that time / the measured launch time."""
@@ -261,7 +279,8 @@ def forward_leg(args, cfg, dtype, batch, steps, ddim_steps, workload, flops_img,
            "ms_per_step": step_ms, "step_ms_spread": clock.spread(), "steps": steps, "dtype": dtype,
            "config": {"workload": workload, "batch": batch},
            "whole_net_tflops": batch * steps / dt * flops_img / 1e12,
-           "alg_hbm_gbs_whole_step": None, "kernels": rows}
+           "alg_hbm_gbs_whole_step": None, "kernels": rows,
+           "class_notes": {k: v for k, v in CLASS_NOTES.items() if k in rows}}
     peak = PEAK_F16_TFLOPS / (3.0 if dtype == "fp32" else 1.0)
     sampled = len(range(0, steps, PROF_EVERY))   # steps whose launches carry HIP-event records
     conv_rows = {k: v for k, v in rows.items() if k.startswith("conv3x3_s1") or k.startswith("conv3x3_plus")}
@@ -285,13 +304,9 @@ def mixed_leg(args, dtype="bf16"):
     64 / 128-channel layers are HBM-bound in 16 bits)."""
     from drivescenegen_amd.configs import CFG5
     b = args.mixed_batch
-    pats = {"conv3x3_s1_mfma_16bit": r"conv_h2_kernel<0, 4, 3, [02], 4, 1, 3, (64|128), 1, 0, 0",
-            "conv3x3_s1_mfma_16bit_two_wg_per_cu": r"conv_h2_kernel<0, [24], 3, [02], 4, 2, 3, (64|128), 1, \d, 0",
-            "conv3x3_plus_fused_shortcut_16bit": r"conv_h2_kernel<0, 4, 3, [02], 4, 1, 3, (64|128), 1, \d, 1",
-            "conv3x3_plus_fused_shortcut_16bit_two_wg_per_cu": r"conv_h2_kernel<0, [24], 3, [02], 4, 2, 3, (64|128), 1, \d, 1"}
     return forward_leg(args, CFG5, dtype, b, args.mixed_steps, args.ddim_steps,
                        "BASELINE configs[4] network: 256x256x8 map+agent raster, default U-Net (56,580,360 params), "
-                       f"mixed {dtype}, DDIM step, batch {b} on 1 GPU", 353.58e9, "_bf16", pats)
+                       f"mixed {dtype}, DDIM step, batch {b} on 1 GPU", 353.58e9, "_bf16", MIXED_PMC_PATTERNS)
 
 
 def cfg4_leg(args):
@@ -299,13 +314,9 @@ def cfg4_leg(args):
     16^2 (66,294,660 parameters), 100-step DDIM, batch 8 on one GPU, fp32-equivalent.  BASELINE calls it the 'HBM-bound
     conv path': four of its six levels are 64 / 128 channels wide at 512^2 ... 64^2."""
     from drivescenegen_amd.configs import CFG4
-    pats = {"conv3x3_s1_mfma_f16x2split": r"conv_h2_kernel<0, 4, 3, 2, 4, 1, 3, 64, 0, 0, 0",
-            "conv3x3_s1_mfma_f16x2split_two_wg_per_cu": r"conv_h2_kernel<0, 2, 3, 2, 4, 2, 3, 64, 0, 1, 0",
-            "conv3x3_plus_fused_shortcut_f16x2split": r"conv_h2_kernel<0, 4, 3, 2, 4, 1, 3, 64, 0, 0, 1",
-            "conv3x3_plus_fused_shortcut_f16x2split_two_wg_per_cu": r"conv_h2_kernel<0, 2, 3, 2, 4, 2, 3, 64, 0, 1, 1"}
     return forward_leg(args, CFG4, "fp32", 8, 20, 100,
                        "BASELINE configs[3]: 512x512x4 high-res raster, U-Net with attention at 16^2 and 32^2 (6 levels, "
-                       "66,294,660 params), 100-step DDIM (eta=0), batch 8 on 1 GPU, fp32-equivalent", CFG4_FLOPS_IMG, "_cfg4", pats)
+                       "66,294,660 params), 100-step DDIM (eta=0), batch 8 on 1 GPU, fp32-equivalent", CFG4_FLOPS_IMG, "_cfg4", CFG4_PMC_PATTERNS)
 
 
 def train_ref_leg(args, steps=8):
@@ -559,6 +570,59 @@ def summary_of(out):
     return s
 
 
+COMPACT_LIMIT = 6000   # bytes; the driver's parser took r03's 15 KB and not r04's 25.6 KB -- stay far below both
+ROOFLINE_KEYS = ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "traffic_source", "traffic_git_head",
+                 "mfma_pipe_util", "avg_launch_ms", "launches", "alg_flops_per_launch", "alg_gbs", "time_share")
+
+
+def write_full_record(out, path=None):
+    """The whole record as JSON under gpurun_out/ (merged back from the GPU box); returns the path or None."""
+    path = path or os.path.join(ROOT, "gpurun_out", "bench_full.json")
+    try:
+        os.makedirs(os.path.dirname(path), exist_ok=True)
+        with open(path, "w") as f:
+            json.dump(out, f)
+        return os.path.relpath(path, ROOT)
+    except OSError:
+        return None
+
+
+def compact_line(out, full_path=None):
+    """The ONE stdout line: the contract's top-level keys, `roofline` reduced to its scalars, `cpu_baseline`, and `summary`
+    (one short object per extra record).  Always below COMPACT_LIMIT bytes: text fields are cut, never the numbers."""
+    def cut(v, n):
+        return v if not isinstance(v, str) or len(v) <= n else v[:n - 1] + "~"
+    keys = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+            "dtype", "data", "config")
+    line = {k: out.get(k) for k in keys}
+    line["dtype"] = cut(line["dtype"], 160)
+    if isinstance(line["config"], dict):
+        line["config"] = {k: cut(v, 200) for k, v in line["config"].items()}
+    rf = out.get("roofline")
+    line["roofline"] = {k: rf.get(k) for k in ROOFLINE_KEYS if k in rf} if isinstance(rf, dict) else None
+    if isinstance(rf, dict):
+        for sub in ("second_kernel", "fused_shortcut_kernel", "fused_shortcut_two_wg_kernel"):
+            if isinstance(rf.get(sub), dict):
+                line["roofline"][sub] = {k: rf[sub].get(k) for k in ("frac", "avg_launch_ms", "launches", "time_share", "traffic")}
+    cb = out.get("cpu_baseline")
+    line["cpu_baseline"] = dict(cb, sample=cut(cb.get("sample"), 200)) if isinstance(cb, dict) else None
+    for k in ("step_ms_spread", "rccl_world", "dist_backend", "per_rank_ms_per_step", "whole_net_tflops"):
+        if k in out:
+            line[k] = out[k]
+    line["full_record"] = full_path
+    line["summary"] = {k: v for k, v in (out.get("summary") or {}).items() if k not in ("headline", "cpu_baseline")}
+    text = json.dumps(line, separators=(",", ":"))
+    if len(text) >= COMPACT_LIMIT:     # (only a pathological record gets here: drop the digest's optional fields, then the digest)
+        line["summary"] = {k: ({kk: vv for kk, vv in v.items() if kk in ("value", "unit", "ms_per_step", "error")}
+                               if isinstance(v, dict) else v) for k, v in line["summary"].items()}
+        text = json.dumps(line, separators=(",", ":"))
+    if len(text) >= COMPACT_LIMIT:
+        line["summary"] = None
+        text = json.dumps(line, separators=(",", ":"))
+    assert len(text) < COMPACT_LIMIT, len(text)
+    return text
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -682,6 +746,7 @@ def main():
             "whole_net_frac_of_f32_peak": value * flops_img / 1e12 / (PEAK_F32_TFLOPS * world),
             "roofline": roofline,
             "kernels": prof,
+            "class_notes": {k: v for k, v in CLASS_NOTES.items() if k in prof},
         }
         if not args.no_extras and world == 1:  # bounded extra legs, N = 1 only; a failure is reported, never hidden
             extras = {}
@@ -700,8 +765,13 @@ def main():
             out["extra_records"] = extras
         if not args.no_cpu and world == 1:  # (rank 0 at N = 1 only: the other ranks of a multi-GPU run would wait for it)
             out["cpu_baseline"] = cpu_leg(args)
-        out["summary"] = summary_of(out)   # LAST key: the headline numbers of every record survive a truncated tail
-        print(json.dumps(out))
+        out["summary"] = summary_of(out)
+        # the FULL record (every class row of every leg, ~25 KB) goes to a file and to stderr; stdout's last line is the
+        # compact line the driver parses (round 4's 25.6-KB line was not parsed: BENCH_r04.json "parsed": null)
+        full_path = write_full_record(out)
+        sys.stderr.write(json.dumps(out) + "\n")
+        sys.stderr.flush()
+        print(compact_line(out, full_path), flush=True)
     if torch.distributed.is_initialized():
         torch.distributed.barrier()
         torch.distributed.destroy_process_group()
