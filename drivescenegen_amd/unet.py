@@ -176,6 +176,7 @@ class UNet2DModel(nn.Module):
         self._plan = None          # dsg_unet_t* (c_void_p)
         self._plan_state = {}      # name -> (data_ptr, version) last pushed
         self._plan_items = None    # cached [(state-dict key, tensor)] of this module tree
+        self._plan_slots, self._plan_mods = [], []   # where each cached tensor / sub-module lives (the cache's validity check)
         self._plan_device = None
         self._ws = None
 
@@ -253,10 +254,13 @@ class UNet2DModel(nn.Module):
             _lib.check(lib.dsg_unet_set_param(self._plan, b"time_proj.freqs", _lib.ptr(fr), fr.numel(),
                                               _lib.stream_ptr(device)))
         # push parameters whose storage or version changed since the last push.  The (name, tensor) list is cached: building
-        # `state_dict()` costs ~0.8 ms per call on the 282-tensor network -- 40 % of a batch-1 denoising step -- the walk over the
-        # cached list ~0.1 ms; `_apply` (.to / .cuda / .float) and `load_state_dict` drop the cache
-        if self._plan_items is None:
-            self._plan_items = list(self.state_dict(keep_vars=True).items())
+        # `state_dict()` costs ~0.8 ms per call on the 282-tensor network -- 40 % of a batch-1 denoising step.  The cache is
+        # VALIDATED on every call: each cached tensor must still be the object its module's `_parameters` /
+        # `_buffers` slot holds and each cached module the object its parent's `_modules` slot holds (~40 us of dict lookups),
+        # so `load_state_dict(assign=True)` through a parent, `mod.weight = nn.Parameter(..)`, `register_parameter`,
+        # `torch.func.functional_call`, parametrize and a swapped sub-module all rebuild the list
+        if self._plan_items is None or not self._plan_items_valid():
+            self._build_plan_items()
         st = None
         for name, p in self._plan_items:
             sig = (p.data_ptr(), p._version)
@@ -271,6 +275,29 @@ class UNet2DModel(nn.Module):
             self._plan_state[name] = sig
         if st is not None:  # one host synchronisation per refresh: the weights' range-guard maxima (dsg.h)
             _lib.check(lib.dsg_unet_commit_params(self._plan))
+
+    def _build_plan_items(self):
+        self._plan_items = list(self.state_dict(keep_vars=True).items())
+        want = {id(t) for _, t in self._plan_items}
+        slots, mods = [], []
+        for m in self.modules():
+            for table in (m._parameters, m._buffers):
+                for k, t in table.items():
+                    if t is not None and id(t) in want:
+                        slots.append((table, k, t))
+            for k, child in m._modules.items():
+                if child is not None:
+                    mods.append((m._modules, k, child))
+        self._plan_slots, self._plan_mods = slots, mods
+
+    def _plan_items_valid(self):
+        for table, k, t in self._plan_slots:
+            if table.get(k) is not t:
+                return False
+        for table, k, m in self._plan_mods:
+            if table.get(k) is not m:
+                return False
+        return True
 
     def _apply(self, fn, *a, **k):
         self._plan_items = None
