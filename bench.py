@@ -472,6 +472,27 @@ def small_batch_leg(args):
             x = step(t, x)
         torch.cuda.synchronize(dev)
         out[f"batch{b}_ms_per_step"] = (time.perf_counter() - t0) / len(ts[5:]) * 1e3
+    # the reference's calls END TO END (VERDICT r04 missing item 3): everything a caller waits for -- x_T, 750 forwards and
+    # scheduler steps, each step's noise (device RNG with no generator; the seeded CPU generator's draws + PCIe for evaluate),
+    # the per-step host work, post-processing, the D2H copy and numpy_to_pil -- next to 750 x the per-step time above
+    pipe = d.DDPMPipeline(unet=net, scheduler=d.DDPMScheduler())
+    pipe(batch_size=1, num_inference_steps=20)     # (warm: plan, workspaces, pinned buffers)
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    images = pipe(batch_size=5, num_inference_steps=750).images                       # generation.py:14-20
+    t_gen = time.perf_counter() - t0
+    assert len(images) == 5
+    t0 = time.perf_counter()
+    arr = pipe(num_inference_steps=750, batch_size=1, generator=torch.manual_seed(14555), output_type="np.array",
+               return_dict=False)[0]                                                  # training_pipeline.py:26-32
+    t_eval = time.perf_counter() - t0
+    assert arr.shape == (1, 256, 256, 3)
+    out["whole_call"] = {
+        "generation_py_batch5_750_steps_s": t_gen, "generation_py_ms_per_step": t_gen / 750 * 1e3,
+        "generation_py_over_750_x_step": t_gen * 1e3 / (750 * out["batch5_ms_per_step"]),
+        "evaluate_batch1_750_steps_cpu_generator_s": t_eval, "evaluate_ms_per_step": t_eval / 750 * 1e3,
+        "evaluate_over_750_x_step": t_eval * 1e3 / (750 * out["batch1_ms_per_step"]),
+        "note": "wall time of DDPMPipeline.__call__ as the reference calls it, PIL / numpy output included"}
     out["config"] = {"workload": "DriveSceneGen default U-Net (train.py:39-57, 3 channels), 750-step DDPM, batch 1 "
                                  "(evaluate) and batch 5 (generation.py), fp32-equivalent"}
     return out
@@ -551,6 +572,8 @@ def summary_of(out):
         if "error" in r:
             return {"error": r["error"][:200]}
         d = {k: r[k] for k in ("value", "unit", "ms_per_step", "batch1_ms_per_step", "batch5_ms_per_step", "peak_mem_gib") if k in r}
+        if isinstance(r.get("whole_call"), dict):
+            d.update({k: round(v, 4) for k, v in r["whole_call"].items() if k.endswith("_ms_per_step") or k.endswith("_x_step")})
         if isinstance(r.get("config"), dict) and "batch" in r["config"]:
             d["batch"] = r["config"]["batch"]
         rf = r.get("roofline")

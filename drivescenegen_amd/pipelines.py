@@ -123,6 +123,73 @@ class _PipelineBase:
         return ImagePipelineOutput(images=arr)
 
 
+class _NoiseStream:
+    """The per-step noise of ``DDPMPipeline.__call__`` in the reference's order of draws (App. A.4: x_T, then one full-batch
+    tensor per step with t > 0, all from ONE generator).  A CPU generator (training_pipeline.py:29 passes
+    ``torch.manual_seed(seed)``) samples on the host: the draw goes into a pinned ring buffer and crosses PCIe on a side stream
+    while the GPU runs the step's U-Net forward, which was enqueued just before -- same generator, same shapes, same order, so
+    the same values as ``randn_tensor(...).to(device)`` bit for bit, without a pageable copy on the critical path.  With no
+    generator, or a device generator, the draw is torch's device RNG kernel on the current stream, as in the reference."""
+
+    def __init__(self, shape, generator, device, rows=None):
+        self.shape, self.gen, self.dev, self.rows = tuple(shape), generator, torch.device(device), rows
+        self.host = generator is not None and generator.device.type == "cpu"
+        self.k = 0
+        if self.host:
+            mine = self.shape if rows is None else (len(range(*rows.indices(self.shape[0]))),) + self.shape[1:]
+            self.pinned = [torch.empty(self.shape, dtype=torch.float32).pin_memory() for _ in range(2)]
+            self.onchip = [torch.empty(mine, dtype=torch.float32, device=self.dev) for _ in range(2)]
+            self.copied = [None, None]    # side stream: the copy out of pinned[i] has finished
+            self.mark = [None, None]      # main stream: everything enqueued before the PREVIOUS draw (the reader of onchip[i] included)
+            self.side = torch.cuda.Stream(self.dev)
+            self.side.wait_stream(torch.cuda.current_stream(self.dev))   # (the fresh buffers' memory may have pending readers)
+
+    def draw(self):
+        """The next tensor of the stream, on the device (this shard's rows of it).  Host-generator draws return one of two
+        resident buffers: a result must be consumed (by work enqueued on the current stream) before the draw after next."""
+        rows = self.rows
+        k, self.k = self.k, self.k + 1
+        if not self.host:
+            z = torch.randn(self.shape, generator=self.gen, device=self.dev, dtype=torch.float32)
+            return z if rows is None else z[rows].contiguous()
+        if k == 0:   # x_T lives through the whole first step: a tensor of its own, the reference's plain path
+            z = torch.randn(self.shape, generator=self.gen, dtype=torch.float32)
+            return (z if rows is None else z[rows]).to(self.dev)
+        i = k & 1
+        main = torch.cuda.current_stream(self.dev)
+        here = torch.cuda.Event()
+        here.record(main)                     # covers the reader of the OTHER buffer (enqueued after the previous draw)
+        if self.copied[i] is not None:
+            self.copied[i].synchronize()      # host: the copy that last read pinned[i]
+        torch.randn(self.shape, generator=self.gen, out=self.pinned[i])
+        src = self.pinned[i] if rows is None else self.pinned[i][rows]
+        with torch.cuda.stream(self.side):
+            if self.mark[i] is not None:
+                self.side.wait_event(self.mark[i])   # device: the kernel that last read onchip[i] (two draws ago) is done
+            self.onchip[i].copy_(src, non_blocking=True)
+            self.copied[i] = torch.cuda.Event()
+            self.copied[i].record(self.side)
+        self.mark[i ^ 1] = here
+        main.wait_event(self.copied[i])       # consumers on the caller's stream see the data
+        return self.onchip[i]
+
+
+def _rows_of(shard, batch):
+    if shard is None:
+        return None
+    rank, world = shard
+    if batch % world != 0:
+        raise ValueError(f"batch {batch} not divisible by world size {world}")
+    per = batch // world
+    return slice(rank * per, (rank + 1) * per)
+
+
+def _device_timestep_rows(timesteps, batch, device):
+    """[steps, batch] int64 on the device, uploaded ONCE per call: row i is the timestep tensor of step i (the loop then
+    hands the U-Net a device view instead of a host scalar -- no H2D copy and no expand kernel per step)."""
+    return timesteps.to(device=device, dtype=torch.long)[:, None].expand(-1, batch).contiguous()
+
+
 class DDPMPipeline(_PipelineBase):
     _class_name = "DDPMPipeline"
     _scheduler_cls = DDPMScheduler
@@ -132,17 +199,22 @@ class DDPMPipeline(_PipelineBase):
                  return_dict: bool = True, shard=None):
         if self.device.type != "cuda":
             raise RuntimeError("DDPMPipeline runs on the MI355X HIP engine only: call .to('cuda') first")
-        image = self._initial_noise(batch_size, generator, shard)
-        self.scheduler.set_timesteps(num_inference_steps)
-        for t in self.scheduler.timesteps:
-            eps = self.unet(image, t).sample
-            noise = None
-            if int(t) > 0:
-                # reference semantics: one generator stream for the whole batch (App. A.4); a shard
-                # draws the full-batch noise and keeps its rows so that N-GPU output == 1-GPU output
-                full = (batch_size,) + tuple(image.shape[1:])
-                noise = self._shard(_randn_like_reference(full, generator, self.device, torch.float32), shard)
-            image = self.scheduler.step(eps, t, image, variance_noise=noise).prev_sample
+        c = self.unet.config
+        ss = c.sample_size
+        full = (batch_size, c.in_channels, ss, ss) if isinstance(ss, int) else (batch_size, c.in_channels, *ss)
+        rows = _rows_of(shard, batch_size)
+        with torch.cuda.device(self.device):
+            # reference semantics: one generator stream for the whole batch (App. A.4); a shard draws the full-batch
+            # tensors and keeps its rows so that N-GPU output == 1-GPU output
+            stream = _NoiseStream(full, generator, self.device, rows)
+            image = stream.draw()
+            self.scheduler.set_timesteps(num_inference_steps)
+            ts = [int(t) for t in self.scheduler.timesteps]
+            tdev = _device_timestep_rows(self.scheduler.timesteps, image.shape[0], self.device)
+            for i, t in enumerate(ts):
+                eps = self.unet(image, tdev[i]).sample
+                noise = stream.draw() if t > 0 else None     # (host draw + PCIe overlap the forward enqueued above)
+                image = self.scheduler.step(eps, t, image, variance_noise=noise).prev_sample
         return self._finish(image, output_type, return_dict)
 
 
@@ -157,7 +229,9 @@ class DDIMPipeline(_PipelineBase):
             raise RuntimeError("DDIMPipeline runs on the MI355X HIP engine only: call .to('cuda') first")
         image = self._initial_noise(batch_size, generator, shard)
         self.scheduler.set_timesteps(num_inference_steps)
-        for t in self.scheduler.timesteps:
-            eps = self.unet(image, t).sample
+        ts = [int(t) for t in self.scheduler.timesteps]
+        tdev = _device_timestep_rows(self.scheduler.timesteps, image.shape[0], self.device)
+        for i, t in enumerate(ts):
+            eps = self.unet(image, tdev[i]).sample
             image = self.scheduler.step(eps, t, image, eta=eta, generator=generator).prev_sample
         return self._finish(image, output_type, return_dict)

@@ -181,10 +181,17 @@ class GradBuckets:
     """All-reduce(mean) of a flat gradient slab in ~bucket_mb buckets.  ``ready(name)`` is called by the
     backward pass when a parameter's gradient is final; a bucket is launched asynchronously on the
     communication stream the moment its last gradient lands (buckets fill back-to-front, so communication
-    overlaps the rest of backward).  ``finish()`` waits for the outstanding work."""
+    overlaps the rest of backward).  ``finish()`` waits for the outstanding work.
 
-    def __init__(self, flat, offsets: dict, group=None, bucket_mb: float = 25.0):
+    ``overlap=False`` (environment: DSG_DDP_OVERLAP=0) is the A/B switch for a first multi-GPU run: the same buckets, in
+    the same order, are launched from ``finish()`` -- after the backward walk -- so nothing of RCCL runs beside the
+    backward kernels.  The reduced values cannot depend on WHEN a bucket is launched; if the two modes ever differ on real
+    xGMI links, the overlap (RCCL's reduction kernels beside the 16-deep-MFMA backward kernels) is what to look at
+    (tools/ddp_smoke.py --selfcheck compares them bitwise)."""
+
+    def __init__(self, flat, offsets: dict, group=None, bucket_mb: float = 25.0, overlap=None):
         self.flat, self.group = flat, group
+        self.overlap = (os.environ.get("DSG_DDP_OVERLAP", "1") != "0") if overlap is None else bool(overlap)
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         # a one-rank RCCL communicator still runs every call below (DSG_FORCE_COLLECTIVES=1: the one-GPU hardware test)
         self.active = self.world > 1 or (dist.is_initialized() and _force_collectives())
@@ -208,6 +215,7 @@ class GradBuckets:
                 self.of[nm] = i
         backend = dist.get_backend(group) if dist.is_initialized() else "none"
         self.avg_native = backend == "nccl"  # RCCL has ReduceOp.AVG; gloo does not
+        self.last_launch_order = []
         self.reset()
 
     def reset(self):
@@ -215,6 +223,7 @@ class GradBuckets:
         self.seen = set()
         self.works = []
         self.launch_order = []
+        self.deferred = []    # overlap off: buckets complete during the walk, launched by finish() in completion order
         self._in_finish = False
 
     # DSG_DDP_TRACE=1 (tests / tools): keep, per step, which buckets were launched from inside the backward walk and a
@@ -229,7 +238,10 @@ class GradBuckets:
         i = self.of[name]
         self.pending[i] -= 1
         if self.pending[i] == 0:
-            self._launch(i)
+            if self.overlap:
+                self._launch(i)
+            else:
+                self.deferred.append(i)
 
     def _launch(self, i):
         b = self.buckets[i]
@@ -253,6 +265,9 @@ class GradBuckets:
         if self.trace_enabled and self.flat.is_cuda:
             end_ev = torch.cuda.Event(enable_timing=True)
             end_ev.record()   # the end of the backward walk on its stream
+        for i in self.deferred:                  # overlap off: the walk's completion order, launched now
+            self._launch(i)
+        self.deferred = []
         for i, left in enumerate(self.pending):  # parameters that got no gradient this step
             if left > 0:
                 self.pending[i] = 0
@@ -273,6 +288,7 @@ class GradBuckets:
                 ms_before_walk_end=[(ev.elapsed_time(end_ev) if ev is not None and end_ev is not None else None)
                                     for _, _, ev in tr])
             self._trace = []
+        self.last_launch_order = list(self.launch_order)   # (kept across reset(): what the step just finished did)
         self.reset()
 
 
@@ -495,6 +511,7 @@ class Accelerator:
         self.sync_gradients = True
         self._accum = 0
         self._buckets = None
+        self.ddp_overlap = None   # None: DSG_DDP_OVERLAP (default on); True / False: this Accelerator's choice (A/B switch)
         self._model = None
         self._log_file = None
         self.trackers = []
@@ -581,9 +598,11 @@ class Accelerator:
             return None
         st = get_train_state(self._model)
         if self._buckets is None or self._buckets.flat.data_ptr() != st.grad_flat.data_ptr():
-            self._buckets = GradBuckets(st.grad_flat, st.offsets)
+            self._buckets = GradBuckets(st.grad_flat, st.offsets, overlap=self.ddp_overlap)
             st.grad_ready_hooks[:] = [self._on_ready]
             st.post_backward[:] = [self._finish_buckets]  # (runs when the backward walk is done, before its loss scale is removed)
+        elif self.ddp_overlap is not None:
+            self._buckets.overlap = bool(self.ddp_overlap)
         return self._buckets
 
     def _finish_buckets(self):

@@ -39,6 +39,17 @@ def _worker(rank, world, port, q):
         for nm, (o, n) in offsets.items():
             assert torch.allclose(flat[o:o + n], torch.full((n,), 1.5 * (1 + int(nm[1:])))), nm
         assert order == sorted(order, reverse=True), order  # last bucket first: overlap with backward
+        # overlap off (DSG_DDP_OVERLAP=0): nothing leaves before finish(); same buckets, same order, same averages
+        for nm, (o, n) in offsets.items():
+            flat[o:o + n] = (rank + 1) * (1 + int(nm[1:]))
+        b2 = GradBuckets(flat, offsets, bucket_mb=0.01, overlap=False)
+        for nm in reversed(list(offsets)):
+            b2.ready(nm)
+        assert b2.launch_order == [] and b2.deferred == order
+        b2.finish()
+        assert b2.last_launch_order == order
+        for nm, (o, n) in offsets.items():
+            assert torch.allclose(flat[o:o + n], torch.full((n,), 1.5 * (1 + int(nm[1:])))), nm
         # a step where one parameter gets no gradient still completes
         flat.fill_(float(rank))
         for nm in list(offsets)[1:]:

@@ -138,6 +138,29 @@ def test_two_ranks_default_net_eight_buckets_overlap_the_backward_walk():
     assert _lines(two, "checksum") == _lines(plain.stdout, "checksum") * 2
 
 
+def test_overlapped_and_deferred_buckets_give_the_same_step_bitwise():
+    """DSG_DDP_OVERLAP / Accelerator.ddp_overlap: the same buckets all-reduced from inside the backward walk and after it.
+    tools/ddp_smoke.py's self-check runs step 0 both ways and compares loss and every updated parameter bit for bit -- on the
+    one-rank RCCL communicator (56.6 M parameters, 8 buckets, the stream hand-over between the walk and RCCL's stream) and at
+    world size 2 on the shared GPU (gloo), where the all-reduce changes the slab.  With DSG_DDP_OVERLAP=0 in the environment a
+    whole run launches nothing from inside the walk, and its steps are bitwise the default run's."""
+    args = [os.path.join("tools", "ddp_smoke.py"), "DEFAULT3", "2", "2", "--selfcheck"]
+    one = _launcher(args, force=True)
+    sc = _lines(one, "selfcheck")
+    assert len(sc) == 1 and sc[0].endswith("OK") and "loss_equal True params_equal True" in sc[0] and "buckets 8" in sc[0], sc
+    two = _launcher([os.path.join("tools", "ddp_smoke.py"), "CFG1", "4", "2"], force=False,
+                    extra_env={"DSG_DIST_BACKEND": "gloo", "DSG_SMOKE_SHARD": "1"}, nproc=2)   # (world > 1: unprompted)
+    sc = _lines(two, "selfcheck")
+    assert len(sc) == 2 and all(x.endswith("OK") and "params_equal True" in x for x in sc), sc
+    # the environment switch on a whole run: no bucket leaves from inside the walk, same bits
+    on = _launcher(args[:-1], force=True, extra_env={"DSG_DDP_TRACE": "1", "DSG_DDP_SELFCHECK": "0"})
+    off = _launcher(args[:-1], force=True, extra_env={"DSG_DDP_TRACE": "1", "DSG_DDP_OVERLAP": "0", "DSG_DDP_SELFCHECK": "0"})
+    tr_on, tr_off = (json.loads(_lines(o, "trace")[0][len("trace "):]) for o in (on, off))
+    assert sum(tr_on["in_walk"]) >= len(tr_on["order"]) - 1 and not any(tr_off["in_walk"]), (tr_on, tr_off)
+    assert tr_on["order"] == tr_off["order"]
+    assert _lines(on, "rank") == _lines(off, "rank") and _lines(on, "checksum") == _lines(off, "checksum")
+
+
 def test_bench_line_under_the_launcher_with_rccl_barrier_and_max():
     out = _launcher(["bench.py", "--gpus", "1", "--steps", "3", "--warmup", "1", "--no-cpu", "--no-extras"], force=True)
     rec = json.loads([ln for ln in out.splitlines() if ln.startswith("{")][-1])

@@ -110,6 +110,47 @@ def test_cfg1_pipeline_seeded_generator_matches_oracle(tiny):
     assert diff.max() <= 1 and (diff > 0).mean() <= 5e-3, (diff.max(), (diff > 0).mean())
 
 
+def test_pipeline_noise_stream_is_bitwise_the_reference_order_of_draws(tiny):
+    """DDPMPipeline draws a CPU generator's noise into pinned buffers one step ahead of its use and copies on a side stream
+    (pipelines._NoiseStream); the U-Net gets its timesteps from a device table uploaded once.  Same generator, same shapes,
+    same order as diffusers' loop (randn_tensor(...).to(device) per step, a host scalar timestep per step): the images must
+    be those of the plain loop, bit for bit -- also for a shard, also when the call is repeated on the same pipeline."""
+    from drivescenegen_amd.schedulers import _randn_like_reference
+    net, _ = tiny
+    sch = d.DDPMScheduler()
+    pipe = d.DDPMPipeline(unet=net, scheduler=sch)
+    n = 25
+
+    def plain(batch, rows=None):
+        gen = torch.manual_seed(4242)
+        x = _randn_like_reference((batch, 3, 64, 64), gen, DEV, torch.float32)
+        x = x if rows is None else x[rows].contiguous()
+        sch.set_timesteps(n)
+        for t in sch.timesteps:
+            eps = net(x, t).sample
+            z = None
+            if int(t) > 0:
+                z = _randn_like_reference((batch, 3, 64, 64), gen, DEV, torch.float32)
+                z = z if rows is None else z[rows].contiguous()
+            x = sch.step(eps, t, x, variance_noise=z).prev_sample
+        return (x / 2 + 0.5).clamp(0, 1).permute(0, 2, 3, 1).cpu().numpy()
+
+    want = plain(3)
+    for _ in range(2):
+        got = pipe(num_inference_steps=n, batch_size=3, generator=torch.manual_seed(4242), output_type="np.array",
+                   return_dict=False)[0]
+        assert np.array_equal(got, want)
+    part = pipe(num_inference_steps=n, batch_size=4, generator=torch.manual_seed(4242), output_type="np.array",
+                return_dict=False, shard=(1, 2))[0]
+    assert np.array_equal(part, plain(4, slice(2, 4)))
+    # no generator: torch's device RNG, as the reference (generation.py:14-20) -- reproducible under torch.cuda.manual_seed
+    torch.cuda.manual_seed(99)
+    a = pipe(num_inference_steps=5, batch_size=2, output_type="np.array").images
+    torch.cuda.manual_seed(99)
+    b = pipe(num_inference_steps=5, batch_size=2, output_type="np.array").images
+    assert np.array_equal(a, b) and np.isfinite(a).all()
+
+
 def test_cfg1_ddim_pipeline_matches_oracle(tiny):
     net, ora = tiny
     pipe = d.DDIMPipeline(unet=net, scheduler=d.DDIMScheduler())
