@@ -11,6 +11,9 @@ rel-L2 <= 1e-3 on the final image; uint8 <= 1 LSB on <= 0.1 % of pixels") and wh
   cfg4_ddim100    BASELINE configs[3]: 100-step DDIM of the 6-level 512x512x4 network, row 0 of the batch-8 x_T
   default3_ddpm750  the reference's own evaluate call (training_pipeline.py:26-32): 750-step ancestral DDPM, batch 1,
                   x_T and every step's noise from torch.manual_seed(14555) in the order DDPMPipeline draws them
+  cfg2_ddim50_c, cfg4_ddim100_c   the two DDIM runs on the CONTRACTIVE weight set (tests/common.py: trajectory_weights --
+                  conv2 / to_out.0 of every block scaled by 0.1): two fp32 runs stay together to the end, so the final image
+                  can be asked for to SURVEY 8c's letter
 
 Inputs and weights are the deterministic streams of drivescenegen_amd/synth.py (tests/common.py rebuilds them), so only
 outputs are stored.  Per case: `final` = x_0 at every `stride`-th pixel (fp32), `final_moments` = per-channel fp64 (mean,
@@ -39,7 +42,7 @@ sys.path.insert(0, ROOT)
 
 from oracle.scheduler_oracle import OracleDDIMScheduler, OracleDDPMScheduler  # noqa: E402
 from oracle.unet_oracle import OracleUNet2DModel  # noqa: E402
-from tests.common import TRAJECTORIES, synth_weights, trajectory_x_T  # noqa: E402
+from tests.common import TRAJECTORIES, trajectory_weights, trajectory_x_T  # noqa: E402
 
 PATH = os.path.join(ROOT, "tests", "golden", "trajectory_golden.npz")
 
@@ -57,7 +60,7 @@ EARLY = 5   # the first steps, stored one by one: the stretch where two fp32 run
 
 def run(key, perturb=0.0, early=False):
     cfg, kind, steps, stride, every = TRAJECTORIES[key][:5]
-    net = synth_weights(OracleUNet2DModel(**cfg)).eval()
+    net = trajectory_weights(OracleUNet2DModel(**cfg), key).eval()
     sch = OracleDDIMScheduler() if kind == "ddim" else OracleDDPMScheduler()
     sch.set_timesteps(steps)
     x, gen = trajectory_x_T(key)

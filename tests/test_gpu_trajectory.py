@@ -6,6 +6,10 @@
   cfg4_ddim100      BASELINE configs[3]: 100-step DDIM of the 6-level 512x512x4 attention network
   default3_ddpm750  the reference's evaluate call (training_pipeline.py:26-32; generation.py:14-20 runs the same loop at
                     batch 5): 750 ancestral DDPM steps, x_T and every step's noise from torch.manual_seed(14555)
+  cfg2_ddim50_c, cfg4_ddim100_c   the same two DDIM runs on the CONTRACTIVE synthetic weight set (tests/common.py:
+                    trajectory_weights -- every block's conv2 / to_out.0 at a tenth): the oracle's own run is stable there
+                    (a 1e-6 perturbation of x_T ends 2.9e-5 / 6.3e-5 away), so criterion (3) below applies and the END of both
+                    configurations' runs is held to SURVEY 8c's letter: rel-L2 <= 1e-3, uint8 <= 1 LSB on <= 0.1 % of pixels
 
 The engine runs every step on its own previous output (nothing is teacher-forced).  What can be asked of the END of such a run
 depends on the network: with the synthetic (untrained, random) weights these U-Nets are not contractive -- the ORACLE ITSELF,
@@ -30,7 +34,7 @@ import torch
 pytestmark = pytest.mark.gpu
 
 import drivescenegen_amd as d  # noqa: E402
-from tests.common import TRAJECTORIES, rel_l2, synth_weights, trajectory_golden, trajectory_x_T  # noqa: E402
+from tests.common import TRAJECTORIES, rel_l2, trajectory_golden, trajectory_weights, trajectory_x_T  # noqa: E402
 
 DEV = "cuda"
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -49,7 +53,7 @@ def _free_run(key):
     rel-L2 at each stored checkpoint)."""
     cfg, kind, steps, stride, every, _ = TRAJECTORIES[key]
     gold = trajectory_golden()
-    net = synth_weights(d.UNet2DModel(**cfg)).to(DEV).eval().requires_grad_(False)
+    net = trajectory_weights(d.UNet2DModel(**cfg), key).to(DEV).eval().requires_grad_(False)
     sch = d.DDIMScheduler() if kind == "ddim" else d.DDPMScheduler()
     sch.set_timesteps(steps)
     x_cpu, gen = trajectory_x_T(key)
@@ -106,6 +110,8 @@ def test_free_running_trajectory_tracks_the_oracle_as_far_as_the_oracle_tracks_i
     for i, e in enumerate(curve + [err]):
         assert e <= max(3 * float(self_div[i]), 1e-5), (key, i, e, float(self_div[i]))
     # (3) where the network lets two fp32 runs end together, the images agree to SURVEY 8c's letter
+    if key.endswith("_c") or key == "default3_ddpm750":
+        assert float(self_div[-1]) <= 1e-4, (key, float(self_div[-1]))   # (these runs exist to be judged by the letter)
     if float(self_div[-1]) <= 1e-4:
         assert err <= 1e-3 and worst <= 1 and frac <= 1e-3, (key, err, worst, frac)
     else:   # moments of the final image: the engine's run is a sample of the same process (5 % on each channel's mean square)

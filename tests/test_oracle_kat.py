@@ -184,7 +184,7 @@ def test_trajectory_golden_is_complete_and_self_consistent():
     import torch
     from oracle.scheduler_oracle import OracleDDIMScheduler
     from oracle.unet_oracle import OracleUNet2DModel
-    from tests.common import TRAJECTORIES, rel_l2, synth_weights, trajectory_golden, trajectory_x_T
+    from tests.common import TRAJECTORIES, rel_l2, synth_weights, trajectory_golden, trajectory_weights, trajectory_x_T
     gold = trajectory_golden()
     for key, (cfg, kind, steps, stride, every, _) in TRAJECTORIES.items():
         fin, u8, cps = gold[key + "/final"], gold[key + "/final_u8"], gold[key + "/checkpoints"]
@@ -206,3 +206,15 @@ def test_trajectory_golden_is_complete_and_self_consistent():
         for tt in sch.timesteps[:every]:
             x = sch.step(net(x, int(tt)).sample, int(tt), x).prev_sample
     assert rel_l2(x[:, :, ::8, ::8], torch.from_numpy(gold[key + "/checkpoints"][1])) <= 1e-5
+    # the contractive weight set: the same stretch, and the stored sensitivity says what the set is for
+    key = "cfg2_ddim50_c"
+    net = trajectory_weights(OracleUNet2DModel(**cfg), key).eval()
+    x, _ = trajectory_x_T(key)
+    with torch.no_grad():
+        for tt in sch.timesteps[:every]:
+            x = sch.step(net(x, int(tt)).sample, int(tt), x).prev_sample
+    assert rel_l2(x[:, :, ::8, ::8], torch.from_numpy(gold[key + "/checkpoints"][1])) <= 1e-5
+    for k in ("cfg2_ddim50_c", "cfg4_ddim100_c"):
+        assert float(gold[k + "/self_divergence"][-1]) <= 1e-4      # two fp32 runs end together ...
+        assert float(gold[k + "/final_moments"][1].min()) > 0.05     # ... on an image that is not degenerate
+    assert float(gold["cfg2_ddim50/self_divergence"][-1]) > 0.1     # (the plain synthetic set: chaotic)

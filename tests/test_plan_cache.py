@@ -59,6 +59,7 @@ def test_forward_runs_the_replaced_weights(mutate):
     x = noisy_inputs(CFG1, 2).to("cuda:0")
     before = net(x, 37).sample.clone()
     mutate(net)
+    net.requires_grad_(False)        # (a fresh nn.Parameter asks for gradients: stay on the inference plan)
     after = net(x, 37).sample
     fresh = d.UNet2DModel(**CFG1).to("cuda:0").eval().requires_grad_(False)
     fresh.load_state_dict({k: v.detach().clone() for k, v in net.state_dict().items()})
