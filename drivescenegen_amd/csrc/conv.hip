@@ -851,11 +851,18 @@ int conv2d_fwd_impl(const dsg_conv_args* a, hipStream_t st, int force_direct) {
 }  // namespace dsg
 
 namespace dsg { int conv_h2_tuning_epoch(); }
-DSG_API int32_t dsg_tuning_epoch(void) { return dsg::conv_h2_tuning_epoch(); }
+static int g_tuning_epoch = 0;   // every accepted dsg_set_tuning call (whatever file owns the switch)
+DSG_API int32_t dsg_tuning_epoch(void) { return dsg::conv_h2_tuning_epoch() + g_tuning_epoch; }
 
 // Tuning / A-B switches (key 1: K-chunk of the fp32 3x3 kernel, 0 = auto | 4 | 8; key 2: fp16x2-split 3x3 kernel
 // on/off).  Not part of the reference surface.
+static int set_tuning_impl(int32_t key, int32_t value);
 DSG_API int dsg_set_tuning(int32_t key, int32_t value) {
+  const int rc = set_tuning_impl(key, value);
+  if (rc == DSG_OK) ++g_tuning_epoch;   // host-side caches keyed on dsg_tuning_epoch see EVERY accepted key
+  return rc;
+}
+static int set_tuning_impl(int32_t key, int32_t value) {
   {  // a test / measurement hook: production processes keep the library's global state immutable
     const char* t = getenv("DSG_TESTING");
     if (t == nullptr || t[0] != '1')

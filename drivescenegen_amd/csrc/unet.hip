@@ -684,6 +684,8 @@ DSG_API int dsg_unet_create(const dsg_unet_config* cfg, dsg_unet_t** out) {
     h->freqs = h->dalloc(half);
     if (h->freqs) DSG_HIP(hipMemcpy(h->freqs, f.data(), half * sizeof(float), hipMemcpyHostToDevice));
   }
+  // (allocated here, not at the first dsg_unet_set_param: that call is documented as legal under stream capture)
+  h->wmax_dev = h->dalloc((int64_t)h->params.size());
   for (void* p : h->allocs)
     if (p == nullptr) return fail(DSG_ERR_HIP, "dsg_unet_create: hipMalloc failed");
   for (auto& p : h->params)
@@ -726,8 +728,7 @@ DSG_API int dsg_unet_set_param(dsg_unet_t* h, const char* name, const float* dat
     if (p.conv && dt == DSG_F32 && (p.wh || p.whf || p.whs)) {
       // range guard: max|w| decides whether the fp16 pairs of the split can carry this tensor.  The maximum is left in
       // the plan's device table; dsg_unet_commit_params (or the next forward) reads the whole table back at once
-      if (!h->wmax_dev) h->wmax_dev = h->dalloc((int64_t)h->params.size());
-      DSG_CHECK_ARG(h->wmax_dev != nullptr, "dsg_unet_set_param: hipMalloc failed");
+      DSG_CHECK_ARG(h->wmax_dev != nullptr, "dsg_unet_set_param: the plan has no range-guard table");
       if (!h->pending.empty() && h->pending_stream != st) {  // (maxima queued on another stream: settle them there first)
         rc = h->commit_ranges();
         if (rc != DSG_OK) return fail(rc, "dsg_unet_set_param: reading the weight maxima back failed");

@@ -47,16 +47,21 @@ class Image_Dataset(torch_data.Dataset):
         return (resize_bilinear(sample, self.size) - 0.5) / 0.5
 
     def __getitem__(self, index):
-        file = self.data_list[index]
-        ext = os.path.splitext(file)[1].lower()
-        with open(file, "rb") as f:
-            if ext == ".pkl":
-                data_dict = torch.load(f, weights_only=False)
+        # a .pkl that does not hold a dict is skipped for the next file, as the reference does (utils/datasets/dataset.py:37-39)
+        # -- bounded by one round of the list; pickles are read with the restricted unpickler unless the config says
+        # trust_pickles=True (imageops.load_sample_pickle: the same policy as GpuImageLoader)
+        from .imageops import load_sample_pickle
+        n = len(self.data_list)
+        for k in range(n):
+            file = self.data_list[(index + k) % n]
+            if os.path.splitext(file)[1].lower() == ".pkl":
+                data_dict = load_sample_pickle(file, bool(getattr(self.config, "trust_pickles", False)))
                 if not isinstance(data_dict, dict):
-                    return self.__getitem__(index + 1)
+                    continue
                 sample = data_dict["fig_tensor"][:, :, :].permute(2, 0, 1).float()
             else:
                 from PIL import Image
-                sample = to_tensor(Image.open(f))
-            sample = self.normalize(sample)
-        return sample
+                with open(file, "rb") as f:
+                    sample = to_tensor(Image.open(f))
+            return self.normalize(sample)
+        raise IndexError(f"Image_Dataset: no usable sample among {n} files (every .pkl holds a non-dict object)")

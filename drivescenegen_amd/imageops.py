@@ -38,6 +38,23 @@ def resize_normalize(images: torch.Tensor, size, mean=0.5, std=0.5) -> torch.Ten
     return out
 
 
+def load_sample_pickle(path, trust_pickles=False):
+    """A ``.pkl`` sample of the reference's dataset (utils/datasets/dataset.py:31-41): ``{"fig_tensor": tensor}``.  Read with
+    ``torch.load(weights_only=True)`` -- such a dict needs nothing more, and a data directory is not a place to run code from.
+    A file that holds anything the restricted unpickler refuses is "not a usable dict" (returns None): the reference skips a
+    non-dict pickle for the next file (dataset.py:37-39) and so do the callers.  ``trust_pickles=True`` falls back to full
+    unpickling -- which executes code from the file -- for pickles that need it."""
+    import pickle
+    with open(path, "rb") as fh:
+        try:
+            return torch.load(fh, weights_only=True)
+        except (pickle.UnpicklingError, RuntimeError, AttributeError, ImportError, EOFError, ValueError):
+            if not trust_pickles:
+                return None
+            fh.seek(0)
+            return torch.load(fh, weights_only=False)
+
+
 class GpuImageLoader:
     """Iterates batches of normalised fp32 [B, C, H, W] GPU tensors from the files ``Image_Dataset`` reads
     (utils/datasets/dataset.py:15-50): PNG / any PIL image, or ``.pkl`` with a ``fig_tensor`` [H, W, C] float entry
@@ -86,14 +103,7 @@ class GpuImageLoader:
                 from PIL import Image
                 a = np.asarray(Image.open(f))
                 return a[:, :, None] if a.ndim == 2 else a
-            with open(f, "rb") as fh:
-                try:  # a {"fig_tensor": tensor} dict needs no arbitrary unpickling
-                    dd = torch.load(fh, weights_only=True)
-                except Exception:
-                    if not self.trust_pickles:
-                        raise
-                    fh.seek(0)
-                    dd = torch.load(fh, weights_only=False)
+            dd = load_sample_pickle(f, self.trust_pickles)
             if isinstance(dd, dict):
                 return np.ascontiguousarray(dd["fig_tensor"][:, :, :].float().numpy())
         raise IndexError(f"GpuImageLoader: no usable sample among {len(self.files)} files (every .pkl holds a non-dict object)")

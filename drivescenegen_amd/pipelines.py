@@ -126,15 +126,19 @@ class _PipelineBase:
 class _NoiseStream:
     """The per-step noise of ``DDPMPipeline.__call__`` in the reference's order of draws (App. A.4: x_T, then one full-batch
     tensor per step with t > 0, all from ONE generator).  A CPU generator (training_pipeline.py:29 passes
-    ``torch.manual_seed(seed)``) samples on the host: the draw goes into a pinned ring buffer and crosses PCIe on a side stream
-    while the GPU runs the step's U-Net forward, which was enqueued just before -- same generator, same shapes, same order, so
-    the same values as ``randn_tensor(...).to(device)`` bit for bit, without a pageable copy on the critical path.  With no
-    generator, or a device generator, the draw is torch's device RNG kernel on the current stream, as in the reference."""
+    ``torch.manual_seed(seed)``) samples on the host: tensor k+1 is drawn by a worker thread into a pinned buffer while the
+    caller enqueues step k's kernels, and crosses PCIe on a side stream while the GPU runs the step's U-Net forward -- same
+    generator, same shapes, same order, so the same values as ``randn_tensor(...).to(device)`` bit for bit, with neither the
+    draw nor a pageable copy on the critical path.  `count` = the draws the call will make: the worker never draws past it,
+    and ``close()`` (always called) joins it and, should the loop have ended early, puts the generator back where the serial
+    loop would have left it.  With no generator, or a device generator, a draw is torch's device RNG kernel on the current
+    stream, as in the reference."""
 
-    def __init__(self, shape, generator, device, rows=None):
-        self.shape, self.gen, self.dev, self.rows = tuple(shape), generator, torch.device(device), rows
+    def __init__(self, shape, generator, device, rows=None, count=1):
+        self.shape, self.gen, self.dev, self.rows, self.count = tuple(shape), generator, torch.device(device), rows, int(count)
         self.host = generator is not None and generator.device.type == "cpu"
         self.k = 0
+        self._pending = None          # (thread, index, generator state before the draw, [exception])
         if self.host:
             mine = self.shape if rows is None else (len(range(*rows.indices(self.shape[0]))),) + self.shape[1:]
             self.pinned = [torch.empty(self.shape, dtype=torch.float32).pin_memory() for _ in range(2)]
@@ -143,6 +147,31 @@ class _NoiseStream:
             self.mark = [None, None]      # main stream: everything enqueued before the PREVIOUS draw (the reader of onchip[i] included)
             self.side = torch.cuda.Stream(self.dev)
             self.side.wait_stream(torch.cuda.current_stream(self.dev))   # (the fresh buffers' memory may have pending readers)
+
+    def _start(self, k):
+        """hand tensor k's draw to a worker thread (one in flight at most; nobody else touches the generator meanwhile)"""
+        import threading
+        i = k & 1
+        if self.copied[i] is not None:
+            self.copied[i].synchronize()      # the copy that last read pinned[i] (two draws ago)
+        box = []
+
+        def work():
+            try:
+                torch.randn(self.shape, generator=self.gen, out=self.pinned[i])
+            except BaseException as e:   # surfaced by draw()
+                box.append(e)
+        snap = self.gen.get_state()
+        th = threading.Thread(target=work, daemon=True)
+        th.start()
+        self._pending = (th, k, snap, box)
+
+    def close(self):
+        if self._pending is not None:     # a tensor was drawn ahead and never asked for: undo the draw
+            th, _, snap, _ = self._pending
+            th.join()
+            self.gen.set_state(snap)
+            self._pending = None
 
     def draw(self):
         """The next tensor of the stream, on the device (this shard's rows of it).  Host-generator draws return one of two
@@ -154,14 +183,22 @@ class _NoiseStream:
             return z if rows is None else z[rows].contiguous()
         if k == 0:   # x_T lives through the whole first step: a tensor of its own, the reference's plain path
             z = torch.randn(self.shape, generator=self.gen, dtype=torch.float32)
-            return (z if rows is None else z[rows]).to(self.dev)
+            out = (z if rows is None else z[rows]).to(self.dev)
+            if self.count > 1:
+                self._start(1)
+            return out
         i = k & 1
+        if self._pending is None:             # (more draws than announced: drawn here, in order)
+            self._start(k)
+        th, kk, _, box = self._pending
+        th.join()
+        self._pending = None
+        if box:
+            raise box[0]
+        assert kk == k
         main = torch.cuda.current_stream(self.dev)
         here = torch.cuda.Event()
         here.record(main)                     # covers the reader of the OTHER buffer (enqueued after the previous draw)
-        if self.copied[i] is not None:
-            self.copied[i].synchronize()      # host: the copy that last read pinned[i]
-        torch.randn(self.shape, generator=self.gen, out=self.pinned[i])
         src = self.pinned[i] if rows is None else self.pinned[i][rows]
         with torch.cuda.stream(self.side):
             if self.mark[i] is not None:
@@ -171,6 +208,8 @@ class _NoiseStream:
             self.copied[i].record(self.side)
         self.mark[i ^ 1] = here
         main.wait_event(self.copied[i])       # consumers on the caller's stream see the data
+        if k + 1 < self.count:
+            self._start(k + 1)                # drawn while the caller enqueues the rest of this step and the next forward
         return self.onchip[i]
 
 
@@ -206,15 +245,18 @@ class DDPMPipeline(_PipelineBase):
         with torch.cuda.device(self.device):
             # reference semantics: one generator stream for the whole batch (App. A.4); a shard draws the full-batch
             # tensors and keeps its rows so that N-GPU output == 1-GPU output
-            stream = _NoiseStream(full, generator, self.device, rows)
-            image = stream.draw()
             self.scheduler.set_timesteps(num_inference_steps)
             ts = [int(t) for t in self.scheduler.timesteps]
-            tdev = _device_timestep_rows(self.scheduler.timesteps, image.shape[0], self.device)
-            for i, t in enumerate(ts):
-                eps = self.unet(image, tdev[i]).sample
-                noise = stream.draw() if t > 0 else None     # (host draw + PCIe overlap the forward enqueued above)
-                image = self.scheduler.step(eps, t, image, variance_noise=noise).prev_sample
+            stream = _NoiseStream(full, generator, self.device, rows, count=1 + sum(1 for t in ts if t > 0))
+            try:
+                image = stream.draw()
+                tdev = _device_timestep_rows(self.scheduler.timesteps, image.shape[0], self.device)
+                for i, t in enumerate(ts):
+                    eps = self.unet(image, tdev[i]).sample
+                    noise = stream.draw() if t > 0 else None     # (drawn while the previous step was enqueued; PCIe under the forward)
+                    image = self.scheduler.step(eps, t, image, variance_noise=noise).prev_sample
+            finally:
+                stream.close()
         return self._finish(image, output_type, return_dict)
 
 

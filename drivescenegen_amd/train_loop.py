@@ -66,12 +66,14 @@ class NoiseAhead:
         self._thread = None
         self._shape = None
         self._out = None
+        self._snap = None
 
     def schedule(self, shape):
         if not self.enabled or self._thread is not None:
             return
         import threading
         self._shape = tuple(shape)
+        self._snap = torch.get_rng_state()    # the global CPU generator before the draw (cancel() goes back to it)
 
         def draw():
             try:
@@ -80,6 +82,14 @@ class NoiseAhead:
                 self._out = e
         self._thread = threading.Thread(target=draw, daemon=True)
         self._thread.start()
+
+    def cancel(self):
+        """The consumer stops before using the scheduled draw (an exception or `break` in its loop, a max-steps cut): join the
+        worker and put the global CPU generator back where the serial loop would be -- the draw never happened."""
+        if self._thread is not None:
+            self._thread.join()
+            self._thread, self._out = None, None
+            torch.set_rng_state(self._snap)
 
     def take(self, shape, device):
         """The noise of the current step on `device`: the scheduled draw when its shape matches, else a draw made now."""
@@ -91,7 +101,8 @@ class NoiseAhead:
                 raise out
             if self._shape == shape:
                 return out.to(device, non_blocking=True)
-            # (cannot happen in `fit`: it schedules the very batch it takes next; keep the generator's order anyway)
+            # (cannot happen in `fit`: it schedules the very batch it takes next): undo the draw, then say so
+            torch.set_rng_state(self._snap)
             raise RuntimeError(f"NoiseAhead: scheduled {self._shape}, asked for {shape}")
         return torch.randn(shape).to(device)
 
@@ -121,13 +132,16 @@ def batches_with_noise(batches, overlap_noise: bool = True):
     ahead = NoiseAhead(overlap_noise)
     it = iter(batches)
     batch = next(it, None)
-    while batch is not None:
-        noise = ahead.take(batch.shape, batch.device)
-        nxt = next(it, None)
-        if nxt is not None:
-            ahead.schedule(nxt.shape)
-        yield batch, noise
-        batch = nxt
+    try:
+        while batch is not None:
+            noise = ahead.take(batch.shape, batch.device)
+            nxt = next(it, None)
+            if nxt is not None:
+                ahead.schedule(nxt.shape)
+            yield batch, noise
+            batch = nxt
+    finally:   # a consumer that stops early (exception, break, max-steps cut) leaves the generator as the serial loop would
+        ahead.cancel()
 
 
 def train_steps(accelerator, model, noise_scheduler, optimizer, lr_scheduler, batches, overlap_noise: bool = True):

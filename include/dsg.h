@@ -613,8 +613,9 @@ int dsg_prof_dump(const char* csv_path);
  *  15  stride-2 convs of channel-blocked tensors on the split path: [1] | 0 = the f32 MFMA kernel
  *  14  attention with head_dim 8 on the matrix cores (fp16x2 split): [1] | 0 = the VALU kernel */
 int dsg_set_tuning(int32_t key, int32_t value);
-/* A counter that advances with every accepted dsg_set_tuning call (0 in a production process): host-side caches of
- * kernel-selection answers (dsg_conv2d_fuses_shortcut, dsg_conv2d_takes_operand, dsg_unet_workspace_bytes) key on it. */
+/* A counter that advances with every accepted dsg_set_tuning call, whichever kernel family the key belongs to (0 in a
+ * production process): host-side caches of kernel-selection answers (dsg_conv2d_fuses_shortcut, dsg_conv2d_takes_operand,
+ * dsg_unet_workspace_bytes) key on it. */
 int32_t dsg_tuning_epoch(void);
 
 #ifdef __cplusplus

@@ -296,3 +296,61 @@ def test_noise_drawn_ahead_is_the_serial_loops_noise():
         assert len(got) == len(ref) == 8
         for (b0, n0), (b1, n1) in zip(ref, got):
             assert torch.equal(b0, b1) and torch.equal(n0, n1) and n1.shape == b1.shape
+
+
+def test_noise_drawn_ahead_is_undone_when_the_consumer_stops_early():
+    """`batches_with_noise` has step k+1's draw in flight when it yields step k.  A consumer that stops there
+    (an exception or `break` in its loop, a max-steps cut) must leave the global CPU generator where the SERIAL loop would
+    have left it -- the epoch-end DDPM sample and the next epoch's sampler seed draw from it next."""
+    from drivescenegen_amd.train_loop import batches_with_noise
+    batches = [torch.zeros(2, 3, 8, 8) for _ in range(5)]
+
+    def run(overlap, stop, how):
+        torch.manual_seed(123)
+        seen = []
+        try:
+            for i, (_b, n) in enumerate(batches_with_noise(batches, overlap)):
+                seen.append(n.clone())
+                if i == stop:
+                    if how == "raise":
+                        raise KeyError("consumer failed")
+                    break
+        except KeyError:
+            pass
+        return seen, torch.randn(4)          # the generator's next consumer
+
+    for how in ("break", "raise"):
+        for stop in (0, 2, 4):
+            s_seen, s_next = run(False, stop, how)
+            o_seen, o_next = run(True, stop, how)
+            assert len(o_seen) == stop + 1 and all(torch.equal(a, b) for a, b in zip(s_seen, o_seen))
+            assert torch.equal(s_next, o_next), (how, stop)
+
+
+def test_untrusted_pickles_that_need_full_unpickling_are_skipped_like_non_dicts(tmp_path):
+    """with the restricted unpickler a .pkl holding a non-allowlisted object raises instead of returning a
+    non-dict -- the reference skips such a file for the next one (utils/datasets/dataset.py:37-39).  Both loaders treat the
+    refusal as 'not a usable dict' (bounded by one round of the list), and `Image_Dataset` no longer unpickles arbitrary
+    objects from the data directory unless the config says trust_pickles=True."""
+    import pickle
+    from types import SimpleNamespace
+    from drivescenegen_amd.dataset import Image_Dataset
+    from drivescenegen_amd.imageops import GpuImageLoader
+
+    with open(tmp_path / "0.pkl", "wb") as f:     # an object that is not on torch's weights_only allowlist
+        pickle.dump(SimpleNamespace(fig_tensor=[[1.0]]), f)
+    torch.save([1, 2, 3], tmp_path / "1.pkl")                                    # a non-dict the restricted unpickler accepts
+    torch.save({"fig_tensor": torch.full((4, 4, 3), 0.25)}, tmp_path / "2.pkl")
+    files = str(tmp_path / "*.pkl")
+    ld = GpuImageLoader(files, (8, 8), batch_size=1, device="cpu")
+    ld.files = sorted(ld.files)
+    assert float(ld._load_one(0).mean()) == 0.25                                 # files 0 and 1 skipped, file 2 used
+    cfg = SimpleNamespace(dataset_name=files, patterns_size_height=8, patterns_size_width=8)
+    ds = Image_Dataset(cfg)
+    ds.data_list = sorted(ds.data_list)
+    x = ds[0]
+    assert x.shape == (3, 8, 8) and torch.allclose(x, torch.full((3, 8, 8), -0.5))   # (0.25 - 0.5) / 0.5
+    os.remove(tmp_path / "2.pkl")
+    ds = Image_Dataset(cfg)
+    with pytest.raises(IndexError, match="no usable sample"):
+        ds[0]

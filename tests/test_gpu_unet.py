@@ -143,6 +143,23 @@ def test_pipeline_noise_stream_is_bitwise_the_reference_order_of_draws(tiny):
     part = pipe(num_inference_steps=n, batch_size=4, generator=torch.manual_seed(4242), output_type="np.array",
                 return_dict=False, shard=(1, 2))[0]
     assert np.array_equal(part, plain(4, slice(2, 4)))
+    # a call that dies mid-loop leaves the generator where the serial loop would have (the worker's extra draw is undone)
+    calls = {"n": 0}
+    real_step = sch.step
+
+    def failing_step(*a, **k):
+        calls["n"] += 1
+        if calls["n"] == 4:
+            raise KeyError("step 4 failed")
+        return real_step(*a, **k)
+    sch.step = failing_step
+    gen = torch.manual_seed(4242)
+    with pytest.raises(KeyError):
+        pipe(num_inference_steps=n, batch_size=3, generator=gen, output_type="np.array")
+    sch.step = real_step
+    ref = torch.manual_seed(4242)
+    state_after_5_draws = [torch.randn((3, 3, 64, 64), generator=ref) for _ in range(5)] and ref.get_state()   # x_T + steps 1..4
+    assert torch.equal(gen.get_state(), state_after_5_draws)
     # no generator: torch's device RNG, as the reference (generation.py:14-20) -- reproducible under torch.cuda.manual_seed
     torch.cuda.manual_seed(99)
     a = pipe(num_inference_steps=5, batch_size=2, output_type="np.array").images
