@@ -851,12 +851,23 @@ __global__ __launch_bounds__(64 * NW, OCC * NW / 4) void conv_h2_kernel(ConvH2P 
       // folded up-sampler: the phase's 2x2 corner of the patch; stride 2: the {y-1, y} x {x-1, x} corner
       const int dy = GM == 2 ? (phase >> 1) + (tap >> 1) : (GM == 3 ? (tap >> 1) : tap / KS);
       const int dx = GM == 2 ? (phase & 1) + (tap & 1) : (GM == 3 ? (tap & 1) : tap % KS);
+#ifdef DSG_H2_ABL_NOFA   // (tools/ timing experiment: tap 0's weight fragments serve every tap -- wrong values, the loop without 8/9 of the A reads)
+      if (tap == 0) {
+#pragma unroll
+        for (int mt = 0; mt < MTN; ++mt)
+#pragma unroll
+          for (int pc = 0; pc < NP; ++pc)
+            fa[0][mt][pc] = fa[1][mt][pc] =
+                *reinterpret_cast<const half8*>(wl + (((pc * TAPS + tap) * 2 + half) * BM + mt * 32 + l31) * 8);
+      }
+#else
 #pragma unroll
       for (int mt = 0; mt < MTN; ++mt)
 #pragma unroll
         for (int pc = 0; pc < NP; ++pc)
           fa[par][mt][pc] =
               *reinterpret_cast<const half8*>(wl + (((pc * TAPS + tap) * 2 + half) * BM + mt * 32 + l31) * 8);
+#endif
 #pragma unroll
       for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
@@ -975,11 +986,13 @@ __global__ __launch_bounds__(64 * NW, OCC * NW / 4) void conv_h2_kernel(ConvH2P 
 #else
     if constexpr (WS) {
       __syncthreads();  // everyone is done with the weight slab (and with cur); nxt's patch is complete
+#ifndef DSG_H2_ABL_WS_NOSLAB   // (tools/ timing experiment: chunk 0's weights serve every chunk -- wrong values, the loop without the exposed slab fetch)
       if (STAGE) {
         dma_next_slab();
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();  // the next chunk's weights are in
       }
+#endif
     } else {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the weight DMAs (not tracked by the compiler) have landed
       __syncthreads();  // nxt is complete; everyone is done reading cur
