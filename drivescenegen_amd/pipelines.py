@@ -126,11 +126,14 @@ class _PipelineBase:
 class _NoiseStream:
     """The per-step noise of ``DDPMPipeline.__call__`` in the reference's order of draws (App. A.4: x_T, then one full-batch
     tensor per step with t > 0, all from ONE generator).  A CPU generator (training_pipeline.py:29 passes
-    ``torch.manual_seed(seed)``) samples on the host: tensor k+1 is drawn by a worker thread into a pinned buffer while the
-    caller enqueues step k's kernels, and crosses PCIe on a side stream while the GPU runs the step's U-Net forward -- same
-    generator, same shapes, same order, so the same values as ``randn_tensor(...).to(device)`` bit for bit, with neither the
-    draw nor a pageable copy on the critical path.  `count` = the draws the call will make: the worker never draws past it,
-    and ``close()`` (always called) joins it and, should the loop have ended early, puts the generator back where the serial
+    ``torch.manual_seed(seed)``) samples on the host: tensor k+1 is drawn by a worker thread into one of two PINNED buffers while
+    the caller enqueues step k's kernels, and the scheduler's step kernel reads that buffer in place, over PCIe
+    (``schedulers.HostNoise``: the noise is read exactly once, 12 bytes per pixel of a batch-1 sample) -- same generator, same
+    shapes, same order, so the same values as ``randn_tensor(...).to(device)`` bit for bit, with neither the draw, nor a
+    pageable copy, nor a second stream's hand-over on the critical path.  Measured on the evaluate call (750 steps, batch 1;
+    tools/whole_call_probe.py): device-RNG loop 2.15 ms per step; this 2.18; a pinned copy on the same stream 2.20; a copy on
+    a side stream with event hand-overs 2.27.  `count` = the draws the call will make: the worker never draws past it, and
+    ``close()`` (always called) joins it and, should the loop have ended early, puts the generator back where the serial
     loop would have left it.  With no generator, or a device generator, a draw is torch's device RNG kernel on the current
     stream, as in the reference."""
 
@@ -140,20 +143,16 @@ class _NoiseStream:
         self.k = 0
         self._pending = None          # (thread, index, generator state before the draw, [exception])
         if self.host:
-            mine = self.shape if rows is None else (len(range(*rows.indices(self.shape[0]))),) + self.shape[1:]
             self.pinned = [torch.empty(self.shape, dtype=torch.float32).pin_memory() for _ in range(2)]
-            self.onchip = [torch.empty(mine, dtype=torch.float32, device=self.dev) for _ in range(2)]
-            self.copied = [None, None]    # side stream: the copy out of pinned[i] has finished
-            self.mark = [None, None]      # main stream: everything enqueued before the PREVIOUS draw (the reader of onchip[i] included)
-            self.side = torch.cuda.Stream(self.dev)
-            self.side.wait_stream(torch.cuda.current_stream(self.dev))   # (the fresh buffers' memory may have pending readers)
+            self.lent = [None, None]  # the HostNoise last handed out on pinned[i] (its `consumed` event guards the reuse)
 
     def _start(self, k):
         """hand tensor k's draw to a worker thread (one in flight at most; nobody else touches the generator meanwhile)"""
         import threading
         i = k & 1
-        if self.copied[i] is not None:
-            self.copied[i].synchronize()      # the copy that last read pinned[i] (two draws ago)
+        if self.lent[i] is not None:
+            self.lent[i].wait_consumed()      # the step kernel that read pinned[i] two draws ago has run
+            self.lent[i] = None
         box = []
 
         def work():
@@ -172,16 +171,23 @@ class _NoiseStream:
             th.join()
             self.gen.set_state(snap)
             self._pending = None
+        if self.host:
+            for h in self.lent:           # the pinned buffers must outlive the kernels that read them
+                if h is not None:
+                    h.wait_consumed()
+            self.lent = [None, None]
 
     def draw(self):
-        """The next tensor of the stream, on the device (this shard's rows of it).  Host-generator draws return one of two
-        resident buffers: a result must be consumed (by work enqueued on the current stream) before the draw after next."""
+        """The next tensor of the stream (this shard's rows of it): a device tensor, or -- host generator, after x_T -- a
+        ``HostNoise`` over a pinned buffer, to be handed to ``scheduler.step(..., variance_noise=...)`` before the draw after
+        next."""
+        from .schedulers import HostNoise
         rows = self.rows
         k, self.k = self.k, self.k + 1
         if not self.host:
             z = torch.randn(self.shape, generator=self.gen, device=self.dev, dtype=torch.float32)
             return z if rows is None else z[rows].contiguous()
-        if k == 0:   # x_T lives through the whole first step: a tensor of its own, the reference's plain path
+        if k == 0:   # x_T is the U-Net's first input: a device tensor, the reference's plain path
             z = torch.randn(self.shape, generator=self.gen, dtype=torch.float32)
             out = (z if rows is None else z[rows]).to(self.dev)
             if self.count > 1:
@@ -196,21 +202,11 @@ class _NoiseStream:
         if box:
             raise box[0]
         assert kk == k
-        main = torch.cuda.current_stream(self.dev)
-        here = torch.cuda.Event()
-        here.record(main)                     # covers the reader of the OTHER buffer (enqueued after the previous draw)
-        src = self.pinned[i] if rows is None else self.pinned[i][rows]
-        with torch.cuda.stream(self.side):
-            if self.mark[i] is not None:
-                self.side.wait_event(self.mark[i])   # device: the kernel that last read onchip[i] (two draws ago) is done
-            self.onchip[i].copy_(src, non_blocking=True)
-            self.copied[i] = torch.cuda.Event()
-            self.copied[i].record(self.side)
-        self.mark[i ^ 1] = here
-        main.wait_event(self.copied[i])       # consumers on the caller's stream see the data
+        out = HostNoise(self.pinned[i] if rows is None else self.pinned[i][rows])
+        self.lent[i] = out
         if k + 1 < self.count:
             self._start(k + 1)                # drawn while the caller enqueues the rest of this step and the next forward
-        return self.onchip[i]
+        return out
 
 
 def _rows_of(shard, batch):

@@ -34,6 +34,27 @@ def _randn_like_reference(shape, generator, device, dtype):
     return torch.randn(shape, generator=generator, device=device, dtype=dtype)
 
 
+class HostNoise:
+    """A step's variance noise in PINNED host memory, read in place by the step kernel (one pass over PCIe) instead of being
+    copied to the device first -- what ``DDPMPipeline`` hands to ``step(..., variance_noise=...)`` when the caller's generator
+    lives on the CPU (training_pipeline.py:26-32).  `consumed` is recorded on the launch stream behind the kernel that read
+    the buffer; its owner waits for it before writing the buffer again."""
+
+    def __init__(self, tensor):
+        if tensor.is_cuda or not tensor.is_contiguous() or tensor.dtype != torch.float32 or not tensor.is_pinned():
+            raise ValueError("HostNoise: a contiguous pinned fp32 host tensor is required")
+        self.tensor = tensor
+        self.consumed = None
+
+    @property
+    def shape(self):
+        return self.tensor.shape
+
+    def wait_consumed(self):
+        if self.consumed is not None:
+            self.consumed.synchronize()
+
+
 class DDPMScheduler:
     config_name = "scheduler_config.json"
     _class_name = "DDPMScheduler"
@@ -157,18 +178,28 @@ class DDPMScheduler:
             raise RuntimeError("DDPMScheduler.step runs on the MI355X HIP engine only (got a CPU tensor)")
         t = int(timestep)
         s = self.step_scalars(t)
-        noise = None
+        noise, host, nptr = None, None, None
         if t > 0:
-            noise = variance_noise if variance_noise is not None else _randn_like_reference(
-                model_output.shape, generator, model_output.device, model_output.dtype)
-            noise = noise.to(sample.device).contiguous()
+            if isinstance(variance_noise, HostNoise):    # pinned host buffer: the kernel reads it in place
+                host = variance_noise
+                if tuple(host.shape) != tuple(sample.shape):
+                    raise ValueError(f"variance_noise has shape {tuple(host.shape)}, the sample {tuple(sample.shape)}")
+                nptr = host.tensor.data_ptr()
+            else:
+                noise = variance_noise if variance_noise is not None else _randn_like_reference(
+                    model_output.shape, generator, model_output.device, model_output.dtype)
+                noise = noise.to(sample.device).contiguous()
+                nptr = _lib.ptr(noise)
         x, e = sample.contiguous(), model_output.contiguous()
         prev = torch.empty_like(x)
         clip = self.config.clip_sample_range if self.config.clip_sample else 0.0
         with torch.cuda.device(x.device):
-            _lib.check(_lib.load().dsg_ddpm_step(_lib.ptr(x), _lib.ptr(e), _lib.ptr(noise), _lib.ptr(prev), x.numel(),
+            _lib.check(_lib.load().dsg_ddpm_step(_lib.ptr(x), _lib.ptr(e), nptr, _lib.ptr(prev), x.numel(),
                                                 s["sqrt_beta_prod_t"], s["sqrt_alpha_prod_t"], clip, s["coef_x0"],
                                                 s["coef_xt"], s["sigma"], _lib.stream_ptr(x.device)))
+            if host is not None:
+                host.consumed = torch.cuda.Event()
+                host.consumed.record(torch.cuda.current_stream(x.device))
         if not return_dict:
             return (prev,)
         return SchedulerOutput(prev_sample=prev)

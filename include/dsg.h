@@ -323,6 +323,8 @@ int dsg_linear_fwd(const float* x, const float* w, const float* b, float* y, int
 int dsg_add_noise(const float* x0, const float* noise, const float* sqrt_a /* device [N] */,
                   const float* sqrt_1ma /* device [N] */, float* out, int32_t n, int64_t per_sample,
                   void* stream);
+/* (`noise` is read once, coalesced: device memory, or device-accessible PINNED host memory -- the evaluate call's seeded CPU
+ *  generator draws into a pinned buffer that the kernel reads in place over PCIe instead of a copy per step) */
 int dsg_ddpm_step(const float* sample, const float* eps, const float* noise /* NULL when t == 0 */,
                   float* prev, int64_t numel, float sqrt_beta_prod_t, float sqrt_alpha_prod_t,
                   float clip /* <=0: no clip */, float coef_x0, float coef_xt, float sigma, void* stream);

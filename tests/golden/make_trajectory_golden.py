@@ -21,7 +21,7 @@ mean square) of the whole x_0, `final_u8` = the whole post-processed image as DD
 ((x / 2 + 0.5).clamp(0, 1) -> HWC -> * 255 -> round -> uint8; generation.py:17-20), and `checkpoints` = x_t at every
 `every`-th step at every 8th pixel -- the curve along which an engine run may drift from the oracle's.
 
-`--sensitivity` adds `self_divergence`: the same oracle run again from an x_T moved by 1e-6 (relative), compared with its own
+`--sensitivity` adds `self_divergence` (and `self_u8_frac`: the fraction of uint8 values the two runs round differently): the same oracle run again from an x_T moved by 1e-6 (relative), compared with its own
 unperturbed run at the same checkpoints and at the end.  With the synthetic (untrained, random) weights these networks are
 not contractive: two fp32 runs that differ by one forward's round-off drift apart exponentially, and the free-running
 tolerance of SURVEY 8c can only be asked for inside the horizon where the oracle agrees with ITSELF.  `--early` stores that
@@ -118,6 +118,10 @@ def main():
             cps, fin = run(key, PERTURB)
             out[key + "/self_divergence"] = np.array([rel(c, g) for c, g in zip(cps, out[key + "/checkpoints"])] +
                                                      [rel(fin, out[key + "/final"])])
+            # ... and what that drift does to the uint8 image (on the stored, strided pixels): the fraction of values the
+            # oracle's two runs round differently -- no implementation can be asked for fewer than the oracle gives itself
+            u8 = lambda a: (np.clip(a / 2 + 0.5, 0, 1) * 255).round().astype("uint8")
+            out[key + "/self_u8_frac"] = np.array([float((u8(fin) != u8(out[key + "/final"])).mean())])
             np.savez_compressed(PATH, **out)
             print("sensitivity", key, out[key + "/self_divergence"], flush=True)
         return
