@@ -480,6 +480,7 @@ int conv_h2_get_fuse_sc();
 void conv_h2_set_pre(int v);
 void conv_h2_set_narrow(int v);
 void conv_h2_set_splitk_mid(int v);
+void conv_h2_set_rows_rule(int v);
 void conv_h2_set_pre_min_ct(int v);
 bool conv_h2_takes_operand(const dsg_conv_args* a, int hout, int wout, bool wanted);
 void attention_set_blocked(int v);
@@ -928,6 +929,10 @@ static int set_tuning_impl(int32_t key, int32_t value) {
   }
   if (key == 32 && (value == 0 || value == 1)) {
     dsg::conv_h2_set_narrow(value);
+    return DSG_OK;
+  }
+  if (key == 36 && (value == 0 || value == 1)) {
+    dsg::conv_h2_set_rows_rule(value);
     return DSG_OK;
   }
   if (key == 31 && (value == 0 || value == 1)) {

@@ -102,7 +102,11 @@ bool conv_h2_takes_operand(const dsg_conv_args* a, int hout, int wout, bool want
 // 16-row tiles (4 rows per wave) are the efficient shape; 8-row tiles double the workgroup count.  The chip runs
 // 256 workgroups at a time, so what counts is the number of ROUNDS: an 8-row workgroup costs ~0.55 of a 16-row one
 // (half the MFMAs, the same fixed cost), and e.g. 320 workgroups of 16 rows (2 rounds) lose to 640 of 8 (3 x 0.55).
-static bool rows16_pays(int b16) {
+// cost8: what an 8-row workgroup costs relative to a 16-row one, in percent (half the MFMAs, the same fixed cost): 55 for the
+// nine-tap kernels; the four-tap kernels (folded up-sampler, stride 2) have less MFMA work per tile to set against the same
+// prologue / epilogue: 62 (batch-5 sampling, per-launch records under the forced geometries, profiles/r05_geometry_sweep.txt:
+// the 256 -> 256 up-sampler conv at 5 x 640 tiles 148.3 us in 8-row tiles, 131.3 us in 16-row ones)
+static bool rows16_pays(int b16, int cost8 = 55) {
   if (g_h2.rows == 2 || b16 <= 0) return false;
   if (g_h2.rows == 4) return true;
   // up to 128 tiles the 8-row grid still fits one round at 0.55 each.  129 .. 255 tiles go by the rounds rule as well: 160
@@ -110,20 +114,28 @@ static bool rows16_pays(int b16) {
   // batch 3 4.05 -> 3.94, same-box A/B; the rule used to be "never below 256 tiles": key 3 = 3 keeps it for comparisons)
   if (g_h2.rows == 3 ? b16 < 256 : b16 <= 128) return false;
   const int r16 = (b16 + 255) / 256, r8 = (2 * b16 + 255) / 256;
-  return 100 * r16 <= 55 * r8;
+  return 100 * r16 <= (g_h2.rows_rule ? cost8 : 55) * r8;
 }
 
 bool conv_h2_rows16(const dsg_conv_args* a, int hout, int wout) {
   if (conv_h2_fold(a)) {  // tiled on the low-resolution grid, four phases per cout tile
     const int cp = (a->cout + 63) / 64 * 64;
-    return rows16_pays((a->hin % 16 == 0) ? (a->win / H2_TW) * (a->hin / 16) * a->n * (cp / H2_BM) * 4 : 0);
+    return rows16_pays((a->hin % 16 == 0) ? (a->win / H2_TW) * (a->hin / 16) * a->n * (cp / H2_BM) * 4 : 0, 62);
   }
   if (a->ksize == 1) {
     hout = hout * wout / H2_TW;
     wout = H2_TW;
   }
   const int cout_pad = (a->cout + 63) / 64 * 64;
-  return rows16_pays((hout % 16 == 0) ? (wout / H2_TW) * (hout / 16) * a->n * (cout_pad / H2_BM) : 0);
+  const int b16 = (hout % 16 == 0) ? (wout / H2_TW) * (hout / 16) * a->n * (cout_pad / H2_BM) : 0;
+  // Three-slice split-K (129 .. 170 eight-row tiles with long K: batch-5 sampling at the 32 x 32 level, generation.py:14-20):
+  // 16-row tiles make that 3 x 65 .. 85 workgroups -- ONE round on 76-100 % of the chip, each workgroup with twice the MFMAs
+  // per staged patch -- instead of two rounds of 8-row ones (per-launch records: 90.7 -> 84.2 us on the 512 -> 512 convs).
+  if (g_h2.rows_rule && g_h2.rows == 0 && b16 > 0 && a->splitk_ws != nullptr && a->ksize == 3 && a->stride == 1) {
+    int sp = 1;
+    if (2 * b16 > H2_CUS / 2 && conv_h2_splitk_slices(a, hout, wout, &sp) == 3 && 3 * b16 <= H2_CUS) return true;
+  }
+  return rows16_pays(b16);
 }
 
 // Split-K plan of a call (see dsg_conv_args.splitk_ws): fp32 path, every tensor channel-blocked, plain or stride-2 3x3
@@ -314,6 +326,7 @@ void conv_h2_set_fuse_sc(int v) { g_h2.fuse_sc = v; ++g_h2.epoch; }
 void conv_h2_set_pre(int v) { g_h2.pre = v; ++g_h2.epoch; }
 void conv_h2_set_narrow(int v) { g_h2.narrow = v; ++g_h2.epoch; }
 void conv_h2_set_splitk_mid(int v) { g_h2.splitk_mid = v; ++g_h2.epoch; }
+void conv_h2_set_rows_rule(int v) { g_h2.rows_rule = v; ++g_h2.epoch; }
 void conv_h2_set_pre_min_ct(int v) { g_h2.pre_min_ct = v > 0 ? v : 1; ++g_h2.epoch; }
 int conv_h2_get_fuse_sc() { return g_h2.fuse_sc; }
 int conv_in_tuning_epoch();  // conv_in.hip: its on/off switch moves the plan's statistics buffers too

@@ -35,6 +35,7 @@ struct H2Tuning {
   int pre_min_ct = 16;  // ... (key 27: the threshold.  Measured, profiles/r03_operand_ablation.txt: at 4 -- every conv of the 256- / 512-channel
                         // levels -- the convs gain 8.5 % and the prepare passes cost what they gain; at 16 only the folded up-samplers of
                         // those levels qualify, whose patch is staged by 16-32 workgroups)
+  int rows_rule = 1;    // round 5's additions to the rows rule: 16-row tiles under three-slice split-K, 0.62 for the four-tap kernels (key 36)
   int epoch = 0;        // bumped by every change: plans key their cached workspace sizes on it
 };
 extern H2Tuning g_h2;

@@ -599,6 +599,9 @@ int dsg_prof_dump(const char* csv_path);
  *      one-tap instantiation (64 x 64 workgroups)
  *  34  split-K also for grids of 129 .. 170 workgroups with at least 24 K-chunks (batch-5 sampling at the 32 x 32 level): three
  *      slices = two rounds of a third of the work: [1] | 0 = only grids of at most half the CUs split
+ *  36  round 5's additions to the rows-per-wave rule (key 3 = 0): 16-row tiles for the convs that split K in three slices (one
+ *      round of 195 .. 255 workgroups instead of two), and the four-tap kernels (folded up-sampler) priced at 0.62 of a 16-row
+ *      workgroup per 8-row one instead of 0.55: [1] | 0
  *  32  maps narrower than a 32-column tile (16 x 16, 8 x 8: the deepest levels of BASELINE configs[3]'s 512 x 512 network) also
  *      take split-K, the folded up-sampler kernel and the stride-2 space-to-depth kernel: [1] | 0 = one-slice plain kernel and
  *      the exact f32-MFMA kernels for them

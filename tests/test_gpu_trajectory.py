@@ -101,7 +101,8 @@ def test_free_running_trajectory_tracks_the_oracle_as_far_as_the_oracle_tracks_i
     _record(key, {"steps": steps, "scheduler": kind, "first_steps_rel_l2": first, "first_steps_oracle_self_divergence": self_early.tolist(),
                   "checkpoint_every": every, "rel_l2_at_checkpoints": curve, "final_rel_l2": err,
                   "oracle_self_divergence_at_checkpoints_and_end": self_div.tolist(),
-                  "u8_pixels_differing": frac, "u8_max_lsb": worst})
+                  "u8_pixels_differing": frac, "u8_max_lsb": worst,
+                  "oracle_self_u8_pixels_differing": (float(gold[key + "/self_u8_frac"][0]) if key + "/self_u8_frac" in gold else None)})
     assert curve[0] == 0.0   # both runs start from the same x_T
     # (1) inside the horizon: SURVEY 8c's free-running tolerance, and the class of the oracle's own drift
     for k in range(EARLY):
@@ -113,7 +114,12 @@ def test_free_running_trajectory_tracks_the_oracle_as_far_as_the_oracle_tracks_i
     if key.endswith("_c") or key == "default3_ddpm750":
         assert float(self_div[-1]) <= 1e-4, (key, float(self_div[-1]))   # (these runs exist to be judged by the letter)
     if float(self_div[-1]) <= 1e-4:
-        assert err <= 1e-3 and worst <= 1 and frac <= 1e-3, (key, err, worst, frac)
+        # uint8: never more than 1 LSB; on <= 0.1 % of the pixels -- or, where the oracle's own two runs (x_T moved by 1e-6)
+        # already round more pixels than that differently, on no more than twice what the oracle does to itself.  (A final
+        # rel-L2 of e puts a value within e * rms * 127.5 LSB of its rounding boundary with probability ~0.8 x that: 2.2e-5
+        # on the configs[1] image is 0.11-0.14 % of the pixels, from ANY fp32 implementation.)
+        own = float(gold[key + "/self_u8_frac"][0]) if key + "/self_u8_frac" in gold else 0.0
+        assert err <= 1e-3 and worst <= 1 and frac <= max(1e-3, 2 * own), (key, err, worst, frac, own)
     else:   # moments of the final image: the engine's run is a sample of the same process (5 % on each channel's mean square)
         mom = torch.from_numpy(gold[key + "/final_moments"])
         ms = x.double().pow(2).mean((0, 2, 3))
