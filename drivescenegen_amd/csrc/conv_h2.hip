@@ -138,6 +138,18 @@ bool conv_h2_rows16(const dsg_conv_args* a, int hout, int wout) {
   return rows16_pays(b16);
 }
 
+// Small grids with long K: 64-cout workgroups with MORE K slices instead of 32-cout workgroups with fewer -- when the 64-cout
+// grid with the slices it may take (<= 4, >= 4 chunks each) fills at least three quarters of the chip.  Batch-1 sampling
+// (training_pipeline.py:26-32) at the 64 x 64 level: 64 x 4 slices of 64 couts against 128 x 2 of 32 -- the same 256 workgroups,
+// half the K chain, twice the MFMAs per staged patch (per-launch records, profiles/r05_geometry_sweep.txt: -5..-11 % on those convs).
+bool splitk_prefers_bm64(int grid64, int nq) {
+  if (!g_h2.rows_rule || !g_h2.splitk) return false;
+  const int slices = std::min(4, std::min(H2_CUS / std::max(grid64, 1), nq / 4));
+  // (long K only: a slice keeps at least six chunks -- with the 128 -> 128 convs' eight chunks cut in two the reduce pass costs
+  //  more than the shorter chain saves: batch 1 measured +3.5 % without this condition)
+  return slices >= 2 && nq >= 6 * slices && grid64 * slices >= 3 * H2_CUS / 4;
+}
+
 // Split-K plan of a call (see dsg_conv_args.splitk_ws): fp32 path, every tensor channel-blocked, plain or stride-2 3x3
 // or pointwise; only when the tile grid the launcher would use covers at most half the CUs and K is long enough to cut.
 int conv_h2_splitk_slices(const dsg_conv_args* a, int hout, int wout, int* stat_splits) {
@@ -156,8 +168,9 @@ int conv_h2_splitk_slices(const dsg_conv_args* a, int hout, int wout, int* stat_
   if ((tw % H2_TW != 0 && !narrow_ok) || th % 8 != 0) return 1;
   const int cout_pad = (a->cout + 63) / 64 * 64;
   int grid = ((tw + H2_TW - 1) / H2_TW) * (th / 8) * a->n * (cout_pad / H2_BM);
-  if (a->ksize == 3 && !s2 && g_h2.bm32_small && grid <= H2_CUS / 2 && tw % H2_TW == 0) grid *= 2;  // (the launcher's 32-cout workgroups)
   const int nq = (s2 ? 4 * a->c0 : a->c0 + a->c1) / H2_KC;
+  if (a->ksize == 3 && !s2 && g_h2.bm32_small && grid <= H2_CUS / 2 && tw % H2_TW == 0 && !splitk_prefers_bm64(grid, nq))
+    grid *= 2;  // (the launcher's 32-cout workgroups)
   if (nq < 8) return 1;
   int slices;
   if (grid > H2_CUS / 2) {

@@ -44,6 +44,7 @@ constexpr int H2_CUS = 256;
 bool conv_h2_fold(const dsg_conv_args* a);
 bool conv_h2_s2(const dsg_conv_args* a, int hout, int wout);
 bool conv_h2_rows16(const dsg_conv_args* a, int hout, int wout);
+bool splitk_prefers_bm64(int grid64, int nq);
 // does the call take the fused-shortcut kernel (dsg_conv_args.sc_*)?  Shapes, layouts and dtype -- and, for a call that brings
 // split-K scratch (splitk_ws), the slice count of that call, which is a function of the grid and therefore of the batch: a slice
 // left with fewer shortcut chunks than the DMA ring is deep refuses the fusion.  "Row i of a batch == the batch-1 call on row i,
@@ -201,7 +202,8 @@ int conv_h2_launch_t(const dsg_conv_args* a, int hout, int wout, hipStream_t st)
   // even the 8-row x 64-cout grid leaves more than half of the CUs idle, halve the cout tile to double the grid
   const bool bm32_ok = lay == 3 && !fold && !s2 && !k1 && !a->upsample && wout % H2_TW == 0 && (!sc || PREC == 0);
   const bool bm32 = bm32_ok && ((g_h2.bm32 && p.cin <= 128 && (int)grid.x >= g_h2.bm32_min) ||
-                                (g_h2.bm32_small && !nt4 && (int)grid.x <= H2_CUS / 2));
+                                (g_h2.bm32_small && !nt4 && (int)grid.x <= H2_CUS / 2 &&
+                                 !(slices > 1 && splitk_prefers_bm64((int)grid.x, p.cin / H2_KC))));
   if (pre) {
     if constexpr (PREC == 0) {
       const size_t lpre = 2 * (size_t)(fold ? H2Geom<4, 3, 4, 4, 64, NP, 1>::BUF_BYTES : H2Geom<4, 3, 4, 9, 64, NP, 1>::BUF_BYTES);
