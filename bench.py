@@ -600,7 +600,7 @@ ROOFLINE_KEYS = ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic
 
 def write_full_record(out, path=None):
     """The whole record as JSON under gpurun_out/ (merged back from the GPU box); returns the path or None."""
-    path = path or os.path.join(ROOT, "gpurun_out", "bench_full.json")
+    path = os.path.abspath(path) if path else os.path.join(ROOT, "gpurun_out", "bench_full.json")
     try:
         os.makedirs(os.path.dirname(path), exist_ok=True)
         with open(path, "w") as f:
@@ -669,6 +669,8 @@ def main():
     ap.add_argument("--train-bf16-batch", type=int, default=128, help="BASELINE configs[4]: 128 per GPU")
     ap.add_argument("--mixed-batch", type=int, default=64)
     ap.add_argument("--mixed-steps", type=int, default=20)
+    ap.add_argument("--full-record", default=None,
+                    help="where the FULL record (every class row of every leg) is written; default gpurun_out/bench_full.json")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -791,7 +793,7 @@ def main():
         out["summary"] = summary_of(out)
         # the FULL record (every class row of every leg, ~25 KB) goes to a file and to stderr; stdout's last line is the
         # compact line the driver parses (round 4's 25.6-KB line was not parsed: BENCH_r04.json "parsed": null)
-        full_path = write_full_record(out)
+        full_path = write_full_record(out, args.full_record)
         sys.stderr.write(json.dumps(out) + "\n")
         sys.stderr.flush()
         print(compact_line(out, full_path), flush=True)

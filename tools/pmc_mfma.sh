@@ -15,7 +15,7 @@ cd "$GRAFT_REPO_ROOT" || exit 1
 export TMPDIR=/tmp
 tag=$1
 export PMC_SUFFIX=${2:-}
-cmd=${PMC_CMD:-"python bench.py --steps 3 --warmup 1 --no-cpu --no-prof --no-extras"}
+cmd=${PMC_CMD:-"python bench.py --steps 3 --warmup 1 --no-cpu --no-prof --no-extras --full-record /tmp/bench_full_scratch.json"}
 export PMC_CMD_TEXT="$cmd"
 export DSG_GIT_HEAD=$(cat tools/_head.txt 2>/dev/null || echo unknown)
 mkdir -p gpurun_out
