@@ -218,3 +218,30 @@ def test_trajectory_golden_is_complete_and_self_consistent():
         assert float(gold[k + "/self_divergence"][-1]) <= 1e-4      # two fp32 runs end together ...
         assert float(gold[k + "/final_moments"][1].min()) > 0.05     # ... on an image that is not degenerate
     assert float(gold["cfg2_ddim50/self_divergence"][-1]) > 0.1     # (the plain synthetic set: chaotic)
+
+
+def test_torch_oracle_agrees_with_the_independent_numpy_restatement():
+    """oracle/unet_numpy.py shares nothing with oracle/unet_oracle.py -- fp64 numpy, a walk over state-dict keys, every operator
+    written out from its definition -- so agreement pins the torch oracle's USE of torch (GroupNorm's eps / biased variance, SDPA's
+    scale and head layout, conv padding / stride, nearest x2, the skip bookkeeping, the timestep embedding's cos-first order).
+    BASELINE configs[0] (two plain levels + mid attention) and the attention-block network (AttnDown / AttnUp, three levels)."""
+    import numpy as np
+    import torch
+    from oracle.unet_numpy import unet_forward
+    from oracle.unet_oracle import OracleUNet2DModel
+    from tests.common import CFG1, CFG4_SMALL, noisy_inputs, rel_l2, synth_weights
+    small = dict(CFG4_SMALL, sample_size=32)      # (pure-numpy convs: keep the maps small)
+    for cfg, ts in ((CFG1, (999, 0)), (small, (437, 3))):
+        net = synth_weights(OracleUNet2DModel(**cfg)).eval()
+        sd = {k: v.detach().numpy() for k, v in net.state_dict().items()}
+        x = noisy_inputs(cfg, 2)
+        t = torch.tensor(ts)
+        with torch.no_grad():
+            want32 = net(x, t).sample
+            want64 = net.double()(x.double(), t).sample
+        got = torch.from_numpy(unet_forward(cfg, sd, x.numpy(), np.asarray(ts)))
+        assert got.shape == want64.shape and torch.isfinite(got).all()
+        # fp64 against fp64: the same function.  (Not 1e-15: the timestep embedding is float32 on both sides, as in diffusers, and
+        # numpy's and torch's float32 exp / cos / sin differ in the last bit.  A semantic slip shows at 1e-3 or more.)
+        assert rel_l2(got, want64) <= 5e-7, rel_l2(got, want64)
+        assert rel_l2(want32.double(), got) <= 2e-6                    # and the fp32 oracle is that function in fp32
