@@ -87,6 +87,21 @@ def test_f2_masks_bit_exact():
     assert 0 < (gm == 255).mean() < 0.5 and 0 < (am == 255).mean() < 0.5
 
 
+def test_f2_gray_mask_equals_the_reference_generated_goldens():
+    """``imageops.gray_mask_batch`` against masks the reference's own ``get_gray_image`` produced
+    (tests/golden/postproc_golden.npz, made by make_postproc_golden.py from image_utils.py:13-43): bit for bit."""
+    import os
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "postproc_golden.npz"))
+    for i in range(int(g["n"])):
+        got = imageops.gray_mask_batch(torch.from_numpy(g[f"img{i}"][None]).to(DEV)).cpu().numpy()[0]
+        assert np.array_equal(got, g[f"mask{i}"]), i
+    # a batch of same-shape cases in one call (per-image decision tables)
+    batch = np.stack([g[f"img{i}"] for i in range(4)])
+    got = imageops.gray_mask_batch(torch.from_numpy(batch).to(DEV)).cpu().numpy()
+    for i in range(4):
+        assert np.array_equal(got[i], g[f"mask{i}"]), i
+
+
 def test_f3_training_resume(tmp_path):
     """Stop after 2 steps, save, rebuild everything from disk, continue: identical to 4 uninterrupted steps."""
     def make():

@@ -126,6 +126,23 @@ def test_postproc_oracle_known_answers():
     assert (rt <= np.arange(256)).all() and (np.arange(256) - rt).max() <= 1
 
 
+def test_postproc_oracle_equals_the_reference_generated_goldens():
+    """tests/golden/postproc_golden.npz holds masks computed by the REFERENCE'S OWN ``get_gray_image``
+    (vectorization/utils/image_utils.py:13-43, imported by path in tests/golden/make_postproc_golden.py): scenes, a tie in the
+    histogram peak, byte values at +-0.1 of the peak's bin edge, a peak in the last bin, uniform noise.  Row f2's oracle must
+    reproduce every mask bit for bit -- the one row whose goldens were made by the reference itself."""
+    import os
+    import numpy as np
+    from oracle.postproc_oracle import get_gray_mask
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "postproc_golden.npz"))
+    assert int(g["n"]) == 8
+    for i in range(int(g["n"])):
+        assert np.array_equal(get_gray_mask(g[f"img{i}"]), g[f"mask{i}"]), i
+    # the edge case really sits on the boundary: bytes 102 and 153 are background (|u/255 - 0.5| <= 0.1 in float64), 101 / 154 are not
+    assert list(g["mask5"][0, [101, 102, 153, 154]]) == [255, 0, 0, 255]
+    assert g["mask4"][0, 0] == 255 and g["mask4"][40, 0] == 0     # the tie goes to the FIRST peak (byte 60)
+
+
 def test_fullsize_golden_vectors_are_what_the_oracle_computes():
     """tests/golden/fullsize_golden.npz (the full-size oracle outputs the `-m gpu` suite compares the engine with) against a
     live run of the oracle on this host: one forward of the train.py:39-57 network on the stored case's rebuilt inputs --
