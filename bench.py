@@ -359,6 +359,95 @@ def train_ref_leg(args, steps=8):
             "peak_mem_gib": torch.cuda.max_memory_allocated(dev) / 2 ** 30}
 
 
+def _write_synth_pngs(folder, count, size=512, seed=14555):
+    """`count` synthetic 512x512 RGB scene rasters (flat background, lanes, agents + light sensor-like noise so that the
+    files do not compress to nothing: ~400 KB each) as PNG files; returns the paths."""
+    import numpy as np
+    from PIL import Image
+    from drivescenegen_amd import synth
+    os.makedirs(folder, exist_ok=True)
+    x = synth.synth_scene_rasters(count, 3, size, size, seed)
+    img = ((x.transpose(0, 2, 3, 1) * 0.5 + 0.5) * 255).round().astype(np.uint8)
+    noise = (synth.uniform01(seed, img.size, stream=5).reshape(img.shape) * 13).astype(np.int16) - 6
+    img = np.clip(img.astype(np.int16) + noise, 0, 255).astype(np.uint8)
+    paths = []
+    for i in range(count):
+        paths.append(os.path.join(folder, f"{i:04d}.png"))
+        Image.fromarray(img[i]).save(paths[-1], compress_level=1)
+    return paths
+
+
+def train_e2e(net, opt, lrs, sch, cfg, batch, dtype, bare_ms, steps=4, warm=2):
+    """The training loop END TO END at the config's own batch, the way the reference runs it
+    (training_pipeline.py:70-97 over train.py:34-35's loader): PNG files on disk -> `GpuImageLoader` (native decode pool,
+    pinned ring, H2D on a side stream, one resize + normalise kernel: dataset.py:32-50) -> `train_loop.train_steps`
+    with (a) the reference's HOST noise draw (`torch.randn(batch.shape)`, training_pipeline.py:72, one step ahead on a worker
+    thread: `NoiseAhead`) and (b) the opt-in library generator (`noise="device"`: dsg_add_noise_philox).  Reported next
+    to the bare tape's step time: images/s of both modes, the loader's own rates, the host draw's cost."""
+    import shutil
+    import tempfile
+    import drivescenegen_amd as d
+    from drivescenegen_amd import imageops, train_loop
+    dev = next(net.parameters()).device
+    c = cfg["in_channels"]
+    folder = tempfile.mkdtemp(prefix="dsg_e2e_")
+    try:
+        t0 = time.perf_counter()
+        _write_synth_pngs(folder, 2 * batch)
+        write_s = time.perf_counter() - t0
+        loader = imageops.GpuImageLoader(os.path.join(folder, "*.png"), (256, 256), batch, shuffle=True, seed=7, device=dev)
+        decode_rate = loader.decode_rate(3)
+        pil_loader = imageops.GpuImageLoader(os.path.join(folder, "*.png"), (256, 256), batch, workers=1, native_png=False, device=dev)
+        pil_rate = pil_loader.decode_rate(1)     # the reference's feeder: one thread, PIL
+
+        def batches(n):
+            """n batches [B, C, 256, 256] from epochs of the loader; the 3 decoded channels are tiled to the config's C"""
+            k = 0
+            while k < n:
+                for x in loader:
+                    yield x if c == 3 else x.repeat(1, (c + 2) // 3, 1, 1)[:, :c].contiguous()
+                    k += 1
+                    if k >= n:
+                        return
+        # the loader alone, GPU side included (decode + H2D + resize kernel), consumer does nothing else
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        n_img = sum(x.shape[0] for x in batches(6))
+        torch.cuda.synchronize(dev)
+        loader_rate = n_img / (time.perf_counter() - t0)
+        # the host draw the reference makes per step (serial CPU generator)
+        t0 = time.perf_counter()
+        torch.randn((batch, c, 256, 256))
+        draw_ms = (time.perf_counter() - t0) * 1e3
+
+        acc = d.Accelerator(mixed_precision="no")   # (the net's compute dtype is already set; no GradScaler for fp32 / bf16)
+
+        def run(noise):
+            t_start, last = None, None
+            for i, loss in enumerate(train_loop.train_steps(acc, net, sch, opt, lrs, batches(warm + steps), noise=noise)):
+                if i == warm - 1:
+                    torch.cuda.synchronize(dev)
+                    t_start = time.perf_counter()
+                last = loss
+            torch.cuda.synchronize(dev)
+            dt = time.perf_counter() - t_start
+            assert torch.isfinite(last).all()
+            return dt / steps * 1e3, float(last)
+        host_ms, host_loss = run("host")
+        dev_ms, dev_loss = run(train_loop.DeviceNoise(seed=14555))
+        return {"what": "PNG files -> GpuImageLoader -> train_steps, at the config's own batch; bare tape = device-resident x0 / noise / t",
+                "batch": batch, "dtype": dtype, "bare_tape_ms": bare_ms, "bare_tape_images_s": batch / bare_ms * 1e3,
+                "host_noise_ms": host_ms, "host_noise_images_s": batch / host_ms * 1e3,
+                "device_noise_ms": dev_ms, "device_noise_images_s": batch / dev_ms * 1e3,
+                "device_noise_vs_bare": bare_ms / dev_ms, "host_noise_vs_bare": bare_ms / host_ms,
+                "host_draw_ms": draw_ms, "loader_images_s": loader_rate, "decode_pool_images_s": decode_rate,
+                "decode_workers": loader.workers, "pil_one_thread_images_s": pil_rate,
+                "png": "512x512 RGB, ~%d KB" % (os.path.getsize(os.path.join(folder, "0000.png")) // 1024),
+                "png_write_s": write_s, "loss_host": host_loss, "loss_device": dev_loss}
+    finally:
+        shutil.rmtree(folder, ignore_errors=True)
+
+
 def train_leg(args, dtype="fp32", batch=64, steps=4):
     """Extra record: optimizer steps of the training loop (training_pipeline.py:70-91: add_noise, U-Net forward, MSE,
     backward, clip 1.0, AdamW, cosine LR) on BASELINE configs[2]'s network at `batch` samples on one GPU; images/s."""
@@ -411,15 +500,23 @@ def train_leg(args, dtype="fp32", batch=64, steps=4):
                                    base + 7: "conv3x3_upsample", base + 8: "conv1x1", base + 2: "conv3x3_s2",
                                    base + 9: "conv3x3_wgrad", 5: "conv_wgrad_f32_mfma", 0: "conv3x3_s1_mfma_f32"})
     lib.dsg_prof_enable(0)
+    e2e = None
+    if not getattr(args, "no_e2e", False):
+        try:
+            e2e = train_e2e(net, opt, lrs, sch, cfg, batch, dtype, dt / steps * 1e3)
+        except Exception as e:  # noqa: BLE001  (reported, never hidden)
+            e2e = {"error": f"{type(e).__name__}: {e}"}
     del net, opt
     torch.cuda.empty_cache()
-    rec = {"metric": "training images/sec (fwd + bwd + clip + AdamW)", "value": batch * steps / dt, "unit": "images/s",
+    rec = {"metric": "training images/sec (fwd + bwd + clip + AdamW) -- BARE TAPE: device-resident x0 / noise / t, no loader, no "
+                     "noise draw; the loop end to end is `e2e`", "value": batch * steps / dt, "unit": "images/s",
            "ms_per_step": dt / steps * 1e3, "step_ms_spread": clock.spread(), "steps": steps, "dtype": dtype,
            "peak_mem_gib": peak_gib,
            "config": {"workload": f"BASELINE configs[{2 if dtype == 'fp32' else 4}]: 256x256x{c} raster, DDPM training step (add_noise, "
                                   f"fwd, MSE, bwd, clip 1.0, AdamW, cosine LR), batch {batch} per GPU (the config's own), {dtype}, "
-                                  "one GPU's share of the data-parallel step (no all-reduce at N = 1)", "batch": batch},
-           "kernels": rows}
+                                  "one GPU's share of the data-parallel step (no all-reduce at N = 1); bare tape, "
+                                  "device-resident inputs", "batch": batch},
+           "e2e": e2e, "kernels": rows}
     # roofline of the dominant BACKWARD kernel (the 3x3 weight gradient) and of the conv class that carries forward and
     # data gradients, priced like the headline: fp32-equivalent = 2500 / 3 TF/s-eq, 16-bit = 2500 TF/s; HBM 8 TB/s
     peak = PEAK_F16_TFLOPS / (3.0 if dtype == "fp32" else 1.0)
@@ -443,6 +540,106 @@ def train_leg(args, dtype="fp32", batch=64, steps=4):
             rec["roofline"]["second_kernel"] = roof(fw, "dsg::conv_h2_kernel<0, *, 3, *> (forward and data-gradient 3x3 convs)",
                                                     r"conv_h2_kernel<0, [24], 3, [02], 4, [12], [03], (64|128), " +
                                                     ("0" if dtype == "fp32" else "[12]"))
+    return rec
+
+
+def train_ddp_leg(args, rank, world, dtype, batch, steps):
+    """Record for N > 1 (every rank calls it): the data-parallel training step north_star names -- BASELINE configs[2]
+    (fp32, 64 per GPU) / configs[4] (bf16, 128 per GPU) through `Accelerator` + `GradBuckets` (train.py:121-122,
+    training_pipeline.py:59-61,86): rank-0 broadcast, ~25-MB reverse-order buckets all-reduced (AVG) on RCCL from INSIDE the
+    backward walk.  Three timings of the same step on every rank (max over ranks): `local` (buckets switched off: the bare
+    tape), `overlap` (the product path), `deferred` (DSG_DDP_OVERLAP=0: the same buckets launched after the walk); exposed
+    communication = mode - local.  Plus the self-check: the all-reduced gradient slab of one backward in both modes, bitwise."""
+    import torch.distributed as dist
+    import drivescenegen_amd as d
+    from drivescenegen_amd import synth
+    from drivescenegen_amd.autograd import get_train_state
+    from drivescenegen_amd.configs import CFG3, CFG5, synth_weights
+    cfg = CFG3 if dtype == "fp32" else CFG5
+    acc = d.Accelerator(mixed_precision="no" if dtype == "fp32" else dtype)
+    dev = acc.device
+    net = synth_weights(d.UNet2DModel(**cfg)).train()
+    opt = d.AdamW(net.parameters(), lr=1e-5)
+    lrs = d.get_cosine_schedule_with_warmup(optimizer=opt, num_warmup_steps=500, num_training_steps=50000)
+    net, opt, lrs = acc.prepare(net, opt, lrs)
+    sch = d.DDPMScheduler()
+    c = cfg["in_channels"]
+    # rank r's shard of the global batch: its own samples, noise and timesteps
+    x0 = torch.from_numpy(synth.synth_scene_rasters(batch, c, 256, 256, 14555 + rank)).to(dev)
+    noise = torch.from_numpy(synth.normal(24556 + rank, (batch, c, 256, 256))).to(dev)
+    t = torch.from_numpy((synth.uniform01(34557 + rank, batch) * 1000).astype("int64")).to(dev)
+
+    def fwd_bwd():
+        with acc.accumulate(net):
+            loss = d.mse_loss(net(sch.add_noise(x0, noise, t), t, return_dict=False)[0], noise)
+            acc.backward(loss)
+        return loss
+
+    def one():
+        with acc.accumulate(net):
+            loss = d.mse_loss(net(sch.add_noise(x0, noise, t), t, return_dict=False)[0], noise)
+            acc.backward(loss)
+            acc.clip_grad_norm_(net.parameters(), 1.0)
+            opt.step()
+            lrs.step()
+            opt.zero_grad()
+        return loss
+
+    acc.ddp_overlap = True
+    for _ in range(2):
+        one()           # (creates the train state, the gradient slab and the buckets; the allocator settles)
+    buckets = acc._buckets
+    assert buckets is not None and buckets.active, "train_ddp_leg: no active gradient buckets (process group missing?)"
+
+    def timed(mode):
+        buckets.active = mode != "local"
+        acc.ddp_overlap = mode != "deferred"
+        one()
+        torch.cuda.synchronize(dev)
+        dist.barrier()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            loss = one()
+        torch.cuda.synchronize(dev)
+        own = (time.perf_counter() - t0) / steps * 1e3
+        assert torch.isfinite(loss.detach()).all()
+        box = torch.tensor([own], dtype=torch.float64, device=dev)
+        gathered = [torch.zeros_like(box) for _ in range(world)]
+        dist.all_gather(gathered, box)
+        per = [float(g) for g in gathered]
+        buckets.active, acc.ddp_overlap = True, True
+        return max(per), per
+    ms, per_rank = {}, {}
+    for mode in ("local", "overlap", "deferred"):
+        ms[mode], per_rank[mode] = timed(mode)
+    # self-check: one backward from the same weights, gradients all-reduced from inside the walk vs after it -- bitwise
+    st = get_train_state(net)
+    slabs = {}
+    for overlap in (True, False):
+        acc.ddp_overlap = overlap
+        st.grad_flat.zero_()
+        fwd_bwd()
+        torch.cuda.synchronize(dev)
+        slabs[overlap] = st.grad_flat.clone()
+        order = list(buckets.last_launch_order)
+    acc.ddp_overlap = True
+    st.grad_flat.zero_()
+    same = torch.tensor([1.0 if torch.equal(slabs[True], slabs[False]) else 0.0], device=dev)
+    dist.all_reduce(same, op=dist.ReduceOp.MIN)
+    peak_gib = torch.cuda.max_memory_allocated(dev) / 2 ** 30
+    rec = {"metric": "data-parallel training images/sec (global), gradient all-reduce overlapped with backward",
+           "value": batch * world / ms["overlap"] * 1e3, "unit": "images/s", "batch_per_gpu": batch, "dtype": dtype,
+           "ms_per_step": ms["overlap"], "ms": ms, "per_rank_ms": per_rank,
+           "exposed_comm_ms": {"overlap": ms["overlap"] - ms["local"], "deferred": ms["deferred"] - ms["local"]},
+           "buckets": len(buckets.buckets), "bucket_mb": 25, "grad_slab_mb": st.grad_flat.numel() * 4 / 2 ** 20,
+           "launch_order": order, "world": world, "backend": dist.get_backend(), "avg_native": buckets.avg_native,
+           "selfcheck_bitwise": bool(float(same) == 1.0), "steps": steps, "peak_mem_gib": peak_gib,
+           "config": {"workload": f"BASELINE configs[{2 if dtype == 'fp32' else 4}]: 256x256x{c}, DDPM training step, batch {batch} per "
+                                  f"GPU x {world} ranks, {dtype}, grads all-reduced (AVG) in ~25-MB buckets from inside the backward walk"}}
+    del net, opt, slabs
+    import gc
+    gc.collect()
+    torch.cuda.empty_cache()
     return rec
 
 
@@ -582,12 +779,22 @@ def summary_of(out):
             for sub in ("second_kernel", "fused_shortcut_kernel", "fused_shortcut_two_wg_kernel"):
                 if isinstance(rf.get(sub), dict):
                     d["roofline"][sub + "_frac"] = rf[sub].get("frac")
+        if isinstance(r.get("e2e"), dict):
+            e = r["e2e"]
+            d["e2e"] = ({"error": e["error"][:160]} if "error" in e else
+                        {k: round(e[k], 3) for k in ("host_noise_images_s", "device_noise_images_s", "device_noise_vs_bare",
+                                                     "host_noise_vs_bare", "host_draw_ms", "loader_images_s",
+                                                     "decode_pool_images_s", "pil_one_thread_images_s") if k in e})
         if isinstance(r.get("step_ms_spread"), dict):
             d["step_ms_min_med_max"] = [round(r["step_ms_spread"][k], 3) for k in ("min", "median", "max")]
         return d
     s = {"headline": short(out)}
     for name, rec in (out.get("extra_records") or {}).items():
         s[name] = short(rec)
+    for name, rec in (out.get("train_ddp") or {}).items():
+        s["train_ddp_" + name] = ({"error": rec["error"][:200]} if "error" in rec else
+                                  {k: rec[k] for k in ("value", "unit", "batch_per_gpu", "world", "backend", "ms", "exposed_comm_ms",
+                                                       "buckets", "selfcheck_bitwise") if k in rec})
     if "cpu_baseline" in out:
         s["cpu_baseline"] = {k: out["cpu_baseline"][k] for k in ("value", "unit", "cores", "kind")}
     return s
@@ -665,6 +872,11 @@ def main():
                          "32/64/128/256 threads run 1.1x/2x/4.4x/36x slower)")
     ap.add_argument("--no-extras", action="store_true",
                     help="skip the extra records (mixed-precision forward, training step, small-batch sampling)")
+    ap.add_argument("--no-ddp", action="store_true", help="skip the data-parallel training record that runs whenever a process group exists")
+    ap.add_argument("--ddp-fp32-batch", type=int, default=64, help="train_ddp: BASELINE configs[2], 64 per GPU (0: skip)")
+    ap.add_argument("--ddp-bf16-batch", type=int, default=128, help="train_ddp: BASELINE configs[4], 128 per GPU (0: skip)")
+    ap.add_argument("--ddp-steps", type=int, default=3)
+    ap.add_argument("--no-e2e", action="store_true", help="skip the end-to-end (files -> loader -> train_steps) part of the training records")
     ap.add_argument("--train-fp32-batch", type=int, default=64, help="BASELINE configs[2]: 64 per GPU")
     ap.add_argument("--train-bf16-batch", type=int, default=128, help="BASELINE configs[4]: 128 per GPU")
     ap.add_argument("--mixed-batch", type=int, default=64)
@@ -702,6 +914,18 @@ def main():
         print(f"warning: --gpus {args.gpus} but WORLD_SIZE={world}", file=sys.stderr)
 
     dt, prof, per_rank, spread = gpu_leg(args, rank, world)
+    train_ddp = None
+    if torch.distributed.is_initialized() and not args.no_ddp:
+        # N > 1 (or the forced one-rank RCCL group): the data-parallel TRAINING step on every rank -- what north_star names
+        # ("RCCL all-reduce over xGMI overlapped with backward"); the inference leg above has no collective to measure
+        train_ddp = {}
+        for name, dtype, batch in (("fp32", "fp32", args.ddp_fp32_batch), ("bf16", "bf16", args.ddp_bf16_batch)):
+            if batch <= 0:
+                continue
+            try:
+                train_ddp[name] = train_ddp_leg(args, rank, world, dtype, batch, args.ddp_steps)
+            except Exception as e:  # noqa: BLE001  (reported; the other ranks fail the same way or the barrier below hangs loudly)
+                train_ddp[name] = {"error": f"{type(e).__name__}: {e}"}
     if rank == 0:
         n_img_steps = args.batch * world * args.steps
         value = n_img_steps / dt
@@ -773,6 +997,8 @@ def main():
             "kernels": prof,
             "class_notes": {k: v for k, v in CLASS_NOTES.items() if k in prof},
         }
+        if train_ddp is not None:
+            out["train_ddp"] = train_ddp
         if not args.no_extras and world == 1:  # bounded extra legs, N = 1 only; a failure is reported, never hidden
             extras = {}
             for name, fn in (("mixed_bf16", lambda: mixed_leg(args, "bf16")), ("configs3_512", lambda: cfg4_leg(args)),

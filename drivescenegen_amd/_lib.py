@@ -151,6 +151,9 @@ SIGNATURES = {
     "dsg_time_embed_fwd": [_vp, _vp, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp],
     "dsg_linear_fwd": [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _vp],
     "dsg_add_noise": [_vp, _vp, _vp, _vp, _vp, _i32, _i64, _vp],
+    "dsg_philox_u32": [_vp, _i64, C.c_uint64, C.c_uint64, _vp],
+    "dsg_philox_normal": [_vp, _i64, C.c_uint64, C.c_uint64, _vp],
+    "dsg_add_noise_philox": [_vp, _vp, _vp, _vp, _vp, _i32, _i64, C.c_uint64, C.c_uint64, _vp],
     "dsg_ddpm_step": [_vp, _vp, _vp, _vp, _i64, _f32, _f32, _f32, _f32, _f32, _f32, _vp],
     "dsg_ddim_step": [_vp, _vp, _vp, _i64, _f32, _f32, _f32, _f32, _f32, _vp],
     "dsg_postprocess": [_vp, _vp, _i32, _i32, _i32, _i32, _vp],
@@ -184,6 +187,8 @@ SIGNATURES = {
     "dsg_adamw_step": [_vp, _vp, _vp, _vp, _i64, _f64, _f64, _f64, _f64, _f64, _i64, _vp, _f32, _vp],
     "dsg_resize_normalize_u8": [_vp, _i32, _i32, _i32, _i32, _vp, _i32, _i32, _f32, _f32, _vp],
     "dsg_resize_normalize_f32": [_vp, _i32, _i32, _i32, _i32, _vp, _i32, _i32, _f32, _f32, _vp],
+    "dsg_png_probe": [C.c_char_p, C.POINTER(_i32), C.POINTER(_i32), C.POINTER(_i32)],
+    "dsg_png_decode_batch": [C.POINTER(C.c_char_p), _i32, _vp, _i32, _i32, _i32, _i32, C.POINTER(_i32)],
     "dsg_hist_u8": [_vp, _i32, _i32, _i32, _vp, _vp],
     "dsg_mask_lut_u8": [_vp, _i32, _i32, _i32, _i32, _i32, _vp, C.c_uint8, C.c_uint8, _vp, _vp],
     "dsg_prof_enable": [_i32],

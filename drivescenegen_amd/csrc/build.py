@@ -14,7 +14,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
 SOURCES = ["common.hip", "conv.hip", "groupnorm.hip", "attention.hip", "temb.hip", "scheduler.hip", "unet.hip", "prof.hip",
-           "conv_bwd.hip", "train_ops.hip", "conv_h2.hip", "conv_h2_bf16.hip", "conv_h2_f16.hip", "imageops.hip", "raster.hip", "conv_in.hip", "conv_out.hip"]
+           "conv_bwd.hip", "train_ops.hip", "conv_h2.hip", "conv_h2_bf16.hip", "conv_h2_f16.hip", "imageops.hip", "raster.hip", "conv_in.hip", "conv_out.hip", "pngdec.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fvisibility=hidden", "-Wall", "-Wno-unused-function"]
 # scheduler.hip must round every fp32 operation individually (bit parity with the reference's torch-CPU
 # expressions); the in-source pragma alone does not stop the backend from forming v_pk_fma_f32.
@@ -64,7 +64,7 @@ def build(force=False, verbose=True):
                 print(f"[dsg build] compiled {os.path.basename(src)}")
     objs = [os.path.join(bdir, s.replace(".hip", ".o")) for s in SOURCES]
     if force or jobs or not os.path.exists(LIB):
-        cmd = ["hipcc", "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs + ["-Wl,-rpath,/opt/rocm/lib"]
+        cmd = ["hipcc", "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs + ["-Wl,-rpath,/opt/rocm/lib", "-lz", "-lpthread"]
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             sys.stderr.write(r.stdout + r.stderr)

@@ -465,6 +465,25 @@ def postprocess(x, mode=0):
 # ---------------------------------------------------------------------------------------------------
 # Training-step ops (backward / loss / optimizer); see include/dsg.h "Training step"
 # ---------------------------------------------------------------------------------------------------
+def philox_u32(numel: int, seed: int, offset: int, device="cuda") -> torch.Tensor:
+    """The first `numel` uint32 (as an int32-typed tensor of raw bits) of the counter-based stream (seed, offset):
+    ``dsg_philox_u32`` -- Philox4x32-10, the generator behind ``DDPMScheduler.add_noise_device``."""
+    out = torch.empty(numel, dtype=torch.int32, device=device)
+    with torch.cuda.device(out.device):
+        _lib.check(_lib.load().dsg_philox_u32(_lib.ptr(out), numel, int(seed) & (2 ** 64 - 1), int(offset) & (2 ** 64 - 1),
+                                             _lib.stream_ptr(out.device)))
+    return out
+
+
+def philox_normal(shape, seed: int, offset: int, device="cuda") -> torch.Tensor:
+    """fp32 N(0, 1) tensor of `shape` from the counter-based stream (seed, offset) (``dsg_philox_normal``)."""
+    out = torch.empty(tuple(shape), dtype=torch.float32, device=device)
+    with torch.cuda.device(out.device):
+        _lib.check(_lib.load().dsg_philox_normal(_lib.ptr(out), out.numel(), int(seed) & (2 ** 64 - 1),
+                                                int(offset) & (2 ** 64 - 1), _lib.stream_ptr(out.device)))
+    return out
+
+
 def wgrad16_supported(c0, c1, cout, h, w, ksize=3, stride=1, upsample=False, dy_coff=0) -> bool:
     """Shapes dsg_conv2d_wgrad serves on channel-blocked 16-bit tensors (include/dsg.h); the rest goes through
     from_blocked() and the fp32 form."""

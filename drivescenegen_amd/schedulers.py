@@ -149,6 +149,28 @@ class DDPMScheduler:
                                                 _lib.ptr(out), n, per, _lib.stream_ptr(x0.device)))
         return out
 
+    def add_noise_device(self, original_samples, timesteps, seed: int, offset: int):
+        """(noisy, noise): the training step's ``noise = torch.randn(shape).to(device)`` (training_pipeline.py:72) and
+        ``add_noise(x0, noise, t)`` (:80) as ONE pass of a library kernel -- the noise is a counter-based Philox4x32-10 /
+        Box-Muller stream named by (seed, offset) (``dsg_add_noise_philox``, include/dsg.h), not the host generator's:
+        opt-in (``train_steps(..., noise="device")``), for throughput.  `noisy` is bitwise ``add_noise(x0, noise, t)``."""
+        x0 = original_samples
+        if not x0.is_cuda or x0.dtype != torch.float32:
+            raise RuntimeError("DDPMScheduler.add_noise_device runs on the MI355X HIP engine only (an fp32 GPU tensor)")
+        sa_t, sb_t = self._sqrt_tables(x0.device)
+        t = timesteps.to(x0.device).flatten()
+        n = t.numel()
+        if x0.dim() == 0 or (n != 1 and n != x0.shape[0]):
+            raise ValueError("add_noise_device: timesteps must have one entry per leading-dim sample (or one entry)")
+        sa, sb = sa_t[t].contiguous(), sb_t[t].contiguous()
+        x0c = x0.contiguous()
+        noisy, noise = torch.empty_like(x0c), torch.empty_like(x0c)
+        with torch.cuda.device(x0.device):
+            _lib.check(_lib.load().dsg_add_noise_philox(_lib.ptr(x0c), _lib.ptr(sa), _lib.ptr(sb), _lib.ptr(noisy),
+                                                       _lib.ptr(noise), n, x0c.numel() // n, int(seed) & (2 ** 64 - 1),
+                                                       int(offset) & (2 ** 64 - 1), _lib.stream_ptr(x0.device)))
+        return noisy, noise
+
     # ---- reverse step -----------------------------------------------------------------------------
     def step_scalars(self, t: int):
         """fp32 scalars of DDPMScheduler.step for timestep t, in the reference's operation order (memoised per

@@ -331,6 +331,20 @@ int dsg_ddpm_step(const float* sample, const float* eps, const float* noise /* N
 int dsg_ddim_step(const float* sample, const float* eps, float* prev, int64_t numel,
                   float sqrt_beta_prod_t, float sqrt_alpha_prod_t, float clip, float sqrt_alpha_prev,
                   float dir_coef, void* stream);
+/* Counter-based device noise: Philox4x32-10 + Box-Muller (opt-in; the default training loop keeps the reference's host draw).
+ *   replaces   training_pipeline.py:72   noise = torch.randn(batch.shape).to(device)      [a serial CPU draw + an H2D copy]
+ *         and  training_pipeline.py:80   noisy = noise_scheduler.add_noise(batch, noise, t)  in the same pass
+ * Element e of the flat tensor takes lane e % 4 of Philox4x32-10(counter = (e/4 lo, e/4 hi, offset lo, offset hi), key = (seed lo,
+ * seed hi)); lanes (0,1) and (2,3) are Box-Muller pairs: u1 = (float(r0) + 0.5f) * 2^-32, u2 = float(r1) * 2^-32,
+ * z0 = sqrt(-2 ln u1) cos(2 pi u2), z1 = ... sin(...).  The uint32 stream is bit-exact against oracle/philox_oracle.py and the
+ * Random123 known-answer vectors; the normals agree with the fp64 evaluation of the same formulas to fp32 rounding.
+ * Stateless: (seed, offset) names a tensor; the caller advances `offset` per draw.  `noisy` is bitwise
+ * dsg_add_noise(x0, noise, ...) on the `noise` this call writes. */
+int dsg_philox_u32(uint32_t* out, int64_t numel, uint64_t seed, uint64_t offset, void* stream);
+int dsg_philox_normal(float* out, int64_t numel, uint64_t seed, uint64_t offset, void* stream);
+int dsg_add_noise_philox(const float* x0, const float* sqrt_a /* device [N] */, const float* sqrt_1ma /* device [N] */,
+                         float* noisy, float* noise, int32_t n, int64_t per_sample, uint64_t seed, uint64_t offset,
+                         void* stream);
 /* Pipeline post-process (DDPMPipeline.__call__ tail, App. A.4): (x/2+0.5).clamp(0,1), NCHW -> NHWC;
  * mode 0: float out; mode 1: uint8 round (generation.py `.images`); mode 2: uint8 truncation
  * (training_pipeline.py:21-22). */
@@ -526,6 +540,18 @@ int dsg_unscale_check(float* g, int64_t numel, float inv_scale, int32_t* found_i
 int dsg_adamw_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t numel, double lr,
                    double beta1, double beta2, double eps, double weight_decay, int64_t step,
                    const float* total_norm, float max_norm, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Host-side batch PNG decoder of the training feeder (row f1; NO device work, no stream): `threads` native threads decode
+ * paths[0..n) into the rows of out[n][h][w][c] (uint8; the loader's PINNED staging buffer), status[i] = 0 or a per-file code
+ * (1 cannot open, 2 not a PNG, 3 unsupported variant, 4 shape differs from (h, w, c), 5 damaged) -- the caller reads THOSE
+ * files with PIL.   replaces   utils/datasets/dataset.py:43-45 `ToTensor(Image.open(f))` on the training thread
+ *                              scripts/train.py:35 DataLoader(num_workers=0)
+ * 8-bit non-interlaced grey / RGB / grey+alpha / RGBA; rows equal np.asarray(PIL.Image.open(f)) bit for bit.
+ * ---------------------------------------------------------------------------------------- */
+int dsg_png_probe(const char* path, int32_t* h, int32_t* w, int32_t* c);
+int dsg_png_decode_batch(const char* const* paths, int32_t n, uint8_t* out, int32_t h, int32_t w, int32_t c,
+                         int32_t threads, int32_t* status /* [n] */);
 
 /* ------------------------------------------------------------------------------------------
  * Rows next to the path.

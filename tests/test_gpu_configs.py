@@ -246,3 +246,29 @@ def test_reference_evaluate_call_750_steps_teacher_forced():
                return_dict=False)[0]
     want = (x.cpu() / 2 + 0.5).clamp(0, 1).permute(0, 2, 3, 1).numpy()
     assert img.shape == (1, 256, 256, 3) and np.array_equal(img, want)
+
+
+def test_generation_batch5_forward_vs_live_oracle_and_selection_rules():
+    """generation.py:14-20 samples at batch 5 on the train.py:39-57 network: at that batch the 32 x 32 level runs the
+    three-slice split-K with 16-row tiles and the 64 x 64 level the 64-cout slices (tuning key 36, default on; ADVICE r05: no
+    whole-net check existed at this batch).  One forward of 5 different x_t at 5 timesteps against the LIVE CPU oracle
+    (rel-L2 <= 1e-4 per row), and key 36 = 0 (the round-4 selection) gives the same eps to fp32 round-off."""
+    from drivescenegen_amd import _lib
+    net = synth_weights(d.UNet2DModel(**DEFAULT3)).to(DEV).eval().requires_grad_(False)
+    ora = synth_weights(OracleUNet2DModel(**DEFAULT3)).eval()
+    x = noisy_inputs(DEFAULT3, 5)
+    t = torch.tensor([749, 500, 250, 20, 0])
+    lib = _lib.load()
+    got = {}
+    try:
+        for on in (1, 0):
+            _lib.check(lib.dsg_set_tuning(36, on))
+            got[on] = net(x.to(DEV), t.to(DEV)).sample.cpu()
+    finally:
+        lib.dsg_set_tuning(36, 1)
+    with torch.no_grad():
+        want = ora(x, t).sample
+    for i in range(5):
+        assert rel_l2(got[1][i], want[i]) <= 1e-4, (i, rel_l2(got[1][i], want[i]))
+        assert rel_l2(got[0][i], want[i]) <= 1e-4, i
+    assert not torch.equal(got[0], got[1]) and rel_l2(got[0], got[1]) <= 2e-6

@@ -177,6 +177,41 @@ def test_fused_shortcut_under_split_k(name, shape):
     assert ((st.sum(2).cpu()[..., 0] - f64.sum((2, 3))).abs() <= 3e-6 * f64.abs().sum((2, 3)) + 1e-4).all()
 
 
+@pytest.mark.parametrize("name,shape,fused", [("b5_deep_plain", (5, 512, 512, 512, 0, 32, 32), False),
+                                              ("b5_deep_fused", (5, 512, 512, 512, 512, 32, 32), True),
+                                              ("b1_bm64_4slices", (1, 512, 256, 512, 256, 64, 64), False),
+                                              ("b1_bm64_4slices_fused", (1, 512, 256, 512, 256, 64, 64), True)])
+def test_tile_height_rule_and_64_cout_slices_keep_the_values(name, shape, fused):
+    """the selection rules of tuning key 36 are default-on and had no numeric test.  (i) batch-5 sampling at the
+    32 x 32 level (generation.py:14-20): 129..170 eight-row tiles with long K take THREE K slices of 16-row tiles (NT = 4
+    kernels, the fused-shortcut form included); (ii) batch 1 at the 64 x 64 level with >= 24 chunks of K: 64-cout workgroups with
+    four slices instead of 32-cout workgroups with two.  Key 36 = 0 is the round-4 selection.  Both settings against fp64 in
+    the split convs' round-off class, against each other to fp32 round-off (another summation order), statistics of what was
+    written -- and the rule really changes the kernel (different bits)."""
+    n, c, cout, sc0, sc1, h, w = shape
+    case = _case(n, c, cout, sc0, sc1, h, w, seed=zlib.crc32(name.encode()) % 1000)
+    ref = _ref64(*case)
+    scale = _bound_sum(case[0], case[1], case[2], case[3], case[4], case[7]) + 1e-30
+    lib = _lib.load()
+    got = {}
+    try:
+        for on in (0, 1):
+            _lib.check(lib.dsg_set_tuning(36, on))
+            got[on] = _run(*case, fused=fused, want_stats=True, splitk=True)
+    finally:
+        lib.dsg_set_tuning(36, 1)
+    assert not torch.equal(got[0][0], got[1][0]), "key 36 did not change the kernel selection for this shape"
+    for on in (0, 1):
+        y, st = got[on]
+        assert torch.isfinite(y).all()
+        assert float(((y.double() - ref).abs() / scale).max()) <= 6e-7, on
+        assert rel_l2(y, ref) <= 2e-6
+        f64 = y.double()
+        assert st is not None
+        assert ((st.sum(2).cpu()[..., 0] - f64.sum((2, 3))).abs() <= 3e-6 * f64.abs().sum((2, 3)) + 1e-4).all()
+    assert rel_l2(got[0][0], got[1][0]) <= 1e-6
+
+
 def test_shapes_that_do_not_fuse_say_so():
     n, c, cout, sc0, sc1, h, w = 1, 64, 64, 64, 0, 16, 16      # a 16-wide map is narrower than a tile
     case = _case(n, c, cout, sc0, sc1, h, w)

@@ -182,3 +182,42 @@ def test_bench_line_of_two_ranks_sharing_the_gpu():
     assert len(per) == 2 and abs(rec["ms_per_step"] - max(per)) <= 1e-6 * max(per)
     assert abs(rec["value"] - 2 * 16 * 3 / (rec["ms_per_step"] * 3e-3)) <= 1e-6 * rec["value"]
     assert rec["config"]["global_batch"] == 32
+
+
+def _ddp_record(out):
+    lines = [ln for ln in out.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, len(lines)
+    assert len(lines[0]) < 6000
+    rec = json.loads(lines[0])
+    return rec, rec["summary"]
+
+
+def test_train_ddp_record_on_a_one_rank_rccl_group():
+    """whenever a process group exists `bench.py` also emits a `train_ddp` record -- the data-parallel
+    TRAINING step through Accelerator + GradBuckets on RCCL, timed with the buckets off / overlapped / deferred, with the
+    bitwise self-check of the two modes -- so the first multi-GPU run measures the exchange north_star names.  Here: the
+    forced one-rank RCCL communicator (an average over one rank is the identity; every collective is still issued)."""
+    out = _launcher(["bench.py", "--gpus", "1", "--steps", "2", "--warmup", "1", "--no-cpu", "--no-extras", "--no-prof",
+                     "--ddp-fp32-batch", "4", "--ddp-bf16-batch", "4", "--ddp-steps", "2"], force=True)
+    rec, summ = _ddp_record(out)
+    for name in ("train_ddp_fp32", "train_ddp_bf16"):
+        r = summ[name]
+        assert "error" not in r, r
+        assert r["world"] == 1 and r["backend"] == "nccl" and r["buckets"] == 8 and r["selfcheck_bitwise"] is True
+        assert r["value"] > 0 and set(r["ms"]) == {"local", "overlap", "deferred"} and all(v > 0 for v in r["ms"].values())
+        assert abs(r["value"] - 4 * 1 / (r["ms"]["overlap"] * 1e-3)) <= 1e-6 * r["value"]
+        assert set(r["exposed_comm_ms"]) == {"overlap", "deferred"}
+
+
+def test_train_ddp_record_of_two_ranks_sharing_the_gpu():
+    """World 2 on the box's one GPU over gloo: the all-reduce really mixes two different shards' gradients (rank-specific
+    samples), both modes still give the same slab bit for bit on both ranks, the global rate counts both ranks."""
+    out = _launcher(["bench.py", "--gpus", "2", "--steps", "2", "--warmup", "1", "--no-cpu", "--no-extras", "--no-prof",
+                     "--ddp-fp32-batch", "2", "--ddp-bf16-batch", "0", "--ddp-steps", "2"], force=False,
+                    extra_env={"DSG_DIST_BACKEND": "gloo"}, nproc=2)
+    rec, summ = _ddp_record(out)
+    r = summ["train_ddp_fp32"]
+    assert "error" not in r, r
+    assert r["world"] == 2 and r["backend"] == "gloo" and r["buckets"] == 8 and r["selfcheck_bitwise"] is True
+    assert abs(r["value"] - 2 * 2 / (r["ms"]["overlap"] * 1e-3)) <= 1e-6 * r["value"]
+    assert "train_ddp_bf16" not in summ and rec["n_gpus"] == 2

@@ -21,28 +21,57 @@ def _scene_u8(n, h, w, seed):
     return np.clip(img.astype(int) + noise - 6, 0, 255).astype(np.uint8)
 
 
-@pytest.mark.parametrize("hs,ws,ho,wo", [(512, 512, 256, 256), (64, 48, 32, 32), (40, 40, 64, 96)])
-def test_f1_resize_normalize_matches_dataset(tmp_path, hs, ws, ho, wo):
-    """One kernel == ToTensor + Resize(antialias=False) + Normalize of dataset.py:21-24,43-45."""
-    from types import SimpleNamespace
+@pytest.mark.parametrize("hs,ws,ho,wo", [(512, 512, 256, 256), (64, 48, 32, 32), (40, 40, 64, 96), (37, 53, 29, 71)])
+def test_f1_resize_normalize_matches_the_oracle(tmp_path, hs, ws, ho, wo):
+    """One kernel == ToTensor + Resize(antialias=False) + Normalize of dataset.py:21-24,43-45, against oracle/dataset_oracle.py
+    (the numpy restatement; pinned to torch's F.interpolate by tests/test_oracle_kat.py) -- the kernel and the loader are
+    compared with the ORACLE, not with the product's own host feeder (VERDICT r05 hygiene)."""
     from PIL import Image
-    from drivescenegen_amd.dataset import Image_Dataset
+    from oracle.dataset_oracle import dataset_item
     imgs = _scene_u8(3, hs, ws, 4)
     for i in range(3):
         Image.fromarray(imgs[i]).save(tmp_path / f"{i}.png")
-    ds = Image_Dataset(SimpleNamespace(dataset_name=str(tmp_path / "*.png"), patterns_size_height=ho,
-                                       patterns_size_width=wo))
-    want = torch.stack([ds[i] for i in range(3)])
-    order = [int(f.split("/")[-1].split(".")[0]) for f in ds.data_list]
-    got = imageops.resize_normalize(torch.from_numpy(imgs[order]).to(DEV), (ho, wo)).cpu()
+    want = torch.from_numpy(np.stack([dataset_item(imgs[i], (ho, wo)) for i in range(3)]))
+    got = imageops.resize_normalize(torch.from_numpy(imgs).to(DEV), (ho, wo)).cpu()
     assert got.shape == want.shape
     assert float((got - want).abs().max()) <= 2e-6
-    # the loader yields the same tensors, batch by batch
-    ld = imageops.GpuImageLoader(str(tmp_path / "*.png"), (ho, wo), batch_size=2, shuffle=False)
-    assert len(ld) == 2
-    batches = [b.cpu() for b in ld]
-    assert [b.shape[0] for b in batches] == [2, 1]
-    assert float((torch.cat(batches) - torch.stack([ds[ds.data_list.index(f)] for f in ld.files])).abs().max()) <= 2e-6
+    # the loader (native PNG decode pool -> pinned ring -> H2D -> the kernel) yields the same tensors, batch by batch;
+    # so does the PIL pool (the path of every non-PNG format)
+    for kw in ({}, {"native_png": False, "workers": 2}):
+        ld = imageops.GpuImageLoader(str(tmp_path / "*.png"), (ho, wo), batch_size=2, shuffle=False, **kw)
+        assert len(ld) == 2
+        batches = [b.cpu() for b in ld]
+        assert [b.shape[0] for b in batches] == [2, 1]
+        assert float((torch.cat(batches) - want).abs().max()) <= 2e-6
+        again = [b.cpu() for b in ld]                      # a second epoch reuses the staging ring
+        assert torch.equal(torch.cat(again), torch.cat(batches))
+
+
+def test_f1_loader_keeps_order_over_many_batches_and_survives_an_early_break(tmp_path):
+    """24 files, batch 4, shuffled: every epoch is a permutation delivered in the sampler's order whatever order the decode
+    threads finish in (each image encodes its own index in its pixels); a consumer that breaks out mid-epoch leaves a loader
+    that still iterates; slots of the pinned ring are rewritten only after their H2D copy (the values would tear otherwise)."""
+    from PIL import Image
+    n = 24
+    for i in range(n):
+        a = np.full((40, 40, 3), i * 10, np.uint8)
+        a[::2, :, 1] = 255 - i
+        Image.fromarray(a).save(tmp_path / f"{i:02d}.png")
+    ld = imageops.GpuImageLoader(str(tmp_path / "*.png"), (40, 40), batch_size=4, shuffle=True, seed=3, workers=5, prefetch=2)
+    for epoch in range(2):
+        seen = []
+        for b in ld:
+            ids = torch.round((b[:, 0, 1, 0].cpu() * 0.5 + 0.5) * 255 / 10).long().tolist()
+            g = torch.round(255 - (b[:, 1, 0, 0].cpu() * 0.5 + 0.5) * 255).long().tolist()
+            assert ids == g                                    # both channels name the same file: no torn rows
+            seen += ids
+        order = np.arange(n)
+        np.random.default_rng(3 + epoch).shuffle(order)
+        assert seen == order.tolist()
+    it = iter(ld)
+    next(it)
+    it.close()                                                 # early exit: the producer runs out, nothing blocks
+    assert sum(b.shape[0] for b in ld) == n
 
 
 def test_f1_pkl_branch_matches_dataset(tmp_path):

@@ -262,3 +262,57 @@ def test_torch_oracle_agrees_with_the_independent_numpy_restatement():
         # numpy's and torch's float32 exp / cos / sin differ in the last bit.  A semantic slip shows at 1e-3 or more.)
         assert rel_l2(got, want64) <= 5e-7, rel_l2(got, want64)
         assert rel_l2(want32.double(), got) <= 2e-6                    # and the fp32 oracle is that function in fp32
+
+
+def test_philox_oracle_known_answers():
+    """oracle/philox_oracle.py against the Random123 distribution's known-answer vectors for philox4x32-10 (its `kat_vectors`
+    file: counter words, key words, expected output) -- the published algorithm the engine's device noise is built on -- and
+    the layout this project puts on top of it (element e = lane e % 4 of block e // 4; the offset in counter words 2, 3)."""
+    import numpy as np
+    from oracle import philox_oracle as po
+
+    def run(ctr, key):
+        return [int(x) for x in po.philox4x32_10(np.array(ctr, dtype=np.uint32), np.array(key, dtype=np.uint32))]
+    assert run([0, 0, 0, 0], [0, 0]) == [0x6627e8d5, 0xe169c58d, 0xbc57ac4c, 0x9b00dbd8]
+    assert run([0xffffffff] * 4, [0xffffffff] * 2) == [0x408f276d, 0x41c83b0e, 0xa20bc7c6, 0x6d5451fd]
+    assert run([0x243f6a88, 0x85a308d3, 0x13198a2e, 0x03707344], [0xa4093822, 0x299f31d0]) == [0xd16cfe09, 0x94fdcceb, 0x5001e420,
+                                                                                              0x24126ea1]
+    # the stream layout: block c of the tensor (seed, offset) is philox((c lo, c hi, offset lo, offset hi), (seed lo, seed hi))
+    seed, offset = 0x299f31d0a4093822, 0x0370734413198a2e
+    s = po.stream_u32(11, seed, offset)
+    assert [int(x) for x in s[4:8]] == run([1, 0, 0x13198a2e, 0x03707344], [0xa4093822, 0x299f31d0])
+    assert len(s) == 11 and [int(x) for x in s[8:11]] == run([2, 0, 0x13198a2e, 0x03707344], [0xa4093822, 0x299f31d0])[:3]
+    # Box-Muller on it: unit variance, no NaN at the ends of the uniform range
+    u1, u2 = po.uniforms(np.array([0, 2 ** 32 - 1], dtype=np.uint32), np.array([0, 2 ** 32 - 1], dtype=np.uint32))
+    assert u1[0] > 0 and u1[1] == 1.0 and u2[0] == 0.0 and u2[1] == 1.0
+    z = po.normals(1 << 16, 14555, 0)
+    assert np.isfinite(z).all() and abs(z.std() - 1) < 2e-2 and abs(z.mean()) < 2e-2
+
+
+def test_dataset_oracle_is_torchs_bilinear_and_the_host_feeder_agrees():
+    """oracle/dataset_oracle.py (ToTensor + Resize(antialias=False) + Normalize of utils/datasets/dataset.py:21-24,43-45,
+    restated in numpy) against torch's own ``F.interpolate(mode="bilinear", align_corners=False)`` on the CPU -- what
+    torchvision's Resize calls on a tensor -- for down-, up- and mixed scalings, and against the product's host feeder
+    ``Image_Dataset`` (row a8) on a PNG and a .pkl sample."""
+    import numpy as np
+    import torch
+    import torch.nn.functional as F
+    from oracle.dataset_oracle import dataset_item, resize_bilinear
+    rng = np.random.default_rng(0)
+    for hs, ws, ho, wo in [(512, 512, 256, 256), (64, 48, 32, 32), (40, 40, 64, 96), (37, 53, 29, 71), (100, 100, 256, 256)]:
+        x = rng.random((3, hs, ws)).astype(np.float32)
+        want = F.interpolate(torch.from_numpy(x)[None], size=(ho, wo), mode="bilinear", align_corners=False, antialias=False)[0]
+        assert float(np.abs(resize_bilinear(x, (ho, wo)) - want.numpy()).max()) <= 3e-7, (hs, ws, ho, wo)
+    import tempfile
+    from types import SimpleNamespace
+    from PIL import Image
+    from drivescenegen_amd.dataset import Image_Dataset
+    with tempfile.TemporaryDirectory() as tmp:
+        img = rng.integers(0, 256, (50, 70, 3), dtype=np.uint8)
+        fig = torch.from_numpy(rng.random((50, 70, 3)).astype(np.float32))
+        Image.fromarray(img).save(f"{tmp}/a.png")
+        torch.save({"fig_tensor": fig}, f"{tmp}/b.pkl")
+        ds = Image_Dataset(SimpleNamespace(dataset_name=f"{tmp}/*", patterns_size_height=32, patterns_size_width=48))
+        ds.data_list.sort()
+        assert float(np.abs(ds[0].numpy() - dataset_item(img, (32, 48))).max()) <= 1e-6
+        assert float(np.abs(ds[1].numpy() - dataset_item(fig.numpy(), (32, 48))).max()) <= 1e-6
