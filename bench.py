@@ -377,7 +377,7 @@ def _write_synth_pngs(folder, count, size=512, seed=14555):
     return paths
 
 
-def train_e2e(net, opt, lrs, sch, cfg, batch, dtype, bare_ms, steps=4, warm=2):
+def train_e2e(net, opt, lrs, sch, cfg, batch, dtype, bare_ms, steps=6, warm=2):
     """The training loop END TO END at the config's own batch, the way the reference runs it
     (training_pipeline.py:70-97 over train.py:34-35's loader): PNG files on disk -> `GpuImageLoader` (native decode pool,
     pinned ring, H2D on a side stream, one resize + normalise kernel: dataset.py:32-50) -> `train_loop.train_steps`

@@ -74,12 +74,14 @@ class GpuImageLoader:
 
     Host side: a batch's files are decoded in parallel, each image straight into its row of a pinned staging buffer from a
     small ring that is allocated once and reused (a slot is rewritten only after the H2D copy that read it has completed:
-    an event per slot); batches come out in the sampler's order whatever order the decodes finish in.  PNG batches go
-    through the library's own decoder (``dsg_png_decode_batch``, csrc/pngdec.hip: `workers` native threads, no GIL);
-    everything else -- other formats, .pkl samples, PNG variants the decoder leaves alone -- through a pool of `workers`
-    Python threads over PIL (which scales poorly: its chunk loop holds the GIL).  The H2D copy runs on a side stream `prefetch` batches ahead; permute +
-    resize + normalise is one HIP kernel (uint8 or float source).  One decode thread gives 145-326 images/s on 512x512
-    RGB PNGs -- below what a training step consumes (249 images/s fp32, 699 bf16); ``decode_rate()`` measures the pool.
+    an event per slot); batches come out in the sampler's order whatever order the decodes finish in.  The H2D copy and
+    the one resize + normalise kernel of a batch are issued by the producer thread on a side stream as soon as the batch is
+    decoded, `prefetch` batches ahead of the consumer.  PNG batches go through the library's own decoder
+    (``dsg_png_decode_batch``, csrc/pngdec.hip: `workers` native threads, no GIL); everything else -- other formats, .pkl
+    samples, PNG variants the decoder leaves alone -- through a pool of `workers` Python threads over PIL (which scales
+    poorly: its chunk loop holds the GIL).  One PIL thread gives 145-326 images/s on 512x512 RGB PNGs -- below what a
+    training step consumes (249 images/s fp32, 699 bf16); ``decode_rate()`` measures the pool (5800-6200 images/s with 16
+    workers on the GPU box).
 
     Under data parallelism (`rank`, `world`) it follows accelerate's prepared loader exactly like
     ``training._ShardedLoader`` (sharding.py): ONE shuffled order per epoch on every rank -- rank 0 draws the epoch's
@@ -229,24 +231,38 @@ class GpuImageLoader:
         return n / (time.perf_counter() - t0)
 
     def __iter__(self):
+        """The producer thread does everything that can run ahead of the consumer: decode into a pinned slot, H2D copy and
+        the resize + normalise kernel on the loader's side stream, an event behind them -- `prefetch` finished batches wait
+        in the queue.  The consumer only makes its stream wait for the batch's event (no copy is ever issued from the
+        training thread, none waits for the training stream)."""
         q: "queue.Queue" = queue.Queue(maxsize=self.prefetch)
         batches = self._batches()
         self.epoch += 1
         stop = threading.Event()
+        if self._copy_stream is None:
+            self._copy_stream = torch.cuda.Stream(self.device)
+        side = self._copy_stream
 
         def producer():
             try:
                 for ids in batches:
                     if stop.is_set():
                         return
-                    q.put(self._decode(ids))
+                    slot, rows = self._decode(ids)
+                    with torch.cuda.stream(side):
+                        dev = slot["buf"][:rows].to(self.device, non_blocking=True)
+                        copied = torch.cuda.Event()
+                        copied.record(side)
+                        slot["event"] = copied   # the slot is rewritten only after this copy has read it (ring of prefetch + 2)
+                        out = resize_normalize(dev, self.size)
+                        ready = torch.cuda.Event()
+                        ready.record(side)
+                    q.put((out, ready))
             except Exception as e:  # surfaced in the consumer
                 q.put(e)
             q.put(None)
 
         threading.Thread(target=producer, daemon=True).start()
-        if self._copy_stream is None:
-            self._copy_stream = torch.cuda.Stream(self.device)
         try:
             while True:
                 item = q.get()
@@ -254,15 +270,11 @@ class GpuImageLoader:
                     return
                 if isinstance(item, Exception):
                     raise item
-                slot, rows = item
-                with torch.cuda.stream(self._copy_stream):
-                    dev = slot["buf"][:rows].to(self.device, non_blocking=True)
-                    ev = torch.cuda.Event()
-                    ev.record(self._copy_stream)
-                slot["event"] = ev    # the producer waits on it before it rewrites the slot (ring of prefetch + 2)
-                torch.cuda.current_stream(self.device).wait_stream(self._copy_stream)
-                dev.record_stream(torch.cuda.current_stream(self.device))
-                yield resize_normalize(dev, self.size)
+                out, ready = item
+                cur = torch.cuda.current_stream(self.device)
+                cur.wait_event(ready)
+                out.record_stream(cur)      # (allocated on the side stream, used on the consumer's)
+                yield out
         finally:     # a consumer that stops early: let the producer run out instead of blocking on a full queue for ever
             stop.set()
             while True:

@@ -252,7 +252,9 @@ def test_generation_batch5_forward_vs_live_oracle_and_selection_rules():
     """generation.py:14-20 samples at batch 5 on the train.py:39-57 network: at that batch the 32 x 32 level runs the
     three-slice split-K with 16-row tiles and the 64 x 64 level the 64-cout slices (tuning key 36, default on; ADVICE r05: no
     whole-net check existed at this batch).  One forward of 5 different x_t at 5 timesteps against the LIVE CPU oracle
-    (rel-L2 <= 1e-4 per row), and key 36 = 0 (the round-4 selection) gives the same eps to fp32 round-off."""
+    (rel-L2 <= 1e-4 per row), and key 36 = 0 (the round-4 selection) gives the same eps BIT FOR BIT: at this batch
+    the rule changes tile HEIGHT under the same three K slices, and tile geometry never changes a bit (per-pixel summation
+    order and the 8 x 32 statistics tiles are geometry-independent by construction)."""
     from drivescenegen_amd import _lib
     net = synth_weights(d.UNet2DModel(**DEFAULT3)).to(DEV).eval().requires_grad_(False)
     ora = synth_weights(OracleUNet2DModel(**DEFAULT3)).eval()
@@ -271,4 +273,4 @@ def test_generation_batch5_forward_vs_live_oracle_and_selection_rules():
     for i in range(5):
         assert rel_l2(got[1][i], want[i]) <= 1e-4, (i, rel_l2(got[1][i], want[i]))
         assert rel_l2(got[0][i], want[i]) <= 1e-4, i
-    assert not torch.equal(got[0], got[1]) and rel_l2(got[0], got[1]) <= 2e-6
+    assert torch.equal(got[0], got[1])

@@ -186,8 +186,9 @@ def test_tile_height_rule_and_64_cout_slices_keep_the_values(name, shape, fused)
     32 x 32 level (generation.py:14-20): 129..170 eight-row tiles with long K take THREE K slices of 16-row tiles (NT = 4
     kernels, the fused-shortcut form included); (ii) batch 1 at the 64 x 64 level with >= 24 chunks of K: 64-cout workgroups with
     four slices instead of 32-cout workgroups with two.  Key 36 = 0 is the round-4 selection.  Both settings against fp64 in
-    the split convs' round-off class, against each other to fp32 round-off (another summation order), statistics of what was
-    written -- and the rule really changes the kernel (different bits)."""
+    the split convs' round-off class and the statistics of what was written.  Rule (i) changes tile HEIGHT under the same
+    three slices: bit-identical by construction (tile geometry never changes a bit); rule (ii) changes the number of K slices:
+    another summation order, equal to fp32 round-off and really different bits."""
     n, c, cout, sc0, sc1, h, w = shape
     case = _case(n, c, cout, sc0, sc1, h, w, seed=zlib.crc32(name.encode()) % 1000)
     ref = _ref64(*case)
@@ -200,7 +201,10 @@ def test_tile_height_rule_and_64_cout_slices_keep_the_values(name, shape, fused)
             got[on] = _run(*case, fused=fused, want_stats=True, splitk=True)
     finally:
         lib.dsg_set_tuning(36, 1)
-    assert not torch.equal(got[0][0], got[1][0]), "key 36 did not change the kernel selection for this shape"
+    if n == 5:
+        assert torch.equal(got[0][0], got[1][0]) and torch.equal(got[0][1], got[1][1])
+    else:
+        assert not torch.equal(got[0][0], got[1][0]), "key 36 did not change the K slicing of this shape"
     for on in (0, 1):
         y, st = got[on]
         assert torch.isfinite(y).all()
