@@ -50,6 +50,7 @@ class ConvArgs(C.Structure):
         ("sc_src0", C.c_void_p), ("sc_src1", C.c_void_p), ("sc_c0", C.c_int32), ("sc_c1", C.c_int32),
         ("sc_weight_h2", C.c_void_p), ("sc_bias", C.c_void_p), ("sc_src_bound", C.c_void_p), ("sc_src_bound1", C.c_void_p),
         ("src_operand", C.c_void_p),
+        ("gnb_x0", C.c_void_p), ("gnb_x1", C.c_void_p), ("gnb_c0", C.c_int32), ("gnb_ss", C.c_void_p), ("gnb_silu", C.c_int32),
     ]
 
 
@@ -119,6 +120,10 @@ SIGNATURES = {
     "dsg_gn_bwd_blocked_add2": [_vp, _i32, _vp, _i32, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp,
                                 _vp, _vp, _vp, _i32, _vp],
     "dsg_gn_bwd_blocked_splits": [_i32],
+    "dsg_gn_bwd_parts": [_vp, _i32, _vp, _i32, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp,
+                         _vp, _vp, _vp, _i32, _vp],
+    "dsg_gn_bwd_blocked_parts": [_vp, _i32, _vp, _i32, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp,
+                                 _vp, _vp, _vp, _i32, _vp, _i32, _vp],
     "dsg_channel_sums_blocked": [_vp, _i32, _i32, _i32, _vp, _i32, _i32, _vp],
     "dsg_add_dt": [_vp, _vp, _i64, _vp, _i32, _vp],
     "dsg_upsample_nearest2x_blocked": [_vp, _vp, _i64, _i32, _i32, _i32, _vp],
@@ -133,6 +138,7 @@ SIGNATURES = {
     "dsg_conv2d_fwd": [C.POINTER(ConvArgs), _vp],
     "dsg_conv2d_fuses_shortcut": [C.POINTER(ConvArgs), C.POINTER(_i32)],
     "dsg_conv2d_takes_operand": [C.POINTER(ConvArgs), C.POINTER(_i32)],
+    "dsg_conv2d_gnb_supported": [C.POINTER(ConvArgs), C.POINTER(_i32)],
     "dsg_conv_operand_bytes": [_i32, _i32, _i32, _i32, _i32, C.POINTER(_sz)],
     "dsg_conv_operand_prepare": [_vp, _i32, _vp, _i32, _i32, _i32, _i32, _vp, _i32, _vp, _vp, _vp, _i32, _vp],
     "dsg_layout_convert": [_vp, _vp, _i32, _i32, _i32, _i32, _vp],

@@ -431,12 +431,20 @@ def _backward(model, st: TrainState, tape: _Tape, dout):
             up_mode = 2 if rec["stride"] == 2 else 0
             whd = rec["whd"] if (rec["stride"] == 1 and not rec["ups"]) else None  # the split kernel has no pool / zero-stuff mode
             if rec["gn"] is not None:
-                da = st.lazy_w(wdn, "wd", lambda wd: ops.conv2d_fused(dy, wd, ksize=k, upsample=up_mode, cout=cin0 + cin1,
-                                                                       pool2=rec["ups"], weight_h2=whd))
+                # the norm's backward statistics (sum du, sum du * x per tile) come out of the data-gradient conv's epilogue where
+                # its kernel has that form (dsg_conv_args.gnb_*): the pass over x and dA that computed them is not run
+                gnb = dict(x0=x0, x1=x1, ss=rec["ss"], silu=rec["silu"]) if (whd is not None and up_mode == 0 and not rec["ups"]) else None
+
+                def dgrad_gn(wd):
+                    kw = dict(ksize=k, upsample=up_mode, cout=cin0 + cin1, pool2=rec["ups"], weight_h2=whd)
+                    if gnb is not None and ops.conv2d_fused(dy, wd, gnb=dict(gnb, query_only=True), **kw):
+                        return ops.conv2d_fused(dy, wd, gnb=gnb, want_stats=True, **kw)
+                    return ops.conv2d_fused(dy, wd, **kw), None
+                da, parts = st.lazy_w(wdn, "wd", dgrad_gn)
                 gnn = rec["gn"]
                 dx0, dx1 = ops.gn_bwd(x0, da, rec["ss"], rec["mr"], P[gnn + ".weight"].detach(), groups, rec["silu"],
                                       st.grad(gnn + ".weight"), st.grad(gnn + ".bias"), src1=x1, add0=tape.g(x0),
-                                      add1=tape.g(x1) if x1 is not None else None)
+                                      add1=tape.g(x1) if x1 is not None else None, parts=parts)
                 done(gnn + ".weight", gnn + ".bias")
                 tape.setg(x0, dx0)
                 if x1 is not None:
@@ -948,14 +956,18 @@ def _backward16(model, st: TrainState, tape: _Tape, dout):
                            upsample=ups, gn_scale_shift=ss, silu=silu, cout=co, dy_coff=dy_coff)
             return False
 
-    def dgrad(dy, wname, k, cout, stride=1, residual=None, col0=0, ncols=None, dst_blocked=True):
-        """dX = conv(dY, W^T flipped) for columns [col0, col0 + ncols) of the conv's input channels; + residual."""
+    def dgrad(dy, wname, k, cout, stride=1, residual=None, col0=0, ncols=None, dst_blocked=True, gnb=None):
+        """dX = conv(dY, W^T flipped) for columns [col0, col0 + ncols) of the conv's input channels; + residual.
+        gnb (dict(x0=, x1=, ss=, silu=)): the conv sits behind a GroupNorm -- returns (dX, parts): parts = the norm's backward
+        statistics from the kernel's epilogue (dsg_conv_args.gnb_*) where the call's kernel has that form, else None."""
         wd_stride = ops._pad32(cout) + 64   # row length of the fp32 data-gradient layout (st.wd_of)
         ncols = ncols or cout
         full = col0 == 0 and ncols == cout
         src_blocked = blocked(dy)
         kdim = chans(dy)
         use16 = kdim % 16 == 0 and ncols % 8 == 0 and (src_blocked or dst_blocked) and (full or (col0 % 8 == 0 and ncols % 64 == 0))
+        if stride == 2 and gnb is not None:
+            return dgrad(dy, wname, k, cout, stride, residual, col0, ncols, dst_blocked), None
         if stride == 2:   # the adjoint of the space-to-depth conv: four 2x2 phase convs of the low-resolution dY
             ok = use16 and full and src_blocked and dst_blocked and dy.shape[3] % 32 == 0 and dy.shape[2] % 8 == 0
             if ok:
@@ -966,10 +978,19 @@ def _backward16(model, st: TrainState, tape: _Tape, dout):
                                  residual=None if residual is None else f32(residual))
             return ops.to_blocked(g, dt)
         if use16:
-            return st.lazy_w(wname, "wd", lambda wd: ops.conv2d_fused(
-                dy, wd if (full or wd is None) else wd[:, :, col0:], ksize=k, cout=ncols, residual=residual,
-                wstride=None if full else wd_stride, src_blocked=src_blocked, dst_blocked=dst_blocked, compute_dtype=dt,
-                weight_h2=packs.get(wname, ops.PACK_DGRAD), weight_h2_col=col0, weight_h2_stride=_pad64(cout)))
+            def run16(wd):
+                kw = dict(ksize=k, cout=ncols, residual=residual, wstride=None if full else wd_stride, src_blocked=src_blocked,
+                          dst_blocked=dst_blocked, compute_dtype=dt, weight_h2=packs.get(wname, ops.PACK_DGRAD),
+                          weight_h2_col=col0, weight_h2_stride=_pad64(cout))
+                w = wd if (full or wd is None) else wd[:, :, col0:]
+                if gnb is None:
+                    return ops.conv2d_fused(dy, w, **kw)
+                if full and residual is None and ops.conv2d_fused(dy, w, gnb=dict(gnb, query_only=True), **kw):
+                    return ops.conv2d_fused(dy, w, gnb=gnb, want_stats=True, **kw)
+                return ops.conv2d_fused(dy, w, **kw), None
+            return st.lazy_w(wname, "wd", run16)
+        if gnb is not None:   # (the fp32 detours below have no such epilogue)
+            return dgrad(dy, wname, k, cout, stride, residual, col0, ncols, dst_blocked), None
         # no 16-bit kernel for this shape (conv_out's 8-channel dY, narrow channel windows): the fp32 kernels
         wd = st.wd_of(wname)
         if not src_blocked and dst_blocked and full and k == 3:   # fp32 [N,C,H,W] dY -> 16-bit blocked dX directly
@@ -1018,12 +1039,13 @@ def _backward16(model, st: TrainState, tape: _Tape, dout):
                 tape.setg(x0, ops.sumpool2x2(dfull, add=tape.g(x0)))
                 continue
             if rec["gn"] is not None:
-                da = dgrad(dy, wn, k, cin0 + cin1, stride=rec["stride"])
+                da, parts = dgrad(dy, wn, k, cin0 + cin1, stride=rec["stride"],
+                                  gnb=dict(x0=x0, x1=x1, ss=rec["ss"], silu=rec["silu"]))
                 gnn = rec["gn"]
                 a0, a0b = tape.g2(x0)
                 dx0, dx1 = ops.gn_bwd_blocked(x0, da, rec["ss"], rec["mr"], P[gnn + ".weight"].detach(), groups, rec["silu"],
                                               st.grad(gnn + ".weight"), st.grad(gnn + ".bias"), src1=x1, add0=a0, add0b=a0b,
-                                              add1=tape.g(x1) if x1 is not None else None)
+                                              add1=tape.g(x1) if x1 is not None else None, parts=parts)
                 done(gnn + ".weight", gnn + ".bias")
                 tape.setg(x0, dx0)
                 if x1 is not None:

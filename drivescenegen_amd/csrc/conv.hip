@@ -481,6 +481,8 @@ void conv_h2_set_pre(int v);
 void conv_h2_set_narrow(int v);
 void conv_h2_set_splitk_mid(int v);
 void conv_h2_set_rows_rule(int v);
+void conv_h2_set_gnb(int v);
+bool conv_h2_gnb_ok(const dsg_conv_args* a, int hout, int wout);
 void conv_h2_set_pre_min_ct(int v);
 bool conv_h2_takes_operand(const dsg_conv_args* a, int hout, int wout, bool wanted);
 void attention_set_blocked(int v);
@@ -760,6 +762,14 @@ int conv2d_fwd_impl(const dsg_conv_args* a, hipStream_t st, int force_direct) {
     DSG_CHECK_SHAPE(!force_direct && conv_h2_takes_operand(a, p.hout, p.wout, false),
                     "dsg_conv2d_fwd: this call's kernel stages its own patch (dsg_conv2d_takes_operand reports 0): pass "
                     "src_operand = NULL");
+  if (a->gnb_x0 != nullptr) {  // GroupNorm-backward statistics: only the split-path kernels with that epilogue serve the call
+    DSG_CHECK_ARG(a->gnb_ss != nullptr && a->stats_out != nullptr && (a->gnb_x1 == nullptr || a->gnb_c0 > 0),
+                  "dsg_conv2d_fwd: gnb_x0 needs gnb_ss and stats_out (and gnb_c0 with gnb_x1)");
+    DSG_CHECK_SHAPE(!force_direct && conv_h2_gnb_ok(a, p.hout, p.wout),
+                    "dsg_conv2d_fwd: this call's kernel has no GroupNorm-backward epilogue (dsg_conv2d_gnb_supported reports 0): "
+                    "pass gnb_x0 = NULL and run the statistics pass");
+    return conv_h2_launch(a, p.hout, p.wout, st);
+  }
   if (a->sc_weight_h2 != nullptr) {  // fused shortcut: only the split-path kernel that contracts it serves the call
     DSG_CHECK_ARG(a->sc_src0 != nullptr && a->sc_c0 > 0 && a->sc_c1 >= 0 && (a->sc_c1 == 0) == (a->sc_src1 == nullptr) &&
                       a->residual == nullptr,
@@ -935,6 +945,10 @@ static int set_tuning_impl(int32_t key, int32_t value) {
     dsg::conv_h2_set_rows_rule(value);
     return DSG_OK;
   }
+  if (key == 37 && (value == 0 || value == 1)) {
+    dsg::conv_h2_set_gnb(value);
+    return DSG_OK;
+  }
   if (key == 31 && (value == 0 || value == 1)) {
     dsg::wgrad_h2_set_wide(value);
     return DSG_OK;
@@ -1018,6 +1032,15 @@ DSG_API int dsg_conv2d_fuses_shortcut(const dsg_conv_args* a, int32_t* yes) {
   if (a->sc_weight_h2 == nullptr || a->sc_src0 == nullptr || a->sc_c0 <= 0 || a->ksize != 3 || a->stride != 1 || a->upsample)
     return DSG_OK;
   *yes = dsg::conv_h2_sc_fusable(a, a->hin, a->win) ? 1 : 0;
+  return DSG_OK;
+}
+
+DSG_API int dsg_conv2d_gnb_supported(const dsg_conv_args* a, int32_t* yes) {
+  DSG_CHECK_ARG(a != nullptr && yes != nullptr, "dsg_conv2d_gnb_supported: NULL pointer");
+  *yes = 0;
+  if (a->gnb_x0 == nullptr || a->ksize != 3 || a->stride != 1 || a->upsample) return DSG_OK;
+  if (a->splitk_ws != nullptr && a->compute_dtype == DSG_F32 && a->src_layout == 1 && a->dst_layout == 1) return DSG_OK;
+  *yes = dsg::conv_h2_gnb_ok(a, a->hin, a->win) ? 1 : 0;
   return DSG_OK;
 }
 

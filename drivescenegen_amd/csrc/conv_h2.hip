@@ -304,6 +304,40 @@ int splitk_reduce_launch(const float* part, int slices, const dsg_conv_args* a, 
   return DSG_OK;
 }
 
+bool conv_h16_bm128(const dsg_conv_args* a, int hout, int wout, bool* r16) {
+  const int cout_pad = (a->cout + 63) / 64 * 64;
+  if (!g_h2.bm128 || cout_pad % 128 != 0 || wout % H2_TW != 0) return false;
+  const int per_row = (wout / H2_TW) * a->n * (cout_pad / 128);
+  *r16 = hout % 16 == 0 && per_row * (hout / 16) >= H2_CUS;
+  return per_row * (hout / (*r16 ? 16 : 8)) >= H2_CUS;
+}
+
+bool conv_h2_gnb_ok(const dsg_conv_args* a, int hout, int wout) {
+  if (!g_h2.enabled || !g_h2.gnb || !g_h2.stats || !conv_h2_eligible(a, hout, wout)) return false;
+  if (a->ksize != 3 || a->stride != 1 || a->upsample || a->pool2 || a->gn_scale_shift || a->sc_weight_h2 || a->src_operand ||
+      a->residual || a->weight_h2 == nullptr || wout % H2_TW != 0 || hout % 8 != 0 || a->gnb_ss == nullptr)
+    return false;
+  const int lay = (a->src_layout ? 1 : 0) | (a->dst_layout ? 2 : 0);
+  const bool h16 = a->compute_dtype != DSG_F32;
+  if (h16 ? lay != 3 : lay != 0) return false;
+  if (g_h2.waves == 8) return false;  // (the eight-wave A/B geometry has no GNB instantiation)
+  int bm = H2_BM;
+  if (h16) {
+    bool r16 = false;
+    if (conv_h16_bm128(a, hout, wout, &r16)) bm = 128;
+    else {  // the launcher's 32-cout workgroups for small grids have no GNB form
+      const int cout_pad = (a->cout + 63) / 64 * 64;
+      const bool nt4 = conv_h2_rows16(a, hout, wout);
+      const int grid = (wout / H2_TW) * (hout / (nt4 ? 16 : 8)) * a->n * (cout_pad / H2_BM);
+      if (g_h2.bm32_small && !nt4 && grid <= H2_CUS / 2) return false;
+      if (g_h2.bm32 && a->c0 + a->c1 <= 128 && grid >= g_h2.bm32_min) return false;
+    }
+  }
+  // every channel tile inside one of the two x tensors
+  if (a->gnb_x1 != nullptr && (a->gnb_c0 <= 0 || a->gnb_c0 >= a->cout || a->gnb_c0 % bm != 0)) return false;
+  return true;
+}
+
 int conv_h2_stats_tiles(const dsg_conv_args* a, int hout, int wout) {
   if (!g_h2.stats || !conv_h2_eligible(a, hout, wout)) return 0;
   if (a->splitk_ws) {  // the split-K path's reduce pass writes its own (coarser) partials
@@ -340,6 +374,7 @@ void conv_h2_set_pre(int v) { g_h2.pre = v; ++g_h2.epoch; }
 void conv_h2_set_narrow(int v) { g_h2.narrow = v; ++g_h2.epoch; }
 void conv_h2_set_splitk_mid(int v) { g_h2.splitk_mid = v; ++g_h2.epoch; }
 void conv_h2_set_rows_rule(int v) { g_h2.rows_rule = v; ++g_h2.epoch; }
+void conv_h2_set_gnb(int v) { g_h2.gnb = v; ++g_h2.epoch; }
 void conv_h2_set_pre_min_ct(int v) { g_h2.pre_min_ct = v > 0 ? v : 1; ++g_h2.epoch; }
 int conv_h2_get_fuse_sc() { return g_h2.fuse_sc; }
 int conv_in_tuning_epoch();  // conv_in.hip: its on/off switch moves the plan's statistics buffers too

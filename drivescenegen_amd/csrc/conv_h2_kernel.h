@@ -81,6 +81,19 @@ struct ConvH2P {
   // zero border, so a tile's halo patch is DMA'd to LDS as it is (no registers, no VALU, no bounds logic).
   const void* pre;
   size_t pre_piece_stride;  // bytes between the two pieces
+  // GroupNorm-backward statistics from the data-gradient conv's epilogue (GNB kernels).  The conv writes dA, the gradient
+  // w.r.t. the ACTIVATED tensor a = silu(x * sc + sh) that the forward conv read; the norm's backward needs, per (n, c),
+  // S1 = sum du and S2 = sum du * xhat with du = dA * silu'(x * sc + sh) -- a pass of its own over x and dA
+  // (gn_bwd_stats*_kernel: 6.3 % of the bf16 training step, 3.9 % of the fp32 one).  Here the epilogue, which holds dA in
+  // registers, reads the pre-norm x of its tile (layout and shape of dst; the channel tile lies in ONE of the two concatenated
+  // sources: the host checks) and the (sc, sh) of its channels, and leaves per-tile partials (sum du, sum du * x) in `stats`
+  // -- the forward statistics' table, [n][cout][tiles][2] -- RAW second moment: xhat = (x - mean) * rstd is applied to the sums
+  // by gnb_parts_reduce_kernel in fp64.  x is read once more, the statistics pass's two reads disappear.
+  const void* gnb_x0;
+  const void* gnb_x1;
+  int gnb_c0;            // channels of gnb_x0 (the rest, cout - gnb_c0, are gnb_x1's)
+  const float* gnb_ss;   // [n][cout][2] (scale, shift) of the norm
+  int gnb_silu;
 };
 
 constexpr int H2_TW = 32, H2_KC = 16, H2_BM = 64;
@@ -141,6 +154,12 @@ __device__ __forceinline__ const char* sgpr_ptr(const char* p) {
 }
 
 __device__ __forceinline__ float silu_fast_h(float x) { return x * __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
+// d/du (u * sigmoid(u)), the arithmetic of train_ops.hip's dsilu (hardware exp / reciprocal): the GNB epilogue's statistics are in
+// the rounding class of the standalone statistics pass
+__device__ __forceinline__ float dsilu_fast(float u) {
+  const float s = __builtin_amdgcn_rcpf(1.0f + __expf(-u));
+  return s * (1.0f + u * (1.0f - s));
+}
 
 // GM: 3 STRIDE-2 3x3 conv (Downsample2D) as a 2x2 conv over the space-to-depth image, which for channel-blocked
 // sources is pure addressing: k-group (cb, py, px) of the 4C "channels" is channel block cb read at pixels
@@ -184,8 +203,10 @@ __device__ __forceinline__ float silu_fast_h(float x) { return x * __builtin_amd
 //      channel block is the only per-lane quantity, computed once per tile), so the loop is MFMAs + fragment reads + ~20
 //      DMA issues per chunk.  For the deep levels, where cout / 64 workgroups would each re-normalise, re-activate and
 //      re-split the same patch (the loop measured 1020 cycles per tap against 755 with nothing staged).
-template <int GM, int NT, int KS, int ACT = 3, int NW = 4, int OCC = 1, int LAY = 0, int BM = 64, int PREC = 0, int WS = 0, int SC = 0, int PRE = 0>
+template <int GM, int NT, int KS, int ACT = 3, int NW = 4, int OCC = 1, int LAY = 0, int BM = 64, int PREC = 0, int WS = 0, int SC = 0, int PRE = 0, int GNB = 0>
 __global__ __launch_bounds__(64 * NW, OCC * NW / 4) void conv_h2_kernel(ConvH2P p) {
+  static_assert(!GNB || (KS == 3 && GM == 0 && ACT == 0 && !SC && !PRE && !WS),
+                "GroupNorm-backward statistics: the plain stride-1 3x3 data-gradient conv");
   static_assert(!WS || KS == 3, "the one-slab layout is for the 3x3 kernels");
   static_assert(!SC || (KS == 3 && GM == 0 && (ACT == 2 || PRE) && LAY == 3),
                 "fused shortcut: plain 3x3 conv2 of a resnet, channel-blocked tensors");
@@ -1035,7 +1056,7 @@ __global__ __launch_bounds__(64 * NW, OCC * NW / 4) void conv_h2_kernel(ConvH2P 
   // element.  The residual values of a 32-channel slab are all in flight before the first use (with one wave per
   // SIMD a load->add->store chain per element would expose the memory latency 64 times).
   // (the host only dispatches here when cout % 8 == 0, so a 4-row half-group is never split by cout)
-  const bool has_r = p.res != nullptr;
+  const bool has_r = GNB ? true : p.res != nullptr;   // (GNB: the "residual" slot carries the pre-norm x, read but not added)
   const int oscale = GM == 2 ? 2 : 1;  // folded mode: the output map is twice the tiled (low-resolution) grid
   const int oplane = p.hout * p.wout * oscale * oscale;
 #ifdef DSG_H2_TIMING_NOSTATS
@@ -1063,8 +1084,18 @@ __global__ __launch_bounds__(64 * NW, OCC * NW / 4) void conv_h2_kernel(ConvH2P 
   const int range = nvalid * oplane * ESD;
   char* dstb = static_cast<char*>(p.dst) + (size_t)blockIdx.y * p.split_stride;
   const __amdgpu_buffer_rsrc_t dst_rs = __builtin_amdgcn_make_buffer_rsrc(dstb + tile_off, 0, range, 0x00020000);
+  const char* res_base = static_cast<const char*>(p.res);
+  size_t res_off = tile_off;
+  if constexpr (GNB) {  // this channel tile's rows of x: in gnb_x0 (gnb_c0 channels per image) or gnb_x1 (the rest)
+    const bool in0 = m0 < p.gnb_c0;
+    res_base = static_cast<const char*>(in0 ? p.gnb_x0 : p.gnb_x1);
+    res_off = ((size_t)n * (in0 ? p.gnb_c0 : p.cout - p.gnb_c0) + (in0 ? m0 : m0 - p.gnb_c0)) * oplane * ESD;
+  }
   const __amdgpu_buffer_rsrc_t res_rs = __builtin_amdgcn_make_buffer_rsrc(
-      has_r ? const_cast<char*>(static_cast<const char*>(p.res)) + tile_off : dstb, 0, has_r ? range : 0, 0x00020000);
+      has_r ? const_cast<char*>(res_base) + res_off : dstb, 0, has_r ? range : 0, 0x00020000);
+  const __amdgpu_buffer_rsrc_t gss_rs = __builtin_amdgcn_make_buffer_rsrc(
+      GNB ? const_cast<float*>(p.gnb_ss + ((size_t)n * p.cout + m0) * 2) : reinterpret_cast<float*>(dstb), 0,
+      GNB ? nvalid * 8 : 0, 0x00020000);
   const __amdgpu_buffer_rsrc_t bias_rs = __builtin_amdgcn_make_buffer_rsrc(
       p.bias ? const_cast<float*>(p.bias + m0) : reinterpret_cast<float*>(dstb), 0, p.bias ? nvalid * 4 : 0, 0x00020000);
   const __amdgpu_buffer_rsrc_t temb_rs = __builtin_amdgcn_make_buffer_rsrc(
@@ -1116,6 +1147,17 @@ __global__ __launch_bounds__(64 * NW, OCC * NW / 4) void conv_h2_kernel(ConvH2P 
         if constexpr (SC)
           addv[r] += __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(scb_rs, 16 * half, crel * 4, 0));
       }
+      float gsc[GNB ? 16 : 1], gsh[GNB ? 16 : 1];  // GNB: the norm's (scale, shift) of this lane's 16 channels of the slab
+      if constexpr (GNB) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+          const int crel = mt * 32 + (r & 3) + 8 * (r >> 2);
+          const u32x2 q = __builtin_amdgcn_raw_buffer_load_b64(gss_rs, 32 * half, crel * 8, 0);
+          gsc[r] = __builtin_bit_cast(float, q.x);
+          gsh[r] = __builtin_bit_cast(float, q.y);
+        }
+      }
       if (has_r) {
         if constexpr (DB) {
 #pragma unroll
@@ -1161,12 +1203,13 @@ __global__ __launch_bounds__(64 * NW, OCC * NW / 4) void conv_h2_kernel(ConvH2P 
 #pragma unroll
           for (int nt = 0; nt < NT; ++nt) {
             const int r = 4 * rg + j;
+            const float radd = GNB ? 0.f : rv[r][nt];
             if constexpr (NP == 2 && (ACT != 2 || SC))
-              vv[j][nt] = ((acc_hi[mt][nt][r] + acc_lo[mt][nt][r] * (1.0f / 2048.0f)) * ep_scale + addv[r]) + rv[r][nt];
+              vv[j][nt] = ((acc_hi[mt][nt][r] + acc_lo[mt][nt][r] * (1.0f / 2048.0f)) * ep_scale + addv[r]) + radd;
             else if constexpr (NP == 2)
-              vv[j][nt] = ((acc_hi[mt][nt][r] + acc_lo[mt][nt][r] * (1.0f / 2048.0f)) + addv[r]) + rv[r][nt];
+              vv[j][nt] = ((acc_hi[mt][nt][r] + acc_lo[mt][nt][r] * (1.0f / 2048.0f)) + addv[r]) + radd;
             else
-              vv[j][nt] = (acc_hi[mt][nt][r] + addv[r]) + rv[r][nt];
+              vv[j][nt] = (acc_hi[mt][nt][r] + addv[r]) + radd;
           }
         if constexpr (DB) {  // the group is 16 contiguous bytes of the pixel's channel block
 #pragma unroll
@@ -1203,10 +1246,25 @@ __global__ __launch_bounds__(64 * NW, OCC * NW / 4) void conv_h2_kernel(ConvH2P 
           for (int j = 0; j < 4; ++j) {
 #pragma unroll
             for (int pr = 0; pr < NT / 2; ++pr) {  // one partial per pair of rows: the same summation tree for any NT
-              const float a = (NARROW && !lane_ok) ? 0.f : vv[j][2 * pr], b = (NARROW && !lane_ok) ? 0.f : vv[j][2 * pr + 1];
+              float a = (NARROW && !lane_ok) ? 0.f : vv[j][2 * pr], b = (NARROW && !lane_ok) ? 0.f : vv[j][2 * pr + 1];
               const int v = ((rg * 4 + j) * (NT / 2) + pr) * 2;
-              stab[stab_sw[v & 3] + v * 64] = a + b;
-              stab[stab_sw[(v + 1) & 3] + (v + 1) * 64] = __builtin_fmaf(a, a, b * b);  // (explicit: every instantiation must round alike)
+              if constexpr (GNB) {  // (sum du, sum du * x) of the row pair, du = dA * silu'(x * sc + sh), dA as it is STORED
+                const int r = 4 * rg + j;
+                const float xa = rv[r][2 * pr], xb = rv[r][2 * pr + 1];
+                if constexpr (ESD == 2) {
+                  a = lo16<PREC>(pack2<PREC>(a, 0.f));
+                  b = lo16<PREC>(pack2<PREC>(b, 0.f));
+                }
+                if (p.gnb_silu) {
+                  a *= dsilu_fast(__builtin_fmaf(xa, gsc[r], gsh[r]));
+                  b *= dsilu_fast(__builtin_fmaf(xb, gsc[r], gsh[r]));
+                }
+                stab[stab_sw[v & 3] + v * 64] = a + b;
+                stab[stab_sw[(v + 1) & 3] + (v + 1) * 64] = __builtin_fmaf(a, xa, b * xb);
+              } else {
+                stab[stab_sw[v & 3] + v * 64] = a + b;
+                stab[stab_sw[(v + 1) & 3] + (v + 1) * 64] = __builtin_fmaf(a, a, b * b);  // (explicit: every instantiation must round alike)
+              }
             }
           }
         }

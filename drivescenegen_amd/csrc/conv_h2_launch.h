@@ -35,6 +35,7 @@ struct H2Tuning {
   int pre_min_ct = 16;  // ... (key 27: the threshold.  Measured, profiles/r03_operand_ablation.txt: at 4 -- every conv of the 256- / 512-channel
                         // levels -- the convs gain 8.5 % and the prepare passes cost what they gain; at 16 only the folded up-samplers of
                         // those levels qualify, whose patch is staged by 16-32 workgroups)
+  int gnb = 1;          // GroupNorm-backward statistics from the data-gradient conv's epilogue (key 37: A/B against the statistics pass)
   int rows_rule = 1;    // round 5's additions to the rows rule: 16-row tiles under three-slice split-K, 0.62 for the four-tap kernels (key 36)
   int epoch = 0;        // bumped by every change: plans key their cached workspace sizes on it
 };
@@ -56,12 +57,17 @@ int conv_h2_splitk_slices(const dsg_conv_args* a, int hout, int wout, int* stat_
 // does the call's kernel read a pre-staged operand image (dsg_conv_args.src_operand)?  `wanted`: also apply the launcher's own
 // pays-off rule (cout tiles per patch); without it the answer is "can", which is what a call that brings an image needs
 bool conv_h2_takes_operand(const dsg_conv_args* a, int hout, int wout, bool wanted);
+// GroupNorm-backward statistics from the epilogue (dsg_conv_args.gnb_*): does the kernel this call would launch have the GNB form,
+// and does every channel tile of it lie in ONE of the two x tensors?  (tuning key 37 = 0: never -- the A/B switch)
+bool conv_h2_gnb_ok(const dsg_conv_args* a, int hout, int wout);
+// 16-bit modes: does the call take 128-cout workgroups, and with 16-row tiles?  (shared by the launcher and conv_h2_gnb_ok)
+bool conv_h16_bm128(const dsg_conv_args* a, int hout, int wout, bool* r16);
 int splitk_reduce_launch(const float* part, int slices, const dsg_conv_args* a, int hout, int wout, int stat_splits,
                          hipStream_t st);
 
-template <int GM, int NT, int KS, int ACT, int NW = 4, int OCC = 1, int LAY = 0, int BM = 64, int PREC = 0, int WS = 0, int SC = 0, int PRE = 0>
+template <int GM, int NT, int KS, int ACT, int NW = 4, int OCC = 1, int LAY = 0, int BM = 64, int PREC = 0, int WS = 0, int SC = 0, int PRE = 0, int GNB = 0>
 static int h2_launch(dim3 grid, size_t lds, hipStream_t st, const ConvH2P& p) {
-  auto kern = conv_h2_kernel<GM, NT, KS, ACT, NW, OCC, LAY, BM, PREC, WS, SC, PRE>;
+  auto kern = conv_h2_kernel<GM, NT, KS, ACT, NW, OCC, LAY, BM, PREC, WS, SC, PRE, GNB>;
   static bool raised = false;
   if (!raised) {
     DSG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -122,6 +128,10 @@ int conv_h2_launch_t(const dsg_conv_args* a, int hout, int wout, hipStream_t st)
   const bool sc = a->sc_weight_h2 != nullptr;
   p.sc_src0 = p.sc_src1 = p.sc_wh = nullptr; p.sc_bias = nullptr; p.sc_c0 = p.sc_c1 = p.sc_cin = p.sc_wh_stride = 0;
   p.pre = nullptr; p.pre_piece_stride = 0;
+  const bool gnb = a->gnb_x0 != nullptr;
+  p.gnb_x0 = a->gnb_x0; p.gnb_x1 = a->gnb_x1; p.gnb_c0 = a->gnb_x1 ? a->gnb_c0 : a->cout; p.gnb_ss = a->gnb_ss; p.gnb_silu = a->gnb_silu;
+  if (gnb && !conv_h2_gnb_ok(a, hout, wout))
+    return fail(DSG_ERR_UNSUPPORTED_SHAPE, "dsg_conv2d_fwd: gnb_* given for a call whose kernel has no GroupNorm-backward epilogue (ask dsg_conv2d_gnb_supported first)");
   if (sc) {
     if (!conv_h2_sc_fusable(a, hout, wout))
       return fail(DSG_ERR_UNSUPPORTED_SHAPE, "dsg_conv2d_fwd: sc_* given for a call that cannot fuse a shortcut (ask dsg_conv2d_fuses_shortcut first)");
@@ -255,12 +265,12 @@ int conv_h2_launch_t(const dsg_conv_args* a, int hout, int wout, hipStream_t st)
     bool done128 = false;
     if constexpr (PREC != 0) {
       // 128-cout workgroups (four MFMA tiles per staged patch) while they still give every CU a workgroup
-      if (g_h2.bm128 && p.cout_pad % 128 == 0 && wout % H2_TW == 0) {
+      bool r16 = false;
+      if (conv_h16_bm128(a, hout, wout, &r16)) {
         const int per_row = p.tiles_x * p.n * (p.cout_pad / 128);
-        const bool r16 = hout % 16 == 0 && per_row * (hout / 16) >= H2_CUS;
         const int th128 = r16 ? 16 : 8;
         const dim3 g128(per_row * (hout / th128));
-        if ((int)g128.x >= H2_CUS) {
+        {
           ConvH2P q = p;
           q.tiles_y = hout / th128;
           const size_t ssb = a->gn_scale_shift ? (size_t)p.cin * 2 * sizeof(float) : 0;
@@ -268,11 +278,13 @@ int conv_h2_launch_t(const dsg_conv_args* a, int hout, int wout, hipStream_t st)
           if (r16) {
             const size_t l128 = 2 * (size_t)H2Geom<4, 3, 4, 9, 128, NP>::BUF_BYTES + ssb;
             if (sc) rc = h2_launch<0, 4, 3, 2, 4, 1, 3, 128, PREC, 0, 1>(g128, l128, st, q);
+            else if (gnb) rc = h2_launch<0, 4, 3, 0, 4, 1, 3, 128, PREC, 0, 0, 0, 1>(g128, l128, st, q);
             else if (act == 0) rc = h2_launch<0, 4, 3, 0, 4, 1, 3, 128, PREC>(g128, l128, st, q);
             else rc = h2_launch<0, 4, 3, 2, 4, 1, 3, 128, PREC>(g128, l128, st, q);
           } else {
             const size_t l128 = 2 * (size_t)H2Geom<2, 3, 4, 9, 128, NP>::BUF_BYTES + ssb;
             if (sc) rc = h2_launch<0, 2, 3, 2, 4, 1, 3, 128, PREC, 0, 1>(g128, l128, st, q);
+            else if (gnb) rc = h2_launch<0, 2, 3, 0, 4, 1, 3, 128, PREC, 0, 0, 0, 1>(g128, l128, st, q);
             else if (act == 0) rc = h2_launch<0, 2, 3, 0, 4, 1, 3, 128, PREC>(g128, l128, st, q);
             else rc = h2_launch<0, 2, 3, 2, 4, 1, 3, 128, PREC>(g128, l128, st, q);
           }
@@ -283,6 +295,11 @@ int conv_h2_launch_t(const dsg_conv_args* a, int hout, int wout, hipStream_t st)
       if (sc) {
         if (nt4) rc = h2_launch<0, 4, 3, 2, 4, (PREC ? DSG_H16_NT4_OCC : 1), 3, 64, PREC, 0, 1>(grid, lds, st, p);
         else rc = h2_launch<0, 2, 3, 2, 4, 1, 3, 64, PREC, 0, 1>(grid, lds, st, p);
+      } else if (gnb) {
+        if constexpr (PREC != 0) {
+          if (nt4) rc = h2_launch<0, 4, 3, 0, 4, DSG_H16_NT4_OCC, 3, 64, PREC, 0, 0, 0, 1>(grid, lds, st, p);
+          else rc = h2_launch<0, 2, 3, 0, 4, 1, 3, 64, PREC, 0, 0, 0, 1>(grid, lds, st, p);
+        }
       } else if (act == 0) DSG_H2_LAUNCH_BLK(0, 3, 0, 3);
       else DSG_H2_LAUNCH_BLK(0, 3, 2, 3);
     }
@@ -290,7 +307,10 @@ int conv_h2_launch_t(const dsg_conv_args* a, int hout, int wout, hipStream_t st)
     if constexpr (PREC != 0) DSG_H2_LAUNCH_BLK(0, 3, 2, 1);
   } else {
     if constexpr (PREC == 0) {
-      if (act == 0) DSG_H2_LAUNCH(0, 3, 0);
+      if (gnb) {  // the fp32 tape's data-gradient conv ([N,C,H,W] both sides)
+        if (nt4) rc = h2_launch<0, 4, 3, 0, 4, 1, 0, 64, 0, 0, 0, 0, 1>(grid, lds, st, p);
+        else rc = h2_launch<0, 2, 3, 0, 4, 1, 0, 64, 0, 0, 0, 0, 1>(grid, lds, st, p);
+      } else if (act == 0) DSG_H2_LAUNCH(0, 3, 0);
       else DSG_H2_LAUNCH(0, 3, 2);
     }
   }

@@ -148,6 +148,31 @@ __global__ __launch_bounds__(256) void gn_bwd_finalize_kernel(const double* __re
   }
 }
 
+// The data-gradient conv's epilogue left per-tile partials (sum du, sum du * x) -- the RAW second moment -- in the forward
+// statistics' table layout, parts[N][C][ntile][2] (dsg_conv_args.gnb_*).  One wave per (n, c): lane l adds tiles l, l + 64, ...
+// in order, a fixed butterfly joins the lanes, and the pair becomes what the statistics pass would have written:
+//   s12[n][c] = (S1, rstd * (S2raw - mean * S1))           (xhat = (x - mean) * rstd applied to the sums, in fp64)
+__global__ __launch_bounds__(256) void gnb_parts_reduce_kernel(const double* __restrict__ parts, const float* __restrict__ mr,
+                                                               int64_t nc_total, int ntile, double* __restrict__ s12) {
+  const int lane = threadIdx.x & 63;
+  const int64_t nc = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (nc >= nc_total) return;
+  const double* pp = parts + nc * ntile * 2;
+  double a = 0.0, b = 0.0;
+  for (int t = lane; t < ntile; t += 64) {
+    const double2 v = *reinterpret_cast<const double2*>(pp + 2 * t);
+    a += v.x;
+    b += v.y;
+  }
+  a = wave_sum_d(a);
+  b = wave_sum_d(b);
+  if (lane == 0) {
+    const double mean = (double)mr[2 * nc], rstd = (double)mr[2 * nc + 1];
+    s12[2 * nc] = a;
+    s12[2 * nc + 1] = rstd * (b - mean * a);
+  }
+}
+
 // grid = (ceil(hw/(256*V)), c0+c1, n), V = 4 (16-byte accesses) when hw % 4 == 0 else 1.  dx = a*du - b - xhat*c2 (+ addend)
 template <int V>
 __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(const float* __restrict__ src0, int c0,
@@ -384,10 +409,11 @@ static inline int stream_blocks2(int64_t numel) {
 
 using dsg::cdiv;
 
-DSG_API int dsg_gn_bwd(const float* src0, int32_t c0, const float* src1, int32_t c1, const float* dy,
-                       const float* scale_shift, const float* mean_rstd, const float* gamma, int32_t silu, int32_t n,
-                       int32_t hw, int32_t groups, const float* add0, const float* add1, float* dx0, float* dx1,
-                       float* dgamma, float* dbeta, double* ws_s12, float* ws_coef, void* stream) {
+static int gn_bwd_f32_impl(const float* src0, int32_t c0, const float* src1, int32_t c1, const float* dy,
+                           const float* scale_shift, const float* mean_rstd, const float* gamma, int32_t silu, int32_t n,
+                           int32_t hw, int32_t groups, const float* add0, const float* add1, float* dx0, float* dx1,
+                           float* dgamma, float* dbeta, double* ws_s12, float* ws_coef, const double* parts, int32_t ntile,
+                           void* stream) {
   DSG_CHECK_ARG(src0 && dy && scale_shift && mean_rstd && gamma && dx0 && dgamma && dbeta && ws_s12 && ws_coef,
                 "dsg_gn_bwd: NULL pointer");
   DSG_CHECK_ARG(c0 > 0 && c1 >= 0 && n > 0 && hw > 0 && groups > 0, "dsg_gn_bwd: bad dims");
@@ -396,8 +422,12 @@ DSG_API int dsg_gn_bwd(const float* src0, int32_t c0, const float* src1, int32_t
   DSG_CHECK_ARG(c % groups == 0, "dsg_gn_bwd: channels not divisible by groups");
   DSG_CHECK_ARG(n <= 65535 && c <= 65535, "dsg_gn_bwd: grid too large");
   hipStream_t st = static_cast<hipStream_t>(stream);
-  hipLaunchKernelGGL(dsg::gn_bwd_stats_kernel, dim3(c, n), dim3(256), 0, st, src0, c0, src1, c1, dy, scale_shift,
-                     mean_rstd, silu, hw, ws_s12);
+  if (parts != nullptr)   // the data-gradient conv's epilogue already summed du and du * x per tile: no pass over x and dy
+    hipLaunchKernelGGL(dsg::gnb_parts_reduce_kernel, dim3((unsigned)dsg::cdiv64((int64_t)n * c, 4)), dim3(256), 0, st, parts,
+                       mean_rstd, (int64_t)n * c, ntile, ws_s12);
+  else
+    hipLaunchKernelGGL(dsg::gn_bwd_stats_kernel, dim3(c, n), dim3(256), 0, st, src0, c0, src1, c1, dy, scale_shift,
+                       mean_rstd, silu, hw, ws_s12);
   DSG_LAUNCH_CHECK();
   {
     const int cpb = n < 256 ? 256 / n : 1;
@@ -413,6 +443,24 @@ DSG_API int dsg_gn_bwd(const float* src0, int32_t c0, const float* src1, int32_t
                        scale_shift, mean_rstd, ws_coef, silu, hw, add0, add1, dx0, dx1);
   DSG_LAUNCH_CHECK();
   return DSG_OK;
+}
+
+DSG_API int dsg_gn_bwd(const float* src0, int32_t c0, const float* src1, int32_t c1, const float* dy,
+                       const float* scale_shift, const float* mean_rstd, const float* gamma, int32_t silu, int32_t n,
+                       int32_t hw, int32_t groups, const float* add0, const float* add1, float* dx0, float* dx1,
+                       float* dgamma, float* dbeta, double* ws_s12, float* ws_coef, void* stream) {
+  return gn_bwd_f32_impl(src0, c0, src1, c1, dy, scale_shift, mean_rstd, gamma, silu, n, hw, groups, add0, add1, dx0, dx1, dgamma,
+                         dbeta, ws_s12, ws_coef, nullptr, 0, stream);
+}
+
+DSG_API int dsg_gn_bwd_parts(const float* src0, int32_t c0, const float* src1, int32_t c1, const float* dy,
+                             const float* scale_shift, const float* mean_rstd, const float* gamma, int32_t silu, int32_t n,
+                             int32_t hw, int32_t groups, const float* add0, const float* add1, float* dx0, float* dx1,
+                             float* dgamma, float* dbeta, double* ws_s12, float* ws_coef, const double* parts, int32_t ntile,
+                             void* stream) {
+  DSG_CHECK_ARG(parts != nullptr && ntile > 0, "dsg_gn_bwd_parts: parts / ntile missing");
+  return gn_bwd_f32_impl(src0, c0, src1, c1, dy, scale_shift, mean_rstd, gamma, silu, n, hw, groups, add0, add1, dx0, dx1, dgamma,
+                         dbeta, ws_s12, ws_coef, parts, ntile, stream);
 }
 
 DSG_API int dsg_channel_sums(const float* x, int32_t n, int32_t c, int32_t hw, float* out_nc, int32_t out_stride,
@@ -783,11 +831,36 @@ DSG_API int dsg_gn_bwd_blocked(const void* src0, int32_t c0, const void* src1, i
                                  dx0, dx1, dgamma, dbeta, ws_s12, ws_coef, dtype, stream);
 }
 
+static int gn_bwd_blocked_impl(const void* src0, int32_t c0, const void* src1, int32_t c1, const void* dy,
+                               const float* scale_shift, const float* mean_rstd, const float* gamma, int32_t silu,
+                               int32_t n, int32_t hw, int32_t groups, const void* add0, const void* add0b, const void* add1,
+                               void* dx0, void* dx1, float* dgamma, float* dbeta, double* ws_s12, float* ws_coef,
+                               int32_t dtype, const double* parts, int32_t ntile, void* stream);
+
 DSG_API int dsg_gn_bwd_blocked_add2(const void* src0, int32_t c0, const void* src1, int32_t c1, const void* dy,
                                     const float* scale_shift, const float* mean_rstd, const float* gamma, int32_t silu,
                                     int32_t n, int32_t hw, int32_t groups, const void* add0, const void* add0b, const void* add1,
                                     void* dx0, void* dx1, float* dgamma, float* dbeta, double* ws_s12, float* ws_coef,
                                     int32_t dtype, void* stream) {
+  return gn_bwd_blocked_impl(src0, c0, src1, c1, dy, scale_shift, mean_rstd, gamma, silu, n, hw, groups, add0, add0b, add1, dx0,
+                             dx1, dgamma, dbeta, ws_s12, ws_coef, dtype, nullptr, 0, stream);
+}
+
+DSG_API int dsg_gn_bwd_blocked_parts(const void* src0, int32_t c0, const void* src1, int32_t c1, const void* dy,
+                                     const float* scale_shift, const float* mean_rstd, const float* gamma, int32_t silu,
+                                     int32_t n, int32_t hw, int32_t groups, const void* add0, const void* add0b, const void* add1,
+                                     void* dx0, void* dx1, float* dgamma, float* dbeta, double* ws_s12, float* ws_coef,
+                                     int32_t dtype, const double* parts, int32_t ntile, void* stream) {
+  DSG_CHECK_ARG(parts != nullptr && ntile > 0, "dsg_gn_bwd_blocked_parts: parts / ntile missing");
+  return gn_bwd_blocked_impl(src0, c0, src1, c1, dy, scale_shift, mean_rstd, gamma, silu, n, hw, groups, add0, add0b, add1, dx0,
+                             dx1, dgamma, dbeta, ws_s12, ws_coef, dtype, parts, ntile, stream);
+}
+
+static int gn_bwd_blocked_impl(const void* src0, int32_t c0, const void* src1, int32_t c1, const void* dy,
+                               const float* scale_shift, const float* mean_rstd, const float* gamma, int32_t silu,
+                               int32_t n, int32_t hw, int32_t groups, const void* add0, const void* add0b, const void* add1,
+                               void* dx0, void* dx1, float* dgamma, float* dbeta, double* ws_s12, float* ws_coef,
+                               int32_t dtype, const double* parts, int32_t ntile, void* stream) {
   using namespace dsg;
   DSG_CHECK_ARG(add0b == nullptr || add0 != nullptr, "dsg_gn_bwd_blocked_add2: add0b without add0");
   DSG_CHECK_ARG(src0 && dy && scale_shift && mean_rstd && gamma && dx0 && dgamma && dbeta && ws_s12 && ws_coef,
@@ -798,6 +871,23 @@ DSG_API int dsg_gn_bwd_blocked_add2(const void* src0, int32_t c0, const void* sr
   const int c = c0 + c1;
   DSG_CHECK_ARG(c % groups == 0 && n <= 65535, "dsg_gn_bwd_blocked: channels not divisible by groups / batch too large");
   hipStream_t st = static_cast<hipStream_t>(stream);
+  const int cpb = n < 256 ? 256 / n : 1;
+  if (parts != nullptr) {  // the data-gradient conv's epilogue already summed du and du * x per tile: no pass over x and dy
+    hipLaunchKernelGGL(gnb_parts_reduce_kernel, dim3((unsigned)cdiv64((int64_t)n * c, 4)), dim3(256), 0, st, parts, mean_rstd,
+                       (int64_t)n * c, ntile, ws_s12);
+    DSG_LAUNCH_CHECK();
+    hipLaunchKernelGGL(gn_bwd_finalize_kernel, dim3(cdiv(c, cpb)), dim3(256), 0, st, ws_s12, gamma, mean_rstd, n, c, groups, hw, ws_coef,
+                       dgamma, dbeta, 1, cpb);
+    DSG_LAUNCH_CHECK();
+    if (dtype == DSG_BF16)
+      hipLaunchKernelGGL(gn_bwd_apply_blk_kernel<1>, dim3(cdiv(hw, 1024), c / 8, n), dim3(256), 0, st, src0, c0, src1, c1, dy,
+                         scale_shift, mean_rstd, ws_coef, silu, hw, add0, add1, dx0, dx1, add0b);
+    else
+      hipLaunchKernelGGL(gn_bwd_apply_blk_kernel<2>, dim3(cdiv(hw, 1024), c / 8, n), dim3(256), 0, st, src0, c0, src1, c1, dy,
+                         scale_shift, mean_rstd, ws_coef, silu, hw, add0, add1, dx0, dx1, add0b);
+    DSG_LAUNCH_CHECK();
+    return DSG_OK;
+  }
   const int splits = dsg_gn_bwd_blocked_splits(hw);
   // ws_s12: [N][C][2] sums followed by the [N][C][splits][2] partials
   double* part = ws_s12 + (size_t)n * c * 2;
@@ -808,7 +898,6 @@ DSG_API int dsg_gn_bwd_blocked_add2(const void* src0, int32_t c0, const void* sr
     hipLaunchKernelGGL(gn_bwd_stats_blk_kernel<2>, dim3(c / 8, n, splits), dim3(256), 0, st, src0, c0, src1, c1, dy, scale_shift,
                        mean_rstd, silu, hw, part);
   DSG_LAUNCH_CHECK();
-  const int cpb = n < 256 ? 256 / n : 1;
   if (splits <= 2) {  // (the deep levels: the finalize pass adds the one or two partials itself, in the same order)
     hipLaunchKernelGGL(gn_bwd_finalize_kernel, dim3(cdiv(c, cpb)), dim3(256), 0, st, part, gamma, mean_rstd, n, c, groups, hw, ws_coef,
                        dgamma, dbeta, splits, cpb);

@@ -173,7 +173,7 @@ def conv2d_fused(src0, weight_r, bias=None, src1=None, ksize=3, stride=1, upsamp
                  silu=False, temb=None, temb_stride=0, residual=None, out=None, direct=False, cout=None,
                  pool2=False, wstride=None, weight_h2=None, want_stats=False, stats_buf=None, weight_h2_col=0, weight_h2_fold=None,
                  src_blocked=False, dst_blocked=False, weight_h2_s2=None, compute_dtype=0, weight_h2_stride=0,
-                 src_bound=None, src_bound1=None, splitk=False, shortcut=None, operand=None):
+                 src_bound=None, src_bound1=None, splitk=False, shortcut=None, operand=None, gnb=None):
     """dsg_conv2d_fwd: see include/dsg.h.  `weight_r` is in engine layout; `temb` is a [N, temb_stride] view
     whose first `cout` columns (from its data pointer) are added per (n, cout).
     want_stats: also return the per-tile GroupNorm statistics [N][cout][tiles][2] (fp64) of the result, or None
@@ -186,7 +186,11 @@ def conv2d_fused(src0, weight_r, bias=None, src1=None, ksize=3, stride=1, upsamp
     (ask `conv2d_fuses_shortcut` first).
     operand: None | "auto" | "query" | a tensor from `conv_operand_prepare` -- the pre-staged operand image of the call's
     sources (dsg_conv_args.src_operand).  "auto" asks dsg_conv2d_takes_operand and prepares the image when the answer is
-    yes; "query" only returns that answer."""
+    yes; "query" only returns that answer.
+    gnb: dict(x0=, x1=None, ss=, silu=True[, query_only=True]) -- this call is the DATA GRADIENT of a conv behind
+    silu?(GroupNorm(cat(x0, x1))): the kernel's epilogue also leaves the norm's backward statistics, per-tile (sum du, sum du * x),
+    in the table `want_stats` returns (dsg_conv_args.gnb_*; hand it to gn_bwd* as `parts`).  query_only: just ask
+    dsg_conv2d_gnb_supported.  Raises when the call's kernel has no such epilogue."""
     lib = _lib.load()
     cdt = dtype_code(compute_dtype)
     blk_dtype = _lib.TORCH_DTYPES[cdt]
@@ -213,7 +217,8 @@ def conv2d_fused(src0, weight_r, bias=None, src1=None, ksize=3, stride=1, upsamp
     pad = ksize // 2
     ho = (hc + 2 * pad - ksize) // stride + 1
     wo = (wc + 2 * pad - ksize) // stride + 1
-    query = operand == "query" or (shortcut is not None and bool(shortcut.get("query_only")))  # host-only: nothing allocated
+    query = (operand == "query" or (shortcut is not None and bool(shortcut.get("query_only")))
+             or (gnb is not None and bool(gnb.get("query_only"))))  # host-only: nothing allocated
     if out is None and not query:
         shape = (n, cout, ho // 2, wo // 2) if pool2 else (n, cout, ho, wo)
         if dst_blocked:
@@ -251,6 +256,15 @@ def conv2d_fused(src0, weight_r, bias=None, src1=None, ksize=3, stride=1, upsamp
         a.sc_weight_h2 = shortcut["weight_h2"].data_ptr()
         a.sc_bias = _lib.ptr(shortcut.get("bias"))
         a.sc_src_bound, a.sc_src_bound1 = _lib.ptr(shortcut.get("bound")), _lib.ptr(shortcut.get("bound1"))
+    if gnb is not None:
+        gx0, gx1 = gnb["x0"], gnb.get("x1")
+        a.gnb_x0, a.gnb_x1 = _lib.ptr(gx0), _lib.ptr(gx1)
+        a.gnb_c0 = (8 * gx0.shape[1] if gx0.dim() == 5 else gx0.shape[1]) if gx1 is not None else cout
+        a.gnb_ss, a.gnb_silu = _lib.ptr(gnb["ss"]), int(bool(gnb.get("silu", True)))
+        if gnb.get("query_only"):
+            yes = C.c_int32(0)
+            _lib.check(lib.dsg_conv2d_gnb_supported(C.byref(a), C.byref(yes)))
+            return bool(yes.value)
     scratch = None
     if splitk:   # small-grid calls may contract K in parallel slices (dsg_conv_args.splitk_ws)
         need = C.c_size_t()
@@ -571,8 +585,10 @@ def gn_scale_shift_train(src0, gamma, beta, groups, eps, src1=None):
     return ss, mr
 
 
-def gn_bwd(src0, dy, ss, mr, gamma, groups, silu, dgamma, dbeta, src1=None, add0=None, add1=None):
-    """Backward of silu?(GroupNorm(cat(src0, src1))); returns (dx0, dx1); dgamma/dbeta accumulated."""
+def gn_bwd(src0, dy, ss, mr, gamma, groups, silu, dgamma, dbeta, src1=None, add0=None, add1=None, parts=None):
+    """Backward of silu?(GroupNorm(cat(src0, src1))); returns (dx0, dx1); dgamma/dbeta accumulated.
+    parts: the [N][C][tiles][2] table a data-gradient conv's GNB epilogue wrote (conv2d_fused(gnb=...)): replaces the
+    statistics pass over x and dy."""
     n, c0 = src0.shape[0], src0.shape[1]
     hw = src0.numel() // (n * c0)
     c1 = src1.shape[1] if src1 is not None else 0
@@ -582,16 +598,25 @@ def gn_bwd(src0, dy, ss, mr, gamma, groups, silu, dgamma, dbeta, src1=None, add0
     s12 = torch.empty((n, c, 2), dtype=torch.float64, device=src0.device)
     coef = torch.empty((n, c, 3), dtype=torch.float32, device=src0.device)
     with torch.cuda.device(src0.device):
-        _lib.check(_lib.load().dsg_gn_bwd(_lib.ptr(src0), c0, _lib.ptr(src1), c1, _lib.ptr(dy), _lib.ptr(ss),
-                                         _lib.ptr(mr), _lib.ptr(gamma), int(silu), n, hw, groups, _lib.ptr(add0),
-                                         _lib.ptr(add1), _lib.ptr(dx0), _lib.ptr(dx1), _lib.ptr(dgamma),
-                                         _lib.ptr(dbeta), _lib.ptr(s12), _lib.ptr(coef), _st(src0)))
+        if parts is not None:
+            _lib.check(_lib.load().dsg_gn_bwd_parts(_lib.ptr(src0), c0, _lib.ptr(src1), c1, _lib.ptr(dy), _lib.ptr(ss),
+                                                   _lib.ptr(mr), _lib.ptr(gamma), int(silu), n, hw, groups, _lib.ptr(add0),
+                                                   _lib.ptr(add1), _lib.ptr(dx0), _lib.ptr(dx1), _lib.ptr(dgamma),
+                                                   _lib.ptr(dbeta), _lib.ptr(s12), _lib.ptr(coef), _lib.ptr(parts),
+                                                   parts.shape[2], _st(src0)))
+        else:
+            _lib.check(_lib.load().dsg_gn_bwd(_lib.ptr(src0), c0, _lib.ptr(src1), c1, _lib.ptr(dy), _lib.ptr(ss),
+                                             _lib.ptr(mr), _lib.ptr(gamma), int(silu), n, hw, groups, _lib.ptr(add0),
+                                             _lib.ptr(add1), _lib.ptr(dx0), _lib.ptr(dx1), _lib.ptr(dgamma),
+                                             _lib.ptr(dbeta), _lib.ptr(s12), _lib.ptr(coef), _st(src0)))
     return dx0, dx1
 
 
-def gn_bwd_blocked(src0, dy, ss, mr, gamma, groups, silu, dgamma, dbeta, src1=None, add0=None, add1=None, add0b=None):
+def gn_bwd_blocked(src0, dy, ss, mr, gamma, groups, silu, dgamma, dbeta, src1=None, add0=None, add1=None, add0b=None,
+                   parts=None):
     """gn_bwd on channel-blocked 16-bit tensors [N, C/8, H, W, 8] (dy covers cat(src0, src1)); returns (dx0, dx1).
-    add0 / add0b / add1: gradients already waiting on the sources (fan-in), added in the same pass."""
+    add0 / add0b / add1: gradients already waiting on the sources (fan-in), added in the same pass.
+    parts: as in gn_bwd."""
     n, cb0, h, w, _ = src0.shape
     c0, c1 = 8 * cb0, (8 * src1.shape[1] if src1 is not None else 0)
     c, hw = c0 + c1, h * w
@@ -601,6 +626,15 @@ def gn_bwd_blocked(src0, dy, ss, mr, gamma, groups, silu, dgamma, dbeta, src1=No
     dx1 = torch.empty_like(src1) if src1 is not None else None
     s12 = torch.empty(n * c * 2 * (1 + splits), dtype=torch.float64, device=src0.device)
     coef = torch.empty((n, c, 3), dtype=torch.float32, device=src0.device)
+    if parts is not None:
+        s12 = torch.empty(n * c * 2, dtype=torch.float64, device=src0.device)
+        with torch.cuda.device(src0.device):
+            _lib.check(lib.dsg_gn_bwd_blocked_parts(_lib.ptr(src0), c0, _lib.ptr(src1), c1, _lib.ptr(dy), _lib.ptr(ss), _lib.ptr(mr),
+                                                    _lib.ptr(gamma), int(silu), n, hw, groups, _lib.ptr(add0), _lib.ptr(add0b),
+                                                    _lib.ptr(add1), _lib.ptr(dx0), _lib.ptr(dx1), _lib.ptr(dgamma), _lib.ptr(dbeta),
+                                                    _lib.ptr(s12), _lib.ptr(coef), _DT_OF[src0.dtype], _lib.ptr(parts),
+                                                    parts.shape[2], _st(src0)))
+        return dx0, dx1
     with torch.cuda.device(src0.device):
         _lib.check(lib.dsg_gn_bwd_blocked_add2(_lib.ptr(src0), c0, _lib.ptr(src1), c1, _lib.ptr(dy), _lib.ptr(ss), _lib.ptr(mr),
                                                _lib.ptr(gamma), int(silu), n, hw, groups, _lib.ptr(add0), _lib.ptr(add0b),

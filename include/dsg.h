@@ -155,6 +155,20 @@ typedef struct {
      folded up-sampler conv of the levels with >= 256 output channels at batch sizes that fill the chip); anything else
      with src_operand set is DSG_ERR_UNSUPPORTED_SHAPE. */
   const void* src_operand;
+  /* GroupNorm-backward statistics from the epilogue (optional; the DATA-GRADIENT call of a conv whose forward read
+     a = silu(GroupNorm(x)): training_pipeline.py:86 `accelerator.backward(loss)` through ResnetBlock2D's norm1 / norm2).
+     dst of such a call is dA, the gradient w.r.t. the activated tensor, and the norm's backward starts with a pass of its own
+     over x and dA for per-(n, c) sums of du = dA * silu'(x * scale + shift) and du * xhat.  With gnb_x0 set (gnb_x1 / gnb_c0:
+     the second tensor of a concatenated x and the channel count of the first) the kernel reads the x of its output tile
+     (same layout / dtype as dst) and gnb_ss ([N][cout][2] scale, shift; gnb_silu: 0 = affine only) in its epilogue and
+     writes per-tile partials (sum du, sum du * x) to stats_out ([N][cout][tiles][2], tiles = dsg_conv2d_stats_tiles) -- the
+     RAW second moment: dsg_gn_bwd*_parts applies xhat = (x - mean) * rstd to the sums.  dst is unchanged.  Served for the
+     calls dsg_conv2d_gnb_supported accepts; anything else with gnb_x0 set is DSG_ERR_UNSUPPORTED_SHAPE. */
+  const void* gnb_x0;
+  const void* gnb_x1;
+  int32_t gnb_c0;
+  const float* gnb_ss;
+  int32_t gnb_silu;
 } dsg_conv_args;
 
 int dsg_conv2d_fwd(const dsg_conv_args* a, void* stream);
@@ -180,6 +194,11 @@ int dsg_conv2d_fuses_shortcut(const dsg_conv_args* a, int32_t* yes);
  * Host-only; set splitk_ws before asking.  Reference: the resnet convs of train.py:39-57's network, run at
  * training_pipeline.py:84 / inside DDPMPipeline.__call__ (training_pipeline.py:26-32, generation.py:14-20). */
 int dsg_conv2d_takes_operand(const dsg_conv_args* a, int32_t* yes);
+/* *yes = 1 when a call with these arguments (gnb_* filled in, stats_out not needed yet) is served by a kernel with the
+ * GroupNorm-backward epilogue: a stride-1 3x3 conv without a norm in front, fused shortcut, operand image or split-K;
+ * 16-bit modes: every tensor channel-blocked; fp32 mode: every tensor [N, C, H, W]; maps a multiple of 32 columns wide; and
+ * every channel tile of the kernel the call selects inside ONE of gnb_x0 / gnb_x1.  Host-only. */
+int dsg_conv2d_gnb_supported(const dsg_conv_args* a, int32_t* yes);
 /* Operand image of cat(src0, src1) (channel-blocked fp32 [N, c/8, hin, win, 8]) for dsg_conv_args.src_operand:
  * [piece 2][N][(c0+c1)/8][hin+2][win+2][8] fp16 -- piece 0 = fp16(v), piece 1 = fp16((v - piece 0) * 2^11) of
  * v = silu(x * scale + shift) (gn_scale_shift [N][c0+c1][2], silu as in the conv call) or, without gn_scale_shift,
@@ -484,6 +503,19 @@ int dsg_gn_bwd_blocked_add2(const void* src0, int32_t c0, const void* src1, int3
                             int32_t n, int32_t hw, int32_t groups, const void* add0, const void* add0b, const void* add1,
                             void* dx0, void* dx1, float* dgamma, float* dbeta, double* ws_s12, float* ws_coef,
                             int32_t dtype, void* stream);
+/* The same two with the statistics pass replaced by the partials a data-gradient conv's epilogue wrote (dsg_conv_args.gnb_*):
+ * parts [N][C][ntile][2] doubles = per-tile (sum du, sum du * x); everything else as above (ws_s12: [N][C][2] doubles suffice).
+ * x is then read by the conv's epilogue and by the apply pass -- four tensor passes instead of five. */
+int dsg_gn_bwd_parts(const float* src0, int32_t c0, const float* src1, int32_t c1, const float* dy,
+                     const float* scale_shift, const float* mean_rstd, const float* gamma, int32_t silu, int32_t n,
+                     int32_t hw, int32_t groups, const float* add0, const float* add1, float* dx0, float* dx1,
+                     float* dgamma, float* dbeta, double* ws_s12, float* ws_coef, const double* parts, int32_t ntile,
+                     void* stream);
+int dsg_gn_bwd_blocked_parts(const void* src0, int32_t c0, const void* src1, int32_t c1, const void* dy,
+                             const float* scale_shift, const float* mean_rstd, const float* gamma, int32_t silu,
+                             int32_t n, int32_t hw, int32_t groups, const void* add0, const void* add0b, const void* add1,
+                             void* dx0, void* dx1, float* dgamma, float* dbeta, double* ws_s12, float* ws_coef,
+                             int32_t dtype, const double* parts, int32_t ntile, void* stream);
 int dsg_gn_bwd_blocked_splits(int32_t hw);
 int dsg_channel_sums_blocked(const void* x, int32_t n, int32_t c, int32_t hw, float* out_nc, int32_t out_stride,
                              int32_t dtype, void* stream);
