@@ -1154,8 +1154,11 @@ __global__ __launch_bounds__(64 * NW, OCC * NW / 4) void conv_h2_kernel(ConvH2P 
           typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
           const int crel = mt * 32 + (r & 3) + 8 * (r >> 2);
           const u32x2 q = __builtin_amdgcn_raw_buffer_load_b64(gss_rs, 32 * half, crel * 8, 0);
-          gsc[r] = __builtin_bit_cast(float, q.x);
-          gsh[r] = __builtin_bit_cast(float, q.y);
+          // (through scalars: hipcc 7.2's front end evaluates __builtin_bit_cast(float, q.y) on the vector's FIRST element --
+          //  the element lvalue decays to the vector's address -- and the load is then narrowed to one dword: profiles/FINDINGS.md)
+          const unsigned q0 = q.x, q1 = q.y;
+          gsc[r] = __builtin_bit_cast(float, q0);
+          gsh[r] = __builtin_bit_cast(float, q1);
         }
       }
       if (has_r) {

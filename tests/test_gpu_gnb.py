@@ -54,7 +54,8 @@ def _ref64(x, dy, wt, gamma, beta, silu):
 # (name, n, cdy, c0, c1, h, w, silu, dtype): which kernel geometry serves the data gradient (cout of that call = c0 + c1)
 CASES = [
     ("bf16_bm128_r16", 8, 64, 128, 0, 64, 64, True, "bf16"),        # 128-cout workgroups, 16-row tiles
-    ("bf16_bm128_r8", 8, 128, 256, 0, 32, 32, True, "bf16"),        # 128-cout workgroups, 8-row tiles
+    ("bf16_bm128_r8", 8, 128, 256, 0, 64, 64, True, "bf16"),        # 128-cout workgroups, 8-row tiles (256 of them; 128 of 16 rows)
+    ("bf16_bm64_nt2_c32", 16, 32, 32, 0, 64, 64, True, "bf16"),     # configs[0]'s shapes: 32 channels = half a 64-cout tile, 8-row tiles
     ("bf16_bm64_nt4", 8, 64, 64, 0, 128, 128, True, "bf16"),        # 64-cout workgroups (cout % 128 != 0), 16-row tiles
     ("bf16_cat_128_64", 8, 64, 128, 64, 64, 64, True, "bf16"),      # concatenated x: tiles of 64 ... 192 % 128 != 0 -> BM 64, c0 % 64 == 0
     ("bf16_cat_256_128", 4, 128, 256, 128, 64, 64, True, "bf16"),   # BM 128, c0 % 128 == 0
@@ -148,6 +149,7 @@ def test_shapes_without_the_form_say_so_and_the_switch_turns_it_off():
     assert not ask(1, 64, 64, 0, 32, 32)[0]            # a grid of at most half the chip: the 32-cout workgroups have no GNB form
     yes, (dyb, gnb, kw) = ask(8, 64, 192, 64, 64, 64)   # cat(192, 64): 128-cout tiles straddle the two x tensors
     assert not yes
+    assert not ask(16, 32, 64, 32, 64, 64)[0]          # configs[0]'s up blocks, cat(64, 32): 96 couts pad to ONE 128-cout tile
     with pytest.raises(RuntimeError, match="GroupNorm-backward epilogue"):
         ops.conv2d_fused(dyb, None, gnb=gnb, want_stats=True, **kw)
     assert not ask(8, 64, 128, 0, 64, 48)[0]           # not a multiple of 32 columns
@@ -178,14 +180,24 @@ def test_training_step_gradients_with_and_without_the_epilogue_statistics(dtn):
             net = synth_weights(d.UNet2DModel(**CFG1)).to(DEV).train().set_compute_dtype(dtn)
             loss = d.mse_loss(net(sch.add_noise(x0, nz, t), t, return_dict=False)[0], nz)
             loss.backward()
-            grads[on] = (float(loss), {k: p.grad.detach().clone() for k, p in net.named_parameters()})
+            grads[on] = (float(loss.detach()), {k: p.grad.detach().clone() for k, p in net.named_parameters()})
     finally:
         lib.dsg_set_tuning(37, 1)
     assert grads[0][0] == grads[1][0]
-    worst, differ = 0.0, 0
-    for k, gq in grads[0][1].items():
-        if float(gq.norm()) > 1e-9:
-            worst = max(worst, _rel(grads[1][1][k], gq))
-            differ += int(not torch.equal(grads[1][1][k], gq))
+    # the whole gradient vector, and every tensor that is not itself rounding noise (a 16-bit tape leaves ~1e-2 of a layer's
+    # typical gradient as noise on the tensors whose true gradient nearly cancels)
+    keys = list(grads[0][1])
+    flat = {on: torch.cat([grads[on][1][k].reshape(-1).double() for k in keys]) for on in (0, 1)}
+    whole = float((flat[1] - flat[0]).norm() / flat[0].norm())
+    norms = torch.tensor([float(grads[0][1][k].norm()) / max(1, grads[0][1][k].numel()) ** 0.5 for k in keys])
+    floor = float(norms.median()) * 0.1
+    worst, worst_key, differ = 0.0, None, 0
+    for k, rms in zip(keys, norms.tolist()):
+        differ += int(not torch.equal(grads[1][1][k], grads[0][1][k]))
+        if rms >= floor:
+            r = _rel(grads[1][1][k], grads[0][1][k])
+            if r > worst:
+                worst, worst_key = r, k
     assert differ > 0, "key 37 changed nothing: no layer of this net took the GNB kernel at this batch"
-    assert worst <= (2e-4 if dtn == "fp32" else 2e-2), worst
+    assert whole <= (1e-4 if dtn == "fp32" else 5e-3), whole
+    assert worst <= (2e-4 if dtn == "fp32" else 2e-2), (worst, worst_key)
