@@ -377,7 +377,7 @@ def _write_synth_pngs(folder, count, size=512, seed=14555):
     return paths
 
 
-def train_e2e(net, opt, lrs, sch, cfg, batch, dtype, bare_ms, steps=6, warm=2):
+def train_e2e(net, opt, lrs, sch, cfg, batch, dtype, bare_ms, steps=6, warm=3):
     """The training loop END TO END at the config's own batch, the way the reference runs it
     (training_pipeline.py:70-97 over train.py:34-35's loader): PNG files on disk -> `GpuImageLoader` (native decode pool,
     pinned ring, H2D on a side stream, one resize + normalise kernel: dataset.py:32-50) -> `train_loop.train_steps`
@@ -423,18 +423,20 @@ def train_e2e(net, opt, lrs, sch, cfg, batch, dtype, bare_ms, steps=6, warm=2):
         acc = d.Accelerator(mixed_precision="no")   # (the net's compute dtype is already set; no GradScaler for fp32 / bf16)
 
         def run(noise):
-            t_start, last = None, None
+            t_start, last, clock = None, None, StepClock(dev)
             for i, loss in enumerate(train_loop.train_steps(acc, net, sch, opt, lrs, batches(warm + steps), noise=noise)):
                 if i == warm - 1:
                     torch.cuda.synchronize(dev)
                     t_start = time.perf_counter()
+                if i >= warm - 1:
+                    clock.tick()
                 last = loss
             torch.cuda.synchronize(dev)
             dt = time.perf_counter() - t_start
             assert torch.isfinite(last).all()
-            return dt / steps * 1e3, float(last)
-        host_ms, host_loss = run("host")
-        dev_ms, dev_loss = run(train_loop.DeviceNoise(seed=14555))
+            return dt / steps * 1e3, float(last), clock.spread()
+        host_ms, host_loss, host_spread = run("host")
+        dev_ms, dev_loss, dev_spread = run(train_loop.DeviceNoise(seed=14555))
         return {"what": "PNG files -> GpuImageLoader -> train_steps, at the config's own batch; bare tape = device-resident x0 / noise / t",
                 "batch": batch, "dtype": dtype, "bare_tape_ms": bare_ms, "bare_tape_images_s": batch / bare_ms * 1e3,
                 "host_noise_ms": host_ms, "host_noise_images_s": batch / host_ms * 1e3,
@@ -443,6 +445,7 @@ def train_e2e(net, opt, lrs, sch, cfg, batch, dtype, bare_ms, steps=6, warm=2):
                 "host_draw_ms": draw_ms, "loader_images_s": loader_rate, "decode_pool_images_s": decode_rate,
                 "decode_workers": loader.workers, "pil_one_thread_images_s": pil_rate,
                 "png": "512x512 RGB, ~%d KB" % (os.path.getsize(os.path.join(folder, "0000.png")) // 1024),
+                "host_noise_step_ms_spread": host_spread, "device_noise_step_ms_spread": dev_spread,
                 "png_write_s": write_s, "loss_host": host_loss, "loss_device": dev_loss}
     finally:
         shutil.rmtree(folder, ignore_errors=True)

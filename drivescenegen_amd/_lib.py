@@ -157,6 +157,7 @@ SIGNATURES = {
     "dsg_time_embed_fwd": [_vp, _vp, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp],
     "dsg_linear_fwd": [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _vp],
     "dsg_add_noise": [_vp, _vp, _vp, _vp, _vp, _i32, _i64, _vp],
+    "dsg_host_device_pointer": [_vp, C.POINTER(_vp)],
     "dsg_philox_u32": [_vp, _i64, C.c_uint64, C.c_uint64, _vp],
     "dsg_philox_normal": [_vp, _i64, C.c_uint64, C.c_uint64, _vp],
     "dsg_add_noise_philox": [_vp, _vp, _vp, _vp, _vp, _i32, _i64, C.c_uint64, C.c_uint64, _vp],

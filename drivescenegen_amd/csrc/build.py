@@ -14,7 +14,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
 SOURCES = ["common.hip", "conv.hip", "groupnorm.hip", "attention.hip", "temb.hip", "scheduler.hip", "unet.hip", "prof.hip",
-           "conv_bwd.hip", "train_ops.hip", "conv_h2.hip", "conv_h2_bf16.hip", "conv_h2_f16.hip", "imageops.hip", "raster.hip", "conv_in.hip", "conv_out.hip", "pngdec.hip"]
+           "conv_bwd.hip", "train_ops.hip", "conv_h2.hip", "conv_h2_bf16.hip", "conv_h2_f16.hip", "imageops.hip", "raster.hip", "conv_in.hip", "conv_out.hip", "pngdec.hip", "conv_h2_gnb.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fvisibility=hidden", "-Wall", "-Wno-unused-function"]
 # scheduler.hip must round every fp32 operation individually (bit parity with the reference's torch-CPU
 # expressions); the in-source pragma alone does not stop the backend from forming v_pk_fma_f32.
@@ -27,6 +27,7 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fvisibility=hi
 # tools/probes/probe_lds_read2.hip + probe_neighbour.hip); tests/test_isa_policy.py keeps the whole library free of that form.
 NO_PK_F32 = ["-Xclang", "-target-feature", "-Xclang", "-packed-fp32-ops"]
 EXTRA_FLAGS = {"scheduler.hip": ["-ffp-contract=off"], "conv_h2_bf16.hip": ["-fno-slp-vectorize"], "conv_h2_f16.hip": ["-fno-slp-vectorize"],
+               "conv_h2_gnb.hip": ["-fno-slp-vectorize"],   # (its epilogue arithmetic was packed into the op_sel hazard form with SLP on)
                "raster.hip": NO_PK_F32, "imageops.hip": NO_PK_F32}
 LIB = os.path.join(ROOT, "lib", "libdsg.so")
 

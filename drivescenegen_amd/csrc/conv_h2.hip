@@ -324,8 +324,10 @@ bool conv_h2_gnb_ok(const dsg_conv_args* a, int hout, int wout) {
   int bm = H2_BM;
   if (h16) {
     bool r16 = false;
-    if (conv_h16_bm128(a, hout, wout, &r16)) bm = 128;
-    else {  // the launcher's 32-cout workgroups for small grids have no GNB form
+    if (conv_h16_bm128(a, hout, wout, &r16)) {
+      bm = 128;
+      if (g_h2.gnb == 2) return false;  // (A/B mode: only the two-workgroups-per-CU 64-cout kernels, whose epilogue runs under the other workgroup's K loop)
+    } else {  // the launcher's 32-cout workgroups for small grids have no GNB form
       const int cout_pad = (a->cout + 63) / 64 * 64;
       const bool nt4 = conv_h2_rows16(a, hout, wout);
       const int grid = (wout / H2_TW) * (hout / (nt4 ? 16 : 8)) * a->n * (cout_pad / H2_BM);

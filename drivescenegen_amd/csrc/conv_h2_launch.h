@@ -89,6 +89,12 @@ static int h2_launch(dim3 grid, size_t lds, hipStream_t st, const ConvH2P& p) {
 // PREC 0 serves every (layout, gather mode, geometry) combination conv_h2_eligible admits; the 16-bit modes serve
 // channel-blocked tensors only (3x3: every tensor blocked, or blocked sources -> fp32 [N,C,H,W] result for conv_out;
 // pointwise: any pair with at least one blocked side).
+// The fp32-tape GNB instantiations live in a translation unit of their own (conv_h2_gnb.hip), built WITHOUT SLP vectorisation:
+// in conv_h2.hip hipcc packed the epilogue's scalar fp32 statistics arithmetic into `v_pk_fma_f32 ... op_sel:[0,0,1]` -- the form
+// that returns wrong values on lanes 48-63 next to a 16-deep MFMA of another wave (profiles/FINDINGS.md, round 4).  The two-rank
+// and under-load tests caught it (overlapped vs deferred buckets no longer bitwise), tests/test_isa_policy.py names the kernels.
+int conv_h2_gnb_f32_launch(bool nt4, dim3 grid, size_t lds, hipStream_t st, const ConvH2P& p);
+
 template <int PREC>
 int conv_h2_launch_t(const dsg_conv_args* a, int hout, int wout, hipStream_t st) {
   constexpr int NP = PREC ? 1 : 2;
@@ -307,10 +313,8 @@ int conv_h2_launch_t(const dsg_conv_args* a, int hout, int wout, hipStream_t st)
     if constexpr (PREC != 0) DSG_H2_LAUNCH_BLK(0, 3, 2, 1);
   } else {
     if constexpr (PREC == 0) {
-      if (gnb) {  // the fp32 tape's data-gradient conv ([N,C,H,W] both sides)
-        if (nt4) rc = h2_launch<0, 4, 3, 0, 4, 1, 0, 64, 0, 0, 0, 0, 1>(grid, lds, st, p);
-        else rc = h2_launch<0, 2, 3, 0, 4, 1, 0, 64, 0, 0, 0, 0, 1>(grid, lds, st, p);
-      } else if (act == 0) DSG_H2_LAUNCH(0, 3, 0);
+      if (gnb) rc = conv_h2_gnb_f32_launch(nt4, grid, lds, st, p);  // the fp32 tape's data-gradient conv ([N,C,H,W] both sides)
+      else if (act == 0) DSG_H2_LAUNCH(0, 3, 0);
       else DSG_H2_LAUNCH(0, 3, 2);
     }
   }

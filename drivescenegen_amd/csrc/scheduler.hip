@@ -272,3 +272,17 @@ DSG_API int dsg_add_noise_philox(const float* x0, const float* sqrt_a, const flo
   DSG_LAUNCH_CHECK();
   return DSG_OK;
 }
+
+// The DEVICE address of a pinned host buffer (hipHostMalloc'ed or hipHostRegister'ed): what a kernel that reads the buffer in
+// place must be given.  With torch's default pinned allocator the two addresses are equal (unified addressing); under its
+// host-register configuration they need not be -- nothing here assumes it.  Fails (DSG_ERR_INVALID_ARG) for pageable memory.
+DSG_API int dsg_host_device_pointer(const void* host, void** device) {
+  DSG_CHECK_ARG(host && device, "dsg_host_device_pointer: NULL pointer");
+  void* d = nullptr;
+  if (hipHostGetDevicePointer(&d, const_cast<void*>(host), 0) != hipSuccess || d == nullptr) {
+    (void)hipGetLastError();
+    return dsg::fail(DSG_ERR_INVALID_ARG, "dsg_host_device_pointer: %p is not device-accessible pinned host memory", host);
+  }
+  *device = d;
+  return DSG_OK;
+}

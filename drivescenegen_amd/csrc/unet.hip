@@ -174,9 +174,13 @@ struct dsg_unet {
       if (p) (void)hipFree(p);
   }
 
+  bool alloc_failed = false;   // a failed hipMalloc anywhere in the plan: dsg_unet_create refuses to hand the plan out
   float* dalloc(int64_t numel) {
     void* p = nullptr;
-    if (hipMalloc(&p, (size_t)numel * sizeof(float)) != hipSuccess) return nullptr;
+    if (hipMalloc(&p, (size_t)numel * sizeof(float)) != hipSuccess) {
+      alloc_failed = true;
+      return nullptr;
+    }
     allocs.push_back(p);
     return static_cast<float*>(p);
   }
@@ -686,8 +690,8 @@ DSG_API int dsg_unet_create(const dsg_unet_config* cfg, dsg_unet_t** out) {
   }
   // (allocated here, not at the first dsg_unet_set_param: that call is documented as legal under stream capture)
   h->wmax_dev = h->dalloc((int64_t)h->params.size());
-  for (void* p : h->allocs)
-    if (p == nullptr) return fail(DSG_ERR_HIP, "dsg_unet_create: hipMalloc failed");
+  if (h->alloc_failed || h->wmax_dev == nullptr || h->freqs == nullptr)
+    return fail(DSG_ERR_HIP, "dsg_unet_create: hipMalloc failed (weights, timestep table or range-guard table)");
   for (auto& p : h->params)
     if (p.dst == nullptr) return fail(DSG_ERR_HIP, "dsg_unet_create: hipMalloc failed for %s", p.name.c_str());
   *out = h.release();

@@ -126,7 +126,7 @@ class _PipelineBase:
 class _NoiseStream:
     """The per-step noise of ``DDPMPipeline.__call__`` in the reference's order of draws (App. A.4: x_T, then one full-batch
     tensor per step with t > 0, all from ONE generator).  A CPU generator (training_pipeline.py:29 passes
-    ``torch.manual_seed(seed)``) samples on the host: tensor k+1 is drawn by a worker thread into one of two PINNED buffers while
+    ``torch.manual_seed(seed)``) samples on the host: tensor k+1 is drawn by a worker thread into one of THREE pinned buffers while
     the caller enqueues step k's kernels, and the scheduler's step kernel reads that buffer in place, over PCIe
     (``schedulers.HostNoise``: the noise is read exactly once, 12 bytes per pixel of a batch-1 sample) -- same generator, same
     shapes, same order, so the same values as ``randn_tensor(...).to(device)`` bit for bit, with neither the draw, nor a
@@ -137,21 +137,25 @@ class _NoiseStream:
     loop would have left it.  With no generator, or a device generator, a draw is torch's device RNG kernel on the current
     stream, as in the reference."""
 
+    RING = 3
+
     def __init__(self, shape, generator, device, rows=None, count=1):
         self.shape, self.gen, self.dev, self.rows, self.count = tuple(shape), generator, torch.device(device), rows, int(count)
         self.host = generator is not None and generator.device.type == "cpu"
         self.k = 0
         self._pending = None          # (thread, index, generator state before the draw, [exception])
         if self.host:
-            self.pinned = [torch.empty(self.shape, dtype=torch.float32).pin_memory() for _ in range(2)]
-            self.lent = [None, None]  # the HostNoise last handed out on pinned[i] (its `consumed` event guards the reuse)
+            # three buffers: the draw of tensor k waits for the kernel that read tensor k - 3, so the host may run two whole
+            # steps ahead of the GPU (with two it stalled on the step before last: never more than one forward queued)
+            self.pinned = [torch.empty(self.shape, dtype=torch.float32).pin_memory() for _ in range(self.RING)]
+            self.lent = [None] * self.RING  # the HostNoise last handed out on pinned[i] (its `consumed` event guards the reuse)
 
     def _start(self, k):
         """hand tensor k's draw to a worker thread (one in flight at most; nobody else touches the generator meanwhile)"""
         import threading
-        i = k & 1
+        i = k % self.RING
         if self.lent[i] is not None:
-            self.lent[i].wait_consumed()      # the step kernel that read pinned[i] two draws ago has run
+            self.lent[i].wait_consumed()      # the step kernel that read pinned[i] three draws ago has run
             self.lent[i] = None
         box = []
 
@@ -175,7 +179,7 @@ class _NoiseStream:
             for h in self.lent:           # the pinned buffers must outlive the kernels that read them
                 if h is not None:
                     h.wait_consumed()
-            self.lent = [None, None]
+            self.lent = [None] * self.RING
 
     def draw(self):
         """The next tensor of the stream (this shard's rows of it): a device tensor, or -- host generator, after x_T -- a
@@ -193,7 +197,7 @@ class _NoiseStream:
             if self.count > 1:
                 self._start(1)
             return out
-        i = k & 1
+        i = k % self.RING
         if self._pending is None:             # (more draws than announced: drawn here, in order)
             self._start(k)
         th, kk, _, box = self._pending

@@ -45,6 +45,12 @@ class HostNoise:
             raise ValueError("HostNoise: a contiguous pinned fp32 host tensor is required")
         self.tensor = tensor
         self.consumed = None
+        # the address the KERNEL reads: asked of the runtime, not assumed equal to the host address (torch's host-register
+        # configuration of the pinned allocator maps the two apart)
+        import ctypes
+        dev = ctypes.c_void_p()
+        _lib.check(_lib.load().dsg_host_device_pointer(tensor.data_ptr(), ctypes.byref(dev)))
+        self.device_ptr = dev.value
 
     @property
     def shape(self):
@@ -206,7 +212,7 @@ class DDPMScheduler:
                 host = variance_noise
                 if tuple(host.shape) != tuple(sample.shape):
                     raise ValueError(f"variance_noise has shape {tuple(host.shape)}, the sample {tuple(sample.shape)}")
-                nptr = host.tensor.data_ptr()
+                nptr = host.device_ptr
             else:
                 noise = variance_noise if variance_noise is not None else _randn_like_reference(
                     model_output.shape, generator, model_output.device, model_output.dtype)

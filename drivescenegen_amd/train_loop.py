@@ -67,17 +67,29 @@ class NoiseAhead:
         self._shape = None
         self._out = None
         self._snap = None
+        self._side = None      # the worker's copy stream: the 268-MB H2D of configs[4]'s tensor does not sit in the training stream
 
-    def schedule(self, shape):
+    def schedule(self, shape, device=None):
         if not self.enabled or self._thread is not None:
             return
         import threading
         self._shape = tuple(shape)
         self._snap = torch.get_rng_state()    # the global CPU generator before the draw (cancel() goes back to it)
+        dev = torch.device(device) if device is not None else None
+        if dev is not None and dev.type == "cuda" and self._side is None:
+            self._side = torch.cuda.Stream(dev)
 
         def draw():
             try:
-                self._out = torch.randn(self._shape, pin_memory=torch.cuda.is_available())
+                host = torch.randn(self._shape, pin_memory=torch.cuda.is_available())
+                if dev is not None and dev.type == "cuda":   # copy ahead too, on the worker's own stream, an event behind it
+                    with torch.cuda.stream(self._side):
+                        on_dev = host.to(dev, non_blocking=True)
+                        ev = torch.cuda.Event()
+                        ev.record(self._side)
+                    self._out = (host, on_dev, ev)
+                else:
+                    self._out = (host, None, None)
             except BaseException as e:  # surfaced by take() on the training thread
                 self._out = e
         self._thread = threading.Thread(target=draw, daemon=True)
@@ -100,7 +112,13 @@ class NoiseAhead:
             if isinstance(out, BaseException):
                 raise out
             if self._shape == shape:
-                return out.to(device, non_blocking=True)
+                host, on_dev, ev = out
+                if on_dev is not None and on_dev.device == torch.device(device):
+                    cur = torch.cuda.current_stream(on_dev.device)
+                    cur.wait_event(ev)
+                    on_dev.record_stream(cur)
+                    return on_dev
+                return host.to(device, non_blocking=True)
             # (cannot happen in `fit`: it schedules the very batch it takes next): undo the draw, then say so
             torch.set_rng_state(self._snap)
             raise RuntimeError(f"NoiseAhead: scheduled {self._shape}, asked for {shape}")
@@ -158,7 +176,7 @@ def batches_with_noise(batches, overlap_noise: bool = True):
             noise = ahead.take(batch.shape, batch.device)
             nxt = next(it, None)
             if nxt is not None:
-                ahead.schedule(nxt.shape)
+                ahead.schedule(nxt.shape, nxt.device)
             yield batch, noise
             batch = nxt
     finally:   # a consumer that stops early (exception, break, max-steps cut) leaves the generator as the serial loop would

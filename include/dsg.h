@@ -350,6 +350,8 @@ int dsg_ddpm_step(const float* sample, const float* eps, const float* noise /* N
 int dsg_ddim_step(const float* sample, const float* eps, float* prev, int64_t numel,
                   float sqrt_beta_prod_t, float sqrt_alpha_prod_t, float clip, float sqrt_alpha_prev,
                   float dir_coef, void* stream);
+/* Device address of a pinned host buffer, for the kernels that read host memory in place (dsg_ddpm_step's `noise`).  Host-only. */
+int dsg_host_device_pointer(const void* host, void** device);
 /* Counter-based device noise: Philox4x32-10 + Box-Muller (opt-in; the default training loop keeps the reference's host draw).
  *   replaces   training_pipeline.py:72   noise = torch.randn(batch.shape).to(device)      [a serial CPU draw + an H2D copy]
  *         and  training_pipeline.py:80   noisy = noise_scheduler.add_noise(batch, noise, t)  in the same pass

@@ -111,8 +111,9 @@ def test_cfg1_pipeline_seeded_generator_matches_oracle(tiny):
 
 
 def test_pipeline_noise_stream_is_bitwise_the_reference_order_of_draws(tiny):
-    """DDPMPipeline draws a CPU generator's noise into pinned buffers one step ahead of its use and copies on a side stream
-    (pipelines._NoiseStream); the U-Net gets its timesteps from a device table uploaded once.  Same generator, same shapes,
+    """DDPMPipeline draws a CPU generator's noise into a ring of three pinned buffers one step ahead of its use, and the step
+    kernel reads the buffer in place over PCIe at the device address the runtime reports for it (pipelines._NoiseStream,
+    schedulers.HostNoise -- no copy, no side stream); the U-Net gets its timesteps from a device table uploaded once.  Same generator, same shapes,
     same order as diffusers' loop (randn_tensor(...).to(device) per step, a host scalar timestep per step): the images must
     be those of the plain loop, bit for bit -- also for a shard, also when the call is repeated on the same pipeline."""
     from drivescenegen_amd.schedulers import _randn_like_reference
@@ -153,13 +154,21 @@ def test_pipeline_noise_stream_is_bitwise_the_reference_order_of_draws(tiny):
             raise KeyError("step 4 failed")
         return real_step(*a, **k)
     sch.step = failing_step
-    gen = torch.manual_seed(4242)
+    # (a PRIVATE generator: torch.manual_seed returns the global one, and comparing the global generator with itself proves
+    #  nothing -- ADVICE r05)
+    gen = torch.Generator().manual_seed(4242)
     with pytest.raises(KeyError):
         pipe(num_inference_steps=n, batch_size=3, generator=gen, output_type="np.array")
     sch.step = real_step
-    ref = torch.manual_seed(4242)
-    state_after_5_draws = [torch.randn((3, 3, 64, 64), generator=ref) for _ in range(5)] and ref.get_state()   # x_T + steps 1..4
-    assert torch.equal(gen.get_state(), state_after_5_draws)
+    state_after_failure = gen.get_state().clone()
+    ref = torch.Generator().manual_seed(4242)
+    for _ in range(5):                                # x_T + the draws of steps 1..4 (the one that died drew its noise before failing)
+        torch.randn((3, 3, 64, 64), generator=ref)
+    assert torch.equal(state_after_failure, ref.get_state())
+    one_more = torch.Generator().manual_seed(4242)
+    for _ in range(6):
+        torch.randn((3, 3, 64, 64), generator=one_more)
+    assert not torch.equal(state_after_failure, one_more.get_state())     # (the worker's extra draw really was undone)
     # no generator: torch's device RNG, as the reference (generation.py:14-20) -- reproducible under torch.cuda.manual_seed
     torch.cuda.manual_seed(99)
     a = pipe(num_inference_steps=5, batch_size=2, output_type="np.array").images

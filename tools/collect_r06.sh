@@ -1,7 +1,7 @@
 #!/bin/bash
-# Everything the round-4 numbers in DESIGN.md / profiles/ come from, in one call on the GPU box (start it through tools/gpu.sh so
+# Everything the round-6 numbers in DESIGN.md / profiles/ come from, in one call on the GPU box (start it through tools/gpu.sh so
 # that the counter files carry the git head):
-#   bash tools/collect_r04.sh <tag>      -> gpurun_out/<tag>_*  (tools/publish_profiles.sh <tag> copies what is judged into profiles/)
+#   bash tools/collect_r06.sh <tag>      -> gpurun_out/<tag>_*  (tools/publish_profiles.sh <tag> copies what is judged into profiles/)
 # Training legs run at the BASELINE configurations' own batch sizes (configs[2]: 64, configs[4]: 128); configs[3] (512^2, batch 8)
 # gets its own kernel-trace, per-launch and HBM-traffic records.
 cd "$GRAFT_REPO_ROOT" || exit 1
@@ -9,10 +9,11 @@ export TMPDIR=/tmp
 tag=$1
 mkdir -p gpurun_out
 # 1. the bench line as the driver runs it (extras and CPU baseline on)
-python bench.py > gpurun_out/${tag}_bench.json 2> gpurun_out/${tag}_bench.err
+# (stdout = the compact line the driver parses; the full record -- every class row of every leg -- goes to its own file)
+python bench.py --full-record gpurun_out/${tag}_bench.json > gpurun_out/${tag}_bench_line.json 2> gpurun_out/${tag}_bench.err
 # 2. headline: rocprofv3 kernel-trace summary, per-launch HIP-event records, PMC passes (HBM traffic; matrix-pipe utilisation)
 bash tools/prof_bench.sh ${tag} --steps 20 > /dev/null
-python bench.py --no-cpu --no-extras --steps 20 --prof-dump gpurun_out/${tag}_conv_launches.csv > /dev/null 2>&1
+python bench.py --no-cpu --no-extras --steps 20 --prof-dump gpurun_out/${tag}_conv_launches.csv --full-record /tmp/bench_full_scratch.json > /dev/null 2>&1
 bash tools/pmc_bench.sh ${tag} > gpurun_out/${tag}_pmc_traffic.txt
 bash tools/pmc_mfma.sh ${tag} > gpurun_out/${tag}_pmc_mfma.txt
 # 3. configs[3]: 512x512x4, the 6-level attention network, batch 8, fp32-equivalent (and bf16 for reference)
@@ -30,8 +31,14 @@ bash tools/prof_cmd.sh ${tag}_train_fp32 python tools/train_bench.py 64 3 fp32 >
 bash tools/prof_cmd.sh ${tag}_train_bf16 python tools/train_bench.py 128 3 bf16 > /dev/null
 PMC_CMD="python tools/train_bench.py 64 1 fp32" bash tools/pmc_bench.sh ${tag} _train_fp32 > gpurun_out/${tag}_pmc_traffic_train_fp32.txt
 PMC_CMD="python tools/train_bench.py 128 1 bf16" bash tools/pmc_bench.sh ${tag} _train_bf16 > gpurun_out/${tag}_pmc_traffic_train_bf16.txt
+# (GroupNorm-backward statistics from the data-gradient convs' epilogues, tuning key 37: same-box A/B, interleaved)
+{ for k in 1 0 1 0; do echo "key 37 = $k"; DSG_TUNING="37=$k" python tools/train_bench.py 128 4 bf16 | tail -1; done
+  for k in 1 0 1 0; do echo "key 37 = $k"; DSG_TUNING="37=$k" python tools/train_bench.py 64 4 fp32 | tail -1; done; } > gpurun_out/${tag}_gnb_ab.txt 2>&1
+DSG_TUNING="37=0" bash tools/prof_cmd.sh ${tag}_train_bf16_gnb_off python tools/train_bench.py 128 3 bf16 > /dev/null
+python tools/cpu_threads_sweep.py 8 16 32 64 128 > gpurun_out/${tag}_cpu_threads_sweep.txt 2>&1
 { python tools/train_bench.py 16 3 fp32; DSG_TUNING=31=0 python tools/train_bench.py 64 3 fp32; python tools/train_bench.py 64 3 fp32; python tools/train_bench.py 32 3 bf16;
   python tools/train_bench.py 128 3 bf16; python tools/train_bench.py 14 3 fp16; python tools/ref_point_probe.py 10; } > gpurun_out/${tag}_other_runs.txt 2>&1
+python tools/whole_call_probe.py 750 >> gpurun_out/${tag}_other_runs.txt 2>&1
 # 6. the other sampling legs
 { python tools/fwd_bench.py cfg4 8 20 fp32; python tools/fwd_bench.py cfg4 8 20 bf16; python tools/fwd_bench.py default3 1 50 fp32; python tools/fwd_bench.py default3 5 50 fp32;
   python tools/fwd_bench.py cfg5 128 10 bf16; } >> gpurun_out/${tag}_other_runs.txt 2>&1
