@@ -395,6 +395,7 @@ def train_e2e(net, opt, lrs, sch, cfg, batch, dtype, bare_ms, steps=6, warm=3):
         t0 = time.perf_counter()
         _write_synth_pngs(folder, 2 * batch)
         write_s = time.perf_counter() - t0
+        print("[bench]   e2e: loader", file=sys.stderr, flush=True)
         loader = imageops.GpuImageLoader(os.path.join(folder, "*.png"), (256, 256), batch, shuffle=True, seed=7, device=dev)
         decode_rate = loader.decode_rate(3)
         pil_loader = imageops.GpuImageLoader(os.path.join(folder, "*.png"), (256, 256), batch, workers=1, native_png=False, device=dev)
@@ -435,7 +436,9 @@ def train_e2e(net, opt, lrs, sch, cfg, batch, dtype, bare_ms, steps=6, warm=3):
             dt = time.perf_counter() - t_start
             assert torch.isfinite(last).all()
             return dt / steps * 1e3, float(last), clock.spread()
+        print("[bench]   e2e: host noise", file=sys.stderr, flush=True)
         host_ms, host_loss, host_spread = run("host")
+        print("[bench]   e2e: device noise", file=sys.stderr, flush=True)
         dev_ms, dev_loss, dev_spread = run(train_loop.DeviceNoise(seed=14555))
         return {"what": "PNG files -> GpuImageLoader -> train_steps, at the config's own batch; bare tape = device-resident x0 / noise / t",
                 "batch": batch, "dtype": dtype, "bare_tape_ms": bare_ms, "bare_tape_images_s": batch / bare_ms * 1e3,
@@ -1009,6 +1012,7 @@ def main():
                              ("train_bf16", lambda: train_leg(args, "bf16", batch=args.train_bf16_batch)),
                              ("train_fp16_reference_point", lambda: train_ref_leg(args)),
                              ("small_batch_sampling", lambda: small_batch_leg(args))):
+                print(f"[bench] extra record: {name}", file=sys.stderr, flush=True)   # (a GPU fault kills the process: say where)
                 try:
                     extras[name] = fn()
                 except Exception as e:  # noqa: BLE001

@@ -919,9 +919,12 @@ def _backward16(model, st: TrainState, tape: _Tape, dout):
         if (blocked(dy) and (blocked(x0) or x1 is None)
                 and ops.wgrad16_supported(c0, c1, co, x0.shape[2], x0.shape[3], k, stride, ups, dy_coff)):
             # (an fp32 [N, C, H, W] source -- the attention output in front of to_out -- is rounded to the tape's type first)
+            # (the sampler convs come through here too: Upsample2D's conv with x at HALF the K grid's resolution, the stride-2 conv
+            #  with dY at half of it -- addressed through a shift in the kernel, no x2 copy of x, no zero-stuffed copy of dY)
             xb = x0 if blocked(x0) else ops.to_blocked(x0.contiguous(), dt)
-            ops.conv_wgrad(xb, dy, st.grad(wname), src1=x1, ksize=k, gn_scale_shift=ss, silu=silu, cout=co, dy_coff=dy_coff,
-                           dy_sums=sums, dy_sums_stride=sums_stride, bias_grad=bias_grad if sums is not None else None)
+            ops.conv_wgrad(xb, dy, st.grad(wname), src1=x1, ksize=k, stride=stride, upsample=ups, gn_scale_shift=ss, silu=silu,
+                           cout=co, dy_coff=dy_coff, dy_sums=sums, dy_sums_stride=sums_stride,
+                           bias_grad=bias_grad if sums is not None else None)
             return (2 if bias_grad is not None else True) if sums is not None else False
         elif (k == 3 and stride == 2 and not ups and x1 is None and dy_coff == 0 and blocked(x0) and blocked(dy) and ss is None
               and ops.wgrad16_supported(c0, 0, co, x0.shape[2], x0.shape[3], 3)):
@@ -1017,9 +1020,14 @@ def _backward16(model, st: TrainState, tape: _Tape, dout):
             if rec["res"] is not None:
                 tape.addg(rec["res"], dy, lazy=True)
             bg = st.grad(wname + ".bias")
-            if rec["ups"]:   # weight gradient from the materialised nearest-x2 input, data gradient at full resolution
-                have = wgrad(ops.upsample_nearest2x(x0), None, dy, wname + ".weight", k, 1, False, None, False,
-                             sums=sums, sums_stride=sstride, bias_grad=bg)
+            if rec["ups"]:   # weight gradient against the nearest-x2 input, data gradient at full resolution
+                if x1 is None and blocked(x0) and blocked(dy) and ops.wgrad16_supported(chans(x0), 0, cout, x0.shape[2], x0.shape[3],
+                                                                                       k, 1, True):
+                    have = wgrad(x0, None, dy, wname + ".weight", k, 1, True, None, False,     # (x read at (y >> 1, x >> 1))
+                                 sums=sums, sums_stride=sstride, bias_grad=bg)
+                else:   # (shapes the kernel's sampler form does not take: the materialised x2 input)
+                    have = wgrad(ops.upsample_nearest2x(x0), None, dy, wname + ".weight", k, 1, False, None, False,
+                                 sums=sums, sums_stride=sstride, bias_grad=bg)
             else:
                 have = wgrad(x0, x1, dy, wname + ".weight", k, rec["stride"], False, rec["ss"], rec["silu"],
                              sums=sums, sums_stride=sstride, bias_grad=bg)

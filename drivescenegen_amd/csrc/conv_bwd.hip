@@ -1461,6 +1461,13 @@ struct Wgrad16P {
                         // of partials for the reduce pass to read back
   float* dysum_ws;      // optional [slab][cout]: per-run sums of dY over its pixels (bias / time-embedding gradients):
                         // the dY tiles pass through this kernel anyway -- saves a pass of its own over dY
+  // Sampler convs (round 6): the kernel's K grid (h x w) stays the FULL-resolution map, one operand lives at half resolution
+  // and is addressed through a shift -- no materialised copy:
+  //   xsh = 1  Upsample2D + conv (nearest x2 in front of the 3x3): x is [N][C/8][h/2][w/2][8], pixel (y, x) reads (y >> 1, x >> 1)
+  //            (was: dsg_upsample_nearest2x_blocked into a 4x larger tensor, 0.26 ms per layer at batch 128, then read back)
+  //   dsh = 1  Downsample2D's stride-2 conv: dY is [N][Co/8][h/2][w/2][8]; pixel (y, x) of the K grid is dY[y/2][x/2] when both are
+  //            even and ZERO otherwise (was: a strided torch copy into a zeroed full-resolution buffer per step)
+  int xsh, dsh;
 };
 
 typedef short wg_s4 __attribute__((ext_vector_type(4)));
@@ -1518,6 +1525,9 @@ __global__ __launch_bounds__(256, COT == 2 ? 1 : 2) void conv_wgrad16_kernel(Wgr
   const int cib = pair_id % p.ci_blocks, cob = pair_id / p.ci_blocks;
   const int ci0 = cib * 64, co0 = cob * COW;
   const int plane = p.h * p.w;
+  // half-resolution operands of the sampler convs (uniform shifts: see Wgrad16P)
+  const int xsh = __builtin_amdgcn_readfirstlane(p.xsh), dsh = __builtin_amdgcn_readfirstlane(p.dsh);
+  const int xplane = plane >> (2 * xsh), xw = p.w >> xsh, dplane = plane >> (2 * dsh), dw_ = p.w >> dsh;
   const bool has_ss = ACT == 2 ? p.ss != nullptr : ACT == 1;
   const bool do_silu = ACT == 2 ? (has_ss && p.silu) : ACT == 1;
 
@@ -1536,9 +1546,9 @@ __global__ __launch_bounds__(256, COT == 2 ? 1 : 2) void conv_wgrad16_kernel(Wgr
   auto begin_strip = [&](int strip) {  // per-strip state: image, column tile, source bases, the image's scale / shift
     n = strip / p.tiles_x;
     ox0 = (strip - n * p.tiles_x) * 32;
-    xsrc = in0 ? static_cast<const unsigned short*>(p.src0) + ((size_t)n * p.c0 + ci0) * plane
-               : static_cast<const unsigned short*>(p.src1) + ((size_t)n * p.c1 + (ci0 - p.c0)) * plane;
-    dsrc = static_cast<const unsigned short*>(p.dy) + ((size_t)n * p.dy_ctotal + p.dy_coff + co0) * plane;
+    xsrc = in0 ? static_cast<const unsigned short*>(p.src0) + ((size_t)n * p.c0 + ci0) * xplane
+               : static_cast<const unsigned short*>(p.src1) + ((size_t)n * p.c1 + (ci0 - p.c0)) * xplane;
+    dsrc = static_cast<const unsigned short*>(p.dy) + ((size_t)n * p.dy_ctotal + p.dy_coff + co0) * dplane;
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
       sc[j] = 1.f;
@@ -1566,7 +1576,7 @@ __global__ __launch_bounds__(256, COT == 2 ? 1 : 2) void conv_wgrad16_kernel(Wgr
     for (int u = 0; u < 3; ++u) {
       const int y = 2 * k - PADK + a_row[u], x = ox0 - PADK + a_col[u];
       valid[u] = a_use[u] && (unsigned)y < (unsigned)p.h && (unsigned)x < (unsigned)p.w;
-      const size_t off = (size_t)a_cb * 8 * plane + ((size_t)(valid[u] ? y : 0) * p.w + (valid[u] ? x : 0)) * 8;
+      const size_t off = (size_t)a_cb * 8 * xplane + ((size_t)((valid[u] ? y : 0) >> xsh) * xw + ((valid[u] ? x : 0) >> xsh)) * 8;
       dst[u] = *reinterpret_cast<const uint4*>(xsrc + off);
     }
   };
@@ -1576,7 +1586,9 @@ __global__ __launch_bounds__(256, COT == 2 ? 1 : 2) void conv_wgrad16_kernel(Wgr
     for (int u = 0; u < 2 * COT; ++u) {
       const int id = tid + 256 * u, cb = id & (DCB - 1), px = id >> DSH;
       const int y = min(2 * s + (px >> 5), p.h - 1), x = ox0 + (px & 31);
-      dst[u] = *reinterpret_cast<const uint4*>(dsrc + (size_t)cb * 8 * plane + ((size_t)y * p.w + x) * 8);
+      const uint4 q = *reinterpret_cast<const uint4*>(dsrc + (size_t)cb * 8 * dplane + ((size_t)(y >> dsh) * dw_ + (x >> dsh)) * 8);
+      const bool hole = dsh != 0 && ((y | x) & 1) != 0;   // (stride-2 conv: the odd rows / columns of the K grid carry no dY)
+      dst[u] = hole ? make_uint4(0u, 0u, 0u, 0u) : q;
     }
   };
   auto load_dy = [&](int s) { load_dy_to(s, xd); };
@@ -2116,10 +2128,18 @@ static void wgrad16_runs(int cin, int cout, int n, int hout, int wout, int cot, 
   if (spw) *spw = per;
 }
 
+// (hout, wout): the kernel's K grid -- the conv's output map; for the two sampler forms the FULL-resolution one: the output map of
+// Upsample2D's conv (2 hin x 2 win), the input map of Downsample2D's stride-2 conv (hin x win): wgrad16_kgrid
+static void wgrad16_kgrid(const dsg_conv_wgrad_args* a, int* kh, int* kw) {
+  *kh = a->upsample ? 2 * a->hin : a->hin;
+  *kw = a->upsample ? 2 * a->win : a->win;
+}
 static bool wgrad16_ok(const dsg_conv_wgrad_args* a, int hout, int wout) {
   const int cin = a->c0 + a->c1, ctot = a->dy_ctotal ? a->dy_ctotal : a->cout;
-  const bool chans = a->stride == 1 && !a->upsample && cin % 64 == 0 && (a->c1 == 0 || a->c0 % 64 == 0) &&
-                     a->cout % 64 == 0 && ctot % 8 == 0 && a->dy_coff % 64 == 0;
+  const bool sampler = (a->upsample != 0) != (a->stride == 2);   // one half-resolution operand (never both)
+  const bool chans = (a->stride == 1 || a->stride == 2) && !(a->upsample && a->stride == 2) && cin % 64 == 0 &&
+                     (a->c1 == 0 || a->c0 % 64 == 0) && a->cout % 64 == 0 && ctot % 8 == 0 && a->dy_coff % 64 == 0;
+  if (sampler) return chans && a->ksize == 3 && a->c1 == 0 && wout % 64 == 0 && hout % 4 == 0;
   if (a->ksize == 1) return chans && (hout * wout) % 64 == 0;  // (re-tiled as rows of 32 pixels)
   return chans && a->ksize == 3 && wout % 32 == 0 && hout % 2 == 0;
 }
@@ -2206,6 +2226,8 @@ static int launch_wgrad16(const dsg_conv_wgrad_args* a, int hout, int wout, hipS
   p.n = a->n; p.h = hout; p.w = wout; p.cout = a->cout;
   p.dy = a->dy; p.dy_ctotal = a->dy_ctotal ? a->dy_ctotal : a->cout; p.dy_coff = a->dy_coff;
   p.ss = a->gn_scale_shift; p.silu = a->silu; p.ws = static_cast<float*>(a->workspace);
+  p.xsh = a->upsample ? 1 : 0;
+  p.dsh = a->stride == 2 ? 1 : 0;
   p.tiles_x = wout / 32; p.stages = hout / 2; p.ci_blocks = p.cin / 64;
   int strips, rsplit, spw;
   const int cot = wgrad16_cot(p.cout, a->ksize);
@@ -2219,8 +2241,8 @@ static int launch_wgrad16(const dsg_conv_wgrad_args* a, int hout, int wout, hipS
   p.dysum_ws = a->dy_sums ? p.ws + (size_t)nslab * taps * p.cin * p.cout : nullptr;
   int pi = -1;
   if (prof_on())
-    pi = prof_begin(29, 2.0 * p.n * hout * wout * (double)p.cout * p.cin * taps,
-                    2.0 * ((double)p.n * p.cin * p.h * p.w + (double)p.n * p.cout * hout * wout), st);
+    pi = prof_begin(29, 2.0 * p.n * (hout >> p.dsh) * (wout >> p.dsh) * (double)p.cout * p.cin * taps,   // (the reference op's FLOPs)
+                    2.0 * ((double)p.n * p.cin * (p.h >> p.xsh) * (p.w >> p.xsh) + (double)p.n * p.cout * (hout >> p.dsh) * (wout >> p.dsh)), st);
   const dim3 grid(p.ci_blocks * (p.cout / (64 * cot)), nslab);
   const bool bf = a->compute_dtype == DSG_BF16;
   const int act = p.ss == nullptr ? 0 : (p.silu ? 1 : 2);
@@ -2302,12 +2324,14 @@ DSG_API int dsg_conv2d_wgrad(const dsg_conv_wgrad_args* a, void* stream) {
   DSG_CHECK_ARG(a->dy_bias_grad == nullptr || a->dy_sums != nullptr, "dsg_conv2d_wgrad: dy_bias_grad rides on dy_sums (give both)");
 
   if (a->compute_dtype != DSG_F32) {  // mixed-precision tape: channel-blocked 16-bit x and dY
-    DSG_CHECK_SHAPE(wgrad16_ok(a, a->hin, a->win) && !a->force_direct,
-                    "dsg_conv2d_wgrad: the 16-bit kernel takes stride-1 3x3 / 1x1 convs with cin %% 64 == 0, cout %% 64 == 0 "
-                    "and (3x3) wout %% 32 == 0, hout %% 2 == 0 or (1x1) h * w %% 64 == 0 (got k %d, stride %d, cin %d + %d, "
-                    "cout %d, %dx%d); convert to fp32 [N,C,H,W] for the rest", a->ksize, a->stride, a->c0, a->c1, a->cout,
-                    a->hin, a->win);
-    return launch_wgrad16(a, a->hin, a->win, st);
+    int kh, kw;
+    wgrad16_kgrid(a, &kh, &kw);
+    DSG_CHECK_SHAPE(wgrad16_ok(a, kh, kw) && !a->force_direct,
+                    "dsg_conv2d_wgrad: the 16-bit kernel takes 3x3 (stride 1, incl. the up-sampler's; stride 2) / 1x1 convs with "
+                    "cin %% 64 == 0, cout %% 64 == 0 and (3x3) wout %% 32 == 0, hout %% 2 == 0 or (1x1) h * w %% 64 == 0 (got k %d, "
+                    "stride %d, upsample %d, cin %d + %d, cout %d, %dx%d); convert to fp32 [N,C,H,W] for the rest", a->ksize,
+                    a->stride, a->upsample, a->c0, a->c1, a->cout, a->hin, a->win);
+    return launch_wgrad16(a, kh, kw, st);
   }
   WgradP p;
   p.src0 = a->src0; p.src1 = a->src1; p.c0 = a->c0; p.c1 = a->c1; p.cin = a->c0 + a->c1;
@@ -2350,8 +2374,10 @@ DSG_API int dsg_conv2d_wgrad_workspace_bytes(const dsg_conv_wgrad_args* a, size_
   const int pad = a->ksize / 2;
   const int hout = (hc + 2 * pad - a->ksize) / a->stride + 1, wout = (wc + 2 * pad - a->ksize) / a->stride + 1;
   if (a->compute_dtype != DSG_F32) {
-    DSG_CHECK_SHAPE(dsg::wgrad16_ok(a, hout, wout), "dsg_conv2d_wgrad_workspace_bytes: shape not served by the 16-bit kernel");
-    *bytes = dsg::wgrad16_ws_bytes(a->c0 + a->c1, a->cout, a->ksize, a->n, hout, wout);
+    int kh, kw;
+    dsg::wgrad16_kgrid(a, &kh, &kw);
+    DSG_CHECK_SHAPE(dsg::wgrad16_ok(a, kh, kw), "dsg_conv2d_wgrad_workspace_bytes: shape not served by the 16-bit kernel");
+    *bytes = dsg::wgrad16_ws_bytes(a->c0 + a->c1, a->cout, a->ksize, a->n, kh, kw);
     return DSG_OK;
   }
   *bytes = a->force_direct ? 0 : dsg::wgrad_ws_bytes(a->c0 + a->c1, a->cout, a->ksize, a->stride, hout, wout, a->n);

@@ -501,8 +501,13 @@ def philox_normal(shape, seed: int, offset: int, device="cuda") -> torch.Tensor:
 def wgrad16_supported(c0, c1, cout, h, w, ksize=3, stride=1, upsample=False, dy_coff=0) -> bool:
     """Shapes dsg_conv2d_wgrad serves on channel-blocked 16-bit tensors (include/dsg.h); the rest goes through
     from_blocked() and the fp32 form."""
-    chans = (stride == 1 and not upsample and (c0 + c1) % 64 == 0 and (c1 == 0 or c0 % 64 == 0) and cout % 64 == 0
-             and dy_coff % 64 == 0)
+    chans = (stride in (1, 2) and not (upsample and stride == 2) and (c0 + c1) % 64 == 0 and (c1 == 0 or c0 % 64 == 0)
+             and cout % 64 == 0 and dy_coff % 64 == 0)
+    if upsample or stride == 2:
+        # the sampler convs: h, w = the source map; one operand at half the K grid's resolution (x behind Upsample2D, dY of the
+        # stride-2 conv), addressed through a shift inside the kernel -- no materialised x2 copy, no zero-stuffed dY
+        kh, kw = (2 * h, 2 * w) if upsample else (h, w)
+        return chans and ksize == 3 and c1 == 0 and kw % 64 == 0 and kh % 4 == 0
     if ksize == 1:
         return chans and (h * w) % 64 == 0
     return chans and ksize == 3 and w % 32 == 0 and h % 2 == 0

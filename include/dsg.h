@@ -466,8 +466,13 @@ typedef struct {
                                    precision training tape): src0 / src1 / dy are channel-blocked [N, C/8, H, W, 8] tensors of
                                    that type, products run once on the 16-bit matrix cores, dw stays fp32.  Served: 3x3
                                    stride-1 convs with (c0 + c1) % 64 == 0, c0 % 64 == 0 when c1 > 0, cout % 64 == 0,
-                                   dy_ctotal % 8 == 0 and dy_coff % 64 == 0, wout % 32 == 0, hout % 2 == 0; anything else is
-                                   DSG_ERR_UNSUPPORTED_SHAPE (convert with dsg_layout_convert_dt and use the fp32 form). */
+                                   dy_ctotal % 8 == 0 and dy_coff % 64 == 0, wout % 32 == 0, hout % 2 == 0; the two SAMPLER
+                                   convs with c1 == 0 on a full-resolution grid of a multiple of 64 columns and 4 rows --
+                                   upsample = 1 (Upsample2D's conv: src0 is the LOW-resolution [N, C/8, hin, win, 8] tensor, read at
+                                   (y >> 1, x >> 1); no nearest-x2 copy is made) and stride = 2 (Downsample2D's conv: dy is the
+                                   [N, Co/8, hin/2, win/2, 8] gradient, taken as zero between its pixels; no zero-stuffed copy is
+                                   made); anything else is DSG_ERR_UNSUPPORTED_SHAPE (convert with dsg_layout_convert_dt and use
+                                   the fp32 form). */
   float* dy_sums;               /* optional; the 16-bit form, and the fp32 form where the split 3x3 kernel serves it (stride 1,
                                    cin % 32 == 0, cout % 64 == 0, wout % 32 == 0, hout % 2 == 0; DSG_ERR_INVALID_ARG
                                    otherwise): out[n * dy_sums_stride + co] = sum over pixels of dY[n][co] (this

@@ -65,6 +65,48 @@ def test_wgrad16(case, mode):
     assert rel_l2(got, ref) <= (2e-4 if gn else 2e-5), rel_l2(got, ref)
 
 
+@pytest.mark.parametrize("mode", ["bf16", "fp16"])
+@pytest.mark.parametrize("case", [("upsample_wide", "ups", 128, 128, 16, 32, 3), ("upsample_64_couts", "ups", 64, 64, 8, 64, 2),
+                                  ("upsample_two_strips", "ups", 64, 256, 6, 64, 2),
+                                  ("stride2_wide", "s2", 128, 128, 32, 64, 3), ("stride2_64_couts", "s2", 64, 64, 16, 128, 2)],
+                         ids=lambda c: c[0])
+def test_wgrad16_sampler_convs_read_the_half_resolution_operand_in_place(case, mode):
+    """The two sampler convs of the U-Net on the 16-bit weight-gradient kernel without a materialised copy (round 6):
+    Upsample2D's conv (train.py:39-57's up blocks: nearest x2 then 3x3) reads the LOW-resolution x at (y >> 1, x >> 1) -- the
+    tape used to write a 4x larger upsampled tensor first; Downsample2D's stride-2 conv takes dY as zero between its pixels --
+    the tape used to copy dY into a zeroed full-resolution buffer with a strided torch copy.  Against fp64 on the same rounded
+    operands, and bitwise against the old route (the same kernel on the materialised tensors: the products and their order
+    are the same)."""
+    _, kind, cin, cout, h, w, n = case          # (h, w): x's map
+    x = _rnd(_t(11, (n, cin, h, w)), mode)
+    xb = ops.to_blocked(x.to(DEV), mode)
+    dw = torch.full((cout, cin, 3, 3), 0.5, dtype=torch.float32, device=DEV)
+    old = torch.full((cout, cin, 3, 3), 0.5, dtype=torch.float32, device=DEV)
+    sums, sums_old = (torch.zeros((n, cout), dtype=torch.float32, device=DEV) for _ in range(2))
+    if kind == "ups":
+        dy = _rnd(_t(12, (n, cout, 2 * h, 2 * w), 0.3), mode)
+        dyb = ops.to_blocked(dy.to(DEV), mode)
+        ref = torch.nn.grad.conv2d_weight(F.interpolate(x.double(), scale_factor=2.0, mode="nearest"), (cout, cin, 3, 3),
+                                          dy.double(), padding=1)
+        assert ops.wgrad16_supported(cin, 0, cout, h, w, 3, 1, True)
+        ops.conv_wgrad(xb, dyb, dw, ksize=3, upsample=True, dy_sums=sums)
+        ops.conv_wgrad(ops.upsample_nearest2x(xb), dyb, old, ksize=3, dy_sums=sums_old)
+    else:
+        dy = _rnd(_t(12, (n, cout, h // 2, w // 2), 0.3), mode)
+        dyb = ops.to_blocked(dy.to(DEV), mode)
+        ref = torch.nn.grad.conv2d_weight(x.double(), (cout, cin, 3, 3), dy.double(), stride=2, padding=1)
+        assert ops.wgrad16_supported(cin, 0, cout, h, w, 3, 2, False)
+        ops.conv_wgrad(xb, dyb, dw, ksize=3, stride=2, dy_sums=sums)
+        up = torch.zeros((n, cout // 8, h, w, 8), dtype=dyb.dtype, device=DEV)
+        up[:, :, ::2, ::2].copy_(dyb)
+        ops.conv_wgrad(xb, up, old, ksize=3, dy_sums=sums_old)
+    assert torch.equal(dw, old) and torch.equal(sums, sums_old)
+    assert torch.allclose(sums.cpu().double(), dy.double().sum((2, 3)), rtol=1e-5, atol=1e-4)
+    assert rel_l2(dw.cpu().double() - 0.5, ref) <= 2e-5, rel_l2(dw.cpu().double() - 0.5, ref)
+    # a shape outside the sampler form says so
+    assert not ops.wgrad16_supported(cin, 64, cout, h, w, 3, 1, True) and not ops.wgrad16_supported(cin, 0, cout, 8, 16, 3, 2, False)
+
+
 @pytest.mark.parametrize("act", ["plain", "gn_silu", "gn_affine"])
 @pytest.mark.parametrize("shape", [(128, 64, 128, 16, 32, 3), (64, 0, 256, 12, 64, 5), (384, 0, 128, 32, 32, 4)],
                          ids=["concat_192_128", "64_256_two_strips", "384_128"])
