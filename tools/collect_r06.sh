@@ -8,9 +8,10 @@ cd "$GRAFT_REPO_ROOT" || exit 1
 export TMPDIR=/tmp
 tag=$1
 mkdir -p gpurun_out
+# (every command runs under `timeout`: a GPU fault under rocprofv3 once left the profiler hanging for 43 minutes of box time)
 # 1. the bench line as the driver runs it (extras and CPU baseline on)
 # (stdout = the compact line the driver parses; the full record -- every class row of every leg -- goes to its own file)
-python bench.py --full-record gpurun_out/${tag}_bench.json > gpurun_out/${tag}_bench_line.json 2> gpurun_out/${tag}_bench.err
+timeout 1200 python bench.py --full-record gpurun_out/${tag}_bench.json > gpurun_out/${tag}_bench_line.json 2> gpurun_out/${tag}_bench.err
 # 2. headline: rocprofv3 kernel-trace summary, per-launch HIP-event records, PMC passes (HBM traffic; matrix-pipe utilisation)
 bash tools/prof_bench.sh ${tag} --steps 20 > /dev/null
 python bench.py --no-cpu --no-extras --steps 20 --prof-dump gpurun_out/${tag}_conv_launches.csv --full-record /tmp/bench_full_scratch.json > /dev/null 2>&1

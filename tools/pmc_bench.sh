@@ -1,5 +1,5 @@
 #!/bin/bash
-# HBM traffic of the bench's kernels from the memory-side L2 counters, one rocprofv3 --pmc pass per counter
+# HBM traffic of the bench's kernels from the memory-side L2 counters, one timeout 900 rocprofv3 --pmc pass per counter
 # (kernel-trace only).  Writes gpurun_out/<tag>_pmc_traffic.json: per kernel, launches and mean bytes per launch,
 # FETCH_SIZE doubled as /opt/skills/guides/MI355X_MICROARCH.md (HBM section) prescribes for gfx950 -- checked here
 # on a 1x1 conv with a known read size (805.3 MB read: FETCH_SIZE reported 394,948 KiB = 0.502 of it; WRITE_SIZE
@@ -15,7 +15,7 @@ export PMC_CMD_TEXT="$cmd"
 export DSG_GIT_HEAD=$(cat tools/_head.txt 2>/dev/null || echo unknown)
 mkdir -p gpurun_out
 for c in FETCH_SIZE WRITE_SIZE; do
-  rocprofv3 --pmc $c --kernel-trace -d /tmp/pmcb_${tag}${PMC_SUFFIX}_$c -o p --output-format csv -- \
+  timeout 900 rocprofv3 --pmc $c --kernel-trace -d /tmp/pmcb_${tag}${PMC_SUFFIX}_$c -o p --output-format csv -- \
     $cmd > /dev/null 2> gpurun_out/${tag}_pmc_$c$PMC_SUFFIX.err
 done
 python - "$tag" <<'PY'

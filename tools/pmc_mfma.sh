@@ -1,5 +1,5 @@
 #!/bin/bash
-# Matrix-core utilisation of the bench's kernels from the SQ counters (one rocprofv3 --pmc pass, kernel-trace only).
+# Matrix-core utilisation of the bench's kernels from the SQ counters (one timeout 900 rocprofv3 --pmc pass, kernel-trace only).
 # Writes gpurun_out/<tag>_pmc_mfma.json: per kernel, launches and per-launch means of SQ_INSTS_MFMA (MFMA instructions
 # issued, summed over waves), SQ_VALU_MFMA_BUSY_CYCLES, SQ_BUSY_CYCLES, GRBM_GUI_ACTIVE (GPU-clock cycles the kernel
 # was resident), and two utilisation figures:
@@ -19,7 +19,7 @@ cmd=${PMC_CMD:-"python bench.py --steps 3 --warmup 1 --no-cpu --no-prof --no-ext
 export PMC_CMD_TEXT="$cmd"
 export DSG_GIT_HEAD=$(cat tools/_head.txt 2>/dev/null || echo unknown)
 mkdir -p gpurun_out
-rocprofv3 --pmc SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE --kernel-trace -d /tmp/pmcm_$tag$PMC_SUFFIX -o p \
+timeout 900 rocprofv3 --pmc SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE --kernel-trace -d /tmp/pmcm_$tag$PMC_SUFFIX -o p \
   --output-format csv -- $cmd > /dev/null 2> gpurun_out/${tag}_pmc_mfma$PMC_SUFFIX.err
 python - "$tag" <<'PY'
 import csv, glob, json, os, re, sys, collections

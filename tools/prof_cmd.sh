@@ -1,11 +1,11 @@
 #!/bin/bash
-# rocprofv3 --kernel-trace --stats over an arbitrary command; compact per-kernel summary to gpurun_out/<tag>_kernel_stats.csv
+# timeout 900 rocprofv3 --kernel-trace --stats over an arbitrary command; compact per-kernel summary to gpurun_out/<tag>_kernel_stats.csv
 # Usage (on the GPU box): bash tools/prof_cmd.sh <tag> <command...>
 cd "$GRAFT_REPO_ROOT" || exit 1
 export TMPDIR=/tmp
 tag=$1; shift
 mkdir -p gpurun_out
-rocprofv3 --kernel-trace --stats -d /tmp/prof_$tag -o p --output-format csv -- "$@" > gpurun_out/${tag}_stdout.txt 2> gpurun_out/${tag}_rocprof.err
+timeout 900 rocprofv3 --kernel-trace --stats -d /tmp/prof_$tag -o p --output-format csv -- "$@" > gpurun_out/${tag}_stdout.txt 2> gpurun_out/${tag}_rocprof.err
 f=$(find /tmp/prof_$tag -name "*kernel_stats.csv" | head -1)
 python - "$f" gpurun_out/${tag}_kernel_stats.csv <<'PY'
 import csv, sys, re
