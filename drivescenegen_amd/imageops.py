@@ -262,7 +262,8 @@ class GpuImageLoader:
                 q.put(e)
             q.put(None)
 
-        threading.Thread(target=producer, daemon=True).start()
+        worker = threading.Thread(target=producer, daemon=True)
+        worker.start()
         try:
             while True:
                 item = q.get()
@@ -275,14 +276,16 @@ class GpuImageLoader:
                 cur.wait_event(ready)
                 out.record_stream(cur)      # (allocated on the side stream, used on the consumer's)
                 yield out
-        finally:     # a consumer that stops early: let the producer run out instead of blocking on a full queue for ever
+        finally:
+            # a consumer that stops early: tell the producer, keep the queue drained so that it cannot block on a full queue, and
+            # JOIN it -- when the iterator is gone no thread of this loader is still decoding, copying or launching kernels
             stop.set()
-            while True:
+            while worker.is_alive():
                 try:
-                    if q.get_nowait() is None:
-                        break
+                    q.get(timeout=0.05)
                 except queue.Empty:
-                    break
+                    pass
+            worker.join()
 
 
 # --------------------------------------------------------------------------------------------------

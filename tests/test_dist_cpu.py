@@ -354,3 +354,20 @@ def test_untrusted_pickles_that_need_full_unpickling_are_skipped_like_non_dicts(
     ds = Image_Dataset(cfg)
     with pytest.raises(IndexError, match="no usable sample"):
         ds[0]
+
+
+def test_device_noise_streams_are_rank_disjoint_and_resumable():
+    """train_loop.DeviceNoise (the opt-in replacement of training_pipeline.py:72's host draw): step k on rank r draws the tensor
+    named (seed, offset = r << 40 | k) -- different ranks never share an offset, a run resumed at step k continues the same
+    sequence, and the oracle's streams for two such names really differ (host logic + the numpy restatement: no GPU)."""
+    import numpy as np
+    from drivescenegen_amd.train_loop import DeviceNoise
+    from oracle import philox_oracle as po
+    a, b = DeviceNoise(seed=3, rank=0), DeviceNoise(seed=3, rank=1)
+    offs_a, offs_b = [a.next_offset() for _ in range(6)], [b.next_offset() for _ in range(6)]
+    assert offs_a == list(range(6)) and offs_b == [(1 << 40) | k for k in range(6)]
+    assert not set(offs_a) & set(offs_b)
+    resumed = DeviceNoise(seed=3, rank=1, step=4)
+    assert [resumed.next_offset(), resumed.next_offset()] == offs_b[4:6]
+    s0, s1 = po.stream_u32(64, 3, offs_a[1]), po.stream_u32(64, 3, offs_b[1])
+    assert not np.array_equal(s0, s1) and np.array_equal(s0, po.stream_u32(64, 3, 1))
