@@ -785,18 +785,24 @@ def summary_of(out):
             for sub in ("second_kernel", "fused_shortcut_kernel", "fused_shortcut_two_wg_kernel"):
                 if isinstance(rf.get(sub), dict):
                     d["roofline"][sub + "_frac"] = rf[sub].get("frac")
-        if isinstance(r.get("e2e"), dict):
-            e = r["e2e"]
-            d["e2e"] = ({"error": e["error"][:160]} if "error" in e else
-                        {k: round(e[k], 3) for k in ("host_noise_images_s", "device_noise_images_s", "device_noise_vs_bare",
-                                                     "host_noise_vs_bare", "host_draw_ms", "loader_images_s",
-                                                     "decode_pool_images_s", "pil_one_thread_images_s") if k in e})
         if isinstance(r.get("step_ms_spread"), dict):
             d["step_ms_min_med_max"] = [round(r["step_ms_spread"][k], 3) for k in ("min", "median", "max")]
         return d
     s = {"headline": short(out)}
     for name, rec in (out.get("extra_records") or {}).items():
         s[name] = short(rec)
+    # the training loop END TO END (files -> loader -> train_steps) next to the bare tape, one entry per training config
+    e2e = {}
+    for name, rec in (out.get("extra_records") or {}).items():
+        e = rec.get("e2e") if isinstance(rec, dict) else None
+        if isinstance(e, dict):
+            key = f"{e.get('dtype', name)}_b{e.get('batch', '')}" if "error" not in e else name
+            e2e[key] = ({"error": e["error"][:160]} if "error" in e else
+                        {k: round(e[k], 3) for k in ("bare_tape_images_s", "device_noise_images_s", "host_noise_images_s",
+                                                     "device_noise_vs_bare", "host_noise_vs_bare", "host_draw_ms", "loader_images_s",
+                                                     "decode_pool_images_s", "pil_one_thread_images_s") if k in e})
+    if e2e:
+        s["train_e2e"] = e2e
     for name, rec in (out.get("train_ddp") or {}).items():
         s["train_ddp_" + name] = ({"error": rec["error"][:200]} if "error" in rec else
                                   {k: rec[k] for k in ("value", "unit", "batch_per_gpu", "world", "backend", "ms", "exposed_comm_ms",

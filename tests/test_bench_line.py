@@ -88,3 +88,30 @@ def test_counter_traffic_is_at_least_the_algorithmic_bytes():
 def test_upsample_class_carries_its_footnote():
     b = _bench()
     assert "4/9" in b.CLASS_NOTES["conv3x3_upsample_mfma_f16x2split"]
+
+
+def test_round6_record_digests_the_end_to_end_loop_and_the_ddp_step():
+    """The records round 6 added must reach the line the driver parses: `summary.train_e2e` (files -> loader -> train_steps at
+    the two training configs' own batch, next to the bare tape: VERDICT r05 item 1) from a full record of the GPU box, and
+    `summary.train_ddp_*` (the data-parallel step with the buckets off / overlapped / deferred: item 3) -- still under 6 KB."""
+    b = _bench()
+    full = json.load(open(os.path.join(ROOT, "profiles", "r06_bench.json")))
+    full["train_ddp"] = {"fp32": {"value": 1990.0, "unit": "images/s", "batch_per_gpu": 64, "world": 8, "backend": "nccl",
+                                  "ms": {"local": 254.0, "overlap": 257.0, "deferred": 262.0},
+                                  "exposed_comm_ms": {"overlap": 3.0, "deferred": 8.0}, "buckets": 8, "selfcheck_bitwise": True,
+                                  "per_rank_ms": {"overlap": [257.0] * 8}, "config": {"workload": "w" * 300}},
+                         "bf16": {"error": "RuntimeError: " + "x" * 2000}}
+    full["summary"] = b.summary_of(full)
+    text = b.compact_line(full, "gpurun_out/bench_full.json")
+    assert len(text) < 6000, len(text)
+    line = json.loads(text)
+    e2e = line["summary"]["train_e2e"]
+    assert set(e2e) == {"fp32_b64", "bf16_b128"}
+    for key, rec in e2e.items():
+        assert 0.95 <= rec["device_noise_vs_bare"] <= 1.05, (key, rec)        # the verdict's bar for the device-noise mode
+        assert 0.9 <= rec["host_noise_vs_bare"] <= 1.05 and rec["loader_images_s"] > 5 * rec["pil_one_thread_images_s"]
+        assert abs(rec["device_noise_images_s"] / rec["bare_tape_images_s"] - rec["device_noise_vs_bare"]) < 2e-3
+    assert "BARE TAPE" in full["extra_records"]["train_bf16"]["metric"]
+    ddp = line["summary"]["train_ddp_fp32"]
+    assert ddp["world"] == 8 and ddp["exposed_comm_ms"] == {"overlap": 3.0, "deferred": 8.0} and ddp["selfcheck_bitwise"] is True
+    assert "per_rank_ms" not in ddp and line["summary"]["train_ddp_bf16"]["error"].startswith("RuntimeError")
