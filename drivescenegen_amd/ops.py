@@ -6,6 +6,7 @@ the whole-network plan (dsg_unet_forward) instead.  GPU tensors only -- no fallb
 from __future__ import annotations
 
 import ctypes as C
+import os
 
 import torch
 
@@ -504,6 +505,8 @@ def wgrad16_supported(c0, c1, cout, h, w, ksize=3, stride=1, upsample=False, dy_
     chans = (stride in (1, 2) and not (upsample and stride == 2) and (c0 + c1) % 64 == 0 and (c1 == 0 or c0 % 64 == 0)
              and cout % 64 == 0 and dy_coff % 64 == 0)
     if upsample or stride == 2:
+        if os.environ.get("DSG_W16_SAMPLER") == "0":   # A/B hook (tools/collect_r06.sh): the round-5 route on materialised tensors
+            return False
         # the sampler convs: h, w = the source map; one operand at half the K grid's resolution (x behind Upsample2D, dY of the
         # stride-2 conv), addressed through a shift inside the kernel -- no materialised x2 copy, no zero-stuffed dY
         kh, kw = (2 * h, 2 * w) if upsample else (h, w)
