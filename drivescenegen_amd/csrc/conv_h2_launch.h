@@ -157,6 +157,7 @@ int conv_h2_launch_t(const dsg_conv_args* a, int hout, int wout, hipStream_t st)
   const int lay = (a->src_layout ? 1 : 0) | (a->dst_layout ? 2 : 0);
   const int act = a->gn_scale_shift ? (a->silu ? 2 : 3) : 0;
   int rc = DSG_OK;
+  bool gnb_done = false;   // (a gnb call must end in a GNB instantiation: conv_h2_gnb_ok and this dispatch are checked against each other below)
   // split-K (PREC 0, every tensor channel-blocked, plain / stride-2 3x3 and pointwise): the slices write fp32 partials
   // to the caller's scratch, the reduce pass does what the epilogue would have
   int stat_splits = 1;
@@ -284,13 +285,13 @@ int conv_h2_launch_t(const dsg_conv_args* a, int hout, int wout, hipStream_t st)
           if (r16) {
             const size_t l128 = 2 * (size_t)H2Geom<4, 3, 4, 9, 128, NP>::BUF_BYTES + ssb;
             if (sc) rc = h2_launch<0, 4, 3, 2, 4, 1, 3, 128, PREC, 0, 1>(g128, l128, st, q);
-            else if (gnb) rc = h2_launch<0, 4, 3, 0, 4, 1, 3, 128, PREC, 0, 0, 0, 1>(g128, l128, st, q);
+            else if (gnb) { gnb_done = true; rc = h2_launch<0, 4, 3, 0, 4, 1, 3, 128, PREC, 0, 0, 0, 1>(g128, l128, st, q); }
             else if (act == 0) rc = h2_launch<0, 4, 3, 0, 4, 1, 3, 128, PREC>(g128, l128, st, q);
             else rc = h2_launch<0, 4, 3, 2, 4, 1, 3, 128, PREC>(g128, l128, st, q);
           } else {
             const size_t l128 = 2 * (size_t)H2Geom<2, 3, 4, 9, 128, NP>::BUF_BYTES + ssb;
             if (sc) rc = h2_launch<0, 2, 3, 2, 4, 1, 3, 128, PREC, 0, 1>(g128, l128, st, q);
-            else if (gnb) rc = h2_launch<0, 2, 3, 0, 4, 1, 3, 128, PREC, 0, 0, 0, 1>(g128, l128, st, q);
+            else if (gnb) { gnb_done = true; rc = h2_launch<0, 2, 3, 0, 4, 1, 3, 128, PREC, 0, 0, 0, 1>(g128, l128, st, q); }
             else if (act == 0) rc = h2_launch<0, 2, 3, 0, 4, 1, 3, 128, PREC>(g128, l128, st, q);
             else rc = h2_launch<0, 2, 3, 2, 4, 1, 3, 128, PREC>(g128, l128, st, q);
           }
@@ -303,6 +304,7 @@ int conv_h2_launch_t(const dsg_conv_args* a, int hout, int wout, hipStream_t st)
         else rc = h2_launch<0, 2, 3, 2, 4, 1, 3, 64, PREC, 0, 1>(grid, lds, st, p);
       } else if (gnb) {
         if constexpr (PREC != 0) {
+          gnb_done = true;
           if (nt4) rc = h2_launch<0, 4, 3, 0, 4, DSG_H16_NT4_OCC, 3, 64, PREC, 0, 0, 0, 1>(grid, lds, st, p);
           else rc = h2_launch<0, 2, 3, 0, 4, 1, 3, 64, PREC, 0, 0, 0, 1>(grid, lds, st, p);
         }
@@ -313,7 +315,7 @@ int conv_h2_launch_t(const dsg_conv_args* a, int hout, int wout, hipStream_t st)
     if constexpr (PREC != 0) DSG_H2_LAUNCH_BLK(0, 3, 2, 1);
   } else {
     if constexpr (PREC == 0) {
-      if (gnb) rc = conv_h2_gnb_f32_launch(nt4, grid, lds, st, p);  // the fp32 tape's data-gradient conv ([N,C,H,W] both sides)
+      if (gnb) { gnb_done = true; rc = conv_h2_gnb_f32_launch(nt4, grid, lds, st, p); }  // the fp32 tape's data-gradient conv ([N,C,H,W] both sides)
       else if (act == 0) DSG_H2_LAUNCH(0, 3, 0);
       else DSG_H2_LAUNCH(0, 3, 2);
     }
@@ -322,6 +324,8 @@ int conv_h2_launch_t(const dsg_conv_args* a, int hout, int wout, hipStream_t st)
 #undef DSG_H2_LAUNCH_BLK
 #undef DSG_H2_LAUNCH_PW
   if (rc != DSG_OK) return rc;
+  if (gnb && !gnb_done)   // (cannot happen while conv_h2_gnb_ok mirrors the dispatch above: the statistics table would hold the forward's sums)
+    return fail(DSG_ERR_UNSUPPORTED_SHAPE, "dsg_conv2d_fwd: internal: a gnb_* call was dispatched to a kernel without the GroupNorm-backward epilogue");
   if (slices > 1) {
     DSG_LAUNCH_CHECK();
     rc = splitk_reduce_launch(static_cast<const float*>(a->splitk_ws), slices, a, hout0, wout0, stat_splits, st);

@@ -201,3 +201,50 @@ def test_training_step_gradients_with_and_without_the_epilogue_statistics(dtn):
     assert differ > 0, "key 37 changed nothing: no layer of this net took the GNB kernel at this batch"
     assert whole <= (1e-4 if dtn == "fp32" else 5e-3), whole
     assert worst <= (2e-4 if dtn == "fp32" else 2e-2), (worst, worst_key)
+
+
+def test_query_and_dispatch_agree_over_a_shape_sweep():
+    """`dsg_conv2d_gnb_supported` mirrors the launcher's kernel selection (workgroup shape by grid size, 32-cout workgroups for
+    small grids, the 128-cout tiles' straddle rule): over a sweep of batch / channel / map sizes every call the query accepts must
+    run (the launcher refuses a gnb call that did not end in a GNB kernel) and return the sums of what it wrote -- checked through
+    sum du per (n, c) against torch on the stored dA -- and every call it rejects must raise."""
+    g = lambda t: t.to(DEV)
+    taken = refused = 0
+    for dtn in ("bf16", "fp32"):
+        dt = ops.dtype_code(dtn)
+        blocked = dtn != "fp32"
+        for (n, cdy, c0, c1, h, w) in [(1, 64, 64, 0, 32, 32), (2, 64, 64, 0, 64, 64), (4, 64, 64, 0, 64, 64), (16, 64, 64, 0, 64, 64),
+                                       (2, 128, 128, 0, 32, 64), (8, 128, 128, 0, 32, 32), (32, 128, 128, 0, 32, 32), (3, 64, 192, 0, 64, 32),
+                                       (8, 64, 64, 64, 64, 64), (8, 64, 128, 128, 32, 32), (2, 64, 256, 128, 32, 32), (8, 64, 320, 0, 32, 32),
+                                       (5, 32, 96, 0, 64, 64), (1, 256, 512, 0, 32, 32), (9, 64, 64, 0, 8, 32)]:
+            x, dy, wt, gamma, beta = _case(n, cdy, c0, c1, h, w, True, 11 * n + c0 + h)
+            c = c0 + c1
+            if blocked:
+                xb = ops.to_blocked(g(x), dt)
+                x0b, x1b = xb[:, :c0 // 8].contiguous(), (xb[:, c0 // 8:].contiguous() if c1 else None)
+                dyb, xr = ops.to_blocked(g(dy), dt), ops.from_blocked(xb).cpu()
+                whd = ops.pack_conv_weight(g(wt), ops.PACK_DGRAD, dt)
+            else:
+                x0b, x1b, dyb, xr = g(x[:, :c0]).contiguous(), (g(x[:, c0:]).contiguous() if c1 else None), g(dy), x
+                whd = ops.relayout_conv_weight_h2_dgrad(g(wt))
+            ss, _ = ops.gn_scale_shift_train(g(xr[:, :c0]).contiguous(), g(gamma), g(beta), GROUPS, 1e-5,
+                                             src1=g(xr[:, c0:]).contiguous() if c1 else None)
+            kw = dict(ksize=3, cout=c, src_blocked=blocked, dst_blocked=blocked, compute_dtype=dt, weight_h2=whd)
+            if blocked:
+                kw["weight_h2_stride"] = (c + 63) // 64 * 64
+            wd = ops.relayout_conv_weight_dgrad(g(wt))
+            gnb = dict(x0=x0b, x1=x1b, ss=ss, silu=True)
+            if ops.conv2d_fused(dyb, wd, gnb=dict(gnb, query_only=True), **kw):
+                da, parts = ops.conv2d_fused(dyb, wd, gnb=gnb, want_stats=True, **kw)
+                daf = (ops.from_blocked(da) if blocked else da).cpu().double()
+                u = xr.double() * ss[:, :, 0].cpu().double()[:, :, None, None] + ss[:, :, 1].cpu().double()[:, :, None, None]
+                s = torch.sigmoid(u)
+                want = (daf * (s * (1 + u * (1 - s)))).sum((2, 3))
+                got = parts.sum(2)[..., 0].cpu()
+                assert _rel(got, want) <= 2e-5, (dtn, n, c0, c1, h, w, _rel(got, want))
+                taken += 1
+            else:
+                with pytest.raises(RuntimeError):
+                    ops.conv2d_fused(dyb, wd, gnb=gnb, want_stats=True, **kw)
+                refused += 1
+    assert taken >= 10 and refused >= 6, (taken, refused)
