@@ -395,6 +395,8 @@ __global__ __launch_bounds__(64 * ATM_NW, DSG_ATM_MINW) void attention_mfma8_ker
 
 static int g_att_mfma = 1;  // head_dim 8 on the matrix cores (tuning key 14: A/B against the VALU kernel)
 void attention_set_mfma(int v) { g_att_mfma = v; }
+static int g_att_bwd_split = 1;  // the fp32 tape's attention backward on the matrix cores, fp16x2 split (tuning key 38: A/B against the VALU kernels)
+void attention_set_bwd_split(int v) { g_att_bwd_split = v; }
 static int g_att_blocked = 1;  // the plan keeps q, k, v and the attention output channel-blocked (tuning key 25)
 void attention_set_blocked(int v) { g_att_blocked = v; }
 bool attention_blocked_ok(int c, int heads, int l) {
@@ -741,14 +743,31 @@ __global__ __launch_bounds__(256) void attention_bwd_dkv_kernel(const float* __r
 //   kernel B (dK, dV): columns = this wave's 32 keys, rows = queries from LDS (with their lse and D):
 //                  S = Q^T K, dP = dO^T V, dV^T += dO(as [d][query]) P, dK^T += Q(as [d][query]) dS
 // ---------------------------------------------------------------------------------------------------
+// (value, (value - hi) * 2^11) as an fp16 pair: the fp16x2 split of the PREC 0 kernels (x == hi + lo * 2^-11 to 2^-22 relative)
+// (a macro: the targets are vector ELEMENTS, which a reference parameter cannot bind to)
+#define ATT_SPLIT(v, hi, lo)                               \
+  do {                                                     \
+    const float sv_ = (v);                                 \
+    const _Float16 sh_ = (_Float16)sv_;                    \
+    (hi) = sh_;                                            \
+    (lo) = (_Float16)((sv_ - (float)sh_) * 2048.0f);       \
+  } while (0)
+
+// PREC 0 (round 6; the fp32 tape's attention backward, training_pipeline.py:86 through the mid block's Attention): every product
+// as the fp16x2 split -- a.b ~ a1.b1 + 2^-11 (a1.b2 + a2.b1), three MFMAs, the cross terms on accumulators of their own -- with
+// dO brought to [1, 2) by a power of two first (the pieces are fp16: unscaled gradients of 1e-6 would land in its subnormals).
+// fp32-class accuracy (tests/test_gpu_train_ops.py: 2e-5 against torch autograd, the VALU kernels' own tolerance) on the
+// matrix cores: the fp32 tape's two VALU kernels were 6.5 ms of the configs[2] step.
 template <int PREC>
-__global__ __launch_bounds__(64 * ATM_NW, 2) void attention_bwd_dq_mfma8_kernel(const float* __restrict__ qkv, const float* __restrict__ o,
+__global__ __launch_bounds__(64 * ATM_NW, PREC == 0 ? 1 : 2) void attention_bwd_dq_mfma8_kernel(const float* __restrict__ qkv, const float* __restrict__ o,
                                                                                const float* __restrict__ dout, const float* __restrict__ lse,
                                                                                float* __restrict__ dqkv, float* __restrict__ dsum, int c,
                                                                                int heads, int l, float qscale) {
-  constexpr bool SCALE = PREC == 2;  // fp16: dO is brought to [1, 2) by a power of two before it is rounded (see above)
+  constexpr bool SPLIT = PREC == 0;
+  constexpr bool SCALE = PREC != 1;  // fp16 pieces: dO is brought to [1, 2) by a power of two before it is rounded (see above)
   __shared__ __attribute__((aligned(16))) _Float16 Kh[ATM_KT * 8], Vk[ATM_KT * 8];   // [key][d]: A operands of S^T and dP^T
   __shared__ __attribute__((aligned(16))) _Float16 Kd[8 * ATM_VSTR];                  // [d][key]: A operand of dQ^T += K dS
+  __shared__ __attribute__((aligned(16))) _Float16 Kl[SPLIT ? ATM_KT * 8 : 8], Vkl[SPLIT ? ATM_KT * 8 : 8], Kdl[SPLIT ? 8 * ATM_VSTR : 8];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, l31 = lane & 31;
   const int qtiles = (l + 32 * ATM_NW - 1) / (32 * ATM_NW);
   int bid = blockIdx.x;
@@ -762,14 +781,15 @@ __global__ __launch_bounds__(64 * ATM_NW, 2) void attention_bwd_dq_mfma8_kernel(
   const int q0 = (qt * ATM_NW + wave) * 32;
   const bool active = q0 < l;
   const int qi = min(q0 + l31, l - 1);
-  att_half4 qh, dh;
+  att_half4 qh, dh, ql, dl;
   float dpart = 0.f;
   float dov4[4], amax = 0.f;
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     const size_t at = (size_t)(4 * half + i) * l + qi;
     dov4[i] = dout[obase + at];
-    qh[i] = att_cvt<PREC>(qp[at] * qscale);
+    if constexpr (SPLIT) ATT_SPLIT(qp[at] * qscale, qh[i], ql[i]);
+    else qh[i] = att_cvt<PREC>(qp[at] * qscale);
     dpart = fmaf(dov4[i], o[obase + at], dpart);
     amax = fmaxf(amax, fabsf(dov4[i]));
   }
@@ -785,13 +805,16 @@ __global__ __launch_bounds__(64 * ATM_NW, 2) void attention_bwd_dq_mfma8_kernel(
     }
   }
 #pragma unroll
-  for (int i = 0; i < 4; ++i) dh[i] = att_cvt<PREC>(dov4[i] * qs);
+  for (int i = 0; i < 4; ++i) {
+    if constexpr (SPLIT) ATT_SPLIT(dov4[i] * qs, dh[i], dl[i]);
+    else dh[i] = att_cvt<PREC>(dov4[i] * qs);
+  }
   const float dd_true = dpart + __shfl_xor(dpart, 32, 64);   // D = rowsum(dO * O) of this lane's query
   const float dd = dd_true * qs;
   const float ls = lse[((size_t)n * heads + h) * l + qi];
-  f32x16 dq;
+  f32x16 dq, dq_lo;
 #pragma unroll
-  for (int r = 0; r < 16; ++r) dq[r] = 0.f;
+  for (int r = 0; r < 16; ++r) dq[r] = dq_lo[r] = 0.f;
   const int vrow = min(l31, 7);
   const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
   for (int j0 = 0; j0 < l; j0 += ATM_KT) {
@@ -804,29 +827,58 @@ __global__ __launch_bounds__(64 * ATM_NW, 2) void attention_bwd_dq_mfma8_kernel(
         kv = kp[(size_t)i * l + j0 + j];
         vv = vp[(size_t)i * l + j0 + j];
       }
-      Kh[j * 8 + i] = att_cvt<PREC>(kv);
-      Kd[i * ATM_VSTR + j] = att_cvt<PREC>(kv);
-      Vk[j * 8 + i] = att_cvt<PREC>(vv);
+      if constexpr (SPLIT) {
+        _Float16 kh16, kl16, vh16, vl16;
+        ATT_SPLIT(kv, kh16, kl16);
+        ATT_SPLIT(vv, vh16, vl16);
+        Kh[j * 8 + i] = kh16; Kl[j * 8 + i] = kl16;
+        Kd[i * ATM_VSTR + j] = kh16; Kdl[i * ATM_VSTR + j] = kl16;
+        Vk[j * 8 + i] = vh16; Vkl[j * 8 + i] = vl16;
+      } else {
+        Kh[j * 8 + i] = att_cvt<PREC>(kv);
+        Kd[i * ATM_VSTR + j] = att_cvt<PREC>(kv);
+        Vk[j * 8 + i] = att_cvt<PREC>(vv);
+      }
     }
     __syncthreads();
     if (!active) continue;
     for (int t = 0; t < kt; t += 32) {
       const att_half4 ka = *reinterpret_cast<const att_half4*>(&Kh[(t + l31) * 8 + 4 * half]);
       const att_half4 va = *reinterpret_cast<const att_half4*>(&Vk[(t + l31) * 8 + 4 * half]);
-      const f32x16 sc = att_mma8<PREC>(ka, qh, zero);   // S^T: rows = keys, this lane's column = its query
-      const f32x16 dp = att_mma8<PREC>(va, dh, zero);   // dP^T
+      f32x16 sc = att_mma8<PREC>(ka, qh, zero);   // S^T: rows = keys, this lane's column = its query
+      f32x16 dp = att_mma8<PREC>(va, dh, zero);   // dP^T
+      if constexpr (SPLIT) {
+        const att_half4 kal = *reinterpret_cast<const att_half4*>(&Kl[(t + l31) * 8 + 4 * half]);
+        const att_half4 val = *reinterpret_cast<const att_half4*>(&Vkl[(t + l31) * 8 + 4 * half]);
+        f32x16 s2 = att_mma8<PREC>(ka, ql, zero), p2 = att_mma8<PREC>(va, dl, zero);
+        s2 = att_mma8<PREC>(kal, qh, s2);
+        p2 = att_mma8<PREC>(val, dh, p2);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          sc[r] += s2[r] * (1.0f / 2048.0f);
+          dp[r] += p2[r] * (1.0f / 2048.0f);
+        }
+      }
 #pragma unroll
       for (int b = 0; b < 2; ++b) {
-        att_half8 dsh;
+        att_half8 dsh, dsl;
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
           const float pv = __builtin_amdgcn_exp2f(sc[8 * b + i] - ls);
-          dsh[i] = att_cvt<PREC>(pv * (dp[8 * b + i] - dd));
+          if constexpr (SPLIT) ATT_SPLIT(pv * (dp[8 * b + i] - dd), dsh[i], dsl[i]);
+          else dsh[i] = att_cvt<PREC>(pv * (dp[8 * b + i] - dd));
         }
         const _Float16* kdp = &Kd[vrow * ATM_VSTR + t + 16 * b + 4 * half];
         const att_half4 k0 = *reinterpret_cast<const att_half4*>(kdp), k1 = *reinterpret_cast<const att_half4*>(kdp + 8);
         const att_half8 kd = {k0[0], k0[1], k0[2], k0[3], k1[0], k1[1], k1[2], k1[3]};
         dq = mma16<PREC>(kd, dsh, dq);
+        if constexpr (SPLIT) {
+          const _Float16* klp = &Kdl[vrow * ATM_VSTR + t + 16 * b + 4 * half];
+          const att_half4 m0 = *reinterpret_cast<const att_half4*>(klp), m1 = *reinterpret_cast<const att_half4*>(klp + 8);
+          const att_half8 kdl = {m0[0], m0[1], m0[2], m0[3], m1[0], m1[1], m1[2], m1[3]};
+          dq_lo = mma16<PREC>(kd, dsl, dq_lo);
+          dq_lo = mma16<PREC>(kdl, dsh, dq_lo);
+        }
       }
     }
   }
@@ -834,18 +886,22 @@ __global__ __launch_bounds__(64 * ATM_NW, 2) void attention_bwd_dq_mfma8_kernel(
   const float sm = qscale * 0.6931471805599453f * qs_inv;  // qscale = log2(e)/sqrt(D); the softmax scale alone is 1/sqrt(D)
   float* dqp = dqkv + ((size_t)n * 3 * c + h * 8) * l;
 #pragma unroll
-  for (int r = 0; r < 4; ++r) dqp[(size_t)(r + 4 * half) * l + q0 + l31] = dq[r] * sm;
+  for (int r = 0; r < 4; ++r)
+    dqp[(size_t)(r + 4 * half) * l + q0 + l31] = (SPLIT ? dq[r] + dq_lo[r] * (1.0f / 2048.0f) : dq[r]) * sm;
   if (half == 0) dsum[((size_t)n * heads + h) * l + q0 + l31] = dd_true;
 }
 
 template <int PREC>
-__global__ __launch_bounds__(64 * ATM_NW, 2) void attention_bwd_dkv_mfma8_kernel(const float* __restrict__ qkv, const float* __restrict__ dout,
+__global__ __launch_bounds__(64 * ATM_NW, PREC == 0 ? 1 : 2) void attention_bwd_dkv_mfma8_kernel(const float* __restrict__ qkv, const float* __restrict__ dout,
                                                                                 const float* __restrict__ lse, const float* __restrict__ dsum,
                                                                                 float* __restrict__ dqkv, int c, int heads, int l,
                                                                                 float qscale) {
-  constexpr bool SCALE = PREC == 2;  // fp16: dO is brought to [1, 2) by a power of two before it is rounded (see above)
+  constexpr bool SPLIT = PREC == 0;  // fp32-class: every product as the fp16x2 split (see the dq kernel)
+  constexpr bool SCALE = PREC != 1;  // fp16 pieces: dO is brought to [1, 2) by a power of two before it is rounded (see above)
   __shared__ __attribute__((aligned(16))) _Float16 Qh[ATM_KT * 8], Gh[ATM_KT * 8];            // [query][d]: A operands of S and dP
   __shared__ __attribute__((aligned(16))) _Float16 Qd[8 * ATM_VSTR], Gd[8 * ATM_VSTR];        // [d][query]: A operands of dK^T, dV^T
+  __shared__ __attribute__((aligned(16))) _Float16 Ql[SPLIT ? ATM_KT * 8 : 8], Gl[SPLIT ? ATM_KT * 8 : 8];
+  __shared__ __attribute__((aligned(16))) _Float16 Qdl[SPLIT ? 8 * ATM_VSTR : 8], Gdl[SPLIT ? 8 * ATM_VSTR : 8];
   __shared__ __attribute__((aligned(16))) float Ls[ATM_KT], Ds[ATM_KT];                        // lse and D of the tile's queries
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, l31 = lane & 31;
   const int ktiles = (l + 32 * ATM_NW - 1) / (32 * ATM_NW);
@@ -861,11 +917,16 @@ __global__ __launch_bounds__(64 * ATM_NW, 2) void attention_bwd_dkv_mfma8_kernel
   const int k0 = (kt_i * ATM_NW + wave) * 32;
   const bool active = k0 < l;
   const int ki = min(k0 + l31, l - 1);
-  att_half4 kh, vh;
+  att_half4 kh, vh, kl, vl;
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
-    kh[i] = att_cvt<PREC>(kp[(size_t)(4 * half + i) * l + ki]);
-    vh[i] = att_cvt<PREC>(vp[(size_t)(4 * half + i) * l + ki]);
+    if constexpr (SPLIT) {
+      ATT_SPLIT(kp[(size_t)(4 * half + i) * l + ki], kh[i], kl[i]);
+      ATT_SPLIT(vp[(size_t)(4 * half + i) * l + ki], vh[i], vl[i]);
+    } else {
+      kh[i] = att_cvt<PREC>(kp[(size_t)(4 * half + i) * l + ki]);
+      vh[i] = att_cvt<PREC>(vp[(size_t)(4 * half + i) * l + ki]);
+    }
   }
   // dK_j and dV_j sum over the queries: ONE scale for the head's whole dO (its 8 l values are contiguous; every workgroup of
   // the head finds the same maximum -- no atomics, no extra buffer); rows far below the maximum lose bits that do not show in the sum
@@ -888,9 +949,9 @@ __global__ __launch_bounds__(64 * ATM_NW, 2) void attention_bwd_dkv_mfma8_kernel
       gs_inv = ldexpf(1.0f, ex - 1);
     }
   }
-  f32x16 dk, dv;
+  f32x16 dk, dv, dk_lo, dv_lo;
 #pragma unroll
-  for (int r = 0; r < 16; ++r) dk[r] = dv[r] = 0.f;
+  for (int r = 0; r < 16; ++r) dk[r] = dv[r] = dk_lo[r] = dv_lo[r] = 0.f;
   const int vrow = min(l31, 7);
   const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
   for (int j0 = 0; j0 < l; j0 += ATM_KT) {
@@ -903,11 +964,21 @@ __global__ __launch_bounds__(64 * ATM_NW, 2) void attention_bwd_dkv_mfma8_kernel
         qv = qp[(size_t)i * l + j0 + j] * qscale;
         gv = dout[obase + (size_t)i * l + j0 + j] * gs;
       }
-      const _Float16 gb = att_cvt<PREC>(gv);
-      Qh[j * 8 + i] = att_cvt<PREC>(qv);
-      Qd[i * ATM_VSTR + j] = att_cvt<PREC>(qv);
-      Gh[j * 8 + i] = gb;
-      Gd[i * ATM_VSTR + j] = gb;
+      if constexpr (SPLIT) {
+        _Float16 q1, q2, g1, g2;
+        ATT_SPLIT(qv, q1, q2);
+        ATT_SPLIT(gv, g1, g2);
+        Qh[j * 8 + i] = q1; Ql[j * 8 + i] = q2;
+        Qd[i * ATM_VSTR + j] = q1; Qdl[i * ATM_VSTR + j] = q2;
+        Gh[j * 8 + i] = g1; Gl[j * 8 + i] = g2;
+        Gd[i * ATM_VSTR + j] = g1; Gdl[i * ATM_VSTR + j] = g2;
+      } else {
+        const _Float16 gb = att_cvt<PREC>(gv);
+        Qh[j * 8 + i] = att_cvt<PREC>(qv);
+        Qd[i * ATM_VSTR + j] = att_cvt<PREC>(qv);
+        Gh[j * 8 + i] = gb;
+        Gd[i * ATM_VSTR + j] = gb;
+      }
     }
     for (int j = tid; j < ATM_KT; j += 64 * ATM_NW) {
       Ls[j] = j < qt ? lse[lbase + j0 + j] : 0.f;
@@ -918,8 +989,20 @@ __global__ __launch_bounds__(64 * ATM_NW, 2) void attention_bwd_dkv_mfma8_kernel
     for (int t = 0; t < qt; t += 32) {
       const att_half4 qa = *reinterpret_cast<const att_half4*>(&Qh[(t + l31) * 8 + 4 * half]);
       const att_half4 ga = *reinterpret_cast<const att_half4*>(&Gh[(t + l31) * 8 + 4 * half]);
-      const f32x16 sc = att_mma8<PREC>(qa, kh, zero);   // S: rows = queries, this lane's column = its key
-      const f32x16 dp = att_mma8<PREC>(ga, vh, zero);   // dP
+      f32x16 sc = att_mma8<PREC>(qa, kh, zero);   // S: rows = queries, this lane's column = its key
+      f32x16 dp = att_mma8<PREC>(ga, vh, zero);   // dP
+      if constexpr (SPLIT) {
+        const att_half4 qal = *reinterpret_cast<const att_half4*>(&Ql[(t + l31) * 8 + 4 * half]);
+        const att_half4 gal = *reinterpret_cast<const att_half4*>(&Gl[(t + l31) * 8 + 4 * half]);
+        f32x16 s2 = att_mma8<PREC>(qa, kl, zero), p2 = att_mma8<PREC>(ga, vl, zero);
+        s2 = att_mma8<PREC>(qal, kh, s2);
+        p2 = att_mma8<PREC>(gal, vh, p2);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          sc[r] += s2[r] * (1.0f / 2048.0f);
+          dp[r] += p2[r] * (1.0f / 2048.0f);
+        }
+      }
 #pragma unroll
       for (int b = 0; b < 2; ++b) {
         // registers 8b .. 8b + 7 = queries t + 16 b + 4 half + {0..3, 8..11}
@@ -929,12 +1012,17 @@ __global__ __launch_bounds__(64 * ATM_NW, 2) void attention_bwd_dkv_mfma8_kernel
         const float4 d1 = *reinterpret_cast<const float4*>(&Ds[t + 16 * b + 4 * half + 8]);
         const float lsr[8] = {l0.x, l0.y, l0.z, l0.w, l1.x, l1.y, l1.z, l1.w};
         const float ddr[8] = {d0.x, d0.y, d0.z, d0.w, d1.x, d1.y, d1.z, d1.w};
-        att_half8 ph, dsh;
+        att_half8 ph, dsh, pl, dsl;
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
           const float pv = __builtin_amdgcn_exp2f(sc[8 * b + i] - lsr[i]);
-          ph[i] = att_cvt<PREC>(pv);
-          dsh[i] = att_cvt<PREC>(pv * (dp[8 * b + i] - ddr[i]));
+          if constexpr (SPLIT) {
+            ATT_SPLIT(pv, ph[i], pl[i]);
+            ATT_SPLIT(pv * (dp[8 * b + i] - ddr[i]), dsh[i], dsl[i]);
+          } else {
+            ph[i] = att_cvt<PREC>(pv);
+            dsh[i] = att_cvt<PREC>(pv * (dp[8 * b + i] - ddr[i]));
+          }
         }
         const _Float16* gdp = &Gd[vrow * ATM_VSTR + t + 16 * b + 4 * half];
         const _Float16* qdp = &Qd[vrow * ATM_VSTR + t + 16 * b + 4 * half];
@@ -944,6 +1032,18 @@ __global__ __launch_bounds__(64 * ATM_NW, 2) void attention_bwd_dkv_mfma8_kernel
         const att_half8 qd = {x0[0], x0[1], x0[2], x0[3], x1[0], x1[1], x1[2], x1[3]};
         dv = mma16<PREC>(gd, ph, dv);
         dk = mma16<PREC>(qd, dsh, dk);
+        if constexpr (SPLIT) {
+          const _Float16* glp = &Gdl[vrow * ATM_VSTR + t + 16 * b + 4 * half];
+          const _Float16* qlp = &Qdl[vrow * ATM_VSTR + t + 16 * b + 4 * half];
+          const att_half4 h0 = *reinterpret_cast<const att_half4*>(glp), h1 = *reinterpret_cast<const att_half4*>(glp + 8);
+          const att_half4 y0 = *reinterpret_cast<const att_half4*>(qlp), y1 = *reinterpret_cast<const att_half4*>(qlp + 8);
+          const att_half8 gdl = {h0[0], h0[1], h0[2], h0[3], h1[0], h1[1], h1[2], h1[3]};
+          const att_half8 qdl = {y0[0], y0[1], y0[2], y0[3], y1[0], y1[1], y1[2], y1[3]};
+          dv_lo = mma16<PREC>(gd, pl, dv_lo);
+          dv_lo = mma16<PREC>(gdl, ph, dv_lo);
+          dk_lo = mma16<PREC>(qd, dsl, dk_lo);
+          dk_lo = mma16<PREC>(qdl, dsh, dk_lo);
+        }
       }
     }
   }
@@ -952,8 +1052,9 @@ __global__ __launch_bounds__(64 * ATM_NW, 2) void attention_bwd_dkv_mfma8_kernel
   float* dvp = dkp + (size_t)c * l;
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
-    dkp[(size_t)(r + 4 * half) * l + k0 + l31] = dk[r] * (0.6931471805599453f * gs_inv);  // (q came pre-scaled by log2(e)/sqrt(D))
-    dvp[(size_t)(r + 4 * half) * l + k0 + l31] = dv[r] * gs_inv;
+    const float dkr = SPLIT ? dk[r] + dk_lo[r] * (1.0f / 2048.0f) : dk[r], dvr = SPLIT ? dv[r] + dv_lo[r] * (1.0f / 2048.0f) : dv[r];
+    dkp[(size_t)(r + 4 * half) * l + k0 + l31] = dkr * (0.6931471805599453f * gs_inv);  // (q came pre-scaled by log2(e)/sqrt(D))
+    dvp[(size_t)(r + 4 * half) * l + k0 + l31] = dvr * gs_inv;
   }
 }
 
@@ -1005,6 +1106,10 @@ DSG_API int dsg_attention_bwd(const float* qkv, const float* out, const float* d
   DSG_CHECK_ARG(n > 0 && c > 0 && heads > 0 && l > 0 && c % heads == 0, "dsg_attention_bwd: bad dims");
   DSG_CHECK_ARG(heads <= 65535 && n <= 65535, "dsg_attention_bwd: grid too large");
   hipStream_t st = static_cast<hipStream_t>(stream);
+  // head_dim 8 (every attention block of the reference's networks): the matrix-core kernels in their fp32-class form (PREC 0);
+  // tuning key 14 = 0 keeps the VALU kernels for A/B
+  if (c / heads == 8 && l % 32 == 0 && dsg::g_att_mfma && dsg::g_att_bwd_split)
+    return dsg::launch_attention_bwd_mfma8<0>(qkv, out, dout, lse, dqkv, dsum_ws, n, c, heads, l, st);
   switch (c / heads) {
     case 8: return dsg::launch_attention_bwd<8>(qkv, out, dout, lse, dqkv, dsum_ws, n, c, heads, l, st);
     case 16: return dsg::launch_attention_bwd<16>(qkv, out, dout, lse, dqkv, dsum_ws, n, c, heads, l, st);

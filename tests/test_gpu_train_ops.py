@@ -143,6 +143,39 @@ def test_attention_backward_bf16_matrix_cores(n, c, heads, l, mode):
     assert float((exact - ref).norm() / ref.norm()) <= 1e-5
 
 
+@pytest.mark.parametrize("n,c,heads,l,mag", [(2, 64, 8, 1024, 1.0), (3, 512, 64, 1024, 1.0), (1, 32, 4, 256, 1e-6), (2, 64, 8, 96, 30.0)])
+def test_attention_backward_fp32_on_the_matrix_cores_is_in_the_valu_kernels_class(n, c, heads, l, mag):
+    """Round 6: `dsg_attention_bwd` (the fp32 tape; training_pipeline.py:86 through the mid block's Attention) runs head_dim 8 on the
+    matrix cores with every product as an fp16x2 split (three MFMAs, dO scaled to [1, 2) by a power of two first) instead of the
+    two VALU kernels.  Against torch autograd in fp64, next to the VALU kernels (tuning key 38 = 0) on the same inputs: the same
+    error class -- also for gradients of 1e-6 (no loss scale) and of 30 (a large one)."""
+    from drivescenegen_amd import _lib
+    qkv = _t(31, (n, 3 * c, l), 1.2).double().requires_grad_(True)
+    dd = c // heads
+    q, k, v = [qkv[:, i * c:(i + 1) * c].view(n, heads, dd, l).transpose(2, 3) for i in range(3)]
+    o = F.scaled_dot_product_attention(q, k, v).transpose(2, 3).reshape(n, c, l)
+    do = _t(32, (n, c, l)) * mag
+    o.backward(do.double())
+    ref = qkv.grad
+    out, lse = ops.attention_train(qkv.detach().float().to(DEV), heads)
+    lib = _lib.load()
+    got = {}
+    try:
+        for on in (1, 0):
+            _lib.check(lib.dsg_set_tuning(38, on))
+            got[on] = ops.attention_bwd(qkv.detach().float().to(DEV), out, do.to(DEV), lse, heads).cpu().double()
+    finally:
+        lib.dsg_set_tuning(38, 1)
+    assert not torch.equal(got[0], got[1])            # (another kernel really ran)
+    for i, name in enumerate(("dq", "dk", "dv")):
+        b = ref[:, i * c:(i + 1) * c]
+        e1 = float((got[1][:, i * c:(i + 1) * c] - b).norm() / b.norm())
+        e0 = float((got[0][:, i * c:(i + 1) * c] - b).norm() / b.norm())
+        assert e1 <= max(2 * e0, 3e-6), (name, e1, e0)
+        assert e1 <= 1e-5, (name, e1)
+    assert torch.isfinite(got[1]).all()
+
+
 def test_linear_silu_backward_and_sums():
     n, kf, mf = 5, 64, 96
     x = _t(41, (n, kf)).requires_grad_(True)
