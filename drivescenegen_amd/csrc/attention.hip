@@ -759,7 +759,7 @@ __global__ __launch_bounds__(256) void attention_bwd_dkv_kernel(const float* __r
 // fp32-class accuracy (tests/test_gpu_train_ops.py: 2e-5 against torch autograd, the VALU kernels' own tolerance) on the
 // matrix cores: the fp32 tape's two VALU kernels were 6.5 ms of the configs[2] step.
 template <int PREC>
-__global__ __launch_bounds__(64 * ATM_NW, PREC == 0 ? 1 : 2) void attention_bwd_dq_mfma8_kernel(const float* __restrict__ qkv, const float* __restrict__ o,
+__global__ __launch_bounds__(64 * ATM_NW, 2) void attention_bwd_dq_mfma8_kernel(const float* __restrict__ qkv, const float* __restrict__ o,
                                                                                const float* __restrict__ dout, const float* __restrict__ lse,
                                                                                float* __restrict__ dqkv, float* __restrict__ dsum, int c,
                                                                                int heads, int l, float qscale) {
