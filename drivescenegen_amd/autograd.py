@@ -171,9 +171,17 @@ class TrainState:
                 self.wf[key] = torch.zeros((c, 1, 3 * c), dtype=torch.float32, device=dev)
                 self.wd[key] = torch.zeros((3 * c, 1, ops._pad32(c) + 64), dtype=torch.float32, device=dev)
                 self.wf[key + ".bias"] = torch.zeros(3 * c, dtype=torch.float32, device=dev)
+            h2 = c % 64 == 0   # the fp16x2-split operand images of the fused projection and of its data gradient (the fp32 tape:
+            if h2 and key not in self.wh:   # round 6 -- the two calls ran on the exact f32 kernel at 77 TF/s, 1.34 ms each at B=64)
+                self.wh[key] = torch.zeros((c // 16, 2, 1, 2, 3 * c, 8), dtype=torch.float16, device=ws[0].device)
+                self.whd[key] = torch.zeros((3 * c // 16, 2, 1, 2, c, 8), dtype=torch.float16, device=ws[0].device)
             for i, w in enumerate(ws):
                 ops.relayout_conv_weight(w, out=self.wf[key], cout_total=3 * c, cout_off=i * c)
                 ops.relayout_conv_weight_dgrad(w, out=self.wd[key][i * c:(i + 1) * c])
+                if h2:
+                    ops.relayout_conv_weight_h2(w, out=self.wh[key], cout_total=3 * c, cout_off=i * c)
+                    # (the data gradient's K is the 3C channels of dqkv: the three projections' images, stacked along K)
+                    ops.relayout_conv_weight_h2_dgrad(w, out=self.whd[key][i * c // 16:(i + 1) * c // 16])
         # biases are tiny: refresh unconditionally through our own copy kernel-free path (slice assignment is a
         # device memcpy, not arithmetic)
         c = self.params[names[0]].shape[0]
@@ -337,11 +345,11 @@ def _forward(model, st: TrainState, tape: _Tape, sample, timesteps):
         heads = c // cfg.attention_head_dim
         gnn = pre + ".group_norm"
         ss, mr = norm_ss(x, None, gnn)
-        qkv = ops.conv2d_fused(x, wf, bias, ksize=1, gn_scale_shift=ss, silu=False)
+        qkv = ops.conv2d_fused(x, wf, bias, ksize=1, gn_scale_shift=ss, silu=False, weight_h2=st.wh.get(pre + ".qkv"))
         n, _, hh, ww = x.shape
         o, lse = ops.attention_train(qkv.view(n, 3 * c, hh * ww), heads)
         o = o.view(n, c, hh, ww)
-        tape.recs.append(dict(kind="qkv", x=x, ss=ss, mr=mr, gn=gnn, pre=pre, qkv=qkv, wd=wd))
+        tape.recs.append(dict(kind="qkv", x=x, ss=ss, mr=mr, gn=gnn, pre=pre, qkv=qkv, wd=wd, whd=st.whd.get(pre + ".qkv")))
         tape.recs.append(dict(kind="attn", qkv=qkv, o=o, lse=lse, heads=heads))
         return conv(o, pre + ".to_out.0", k=1, res=x, feeds_norm=True)
 
@@ -485,7 +493,7 @@ def _backward(model, st: TrainState, tape: _Tape, dout):
                 ops.conv_wgrad(x, dqkv, st.grad(f"{pre}.{t}.weight"), ksize=1, gn_scale_shift=rec["ss"], silu=False,
                                cout=c, dy_coff=i * c)
                 done(f"{pre}.{t}.weight", f"{pre}.{t}.bias")
-            da = ops.conv2d_fused(dqkv, rec["wd"], ksize=1, cout=c)
+            da = ops.conv2d_fused(dqkv, rec["wd"], ksize=1, cout=c, weight_h2=rec.get("whd"))
             gnn = rec["gn"]
             dx, _ = ops.gn_bwd(x, da, rec["ss"], rec["mr"], P[gnn + ".weight"].detach(), groups, False,
                                st.grad(gnn + ".weight"), st.grad(gnn + ".bias"), add0=tape.g(x))
