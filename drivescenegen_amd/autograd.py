@@ -381,6 +381,46 @@ def _forward(model, st: TrainState, tape: _Tape, sample, timesteps):
     return conv(x, "conv_out", gn="conv_norm_out", silu=True)
 
 
+def _wgrad_padded_f32(st, x0, x1, dy, wname, k, rec):
+    """Weight gradient of a plain 3x3 conv with FEW channels on one side (conv_in: 3 / 4 / 8 inputs; conv_out: as many outputs) on
+    the fp32 tape: the narrow side is padded with zero channels to the split kernel's granule (32 inputs, 64 outputs) -- a
+    [64 x 32..64] weight gradient of which one corner is kept.  The exact f32 kernels took 2.9 ms (conv_out) + 1.4 ms (conv_in) of
+    the configs[2] step at 50-60 TF/s; the padded buffers keep their zero channels between steps (only the real channels are
+    copied in).  Returns False for shapes this does not serve (the caller then runs the plain call)."""
+    if k != 3 or rec["stride"] != 1 or rec["ups"] or x1 is not None:
+        return False
+    n, cin, h, w = x0.shape
+    cout = dy.shape[1]
+    cp, op = (cin + 31) // 32 * 32, (cout + 63) // 64 * 64
+    if (cp == cin and op == cout) or cp > 64 or op > 64 or not ops.wgrad_h2_supported(cp, 0, op, h, w, 3, 1, False):
+        return False
+
+    def padded(t, c, cpad, tag):
+        if c == cpad:
+            return t
+        key = ("pad32", wname, tag, n, cpad, h, w)
+        buf = st.scratch16.get(key)
+        if buf is None:
+            buf = st.scratch16[key] = torch.zeros((n, cpad, h, w), dtype=torch.float32, device=t.device)
+        buf[:, :c].copy_(t)     # (a device copy of the real channels; the zero channels were written once)
+        return buf
+    xb, dyb = padded(x0, cin, cp, "x"), padded(dy.contiguous(), cout, op, "dy")
+    ss = rec["ss"]
+    if ss is not None and cp != cin:
+        ssp = torch.zeros((n, cp, 2), dtype=ss.dtype, device=ss.device)   # (zero scale / shift: a zero channel stays zero)
+        ssp[:, :cin].copy_(ss)
+        ss = ssp
+    key = ("pad32", wname, "dw")
+    tmp = st.scratch16.get(key)
+    if tmp is None:
+        tmp = st.scratch16[key] = torch.empty((op, cp, 3, 3), dtype=torch.float32, device=dy.device)
+    tmp.zero_()
+    ops.conv_wgrad(xb, dyb, tmp, ksize=3, gn_scale_shift=ss, silu=rec["silu"], cout=op)
+    g = st.grad(wname + ".weight")
+    g.copy_(ops.add(g, tmp[:cout, :cin].contiguous()))
+    return True
+
+
 def _backward(model, st: TrainState, tape: _Tape, dout):
     P = st.params
     groups = model.config.norm_num_groups
@@ -419,6 +459,8 @@ def _backward(model, st: TrainState, tape: _Tape, dout):
             kw = dict(dy_sums=sums, dy_sums_stride=sstride, bias_grad=st.grad(wname + ".bias")) if byp else {}
             if ups_h2:
                 ops.conv_wgrad(ops.upsample_nearest2x(x0), dy, st.grad(wname + ".weight"), ksize=k, **kw)
+            elif not byp and _wgrad_padded_f32(st, x0, x1, dy, wname, k, rec):
+                pass   # conv_in / conv_out: few channels on one side, padded with zero channels onto the split kernel
             else:
                 ops.conv_wgrad(x0, dy, st.grad(wname + ".weight"), src1=x1, ksize=k, stride=rec["stride"],
                                upsample=rec["ups"], gn_scale_shift=rec["ss"], silu=rec["silu"], **kw)
