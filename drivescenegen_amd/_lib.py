@@ -120,6 +120,8 @@ SIGNATURES = {
     "dsg_gn_bwd_blocked_add2": [_vp, _i32, _vp, _i32, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp,
                                 _vp, _vp, _vp, _i32, _vp],
     "dsg_gn_bwd_blocked_splits": [_i32],
+    "dsg_gn_bwd_add2": [_vp, _i32, _vp, _i32, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
+                        _vp, _vp, _vp, _i32, _vp],
     "dsg_gn_bwd_parts": [_vp, _i32, _vp, _i32, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp,
                          _vp, _vp, _vp, _i32, _vp],
     "dsg_gn_bwd_blocked_parts": [_vp, _i32, _vp, _i32, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp,

@@ -441,7 +441,7 @@ def _backward(model, st: TrainState, tape: _Tape, dout):
             wname, cout, k = rec["wname"], rec["cout"], rec["k"]
             x0, x1 = rec["x0"], rec["x1"]
             if rec["res"] is not None:
-                tape.addg(rec["res"], dy)
+                tape.addg(rec["res"], dy, lazy=True)   # (a pending pair is summed inside the next GroupNorm backward on it: add0b)
             # up-sampler conv (no norm, one source): both gradients run at full resolution on the split matrix-core
             # kernels -- the weight gradient from the materialised nearest-x2 input, the data gradient as a plain
             # transposed conv followed by the upsample's adjoint (2x2 sum-pool)
@@ -492,8 +492,9 @@ def _backward(model, st: TrainState, tape: _Tape, dout):
                     return ops.conv2d_fused(dy, wd, **kw), None
                 da, parts = st.lazy_w(wdn, "wd", dgrad_gn)
                 gnn = rec["gn"]
+                a0, a0b = tape.g2(x0)
                 dx0, dx1 = ops.gn_bwd(x0, da, rec["ss"], rec["mr"], P[gnn + ".weight"].detach(), groups, rec["silu"],
-                                      st.grad(gnn + ".weight"), st.grad(gnn + ".bias"), src1=x1, add0=tape.g(x0),
+                                      st.grad(gnn + ".weight"), st.grad(gnn + ".bias"), src1=x1, add0=a0, add0b=a0b,
                                       add1=tape.g(x1) if x1 is not None else None, parts=parts)
                 done(gnn + ".weight", gnn + ".bias")
                 tape.setg(x0, dx0)

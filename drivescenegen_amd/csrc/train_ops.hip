@@ -182,7 +182,7 @@ __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(const float* __restri
                                                            const float* __restrict__ coef, int silu, int hw,
                                                            const float* __restrict__ add0,
                                                            const float* __restrict__ add1, float* __restrict__ dx0,
-                                                           float* __restrict__ dx1) {
+                                                           float* __restrict__ dx1, const float* __restrict__ add0b) {
   const int c = blockIdx.y, n = blockIdx.z, ct = c0 + c1;
   const int i = (blockIdx.x * 256 + threadIdx.x) * V;
   if (i >= hw) return;
@@ -190,6 +190,7 @@ __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(const float* __restri
   const size_t xo = first ? ((size_t)n * c0 + c) * hw + i : ((size_t)n * c1 + (c - c0)) * hw + i;
   const float* xs = first ? src0 : src1;
   const float* as = first ? add0 : add1;
+  const float* as2 = first ? add0b : nullptr;   // (a second fan-in term of source 0: skip-connection + residual gradients)
   float* ds = first ? dx0 : dx1;
   const size_t k = (size_t)n * ct + c;
   const float sc = ss[2 * k], sh = ss[2 * k + 1], mean = mr[2 * k], rstd = mr[2 * k + 1];
@@ -203,11 +204,15 @@ __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(const float* __restri
     if (as) {
       const float4 a4 = *reinterpret_cast<const float4*>(as + xo);
       ad[0] = a4.x; ad[1] = a4.y; ad[2] = a4.z; ad[3] = a4.w;
+      if (as2) {   // (summed first, as the separate add pass did: the same bits)
+        const float4 b4 = *reinterpret_cast<const float4*>(as2 + xo);
+        ad[0] += b4.x; ad[1] += b4.y; ad[2] += b4.z; ad[3] += b4.w;
+      }
     }
   } else {
     x[0] = xs[xo];
     du[0] = dy[k * hw + i];
-    if (as) ad[0] = as[xo];
+    if (as) ad[0] = as[xo] + (as2 ? as2[xo] : 0.f);
   }
   float v[V];
 #pragma unroll
@@ -413,7 +418,8 @@ static int gn_bwd_f32_impl(const float* src0, int32_t c0, const float* src1, int
                            const float* scale_shift, const float* mean_rstd, const float* gamma, int32_t silu, int32_t n,
                            int32_t hw, int32_t groups, const float* add0, const float* add1, float* dx0, float* dx1,
                            float* dgamma, float* dbeta, double* ws_s12, float* ws_coef, const double* parts, int32_t ntile,
-                           void* stream) {
+                           void* stream, const float* add0b = nullptr) {
+  DSG_CHECK_ARG(add0b == nullptr || add0 != nullptr, "dsg_gn_bwd: add0b without add0");
   DSG_CHECK_ARG(src0 && dy && scale_shift && mean_rstd && gamma && dx0 && dgamma && dbeta && ws_s12 && ws_coef,
                 "dsg_gn_bwd: NULL pointer");
   DSG_CHECK_ARG(c0 > 0 && c1 >= 0 && n > 0 && hw > 0 && groups > 0, "dsg_gn_bwd: bad dims");
@@ -437,10 +443,10 @@ static int gn_bwd_f32_impl(const float* src0, int32_t c0, const float* src1, int
   DSG_LAUNCH_CHECK();
   if ((hw & 3) == 0)
     hipLaunchKernelGGL(dsg::gn_bwd_apply_kernel<4>, dim3(cdiv(hw, 1024), c, n), dim3(256), 0, st, src0, c0, src1, c1, dy,
-                       scale_shift, mean_rstd, ws_coef, silu, hw, add0, add1, dx0, dx1);
+                       scale_shift, mean_rstd, ws_coef, silu, hw, add0, add1, dx0, dx1, add0b);
   else
     hipLaunchKernelGGL(dsg::gn_bwd_apply_kernel<1>, dim3(cdiv(hw, 256), c, n), dim3(256), 0, st, src0, c0, src1, c1, dy,
-                       scale_shift, mean_rstd, ws_coef, silu, hw, add0, add1, dx0, dx1);
+                       scale_shift, mean_rstd, ws_coef, silu, hw, add0, add1, dx0, dx1, add0b);
   DSG_LAUNCH_CHECK();
   return DSG_OK;
 }
@@ -451,6 +457,16 @@ DSG_API int dsg_gn_bwd(const float* src0, int32_t c0, const float* src1, int32_t
                        float* dgamma, float* dbeta, double* ws_s12, float* ws_coef, void* stream) {
   return gn_bwd_f32_impl(src0, c0, src1, c1, dy, scale_shift, mean_rstd, gamma, silu, n, hw, groups, add0, add1, dx0, dx1, dgamma,
                          dbeta, ws_s12, ws_coef, nullptr, 0, stream);
+}
+
+DSG_API int dsg_gn_bwd_add2(const float* src0, int32_t c0, const float* src1, int32_t c1, const float* dy,
+                            const float* scale_shift, const float* mean_rstd, const float* gamma, int32_t silu, int32_t n,
+                            int32_t hw, int32_t groups, const float* add0, const float* add0b, const float* add1, float* dx0,
+                            float* dx1, float* dgamma, float* dbeta, double* ws_s12, float* ws_coef, const double* parts,
+                            int32_t ntile, void* stream) {
+  DSG_CHECK_ARG((parts == nullptr) == (ntile == 0), "dsg_gn_bwd_add2: parts / ntile go together");
+  return gn_bwd_f32_impl(src0, c0, src1, c1, dy, scale_shift, mean_rstd, gamma, silu, n, hw, groups, add0, add1, dx0, dx1, dgamma,
+                         dbeta, ws_s12, ws_coef, parts, ntile, stream, add0b);
 }
 
 DSG_API int dsg_gn_bwd_parts(const float* src0, int32_t c0, const float* src1, int32_t c1, const float* dy,

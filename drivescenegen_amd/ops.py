@@ -593,7 +593,7 @@ def gn_scale_shift_train(src0, gamma, beta, groups, eps, src1=None):
     return ss, mr
 
 
-def gn_bwd(src0, dy, ss, mr, gamma, groups, silu, dgamma, dbeta, src1=None, add0=None, add1=None, parts=None):
+def gn_bwd(src0, dy, ss, mr, gamma, groups, silu, dgamma, dbeta, src1=None, add0=None, add1=None, parts=None, add0b=None):
     """Backward of silu?(GroupNorm(cat(src0, src1))); returns (dx0, dx1); dgamma/dbeta accumulated.
     parts: the [N][C][tiles][2] table a data-gradient conv's GNB epilogue wrote (conv2d_fused(gnb=...)): replaces the
     statistics pass over x and dy."""
@@ -606,7 +606,13 @@ def gn_bwd(src0, dy, ss, mr, gamma, groups, silu, dgamma, dbeta, src1=None, add0
     s12 = torch.empty((n, c, 2), dtype=torch.float64, device=src0.device)
     coef = torch.empty((n, c, 3), dtype=torch.float32, device=src0.device)
     with torch.cuda.device(src0.device):
-        if parts is not None:
+        if add0b is not None:    # a second waiting gradient of source 0, added in the same pass
+            _lib.check(_lib.load().dsg_gn_bwd_add2(_lib.ptr(src0), c0, _lib.ptr(src1), c1, _lib.ptr(dy), _lib.ptr(ss),
+                                                  _lib.ptr(mr), _lib.ptr(gamma), int(silu), n, hw, groups, _lib.ptr(add0),
+                                                  _lib.ptr(add0b), _lib.ptr(add1), _lib.ptr(dx0), _lib.ptr(dx1), _lib.ptr(dgamma),
+                                                  _lib.ptr(dbeta), _lib.ptr(s12), _lib.ptr(coef), _lib.ptr(parts),
+                                                  parts.shape[2] if parts is not None else 0, _st(src0)))
+        elif parts is not None:
             _lib.check(_lib.load().dsg_gn_bwd_parts(_lib.ptr(src0), c0, _lib.ptr(src1), c1, _lib.ptr(dy), _lib.ptr(ss),
                                                    _lib.ptr(mr), _lib.ptr(gamma), int(silu), n, hw, groups, _lib.ptr(add0),
                                                    _lib.ptr(add1), _lib.ptr(dx0), _lib.ptr(dx1), _lib.ptr(dgamma),

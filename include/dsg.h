@@ -518,6 +518,14 @@ int dsg_gn_bwd_parts(const float* src0, int32_t c0, const float* src1, int32_t c
                      int32_t hw, int32_t groups, const float* add0, const float* add1, float* dx0, float* dx1,
                      float* dgamma, float* dbeta, double* ws_s12, float* ws_coef, const double* parts, int32_t ntile,
                      void* stream);
+/* dsg_gn_bwd with a second fan-in term for source 0 (dx0 += add0 + add0b, summed in that order: the bits of the separate add pass
+ * it replaces -- a resnet input that is both a skip connection and its block's residual) and, optionally (parts != NULL, ntile > 0),
+ * the epilogue partials in place of the statistics pass. */
+int dsg_gn_bwd_add2(const float* src0, int32_t c0, const float* src1, int32_t c1, const float* dy,
+                    const float* scale_shift, const float* mean_rstd, const float* gamma, int32_t silu, int32_t n,
+                    int32_t hw, int32_t groups, const float* add0, const float* add0b, const float* add1, float* dx0,
+                    float* dx1, float* dgamma, float* dbeta, double* ws_s12, float* ws_coef, const double* parts,
+                    int32_t ntile, void* stream);
 int dsg_gn_bwd_blocked_parts(const void* src0, int32_t c0, const void* src1, int32_t c1, const void* dy,
                              const float* scale_shift, const float* mean_rstd, const float* gamma, int32_t silu,
                              int32_t n, int32_t hw, int32_t groups, const void* add0, const void* add0b, const void* add1,
