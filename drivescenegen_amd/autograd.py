@@ -171,7 +171,7 @@ class TrainState:
                 self.wf[key] = torch.zeros((c, 1, 3 * c), dtype=torch.float32, device=dev)
                 self.wd[key] = torch.zeros((3 * c, 1, ops._pad32(c) + 64), dtype=torch.float32, device=dev)
                 self.wf[key + ".bias"] = torch.zeros(3 * c, dtype=torch.float32, device=dev)
-            h2 = c % 64 == 0   # the fp16x2-split operand images of the fused projection and of its data gradient (the fp32 tape:
+            h2 = c % 64 == 0 and not _R5_ROUTES   # the fp16x2-split operand images of the fused projection and of its data gradient (the fp32 tape:
             if h2 and key not in self.wh:   # round 6 -- the two calls ran on the exact f32 kernel at 77 TF/s, 1.34 ms each at B=64)
                 self.wh[key] = torch.zeros((c // 16, 2, 1, 2, 3 * c, 8), dtype=torch.float16, device=ws[0].device)
                 self.whd[key] = torch.zeros((3 * c // 16, 2, 1, 2, c, 8), dtype=torch.float16, device=ws[0].device)
@@ -196,6 +196,12 @@ def get_train_state(model) -> TrainState:
         st = TrainState(model)
         model._train_state = st
     return st
+
+
+# A/B hook of the measurement scripts (tools/collect_r06.sh): DSG_F32_TAPE_R5=1 keeps the fp32 tape on the routes round 5 ran -- the
+# fused q/k/v projection on the exact f32 kernel, conv_in / conv_out weight gradients unpadded, residual + skip gradients summed by a
+# pass of their own -- next to DSG_TUNING="37=0,38=0" for the two kernel-level changes.
+_R5_ROUTES = os.environ.get("DSG_F32_TAPE_R5") == "1"
 
 
 class _Tape:
@@ -387,7 +393,7 @@ def _wgrad_padded_f32(st, x0, x1, dy, wname, k, rec):
     [64 x 32..64] weight gradient of which one corner is kept.  The exact f32 kernels took 2.9 ms (conv_out) + 1.4 ms (conv_in) of
     the configs[2] step at 50-60 TF/s; the padded buffers keep their zero channels between steps (only the real channels are
     copied in).  Returns False for shapes this does not serve (the caller then runs the plain call)."""
-    if k != 3 or rec["stride"] != 1 or rec["ups"] or x1 is not None:
+    if k != 3 or rec["stride"] != 1 or rec["ups"] or x1 is not None or _R5_ROUTES:
         return False
     n, cin, h, w = x0.shape
     cout = dy.shape[1]
@@ -432,6 +438,7 @@ def _backward(model, st: TrainState, tape: _Tape, dout):
             for nm in names:
                 h(nm)
 
+    dysums = {}   # id(dy) -> (dy, its per-(n, c) sums, row stride): filled by every conv's backward, read by the shortcut's
     for rec in reversed(tape.recs):
         kind = rec["kind"]
         if kind == "conv":
@@ -441,7 +448,7 @@ def _backward(model, st: TrainState, tape: _Tape, dout):
             wname, cout, k = rec["wname"], rec["cout"], rec["k"]
             x0, x1 = rec["x0"], rec["x1"]
             if rec["res"] is not None:
-                tape.addg(rec["res"], dy, lazy=True)   # (a pending pair is summed inside the next GroupNorm backward on it: add0b)
+                tape.addg(rec["res"], dy, lazy=not _R5_ROUTES)   # (a pending pair is summed inside the next GroupNorm backward on it: add0b)
             # up-sampler conv (no norm, one source): both gradients run at full resolution on the split matrix-core
             # kernels -- the weight gradient from the materialised nearest-x2 input, the data gradient as a plain
             # transposed conv followed by the upsample's adjoint (2x2 sum-pool)
@@ -465,8 +472,15 @@ def _backward(model, st: TrainState, tape: _Tape, dout):
                 ops.conv_wgrad(x0, dy, st.grad(wname + ".weight"), src1=x1, ksize=k, stride=rec["stride"],
                                upsample=rec["ups"], gn_scale_shift=rec["ss"], silu=rec["silu"], **kw)
             if not byp:
-                ops.channel_sums(dy, out=sums, out_stride=sstride)
+                # (a resnet's conv_shortcut sees the very gradient tensor its conv2 saw -- y = conv2(..) + shortcut(x) -- whose
+                #  per-(n, c) sums conv2's weight gradient has just left behind: no pass of its own over dy for the bias gradient)
+                seen = None if _R5_ROUTES else dysums.get(id(dy))
+                if seen is not None and seen[0] is dy:
+                    sums, sstride = seen[1], seen[2]
+                else:
+                    ops.channel_sums(dy, out=sums, out_stride=sstride)
                 ops.reduce_rows_add(sums, st.grad(wname + ".bias"), stride=sstride)
+            dysums[id(dy)] = (dy, sums, sstride)
             done(wname + ".weight", wname + ".bias")
             if rec["toff"] is not None:
                 _temb_proj_grads(st, tb, wname[:-len(".conv1")], done)
