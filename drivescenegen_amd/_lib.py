@@ -51,6 +51,7 @@ class ConvArgs(C.Structure):
         ("sc_weight_h2", C.c_void_p), ("sc_bias", C.c_void_p), ("sc_src_bound", C.c_void_p), ("sc_src_bound1", C.c_void_p),
         ("src_operand", C.c_void_p),
         ("gnb_x0", C.c_void_p), ("gnb_x1", C.c_void_p), ("gnb_c0", C.c_int32), ("gnb_ss", C.c_void_p), ("gnb_silu", C.c_int32),
+        ("s2_window4", C.c_int32),
     ]
 
 

@@ -202,6 +202,8 @@ def get_train_state(model) -> TrainState:
 # fused q/k/v projection on the exact f32 kernel, conv_in / conv_out weight gradients unpadded, residual + skip gradients summed by a
 # pass of their own -- next to DSG_TUNING="37=0,38=0" for the two kernel-level changes.
 _R5_ROUTES = os.environ.get("DSG_F32_TAPE_R5") == "1"
+# ... and DSG_UPS_DGRAD_FULLRES=1 keeps the 16-bit tape's up-sampler data gradient on the full-resolution 3x3 conv + 2x2 sums
+_UPS_DGRAD_FULLRES = os.environ.get("DSG_UPS_DGRAD_FULLRES") == "1"
 
 
 class _Tape:
@@ -488,6 +490,13 @@ def _backward(model, st: TrainState, tape: _Tape, dout):
                 continue
             cin0, cin1 = x0.shape[1], (x1.shape[1] if x1 is not None else 0)
             wdn, wd_stride = wname + ".weight", ops._pad32(cin0 + cin1) + 64  # (row length of TrainState.wd_of's layout)
+            # up-sampler conv: one 4x4 stride-2 window over dY per low-resolution pixel (16 taps: dsg_conv_args.s2_window4) where the
+            # space-to-depth kernel takes the shape; else the 3x3 data gradient at full resolution + 2x2 sums (36 taps)
+            if (rec["ups"] and x1 is None and rec["gn"] is None and k == 3 and not _UPS_DGRAD_FULLRES and not _R5_ROUTES
+                    and cout % 8 == 0 and cin0 % 8 == 0 and x0.shape[2] % 8 == 0 and (x0.shape[3] % 32 == 0 or x0.shape[3] in (8, 16))):
+                tape.setg(x0, ops.conv2d_fused(dy, None, ksize=3, stride=2, cout=cin0, residual=tape.g(x0), s2_window4=True,
+                                               weight_h2_s2=st.pack32(wdn, ops.PACK_DGRAD_UPS)))
+                continue
             if ups_h2:
                 dfull = st.lazy_w(wdn, "wd", lambda wd: ops.conv2d_fused(dy, wd, ksize=k, cout=cin0, weight_h2=rec["whd"]))
                 tape.setg(x0, ops.sumpool2x2(dfull, add=tape.g(x0)))
@@ -1108,6 +1117,14 @@ def _backward16(model, st: TrainState, tape: _Tape, dout):
             cin0, cin1 = chans(x0), (chans(x1) if x1 is not None else 0)
             wn = wname + ".weight"
             if rec["ups"]:
+                # one 4x4 stride-2 window over dY per low-resolution pixel (16 taps; dsg_conv_args.s2_window4) where the
+                # space-to-depth kernel takes the shape; else the 3x3 data gradient at full resolution + 2x2 sums (36 taps)
+                if (not _UPS_DGRAD_FULLRES and k == 3 and blocked(dy) and blocked(x0) and cout % 8 == 0 and cin0 % 8 == 0
+                        and x0.shape[2] % 8 == 0 and (x0.shape[3] % 32 == 0 or x0.shape[3] in (8, 16))):
+                    tape.setg(x0, ops.conv2d_fused(dy, None, ksize=3, stride=2, cout=cin0, residual=tape.g(x0), src_blocked=True,
+                                                   dst_blocked=True, compute_dtype=dt, s2_window4=True,
+                                                   weight_h2_s2=packs.get(wn, ops.PACK_DGRAD_UPS)))
+                    continue
                 dfull = dgrad(dy, wn, k, cin0)
                 tape.setg(x0, ops.sumpool2x2(dfull, add=tape.g(x0)))
                 continue

@@ -453,6 +453,7 @@ __global__ void weight_relayout_kernel(const float* __restrict__ w, float* __res
 }
 
 bool conv_h2_eligible(const dsg_conv_args* a, int hout, int wout);
+bool conv_h2_s2(const dsg_conv_args* a, int hout, int wout);
 int conv_h2_launch(const dsg_conv_args* a, int hout, int wout, hipStream_t st);
 int conv_h2_stats_tiles(const dsg_conv_args* a, int hout, int wout);
 // conv_in.hip: fp32 [N,C<=8,H,W] image -> channel-blocked activations, every compute_dtype
@@ -769,6 +770,14 @@ int conv2d_fwd_impl(const dsg_conv_args* a, hipStream_t st, int force_direct) {
     DSG_CHECK_SHAPE(!force_direct && conv_h2_gnb_ok(a, p.hout, p.wout),
                     "dsg_conv2d_fwd: this call's kernel has no GroupNorm-backward epilogue (dsg_conv2d_gnb_supported reports 0): "
                     "pass gnb_x0 = NULL and run the statistics pass");
+    return conv_h2_launch(a, p.hout, p.wout, st);
+  }
+  if (a->s2_window4) {  // data gradient of an up-sampler conv as one 4x4 stride-2 window: the space-to-depth kernel only
+    DSG_CHECK_ARG(a->s2_window4 == 1 && a->stride == 2 && a->ksize == 3 && a->weight_h2_s2 != nullptr,
+                  "dsg_conv2d_fwd: s2_window4 must be 0 or 1 and needs stride 2, ksize 3 and weight_h2_s2 (pack kind 5)");
+    DSG_CHECK_SHAPE(!force_direct && conv_h2_s2(a, p.hout, p.wout),
+                    "dsg_conv2d_fwd: s2_window4: the space-to-depth kernel does not take this call (channel-blocked tensors, "
+                    "c0 %% 8 == 0, cout %% 8 == 0, output rows %% 8 == 0, output width 8, 16 or a multiple of 32)");
     return conv_h2_launch(a, p.hout, p.wout, st);
   }
   if (a->sc_weight_h2 != nullptr) {  // fused shortcut: only the split-path kernel that contracts it serves the call

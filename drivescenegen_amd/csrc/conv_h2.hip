@@ -22,8 +22,11 @@ bool conv_h2_fold(const dsg_conv_args* a) {
 
 // stride-2 3x3 conv as a 2x2 conv over the space-to-depth image (GM = 3): channel-blocked tensors only
 bool conv_h2_s2(const dsg_conv_args* a, int hout, int wout) {
+  // (the up-sampler's data gradient, s2_window4, also on fp32 [N,C,H,W] tensors: the fp32 tape's layout)
+  const bool lay_ok = (a->src_layout == 1 && a->dst_layout == 1) ||
+                      (a->s2_window4 && a->src_layout == 0 && a->dst_layout == 0 && a->compute_dtype == DSG_F32);
   return g_h2.enabled && g_h2.s2 && a->weight_h2_s2 != nullptr && a->stride == 2 && a->ksize == 3 && !a->upsample &&
-         !a->pool2 && !a->gn_scale_shift && a->src_layout == 1 && a->dst_layout == 1 && a->c1 == 0 && a->c0 % 8 == 0 &&
+         !a->pool2 && !a->gn_scale_shift && lay_ok && a->c1 == 0 && a->c0 % 8 == 0 &&
          a->cout % 8 == 0 && a->hin % 2 == 0 && a->win % 2 == 0 && hout % 8 == 0 &&
          (wout % H2_TW == 0 || (g_h2.narrow && (wout == 16 || wout == 8)));
 }
@@ -399,14 +402,19 @@ int conv_h2_tuning_epoch() { return g_h2.epoch + conv_in_tuning_epoch(); }
 //   4 data gradient of a stride-2 conv, in the folded up-sampler's form: K = cout, N = cin, 4 phases x 2x2 taps over
 //     the LOW-resolution dY; input pixel 2m + py receives dY[m] * W[1] (py = 0) or dY[m] * W[2] + dY[m+1] * W[0]
 //     (py = 1), i.e. corner row tr of phase py is the 3x3 row {-, 1} / {2, 0}; the same in x
+//   5 data gradient of the up-sampler (nearest-2x + 3x3 conv), as ONE stride-2 conv over the space-to-depth image of the
+//     full-resolution dY (kind 2's axes with the roles of the channels swapped): K = 4 cout (channel block, pixel parity,
+//     channel in block), N = cin, 2x2 taps; dX[y] = sum over the 4x4 window of dY rows 2y - 1 + i, i = 0..3, each row
+//     weighted by the sum of the 3x3 rows that read low-resolution row y through it: {2}, {1, 2}, {0, 1}, {0}; tap ty
+//     of parity py is window row i = 2 ty - py + 1; the same in x
 // ---------------------------------------------------------------------------------------------------------------
 // element i of the operand image of one weight (the body of weight_pack_kernel; weight_pack_batch_kernel runs it too)
 __device__ __forceinline__ void weight_pack_elem(const float* __restrict__ w, unsigned short* __restrict__ dst, int cout_w,
                                                  int cin_w, int ksize, int kind, int dt, int n_pad, int n_off, int64_t i) {
   const int taps_w = ksize * ksize;
-  const int taps = (kind == 1 || kind == 2 || kind == 4) ? 4 : taps_w;
-  const int kdim = kind == 2 ? 4 * cin_w : ((kind == 3 || kind == 4) ? cout_w : cin_w);
-  const int ndim = (kind == 3 || kind == 4) ? cin_w : cout_w;
+  const int taps = (kind == 1 || kind == 2 || kind == 4 || kind == 5) ? 4 : taps_w;
+  const int kdim = kind == 2 ? 4 * cin_w : (kind == 5 ? 4 * cout_w : ((kind == 3 || kind == 4) ? cout_w : cin_w));
+  const int ndim = (kind == 3 || kind == 4 || kind == 5) ? cin_w : cout_w;
   const int nq = kdim / 16, np = dt == 0 ? 2 : 1;
   {
     const int j = (int)(i % 8);
@@ -436,6 +444,14 @@ __device__ __forceinline__ void weight_pack_elem(const float* __restrict__ w, un
       const int gi = 2 * q + g, cb = gi >> 2, pp = gi & 3;
       const int dy = 2 * (tap >> 1) + (pp >> 1) - 1, dx = 2 * (tap & 1) + (pp & 1) - 1;
       if (dy >= 0 && dx >= 0) v = w[((int64_t)nn * cin_w + cb * 8 + j) * 9 + dy * 3 + dx];  // (dy, dx <= 2)
+    } else if (kind == 5) {
+      const int gi = 2 * q + g, cb = gi >> 2, pp = gi & 3;
+      const int wi = 2 * (tap >> 1) - (pp >> 1) + 1, wj = 2 * (tap & 1) - (pp & 1) + 1;  // window row / column, 0..3
+      const int dy0 = wi == 0 ? 2 : (wi == 1 ? 1 : 0), dy1 = wi <= 1 ? 2 : (wi == 2 ? 1 : 0);
+      const int dx0 = wj == 0 ? 2 : (wj == 1 ? 1 : 0), dx1 = wj <= 1 ? 2 : (wj == 2 ? 1 : 0);
+      const float* wp = w + ((int64_t)(cb * 8 + j) * cin_w + nn) * 9;
+      for (int dy = dy0; dy <= dy1; ++dy)
+        for (int dx = dx0; dx <= dx1; ++dx) v += wp[dy * 3 + dx];
     } else {  // kind 4
       const int py = phase >> 1, px = phase & 1, tr = tap >> 1, tc = tap & 1;
       const int ky = py == 0 ? (tr == 1 ? 1 : -1) : (tr == 0 ? 2 : 0);
@@ -458,9 +474,9 @@ __device__ __forceinline__ void weight_pack_elem(const float* __restrict__ w, un
 __global__ void weight_pack_kernel(const float* __restrict__ w, unsigned short* __restrict__ dst, int cout_w, int cin_w,
                                    int ksize, int kind, int dt, int n_pad, int n_off) {
   const bool phased = kind == 1 || kind == 4;
-  const int taps = (kind == 1 || kind == 2 || kind == 4) ? 4 : ksize * ksize;
-  const int kdim = kind == 2 ? 4 * cin_w : ((kind == 3 || kind == 4) ? cout_w : cin_w);
-  const int ndim = (kind == 3 || kind == 4) ? cin_w : cout_w;
+  const int taps = (kind == 1 || kind == 2 || kind == 4 || kind == 5) ? 4 : ksize * ksize;
+  const int kdim = kind == 2 ? 4 * cin_w : (kind == 5 ? 4 * cout_w : ((kind == 3 || kind == 4) ? cout_w : cin_w));
+  const int ndim = (kind == 3 || kind == 4 || kind == 5) ? cin_w : cout_w;
   const int64_t total = (phased ? 4 : 1) * (int64_t)(kdim / 16) * taps * 2 * ndim * 8;
   for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x)
     weight_pack_elem(w, dst, cout_w, cin_w, ksize, kind, dt, n_pad, n_off, i);
@@ -635,14 +651,15 @@ DSG_API int dsg_conv_operand_prepare(const float* src0, int32_t c0, const float*
 
 static int pack_dims(int32_t cout, int32_t cin, int32_t ksize, int32_t kind, int32_t dtype, int32_t n_total,
                      int* kdim, int* ndim, int* taps, int* phases, int* n_pad) {
-  DSG_CHECK_ARG(kind >= 0 && kind <= 4, "dsg_conv_weight_pack: kind must be 0..4 (got %d)", kind);
+  DSG_CHECK_ARG(kind >= 0 && kind <= 5, "dsg_conv_weight_pack: kind must be 0..5 (got %d)", kind);
   DSG_CHECK_ARG(dtype >= DSG_F32 && dtype <= DSG_F16, "dsg_conv_weight_pack: dtype must be DSG_F32 / DSG_BF16 / DSG_F16");
   DSG_CHECK_ARG(cout > 0 && cin > 0 && (ksize == 1 || ksize == 3), "dsg_conv_weight_pack: bad dims");
-  DSG_CHECK_ARG(kind == 0 || kind == 3 || ksize == 3, "dsg_conv_weight_pack: kinds 1, 2, 4 are 3x3 only");
+  DSG_CHECK_ARG(kind == 0 || kind == 3 || ksize == 3, "dsg_conv_weight_pack: kinds 1, 2, 4, 5 are 3x3 only");
   DSG_CHECK_ARG(kind != 2 || cin % 8 == 0, "dsg_conv_weight_pack: the stride-2 form needs cin %% 8 == 0 (got %d)", cin);
-  *kdim = kind == 2 ? 4 * cin : ((kind == 3 || kind == 4) ? cout : cin);
-  *ndim = (kind == 3 || kind == 4) ? cin : cout;
-  *taps = (kind == 1 || kind == 2 || kind == 4) ? 4 : ksize * ksize;
+  DSG_CHECK_ARG(kind != 5 || cout % 8 == 0, "dsg_conv_weight_pack: the up-sampler's data-gradient form needs cout %% 8 == 0 (got %d)", cout);
+  *kdim = kind == 2 ? 4 * cin : (kind == 5 ? 4 * cout : ((kind == 3 || kind == 4) ? cout : cin));
+  *ndim = (kind == 3 || kind == 4 || kind == 5) ? cin : cout;
+  *taps = (kind == 1 || kind == 2 || kind == 4 || kind == 5) ? 4 : ksize * ksize;
   *phases = (kind == 1 || kind == 4) ? 4 : 1;
   DSG_CHECK_ARG(*kdim % 16 == 0, "dsg_conv_weight_pack: the contraction axis (%d) must be a multiple of 16", *kdim);
   if (n_total == 0) n_total = *ndim;

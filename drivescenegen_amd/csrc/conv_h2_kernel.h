@@ -220,7 +220,8 @@ __global__ __launch_bounds__(64 * NW, OCC * NW / 4) void conv_h2_kernel(ConvH2P 
   constexpr int ESS = S16 ? 2 : 4;              // bytes per source element
   constexpr int ESD = (PREC != 0 && DB) ? 2 : 4;  // bytes per dst / residual element
   constexpr int MTN = BM / 32;  // 32-channel MFMA tiles per workgroup
-  using G = H2Geom<NT, KS, NW, (GM == 2 || GM == 3) ? 4 : KS * KS, BM, NP, PRE>;
+  constexpr bool S2D = GM == 3 || GM == 4;    // 2x2 taps over the space-to-depth image (GM 4: the 4x4 stride-2 window, see load_frags)
+  using G = H2Geom<NT, KS, NW, (GM == 2 || S2D) ? 4 : KS * KS, BM, NP, PRE>;
   constexpr int NTH = G::NTH;
   constexpr int H2_TH = G::TH, H2_PSZ = G::PSZ, H2_XHALFS = G::XHALFS, H2_BUF_BYTES = G::BUF_BYTES, H2_NU = G::NU;
   constexpr int H2_PSTR = G::PSTR;  // positions between the (piece, k-group) regions of a patch
@@ -281,7 +282,7 @@ __global__ __launch_bounds__(64 * NW, OCC * NW / 4) void conv_h2_kernel(ConvH2P 
       const int gy = oy0 - PADK + py, gx = ox0 - PADK + px;
       const int slot = H2_WHALFS + (g * H2_PSTR + pos) * 8;  // piece 0; piece 1 is 2*PSTR*8 halfs further
       if (gy >= 0 && gy < p.hc && gx >= 0 && gx < p.wc) {
-        off = GM == 3 ? (2 * gy) * p.win + 2 * gx : (GM == 1 ? (gy >> 1) : gy) * p.win + (GM == 1 ? (gx >> 1) : gx);
+        off = S2D ? (2 * gy) * p.win + 2 * gx : (GM == 1 ? (gy >> 1) : gy) * p.win + (GM == 1 ? (gx >> 1) : gx);
         xo = slot;
         xo2 = NP == 2 ? slot + 2 * H2_PSTR * 8 : slot;
       } else {
@@ -348,9 +349,9 @@ __global__ __launch_bounds__(64 * NW, OCC * NW / 4) void conv_h2_kernel(ConvH2P 
   for (int j = 0; j < 8; ++j) soff[j] = __builtin_amdgcn_readfirstlane(j * plane * 4);
   // descriptor of k-group g of chunk q: its 8 channel planes / its channel block (uniform)
   auto grp_rs = [&](const char* sp, int q, int g) -> __amdgpu_buffer_rsrc_t {
-    if constexpr (GM == 3) {  // group (cb, py, px) of the space-to-depth image: block cb, first pixel (py, px)
+    if constexpr (S2D) {  // group (cb, py, px) of the space-to-depth image: block cb, first pixel (py, px)
       const int gi = 2 * (q + qb) + g, cb = gi >> 2, pp = gi & 3;
-      const int first = ((pp >> 1) * p.win + (pp & 1)) * 8;
+      const int first = ((pp >> 1) * p.win + (pp & 1)) * (SB ? 8 : 1);  // in elements ([N,C,H,W]: the group's 8 planes start there)
       return __builtin_amdgcn_make_buffer_rsrc(
           const_cast<char*>(src0b + (((size_t)n * p.c0 + cb * 8) * plane + first) * ESS), 0, (8 * plane - first) * ESS,
           0x00020000);
@@ -870,8 +871,11 @@ __global__ __launch_bounds__(64 * NW, OCC * NW / 4) void conv_h2_kernel(ConvH2P 
     half8 fa[2][MTN][NP], fb[2][NT][NP];  // [parity][tile][piece]
     auto load_frags = [&](int tap, int par) {
       // folded up-sampler: the phase's 2x2 corner of the patch; stride 2: the {y-1, y} x {x-1, x} corner
-      const int dy = GM == 2 ? (phase >> 1) + (tap >> 1) : (GM == 3 ? (tap >> 1) : tap / KS);
-      const int dx = GM == 2 ? (phase & 1) + (tap & 1) : (GM == 3 ? (tap & 1) : tap % KS);
+      // GM 4 (data gradient of nearest-2x + 3x3 conv: a 4x4 stride-2 window over dY that starts at (2y - 1, 2x - 1)): window
+      // row i is source row 2 (y - 1 + (i + 1) / 2) + ((i + 1) & 1), so the chunk's row parity py = (q + qb) & 1 owns window
+      // rows {1 - py, 3 - py} = patch rows (tap >> 1) + 1 - py (the patch starts at y - 1); same in x with px = the lane half
+      const int dy = GM == 2 ? (phase >> 1) + (tap >> 1) : (GM == 3 ? (tap >> 1) : (GM == 4 ? (tap >> 1) + 1 - ((q + qb) & 1) : tap / KS));
+      const int dx = GM == 2 ? (phase & 1) + (tap & 1) : (GM == 3 ? (tap & 1) : (GM == 4 ? (tap & 1) + 1 - half : tap % KS));
 #ifdef DSG_H2_ABL_NOFA   // (tools/ timing experiment: tap 0's weight fragments serve every tap -- wrong values, the loop without 8/9 of the A reads)
       if (tap == 0) {
 #pragma unroll

@@ -228,6 +228,12 @@ int conv_h2_launch_t(const dsg_conv_args* a, int hout, int wout, hipStream_t st)
       else if (sc) rc = h2_launch<0, 4, 3, 0, 4, 1, 3, 64, 0, 0, 1, 1>(grid, lpre, st, p);
       else rc = h2_launch<0, 4, 3, 0, 4, 1, 3, 64, 0, 0, 0, 1>(grid, lpre, st, p);
     }
+  } else if (s2 && a->s2_window4) {  // the up-sampler's data gradient: same patch and K axis, the taps of a 4x4 window
+    if (lay) DSG_H2_LAUNCH_BLK(4, 3, 0, 3);
+    else if constexpr (PREC == 0) {
+      if (nt4) rc = h2_launch<4, 4, 3, 0>(grid, lds, st, p);
+      else rc = h2_launch<4, 2, 3, 0>(grid, lds, st, p);
+    }
   } else if (s2) {
     DSG_H2_LAUNCH_BLK(3, 3, 0, 3);
   } else if (fold) {

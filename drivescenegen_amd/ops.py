@@ -38,7 +38,7 @@ def relayout_conv_weight(w_oihw: torch.Tensor, out: torch.Tensor = None, cout_to
 
 
 _DT_OF = {torch.float32: _lib.DSG_F32, torch.bfloat16: _lib.DSG_BF16, torch.float16: _lib.DSG_F16}
-PACK_FWD, PACK_FOLD, PACK_S2, PACK_DGRAD, PACK_DGRAD_S2 = 0, 1, 2, 3, 4
+PACK_FWD, PACK_FOLD, PACK_S2, PACK_DGRAD, PACK_DGRAD_S2, PACK_DGRAD_UPS = 0, 1, 2, 3, 4, 5
 
 
 def dtype_code(dtype) -> int:
@@ -89,7 +89,7 @@ class PackTable:
                 j.cout, j.cin = w.shape[0], w.shape[1]
                 j.ksize = w.shape[2] if w.dim() == 4 else 1
                 j.dtype, j.n_total, j.n_off = dtype_code(job.get("dtype", 0)), int(job.get("n_total", 0)), int(job.get("n_off", 0))
-                ndim = j.cin if kind in (PACK_DGRAD, PACK_DGRAD_S2) else j.cout
+                ndim = j.cin if kind in (PACK_DGRAD, PACK_DGRAD_S2, PACK_DGRAD_UPS) else j.cout
                 j.n_pad = ((j.n_total or ndim) + 63) // 64 * 64
             items = C.c_int64()
             _lib.check(lib.dsg_conv_weight_pack_batch_items(C.byref(j), C.byref(items)))
@@ -174,7 +174,7 @@ def conv2d_fused(src0, weight_r, bias=None, src1=None, ksize=3, stride=1, upsamp
                  silu=False, temb=None, temb_stride=0, residual=None, out=None, direct=False, cout=None,
                  pool2=False, wstride=None, weight_h2=None, want_stats=False, stats_buf=None, weight_h2_col=0, weight_h2_fold=None,
                  src_blocked=False, dst_blocked=False, weight_h2_s2=None, compute_dtype=0, weight_h2_stride=0,
-                 src_bound=None, src_bound1=None, splitk=False, shortcut=None, operand=None, gnb=None):
+                 src_bound=None, src_bound1=None, splitk=False, shortcut=None, operand=None, gnb=None, s2_window4=False):
     """dsg_conv2d_fwd: see include/dsg.h.  `weight_r` is in engine layout; `temb` is a [N, temb_stride] view
     whose first `cout` columns (from its data pointer) are added per (n, cout).
     want_stats: also return the per-tile GroupNorm statistics [N][cout][tiles][2] (fp64) of the result, or None
@@ -191,7 +191,9 @@ def conv2d_fused(src0, weight_r, bias=None, src1=None, ksize=3, stride=1, upsamp
     gnb: dict(x0=, x1=None, ss=, silu=True[, query_only=True]) -- this call is the DATA GRADIENT of a conv behind
     silu?(GroupNorm(cat(x0, x1))): the kernel's epilogue also leaves the norm's backward statistics, per-tile (sum du, sum du * x),
     in the table `want_stats` returns (dsg_conv_args.gnb_*; hand it to gn_bwd* as `parts`).  query_only: just ask
-    dsg_conv2d_gnb_supported.  Raises when the call's kernel has no such epilogue."""
+    dsg_conv2d_gnb_supported.  Raises when the call's kernel has no such epilogue.
+    s2_window4: with stride=2 and weight_h2_s2 = pack_conv_weight(w, PACK_DGRAD_UPS): the call is the data gradient of the
+    up-sampler conv `w` (src0 = dY at full resolution, result = dX at half of it; dsg_conv_args.s2_window4)."""
     lib = _lib.load()
     cdt = dtype_code(compute_dtype)
     blk_dtype = _lib.TORCH_DTYPES[cdt]
@@ -241,6 +243,7 @@ def conv2d_fused(src0, weight_r, bias=None, src1=None, ksize=3, stride=1, upsamp
             a.weight_h2_cout_stride = weight_h2.shape[-2] if weight_h2_col or weight_h2.shape[-2] != (cout + 63) // 64 * 64 else 0
     a.weight_h2_fold = weight_h2_fold.data_ptr() if weight_h2_fold is not None else None
     a.weight_h2_s2 = weight_h2_s2.data_ptr() if weight_h2_s2 is not None else None
+    a.s2_window4 = int(bool(s2_window4))
     a.gn_scale_shift, a.silu = _lib.ptr(gn_scale_shift), int(silu)
     if temb is not None:
         if not temb.is_cuda:

@@ -169,6 +169,13 @@ typedef struct {
   int32_t gnb_c0;
   const float* gnb_ss;
   int32_t gnb_silu;
+  /* With stride == 2 and weight_h2_s2: 0 = the 3x3 pad-1 conv above.  1 = the call is the DATA GRADIENT of an up-sampler
+     (nearest-2x followed by a 3x3 conv; reference: diffusers Upsample2D as built by DriveSceneGen/utils/model/unet_2d.py's
+     up blocks): src0 is dY at full resolution [N, c0, 2h, 2w], dst is dX [N, cout, h, w] (c0 = the up-sampler conv's cout,
+     cout = its cin), weight_h2_s2 is dsg_conv_weight_pack kind 5 of the conv's weight: one 4x4 stride-2 window per low-resolution
+     pixel, 16 taps instead of the 36 of "3x3 data gradient at full resolution, then sum the 2x2 pixels".  Channel-blocked
+     tensors only (`weight` is not read); DSG_ERR_UNSUPPORTED_SHAPE where the space-to-depth kernel does not take the shape. */
+  int32_t s2_window4;
 } dsg_conv_args;
 
 int dsg_conv2d_fwd(const dsg_conv_args* a, void* stream);
@@ -222,7 +229,9 @@ int dsg_conv_weight_relayout_h2(const float* w_oihw, void* dst_half, int32_t cou
  * 1 rounded value for DSG_BF16 / DSG_F16.  kind: 0 forward conv (dsg_conv_args.weight_h2); 1 folded up-sampler
  * (weight_h2_fold); 2 stride-2 conv over the space-to-depth image (weight_h2_s2); 3 data gradient (K = cout, N = cin,
  * taps reversed: weight_h2 of the conv dX = conv(dY, .)); 4 data gradient of a stride-2 conv as four 2x2 phase convs of
- * the low-resolution dY (weight_h2_fold of a call with upsample == 1: the adjoint of kind 2).  n_total / n_off place
+ * the low-resolution dY (weight_h2_fold of a call with upsample == 1: the adjoint of kind 2); 5 data gradient of an
+ * up-sampler conv (nearest-2x + 3x3) as one stride-2 conv with a 4x4 window over the full-resolution dY (weight_h2_s2 of a
+ * call with s2_window4 == 1: K = 4 cout in kind 2's (block, pixel parity) order, N = cin; cout % 8 == 0).  n_total / n_off place
  * this weight's N columns inside a wider matrix (kinds 0 and 3; 0 = no window). */
 int dsg_conv_weight_pack(const float* w_oihw, void* dst, int32_t cout, int32_t cin, int32_t ksize, int32_t kind,
                          int32_t dtype, int32_t n_total, int32_t n_off, void* stream);

@@ -251,6 +251,44 @@ def test_training_step_mixed_vs_fp32_oracle(cfg, mode):
     assert total <= 3e-2 and worst[1] <= 1.2e-1, (total, worst)
 
 
+@pytest.mark.parametrize("mode", ["bf16", "fp32"])
+@pytest.mark.parametrize("cfg", [CFG1, CFG4_SMALL], ids=["cfg1_tiny", "attn_blocks"])
+def test_upsampler_data_gradient_routes_agree(cfg, mode, monkeypatch):
+    """The 16-bit tape's up-sampler data gradient: one 4x4 stride-2 window over dY (dsg_conv_args.s2_window4, the route the
+    tape takes) against the 3x3 data gradient at full resolution + 2x2 sums it replaces (DSG_UPS_DGRAD_FULLRES=1): the same
+    sums with two roundings less -- whole gradient vector within 1e-2 of each other (fp32 tape, [N,C,H,W] tensors: 2e-6), loss
+    bit-identical (same forward)."""
+    from drivescenegen_amd import autograd as ag
+    b, ss = 2, cfg["sample_size"]
+    x0 = torch.from_numpy(synth.synth_scene_rasters(b, cfg["in_channels"], ss, ss, 5))
+    noise = torch.from_numpy(synth.normal(6, tuple(x0.shape)))
+    t = torch.tensor([12, 700])
+    calls = []
+    real = ops.conv2d_fused
+
+    def spy(*a, **kw):
+        calls.append(bool(kw.get("s2_window4")))
+        return real(*a, **kw)
+
+    monkeypatch.setattr(ops, "conv2d_fused", spy)
+    res = []
+    for fullres in (False, True):
+        monkeypatch.setattr(ag, "_UPS_DGRAD_FULLRES", fullres)
+        calls.clear()
+        net = synth_weights(d.UNet2DModel(**cfg)).to(DEV).train().set_compute_dtype(mode)
+        sch = d.DDPMScheduler()
+        noisy = sch.add_noise(x0.to(DEV), noise.to(DEV), t.to(DEV))
+        loss = d.mse_loss(net(noisy, t.to(DEV), return_dict=False)[0], noise.to(DEV))
+        loss.backward()
+        n_ups = sum(1 for k in net.state_dict() if k.endswith("upsamplers.0.conv.weight"))
+        assert sum(calls) == (0 if fullres else n_ups), (sum(calls), n_ups)
+        res.append((float(loss.detach().cpu()), {k: p.grad.detach().cpu().double() for k, p in net.named_parameters()}))
+    assert res[0][0] == res[1][0]
+    num = sum(float((res[0][1][k] - res[1][1][k]).pow(2).sum()) for k in res[0][1])
+    den = sum(float(res[1][1][k].pow(2).sum()) for k in res[0][1])
+    assert (num / den) ** 0.5 <= (1e-2 if mode == "bf16" else 2e-6), (num / den) ** 0.5
+
+
 def test_fp16_grad_scaler_skips_a_non_finite_step_and_recovers():
     """accelerate's fp16 path (training_pipeline.py:86-91 under train.py:24): scaled backward, unscale + clip, a step
     whose gradients are not finite is skipped -- parameters, AdamW moments and the LR schedule stay put, the scale

@@ -26,7 +26,7 @@ def test_pack_batch_matches_one_by_one():
     seed = 0
     for dt in ("fp32", "bf16", "fp16"):
         for (cout, cin, k, kind) in [(64, 32, 3, ops.PACK_FWD), (96, 64, 3, ops.PACK_FWD), (128, 64, 3, ops.PACK_DGRAD),
-                                     (64, 64, 3, ops.PACK_FOLD), (64, 32, 3, ops.PACK_S2), (64, 48, 3, ops.PACK_DGRAD_S2),
+                                     (64, 64, 3, ops.PACK_FOLD), (64, 32, 3, ops.PACK_S2), (64, 48, 3, ops.PACK_DGRAD_S2), (40, 72, 3, ops.PACK_DGRAD_UPS),
                                      (128, 96, 1, ops.PACK_FWD), (64, 128, 1, ops.PACK_DGRAD), (8, 64, 3, ops.PACK_FWD)]:
             seed += 1
             w = _t(seed, (cout, cin, k, k) if k == 3 else (cout, cin), 0.1)
