@@ -494,6 +494,7 @@ void unet_set_blocked(int v);
 void attention_set_mfma(int v);
 void wgrad_h2_set_enabled(int on);
 void conv_wgrad16_set_wide(int v);
+void conv_wgrad16_set_fold(int v);
 void wgrad_h2_set_wide(int v);
 void conv_wgrad16_set_pw(int v);
 void conv_h2_set_fold(int on);
@@ -961,6 +962,10 @@ static int set_tuning_impl(int32_t key, int32_t value) {
   }
   if (key == 38 && (value == 0 || value == 1)) {
     dsg::attention_set_bwd_split(value);
+    return DSG_OK;
+  }
+  if (key == 39 && (value == 0 || value == 1)) {
+    dsg::conv_wgrad16_set_fold(value);
     return DSG_OK;
   }
   if (key == 31 && (value == 0 || value == 1)) {

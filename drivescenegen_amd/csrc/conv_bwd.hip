@@ -227,6 +227,7 @@ struct DysumJob {
   int out_stride;
   float* bias_grad;   // may be null
   int blocks;         // cdiv(cout, 32)
+  int parts;          // 1; 4 = every slab row holds [4 pixel parities][cout] (the folded up-sampler form): summed here
 };
 // block b of the job: 32 channels x 8 image groups
 __device__ __forceinline__ void dysum_job_block(const DysumJob& j, int b) {
@@ -236,7 +237,8 @@ __device__ __forceinline__ void dysum_job_block(const DysumJob& j, int b) {
   if (co < j.cout) {
     for (int ni = g; ni < j.n; ni += 8) {
       float t = 0.f;
-      for (int k = 0; k < j.slabs_per_image; ++k) t += j.part[((size_t)ni * j.slabs_per_image + k) * j.cout + co];
+      for (int k = 0; k < j.slabs_per_image; ++k)
+        for (int q = 0; q < j.parts; ++q) t += j.part[(((size_t)ni * j.slabs_per_image + k) * j.parts + q) * j.cout + co];
       j.out[(size_t)ni * j.out_stride + co] = t;
       acc += (double)t;
     }
@@ -365,7 +367,7 @@ __global__ __launch_bounds__(256) void wgrad_reduce_t_kernel(const float* __rest
 static DysumJob dysum_job(const float* part, int slabs_per_image, int cout, int n, float* out, int out_stride, float* bias_grad) {
   DysumJob j;
   j.part = part; j.slabs_per_image = slabs_per_image; j.cout = cout; j.n = n; j.out = out; j.out_stride = out_stride;
-  j.bias_grad = bias_grad; j.blocks = part ? cdiv(cout, 32) : 0;
+  j.bias_grad = bias_grad; j.blocks = part ? cdiv(cout, 32) : 0; j.parts = 1;
   return j;
 }
 
@@ -382,6 +384,52 @@ static void launch_wgrad_reduce(const float* ws, int nslab, int taps, int cin, i
     hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)(main_blocks + j.blocks)), dim3(256), 0, st, ws, nslab, taps, cin, cout,
                        cin_pad, cout_pad, dw, j, main_blocks);
   }
+}
+
+// Reduce pass of the folded up-sampler form (Wgrad16P.fold_co): ws[slab][tap (ty, tx)][ci][parity p][co] -> dw[co][ci][ky][kx] +=
+// sum over the slabs (in slab order) of the four (tap, parity) terms that weight reads x through: parity py of an output row
+// 2y + py reads x row y + floor((py - 1 + ky) / 2), which is the parity's tap ty = (py == 0 ? ky != 0 : ky == 2); the same in x.
+// One thread per (ci, co): 16 coalesced reads per slab (co fastest), nine read-modify-writes of dw.
+__global__ __launch_bounds__(256) void wgrad_fold_reduce_kernel(const float* __restrict__ ws, int nslab, int cin, int co,
+                                                                float* __restrict__ dw, DysumJob job, int main_blocks) {
+  if ((int)blockIdx.x >= main_blocks) {  // (the launch's extra workgroups)
+    dysum_job_block(job, blockIdx.x - main_blocks);
+    return;
+  }
+  const int64_t i = blockIdx.x * (int64_t)256 + threadIdx.x;
+  if (i >= (int64_t)cin * co) return;
+  const int c = (int)(i % co), ci = (int)(i / co);
+  const int64_t tstride = (int64_t)cin * 4 * co, slab = 4 * tstride;
+  float h[4][4];  // [tap][parity]
+#pragma unroll
+  for (int t = 0; t < 4; ++t)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) h[t][q] = 0.f;
+  const float* base = ws + (int64_t)ci * 4 * co + c;
+  for (int k = 0; k < nslab; ++k, base += slab) {
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) h[t][q] += base[t * tstride + q * co];
+  }
+  float* out = dw + ((size_t)c * cin + ci) * 9;
+#pragma unroll
+  for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+    for (int kx = 0; kx < 3; ++kx) {
+      float v = 0.f;
+#pragma unroll
+      for (int py = 0; py < 2; ++py)
+#pragma unroll
+        for (int px = 0; px < 2; ++px) {
+          const int ty = py == 0 ? (ky != 0) : (ky == 2), tx = px == 0 ? (kx != 0) : (kx == 2);
+          v += h[ty * 2 + tx][py * 2 + px];
+          // (scalar adds: left to the SLP vectoriser these sums became v_pk_add_f32 ... op_sel:[0,1], the form that returns wrong
+          //  values on lanes 48-63 beside another wave's MFMAs -- tests/test_isa_policy.py)
+          asm volatile("" : "+v"(v));
+        }
+      out[ky * 3 + kx] += v;
+    }
 }
 
 // Generic VALU fallback (odd spatial sizes): one thread per (co, ci, tap), loops over all pixels.
@@ -1468,6 +1516,12 @@ struct Wgrad16P {
   //   dsh = 1  Downsample2D's stride-2 conv: dY is [N][Co/8][h/2][w/2][8]; pixel (y, x) of the K grid is dY[y/2][x/2] when both are
   //            even and ZERO otherwise (was: a strided torch copy into a zeroed full-resolution buffer per step)
   int xsh, dsh;
+  // Upsample2D + conv, folded (FOLD = 1): the K grid is the LOW-resolution map (h x w = x's), dY [N][Co/8][2h][2w][8] is read as its
+  // space-to-depth image with 4 Co channels in parity-major order (channel p * fold_co + c = dY[c] at pixels (2y + py, 2x + px),
+  // p = 2 py + px; cout = 4 fold_co), and a workgroup -- whose co block lies inside ONE parity -- contracts only the 2 x 2 taps of the
+  // 3 x 3 window that parity reads: x rows y + py - 1 + {0, 1}.  16 (tap, parity) products per low-resolution pixel instead of the 36
+  // of nine taps at full resolution; wgrad_fold_reduce_kernel adds the four (tap, parity) terms each 3 x 3 weight gradient is the sum of.
+  int fold_co;
 };
 
 typedef short wg_s4 __attribute__((ext_vector_type(4)));
@@ -1507,9 +1561,10 @@ struct W16Geom {
 // accumulator tiles, 512 registers, one workgroup per CU.  An activation fragment then feeds two matrix instructions (11
 // LDS fragments per 18 instead of 10 per 9: at COT = 1 the LDS pipe is as busy as the matrix pipe), the activation
 // arithmetic of the staging is paid once per 128 output channels instead of per 64, and x is re-read cout / 128 times.
-template <int PREC, int KS, int ACT = 2, int COT = 1>
+template <int PREC, int KS, int ACT = 2, int COT = 1, int FOLD = 0>
 __global__ __launch_bounds__(256, COT == 2 ? 1 : 2) void conv_wgrad16_kernel(Wgrad16P p) {
-  constexpr int W16_PW = W16Geom<KS>::PW, W16_A_HALFS = W16Geom<KS>::A_HALFS, PADK = KS / 2, TAPS = KS * KS;
+  static_assert(!FOLD || (KS == 3 && ACT == 0), "folded up-sampler form: 3x3, sources used as they are");
+  constexpr int W16_PW = W16Geom<KS>::PW, W16_A_HALFS = W16Geom<KS>::A_HALFS, PADK = KS / 2, TAPS = FOLD ? 4 : KS * KS;
   constexpr int W16_D_HALFS = W16Geom<KS, COT>::D_HALFS, COW = 64 * COT, DCB = 8 * COT, DSH = COT == 2 ? 4 : 3;
   extern __shared__ __attribute__((aligned(16))) unsigned char wsm16[];
   unsigned short* Ab = reinterpret_cast<unsigned short*>(wsm16);
@@ -1527,7 +1582,11 @@ __global__ __launch_bounds__(256, COT == 2 ? 1 : 2) void conv_wgrad16_kernel(Wgr
   const int plane = p.h * p.w;
   // half-resolution operands of the sampler convs (uniform shifts: see Wgrad16P)
   const int xsh = __builtin_amdgcn_readfirstlane(p.xsh), dsh = __builtin_amdgcn_readfirstlane(p.dsh);
-  const int xplane = plane >> (2 * xsh), xw = p.w >> xsh, dplane = plane >> (2 * dsh), dw_ = p.w >> dsh;
+  const int xplane = plane >> (2 * xsh), xw = p.w >> xsh;
+  const int dplane = FOLD ? 4 * plane : plane >> (2 * dsh), dw_ = FOLD ? 2 * p.w : p.w >> dsh;
+  // folded form: this co block's pixel parity (uniform) and its first channel inside dY
+  const int fpp = FOLD ? co0 / p.fold_co : 0, fpy = fpp >> 1, fpx = fpp & 1;
+  const int co0d = FOLD ? co0 - fpp * p.fold_co : co0;
   const bool has_ss = ACT == 2 ? p.ss != nullptr : ACT == 1;
   const bool do_silu = ACT == 2 ? (has_ss && p.silu) : ACT == 1;
 
@@ -1548,7 +1607,7 @@ __global__ __launch_bounds__(256, COT == 2 ? 1 : 2) void conv_wgrad16_kernel(Wgr
     ox0 = (strip - n * p.tiles_x) * 32;
     xsrc = in0 ? static_cast<const unsigned short*>(p.src0) + ((size_t)n * p.c0 + ci0) * xplane
                : static_cast<const unsigned short*>(p.src1) + ((size_t)n * p.c1 + (ci0 - p.c0)) * xplane;
-    dsrc = static_cast<const unsigned short*>(p.dy) + ((size_t)n * p.dy_ctotal + p.dy_coff + co0) * dplane;
+    dsrc = static_cast<const unsigned short*>(p.dy) + ((size_t)n * p.dy_ctotal + p.dy_coff + co0d) * dplane;
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
       sc[j] = 1.f;
@@ -1586,8 +1645,9 @@ __global__ __launch_bounds__(256, COT == 2 ? 1 : 2) void conv_wgrad16_kernel(Wgr
     for (int u = 0; u < 2 * COT; ++u) {
       const int id = tid + 256 * u, cb = id & (DCB - 1), px = id >> DSH;
       const int y = min(2 * s + (px >> 5), p.h - 1), x = ox0 + (px & 31);
-      const uint4 q = *reinterpret_cast<const uint4*>(dsrc + (size_t)cb * 8 * dplane + ((size_t)(y >> dsh) * dw_ + (x >> dsh)) * 8);
-      const bool hole = dsh != 0 && ((y | x) & 1) != 0;   // (stride-2 conv: the odd rows / columns of the K grid carry no dY)
+      const size_t dpx = FOLD ? (size_t)(2 * y + fpy) * dw_ + (2 * x + fpx) : (size_t)(y >> dsh) * dw_ + (x >> dsh);
+      const uint4 q = *reinterpret_cast<const uint4*>(dsrc + (size_t)cb * 8 * dplane + dpx * 8);
+      const bool hole = !FOLD && dsh != 0 && ((y | x) & 1) != 0;   // (stride-2 conv: the odd rows / columns of the K grid carry no dY)
       dst[u] = hole ? make_uint4(0u, 0u, 0u, 0u) : q;
     }
   };
@@ -1723,7 +1783,8 @@ __global__ __launch_bounds__(256, COT == 2 ? 1 : 2) void conv_wgrad16_kernel(Wgr
   const int s16 = lane & 15, g16 = (lane >> 4) & 1;
   const int t_px = s16 >> 2, t_ch = g16 * 16 + (s16 & 3) * 4;
   // (the lane's pixel offset inside a k-step folded into the bases: what is left per fragment is a compile-time offset)
-  const unsigned short* a_lane = Ab + cit * (W16_SLOTS * W16_PW * 32) + t_ch + (half * 8 + t_px) * 32;
+  // (folded form: the parity's 2 x 2 corner of the window starts at column fpx / row fpy of it)
+  const unsigned short* a_lane = Ab + cit * (W16_SLOTS * W16_PW * 32) + t_ch + (half * 8 + t_px + fpx) * 32;
   const unsigned short* d_lane = Db + cot * (64 * 32) + t_ch + (half * 8 + t_px) * 32;
   auto tr4 = [](const unsigned short* q) -> wg_s4 {
     return __builtin_amdgcn_ds_read_tr16_b64_v4i16(
@@ -1759,7 +1820,7 @@ __global__ __launch_bounds__(256, COT == 2 ? 1 : 2) void conv_wgrad16_kernel(Wgr
     const unsigned short* dl = d_lane + par * W16_D_HALFS;
     const unsigned short* arow[KS + 1];  // ring rows of input rows 2s - PADK + j: one address per row and stage
 #pragma unroll
-    for (int j = 0; j <= KS; ++j) arow[j] = a_lane + ((2 * s + j) % W16_SLOTS) * (W16_PW * 32);
+    for (int j = 0; j <= KS; ++j) arow[j] = a_lane + ((2 * s + j + fpy) % W16_SLOTS) * (W16_PW * 32);
     // Fragments are fetched ONE K-STEP AHEAD, each into the registers its MFMA has just read: a tap's operand is in flight
     // for the nine MFMAs of a k-step instead of being waited for right behind its read (left to itself the compiler issued
     // most reads directly in front of their MFMA: an LDS round trip per matrix instruction).
@@ -1776,8 +1837,8 @@ __global__ __launch_bounds__(256, COT == 2 ? 1 : 2) void conv_wgrad16_kernel(Wgr
       return __builtin_bit_cast(half8, wg_s8{(short)kk, (short)tp, 2, 3, 4, 5, 6, 7});
 #endif
       const int orow = kk >> 1, colb = (kk & 1) * 16;
-      const int dy = tp / KS, dx = tp % KS;
-      const unsigned short* ap = arow[orow + dy] + (colb + dx) * 32;  // input row 2s - PADK + orow + dy
+      const int dy = FOLD ? tp >> 1 : tp / KS, dx = FOLD ? tp & 1 : tp % KS;
+      const unsigned short* ap = arow[orow + dy] + (colb + dx) * 32;  // input row 2s - PADK + orow + dy (+ fpy)
       const wg_s4 a0 = tr4(ap), a1 = tr4(ap + 4 * 32);
       return __builtin_bit_cast(half8, wg_s8{a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w});
     };
@@ -1815,8 +1876,11 @@ __global__ __launch_bounds__(256, COT == 2 ? 1 : 2) void conv_wgrad16_kernel(Wgr
             piece_p2(g - 3);
             if (((g - 3) & 3) == 3) write_rows(s + 2, (g - 3) >> 2);
           }
-        } else if (g <= 18) {
+        } else if (!FOLD && g <= 18) {
           commit_dy_u(par ^ 1, s + 1 < s1, g - 15);
+        }
+        if constexpr (FOLD) {  // (16 slots per stage instead of 36: the dY tile goes out next to the last pieces)
+          if (g >= 12) commit_dy_u(par ^ 1, s + 1 < s1, g - 12);
         }
       }
 #if defined(DSG_W16_ABL_NOMMA)   // (tools/ timing experiments only: wrong results, the loop's time without a component)
@@ -2086,6 +2150,13 @@ static void wgrad16_pw_plan(int c0, int c1, int cout, int n, int plane, int* mi,
 
 static int g_wgrad16_wide = 1;  // dsg_set_tuning key 29 (tests / A-B runs): 0 = the 64 x 64 workgroup everywhere
 void conv_wgrad16_set_wide(int v) { g_wgrad16_wide = v; }
+static int g_wgrad16_fold = 1;  // dsg_set_tuning key 39 (tests / A-B runs): 0 = Upsample2D's conv on the nine-tap kernel at full resolution
+void conv_wgrad16_set_fold(int v) { g_wgrad16_fold = v; }
+// Upsample2D's conv in the folded form (Wgrad16P.fold_co): the sampler form's shapes (wgrad16_ok) without GroupNorm in front
+static bool wgrad16_fold(const dsg_conv_wgrad_args* a) {
+  return g_wgrad16_fold && a->upsample == 1 && a->stride == 1 && a->ksize == 3 && a->c1 == 0 && a->gn_scale_shift == nullptr &&
+         a->cout % 64 == 0 && a->win % 32 == 0 && a->hin % 2 == 0;
+}
 // co tiles per wave: 2 (a 64 ci x 128 co workgroup, one per CU) for the 3x3 gradients whose cout allows it
 static int wgrad16_cot(int cout, int ksize) { return (g_wgrad16_wide && ksize == 3 && cout % 128 == 0) ? 2 : 1; }
 
@@ -2165,6 +2236,18 @@ static size_t wgrad16_ws_bytes(int cin, int cout, int ksize, int n, int hout, in
   return most;
 }
 
+// ... of the folded up-sampler form (4 taps x [cin][4 cout] per slab on x's own map)
+static size_t wgrad16_fold_ws_bytes(const dsg_conv_wgrad_args* a) {
+  size_t most = 0;
+  const int cin = a->c0 + a->c1, c4 = 4 * a->cout;
+  for (int cot = 1; cot <= (a->cout % 128 == 0 ? 2 : 1); ++cot) {
+    int strips, rsplit, spw;
+    wgrad16_runs(cin, c4, a->n, a->hin, a->win, cot, &strips, &rsplit, &spw);
+    most = std::max(most, ((size_t)(strips / spw) * rsplit * 4 * cin * c4 + (size_t)strips * rsplit * c4) * sizeof(float));
+  }
+  return most;
+}
+
 static int launch_wgrad16_pw(const dsg_conv_wgrad_args* a, int plane, hipStream_t st) {
   Wgrad16PwP p;
   p.src0 = a->src0; p.src1 = a->src1; p.c0 = a->c0; p.c1 = a->c1; p.cin = a->c0 + a->c1; p.n = a->n; p.plane = plane;
@@ -2217,20 +2300,26 @@ static int launch_wgrad16_pw(const dsg_conv_wgrad_args* a, int plane, hipStream_
 static int launch_wgrad16(const dsg_conv_wgrad_args* a, int hout, int wout, hipStream_t st) {
   if (a->ksize == 1 && g_wgrad16_pw) return launch_wgrad16_pw(a, hout * wout, st);
   Wgrad16P p;
-  const int taps = a->ksize * a->ksize;
+  const bool fold = wgrad16_fold(a);  // Upsample2D's conv: the K grid is x's own map, dY its space-to-depth image (Wgrad16P.fold_co)
+  const int taps = fold ? 4 : a->ksize * a->ksize;
   if (a->ksize == 1) {  // pointwise: rows of 32 pixels
     hout = hout * wout / 32;
     wout = 32;
   }
+  if (fold) {
+    hout = a->hin;
+    wout = a->win;
+  }
   p.src0 = a->src0; p.src1 = a->src1; p.c0 = a->c0; p.c1 = a->c1; p.cin = a->c0 + a->c1;
-  p.n = a->n; p.h = hout; p.w = wout; p.cout = a->cout;
+  p.n = a->n; p.h = hout; p.w = wout; p.cout = fold ? 4 * a->cout : a->cout; p.fold_co = fold ? a->cout : 0;
   p.dy = a->dy; p.dy_ctotal = a->dy_ctotal ? a->dy_ctotal : a->cout; p.dy_coff = a->dy_coff;
   p.ss = a->gn_scale_shift; p.silu = a->silu; p.ws = static_cast<float*>(a->workspace);
-  p.xsh = a->upsample ? 1 : 0;
+  p.xsh = (a->upsample && !fold) ? 1 : 0;
   p.dsh = a->stride == 2 ? 1 : 0;
   p.tiles_x = wout / 32; p.stages = hout / 2; p.ci_blocks = p.cin / 64;
   int strips, rsplit, spw;
-  const int cot = wgrad16_cot(p.cout, a->ksize);
+  const int cot = wgrad16_cot(a->cout, a->ksize);   // (by the conv's own cout: a folded co block stays inside one parity; 64-co
+                                                    // workgroups for every folded layer measured +0.2 % on the bf16 step)
   wgrad16_runs(p.cin, p.cout, p.n, hout, wout, cot, &strips, &rsplit, &spw);
   p.nrs = rsplit;
   p.spw = spw;
@@ -2241,7 +2330,8 @@ static int launch_wgrad16(const dsg_conv_wgrad_args* a, int hout, int wout, hipS
   p.dysum_ws = a->dy_sums ? p.ws + (size_t)nslab * taps * p.cin * p.cout : nullptr;
   int pi = -1;
   if (prof_on())
-    pi = prof_begin(29, 2.0 * p.n * (hout >> p.dsh) * (wout >> p.dsh) * (double)p.cout * p.cin * taps,   // (the reference op's FLOPs)
+    pi = prof_begin(29, fold ? 2.0 * p.n * (4.0 * hout * wout) * (double)a->cout * p.cin * 9
+                             : 2.0 * p.n * (hout >> p.dsh) * (wout >> p.dsh) * (double)p.cout * p.cin * taps,   // (the reference op's FLOPs)
                     2.0 * ((double)p.n * p.cin * (p.h >> p.xsh) * (p.w >> p.xsh) + (double)p.n * p.cout * (hout >> p.dsh) * (wout >> p.dsh)), st);
   const dim3 grid(p.ci_blocks * (p.cout / (64 * cot)), nslab);
   const bool bf = a->compute_dtype == DSG_BF16;
@@ -2259,7 +2349,16 @@ static int launch_wgrad16(const dsg_conv_wgrad_args* a, int hout, int wout, hipS
     else if (act == 1) hipLaunchKernelGGL((conv_wgrad16_kernel<PRC, 3, 1, 2>), grid, dim3(256), lds, st, p);                \
     else hipLaunchKernelGGL((conv_wgrad16_kernel<PRC, 3, 2, 2>), grid, dim3(256), lds, st, p);                              \
   } while (0)
-  if (cot == 2) {
+  if (fold) {
+    constexpr size_t lds1 = (size_t)W16Geom<3, 1>::LDS_BYTES, lds2 = (size_t)W16Geom<3, 2>::LDS_BYTES;
+    if (cot == 2) {
+      if (bf) hipLaunchKernelGGL((conv_wgrad16_kernel<1, 3, 0, 2, 1>), grid, dim3(256), lds2, st, p);
+      else hipLaunchKernelGGL((conv_wgrad16_kernel<2, 3, 0, 2, 1>), grid, dim3(256), lds2, st, p);
+    } else {
+      if (bf) hipLaunchKernelGGL((conv_wgrad16_kernel<1, 3, 0, 1, 1>), grid, dim3(256), lds1, st, p);
+      else hipLaunchKernelGGL((conv_wgrad16_kernel<2, 3, 0, 1, 1>), grid, dim3(256), lds1, st, p);
+    }
+  } else if (cot == 2) {
     if (bf) DSG_W16_LAUNCH_WIDE(1);
     else DSG_W16_LAUNCH_WIDE(2);
   } else if (a->ksize == 3) {
@@ -2274,9 +2373,16 @@ static int launch_wgrad16(const dsg_conv_wgrad_args* a, int hout, int wout, hipS
   DSG_LAUNCH_CHECK();
   const int64_t slab = (int64_t)taps * p.cin * p.cout;
   (void)slab;
-  const DysumJob job = dysum_job(a->dy_sums ? p.dysum_ws : nullptr, p.tiles_x * rsplit, p.cout, p.n, a->dy_sums,
-                                 a->dy_sums_stride ? a->dy_sums_stride : p.cout, a->dy_bias_grad);
-  launch_wgrad_reduce(p.ws, nslab, taps, p.cin, p.cout, p.cin, p.cout, a->dw, st, &job);
+  DysumJob job = dysum_job(a->dy_sums ? p.dysum_ws : nullptr, p.tiles_x * rsplit, a->cout, p.n, a->dy_sums,
+                           a->dy_sums_stride ? a->dy_sums_stride : a->cout, a->dy_bias_grad);
+  if (fold) {
+    job.parts = 4;
+    const int main_blocks = (int)cdiv64((int64_t)p.cin * a->cout, 256);
+    hipLaunchKernelGGL(wgrad_fold_reduce_kernel, dim3((unsigned)(main_blocks + job.blocks)), dim3(256), 0, st, p.ws, nslab, p.cin,
+                       a->cout, a->dw, job, main_blocks);
+  } else {
+    launch_wgrad_reduce(p.ws, nslab, taps, p.cin, p.cout, p.cin, p.cout, a->dw, st, &job);
+  }
   prof_end(pi, st);
   DSG_LAUNCH_CHECK();
   return DSG_OK;
@@ -2378,6 +2484,8 @@ DSG_API int dsg_conv2d_wgrad_workspace_bytes(const dsg_conv_wgrad_args* a, size_
     dsg::wgrad16_kgrid(a, &kh, &kw);
     DSG_CHECK_SHAPE(dsg::wgrad16_ok(a, kh, kw), "dsg_conv2d_wgrad_workspace_bytes: shape not served by the 16-bit kernel");
     *bytes = dsg::wgrad16_ws_bytes(a->c0 + a->c1, a->cout, a->ksize, a->n, kh, kw);
+    if (a->upsample == 1 && a->ksize == 3 && a->c1 == 0 && a->cout % 64 == 0 && a->win % 32 == 0 && a->hin % 2 == 0)
+      *bytes = std::max(*bytes, dsg::wgrad16_fold_ws_bytes(a));  // (either form: the tuning key may change between the query and the launch)
     return DSG_OK;
   }
   *bytes = a->force_direct ? 0 : dsg::wgrad_ws_bytes(a->c0 + a->c1, a->cout, a->ksize, a->stride, hout, wout, a->n);

@@ -687,6 +687,12 @@ int dsg_prof_dump(const char* csv_path);
  *  32  maps narrower than a 32-column tile (16 x 16, 8 x 8: the deepest levels of BASELINE configs[3]'s 512 x 512 network) also
  *      take split-K, the folded up-sampler kernel and the stride-2 space-to-depth kernel: [1] | 0 = one-slice plain kernel and
  *      the exact f32-MFMA kernels for them
+ *  37  GroupNorm-backward statistics from the data-gradient conv's epilogue (dsg_conv_args.gnb_*): [1] | 0 = dsg_conv2d_gnb_supported
+ *      answers no (the statistics pass runs) | 2 = only the 64-cout workgroups carry the epilogue
+ *  38  fp32 attention backward (head_dim 8, L % 32 == 0) as fp16x2-split products on the matrix cores: [1] | 0 = the VALU kernels
+ *  39  16-bit weight gradient of Upsample2D's conv in the folded form -- x's own map as the K grid, dY read as its space-to-depth
+ *      image, the 2 x 2 taps a pixel parity reads: 16 products per low-resolution pixel instead of 36: [1] | 0 = nine taps at full
+ *      resolution with x addressed at (y >> 1, x >> 1)
  *  31  fp32-equivalent 3x3 weight gradients with cout % 128 == 0 as 32 ci x 128 co workgroups (a wave keeps two co tiles, nine
  *      (tap, co tile) units on every wave; conv_wgrad_h2w_kernel): [1] | 0 = the 32 ci x 64 co workgroup everywhere
  *  29  16-bit 3x3 weight gradients with cout % 128 == 0 as 64 ci x 128 co workgroups (a wave keeps two co tiles, one

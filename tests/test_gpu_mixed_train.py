@@ -67,16 +67,20 @@ def test_wgrad16(case, mode):
 
 @pytest.mark.parametrize("mode", ["bf16", "fp16"])
 @pytest.mark.parametrize("case", [("upsample_wide", "ups", 128, 128, 16, 32, 3), ("upsample_64_couts", "ups", 64, 64, 8, 64, 2),
-                                  ("upsample_two_strips", "ups", 64, 256, 6, 64, 2),
+                                  ("upsample_two_strips", "ups", 64, 256, 6, 64, 2), ("upsample_batch_24", "ups", 64, 128, 8, 32, 24),
+                                  ("upsample_512_wide", "ups", 256, 512, 4, 32, 1), ("upsample_192_couts", "ups", 128, 192, 16, 32, 2),
                                   ("stride2_wide", "s2", 128, 128, 32, 64, 3), ("stride2_64_couts", "s2", 64, 64, 16, 128, 2)],
                          ids=lambda c: c[0])
 def test_wgrad16_sampler_convs_read_the_half_resolution_operand_in_place(case, mode):
     """The two sampler convs of the U-Net on the 16-bit weight-gradient kernel without a materialised copy (round 6):
-    Upsample2D's conv (train.py:39-57's up blocks: nearest x2 then 3x3) reads the LOW-resolution x at (y >> 1, x >> 1) -- the
-    tape used to write a 4x larger upsampled tensor first; Downsample2D's stride-2 conv takes dY as zero between its pixels --
-    the tape used to copy dY into a zeroed full-resolution buffer with a strided torch copy.  Against fp64 on the same rounded
-    operands, and bitwise against the old route (the same kernel on the materialised tensors: the products and their order
-    are the same)."""
+    Upsample2D's conv (train.py:39-57's up blocks: nearest x2 then 3x3) reads the LOW-resolution x -- the tape used to write a
+    4x larger upsampled tensor first; Downsample2D's stride-2 conv takes dY as zero between its pixels -- the tape used to copy
+    dY into a zeroed full-resolution buffer with a strided torch copy.  Against fp64 on the same rounded operands; the nine-tap
+    forms (x at (y >> 1, x >> 1): dsg_set_tuning key 39 = 0 for the up-sampler) bitwise against the old route (the same kernel
+    on the materialised tensors: the products and their order are the same); the up-sampler's folded form (key 39 = 1, the
+    default: x's own map as the K grid, dY as its space-to-depth image, 4 taps per pixel parity) against fp64 and the nine-tap
+    form."""
+    from drivescenegen_amd import _lib
     _, kind, cin, cout, h, w, n = case          # (h, w): x's map
     x = _rnd(_t(11, (n, cin, h, w)), mode)
     xb = ops.to_blocked(x.to(DEV), mode)
@@ -89,8 +93,22 @@ def test_wgrad16_sampler_convs_read_the_half_resolution_operand_in_place(case, m
         ref = torch.nn.grad.conv2d_weight(F.interpolate(x.double(), scale_factor=2.0, mode="nearest"), (cout, cin, 3, 3),
                                           dy.double(), padding=1)
         assert ops.wgrad16_supported(cin, 0, cout, h, w, 3, 1, True)
-        ops.conv_wgrad(xb, dyb, dw, ksize=3, upsample=True, dy_sums=sums)
+        try:
+            _lib.check(_lib.load().dsg_set_tuning(39, 0))
+            ops.conv_wgrad(xb, dyb, dw, ksize=3, upsample=True, dy_sums=sums)
+        finally:
+            _lib.load().dsg_set_tuning(39, 1)
         ops.conv_wgrad(ops.upsample_nearest2x(xb), dyb, old, ksize=3, dy_sums=sums_old)
+        # the folded form: the same sums in another order
+        fdw = torch.full((cout, cin, 3, 3), 0.5, dtype=torch.float32, device=DEV)
+        fsums = torch.full((n, cout + 2), -3.0, dtype=torch.float32, device=DEV)
+        fbias = torch.full((cout,), 0.25, dtype=torch.float32, device=DEV)
+        ops.conv_wgrad(xb, dyb, fdw, ksize=3, upsample=True, dy_sums=fsums[:, 1:], dy_sums_stride=fsums.stride(0), bias_grad=fbias)
+        assert rel_l2(fdw.cpu().double() - 0.5, ref) <= 2e-5, rel_l2(fdw.cpu().double() - 0.5, ref)
+        assert float((fdw - dw).abs().max()) <= 1e-5 * float(ref.abs().max()) + 1e-6 * float((dw - 0.5).abs().max())
+        assert torch.allclose(fsums[:, 1:cout + 1].cpu().double(), dy.double().sum((2, 3)), rtol=1e-5, atol=1e-4)
+        assert float(fsums[:, 0].min()) == -3.0 and float(fsums[:, cout + 1:].max()) == -3.0
+        assert torch.allclose(fbias.cpu().double() - 0.25, dy.double().sum((0, 2, 3)), rtol=1e-5, atol=2e-4)
     else:
         dy = _rnd(_t(12, (n, cout, h // 2, w // 2), 0.3), mode)
         dyb = ops.to_blocked(dy.to(DEV), mode)
@@ -287,6 +305,38 @@ def test_upsampler_data_gradient_routes_agree(cfg, mode, monkeypatch):
     num = sum(float((res[0][1][k] - res[1][1][k]).pow(2).sum()) for k in res[0][1])
     den = sum(float(res[1][1][k].pow(2).sum()) for k in res[0][1])
     assert (num / den) ** 0.5 <= (1e-2 if mode == "bf16" else 2e-6), (num / den) ** 0.5
+
+
+def test_folded_upsampler_weight_gradient_in_a_whole_step():
+    """dsg_set_tuning key 39 on / off on a whole bf16 training step of the tiny network (its up-sampler conv -- 64 -> 64 channels
+    on a 32 x 32 map -- takes the folded kernel): same forward, every gradient within fp32 round-off of the other form (the
+    two forms add the same bf16 products in another order)."""
+    from drivescenegen_amd import _lib
+    cfg = CFG1
+    b, ss = 2, cfg["sample_size"]
+    x0 = torch.from_numpy(synth.synth_scene_rasters(b, cfg["in_channels"], ss, ss, 5))
+    noise = torch.from_numpy(synth.normal(6, tuple(x0.shape)))
+    t = torch.tensor([12, 700])
+    res = []
+    try:
+        for fold in (1, 0):
+            _lib.check(_lib.load().dsg_set_tuning(39, fold))
+            net = synth_weights(d.UNet2DModel(**cfg)).to(DEV).train().set_compute_dtype("bf16")
+            noisy = d.DDPMScheduler().add_noise(x0.to(DEV), noise.to(DEV), t.to(DEV))
+            loss = d.mse_loss(net(noisy, t.to(DEV), return_dict=False)[0], noise.to(DEV))
+            loss.backward()
+            res.append((float(loss.detach().cpu()), {k: p.grad.detach().cpu().double() for k, p in net.named_parameters()}))
+    finally:
+        _lib.load().dsg_set_tuning(39, 1)
+    assert res[0][0] == res[1][0]
+    ups = [k for k in res[0][1] if k.endswith("upsamplers.0.conv.weight")]
+    assert ups
+    for k in res[0][1]:
+        a, b2 = res[0][1][k], res[1][1][k]
+        if k in ups or k.endswith("upsamplers.0.conv.bias"):
+            assert float((a - b2).abs().max()) <= 2e-5 * float(b2.abs().max()) + 1e-12, k
+        else:
+            assert torch.equal(a, b2), k
 
 
 def test_fp16_grad_scaler_skips_a_non_finite_step_and_recovers():
