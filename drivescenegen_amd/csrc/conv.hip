@@ -956,7 +956,7 @@ static int set_tuning_impl(int32_t key, int32_t value) {
     dsg::conv_h2_set_rows_rule(value);
     return DSG_OK;
   }
-  if (key == 37 && value >= 0 && value <= 2) {
+  if (key == 37 && value >= 0 && value <= 3) {
     dsg::conv_h2_set_gnb(value);
     return DSG_OK;
   }

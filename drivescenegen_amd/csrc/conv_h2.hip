@@ -310,6 +310,11 @@ int splitk_reduce_launch(const float* part, int slices, const dsg_conv_args* a, 
 bool conv_h16_bm128(const dsg_conv_args* a, int hout, int wout, bool* r16) {
   const int cout_pad = (a->cout + 63) / 64 * 64;
   if (!g_h2.bm128 || cout_pad % 128 != 0 || wout % H2_TW != 0) return false;
+  // GroupNorm-backward epilogue over cat(x0, x1) whose seam is not a multiple of 128 channels (the 64 + 64 concat of the outermost
+  // up block): 64-cout workgroups, two per CU.  The 128-cout tile CAN read x across the seam (the epilogue picks the tensor per
+  // 32-channel slab), but on these short-K convs its epilogue is not hidden behind anything: bf16 B=128 step 180.4 ms against
+  // 179.8 with the statistics pass, and 178.2 against 178.8 on 64-cout workgroups (profiles/r06_gnb_seam_ab.txt)
+  if (a->gnb_x0 != nullptr && a->gnb_x1 != nullptr && a->gnb_c0 % 128 != 0 && g_h2.gnb_seam64) return false;
   const int per_row = (wout / H2_TW) * a->n * (cout_pad / 128);
   *r16 = hout % 16 == 0 && per_row * (hout / 16) >= H2_CUS;
   return per_row * (hout / (*r16 ? 16 : 8)) >= H2_CUS;
@@ -338,8 +343,10 @@ bool conv_h2_gnb_ok(const dsg_conv_args* a, int hout, int wout) {
       if (g_h2.bm32 && a->c0 + a->c1 <= 128 && grid >= g_h2.bm32_min) return false;
     }
   }
-  // every channel tile inside one of the two x tensors
-  if (a->gnb_x1 != nullptr && (a->gnb_c0 <= 0 || a->gnb_c0 >= a->cout || a->gnb_c0 % bm != 0)) return false;
+  // the two x tensors meet between two 32-channel slabs of a tile (the epilogue reads x slab by slab: the 64 + 64 concat of the
+  // outermost up block under 128-cout workgroups; key 37 = 3: only between two tiles, round 6's first rule -- such calls then lose
+  // the epilogue to a statistics pass over x and dA per half, 2 x 0.5 ms per conv at batch 128)
+  if (a->gnb_x1 != nullptr && (a->gnb_c0 <= 0 || a->gnb_c0 >= a->cout || a->gnb_c0 % (g_h2.gnb_seam64 ? 32 : bm) != 0)) return false;
   return true;
 }
 
@@ -379,7 +386,7 @@ void conv_h2_set_pre(int v) { g_h2.pre = v; ++g_h2.epoch; }
 void conv_h2_set_narrow(int v) { g_h2.narrow = v; ++g_h2.epoch; }
 void conv_h2_set_splitk_mid(int v) { g_h2.splitk_mid = v; ++g_h2.epoch; }
 void conv_h2_set_rows_rule(int v) { g_h2.rows_rule = v; ++g_h2.epoch; }
-void conv_h2_set_gnb(int v) { g_h2.gnb = v; ++g_h2.epoch; }
+void conv_h2_set_gnb(int v) { g_h2.gnb = v == 3 ? 1 : v; g_h2.gnb_seam64 = v != 3; ++g_h2.epoch; }
 void conv_h2_set_pre_min_ct(int v) { g_h2.pre_min_ct = v > 0 ? v : 1; ++g_h2.epoch; }
 int conv_h2_get_fuse_sc() { return g_h2.fuse_sc; }
 int conv_in_tuning_epoch();  // conv_in.hip: its on/off switch moves the plan's statistics buffers too

@@ -1090,13 +1090,23 @@ __global__ __launch_bounds__(64 * NW, OCC * NW / 4) void conv_h2_kernel(ConvH2P 
   const __amdgpu_buffer_rsrc_t dst_rs = __builtin_amdgcn_make_buffer_rsrc(dstb + tile_off, 0, range, 0x00020000);
   const char* res_base = static_cast<const char*>(p.res);
   size_t res_off = tile_off;
+  int gnb_seam = BM;  // GNB: the tile's first channel that lives in gnb_x1 (relative to m0; a multiple of 32: the host's rule)
   if constexpr (GNB) {  // this channel tile's rows of x: in gnb_x0 (gnb_c0 channels per image) or gnb_x1 (the rest)
     const bool in0 = m0 < p.gnb_c0;
     res_base = static_cast<const char*>(in0 ? p.gnb_x0 : p.gnb_x1);
     res_off = ((size_t)n * (in0 ? p.gnb_c0 : p.cout - p.gnb_c0) + (in0 ? m0 : m0 - p.gnb_c0)) * oplane * ESD;
+    if (in0 && p.gnb_x1 != nullptr && p.gnb_c0 < m0 + BM) gnb_seam = p.gnb_c0 - m0;  // the two tensors meet inside this tile
   }
-  const __amdgpu_buffer_rsrc_t res_rs = __builtin_amdgcn_make_buffer_rsrc(
+  const __amdgpu_buffer_rsrc_t res_rs0 = __builtin_amdgcn_make_buffer_rsrc(
       has_r ? const_cast<char*>(res_base) + res_off : dstb, 0, has_r ? range : 0, 0x00020000);
+  // ... and the 32-channel slabs from the seam on: gnb_x1, based so that the tile-relative channel offsets below still apply
+  // (the base lies gnb_seam planes in front of the image's first x1 channel; nothing below the seam is read through it)
+  const __amdgpu_buffer_rsrc_t res_rs1 =
+      (GNB && gnb_seam < BM)
+          ? __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(static_cast<const char*>(p.gnb_x1)) +
+                                                  ((ptrdiff_t)n * (p.cout - p.gnb_c0) - gnb_seam) * (ptrdiff_t)oplane * ESD,
+                                              0, range, 0x00020000)
+          : res_rs0;
   const __amdgpu_buffer_rsrc_t gss_rs = __builtin_amdgcn_make_buffer_rsrc(
       GNB ? const_cast<float*>(p.gnb_ss + ((size_t)n * p.cout + m0) * 2) : reinterpret_cast<float*>(dstb), 0,
       GNB ? nvalid * 8 : 0, 0x00020000);
@@ -1165,6 +1175,7 @@ __global__ __launch_bounds__(64 * NW, OCC * NW / 4) void conv_h2_kernel(ConvH2P 
           gsh[r] = __builtin_bit_cast(float, q1);
         }
       }
+      const __amdgpu_buffer_rsrc_t res_rs = (GNB && mt * 32 >= gnb_seam) ? res_rs1 : res_rs0;  // (uniform)
       if (has_r) {
         if constexpr (DB) {
 #pragma unroll

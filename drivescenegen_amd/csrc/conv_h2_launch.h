@@ -36,6 +36,7 @@ struct H2Tuning {
                         // levels -- the convs gain 8.5 % and the prepare passes cost what they gain; at 16 only the folded up-samplers of
                         // those levels qualify, whose patch is staged by 16-32 workgroups)
   int gnb = 1;          // GroupNorm-backward statistics from the data-gradient conv's epilogue (key 37: A/B against the statistics pass)
+  int gnb_seam64 = 1;   // ... also where the two x tensors meet inside a channel tile, at a multiple of 32 channels (key 37 = 3: off)
   int rows_rule = 1;    // round 5's additions to the rows rule: 16-row tiles under three-slice split-K, 0.62 for the four-tap kernels (key 36)
   int epoch = 0;        // bumped by every change: plans key their cached workspace sizes on it
 };

@@ -322,6 +322,9 @@ class UNet2DModel(nn.Module):
                                "and inputs to 'cuda' (there is no CPU fallback)")
         if sample.dtype != torch.float32:
             raise RuntimeError(f"UNet2DModel: input dtype {sample.dtype} not supported (fp32 engine)")
+        # (both paths hand raw pointers to kernels that index by the configured channel count: a wrong shape must stop here)
+        if sample.dim() != 4 or sample.shape[1] != self.config.in_channels:
+            raise ValueError(f"expected a [N, {self.config.in_channels}, H, W] sample, got {tuple(sample.shape)}")
         if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
             from .autograd import unet_forward_train
             out = unet_forward_train(self, sample, timestep)

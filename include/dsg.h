@@ -204,7 +204,7 @@ int dsg_conv2d_takes_operand(const dsg_conv_args* a, int32_t* yes);
 /* *yes = 1 when a call with these arguments (gnb_* filled in, stats_out not needed yet) is served by a kernel with the
  * GroupNorm-backward epilogue: a stride-1 3x3 conv without a norm in front, fused shortcut, operand image or split-K;
  * 16-bit modes: every tensor channel-blocked; fp32 mode: every tensor [N, C, H, W]; maps a multiple of 32 columns wide; and
- * every channel tile of the kernel the call selects inside ONE of gnb_x0 / gnb_x1.  Host-only. */
+ * gnb_c0 a multiple of 32 (the epilogue reads x in 32-channel slabs: gnb_x0 and gnb_x1 may meet inside a channel tile).  Host-only. */
 int dsg_conv2d_gnb_supported(const dsg_conv_args* a, int32_t* yes);
 /* Operand image of cat(src0, src1) (channel-blocked fp32 [N, c/8, hin, win, 8]) for dsg_conv_args.src_operand:
  * [piece 2][N][(c0+c1)/8][hin+2][win+2][8] fp16 -- piece 0 = fp16(v), piece 1 = fp16((v - piece 0) * 2^11) of
@@ -688,7 +688,8 @@ int dsg_prof_dump(const char* csv_path);
  *      take split-K, the folded up-sampler kernel and the stride-2 space-to-depth kernel: [1] | 0 = one-slice plain kernel and
  *      the exact f32-MFMA kernels for them
  *  37  GroupNorm-backward statistics from the data-gradient conv's epilogue (dsg_conv_args.gnb_*): [1] | 0 = dsg_conv2d_gnb_supported
- *      answers no (the statistics pass runs) | 2 = only the 64-cout workgroups carry the epilogue
+ *      answers no (the statistics pass runs) | 2 = only the 64-cout workgroups carry the epilogue | 3 = as 1, but a call whose two
+ *      x tensors meet INSIDE a channel tile (at a multiple of 32 channels) loses the epilogue (round 6's first rule)
  *  38  fp32 attention backward (head_dim 8, L % 32 == 0) as fp16x2-split products on the matrix cores: [1] | 0 = the VALU kernels
  *  39  16-bit weight gradient of Upsample2D's conv in the folded form -- x's own map as the K grid, dY read as its space-to-depth
  *      image, the 2 x 2 taps a pixel parity reads: 16 products per low-resolution pixel instead of 36: [1] | 0 = nine taps at full

@@ -147,13 +147,23 @@ def test_shapes_without_the_form_say_so_and_the_switch_turns_it_off():
         return ops.conv2d_fused(dyb, None, gnb=dict(gnb, query_only=True), **kw), (dyb, gnb, kw)
     assert ask(8, 64, 128, 0, 64, 64)[0]
     assert not ask(1, 64, 64, 0, 32, 32)[0]            # a grid of at most half the chip: the 32-cout workgroups have no GNB form
-    yes, (dyb, gnb, kw) = ask(8, 64, 192, 64, 64, 64)   # cat(192, 64): 128-cout tiles straddle the two x tensors
-    assert not yes
-    assert not ask(16, 32, 64, 32, 64, 64)[0]          # configs[0]'s up blocks, cat(64, 32): 96 couts pad to ONE 128-cout tile
-    with pytest.raises(RuntimeError, match="GroupNorm-backward epilogue"):
-        ops.conv2d_fused(dyb, None, gnb=gnb, want_stats=True, **kw)
-    assert not ask(8, 64, 128, 0, 64, 48)[0]           # not a multiple of 32 columns
+    # cat(192, 64) / configs[0]'s cat(64, 32) / cat(96, 32): the x tensors do not meet at a multiple of 128 channels -- such calls
+    # run on 64-cout workgroups, and where the seam falls inside one of those (96 | 32) the epilogue reads x slab by slab (32
+    # channels) from the tensor that holds it (values: test_query_and_dispatch_agree_over_a_shape_sweep); key 37 = 3 refuses
+    # them, as round 6's first rule did
+    assert ask(8, 64, 192, 64, 64, 64)[0] and ask(16, 32, 64, 32, 64, 64)[0] and ask(8, 64, 96, 32, 64, 64)[0]
     lib = _lib.load()
+    try:
+        _lib.check(lib.dsg_set_tuning(37, 3))
+        yes, (dyb, gnb, kw) = ask(8, 64, 192, 64, 64, 64)
+        assert not yes and not ask(8, 64, 96, 32, 64, 64)[0]
+        with pytest.raises(RuntimeError, match="GroupNorm-backward epilogue"):
+            ops.conv2d_fused(dyb, None, gnb=gnb, want_stats=True, **kw)
+        assert ask(8, 64, 128, 0, 64, 64)[0]
+    finally:
+        lib.dsg_set_tuning(37, 1)
+    assert not ask(8, 64, 112, 16, 64, 64)[0]          # cat(112, 16): the seam is inside a 32-channel slab
+    assert not ask(8, 64, 128, 0, 64, 48)[0]           # not a multiple of 32 columns
     try:
         _lib.check(lib.dsg_set_tuning(37, 0))
         assert not ask(8, 64, 128, 0, 64, 64)[0]
@@ -216,7 +226,9 @@ def test_query_and_dispatch_agree_over_a_shape_sweep():
         for (n, cdy, c0, c1, h, w) in [(1, 64, 64, 0, 32, 32), (2, 64, 64, 0, 64, 64), (4, 64, 64, 0, 64, 64), (16, 64, 64, 0, 64, 64),
                                        (2, 128, 128, 0, 32, 64), (8, 128, 128, 0, 32, 32), (32, 128, 128, 0, 32, 32), (3, 64, 192, 0, 64, 32),
                                        (8, 64, 64, 64, 64, 64), (8, 64, 128, 128, 32, 32), (2, 64, 256, 128, 32, 32), (8, 64, 320, 0, 32, 32),
-                                       (5, 32, 96, 0, 64, 64), (1, 256, 512, 0, 32, 32), (9, 64, 64, 0, 8, 32)]:
+                                       (5, 32, 96, 0, 64, 64), (1, 256, 512, 0, 32, 32), (9, 64, 64, 0, 8, 32),
+                                       (8, 64, 192, 64, 64, 64), (16, 32, 64, 32, 64, 64), (8, 64, 96, 32, 64, 64),
+                                       (32, 64, 64, 64, 64, 64), (8, 64, 112, 16, 64, 64), (4, 64, 32, 96, 64, 64)]:
             x, dy, wt, gamma, beta = _case(n, cdy, c0, c1, h, w, True, 11 * n + c0 + h)
             c = c0 + c1
             if blocked:

@@ -277,6 +277,25 @@ def test_param_update_is_picked_up(tiny):
         net.conv_out.bias.sub_(1.0)
 
 
+@pytest.mark.parametrize("mode", ["eval", "train_fp32", "train_bf16"])
+def test_wrong_channel_count_is_refused_before_any_kernel(mode):
+    """A sample whose channel count is not config.in_channels raises in forward() -- inference plan and both training tapes --
+    instead of handing the conv_in kernel a tensor it indexes past the end of (diffusers' UNet2DModel fails in F.conv2d with a
+    shape error; a probe script that passed 4 channels to the 8-channel network ended in a GPU memory fault before this check)."""
+    net = synth_weights(d.UNet2DModel(**CFG1)).to(DEV)
+    if mode == "eval":
+        net.eval().requires_grad_(False)
+    else:
+        net.train().set_compute_dtype("fp32" if mode == "train_fp32" else "bf16")
+    bad = torch.zeros(2, CFG1["in_channels"] + 1, CFG1["sample_size"], CFG1["sample_size"], device=DEV)
+    with pytest.raises(ValueError):
+        net(bad, 5)
+    with pytest.raises(ValueError):
+        net(bad[:, :1], 5)
+    with pytest.raises(ValueError):
+        net(bad[0, :CFG1["in_channels"]], 5)
+
+
 def test_batch_invariant_flag_and_tuning_gate():
     """dsg_unet_config.flags / DSG_UNET_BATCH_INVARIANT (UNet2DModel.batch_invariant): per-plan, no process-global state --
     row i of a batch is bitwise the batch-1 call; the default plan (split-K on small grids) agrees to fp32 round-off.
