@@ -320,8 +320,12 @@ def _forward(model, st: TrainState, tape: _Tape, sample, timesteps):
         # Range guard of the split path: a conv WITHOUT a norm in front (shortcut, up- / down-sampler) reads the
         # residual stream as it is; where the producing conv left statistics, their per-image bound goes along
         # (dsg_conv_args.src_bound: exact power-of-two pre-scaling outside [2^-6, 2^12], a no-op inside)
+        # (down-sampler convs: the 2x2 conv over the space-to-depth image, as the inference plan's -- [N,C,H,W] tensors here)
+        s2p = st.pack32(wname + ".weight", ops.PACK_S2) if (stride == 2 and k == 3 and x1 is None and gn is None and not _R5_ROUTES
+                                                             and x0.shape[1] % 8 == 0 and cout % 8 == 0 and x0.shape[2] % 16 == 0
+                                                             and (x0.shape[3] % 64 == 0 or x0.shape[3] in (16, 32))) else None
         b0 = b1 = None
-        if gn is None and (wh is not None or fold is not None):
+        if gn is None and (wh is not None or fold is not None or s2p is not None):
             b0 = bound_of(x0)
             b1 = bound_of(x1) if (x1 is not None and b0 is not None) else None
             if x1 is not None and b1 is None:
@@ -330,7 +334,7 @@ def _forward(model, st: TrainState, tape: _Tape, sample, timesteps):
         y = st.lazy_w(wname + ".weight", "wf", lambda wf: ops.conv2d_fused(
             x0, wf, bias, src1=x1, ksize=k, stride=stride, upsample=ups, gn_scale_shift=ss, silu=silu,
             temb=None if toff is None else tproj[:, toff:], temb_stride=tproj.stride(0), residual=res, cout=cout,
-            weight_h2=wh, weight_h2_fold=fold, want_stats=feeds_norm, src_bound=b0, src_bound1=b1))
+            weight_h2=wh, weight_h2_fold=fold, weight_h2_s2=s2p, want_stats=feeds_norm, src_bound=b0, src_bound1=b1))
         if feeds_norm:
             y, ystats = y
             if ystats is not None:

@@ -22,9 +22,9 @@ bool conv_h2_fold(const dsg_conv_args* a) {
 
 // stride-2 3x3 conv as a 2x2 conv over the space-to-depth image (GM = 3): channel-blocked tensors only
 bool conv_h2_s2(const dsg_conv_args* a, int hout, int wout) {
-  // (the up-sampler's data gradient, s2_window4, also on fp32 [N,C,H,W] tensors: the fp32 tape's layout)
+  // (also on fp32 [N,C,H,W] tensors, the fp32 tape's layout: its down-sampler convs and its up-samplers' data gradient, s2_window4)
   const bool lay_ok = (a->src_layout == 1 && a->dst_layout == 1) ||
-                      (a->s2_window4 && a->src_layout == 0 && a->dst_layout == 0 && a->compute_dtype == DSG_F32);
+                      (a->src_layout == 0 && a->dst_layout == 0 && a->compute_dtype == DSG_F32 && (a->s2_window4 || g_h2.s2_nchw));
   return g_h2.enabled && g_h2.s2 && a->weight_h2_s2 != nullptr && a->stride == 2 && a->ksize == 3 && !a->upsample &&
          !a->pool2 && !a->gn_scale_shift && lay_ok && a->c1 == 0 && a->c0 % 8 == 0 &&
          a->cout % 8 == 0 && a->hin % 2 == 0 && a->win % 2 == 0 && hout % 8 == 0 &&
@@ -386,6 +386,7 @@ void conv_h2_set_pre(int v) { g_h2.pre = v; ++g_h2.epoch; }
 void conv_h2_set_narrow(int v) { g_h2.narrow = v; ++g_h2.epoch; }
 void conv_h2_set_splitk_mid(int v) { g_h2.splitk_mid = v; ++g_h2.epoch; }
 void conv_h2_set_rows_rule(int v) { g_h2.rows_rule = v; ++g_h2.epoch; }
+void conv_h2_set_s2_nchw(int v) { g_h2.s2_nchw = v; ++g_h2.epoch; }
 void conv_h2_set_gnb(int v) { g_h2.gnb = v == 3 ? 1 : v; g_h2.gnb_seam64 = v != 3; ++g_h2.epoch; }
 void conv_h2_set_pre_min_ct(int v) { g_h2.pre_min_ct = v > 0 ? v : 1; ++g_h2.epoch; }
 int conv_h2_get_fuse_sc() { return g_h2.fuse_sc; }

@@ -36,6 +36,7 @@ struct H2Tuning {
                         // levels -- the convs gain 8.5 % and the prepare passes cost what they gain; at 16 only the folded up-samplers of
                         // those levels qualify, whose patch is staged by 16-32 workgroups)
   int gnb = 1;          // GroupNorm-backward statistics from the data-gradient conv's epilogue (key 37: A/B against the statistics pass)
+  int s2_nchw = 1;      // stride-2 convs of fp32 [N,C,H,W] tensors on the space-to-depth kernel too (key 40: A/B against the exact f32 kernel)
   int gnb_seam64 = 1;   // ... also where the two x tensors meet inside a channel tile, at a multiple of 32 channels (key 37 = 3: off)
   int rows_rule = 1;    // round 5's additions to the rows rule: 16-row tiles under three-slice split-K, 0.62 for the four-tap kernels (key 36)
   int epoch = 0;        // bumped by every change: plans key their cached workspace sizes on it
@@ -236,7 +237,11 @@ int conv_h2_launch_t(const dsg_conv_args* a, int hout, int wout, hipStream_t st)
       else rc = h2_launch<4, 2, 3, 0>(grid, lds, st, p);
     }
   } else if (s2) {
-    DSG_H2_LAUNCH_BLK(3, 3, 0, 3);
+    if (lay) DSG_H2_LAUNCH_BLK(3, 3, 0, 3);
+    else if constexpr (PREC == 0) {
+      if (nt4) rc = h2_launch<3, 4, 3, 0>(grid, lds, st, p);
+      else rc = h2_launch<3, 2, 3, 0>(grid, lds, st, p);
+    }
   } else if (fold) {
     if (lay) DSG_H2_LAUNCH_BLK(2, 3, 0, 3);
     else if constexpr (PREC == 0) {

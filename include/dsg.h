@@ -102,7 +102,7 @@ typedef struct {
                                    on the load side, tools/membench.hip).  dsg_unet_forward keeps its intermediate
                                    activations in this layout; the public tensors stay [N, C, H, W]. */
   int32_t dst_layout;           /* the same for dst and residual */
-  const void* weight_h2_s2;     /* optional, stride == 2 with channel-blocked src and dst only: the 3x3 weights laid out for
+  const void* weight_h2_s2;     /* optional, stride == 2 with both src and dst channel-blocked, or (fp32) both [N, C, H, W]: the 3x3 weights laid out for
                                    the 2x2 conv over the space-to-depth image (dsg_conv_weight_relayout_h2_s2); the
                                    down-sampler conv then runs on the split path too */
   int32_t compute_dtype;        /* dsg_dtype.  DSG_F32 (0): everything above as described.  DSG_BF16 / DSG_F16: the
@@ -694,6 +694,8 @@ int dsg_prof_dump(const char* csv_path);
  *  39  16-bit weight gradient of Upsample2D's conv in the folded form -- x's own map as the K grid, dY read as its space-to-depth
  *      image, the 2 x 2 taps a pixel parity reads: 16 products per low-resolution pixel instead of 36: [1] | 0 = nine taps at full
  *      resolution with x addressed at (y >> 1, x >> 1)
+ *  40  stride-2 3x3 convs of fp32 [N,C,H,W] tensors (weight_h2_s2 given: the fp32 training tape's down-samplers) on the
+ *      space-to-depth kernel, as the channel-blocked ones: [1] | 0 = the exact f32 MFMA kernel
  *  31  fp32-equivalent 3x3 weight gradients with cout % 128 == 0 as 32 ci x 128 co workgroups (a wave keeps two co tiles, nine
  *      (tap, co tile) units on every wave; conv_wgrad_h2w_kernel): [1] | 0 = the 32 ci x 64 co workgroup everywhere
  *  29  16-bit 3x3 weight gradients with cout % 128 == 0 as 64 ci x 128 co workgroups (a wave keeps two co tiles, one

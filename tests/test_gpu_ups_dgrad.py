@@ -126,3 +126,43 @@ def test_window4_refused_where_the_kernel_does_not_serve():
     x = torch.zeros(1, 64, 16, 64, device=DEV)   # [N,C,H,W] tensors with a 16-bit compute type: refused as well
     with pytest.raises(_lib.DsgError):
         ops.conv2d_fused(x, None, ksize=3, stride=2, cout=64, weight_h2_s2=pk, s2_window4=True, compute_dtype="bf16")
+
+
+S2_CASES = [("tile32_16rows", 64, 64, 32, 64, 2), ("cin128_cout64_big", 128, 64, 64, 64, 16), ("narrow_16", 64, 128, 32, 32, 2),
+            ("narrow_8", 32, 64, 16, 16, 3), ("cout_not_64", 24, 40, 16, 64, 1)]
+
+
+@pytest.mark.parametrize("scale", [1.0, 3.0e5], ids=["unit", "range_guard"])
+@pytest.mark.parametrize("case", S2_CASES, ids=[c[0] for c in S2_CASES])
+def test_stride2_conv_fp32_nchw_on_the_space_to_depth_kernel(case, scale):
+    """Downsample2D's conv (3x3, stride 2, padding 1; diffusers Downsample2D inside the down blocks of
+    DriveSceneGen/utils/model/unet_2d.py's network) on fp32 [N,C,H,W] tensors -- the fp32 training tape's layout -- through the
+    2x2-tap kernel over the space-to-depth image (dsg_set_tuning key 40; the channel-blocked form has served the inference plan
+    since round 2): against F.conv2d in fp64, against the exact f32 kernel it replaces, statistics and range guard included
+    (scale 3e5: the source is outside fp16's range and goes through the per-image power-of-two pre-scaling)."""
+    from drivescenegen_amd import _lib
+    name, cin, cout, h, w, n = case
+    x = _t(11, (n, cin, h, w), scale)
+    wt = _t(12, (cout, cin, 3, 3), 1.0 / np.sqrt(9 * cin))
+    bias = _t(13, (cout,), 0.1)
+    res = _t(14, (n, cout, h // 2, w // 2), scale)
+    ref = F.conv2d(x.double(), wt.double(), bias.double(), stride=2, padding=1) + res.double()
+    xd = x.to(DEV)
+    bound = ops.range_bound_from_stats(ops.gn_channel_stats_blocked(ops.to_blocked(xd, "fp32")))
+    kw = dict(ksize=3, stride=2, cout=cout, residual=res.to(DEV), weight_h2_s2=ops.pack_conv_weight(wt.to(DEV), ops.PACK_S2, "fp32"),
+              want_stats=True, src_bound=bound)
+    got, stats = ops.conv2d_fused(xd, None, bias.to(DEV), **kw)
+    assert got.shape == (n, cout, h // 2, w // 2)
+    assert rel_l2(got.cpu(), ref) <= 2e-6, rel_l2(got.cpu(), ref)
+    assert stats is not None
+    s_got = stats.cpu().sum(2)
+    assert torch.allclose(s_got[..., 0], ref.sum((2, 3)), rtol=1e-5, atol=1e-4 * scale * scale)
+    assert torch.allclose(s_got[..., 1], ref.pow(2).sum((2, 3)), rtol=1e-5)
+    try:   # the exact kernel (needs the fp32 engine layout; no statistics from it)
+        _lib.check(_lib.load().dsg_set_tuning(40, 0))
+        with pytest.raises(RuntimeError):
+            ops.conv2d_fused(xd, None, bias.to(DEV), **kw)
+        old = ops.conv2d_fused(xd, ops.relayout_conv_weight(wt.to(DEV)), bias.to(DEV), ksize=3, stride=2, cout=cout, residual=res.to(DEV))
+    finally:
+        _lib.load().dsg_set_tuning(40, 1)
+    assert rel_l2(got.cpu(), old.cpu()) <= 3e-6
