@@ -202,7 +202,7 @@ def get_train_state(model) -> TrainState:
 # fused q/k/v projection on the exact f32 kernel, conv_in / conv_out weight gradients unpadded, residual + skip gradients summed by a
 # pass of their own -- next to DSG_TUNING="37=0,38=0" for the two kernel-level changes.
 _R5_ROUTES = os.environ.get("DSG_F32_TAPE_R5") == "1"
-# ... and DSG_UPS_DGRAD_FULLRES=1 keeps the 16-bit tape's up-sampler data gradient on the full-resolution 3x3 conv + 2x2 sums
+# ... and DSG_UPS_DGRAD_FULLRES=1 keeps both tapes' up-sampler data gradient on the full-resolution 3x3 conv + 2x2 sums
 _UPS_DGRAD_FULLRES = os.environ.get("DSG_UPS_DGRAD_FULLRES") == "1"
 
 
@@ -317,13 +317,13 @@ def _forward(model, st: TrainState, tape: _Tape, sample, timesteps):
         # (up-sampler convs: the folded 2x2 phase kernels of the inference plan instead of the nearest-x2 gather)
         fold = st.pack32(wname + ".weight", ops.PACK_FOLD) if (ups and k == 3 and x1 is None and gn is None
                                                                  and x0.shape[1] % 16 == 0 and cout % 64 == 0) else None
-        # Range guard of the split path (ADVICE r02): a conv WITHOUT a norm in front (shortcut, up- / down-sampler) reads the
-        # residual stream as it is; where the producing conv left statistics, their per-image bound goes along
-        # (dsg_conv_args.src_bound: exact power-of-two pre-scaling outside [2^-6, 2^12], a no-op inside)
         # (down-sampler convs: the 2x2 conv over the space-to-depth image, as the inference plan's -- [N,C,H,W] tensors here)
         s2p = st.pack32(wname + ".weight", ops.PACK_S2) if (stride == 2 and k == 3 and x1 is None and gn is None and not _R5_ROUTES
                                                              and x0.shape[1] % 8 == 0 and cout % 8 == 0 and x0.shape[2] % 16 == 0
                                                              and (x0.shape[3] % 64 == 0 or x0.shape[3] in (16, 32))) else None
+        # Range guard of the split path (ADVICE r02): a conv WITHOUT a norm in front (shortcut, up- / down-sampler) reads the
+        # residual stream as it is; where the producing conv left statistics, their per-image bound goes along
+        # (dsg_conv_args.src_bound: exact power-of-two pre-scaling outside [2^-6, 2^12], a no-op inside)
         b0 = b1 = None
         if gn is None and (wh is not None or fold is not None or s2p is not None):
             b0 = bound_of(x0)

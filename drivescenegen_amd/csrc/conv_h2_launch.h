@@ -194,7 +194,9 @@ int conv_h2_launch_t(const dsg_conv_args* a, int hout, int wout, hipStream_t st)
     const double cin_ref = a->c0 + a->c1;  // (stride 2: the kernel's 4 C x 4 taps are the reference op's C x 9)
     const double sc_cin = sc ? p.sc_cin : 0;  // fused shortcut: its 1x1 FLOPs, source and weight bytes count too
     const double es = (PREC && (lay & 1)) ? 2.0 : 4.0, ed = (PREC && (lay & 2)) ? 2.0 : 4.0, ew = PREC ? 2.0 : 4.0;
-    pi = prof_begin((PREC ? 20 : 0) + (s2 ? 2 : (a->ksize == 1 ? 8 : (a->upsample ? 7 : (sc ? (ws2 ? 14 : 13) : (ws2 ? 10 : 6))))), 2.0 * px * p.cout * (cin_ref * taps + sc_cin),
+    // (the up-sampler's data gradient, s2_window4: the reference op is a 3x3 conv over the FULL-resolution map, 4 px output pixels' worth)
+    pi = prof_begin((PREC ? 20 : 0) + (s2 ? 2 : (a->ksize == 1 ? 8 : (a->upsample ? 7 : (sc ? (ws2 ? 14 : 13) : (ws2 ? 10 : 6))))),
+                    2.0 * px * (a->s2_window4 ? 4.0 : 1.0) * p.cout * (cin_ref * taps + sc_cin),
                     es * (double)p.n * (cin_ref + sc_cin) * p.hin * p.win + ew * (cin_ref * taps + sc_cin) * p.cout +
                         ed * px * p.cout * (p.res ? 2.0 : 1.0), st);
   }
