@@ -484,6 +484,7 @@ void conv_h2_set_splitk_mid(int v);
 void conv_h2_set_rows_rule(int v);
 void conv_h2_set_gnb(int v);
 void conv_h2_set_s2_nchw(int v);
+void conv_h2_set_gnb_bm64(int v);
 void attention_set_bwd_split(int v);
 bool conv_h2_gnb_ok(const dsg_conv_args* a, int hout, int wout);
 void conv_h2_set_pre_min_ct(int v);
@@ -963,6 +964,10 @@ static int set_tuning_impl(int32_t key, int32_t value) {
   }
   if (key == 38 && (value == 0 || value == 1)) {
     dsg::attention_set_bwd_split(value);
+    return DSG_OK;
+  }
+  if (key == 41 && (value == 0 || value == 1)) {
+    dsg::conv_h2_set_gnb_bm64(value);
     return DSG_OK;
   }
   if (key == 40 && (value == 0 || value == 1)) {

@@ -315,6 +315,10 @@ bool conv_h16_bm128(const dsg_conv_args* a, int hout, int wout, bool* r16) {
   // 32-channel slab), but on these short-K convs its epilogue is not hidden behind anything: bf16 B=128 step 180.4 ms against
   // 179.8 with the statistics pass, and 178.2 against 178.8 on 64-cout workgroups (profiles/r06_gnb_seam_ab.txt)
   if (a->gnb_x0 != nullptr && a->gnb_x1 != nullptr && a->gnb_c0 % 128 != 0 && g_h2.gnb_seam64) return false;
+  // ... and so do ALL calls with the epilogue (key 41): one 128-cout workgroup per CU runs its VALU-bound epilogue with nothing beside
+  // it, two 64-cout workgroups run it under each other's K loops -- bf16 B=128 step 175.7-175.9 ms against 177.3-177.5 with the
+  // 128-cout workgroups (only the convs with at most 128 / 256 dY channels: 176.4-176.6 / 175.8-176.5; profiles/r06_gnb_bm64_ab.txt)
+  if (a->gnb_x0 != nullptr && g_h2.gnb_bm64) return false;
   const int per_row = (wout / H2_TW) * a->n * (cout_pad / 128);
   *r16 = hout % 16 == 0 && per_row * (hout / 16) >= H2_CUS;
   return per_row * (hout / (*r16 ? 16 : 8)) >= H2_CUS;
@@ -386,6 +390,7 @@ void conv_h2_set_pre(int v) { g_h2.pre = v; ++g_h2.epoch; }
 void conv_h2_set_narrow(int v) { g_h2.narrow = v; ++g_h2.epoch; }
 void conv_h2_set_splitk_mid(int v) { g_h2.splitk_mid = v; ++g_h2.epoch; }
 void conv_h2_set_rows_rule(int v) { g_h2.rows_rule = v; ++g_h2.epoch; }
+void conv_h2_set_gnb_bm64(int v) { g_h2.gnb_bm64 = v; ++g_h2.epoch; }
 void conv_h2_set_s2_nchw(int v) { g_h2.s2_nchw = v; ++g_h2.epoch; }
 void conv_h2_set_gnb(int v) { g_h2.gnb = v == 3 ? 1 : v; g_h2.gnb_seam64 = v != 3; ++g_h2.epoch; }
 void conv_h2_set_pre_min_ct(int v) { g_h2.pre_min_ct = v > 0 ? v : 1; ++g_h2.epoch; }

@@ -37,6 +37,7 @@ struct H2Tuning {
                         // those levels qualify, whose patch is staged by 16-32 workgroups)
   int gnb = 1;          // GroupNorm-backward statistics from the data-gradient conv's epilogue (key 37: A/B against the statistics pass)
   int s2_nchw = 1;      // stride-2 convs of fp32 [N,C,H,W] tensors on the space-to-depth kernel too (key 40: A/B against the exact f32 kernel)
+  int gnb_bm64 = 1;     // 16-bit data-gradient convs with the GNB epilogue on 64-cout workgroups, two per CU (key 41: 0 = 128-cout ones where the plain conv takes them)
   int gnb_seam64 = 1;   // ... also where the two x tensors meet inside a channel tile, at a multiple of 32 channels (key 37 = 3: off)
   int rows_rule = 1;    // round 5's additions to the rows rule: 16-row tiles under three-slice split-K, 0.62 for the four-tap kernels (key 36)
   int epoch = 0;        // bumped by every change: plans key their cached workspace sizes on it

@@ -694,6 +694,8 @@ int dsg_prof_dump(const char* csv_path);
  *  39  16-bit weight gradient of Upsample2D's conv in the folded form -- x's own map as the K grid, dY read as its space-to-depth
  *      image, the 2 x 2 taps a pixel parity reads: 16 products per low-resolution pixel instead of 36: [1] | 0 = nine taps at full
  *      resolution with x addressed at (y >> 1, x >> 1)
+ *  41  16-bit data-gradient convs with the GroupNorm-backward epilogue (gnb_*) on 64-cout workgroups, two per CU, whatever the
+ *      plain conv would take: [1] | 0 = 128-cout workgroups where cout % 128 == 0 and the grid fills the chip (round 6's first form)
  *  40  stride-2 3x3 convs of fp32 [N,C,H,W] tensors (weight_h2_s2 given: the fp32 training tape's down-samplers) on the
  *      space-to-depth kernel, as the channel-blocked ones: [1] | 0 = the exact f32 MFMA kernel
  *  31  fp32-equivalent 3x3 weight gradients with cout % 128 == 0 as 32 ci x 128 co workgroups (a wave keeps two co tiles, nine

@@ -67,8 +67,18 @@ CASES = [
 ]
 
 
+@pytest.fixture(params=[1, 0], ids=["gnb_on_64_cout_workgroups", "gnb_on_128_cout_workgroups"])
+def gnb_workgroups(request):
+    """dsg_set_tuning key 41: the 16-bit GNB data gradients run on 64-cout workgroups by default; 0 lets them take the 128-cout
+    ones the case names describe (both instantiations stay covered)"""
+    lib = _lib.load()
+    _lib.check(lib.dsg_set_tuning(41, request.param))
+    yield request.param
+    lib.dsg_set_tuning(41, 1)
+
+
 @pytest.mark.parametrize("case", CASES, ids=[c[0] for c in CASES])
-def test_epilogue_statistics_equal_the_statistics_pass(case):
+def test_epilogue_statistics_equal_the_statistics_pass(case, gnb_workgroups):
     name, n, cdy, c0, c1, h, w, silu, dtn = case
     x, dy, wt, gamma, beta = _case(n, cdy, c0, c1, h, w, silu, seed=sum(map(ord, name)))
     c = c0 + c1
@@ -155,13 +165,17 @@ def test_shapes_without_the_form_say_so_and_the_switch_turns_it_off():
     lib = _lib.load()
     try:
         _lib.check(lib.dsg_set_tuning(37, 3))
+        assert not ask(8, 64, 96, 32, 64, 64)[0]           # the seam inside a 64-cout tile
+        assert ask(8, 64, 192, 64, 64, 64)[0]              # ... between two 64-cout tiles (key 41: the GNB calls' workgroups)
+        _lib.check(lib.dsg_set_tuning(41, 0))              # ... inside a 128-cout one
         yes, (dyb, gnb, kw) = ask(8, 64, 192, 64, 64, 64)
-        assert not yes and not ask(8, 64, 96, 32, 64, 64)[0]
+        assert not yes
         with pytest.raises(RuntimeError, match="GroupNorm-backward epilogue"):
             ops.conv2d_fused(dyb, None, gnb=gnb, want_stats=True, **kw)
         assert ask(8, 64, 128, 0, 64, 64)[0]
     finally:
         lib.dsg_set_tuning(37, 1)
+        lib.dsg_set_tuning(41, 1)
     assert not ask(8, 64, 112, 16, 64, 64)[0]          # cat(112, 16): the seam is inside a 32-channel slab
     assert not ask(8, 64, 128, 0, 64, 48)[0]           # not a multiple of 32 columns
     try:
@@ -213,7 +227,7 @@ def test_training_step_gradients_with_and_without_the_epilogue_statistics(dtn):
     assert worst <= (2e-4 if dtn == "fp32" else 2e-2), (worst, worst_key)
 
 
-def test_query_and_dispatch_agree_over_a_shape_sweep():
+def test_query_and_dispatch_agree_over_a_shape_sweep(gnb_workgroups):
     """`dsg_conv2d_gnb_supported` mirrors the launcher's kernel selection (workgroup shape by grid size, 32-cout workgroups for
     small grids, the 128-cout tiles' straddle rule): over a sweep of batch / channel / map sizes every call the query accepts must
     run (the launcher refuses a gnb call that did not end in a GNB kernel) and return the sums of what it wrote -- checked through
