@@ -1,6 +1,7 @@
 #!/bin/bash
 # Round 6, final: the training tapes changed after tools/collect_r06_late.sh ran (up-sampler convs: data gradient as one 4x4 stride-2
-# window, weight gradient folded onto x's own map; GroupNorm-backward epilogue for the 64 + 64 concat convs): the bench line, the
+# window, weight gradient folded onto x's own map; GroupNorm-backward epilogue for the 64 + 64 concat convs and on 64-cout workgroups;
+# the fp32 tape's down-samplers on the space-to-depth kernel): the bench line, the
 # training legs' kernel / HBM-traffic records and the same-box A/B of the round's training routes against round 5's again, on one
 # box, then the whole GPU suite alone and next to a mixed load.
 #   bash tools/gpu.sh --timeout 3000 -- 'bash tools/collect_r06_final.sh r06'
@@ -13,7 +14,9 @@ bash tools/prof_cmd.sh ${tag}_train_fp32 python tools/train_bench.py 64 3 fp32 >
 bash tools/prof_cmd.sh ${tag}_train_bf16 python tools/train_bench.py 128 3 bf16 > /dev/null
 PMC_CMD="python tools/train_bench.py 64 1 fp32" bash tools/pmc_bench.sh ${tag} _train_fp32 > gpurun_out/${tag}_pmc_traffic_train_fp32.txt
 PMC_CMD="python tools/train_bench.py 128 1 bf16" bash tools/pmc_bench.sh ${tag} _train_bf16 > gpurun_out/${tag}_pmc_traffic_train_bf16.txt
-R5F="DSG_F32_TAPE_R5=1 DSG_UPS_DGRAD_FULLRES=1 DSG_TUNING=37=0,38=0"
+PMC_CMD="python tools/train_bench.py 64 1 fp32" bash tools/pmc_mfma.sh ${tag} _train_fp32 > gpurun_out/${tag}_pmc_mfma_train_fp32.txt
+PMC_CMD="python tools/train_bench.py 128 1 bf16" bash tools/pmc_mfma.sh ${tag} _train_bf16 > gpurun_out/${tag}_pmc_mfma_train_bf16.txt
+R5F="DSG_F32_TAPE_R5=1 DSG_UPS_DGRAD_FULLRES=1 DSG_TUNING=37=0,38=0,40=0"
 R5B="DSG_UPS_DGRAD_FULLRES=1 DSG_W16_SAMPLER=0 DSG_TUNING=37=0,39=0"
 { echo "fp32, batch 64 (tools/train_bench.py 64 4 fp32), interleaved on one box";
   for r in 1 2 3; do echo "round-6 fp32 tape"; timeout 300 python tools/train_bench.py 64 4 fp32 2>&1 | tail -1;
