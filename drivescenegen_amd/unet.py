@@ -325,6 +325,9 @@ class UNet2DModel(nn.Module):
         # (both paths hand raw pointers to kernels that index by the configured channel count: a wrong shape must stop here)
         if sample.dim() != 4 or sample.shape[1] != self.config.in_channels:
             raise ValueError(f"expected a [N, {self.config.in_channels}, H, W] sample, got {tuple(sample.shape)}")
+        div = 1 << (len(self.config.block_out_channels) - 1)   # (the skip connections' maps must match the up path's: diffusers fails in torch.cat)
+        if sample.shape[2] % div or sample.shape[3] % div:
+            raise ValueError(f"sample size {sample.shape[2]}x{sample.shape[3]} is not divisible by 2^(num_blocks-1) = {div}")
         if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
             from .autograd import unet_forward_train
             out = unet_forward_train(self, sample, timestep)

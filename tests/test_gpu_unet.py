@@ -294,6 +294,9 @@ def test_wrong_channel_count_is_refused_before_any_kernel(mode):
         net(bad[:, :1], 5)
     with pytest.raises(ValueError):
         net(bad[0, :CFG1["in_channels"]], 5)
+    odd = torch.zeros(2, CFG1["in_channels"], CFG1["sample_size"] + 1, CFG1["sample_size"], device=DEV)   # 65 rows: the skip maps would not match
+    with pytest.raises((ValueError, RuntimeError)):
+        net(odd, 5)
 
 
 def test_batch_invariant_flag_and_tuning_gate():
